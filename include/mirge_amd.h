@@ -1,0 +1,209 @@
+/*
+ * mirge_amd.h -- C-ABI of the MI355X-native short-read annotation engine.
+ *
+ * This is the drop-in boundary for ONE path of miRge2.0's annotate mode: the
+ * sequential bowtie cascade over collapsed unique reads plus the per-read
+ * count tally.  The reference has no function ABI at this boundary -- it
+ * shells out to the external `bowtie` / `bowtie-inspect` binaries and parses
+ * their text output.  Each entry point below names the reference call site
+ * (file:line under src/mirge/) whose work it replaces:
+ *
+ *   RAP = utils/runAnnotationPipeline.py   SUM = utils/summarize.py
+ *   MAIN = __main__.py
+ *
+ * Conventions
+ *   - plain C, no torch / C++ types in any signature;
+ *   - every function returns 0 on success, <0 on error; the message is kept
+ *     per-thread and read with mrg_last_error() (the Python host turns a
+ *     non-zero status into the reference's "Alignment to library %s exited
+ *     with none-zero status." + exit(1), RAP:661-663);
+ *   - the caller allocates and owns every bulk buffer; the library owns only
+ *     the opaque handles (mrg_index, mrg_ctx) and frees them in *_free/_destroy;
+ *   - pointers named d_* are DEVICE (HBM) pointers, everything else is host
+ *     memory; `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - there is no CPU fallback: every compute entry point fails with
+ *     MRG_ERR_NO_DEVICE when no gfx950 device is usable.
+ *
+ * Read encoding: 2 bits per base, A=0 C=1 G=2 T=3, base i of a read in bits
+ * [2i,2i+1] of word (i/32), words stored structure-of-arrays:
+ * d_reads[w * n + r] is word w of read r (coalesced when a wave takes 64
+ * consecutive reads).  Reads containing N carry an optional mask of the same
+ * shape (bit 2i of the d_nmask word set = base i is N, its 2-bit code is then
+ * 0; N always counts as a mismatch, as in bowtie 1).
+ */
+#ifndef MIRGE_AMD_H
+#define MIRGE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRG_OK 0
+#define MRG_ERR_ARG (-1)
+#define MRG_ERR_IO (-2)
+#define MRG_ERR_NO_DEVICE (-3)
+#define MRG_ERR_HIP (-4)
+#define MRG_ERR_NOMEM (-5)
+#define MRG_ERR_FORMAT (-6)
+
+#define MRG_MAX_PASSES 16
+#define MRG_MAX_WORDS 4 /* reads up to 128 nt */
+
+typedef struct mrg_index mrg_index; /* host-side FM index of one library */
+typedef struct mrg_ctx mrg_ctx;     /* one per GPU: HBM copies + workspaces */
+
+int mrg_version(void);
+const char *mrg_last_error(void);
+
+/* ------------------------------------------------------------------ *
+ * Index: replaces `bowtie-build` (offline) and `bowtie-inspect`
+ * (SUM:6, RAP:610-611, RAP:630).  Host-only C++; no GPU needed.
+ * ------------------------------------------------------------------ */
+
+/* Build from in-memory entries (names[i], seqs[i] are NUL-terminated; seqs may
+ * contain N/n, which splits an entry into un-alignable gaps as bowtie does). */
+int mrg_index_build(const char *const *names, const char *const *seqs,
+                    uint32_t n_ref, mrg_index **out);
+/* Build from a FASTA file (multi-line records allowed; name = header up to
+ * first whitespace, as bowtie-build records it). */
+int mrg_index_build_fasta(const char *fasta_path, mrg_index **out);
+int mrg_index_save(const mrg_index *ix, const char *path);
+int mrg_index_load(const char *path, mrg_index **out);
+void mrg_index_free(mrg_index *ix);
+
+typedef struct mrg_index_info {
+  uint32_t n_ref;      /* library entries (histogram bins for the miRNA lib) */
+  uint32_t n_seg;      /* N-free segments */
+  uint32_t n_bases;    /* concatenated text length (without sentinel) */
+  uint32_t n_blocks;   /* 32-byte occ blocks (64 BWT symbols each) */
+  uint32_t primary;    /* BWT row holding the sentinel */
+  uint32_t text_words; /* 2-bit packed text, 32-bit words incl. padding */
+  uint32_t C[4];       /* first BWT row of each symbol */
+  uint64_t bytes_fm;   /* n_blocks * 32 */
+  uint64_t bytes_sa;   /* (n_bases + 1) * 4 */
+} mrg_index_info;
+
+int mrg_index_get_info(const mrg_index *ix, mrg_index_info *info);
+/* `bowtie-inspect -n`: name of entry i, valid for the index lifetime (SUM:6-9). */
+int mrg_index_name(const mrg_index *ix, uint32_t i, const char **name);
+/* `bowtie-inspect`: sequence of entry i (N restored) into buf (cap bytes incl. NUL). */
+int mrg_index_seq(const mrg_index *ix, uint32_t i, char *buf, uint32_t cap,
+                  uint32_t *len);
+
+/* Raw views for tests and the oracle's CPU port (read-only, index lifetime). */
+typedef struct mrg_index_view {
+  const uint32_t *blocks;    /* n_blocks * 8 words: cnt[4], lo(2), hi(2) */
+  const uint32_t *text;      /* text_words */
+  const uint32_t *sa;        /* n_bases + 1 */
+  const uint32_t *seg_start; /* n_seg + 1 */
+  const uint32_t *seg_ref;   /* n_seg */
+  const uint32_t *seg_off;   /* n_seg */
+  const uint32_t *chunk_seg; /* (n_bases >> 5) + 2 */
+} mrg_index_view;
+int mrg_index_get_view(const mrg_index *ix, mrg_index_view *view);
+
+/* ------------------------------------------------------------------ *
+ * Context: one per GPU.  Replaces the per-pass process spawn + .ebwt
+ * load of RAP:643 / RAP:689 with libraries resident in HBM.
+ * ------------------------------------------------------------------ */
+int mrg_ctx_create(int device, mrg_ctx **out);
+void mrg_ctx_destroy(mrg_ctx *ctx);
+/* Upload one library; *lib_id is what mrg_pass_cfg.lib refers to. */
+int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
+/* Tunables (all have defaults): "lds_budget" bytes of LDS a match workgroup
+ * may use for a staged library; "wstop" interval width at which a seed search
+ * stops narrowing and hands over to verification (0 = never). */
+int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);
+int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,
+                        char *arch, uint32_t arch_cap);
+
+/* One alignment pass = one bowtie command line of RAP:577-599 / RAP:688. */
+typedef struct mrg_pass_cfg {
+  int32_t lib;          /* library id from mrg_ctx_add_library */
+  int32_t seed_len;     /* -l (28) for -n mode; >= MRG_MAX_WORDS*32 for -v mode */
+  int32_t max_mm_seed;  /* -n N, or V for -v mode */
+  int32_t max_mm_total; /* 2 for -n mode (-e 70 at Q40), V for -v mode */
+  int32_t trim5;        /* -5 */
+  int32_t trim3;        /* -3 */
+  int32_t min_len;      /* length filter of RAP:543-554: process min_len<=len<=max_len */
+  int32_t max_len;
+  int32_t poly_t;       /* 1 = pass 3 (RAP:664-686): need T{3,}$, strip all 3' T, >=11 nt */
+  int32_t reserved;
+} mrg_pass_cfg;
+
+typedef struct mrg_pass_stats {
+  uint64_t processed;  /* "# reads processed" (RAP:9-18) */
+  uint64_t aligned;    /* "# reads with at least one reported alignment" */
+  uint64_t steps;      /* FM backward-extension (LF) steps executed */
+  uint64_t candidates; /* seed occurrences verified against the text */
+  float ms;            /* device time of the pass (the reference's cpuTime) */
+  uint32_t lds_bytes;  /* LDS staged for this pass (0 = index served from HBM/L2) */
+} mrg_pass_stats;
+
+/* Bytes of device workspace mrg_cascade_run needs for n reads. */
+int mrg_cascade_workspace_bytes(uint64_t n, uint64_t *bytes);
+
+/*
+ * The cascade (RAP:636-705): passes run in order; a read is offered to pass i
+ * only if no earlier pass claimed it (writeSeqToAnnot RAP:543-554 +
+ * updateAnnotDic RAP:341-345).  Outputs, one entry per read:
+ *   d_pass_id  -1 = unannotated, else index of the claiming pass
+ *   d_ref_id   library entry index (order of mrg_index_name), -1 if unannotated
+ *   d_pos      0-based offset in the entry of the first untrimmed base
+ *              (SAM POS-1), -1 if unannotated
+ *   d_mm       mismatches of the reported alignment (0 if unannotated)
+ * Tie rule (bowtie's own choice is RNG-driven): fewest mismatches, then lowest
+ * entry index, then lowest offset.
+ * d_pass_counts: 2*n_pass uint64 (processed, aligned per pass) written on
+ * device so a sharded run can all-reduce them without a host round trip.
+ * Asynchronous on `stream`; call mrg_cascade_stats after synchronising.
+ */
+int mrg_cascade_run(mrg_ctx *ctx, const uint64_t *d_reads, uint32_t words_per_read,
+                    const uint8_t *d_lens, const uint64_t *d_nmask, uint64_t n,
+                    const mrg_pass_cfg *passes, uint32_t n_pass, int8_t *d_pass_id,
+                    int32_t *d_ref_id, int32_t *d_pos, uint8_t *d_mm,
+                    uint64_t *d_pass_counts, void *d_workspace,
+                    uint64_t workspace_bytes, void *stream);
+/* Synchronises `stream` of the last run and returns its per-pass statistics. */
+int mrg_cascade_stats(mrg_ctx *ctx, mrg_pass_stats *stats, uint32_t n_pass);
+
+/*
+ * The tally (SUM:34-66): per sample s and read r with quant[r][s] != 0:
+ *   trimmedUniq[s]++ ; cat[pass][s] += quant ; cat[n_pass][s] (remReads) for -1
+ *   pass == canon_pass : mir_quant[ref][s] += q ; mir_iscan[ref][s] += q
+ *   pass == isomir_pass: mir_quant[ref][s] += q
+ * d_counts layout (uint64, caller zeroes it):
+ *   [0, M*S) mir_quant | [M*S, 2*M*S) mir_iscan |
+ *   [2*M*S, 2*M*S + (n_pass+1)*S) category totals | then S trimmedUniq
+ */
+int mrg_tally_counts_len(uint32_t n_mirna, uint32_t n_samples, uint32_t n_pass,
+                         uint64_t *len);
+int mrg_tally_run(mrg_ctx *ctx, const int8_t *d_pass_id, const int32_t *d_ref_id,
+                  const uint32_t *d_quant, uint64_t n, uint32_t n_samples,
+                  uint32_t n_mirna, uint32_t n_pass, int32_t canon_pass,
+                  int32_t isomir_pass, uint64_t *d_counts, void *stream);
+
+/*
+ * Host-buffer convenience for a caller without its own device allocator (the
+ * ctypes stub of INTEGRATION.md): H2D, cascade, tally, D2H in one call.
+ * counts may be NULL (then quant/n_samples are ignored).
+ */
+int mrg_annotate_host(mrg_ctx *ctx, const uint64_t *reads, uint32_t words_per_read,
+                      const uint8_t *lens, const uint64_t *nmask, uint64_t n,
+                      const mrg_pass_cfg *passes, uint32_t n_pass, int8_t *pass_id,
+                      int32_t *ref_id, int32_t *pos, uint8_t *mm,
+                      mrg_pass_stats *stats, const uint32_t *quant,
+                      uint32_t n_samples, uint32_t n_mirna, int32_t canon_pass,
+                      int32_t isomir_pass, uint64_t *counts);
+
+/* Packing helper used by hosts without numpy: ASCII reads -> SoA words. */
+int mrg_pack_reads(const char *const *seqs, uint64_t n, uint32_t words_per_read,
+                   uint64_t *reads, uint8_t *lens, uint64_t *nmask, int *has_n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRGE_AMD_H */

@@ -1,0 +1,113 @@
+"""ctypes binding of the C-ABI in include/mirge_amd.h.
+
+The shared library is built in-tree (mirge_amd/lib/libmirge_amd.so) by
+`make -C mirge_amd/csrc` / `__graft_entry__.build()`.  There is no Python or
+CPU fallback: if the library is missing, loading raises; if no gfx950 device is
+usable, mrg_ctx_create fails with MRG_ERR_NO_DEVICE and `check` raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmirge_amd.so")
+
+MRG_MAX_PASSES = 16
+MRG_MAX_WORDS = 4
+MRG_ERR_NO_DEVICE = -3
+
+
+class MirgeAmdError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("mirge_amd C-ABI error %d: %s" % (code, message))
+        self.code = code
+
+
+class PassCfg(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in
+                ("lib", "seed_len", "max_mm_seed", "max_mm_total", "trim5", "trim3", "min_len",
+                 "max_len", "poly_t", "reserved")]
+
+
+class PassStats(C.Structure):
+    _fields_ = [("processed", C.c_uint64), ("aligned", C.c_uint64), ("steps", C.c_uint64),
+                ("candidates", C.c_uint64), ("ms", C.c_float), ("lds_bytes", C.c_uint32)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("n_ref", C.c_uint32), ("n_seg", C.c_uint32), ("n_bases", C.c_uint32),
+                ("n_blocks", C.c_uint32), ("primary", C.c_uint32), ("text_words", C.c_uint32),
+                ("C", C.c_uint32 * 4), ("bytes_fm", C.c_uint64), ("bytes_sa", C.c_uint64)]
+
+
+class IndexView(C.Structure):
+    _fields_ = [(k, C.POINTER(C.c_uint32)) for k in
+                ("blocks", "text", "sa", "seg_start", "seg_ref", "seg_off", "chunk_seg")]
+
+
+# name -> (restype, argtypes); every symbol include/mirge_amd.h declares
+SIGNATURES = {
+    "mrg_version": (C.c_int, []),
+    "mrg_last_error": (C.c_char_p, []),
+    "mrg_index_build": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_uint32,
+                                  C.POINTER(C.c_void_p)]),
+    "mrg_index_build_fasta": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "mrg_index_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "mrg_index_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "mrg_index_free": (None, [C.c_void_p]),
+    "mrg_index_get_info": (C.c_int, [C.c_void_p, C.POINTER(IndexInfo)]),
+    "mrg_index_name": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_char_p)]),
+    "mrg_index_seq": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32,
+                                C.POINTER(C.c_uint32)]),
+    "mrg_index_get_view": (C.c_int, [C.c_void_p, C.POINTER(IndexView)]),
+    "mrg_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "mrg_ctx_destroy": (None, [C.c_void_p]),
+    "mrg_ctx_add_library": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
+    "mrg_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "mrg_ctx_device_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
+                                      C.c_char_p, C.c_uint32]),
+    "mrg_cascade_workspace_bytes": (C.c_int, [C.c_uint64, C.POINTER(C.c_uint64)]),
+    "mrg_cascade_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                  C.c_uint64, C.POINTER(PassCfg), C.c_uint32, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_uint64, C.c_void_p]),
+    "mrg_cascade_stats": (C.c_int, [C.c_void_p, C.POINTER(PassStats), C.c_uint32]),
+    "mrg_tally_counts_len": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32,
+                                       C.POINTER(C.c_uint64)]),
+    "mrg_tally_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
+                                C.c_void_p, C.c_void_p]),
+    "mrg_annotate_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                    C.c_uint64, C.POINTER(PassCfg), C.c_uint32, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PassStats),
+                                    C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
+                                    C.c_void_p]),
+    "mrg_pack_reads": (C.c_int, [C.POINTER(C.c_char_p), C.c_uint64, C.c_uint32, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmirge_amd.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s not found: build it with `make -C mirge_amd/csrc` (hipcc --offload-arch=gfx950). "
+            "mirge_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().mrg_last_error()
+        raise MirgeAmdError(rc, msg.decode("utf-8", "replace") if msg else "")
+    return rc

@@ -1,0 +1,601 @@
+// C-ABI of include/mirge_amd.h: handle management, HBM residency of the
+// libraries, the cascade driver (one match launch per bowtie command line of
+// RAP:577-599 / RAP:688, survivor lists kept on device) and the tally launch.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mirge_amd.h"
+#include "fm_index.hpp"
+#include "kernels.hpp"
+
+struct mrg_index {
+  mrg::FmIndex ix;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                              \
+  do {                                                                             \
+    hipError_t e_ = (expr);                                                        \
+    if (e_ != hipSuccess)                                                          \
+      return fail(MRG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                             \
+  } while (0)
+
+struct DevLib {
+  uint32_t *blocks = nullptr, *text = nullptr, *sa = nullptr, *seg_start = nullptr,
+           *seg_ref = nullptr, *seg_off = nullptr, *chunk_seg = nullptr;
+  uint32_t n = 0, nblk = 0, primary = 0, text_words = 0, n_seg = 0, n_ref = 0;
+  uint32_t C[4] = {0, 0, 0, 0};
+};
+
+template <class T>
+int upload(T** dst, const std::vector<T>& v, size_t pad_to_multiple = 1) {
+  size_t n = v.size();
+  size_t n_alloc = ((n + pad_to_multiple - 1) / pad_to_multiple) * pad_to_multiple;
+  if (n_alloc == 0) n_alloc = pad_to_multiple;
+  HIP_TRY(hipMalloc((void**)dst, n_alloc * sizeof(T)));
+  HIP_TRY(hipMemset(*dst, 0, n_alloc * sizeof(T)));
+  if (n) HIP_TRY(hipMemcpy(*dst, v.data(), n * sizeof(T), hipMemcpyHostToDevice));
+  return MRG_OK;
+}
+
+constexpr uint32_t kStatsPerPass = 4;
+
+}  // namespace
+
+struct mrg_ctx {
+  int device = 0;
+  int n_cu = 0;
+  uint64_t hbm_bytes = 0;
+  std::string arch;
+  int64_t lds_budget = 160 * 1024;
+  int64_t wstop = 0;
+  int64_t blocks_per_cu_global = 8;
+  std::vector<DevLib> libs;
+  // last run
+  hipStream_t last_stream = nullptr;
+  uint64_t* last_stats_dev = nullptr;
+  uint32_t last_n_pass = 0;
+  uint32_t last_lds[MRG_MAX_PASSES] = {0};
+  hipEvent_t ev[MRG_MAX_PASSES + 1] = {nullptr};
+  bool ev_ready = false;
+};
+
+extern "C" {
+
+int mrg_version(void) { return 100; }
+const char* mrg_last_error(void) { return g_err.c_str(); }
+
+// ----------------------------------------------------------------- index
+int mrg_index_build(const char* const* names, const char* const* seqs, uint32_t n_ref,
+                    mrg_index** out) {
+  if (!out || (n_ref && (!names || !seqs))) return fail(MRG_ERR_ARG, "mrg_index_build: null argument");
+  try {
+    std::vector<std::string> nv(n_ref), sv(n_ref);
+    for (uint32_t i = 0; i < n_ref; ++i) {
+      nv[i] = names[i];
+      sv[i] = seqs[i];
+    }
+    auto h = std::make_unique<mrg_index>();
+    mrg::build_index(nv, sv, h->ix);
+    *out = h.release();
+    return MRG_OK;
+  } catch (const std::bad_alloc&) {
+    return fail(MRG_ERR_NOMEM, "mrg_index_build: out of memory");
+  } catch (const std::exception& e) {
+    return fail(MRG_ERR_FORMAT, "mrg_index_build: %s", e.what());
+  }
+}
+
+int mrg_index_build_fasta(const char* fasta_path, mrg_index** out) {
+  if (!fasta_path || !out) return fail(MRG_ERR_ARG, "mrg_index_build_fasta: null argument");
+  try {
+    std::vector<std::string> nv, sv;
+    mrg::read_fasta(fasta_path, nv, sv);
+    auto h = std::make_unique<mrg_index>();
+    mrg::build_index(nv, sv, h->ix);
+    *out = h.release();
+    return MRG_OK;
+  } catch (const std::bad_alloc&) {
+    return fail(MRG_ERR_NOMEM, "mrg_index_build_fasta: out of memory");
+  } catch (const std::exception& e) {
+    return fail(MRG_ERR_IO, "mrg_index_build_fasta: %s", e.what());
+  }
+}
+
+int mrg_index_save(const mrg_index* ix, const char* path) {
+  if (!ix || !path) return fail(MRG_ERR_ARG, "mrg_index_save: null argument");
+  try {
+    mrg::save_index(ix->ix, path);
+    return MRG_OK;
+  } catch (const std::exception& e) {
+    return fail(MRG_ERR_IO, "mrg_index_save: %s", e.what());
+  }
+}
+
+int mrg_index_load(const char* path, mrg_index** out) {
+  if (!path || !out) return fail(MRG_ERR_ARG, "mrg_index_load: null argument");
+  try {
+    auto h = std::make_unique<mrg_index>();
+    mrg::load_index(path, h->ix);
+    *out = h.release();
+    return MRG_OK;
+  } catch (const std::exception& e) {
+    return fail(MRG_ERR_IO, "mrg_index_load: %s", e.what());
+  }
+}
+
+void mrg_index_free(mrg_index* ix) { delete ix; }
+
+int mrg_index_get_info(const mrg_index* h, mrg_index_info* info) {
+  if (!h || !info) return fail(MRG_ERR_ARG, "mrg_index_get_info: null argument");
+  const mrg::FmIndex& ix = h->ix;
+  info->n_ref = (uint32_t)ix.names.size();
+  info->n_seg = (uint32_t)ix.seg_ref.size();
+  info->n_bases = ix.n;
+  info->n_blocks = (uint32_t)ix.blocks.size();
+  info->primary = ix.primary;
+  info->text_words = (uint32_t)ix.text.size();
+  for (int c = 0; c < 4; ++c) info->C[c] = ix.C[c];
+  info->bytes_fm = (uint64_t)ix.blocks.size() * 32;
+  info->bytes_sa = (uint64_t)ix.sa.size() * 4;
+  return MRG_OK;
+}
+
+int mrg_index_name(const mrg_index* h, uint32_t i, const char** name) {
+  if (!h || !name) return fail(MRG_ERR_ARG, "mrg_index_name: null argument");
+  if (i >= h->ix.names.size()) return fail(MRG_ERR_ARG, "mrg_index_name: entry %u out of range", i);
+  *name = h->ix.names[i].c_str();
+  return MRG_OK;
+}
+
+int mrg_index_seq(const mrg_index* h, uint32_t i, char* buf, uint32_t cap, uint32_t* len) {
+  if (!h || !len) return fail(MRG_ERR_ARG, "mrg_index_seq: null argument");
+  if (i >= h->ix.names.size()) return fail(MRG_ERR_ARG, "mrg_index_seq: entry %u out of range", i);
+  *len = h->ix.ref_len[i];
+  if (!buf) return MRG_OK;
+  if (cap < *len + 1) return fail(MRG_ERR_ARG, "mrg_index_seq: buffer too small (%u < %u)", cap, *len + 1);
+  std::string s = mrg::entry_sequence(h->ix, i);
+  std::memcpy(buf, s.c_str(), s.size() + 1);
+  return MRG_OK;
+}
+
+int mrg_index_get_view(const mrg_index* h, mrg_index_view* v) {
+  if (!h || !v) return fail(MRG_ERR_ARG, "mrg_index_get_view: null argument");
+  const mrg::FmIndex& ix = h->ix;
+  v->blocks = reinterpret_cast<const uint32_t*>(ix.blocks.data());
+  v->text = ix.text.data();
+  v->sa = ix.sa.data();
+  v->seg_start = ix.seg_start.data();
+  v->seg_ref = ix.seg_ref.data();
+  v->seg_off = ix.seg_off.data();
+  v->chunk_seg = ix.chunk_seg.data();
+  return MRG_OK;
+}
+
+// --------------------------------------------------------------- context
+int mrg_ctx_create(int device, mrg_ctx** out) {
+  if (!out) return fail(MRG_ERR_ARG, "mrg_ctx_create: null argument");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(MRG_ERR_NO_DEVICE,
+                "mrg_ctx_create: no HIP device visible (%s); this engine has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  if (device < 0 || device >= count)
+    return fail(MRG_ERR_NO_DEVICE, "mrg_ctx_create: device %d not in [0,%d)", device, count);
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  auto ctx = std::make_unique<mrg_ctx>();
+  ctx->device = device;
+  ctx->n_cu = prop.multiProcessorCount;
+  ctx->hbm_bytes = prop.totalGlobalMem;
+  ctx->arch = prop.gcnArchName;
+  if (ctx->arch.rfind("gfx950", 0) != 0)
+    return fail(MRG_ERR_NO_DEVICE, "mrg_ctx_create: device %d is %s; kernels are built for gfx950 only",
+                device, ctx->arch.c_str());
+  ctx->lds_budget = (int64_t)prop.sharedMemPerBlock;  // 160 KiB on gfx950
+  if (ctx->lds_budget > 160 * 1024) ctx->lds_budget = 160 * 1024;
+  *out = ctx.release();
+  return MRG_OK;
+}
+
+void mrg_ctx_destroy(mrg_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  for (DevLib& l : ctx->libs) {
+    (void)hipFree(l.blocks);
+    (void)hipFree(l.text);
+    (void)hipFree(l.sa);
+    (void)hipFree(l.seg_start);
+    (void)hipFree(l.seg_ref);
+    (void)hipFree(l.seg_off);
+    (void)hipFree(l.chunk_seg);
+  }
+  if (ctx->ev_ready)
+    for (auto& e : ctx->ev) (void)hipEventDestroy(e);
+  delete ctx;
+}
+
+int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
+  if (!ctx || !h || !lib_id) return fail(MRG_ERR_ARG, "mrg_ctx_add_library: null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const mrg::FmIndex& ix = h->ix;
+  DevLib l;
+  l.n = ix.n;
+  l.nblk = (uint32_t)ix.blocks.size();
+  l.primary = ix.primary;
+  l.n_seg = (uint32_t)ix.seg_ref.size();
+  l.n_ref = (uint32_t)ix.names.size();
+  for (int c = 0; c < 4; ++c) l.C[c] = ix.C[c];
+  std::vector<uint32_t> blk(reinterpret_cast<const uint32_t*>(ix.blocks.data()),
+                            reinterpret_cast<const uint32_t*>(ix.blocks.data()) + ix.blocks.size() * 8);
+  int rc;
+  if ((rc = upload(&l.blocks, blk, 4))) return rc;
+  // text is staged into LDS 16 B at a time: round its word count up to 4
+  l.text_words = (uint32_t)((ix.text.size() + 3) / 4 * 4);
+  if ((rc = upload(&l.text, ix.text, 4))) return rc;
+  if ((rc = upload(&l.sa, ix.sa))) return rc;
+  if ((rc = upload(&l.seg_start, ix.seg_start))) return rc;
+  if ((rc = upload(&l.seg_ref, ix.seg_ref))) return rc;
+  if ((rc = upload(&l.seg_off, ix.seg_off))) return rc;
+  if ((rc = upload(&l.chunk_seg, ix.chunk_seg))) return rc;
+  ctx->libs.push_back(l);
+  *lib_id = (int32_t)ctx->libs.size() - 1;
+  return MRG_OK;
+}
+
+int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
+  if (!ctx || !key) return fail(MRG_ERR_ARG, "mrg_ctx_set_option: null argument");
+  std::string k(key);
+  if (k == "lds_budget") {
+    if (value < 0 || value > 160 * 1024) return fail(MRG_ERR_ARG, "lds_budget must be in [0,163840]");
+    ctx->lds_budget = value;
+  } else if (k == "wstop") {
+    if (value < 0) return fail(MRG_ERR_ARG, "wstop must be >= 0");
+    ctx->wstop = value;
+  } else if (k == "blocks_per_cu_global") {
+    if (value < 1 || value > 8) return fail(MRG_ERR_ARG, "blocks_per_cu_global must be in [1,8]");
+    ctx->blocks_per_cu_global = value;
+  } else {
+    return fail(MRG_ERR_ARG, "mrg_ctx_set_option: unknown key '%s'", key);
+  }
+  return MRG_OK;
+}
+
+int mrg_ctx_device_info(const mrg_ctx* ctx, int32_t* n_cu, uint64_t* hbm_bytes, char* arch,
+                        uint32_t arch_cap) {
+  if (!ctx) return fail(MRG_ERR_ARG, "mrg_ctx_device_info: null argument");
+  if (n_cu) *n_cu = ctx->n_cu;
+  if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+  if (arch && arch_cap) {
+    std::snprintf(arch, arch_cap, "%s", ctx->arch.c_str());
+  }
+  return MRG_OK;
+}
+
+// --------------------------------------------------------------- cascade
+// workspace: [idx A: n u32][idx B: n u32][list counts: MRG_MAX_PASSES+1 u32, padded]
+//            [stats: MRG_MAX_PASSES * 4 u64]
+static uint64_t ws_idx_bytes(uint64_t n) { return ((n * 4 + 255) / 256) * 256; }
+static const uint64_t kWsCountsBytes = 256;
+static const uint64_t kWsStatsBytes = MRG_MAX_PASSES * kStatsPerPass * 8;
+
+int mrg_cascade_workspace_bytes(uint64_t n, uint64_t* bytes) {
+  if (!bytes) return fail(MRG_ERR_ARG, "mrg_cascade_workspace_bytes: null argument");
+  *bytes = 2 * ws_idx_bytes(n) + kWsCountsBytes + kWsStatsBytes;
+  return MRG_OK;
+}
+
+int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_read,
+                    const uint8_t* d_lens, const uint64_t* d_nmask, uint64_t n,
+                    const mrg_pass_cfg* passes, uint32_t n_pass, int8_t* d_pass_id,
+                    int32_t* d_ref_id, int32_t* d_pos, uint8_t* d_mm, uint64_t* d_pass_counts,
+                    void* d_workspace, uint64_t workspace_bytes, void* stream_) {
+  if (!ctx || !passes || !d_pass_id || !d_ref_id || !d_pos || !d_mm || !d_workspace)
+    return fail(MRG_ERR_ARG, "mrg_cascade_run: null argument");
+  if (n && (!d_reads || !d_lens)) return fail(MRG_ERR_ARG, "mrg_cascade_run: null read buffers");
+  if (n_pass == 0 || n_pass > MRG_MAX_PASSES)
+    return fail(MRG_ERR_ARG, "mrg_cascade_run: n_pass %u not in [1,%d]", n_pass, MRG_MAX_PASSES);
+  if (words_per_read != 1 && words_per_read != 2 && words_per_read != 4)
+    return fail(MRG_ERR_ARG, "mrg_cascade_run: words_per_read must be 1, 2 or 4 (got %u)", words_per_read);
+  if (n >= 0xfffffff0ull) return fail(MRG_ERR_ARG, "mrg_cascade_run: at most 2^32-16 reads per call");
+  uint64_t need = 0;
+  mrg_cascade_workspace_bytes(n, &need);
+  if (workspace_bytes < need)
+    return fail(MRG_ERR_ARG, "mrg_cascade_run: workspace %llu < %llu bytes",
+                (unsigned long long)workspace_bytes, (unsigned long long)need);
+  for (uint32_t i = 0; i < n_pass; ++i) {
+    const mrg_pass_cfg& c = passes[i];
+    if (c.lib < 0 || (size_t)c.lib >= ctx->libs.size())
+      return fail(MRG_ERR_ARG, "mrg_cascade_run: pass %u names unknown library %d", i, c.lib);
+    if (c.max_mm_seed < 0 || c.max_mm_seed > 3 || c.max_mm_total < c.max_mm_seed || c.trim5 < 0 ||
+        c.trim5 > 31 || c.trim3 < 0 || c.seed_len < 1)
+      return fail(MRG_ERR_ARG, "mrg_cascade_run: pass %u has an invalid policy", i);
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!ctx->ev_ready) {
+    for (auto& e : ctx->ev) HIP_TRY(hipEventCreate(&e));
+    ctx->ev_ready = true;
+  }
+
+  char* ws = (char*)d_workspace;
+  uint32_t* idx[2] = {(uint32_t*)ws, (uint32_t*)(ws + ws_idx_bytes(n))};
+  uint32_t* counts = (uint32_t*)(ws + 2 * ws_idx_bytes(n));
+  uint64_t* stats = (uint64_t*)(ws + 2 * ws_idx_bytes(n) + kWsCountsBytes);
+  HIP_TRY(hipMemsetAsync(counts, 0, kWsCountsBytes + kWsStatsBytes, stream));
+  if (n) {
+    HIP_TRY(hipMemsetAsync(d_pass_id, 0xFF, n, stream));
+    HIP_TRY(hipMemsetAsync(d_ref_id, 0xFF, n * 4, stream));
+    HIP_TRY(hipMemsetAsync(d_pos, 0xFF, n * 4, stream));
+    HIP_TRY(hipMemsetAsync(d_mm, 0, n, stream));
+  }
+
+  HIP_TRY(hipEventRecord(ctx->ev[0], stream));
+  for (uint32_t i = 0; i < n_pass; ++i) {
+    const mrg_pass_cfg& c = passes[i];
+    const DevLib& l = ctx->libs[c.lib];
+    mrg::MatchParams p;
+    p.blocks = l.blocks;
+    p.text = l.text;
+    p.sa = l.sa;
+    p.seg_start = l.seg_start;
+    p.seg_ref = l.seg_ref;
+    p.seg_off = l.seg_off;
+    p.chunk_seg = l.chunk_seg;
+    p.n = l.n;
+    p.nblk = l.nblk;
+    p.primary = l.primary;
+    p.text_words = l.text_words;
+    for (int k = 0; k < 4; ++k) p.C[k] = l.C[k];
+    p.reads = d_reads;
+    p.lens = d_lens;
+    p.nmask = d_nmask;
+    p.n_total = (uint32_t)n;
+    p.idx_in = i == 0 ? nullptr : idx[(i - 1) & 1];
+    p.n_in = i == 0 ? nullptr : counts + (i - 1);
+    p.idx_out = (i + 1 < n_pass) ? idx[i & 1] : nullptr;
+    p.n_out = counts + i;
+    p.pass_id = d_pass_id;
+    p.ref_id = d_ref_id;
+    p.pos = d_pos;
+    p.mm = d_mm;
+    p.counters = stats + (size_t)i * kStatsPerPass;
+    p.seed_len = c.seed_len;
+    p.max_mm_seed = c.max_mm_seed;
+    p.max_mm_total = c.max_mm_total;
+    p.trim5 = c.trim5;
+    p.trim3 = c.trim3;
+    p.min_len = c.min_len;
+    p.max_len = c.max_len;
+    p.poly_t = c.poly_t;
+    p.pass_index = (int32_t)i;
+    p.wstop = (uint32_t)ctx->wstop;
+
+    // residency decision: blocks + text, blocks only, or nothing in LDS
+    const uint64_t blk_bytes = (uint64_t)l.nblk * 32, txt_bytes = (uint64_t)l.text_words * 4;
+    int lds_mode = 0;
+    uint32_t lds_bytes = 0;
+    if (blk_bytes + txt_bytes <= (uint64_t)ctx->lds_budget) {
+      lds_mode = 2;
+      lds_bytes = (uint32_t)(blk_bytes + txt_bytes);
+    } else if (blk_bytes <= (uint64_t)ctx->lds_budget) {
+      lds_mode = 1;
+      lds_bytes = (uint32_t)blk_bytes;
+    }
+    uint32_t grid;
+    if (lds_mode) {
+      // 1024-thread workgroups; two per CU when two staged copies fit
+      uint32_t per_cu = (lds_bytes * 2 <= 160 * 1024) ? 2 : 1;
+      grid = (uint32_t)ctx->n_cu * per_cu;
+    } else {
+      grid = (uint32_t)ctx->n_cu * (uint32_t)ctx->blocks_per_cu_global;
+    }
+    ctx->last_lds[i] = lds_bytes;
+    if (n) HIP_TRY(mrg::launch_match(p, words_per_read, lds_mode, grid, lds_bytes, stream));
+    HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
+  }
+  if (d_pass_counts) HIP_TRY(mrg::launch_export_pass_counts(stats, n_pass, d_pass_counts, stream));
+  ctx->last_stream = stream;
+  ctx->last_stats_dev = stats;
+  ctx->last_n_pass = n_pass;
+  return MRG_OK;
+}
+
+int mrg_cascade_stats(mrg_ctx* ctx, mrg_pass_stats* out, uint32_t n_pass) {
+  if (!ctx || !out) return fail(MRG_ERR_ARG, "mrg_cascade_stats: null argument");
+  if (!ctx->last_stats_dev || n_pass != ctx->last_n_pass)
+    return fail(MRG_ERR_ARG, "mrg_cascade_stats: no matching cascade run (%u vs %u passes)", n_pass,
+                ctx->last_n_pass);
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+  uint64_t host[MRG_MAX_PASSES * kStatsPerPass];
+  HIP_TRY(hipMemcpy(host, ctx->last_stats_dev, (size_t)n_pass * kStatsPerPass * 8, hipMemcpyDeviceToHost));
+  for (uint32_t i = 0; i < n_pass; ++i) {
+    out[i].processed = host[i * kStatsPerPass + 0];
+    out[i].aligned = host[i * kStatsPerPass + 1];
+    out[i].steps = host[i * kStatsPerPass + 2];
+    out[i].candidates = host[i * kStatsPerPass + 3];
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
+    out[i].ms = ms;
+    out[i].lds_bytes = ctx->last_lds[i];
+  }
+  return MRG_OK;
+}
+
+// ----------------------------------------------------------------- tally
+int mrg_tally_counts_len(uint32_t n_mirna, uint32_t n_samples, uint32_t n_pass, uint64_t* len) {
+  if (!len) return fail(MRG_ERR_ARG, "mrg_tally_counts_len: null argument");
+  *len = 2ull * n_mirna * n_samples + (uint64_t)(n_pass + 1) * n_samples + n_samples;
+  return MRG_OK;
+}
+
+int mrg_tally_run(mrg_ctx* ctx, const int8_t* d_pass_id, const int32_t* d_ref_id,
+                  const uint32_t* d_quant, uint64_t n, uint32_t n_samples, uint32_t n_mirna,
+                  uint32_t n_pass, int32_t canon_pass, int32_t isomir_pass, uint64_t* d_counts,
+                  void* stream_) {
+  if (!ctx || !d_counts) return fail(MRG_ERR_ARG, "mrg_tally_run: null argument");
+  if (n && (!d_pass_id || !d_ref_id || !d_quant)) return fail(MRG_ERR_ARG, "mrg_tally_run: null buffers");
+  if (n_samples == 0 || n_pass == 0 || n_pass > MRG_MAX_PASSES)
+    return fail(MRG_ERR_ARG, "mrg_tally_run: bad n_samples/n_pass");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (n == 0) return MRG_OK;
+  mrg::TallyParams p;
+  p.pass_id = d_pass_id;
+  p.ref_id = d_ref_id;
+  p.quant = d_quant;
+  p.n = n;
+  p.n_samples = n_samples;
+  p.n_mirna = n_mirna;
+  p.n_pass = n_pass;
+  p.canon_pass = canon_pass;
+  p.isomir_pass = isomir_pass;
+  p.counts = d_counts;
+  uint64_t bins = 0;
+  mrg_tally_counts_len(n_mirna, n_samples, n_pass, &bins);
+  const uint64_t lds = bins * 8;
+  const bool lds_hist = lds <= (uint64_t)ctx->lds_budget;
+  uint64_t want = (n + mrg::kTallyThreads - 1) / mrg::kTallyThreads;
+  uint32_t per_cu = lds_hist ? (lds * 2 <= 160 * 1024 ? 2u : 1u) : 2u;
+  uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)ctx->n_cu * per_cu);
+  HIP_TRY(mrg::launch_tally(p, lds_hist, grid, lds_hist ? (uint32_t)lds : 0u, (hipStream_t)stream_));
+  return MRG_OK;
+}
+
+// ----------------------------------------------------- host convenience
+int mrg_annotate_host(mrg_ctx* ctx, const uint64_t* reads, uint32_t words_per_read,
+                      const uint8_t* lens, const uint64_t* nmask, uint64_t n,
+                      const mrg_pass_cfg* passes, uint32_t n_pass, int8_t* pass_id, int32_t* ref_id,
+                      int32_t* pos, uint8_t* mm, mrg_pass_stats* stats, const uint32_t* quant,
+                      uint32_t n_samples, uint32_t n_mirna, int32_t canon_pass, int32_t isomir_pass,
+                      uint64_t* counts) {
+  if (!ctx || !passes || !pass_id || !ref_id || !pos || !mm)
+    return fail(MRG_ERR_ARG, "mrg_annotate_host: null argument");
+  if (n && (!reads || !lens)) return fail(MRG_ERR_ARG, "mrg_annotate_host: null read buffers");
+  HIP_TRY(hipSetDevice(ctx->device));
+  struct Bufs {
+    std::vector<void*> v;
+    ~Bufs() {
+      for (void* p : v) (void)hipFree(p);
+    }
+    int get(void** p, size_t bytes) {
+      hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+      if (e != hipSuccess) return fail(MRG_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+      v.push_back(*p);
+      return MRG_OK;
+    }
+  } bufs;
+  int rc;
+  uint64_t *d_reads = nullptr, *d_nmask = nullptr, *d_counts = nullptr, *d_pc = nullptr;
+  uint8_t *d_lens = nullptr, *d_mm = nullptr;
+  int8_t* d_pass = nullptr;
+  int32_t *d_ref = nullptr, *d_pos = nullptr;
+  uint32_t* d_quant = nullptr;
+  void* d_ws = nullptr;
+  uint64_t ws_bytes = 0;
+  mrg_cascade_workspace_bytes(n, &ws_bytes);
+  const size_t rbytes = (size_t)n * words_per_read * 8;
+  if ((rc = bufs.get((void**)&d_reads, rbytes))) return rc;
+  if ((rc = bufs.get((void**)&d_lens, n))) return rc;
+  if (nmask && (rc = bufs.get((void**)&d_nmask, rbytes))) return rc;
+  if ((rc = bufs.get((void**)&d_pass, n))) return rc;
+  if ((rc = bufs.get((void**)&d_ref, n * 4))) return rc;
+  if ((rc = bufs.get((void**)&d_pos, n * 4))) return rc;
+  if ((rc = bufs.get((void**)&d_mm, n))) return rc;
+  if ((rc = bufs.get((void**)&d_pc, 2 * MRG_MAX_PASSES * 8))) return rc;
+  if ((rc = bufs.get(&d_ws, ws_bytes))) return rc;
+  if (n) {
+    HIP_TRY(hipMemcpy(d_reads, reads, rbytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_lens, lens, n, hipMemcpyHostToDevice));
+    if (nmask) HIP_TRY(hipMemcpy(d_nmask, nmask, rbytes, hipMemcpyHostToDevice));
+  }
+  rc = mrg_cascade_run(ctx, d_reads, words_per_read, d_lens, d_nmask, n, passes, n_pass, d_pass, d_ref,
+                       d_pos, d_mm, d_pc, d_ws, ws_bytes, nullptr);
+  if (rc) return rc;
+  std::vector<mrg_pass_stats> st(n_pass);
+  if ((rc = mrg_cascade_stats(ctx, st.data(), n_pass))) return rc;
+  if (stats) std::memcpy(stats, st.data(), n_pass * sizeof(mrg_pass_stats));
+  if (counts) {
+    if (!quant || n_samples == 0) return fail(MRG_ERR_ARG, "mrg_annotate_host: counts requested without quant");
+    uint64_t clen = 0;
+    mrg_tally_counts_len(n_mirna, n_samples, n_pass, &clen);
+    if ((rc = bufs.get((void**)&d_counts, clen * 8))) return rc;
+    if ((rc = bufs.get((void**)&d_quant, n * n_samples * 4))) return rc;
+    HIP_TRY(hipMemset(d_counts, 0, clen * 8));
+    if (n) HIP_TRY(hipMemcpy(d_quant, quant, n * n_samples * 4, hipMemcpyHostToDevice));
+    if ((rc = mrg_tally_run(ctx, d_pass, d_ref, d_quant, n, n_samples, n_mirna, n_pass, canon_pass,
+                            isomir_pass, d_counts, nullptr)))
+      return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(counts, d_counts, clen * 8, hipMemcpyDeviceToHost));
+  }
+  if (n) {
+    HIP_TRY(hipMemcpy(pass_id, d_pass, n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ref_id, d_ref, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pos, d_pos, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mm, d_mm, n, hipMemcpyDeviceToHost));
+  }
+  return MRG_OK;
+}
+
+// ------------------------------------------------------------- packing
+int mrg_pack_reads(const char* const* seqs, uint64_t n, uint32_t words_per_read, uint64_t* reads,
+                   uint8_t* lens, uint64_t* nmask, int* has_n) {
+  if ((n && (!seqs || !reads || !lens)) || words_per_read == 0 || words_per_read > MRG_MAX_WORDS)
+    return fail(MRG_ERR_ARG, "mrg_pack_reads: bad argument");
+  int any_n = 0;
+  for (uint64_t r = 0; r < n; ++r) {
+    const char* s = seqs[r];
+    size_t L = std::strlen(s);
+    if (L > (size_t)words_per_read * 32)
+      return fail(MRG_ERR_ARG, "mrg_pack_reads: read %llu has %zu nt, more than %u words hold",
+                  (unsigned long long)r, L, words_per_read);
+    lens[r] = (uint8_t)L;
+    for (uint32_t w = 0; w < words_per_read; ++w) {
+      reads[(size_t)w * n + r] = 0;
+      if (nmask) nmask[(size_t)w * n + r] = 0;
+    }
+    for (size_t i = 0; i < L; ++i) {
+      uint64_t code = 0;
+      bool isn = false;
+      switch (s[i]) {
+        case 'A': case 'a': code = 0; break;
+        case 'C': case 'c': code = 1; break;
+        case 'G': case 'g': code = 2; break;
+        case 'T': case 't': code = 3; break;
+        default: isn = true; break;
+      }
+      reads[(size_t)(i >> 5) * n + r] |= code << ((i & 31) * 2);
+      if (isn) {
+        any_n = 1;
+        if (nmask) nmask[(size_t)(i >> 5) * n + r] |= 1ull << ((i & 31) * 2);
+      }
+    }
+  }
+  if (has_n) *has_n = any_n;
+  return MRG_OK;
+}
+
+}  // extern "C"

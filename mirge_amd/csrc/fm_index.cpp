@@ -1,0 +1,384 @@
+// Host-side construction of the FM index (see fm_index.hpp for the layout and
+// the reference role).  Pure C++17, no GPU.
+#include "fm_index.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+
+namespace mrg {
+
+// ---------------------------------------------------------------------------
+// Suffix array by induced sorting.  `s[n-1]` is the unique smallest symbol.
+// Works in place in `sa`; the reduced problem reuses the tail of `sa`.
+// ---------------------------------------------------------------------------
+namespace {
+
+template <class Sym>
+struct Sais {
+  const Sym* s;
+  int32_t* sa;
+  int32_t n;
+  int32_t K;
+  std::vector<uint8_t> stype;  // 1 = S-type suffix
+  std::vector<int32_t> bkt;
+
+  bool lms(int32_t i) const { return i > 0 && stype[i] && !stype[i - 1]; }
+
+  void bucket_ends() {
+    std::fill(bkt.begin(), bkt.end(), 0);
+    for (int32_t i = 0; i < n; ++i) ++bkt[(int32_t)s[i]];
+    int32_t sum = 0;
+    for (int32_t c = 0; c < K; ++c) {
+      sum += bkt[c];
+      bkt[c] = sum;
+    }
+  }
+  void bucket_starts() {
+    std::fill(bkt.begin(), bkt.end(), 0);
+    for (int32_t i = 0; i < n; ++i) ++bkt[(int32_t)s[i]];
+    int32_t sum = 0;
+    for (int32_t c = 0; c < K; ++c) {
+      int32_t cnt = bkt[c];
+      bkt[c] = sum;
+      sum += cnt;
+    }
+  }
+  void induce() {
+    bucket_starts();
+    for (int32_t i = 0; i < n; ++i) {
+      int32_t p = sa[i];
+      if (p > 0 && !stype[p - 1]) sa[bkt[(int32_t)s[p - 1]]++] = p - 1;
+    }
+    bucket_ends();
+    for (int32_t i = n - 1; i >= 0; --i) {
+      int32_t p = sa[i];
+      if (p > 0 && stype[p - 1]) sa[--bkt[(int32_t)s[p - 1]]] = p - 1;
+    }
+  }
+
+  void run() {
+    if (n == 1) {
+      sa[0] = 0;
+      return;
+    }
+    stype.assign(n, 0);
+    bkt.assign(K, 0);
+    stype[n - 1] = 1;
+    for (int32_t i = n - 2; i >= 0; --i)
+      stype[i] = (s[i] < s[i + 1] || (s[i] == s[i + 1] && stype[i + 1])) ? 1 : 0;
+
+    // 1. sort the LMS substrings
+    std::fill(sa, sa + n, -1);
+    bucket_ends();
+    for (int32_t i = 1; i < n; ++i)
+      if (lms(i)) sa[--bkt[(int32_t)s[i]]] = i;
+    induce();
+
+    // 2. name them
+    int32_t n1 = 0;
+    for (int32_t i = 0; i < n; ++i)
+      if (lms(sa[i])) sa[n1++] = sa[i];
+    std::fill(sa + n1, sa + n, -1);
+    int32_t names = 0, prev = -1;
+    for (int32_t i = 0; i < n1; ++i) {
+      int32_t pos = sa[i];
+      bool diff = (prev < 0);
+      for (int32_t d = 0; !diff; ++d) {
+        if (s[pos + d] != s[prev + d] || stype[pos + d] != stype[prev + d]) {
+          diff = true;
+        } else if (d > 0 && (lms(pos + d) || lms(prev + d))) {
+          break;
+        }
+      }
+      if (diff) {
+        ++names;
+        prev = pos;
+      }
+      sa[n1 + (pos >> 1)] = names - 1;
+    }
+    for (int32_t i = n - 1, j = n - 1; i >= n1; --i)
+      if (sa[i] >= 0) sa[j--] = sa[i];
+
+    // 3. order the LMS suffixes (recursively when names collide)
+    int32_t* sa1 = sa;
+    int32_t* s1 = sa + (n - n1);
+    if (names < n1) {
+      Sais<int32_t> sub{s1, sa1, n1, names, {}, {}};
+      sub.run();
+    } else {
+      for (int32_t i = 0; i < n1; ++i) sa1[s1[i]] = i;
+    }
+
+    // 4. induce the full order from the sorted LMS suffixes
+    for (int32_t i = 1, j = 0; i < n; ++i)
+      if (lms(i)) s1[j++] = i;
+    for (int32_t i = 0; i < n1; ++i) sa1[i] = s1[sa1[i]];
+    std::fill(sa + n1, sa + n, -1);
+    bucket_ends();
+    for (int32_t i = n1 - 1; i >= 0; --i) {
+      int32_t p = sa[i];
+      sa[i] = -1;
+      sa[--bkt[(int32_t)s[p]]] = p;
+    }
+    induce();
+  }
+};
+
+}  // namespace
+
+void suffix_array(const int32_t* s, int32_t* sa, int32_t n, int32_t K) {
+  Sais<int32_t> top{s, sa, n, K, {}, {}};
+  top.run();
+}
+
+// ---------------------------------------------------------------------------
+// FASTA
+// ---------------------------------------------------------------------------
+void read_fasta(const std::string& path, std::vector<std::string>& names,
+                std::vector<std::string>& seqs) {
+  std::ifstream in(path);
+  if (!in) throw std::runtime_error("cannot open FASTA " + path);
+  std::string line;
+  bool have = false;
+  while (std::getline(in, line)) {
+    while (!line.empty() && (line.back() == '\r' || line.back() == '\n' || line.back() == ' '))
+      line.pop_back();
+    if (line.empty()) continue;
+    if (line[0] == '>') {
+      size_t e = 1;
+      while (e < line.size() && line[e] != ' ' && line[e] != '\t') ++e;
+      names.emplace_back(line.substr(1, e - 1));
+      seqs.emplace_back();
+      have = true;
+    } else {
+      if (!have) throw std::runtime_error("FASTA " + path + ": sequence before first header");
+      seqs.back() += line;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Index construction
+// ---------------------------------------------------------------------------
+static inline int base_code(char ch) {
+  switch (ch) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return -1;
+  }
+}
+
+static void finish_from_codes(const std::vector<uint8_t>& codes, FmIndex& ix) {
+  // codes: text bases 0..3, length n.
+  const uint32_t n = (uint32_t)codes.size();
+  ix.n = n;
+
+  // suffix array of codes+1 followed by sentinel 0
+  {
+    std::vector<uint8_t> t(n + 1);
+    for (uint32_t i = 0; i < n; ++i) t[i] = codes[i] + 1;
+    t[n] = 0;
+    std::vector<int32_t> sa(n + 1);
+    Sais<uint8_t> top{t.data(), sa.data(), (int32_t)(n + 1), 5, {}, {}};
+    top.run();
+    ix.sa.resize(n + 1);
+    for (uint32_t i = 0; i <= n; ++i) ix.sa[i] = (uint32_t)sa[i];
+  }
+
+  // BWT -> occ blocks
+  const uint32_t m = n + 1;
+  const uint32_t nblk = (m >> 6) + 1;
+  ix.blocks.assign(nblk, OccBlock{{0, 0, 0, 0}, 0, 0});
+  uint32_t run[4] = {0, 0, 0, 0};
+  ix.primary = 0;
+  for (uint32_t i = 0; i < m; ++i) {
+    if ((i & 63) == 0) {
+      OccBlock& b = ix.blocks[i >> 6];
+      for (int c = 0; c < 4; ++c) b.cnt[c] = run[c];
+    }
+    uint32_t p = ix.sa[i];
+    if (p == 0) {
+      ix.primary = i;  // sentinel row: stored as symbol 0, never counted
+      continue;
+    }
+    uint32_t c = codes[p - 1];
+    OccBlock& b = ix.blocks[i >> 6];
+    b.lo |= (uint64_t)(c & 1) << (i & 63);
+    b.hi |= (uint64_t)((c >> 1) & 1) << (i & 63);
+    ++run[c];
+  }
+  if ((m & 63) == 0) {
+    OccBlock& b = ix.blocks[m >> 6];
+    for (int c = 0; c < 4; ++c) b.cnt[c] = run[c];
+  }
+  uint32_t sum = 1;  // row 0 is the sentinel suffix
+  for (int c = 0; c < 4; ++c) {
+    ix.C[c] = sum;
+    sum += run[c];
+  }
+
+  // packed text, padded so a 64-bit window can be read at any base
+  const uint32_t words = (n + 15) / 16 + 4;
+  ix.text.assign(words, 0);
+  for (uint32_t p = 0; p < n; ++p)
+    ix.text[p >> 4] |= (uint32_t)codes[p] << ((p & 15) * 2);
+}
+
+void build_index(const std::vector<std::string>& names,
+                 const std::vector<std::string>& seqs, FmIndex& ix) {
+  if (names.size() != seqs.size()) throw std::runtime_error("names/seqs size mismatch");
+  ix = FmIndex();
+  ix.names = names;
+  uint64_t total = 0;
+  for (auto& s : seqs) total += s.size();
+  if (total >= 0x7ffffff0ull) throw std::runtime_error("library too large for 32-bit index");
+
+  std::vector<uint8_t> codes;
+  codes.reserve(total);
+  ix.ref_len.resize(seqs.size());
+  ix.ref_n_runs.resize(seqs.size());
+  for (size_t r = 0; r < seqs.size(); ++r) {
+    const std::string& s = seqs[r];
+    ix.ref_len[r] = (uint32_t)s.size();
+    uint32_t i = 0;
+    const uint32_t L = (uint32_t)s.size();
+    while (i < L) {
+      if (base_code(s[i]) < 0) {
+        uint32_t j = i;
+        while (j < L && base_code(s[j]) < 0) ++j;
+        ix.ref_n_runs[r].push_back(i);
+        ix.ref_n_runs[r].push_back(j - i);
+        i = j;
+      } else {
+        uint32_t j = i;
+        ix.seg_start.push_back((uint32_t)codes.size());
+        ix.seg_ref.push_back((uint32_t)r);
+        ix.seg_off.push_back(i);
+        while (j < L) {
+          int c = base_code(s[j]);
+          if (c < 0) break;
+          codes.push_back((uint8_t)c);
+          ++j;
+        }
+        i = j;
+      }
+    }
+  }
+  ix.seg_start.push_back((uint32_t)codes.size());
+
+  finish_from_codes(codes, ix);
+
+  // chunk -> segment map for O(1) locate
+  const uint32_t nchunk = (ix.n >> 5) + 2;
+  ix.chunk_seg.assign(nchunk, 0);
+  const uint32_t nseg = (uint32_t)ix.seg_ref.size();
+  uint32_t sgi = 0;
+  for (uint32_t ch = 0; ch < nchunk; ++ch) {
+    uint64_t p = (uint64_t)ch << 5;
+    while (sgi + 1 < nseg && ix.seg_start[sgi + 1] <= p) ++sgi;
+    ix.chunk_seg[ch] = sgi;
+  }
+}
+
+std::string entry_sequence(const FmIndex& ix, uint32_t r) {
+  std::string out(ix.ref_len[r], 'N');
+  static const char L[4] = {'A', 'C', 'G', 'T'};
+  // segments of this entry are contiguous in seg_ref; find the first by scan
+  auto it = std::lower_bound(ix.seg_ref.begin(), ix.seg_ref.end(), r);
+  for (size_t sg = it - ix.seg_ref.begin(); sg < ix.seg_ref.size() && ix.seg_ref[sg] == r; ++sg) {
+    uint32_t a = ix.seg_start[sg], b = ix.seg_start[sg + 1], off = ix.seg_off[sg];
+    for (uint32_t p = a; p < b; ++p)
+      out[off + (p - a)] = L[(ix.text[p >> 4] >> ((p & 15) * 2)) & 3];
+  }
+  return out;
+}
+
+// ---------------------------------------------------------------------------
+// Serialisation ("MRGFM1\0\0" + counts + raw arrays)
+// ---------------------------------------------------------------------------
+namespace {
+const char kMagic[8] = {'M', 'R', 'G', 'F', 'M', '1', 0, 0};
+
+template <class T>
+void put_vec(std::ofstream& o, const std::vector<T>& v) {
+  uint64_t n = v.size();
+  o.write((const char*)&n, 8);
+  if (n) o.write((const char*)v.data(), (std::streamsize)(n * sizeof(T)));
+}
+template <class T>
+void get_vec(std::ifstream& in, std::vector<T>& v) {
+  uint64_t n = 0;
+  in.read((char*)&n, 8);
+  if (!in || n > (1ull << 34)) throw std::runtime_error("index file truncated or corrupt");
+  v.resize(n);
+  if (n) in.read((char*)v.data(), (std::streamsize)(n * sizeof(T)));
+  if (!in) throw std::runtime_error("index file truncated");
+}
+}  // namespace
+
+void save_index(const FmIndex& ix, const std::string& path) {
+  std::ofstream o(path, std::ios::binary);
+  if (!o) throw std::runtime_error("cannot write " + path);
+  o.write(kMagic, 8);
+  uint32_t hdr[8] = {ix.n, ix.primary, ix.C[0], ix.C[1], ix.C[2], ix.C[3],
+                     (uint32_t)ix.names.size(), 0};
+  o.write((const char*)hdr, sizeof(hdr));
+  for (size_t r = 0; r < ix.names.size(); ++r) {
+    uint32_t l = (uint32_t)ix.names[r].size();
+    o.write((const char*)&l, 4);
+    o.write(ix.names[r].data(), l);
+    put_vec(o, ix.ref_n_runs[r]);
+  }
+  put_vec(o, ix.ref_len);
+  put_vec(o, ix.blocks);
+  put_vec(o, ix.text);
+  put_vec(o, ix.sa);
+  put_vec(o, ix.seg_start);
+  put_vec(o, ix.seg_ref);
+  put_vec(o, ix.seg_off);
+  put_vec(o, ix.chunk_seg);
+  if (!o) throw std::runtime_error("short write to " + path);
+}
+
+void load_index(const std::string& path, FmIndex& ix) {
+  std::ifstream in(path, std::ios::binary);
+  if (!in) throw std::runtime_error("cannot open " + path);
+  char magic[8];
+  in.read(magic, 8);
+  if (!in || std::memcmp(magic, kMagic, 8) != 0)
+    throw std::runtime_error(path + " is not a mirge_amd index");
+  uint32_t hdr[8];
+  in.read((char*)hdr, sizeof(hdr));
+  ix = FmIndex();
+  ix.n = hdr[0];
+  ix.primary = hdr[1];
+  for (int c = 0; c < 4; ++c) ix.C[c] = hdr[2 + c];
+  uint32_t nref = hdr[6];
+  ix.names.resize(nref);
+  ix.ref_n_runs.resize(nref);
+  for (uint32_t r = 0; r < nref; ++r) {
+    uint32_t l = 0;
+    in.read((char*)&l, 4);
+    if (!in || l > (1u << 20)) throw std::runtime_error("index file corrupt (name)");
+    ix.names[r].resize(l);
+    in.read(&ix.names[r][0], l);
+    get_vec(in, ix.ref_n_runs[r]);
+  }
+  get_vec(in, ix.ref_len);
+  get_vec(in, ix.blocks);
+  get_vec(in, ix.text);
+  get_vec(in, ix.sa);
+  get_vec(in, ix.seg_start);
+  get_vec(in, ix.seg_ref);
+  get_vec(in, ix.seg_off);
+  get_vec(in, ix.chunk_seg);
+  if (ix.sa.size() != (size_t)ix.n + 1 || ix.blocks.size() != (size_t)((ix.n + 1) >> 6) + 1)
+    throw std::runtime_error("index file inconsistent");
+}
+
+}  // namespace mrg

@@ -1,0 +1,56 @@
+// Host-side FM index of one reference library (internal header).
+//
+// Role in the reference: the prebuilt bowtie 1 `.ebwt` files under
+// miRge.Libs/<species>/index.Libs (MAIN:262-281) that every cascade pass loads
+// (RAP:643, RAP:689).  This is our own format, laid out for the gfx950 match
+// kernel, not a reader of bowtie's.
+//
+// Layout (all little-endian, what is uploaded to HBM verbatim):
+//   blocks   32 B per 64 BWT symbols: uint32 cnt[4] (symbols before the block,
+//            sentinel excluded), uint64 lo (bit0 plane), uint64 hi (bit1 plane)
+//   text     2 bits/base, 16 bases per uint32, base p in bits [2(p&15), +1]
+//   sa       full suffix array of text+'$' (sa[0] = n): HBM is 288 GB, so the
+//            locate step is one load instead of a sampled-SA walk
+//   seg_*    N-free segments of the entries; an alignment must sit in one
+//   chunk_seg[p>>5] = segment holding text position (p & ~31)
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace mrg {
+
+struct OccBlock {
+  uint32_t cnt[4];
+  uint64_t lo;
+  uint64_t hi;
+};
+static_assert(sizeof(OccBlock) == 32, "occ block must be 32 bytes");
+
+struct FmIndex {
+  std::vector<std::string> names;
+  std::vector<uint32_t> ref_len;                 // full entry length incl. N
+  std::vector<std::vector<uint32_t>> ref_n_runs; // per entry: (start,len) pairs of N runs
+  uint32_t n = 0;                                // text bases
+  uint32_t primary = 0;
+  uint32_t C[4] = {0, 0, 0, 0};
+  std::vector<OccBlock> blocks;
+  std::vector<uint32_t> text;
+  std::vector<uint32_t> sa;
+  std::vector<uint32_t> seg_start, seg_ref, seg_off, chunk_seg;
+};
+
+// Throws std::runtime_error on malformed input.
+void build_index(const std::vector<std::string>& names,
+                 const std::vector<std::string>& seqs, FmIndex& out);
+void read_fasta(const std::string& path, std::vector<std::string>& names,
+                std::vector<std::string>& seqs);
+void save_index(const FmIndex& ix, const std::string& path);
+void load_index(const std::string& path, FmIndex& ix);
+std::string entry_sequence(const FmIndex& ix, uint32_t i);
+
+// Suffix array of s[0..n) over alphabet [0,K); s[n-1] must be the unique
+// smallest symbol.  Induced sorting (SA-IS).
+void suffix_array(const int32_t* s, int32_t* sa, int32_t n, int32_t K);
+
+}  // namespace mrg

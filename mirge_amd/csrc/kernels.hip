@@ -1,0 +1,401 @@
+// gfx950 (CDNA4, wave64) kernels of the annotation cascade.
+//
+// What they replace in the reference: the nine external bowtie runs of
+// runAnnotationPipeline (RAP:636-705), the Python survivor scan between them
+// (writeSeqToAnnot RAP:543-554, updateAnnotDic RAP:341-352) and the Python
+// histogram loop of summarize (SUM:34-66).
+//
+// match_kernel: one read per lane.  A pass's mismatch policy is turned into
+// K = max_mm_seed+1 pigeonhole pieces of the seed region; each piece is an
+// exact FM backward search (the rank/occ blocks and, when they fit, the packed
+// text are staged in LDS), every occurrence is located through the full suffix
+// array and verified against the 2-bit text with XOR+popcount, and the best
+// (mismatches, text position) wins.  Unclaimed reads are appended to the next
+// pass's survivor list with one wave-aggregated atomic per wave.
+//
+// This is integer/index work: no MFMA.  The budget that matters is LDS
+// accesses + VALU per LF step for staged libraries and L2/MALL/HBM gathers for
+// the large ones.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+namespace mrg {
+
+namespace {
+
+constexpr uint64_t kOdd = 0x5555555555555555ull;
+
+__device__ __forceinline__ uint64_t low_bits(uint32_t nbits) {
+  // nbits in [0,64]
+  return nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
+}
+
+__device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Access to one library, index blocks / text either in LDS or in global memory.
+template <bool LDSI, bool LDST>
+struct Lib {
+  const uint32_t* __restrict__ gblocks;
+  const uint32_t* __restrict__ gtext;
+  const uint32_t* sblocks;  // LDS
+  const uint32_t* stext;    // LDS
+  uint32_t primary;
+  uint32_t C0, C1, C2, C3;
+
+  // first BWT row of symbol c (selects, so nothing is indexed at run time)
+  __device__ __forceinline__ uint32_t first_row(uint32_t c) const {
+    const uint32_t a = (c & 1) ? C1 : C0, b = (c & 1) ? C3 : C2;
+    return (c & 2) ? b : a;
+  }
+
+  __device__ __forceinline__ uint32_t occ(uint32_t c, uint32_t i) const {
+    const uint32_t b = i >> 6, r = i & 63;
+    uint32_t cnt;
+    uint64_t lo, hi;
+    if (LDSI) {
+      const uint32_t* blk = sblocks + b * 8;
+      cnt = blk[c];
+      const uint4 v = *reinterpret_cast<const uint4*>(blk + 4);
+      lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
+      hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    } else {
+      const uint32_t* blk = gblocks + (size_t)b * 8;
+      cnt = blk[c];
+      const uint4 v = *reinterpret_cast<const uint4*>(blk + 4);
+      lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
+      hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    }
+    uint64_t e = ((c & 1) ? lo : ~lo) & ((c & 2) ? hi : ~hi);
+    e &= (1ull << r) - 1ull;
+    uint32_t o = cnt + (uint32_t)__popcll(e);
+    // the sentinel row is stored as symbol 0 inside its own block only
+    o -= (uint32_t)((c == 0) & (i > primary) & (b == (primary >> 6)));
+    return o;
+  }
+
+  __device__ __forceinline__ uint64_t window(uint32_t p) const {
+    const uint32_t i = p >> 4, sh = (p & 15) * 2;
+    uint32_t w0, w1, w2;
+    if (LDST) {
+      w0 = stext[i];
+      w1 = stext[i + 1];
+      w2 = stext[i + 2];
+    } else {
+      w0 = gtext[i];
+      w1 = gtext[i + 1];
+      w2 = gtext[i + 2];
+    }
+    const uint64_t lo64 = (uint64_t)w0 | ((uint64_t)w1 << 32);
+    return (lo64 >> sh) | ((((uint64_t)w2) << 1) << (63 - sh));
+  }
+};
+
+template <int W>
+__device__ __forceinline__ uint64_t pick_word(const uint64_t (&rd)[W], uint32_t w) {
+  uint64_t v = rd[0];
+#pragma unroll
+  for (int k = 1; k < W; ++k) v = (w == (uint32_t)k) ? rd[k] : v;
+  return v;
+}
+
+// Drop `t` (<32) bases from the 5' end: base i becomes base i - t.
+template <int W>
+__device__ __forceinline__ void shift_out_5p(uint64_t (&rd)[W], uint32_t t) {
+  if (t == 0) return;
+  const uint32_t sh = 2 * t;
+#pragma unroll
+  for (int k = 0; k + 1 < W; ++k) rd[k] = (rd[k] >> sh) | (rd[k + 1] << (64 - sh));
+  rd[W - 1] >>= sh;
+}
+
+}  // namespace
+
+template <int W, bool LDSI, bool LDST>
+__global__ void __launch_bounds__(MatchBlock<LDSI>::kThreads)
+match_kernel(const MatchParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  constexpr uint32_t BLOCK = MatchBlock<LDSI>::kThreads;
+
+  // ---- stage the library into LDS (16 B per lane per trip) ----
+  const uint32_t blk_words = p.nblk * 8;
+  if (LDSI) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.blocks);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (uint32_t i = threadIdx.x; i < blk_words / 4; i += BLOCK) dst[i] = src[i];
+  }
+  if (LDST) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.text);
+    uint4* dst = reinterpret_cast<uint4*>(smem + blk_words);
+    for (uint32_t i = threadIdx.x; i < p.text_words / 4; i += BLOCK) dst[i] = src[i];
+  }
+  if (LDSI || LDST) __syncthreads();
+
+  Lib<LDSI, LDST> lib;
+  lib.gblocks = p.blocks;
+  lib.gtext = p.text;
+  lib.sblocks = smem;
+  lib.stext = smem + blk_words;
+  lib.primary = p.primary;
+  lib.C0 = p.C[0];
+  lib.C1 = p.C[1];
+  lib.C2 = p.C[2];
+  lib.C3 = p.C[3];
+
+  const uint32_t n_in = p.idx_in ? *p.n_in : p.n_total;
+  const uint32_t lane = threadIdx.x & 63;
+  uint64_t c_processed = 0, c_aligned = 0, c_steps = 0, c_cands = 0;
+
+  for (uint32_t base = blockIdx.x * BLOCK; base < n_in; base += gridDim.x * BLOCK) {
+    const uint32_t t = base + threadIdx.x;
+    const bool active = t < n_in;
+    uint32_t r = 0;
+    uint64_t rd[W], nm[W];
+    uint32_t L0 = 0;
+    if (active) {
+      r = p.idx_in ? p.idx_in[t] : t;
+      L0 = p.lens[r];
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        rd[k] = p.reads[(size_t)k * p.n_total + r];
+        nm[k] = p.nmask ? p.nmask[(size_t)k * p.n_total + r] : 0ull;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < W; ++k) rd[k] = nm[k] = 0ull;
+    }
+
+    // ---- which reads this pass's FASTA would contain (RAP:543-554, 664-686) ----
+    bool eligible = active && (int32_t)L0 >= p.min_len && (int32_t)L0 <= p.max_len;
+    int32_t L = (int32_t)L0;
+    if (p.poly_t) {
+      // number of trailing T (code 3); an N base is never a T
+      int32_t hb = -1;  // highest base that is not T
+#pragma unroll
+      for (int k = W - 1; k >= 0; --k) {
+        const int32_t nb = min(32, max(0, L - 32 * k));
+        uint64_t x = (~rd[k] | nm[k] | (nm[k] << 1)) & low_bits(2 * nb);
+        if (hb < 0 && x != 0ull) hb = 32 * k + ((63 - __clzll((long long)x)) >> 1);
+      }
+      const int32_t tail = L - 1 - hb;
+      eligible = eligible && tail >= 3 && (L - tail) >= 11;
+      L = L - tail;
+    }
+    L -= p.trim5 + p.trim3;
+    shift_out_5p<W>(rd, (uint32_t)p.trim5);
+    if (p.nmask) shift_out_5p<W>(nm, (uint32_t)p.trim5);
+    if (eligible) ++c_processed;
+
+    uint64_t best = ~0ull;  // (mm << 32) | text position
+    if (eligible && L > p.max_mm_seed) {
+      const int32_t R = min(L, p.seed_len);
+      const int32_t K = p.max_mm_seed + 1;
+      for (int32_t k = 0; k < K; ++k) {
+        const int32_t a = (R * k) / K, b = (R * (k + 1)) / K;
+        if (p.nmask) {
+          // a piece holding an N can never be the exact one
+          bool has_n = false;
+#pragma unroll
+          for (int w = 0; w < W; ++w) {
+            const int32_t lo_b = max(a - 32 * w, 0), hi_b = min(b - 32 * w, 32);
+            if (hi_b > lo_b) has_n |= (nm[w] & low_bits(2 * hi_b) & ~low_bits(2 * lo_b)) != 0ull;
+          }
+          if (has_n) continue;
+        }
+        // ---- exact backward search of read[a,b) ----
+        uint32_t lo = 0, hi = p.n + 1;
+        int32_t j = b;
+        while (j > a && hi > lo && (hi - lo) > p.wstop) {
+          --j;
+          const uint32_t c = (uint32_t)(pick_word<W>(rd, (uint32_t)j >> 5) >> ((j & 31) * 2)) & 3u;
+          const uint32_t cc = lib.first_row(c);
+          lo = cc + lib.occ(c, lo);
+          hi = cc + lib.occ(c, hi);
+          ++c_steps;
+        }
+        // ---- locate + verify every occurrence ----
+        for (uint32_t i = lo; i < hi; ++i) {
+          const int32_t s = (int32_t)p.sa[i] - j;
+          ++c_cands;
+          if (s < 0 || (uint32_t)(s + L) > p.n) continue;
+          uint32_t mm_total = 0, mm_seed = 0;
+#pragma unroll
+          for (int w = 0; w < W; ++w) {
+            const int32_t nb = min(32, L - 32 * w);
+            if (nb > 0) {
+              const uint64_t x = lib.window((uint32_t)s + 32u * w) ^ rd[w];
+              const uint64_t m = (((x | (x >> 1)) & kOdd) | nm[w]) & low_bits(2 * nb);
+              mm_total += (uint32_t)__popcll(m);
+              const int32_t ns = min(nb, max(0, p.seed_len - 32 * w));
+              mm_seed += (uint32_t)__popcll(m & low_bits(2 * ns));
+            }
+          }
+          if ((int32_t)mm_seed > p.max_mm_seed || (int32_t)mm_total > p.max_mm_total) continue;
+          const uint64_t key = ((uint64_t)mm_total << 32) | (uint32_t)s;
+          if (key >= best) continue;
+          // the alignment must sit inside one N-free segment of one entry
+          uint32_t sg = p.chunk_seg[(uint32_t)s >> 5];
+          while (p.seg_start[sg + 1] <= (uint32_t)s) ++sg;
+          if ((uint32_t)(s + L) <= p.seg_start[sg + 1]) best = key;
+        }
+        if ((best >> 32) == 0ull) break;  // an exact hit is always seen by piece 0
+      }
+    }
+
+    const bool aligned = best != ~0ull;
+    if (aligned) {
+      ++c_aligned;
+      const uint32_t s = (uint32_t)best;
+      uint32_t sg = p.chunk_seg[s >> 5];
+      while (p.seg_start[sg + 1] <= s) ++sg;
+      p.pass_id[r] = (int8_t)p.pass_index;
+      p.ref_id[r] = (int32_t)p.seg_ref[sg];
+      p.pos[r] = (int32_t)(s - p.seg_start[sg] + p.seg_off[sg]);
+      p.mm[r] = (uint8_t)(best >> 32);
+    }
+
+    // ---- survivors of this pass feed the next one (wave-aggregated append) ----
+    if (p.idx_out) {
+      const bool survive = active && !aligned;
+      const uint64_t mask = __ballot(survive);
+      if (mask) {
+        uint32_t wbase = 0;
+        if (lane == 0) wbase = atomicAdd(p.n_out, (uint32_t)__popcll(mask));
+        wbase = __shfl(wbase, 0, 64);
+        if (survive) p.idx_out[wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = r;
+      }
+    }
+  }
+
+  c_processed = wave_sum(c_processed);
+  c_aligned = wave_sum(c_aligned);
+  c_steps = wave_sum(c_steps);
+  c_cands = wave_sum(c_cands);
+  if (lane == 0) {
+    if (c_processed) atomicAdd((unsigned long long*)&p.counters[0], (unsigned long long)c_processed);
+    if (c_aligned) atomicAdd((unsigned long long*)&p.counters[1], (unsigned long long)c_aligned);
+    if (c_steps) atomicAdd((unsigned long long*)&p.counters[2], (unsigned long long)c_steps);
+    if (c_cands) atomicAdd((unsigned long long*)&p.counters[3], (unsigned long long)c_cands);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Tally (SUM:34-66): privatised LDS histogram per workgroup, flushed with one
+// global atomic per non-zero bin.  `LDSH` = the bins fit in LDS.
+// ---------------------------------------------------------------------------
+template <bool LDSH>
+__global__ void __launch_bounds__(kTallyThreads) tally_kernel(const TallyParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  unsigned long long* hist = reinterpret_cast<unsigned long long*>(smem);
+  const uint32_t S = p.n_samples, M = p.n_mirna;
+  const uint32_t n_bins = 2 * M * S + (p.n_pass + 1) * S + S;
+  const uint32_t cat0 = 2 * M * S, uniq0 = cat0 + (p.n_pass + 1) * S;
+  unsigned long long* g = reinterpret_cast<unsigned long long*>(p.counts);
+  if (LDSH) {
+    for (uint32_t i = threadIdx.x; i < n_bins; i += kTallyThreads) hist[i] = 0ull;
+    __syncthreads();
+  }
+  unsigned long long* h = LDSH ? hist : g;
+
+  for (uint64_t r = (uint64_t)blockIdx.x * kTallyThreads + threadIdx.x; r < p.n;
+       r += (uint64_t)gridDim.x * kTallyThreads) {
+    const int32_t pass = p.pass_id[r];
+    const int32_t ref = (pass == p.canon_pass || pass == p.isomir_pass) ? p.ref_id[r] : 0;
+    const uint32_t cat = pass < 0 ? p.n_pass : (uint32_t)pass;
+    for (uint32_t s = 0; s < S; ++s) {
+      const unsigned long long q = p.quant[r * S + s];
+      if (q == 0ull) continue;
+      atomicAdd(&h[uniq0 + s], 1ull);
+      atomicAdd(&h[cat0 + cat * S + s], q);
+      if (pass == p.canon_pass) {
+        atomicAdd(&h[(uint32_t)ref * S + s], q);
+        atomicAdd(&h[M * S + (uint32_t)ref * S + s], q);
+      } else if (pass == p.isomir_pass) {
+        atomicAdd(&h[(uint32_t)ref * S + s], q);
+      }
+    }
+  }
+  if (LDSH) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_bins; i += kTallyThreads) {
+      const unsigned long long v = hist[i];
+      if (v) atomicAdd(&g[i], v);
+    }
+  }
+}
+
+__global__ void export_pass_counts_kernel(const uint64_t* stats, uint32_t n_pass,
+                                          uint64_t* out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pass) {
+    out[2 * i] = stats[4 * i];
+    out[2 * i + 1] = stats[4 * i + 1];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Launch helpers (host)
+// ---------------------------------------------------------------------------
+template <int W, bool LDSI, bool LDST>
+static hipError_t launch_match_t(const MatchParams& p, uint32_t grid, uint32_t lds_bytes,
+                                 hipStream_t stream) {
+  auto kern = match_kernel<W, LDSI, LDST>;
+  if (lds_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(MatchBlock<LDSI>::kThreads), lds_bytes, stream, p);
+  return hipGetLastError();
+}
+
+template <int W>
+static hipError_t launch_match_w(const MatchParams& p, int lds_mode, uint32_t grid,
+                                 uint32_t lds_bytes, hipStream_t stream) {
+  switch (lds_mode) {
+    case 2: return launch_match_t<W, true, true>(p, grid, lds_bytes, stream);
+    case 1: return launch_match_t<W, true, false>(p, grid, lds_bytes, stream);
+    default: return launch_match_t<W, false, false>(p, grid, 0, stream);
+  }
+}
+
+hipError_t launch_match(const MatchParams& p, uint32_t words_per_read, int lds_mode,
+                        uint32_t grid, uint32_t lds_bytes, hipStream_t stream) {
+  switch (words_per_read) {
+    case 1: return launch_match_w<1>(p, lds_mode, grid, lds_bytes, stream);
+    case 2: return launch_match_w<2>(p, lds_mode, grid, lds_bytes, stream);
+    case 4: return launch_match_w<4>(p, lds_mode, grid, lds_bytes, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_tally(const TallyParams& p, bool lds_hist, uint32_t grid,
+                        uint32_t lds_bytes, hipStream_t stream) {
+  if (lds_hist) {
+    auto kern = tally_kernel<true>;
+    if (lds_bytes > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds_bytes);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kTallyThreads), lds_bytes, stream, p);
+  } else {
+    hipLaunchKernelGGL(tally_kernel<false>, dim3(grid), dim3(kTallyThreads), 0, stream, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_export_pass_counts(const uint64_t* stats, uint32_t n_pass, uint64_t* out,
+                                     hipStream_t stream) {
+  hipLaunchKernelGGL(export_pass_counts_kernel, dim3(1), dim3(64), 0, stream, stats, n_pass, out);
+  return hipGetLastError();
+}
+
+}  // namespace mrg

@@ -1,0 +1,68 @@
+// Kernel parameter blocks and launch entry points shared by kernels.hip and
+// capi.hip (internal header).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mrg {
+
+// LDS-staged variants run one 1024-thread workgroup per staged copy (16 waves
+// share one copy of the library); the HBM/L2-served variant uses 256-thread
+// workgroups at full occupancy to cover gather latency.
+template <bool LDSI>
+struct MatchBlock {
+  static constexpr uint32_t kThreads = LDSI ? 1024u : 256u;
+};
+constexpr uint32_t kTallyThreads = 1024u;
+
+struct MatchParams {
+  // library (device pointers)
+  const uint32_t* blocks;
+  const uint32_t* text;
+  const uint32_t* sa;
+  const uint32_t* seg_start;
+  const uint32_t* seg_ref;
+  const uint32_t* seg_off;
+  const uint32_t* chunk_seg;
+  uint32_t n, nblk, primary, text_words;
+  uint32_t C[4];
+  // reads
+  const uint64_t* reads;
+  const uint8_t* lens;
+  const uint64_t* nmask;  // may be null
+  uint32_t n_total;       // SoA stride and identity list length
+  const uint32_t* idx_in; // null = identity list of n_total reads
+  const uint32_t* n_in;
+  uint32_t* idx_out;      // null on the last pass
+  uint32_t* n_out;
+  // outputs
+  int8_t* pass_id;
+  int32_t* ref_id;
+  int32_t* pos;
+  uint8_t* mm;
+  uint64_t* counters;  // processed, aligned, steps, candidates of this pass
+  // policy
+  int32_t seed_len, max_mm_seed, max_mm_total, trim5, trim3, min_len, max_len, poly_t;
+  int32_t pass_index;
+  uint32_t wstop;
+};
+
+struct TallyParams {
+  const int8_t* pass_id;
+  const int32_t* ref_id;
+  const uint32_t* quant;
+  uint64_t n;
+  uint32_t n_samples, n_mirna, n_pass;
+  int32_t canon_pass, isomir_pass;
+  uint64_t* counts;
+};
+
+// lds_mode: 0 = index in HBM/L2, 1 = occ blocks in LDS, 2 = occ blocks + text in LDS
+hipError_t launch_match(const MatchParams& p, uint32_t words_per_read, int lds_mode,
+                        uint32_t grid, uint32_t lds_bytes, hipStream_t stream);
+hipError_t launch_tally(const TallyParams& p, bool lds_hist, uint32_t grid,
+                        uint32_t lds_bytes, hipStream_t stream);
+hipError_t launch_export_pass_counts(const uint64_t* stats, uint32_t n_pass, uint64_t* out,
+                                     hipStream_t stream);
+
+}  // namespace mrg

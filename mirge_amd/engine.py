@@ -1,0 +1,253 @@
+"""Columnar host API over the C-ABI: one Engine per GPU.
+
+This is the scale path (10^7..10^8 reads): packed reads, counts and
+assignments live in HBM as flat arrays instead of the reference's dict of dicts
+(`seqDic`, MAIN:318-321; infeasible at 10^8 entries).  `mirge_amd.annotate`
+materialises the reference's dict shapes from these arrays for small inputs.
+
+torch is used only for device memory, streams and (in mirge_amd.dist)
+torch.distributed; every kernel is launched through libmirge_amd.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+from ._native import PassCfg, PassStats, check
+
+V_MODE_SEED = 1024  # "-v": the seed region is the whole read
+
+# The nine (ten) bowtie command lines of runAnnotationPipeline.py:577-599 / :688:
+# (library key, min_len, max_len, seed_len, max_mm_seed, max_mm_total, trim5, trim3, poly_t)
+MIRGE_PASS_TABLE = [
+    ("mirna", 0, 25, 28, 0, 2, 0, 0, 0),                    # len < 26 ; -n 0
+    ("hairpin", 26, 255, 28, 1, 2, 0, 0, 0),                # len > 25 ; -n 1
+    ("mature_trna", 0, 255, V_MODE_SEED, 1, 1, 0, 0, 0),    # -v 1 -a --best --strata
+    ("pre_trna", 0, 255, V_MODE_SEED, 0, 0, 0, 0, 1),       # poly-T rule ; -v 0 -a --best --strata
+    ("snorna", 0, 255, 28, 1, 2, 0, 0, 0),                  # -n 1
+    ("rrna", 0, 255, 28, 1, 2, 0, 0, 0),                    # -n 1
+    ("ncrna_others", 0, 255, 28, 1, 2, 0, 0, 0),            # -n 1
+    ("mrna", 0, 255, 28, 0, 2, 0, 0, 0),                    # -n 0
+    ("mirna", 0, 255, V_MODE_SEED, 2, 2, 1, 2, 0),          # -5 1 -3 2 -v 2 --best
+    ("spike-in", 0, 255, 28, 0, 2, 0, 0, 0),                # -n 0 (only with -spikeIn)
+]
+CANON_PASS = 0   # annot slot 1 "exact miRNA"
+ISOMIR_PASS = 8  # annot slot 9 "isomiR miRNA"
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class ReadSet:
+    """Packed reads resident in HBM."""
+
+    def __init__(self, words, lens, nmask=None, quant=None, device="cuda:0"):
+        torch = _torch()
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        self.W, self.n = words.shape
+        self.device = torch.device(device)
+        self.words = torch.from_numpy(words.view(np.int64)).to(self.device)
+        self.lens = torch.from_numpy(np.ascontiguousarray(lens, dtype=np.uint8)).to(self.device)
+        self.nmask = None
+        if nmask is not None:
+            nm = np.ascontiguousarray(nmask, dtype=np.uint64)
+            self.nmask = torch.from_numpy(nm.view(np.int64)).to(self.device)
+        self.quant = None
+        if quant is not None:
+            q = np.ascontiguousarray(quant, dtype=np.uint32)
+            if q.ndim == 1:
+                q = q[:, None]
+            self.quant = torch.from_numpy(q.view(np.int32)).to(self.device)
+
+    @property
+    def n_samples(self):
+        return 0 if self.quant is None else int(self.quant.shape[1])
+
+
+class CascadeResult:
+    def __init__(self, pass_id, ref_id, pos, mm, pass_counts, engine, n_pass):
+        self.pass_id, self.ref_id, self.pos, self.mm = pass_id, ref_id, pos, mm
+        self.pass_counts = pass_counts  # device int64 [2*n_pass]: processed, aligned
+        self._engine = engine
+        self.n_pass = n_pass
+        self._stats = None
+
+    @property
+    def stats(self):
+        """Synchronises; list of dicts per pass."""
+        if self._stats is None:
+            self._stats = self._engine._read_stats(self.n_pass)
+        return self._stats
+
+    def to_host(self):
+        return (self.pass_id.cpu().numpy(), self.ref_id.cpu().numpy(), self.pos.cpu().numpy(),
+                self.mm.cpu().numpy())
+
+
+class Engine:
+    def __init__(self, device=0):
+        self._lib = _native.load()
+        h = C.c_void_p()
+        check(self._lib.mrg_ctx_create(int(device), C.byref(h)))
+        self._h = h
+        self.device_index = int(device)
+        self.device = "cuda:%d" % int(device)
+        self.libs = {}      # key -> lib id
+        self.indexes = {}   # key -> FmIndex (kept alive; names for reports)
+        self._ws = None
+        n_cu = C.c_int32()
+        hbm = C.c_uint64()
+        arch = C.create_string_buffer(64)
+        check(self._lib.mrg_ctx_device_info(self._h, C.byref(n_cu), C.byref(hbm), arch, 64))
+        self.n_cu, self.hbm_bytes, self.arch = n_cu.value, hbm.value, arch.value.decode()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mrg_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        check(self._lib.mrg_ctx_set_option(self._h, key.encode(), int(value)))
+
+    def add_library(self, key, index):
+        lid = C.c_int32(-1)
+        check(self._lib.mrg_ctx_add_library(self._h, index._h, C.byref(lid)))
+        self.libs[key] = lid.value
+        self.indexes[key] = index
+        return lid.value
+
+    # ------------------------------------------------------------------
+    def mirge_passes(self, spike_in=False):
+        """PassCfg array for the reference's cascade (runAnnotationPipeline.py:574-599)."""
+        rows = MIRGE_PASS_TABLE[:10 if spike_in else 9]
+        return self.make_passes([dict(lib=k, min_len=a, max_len=b, seed_len=s, max_mm_seed=ms,
+                                      max_mm_total=mt, trim5=t5, trim3=t3, poly_t=pt)
+                                 for (k, a, b, s, ms, mt, t5, t3, pt) in rows])
+
+    def make_passes(self, rows):
+        arr = (PassCfg * len(rows))()
+        for i, r in enumerate(rows):
+            lib = r["lib"]
+            arr[i].lib = self.libs[lib] if isinstance(lib, str) else int(lib)
+            arr[i].seed_len = int(r.get("seed_len", 28))
+            arr[i].max_mm_seed = int(r.get("max_mm_seed", 0))
+            arr[i].max_mm_total = int(r.get("max_mm_total", 2))
+            arr[i].trim5 = int(r.get("trim5", 0))
+            arr[i].trim3 = int(r.get("trim3", 0))
+            arr[i].min_len = int(r.get("min_len", 0))
+            arr[i].max_len = int(r.get("max_len", 255))
+            arr[i].poly_t = int(r.get("poly_t", 0))
+        return arr
+
+    # ------------------------------------------------------------------
+    def _stream_ptr(self):
+        torch = _torch()
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, n):
+        torch = _torch()
+        need = C.c_uint64()
+        check(self._lib.mrg_cascade_workspace_bytes(n, C.byref(need)))
+        if self._ws is None or self._ws.numel() < need.value:
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def cascade(self, reads, passes, out=None):
+        """Run the cascade on a ReadSet; asynchronous on torch's current stream."""
+        torch = _torch()
+        n, n_pass = reads.n, len(passes)
+        dev = self.device
+        if out is None:
+            out = (torch.empty(n, dtype=torch.int8, device=dev),
+                   torch.empty(n, dtype=torch.int32, device=dev),
+                   torch.empty(n, dtype=torch.int32, device=dev),
+                   torch.empty(n, dtype=torch.uint8, device=dev),
+                   torch.zeros(2 * n_pass, dtype=torch.int64, device=dev))
+        pass_id, ref_id, pos, mm, pass_counts = out
+        ws = self._workspace(n)
+        check(self._lib.mrg_cascade_run(
+            self._h, reads.words.data_ptr(), reads.W, reads.lens.data_ptr(),
+            reads.nmask.data_ptr() if reads.nmask is not None else None, n, passes, n_pass,
+            pass_id.data_ptr(), ref_id.data_ptr(), pos.data_ptr(), mm.data_ptr(),
+            pass_counts.data_ptr(), ws.data_ptr(), ws.numel(), self._stream_ptr()))
+        return CascadeResult(pass_id, ref_id, pos, mm, pass_counts, self, n_pass)
+
+    def _read_stats(self, n_pass):
+        st = (PassStats * n_pass)()
+        check(self._lib.mrg_cascade_stats(self._h, st, n_pass))
+        return [dict(processed=int(s.processed), aligned=int(s.aligned), steps=int(s.steps),
+                     candidates=int(s.candidates), ms=float(s.ms), lds_bytes=int(s.lds_bytes))
+                for s in st]
+
+    def counts_len(self, n_mirna, n_samples, n_pass):
+        ln = C.c_uint64()
+        check(self._lib.mrg_tally_counts_len(n_mirna, n_samples, n_pass, C.byref(ln)))
+        return int(ln.value)
+
+    def tally(self, reads, result, n_mirna, canon_pass=CANON_PASS, isomir_pass=ISOMIR_PASS,
+              counts=None):
+        """summarize.py:34-66 on device; returns the fused int64 count vector (device)."""
+        torch = _torch()
+        if reads.quant is None:
+            raise ValueError("ReadSet has no quant matrix")
+        S = reads.n_samples
+        ln = self.counts_len(n_mirna, S, result.n_pass)
+        if counts is None:
+            counts = torch.zeros(ln, dtype=torch.int64, device=self.device)
+        check(self._lib.mrg_tally_run(
+            self._h, result.pass_id.data_ptr(), result.ref_id.data_ptr(), reads.quant.data_ptr(),
+            reads.n, S, n_mirna, result.n_pass, canon_pass, isomir_pass, counts.data_ptr(),
+            self._stream_ptr()))
+        return counts
+
+    # ------------------------------------------------------------------
+    def annotate_host(self, words, lens, nmask, passes, quant=None, n_mirna=0,
+                      canon_pass=CANON_PASS, isomir_pass=ISOMIR_PASS):
+        """Host-buffer path of the C-ABI (mrg_annotate_host): numpy in, numpy out."""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        W, n = words.shape
+        lens = np.ascontiguousarray(lens, dtype=np.uint8)
+        nm = None if nmask is None else np.ascontiguousarray(nmask, dtype=np.uint64)
+        n_pass = len(passes)
+        pass_id = np.empty(n, dtype=np.int8)
+        ref_id = np.empty(n, dtype=np.int32)
+        pos = np.empty(n, dtype=np.int32)
+        mm = np.empty(n, dtype=np.uint8)
+        st = (PassStats * n_pass)()
+        counts = None
+        q = None
+        S = 0
+        if quant is not None:
+            q = np.ascontiguousarray(quant, dtype=np.uint32)
+            if q.ndim == 1:
+                q = q[:, None]
+            S = q.shape[1]
+            counts = np.zeros(self.counts_len(n_mirna, S, n_pass), dtype=np.uint64)
+        check(self._lib.mrg_annotate_host(
+            self._h, words.ctypes.data, W, lens.ctypes.data, None if nm is None else nm.ctypes.data,
+            n, passes, n_pass, pass_id.ctypes.data, ref_id.ctypes.data, pos.ctypes.data,
+            mm.ctypes.data, st, None if q is None else q.ctypes.data, S, n_mirna, canon_pass,
+            isomir_pass, None if counts is None else counts.ctypes.data))
+        stats = [dict(processed=int(s.processed), aligned=int(s.aligned), steps=int(s.steps),
+                      candidates=int(s.candidates), ms=float(s.ms), lds_bytes=int(s.lds_bytes))
+                 for s in st]
+        return dict(pass_id=pass_id, ref_id=ref_id, pos=pos, mm=mm, stats=stats, counts=counts)
+
+
+def split_counts(counts, n_mirna, n_samples, n_pass):
+    """Views into the fused count vector (layout of mrg_tally_run)."""
+    M, S = n_mirna, n_samples
+    c = np.asarray(counts).astype(np.int64)
+    quant = c[:M * S].reshape(M, S)
+    iscan = c[M * S:2 * M * S].reshape(M, S)
+    cat = c[2 * M * S:2 * M * S + (n_pass + 1) * S].reshape(n_pass + 1, S)
+    uniq = c[2 * M * S + (n_pass + 1) * S:2 * M * S + (n_pass + 2) * S]
+    return quant, iscan, cat, uniq

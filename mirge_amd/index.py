@@ -1,0 +1,121 @@
+"""FM index of one reference library (host side).
+
+Replaces what the reference gets from `bowtie-build` (offline, the `.ebwt`
+files MAIN:262-281 checks for) and from `bowtie-inspect` at run time
+(summarize.py:6-9 for the miRNA names that define the histogram bins;
+runAnnotationPipeline.py:610-611,630 for name -> sequence dictionaries).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _native
+from ._native import check
+
+
+class FmIndex:
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle)
+        self._lib = _native.load()
+        info = _native.IndexInfo()
+        check(self._lib.mrg_index_get_info(self._h, C.byref(info)))
+        self.info = info
+        self._names = None
+
+    # ---- construction --------------------------------------------------
+    @classmethod
+    def build(cls, names, seqs):
+        lib = _native.load()
+        n = len(names)
+        if n != len(seqs):
+            raise ValueError("names and seqs differ in length")
+        arr_n = (C.c_char_p * n)(*[s.encode("ascii") for s in names])
+        arr_s = (C.c_char_p * n)(*[s.encode("ascii") for s in seqs])
+        h = C.c_void_p()
+        check(lib.mrg_index_build(arr_n, arr_s, n, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_fasta(cls, path):
+        lib = _native.load()
+        h = C.c_void_p()
+        check(lib.mrg_index_build_fasta(os.fsencode(path), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def load(cls, path):
+        lib = _native.load()
+        h = C.c_void_p()
+        check(lib.mrg_index_load(os.fsencode(path), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def open_prefix(cls, prefix):
+        """Resolve a bowtie-style index prefix as the reference passes it around
+        (MAIN:269-281): `<prefix>.mrgfm` if built, else build from `<prefix>.fa`
+        (what `bowtie-inspect <prefix>` would print)."""
+        if os.path.isfile(prefix + ".mrgfm"):
+            return cls.load(prefix + ".mrgfm")
+        for ext in (".fa", ".fasta"):
+            if os.path.isfile(prefix + ext):
+                return cls.from_fasta(prefix + ext)
+        raise FileNotFoundError(
+            "no %s.mrgfm or %s.fa: build one with `python -m mirge_amd.build_index`" % (prefix, prefix))
+
+    def save(self, path):
+        check(self._lib.mrg_index_save(self._h, os.fsencode(path)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.mrg_index_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- bowtie-inspect equivalents -------------------------------------
+    @property
+    def n_ref(self):
+        return int(self.info.n_ref)
+
+    @property
+    def names(self):
+        """`bowtie-inspect -n` (summarize.py:6-9)."""
+        if self._names is None:
+            out = []
+            p = C.c_char_p()
+            for i in range(self.n_ref):
+                check(self._lib.mrg_index_name(self._h, i, C.byref(p)))
+                out.append(p.value.decode("ascii"))
+            self._names = out
+        return self._names
+
+    def sequence(self, i):
+        """`bowtie-inspect`: sequence of entry i."""
+        ln = C.c_uint32()
+        check(self._lib.mrg_index_seq(self._h, i, None, 0, C.byref(ln)))
+        buf = C.create_string_buffer(ln.value + 1)
+        check(self._lib.mrg_index_seq(self._h, i, buf, ln.value + 1, C.byref(ln)))
+        return buf.value.decode("ascii")
+
+    def name_seq_dict(self):
+        return {n: self.sequence(i) for i, n in enumerate(self.names)}
+
+    # ---- raw arrays (tests, the oracle's CPU port) -----------------------
+    def view(self):
+        v = _native.IndexView()
+        check(self._lib.mrg_index_get_view(self._h, C.byref(v)))
+        inf = self.info
+
+        def arr(ptr, n):
+            return np.ctypeslib.as_array(ptr, shape=(n,))
+
+        return dict(
+            blocks=arr(v.blocks, inf.n_blocks * 8), text=arr(v.text, inf.text_words),
+            sa=arr(v.sa, inf.n_bases + 1), seg_start=arr(v.seg_start, inf.n_seg + 1),
+            seg_ref=arr(v.seg_ref, max(inf.n_seg, 1))[:inf.n_seg],
+            seg_off=arr(v.seg_off, max(inf.n_seg, 1))[:inf.n_seg],
+            chunk_seg=arr(v.chunk_seg, (inf.n_bases >> 5) + 2),
+            n=int(inf.n_bases), primary=int(inf.primary), C=[int(c) for c in inf.C],
+            _owner=self)

@@ -1,0 +1,261 @@
+"""Seeded synthetic miRge libraries and read sets (there is no network, and the
+real `miRge.Libs` are not in the image).
+
+Shapes follow SURVEY.md section 8(d): seven libraries sized like the human
+miRBase-era set (miRNA entries are 2 nt 5' flank + mature + 6 nt 3' flank as
+runAnnotationPipeline.py:413 assumes, cut out of their hairpins), plus the
+companion merges CSV (miRNAmerge.py:15-36) and 2-line miRNA FASTA
+(miRNAmerge.py:4-11).  Reads are fixed-length 22-mers in the stated mixture.
+This module builds inputs only; it never computes an expected answer.
+"""
+import os
+
+import numpy as np
+
+_LETTERS = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+LIB_KEYS = ["mirna", "hairpin", "mature_trna", "pre_trna", "snorna", "rrna", "ncrna_others", "mrna"]
+
+# entries, (min_len, max_len) -- SURVEY.md 8(d) defaults
+FULL_SHAPES = {
+    "mirna": 2800,
+    "hairpin": (1900, 60, 120),
+    "mature_trna": (450, 72, 76),
+    "pre_trna": (600, 25, 60),
+    "snorna": (1000, 70, 300),
+    "rrna": [121, 157, 954, 1559, 1869, 5070, 1800, 3400],
+    "ncrna_others": (20000, 100, 1000),
+    "mrna": (50000, 500, 5000),
+}
+
+
+def codes_to_str(codes):
+    return _LETTERS[codes].tobytes().decode("ascii")
+
+
+class SynthLibraries:
+    """libs[key] = (names, seqs); codes[key] = (concatenated uint8 codes, starts)."""
+
+    def __init__(self, seed=20181, scale=1.0, n_paralogs=60, n_snp=120):
+        rng = np.random.default_rng(seed)
+        self.libs, self.codes = {}, {}
+
+        def sc(n, lo=4):
+            return max(lo, int(round(n * scale)))
+
+        # ---- hairpins with two embedded arms; miRNA entries are cut from them ----
+        n_hp, hp_lo, hp_hi = FULL_SHAPES["hairpin"]
+        n_hp = sc(n_hp)
+        n_mir = sc(FULL_SHAPES["mirna"])
+        hp_len = rng.integers(hp_lo, hp_hi + 1, n_hp)
+        hp_codes = [rng.integers(0, 4, int(L), dtype=np.uint8) for L in hp_len]
+        mat_len_choices = np.array([18, 19, 20, 21, 22, 22, 22, 22, 23, 23, 24, 25])
+        mir_names, mir_seqs, self.mirna_mature = [], [], []
+        for j in range(n_mir):
+            h = j % n_hp
+            arm3 = (j // n_hp) % 2 == 1
+            L = int(hp_len[h])
+            mlen = int(mat_len_choices[rng.integers(0, len(mat_len_choices))])
+            lo = 2 if not arm3 else L // 2 + 2
+            hi = (L // 2 - mlen - 6) if not arm3 else (L - mlen - 6)
+            start = int(rng.integers(lo, max(lo, hi) + 1)) if hi >= lo else lo
+            start = min(start, L - mlen - 6)
+            entry = hp_codes[h][start - 2:start + mlen + 6]
+            mir_names.append("syn-miR-%d-%s" % (h + 1, "3p" if arm3 else "5p") +
+                             ("" if j < 2 * n_hp else ".%d" % (j // (2 * n_hp))))
+            mir_seqs.append(codes_to_str(entry))
+        # paralogs: same mature, different flanks -> exact reads tie between entries;
+        # the merges CSV folds each pair (miRNAmerge.py:15-36)
+        self.merges = []
+        n_par = min(sc(n_paralogs, 1), n_mir // 4)
+        for k in range(n_par):
+            a = int(rng.integers(0, n_mir))
+            s = mir_seqs[a]
+            flank5 = codes_to_str(rng.integers(0, 4, 2, dtype=np.uint8))
+            flank3 = codes_to_str(rng.integers(0, 4, 6, dtype=np.uint8))
+            name_b = mir_names[a] + "-par%d" % k
+            mir_names.append(name_b)
+            mir_seqs.append(flank5 + s[2:-6] + flank3)
+            self.merges.append("%s/%s,%s,%s" % (mir_names[a], name_b, mir_names[a], name_b))
+        # SNP entries: one substitution inside the mature (names carry .SNP, RAP:417-418)
+        n_s = min(sc(n_snp, 1), n_mir // 4)
+        for k in range(n_s):
+            a = int(rng.integers(0, n_mir))
+            s = list(mir_seqs[a])
+            p = int(rng.integers(4, len(s) - 8))
+            s[p] = "ACGT"[("ACGT".index(s[p]) + 1 + int(rng.integers(0, 3))) % 4]
+            mir_names.append(mir_names[a] + ".SNP%d" % k)
+            mir_seqs.append("".join(s))
+        self.libs["mirna"] = (mir_names, mir_seqs)
+        self.libs["hairpin"] = (["syn-mir-%d" % (h + 1) for h in range(n_hp)],
+                                [codes_to_str(c) for c in hp_codes])
+
+        def uniform_lib(key, prefix, n, lo, hi, suffix=""):
+            lens = rng.integers(lo, hi + 1, n)
+            blob = rng.integers(0, 4, int(lens.sum()), dtype=np.uint8)
+            text = _LETTERS[blob].tobytes().decode("ascii")
+            off = np.concatenate([[0], np.cumsum(lens)])
+            self.libs[key] = (["%s-%d" % (prefix, i + 1) for i in range(n)],
+                              [text[off[i]:off[i + 1]] + suffix for i in range(n)])
+
+        n, lo, hi = FULL_SHAPES["mature_trna"]
+        uniform_lib("mature_trna", "syn-tRNA", sc(n), lo, hi, suffix="CCA")
+        n, lo, hi = FULL_SHAPES["pre_trna"]
+        uniform_lib("pre_trna", "syn-pretRNA", sc(n), lo, hi)
+        n, lo, hi = FULL_SHAPES["snorna"]
+        uniform_lib("snorna", "syn-snoRNA", sc(n), lo, hi)
+        rr = [max(60, int(L * min(1.0, max(scale, 0.05)))) for L in FULL_SHAPES["rrna"]]
+        self.libs["rrna"] = (["syn-rRNA-%d" % (i + 1) for i in range(len(rr))],
+                             [codes_to_str(rng.integers(0, 4, L, dtype=np.uint8)) for L in rr])
+        n, lo, hi = FULL_SHAPES["ncrna_others"]
+        uniform_lib("ncrna_others", "syn-ncRNA", sc(n), lo, hi)
+        n, lo, hi = FULL_SHAPES["mrna"]
+        uniform_lib("mrna", "syn-mRNA", sc(n), lo, hi)
+
+        lut = np.zeros(256, dtype=np.uint8)
+        for i, ch in enumerate(b"ACGT"):
+            lut[ch] = i
+        for key, (names, seqs) in self.libs.items():
+            lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+            starts = np.concatenate([[0], np.cumsum(lens)])
+            blob = lut[np.frombuffer("".join(seqs).encode("ascii"), dtype=np.uint8)]
+            self.codes[key] = (blob, starts)
+
+    def total_bases(self, key):
+        return int(self.codes[key][1][-1])
+
+    def write_layout(self, root, species="syn", db="miRBase"):
+        """Write the miRge.Libs directory layout with FASTA
+        files where the reference keeps `.ebwt` indexes."""
+        ix = os.path.join(root, species, "index.Libs")
+        fa = os.path.join(root, species, "fasta.Libs")
+        an = os.path.join(root, species, "annotation.Libs")
+        for d in (ix, fa, an):
+            os.makedirs(d, exist_ok=True)
+        fname = {"mirna": "mirna_" + db, "hairpin": "hairpin_" + db}
+        for key, (names, seqs) in self.libs.items():
+            with open(os.path.join(ix, "%s_%s.fa" % (species, fname.get(key, key))), "w") as fh:
+                for n, s in zip(names, seqs):
+                    fh.write(">%s\n%s\n" % (n, s))
+        names, seqs = self.libs["mirna"]
+        with open(os.path.join(fa, "%s_mirna_SNP_pseudo_%s.fa" % (species, db)), "w") as fh:
+            for n, s in zip(names, seqs):
+                fh.write(">%s\n%s\n" % (n, s[2:-6]))
+        with open(os.path.join(an, "%s_merges_%s.csv" % (species, db)), "w") as fh:
+            for line in self.merges:
+                fh.write(line + "\n")
+        return os.path.join(ix, species + "_")
+
+
+# read mixture of SURVEY.md 8(d): fraction per source
+DEFAULT_MIX = dict(mirna_exact=0.55, isomir=0.15, trna=0.05, snorna=0.05, rrna_ncrna=0.05,
+                   mrna=0.05, polyt=0.03, random=0.07)
+EXACT_ONLY_MIX = dict(mirna_exact=0.02, random=0.98)  # config 2: "collapsed unique" is mostly misses
+
+
+def _cut(rng, codes, starts, entries, offs, L):
+    base = starts[entries] + offs
+    return codes[base[:, None] + np.arange(L)[None, :]]
+
+
+def _substitute(rng, mat, frac):
+    m = mat.shape[0]
+    pick = np.nonzero(rng.random(m) < frac)[0]
+    col = rng.integers(0, mat.shape[1], pick.size)
+    mat[pick, col] = (mat[pick, col] + rng.integers(1, 4, pick.size)) & 3
+    return mat
+
+
+def synth_reads(libs, n, seed=355, L=22, mix=None, zipf_s=1.1):
+    """Returns uint8 codes [n, L] (values 0..3) drawn from the mixture, shuffled."""
+    rng = np.random.default_rng(seed)
+    mix = dict(DEFAULT_MIX if mix is None else mix)
+    keys = list(mix)
+    frac = np.array([mix[k] for k in keys], dtype=np.float64)
+    counts = np.floor(frac / frac.sum() * n).astype(np.int64)
+    counts[0] += n - counts.sum()
+    out = np.empty((n, L), dtype=np.uint8)
+    at = 0
+
+    def sample_sub(key, m, length, zipf=False):
+        codes, starts = libs.codes[key]
+        n_ent = len(starts) - 1
+        lens = np.diff(starts)
+        if zipf:
+            ranks = np.minimum(rng.zipf(zipf_s, m) - 1, n_ent * 50) % n_ent
+            perm = np.random.default_rng(seed + 1).permutation(n_ent)
+            ent = perm[ranks]
+        else:
+            # entries weighted by length, so long transcripts dominate as in real data
+            ent = np.searchsorted(starts, rng.integers(0, starts[-1], m), side="right") - 1
+        room = lens[ent] - length
+        bad = room < 0
+        if bad.any():
+            ok_ent = np.nonzero(lens >= length)[0]
+            ent[bad] = ok_ent[rng.integers(0, ok_ent.size, int(bad.sum()))]
+            room = lens[ent] - length
+        off = (rng.random(m) * (room + 1)).astype(np.int64)
+        return codes, starts, ent, off
+
+    for k, m in zip(keys, counts):
+        m = int(m)
+        if m == 0:
+            continue
+        if k == "mirna_exact":
+            codes, starts, ent, _ = sample_sub("mirna", m, L, zipf=True)
+            lens = np.diff(starts)[ent]
+            off = np.clip(2 + rng.integers(-2, 3, m), 0, lens - L)
+            blk = _cut(rng, codes, starts, ent, off, L)
+        elif k == "isomir":
+            codes, starts, ent, _ = sample_sub("mirna", m, L, zipf=True)
+            lens = np.diff(starts)[ent]
+            off = np.clip(2 + rng.integers(-1, 2, m), 0, lens - L)
+            blk = _cut(rng, codes, starts, ent, off, L).copy()
+            kind = rng.integers(0, 3, m)
+            # 0: non-templated 3' addition (last base replaced by A or T)
+            add = np.nonzero(kind == 0)[0]
+            blk[add, L - 1] = np.where(rng.random(add.size) < 0.5, 0, 3)
+            # 1: one internal substitution
+            sub = np.nonzero(kind == 1)[0]
+            col = rng.integers(3, L - 4, sub.size)
+            blk[sub, col] = (blk[sub, col] + rng.integers(1, 4, sub.size)) & 3
+            # 2: substitution + addition
+            both = np.nonzero(kind == 2)[0]
+            col = rng.integers(3, L - 4, both.size)
+            blk[both, col] = (blk[both, col] + rng.integers(1, 4, both.size)) & 3
+            blk[both, L - 1] = np.where(rng.random(both.size) < 0.5, 0, 3)
+        elif k in ("trna", "snorna", "mrna"):
+            key = {"trna": "mature_trna", "snorna": "snorna", "mrna": "mrna"}[k]
+            codes, starts, ent, off = sample_sub(key, m, L)
+            blk = _substitute(rng, _cut(rng, codes, starts, ent, off, L).copy(), 0.3)
+        elif k == "rrna_ncrna":
+            h = m // 2
+            c1, s1, e1, o1 = sample_sub("rrna", h, L)
+            c2, s2, e2, o2 = sample_sub("ncrna_others", m - h, L)
+            blk = np.concatenate([_cut(rng, c1, s1, e1, o1, L), _cut(rng, c2, s2, e2, o2, L)])
+            blk = _substitute(rng, blk.copy(), 0.3)
+        elif k == "polyt":
+            tail = 4
+            codes, starts, ent, off = sample_sub("pre_trna", m, L - tail)
+            blk = np.full((m, L), 3, dtype=np.uint8)
+            blk[:, :L - tail] = _cut(rng, codes, starts, ent, off, L - tail)
+        elif k == "random":
+            blk = rng.integers(0, 4, (m, L), dtype=np.uint8)
+        else:
+            raise KeyError(k)
+        out[at:at + m] = blk
+        at += m
+    rng.shuffle(out, axis=0)
+    return out
+
+
+def synth_quant(n, n_samples=1, seed=355):
+    """Per-read, per-sample counts (uint32): mostly 1, geometric tail; with more
+    than one sample some entries are zero, as after collapsing several FASTQs."""
+    rng = np.random.default_rng(seed + 7)
+    q = rng.geometric(0.6, size=(n, n_samples)).astype(np.uint32)
+    if n_samples > 1:
+        q[rng.random((n, n_samples)) < 0.3] = 0
+        dead = q.sum(axis=1) == 0
+        q[dead, 0] = 1
+    return q

@@ -1,0 +1,208 @@
+/*
+ * oracle/fm_cpu.c -- TEST INFRASTRUCTURE, not product code.
+ *
+ * Plain-C, host-core port of the cascade's seed-and-verify matcher, driven by
+ * the same index arrays the GPU uploads (mrg_index_get_view) and the same
+ * packed reads.  Two uses only:
+ *   - tests: a second checker that also yields the per-read LF-step and
+ *     candidate counts the GPU kernel must reproduce (they define the
+ *     algorithmic bytes of bench.py's roofline);
+ *   - bench.py: the "port" CPU baseline timed on the GPU box's host cores.
+ * The semantic truth is oracle/bowtie_model.c (exhaustive scan); this file is
+ * checked against it in tests/.  PARITY UNPINNED against bowtie itself, see the
+ * header of bowtie_model.c.
+ *
+ * One pass = one bowtie command line of runAnnotationPipeline.py:577-599/688;
+ * run_cascade() applies them in order to the reads no earlier pass claimed
+ * (writeSeqToAnnot :543-554, updateAnnotDic :341-345, poly-T rule :664-686).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+  const uint32_t *blocks, *text, *sa, *seg_start, *seg_ref, *seg_off, *chunk_seg;
+  uint32_t n, primary;
+  uint32_t C[4];
+} orc_lib;
+
+typedef struct {
+  int32_t lib, seed_len, max_mm_seed, max_mm_total, trim5, trim3, min_len, max_len, poly_t,
+      reserved;
+} orc_pass;
+
+#define ODD 0x5555555555555555ull
+
+static inline uint64_t low_bits(int nbits) {
+  return nbits >= 64 ? ~0ull : (nbits <= 0 ? 0ull : ((1ull << nbits) - 1ull));
+}
+
+static inline uint32_t occ(const orc_lib *l, uint32_t c, uint32_t i) {
+  uint32_t b = i >> 6, r = i & 63;
+  const uint32_t *blk = l->blocks + (size_t)b * 8;
+  uint64_t lo = (uint64_t)blk[4] | ((uint64_t)blk[5] << 32);
+  uint64_t hi = (uint64_t)blk[6] | ((uint64_t)blk[7] << 32);
+  uint64_t e = ((c & 1) ? lo : ~lo) & ((c & 2) ? hi : ~hi);
+  e &= (1ull << r) - 1ull;
+  uint32_t o = blk[c] + (uint32_t)__builtin_popcountll(e);
+  if (c == 0 && i > l->primary && b == (l->primary >> 6)) --o;
+  return o;
+}
+
+static inline uint64_t window(const orc_lib *l, uint32_t p) {
+  uint32_t i = p >> 4, sh = (p & 15) * 2;
+  uint64_t lo64 = (uint64_t)l->text[i] | ((uint64_t)l->text[i + 1] << 32);
+  return sh ? (lo64 >> sh) | ((uint64_t)l->text[i + 2] << (64 - sh)) : lo64;
+}
+
+static void shift5(uint64_t *rd, int W, int t) {
+  if (!t) return;
+  int sh = 2 * t;
+  for (int k = 0; k + 1 < W; ++k) rd[k] = (rd[k] >> sh) | (rd[k + 1] << (64 - sh));
+  rd[W - 1] >>= sh;
+}
+
+/* Returns 1 if aligned; *key = (mm << 32) | text position. */
+static int match_one(const orc_lib *l, const orc_pass *p, const uint64_t *rd, const uint64_t *nm,
+                     int W, int L, uint32_t wstop, uint64_t *key, uint64_t *steps,
+                     uint64_t *cands) {
+  uint64_t best = ~0ull;
+  if (L <= p->max_mm_seed) return 0;
+  int R = L < p->seed_len ? L : p->seed_len;
+  int K = p->max_mm_seed + 1;
+  for (int k = 0; k < K; ++k) {
+    int a = (R * k) / K, b = (R * (k + 1)) / K;
+    int has_n = 0;
+    for (int i = a; i < b; ++i)
+      if ((nm[i >> 5] >> ((i & 31) * 2)) & 1) has_n = 1;
+    if (has_n) continue;
+    uint32_t lo = 0, hi = l->n + 1;
+    int j = b;
+    while (j > a && hi > lo && (hi - lo) > wstop) {
+      --j;
+      uint32_t c = (uint32_t)(rd[j >> 5] >> ((j & 31) * 2)) & 3u;
+      lo = l->C[c] + occ(l, c, lo);
+      hi = l->C[c] + occ(l, c, hi);
+      ++*steps;
+    }
+    for (uint32_t i = lo; i < hi; ++i) {
+      int64_t s = (int64_t)l->sa[i] - j;
+      ++*cands;
+      if (s < 0 || (uint64_t)(s + L) > l->n) continue;
+      int mm_total = 0, mm_seed = 0;
+      for (int w = 0; w < W; ++w) {
+        int nb = L - 32 * w;
+        if (nb > 32) nb = 32;
+        if (nb <= 0) break;
+        uint64_t x = window(l, (uint32_t)s + 32u * w) ^ rd[w];
+        uint64_t m = (((x | (x >> 1)) & ODD) | nm[w]) & low_bits(2 * nb);
+        mm_total += __builtin_popcountll(m);
+        int ns = p->seed_len - 32 * w;
+        if (ns > nb) ns = nb;
+        mm_seed += __builtin_popcountll(m & low_bits(2 * ns));
+      }
+      if (mm_seed > p->max_mm_seed || mm_total > p->max_mm_total) continue;
+      uint64_t cand = ((uint64_t)mm_total << 32) | (uint32_t)s;
+      if (cand >= best) continue;
+      uint32_t sg = l->chunk_seg[(uint32_t)s >> 5];
+      while (l->seg_start[sg + 1] <= (uint32_t)s) ++sg;
+      if ((uint32_t)(s + L) <= l->seg_start[sg + 1]) best = cand;
+    }
+    if ((best >> 32) == 0) break;
+  }
+  if (best == ~0ull) return 0;
+  *key = best;
+  return 1;
+}
+
+/*
+ * reads: SoA words (reads[w*n + r]), nmask same shape or NULL.
+ * stats: per pass {processed, aligned, steps, candidates}.
+ * per_read_steps (optional, n entries): LF steps summed over the passes.
+ */
+void orc_run_cascade(const orc_lib *libs, const orc_pass *passes, int n_pass, const uint64_t *reads,
+                     int W, const uint8_t *lens, const uint64_t *nmask, uint64_t n, uint32_t wstop,
+                     int8_t *pass_id, int32_t *ref_id, int32_t *pos, uint8_t *mm, uint64_t *stats,
+                     uint32_t *per_read_steps) {
+  memset(stats, 0, sizeof(uint64_t) * 4 * (size_t)n_pass);
+  for (uint64_t r = 0; r < n; ++r) {
+    pass_id[r] = -1;
+    ref_id[r] = -1;
+    pos[r] = -1;
+    mm[r] = 0;
+    if (per_read_steps) per_read_steps[r] = 0;
+  }
+  for (int pi = 0; pi < n_pass; ++pi) {
+    const orc_pass *p = &passes[pi];
+    const orc_lib *l = &libs[p->lib];
+    uint64_t processed = 0, aligned = 0, steps = 0, cands = 0;
+#pragma omp parallel for schedule(dynamic, 4096) reduction(+ : processed, aligned, steps, cands)
+    for (int64_t r = 0; r < (int64_t)n; ++r) {
+      if (pass_id[r] >= 0) continue;
+      int L = lens[r];
+      if (L < p->min_len || L > p->max_len) continue;
+      uint64_t rd[4] = {0, 0, 0, 0}, nm[4] = {0, 0, 0, 0};
+      for (int w = 0; w < W; ++w) {
+        rd[w] = reads[(size_t)w * n + r];
+        nm[w] = nmask ? nmask[(size_t)w * n + r] : 0ull;
+      }
+      if (p->poly_t) {
+        int tail = 0;
+        for (int i = L - 1; i >= 0; --i) {
+          int isn = (int)((nm[i >> 5] >> ((i & 31) * 2)) & 1);
+          int code = (int)((rd[i >> 5] >> ((i & 31) * 2)) & 3);
+          if (code == 3 && !isn) ++tail;
+          else break;
+        }
+        if (tail < 3 || L - tail < 11) continue;
+        L -= tail;
+      }
+      L -= p->trim5 + p->trim3;
+      shift5(rd, W, p->trim5);
+      shift5(nm, W, p->trim5);
+      ++processed;
+      uint64_t key = 0, st = 0, cd = 0;
+      int ok = L > 0 && match_one(l, p, rd, nm, W, L, wstop, &key, &st, &cd);
+      steps += st;
+      cands += cd;
+      if (per_read_steps) per_read_steps[r] += (uint32_t)st;
+      if (ok) {
+        uint32_t s = (uint32_t)key;
+        uint32_t sg = l->chunk_seg[s >> 5];
+        while (l->seg_start[sg + 1] <= s) ++sg;
+        pass_id[r] = (int8_t)pi;
+        ref_id[r] = (int32_t)l->seg_ref[sg];
+        pos[r] = (int32_t)(s - l->seg_start[sg] + l->seg_off[sg]);
+        mm[r] = (uint8_t)(key >> 32);
+        ++aligned;
+      }
+    }
+    stats[4 * pi + 0] = processed;
+    stats[4 * pi + 1] = aligned;
+    stats[4 * pi + 2] = steps;
+    stats[4 * pi + 3] = cands;
+  }
+}
+
+/* Tally of summarize.py:34-66 on columnar arrays (same layout as mrg_tally_run). */
+void orc_tally(const int8_t *pass_id, const int32_t *ref_id, const uint32_t *quant, uint64_t n,
+               uint32_t S, uint32_t M, uint32_t n_pass, int canon_pass, int isomir_pass,
+               uint64_t *counts) {
+  uint64_t cat0 = 2ull * M * S, uniq0 = cat0 + (uint64_t)(n_pass + 1) * S;
+  for (uint64_t r = 0; r < n; ++r) {
+    int pass = pass_id[r];
+    uint32_t cat = pass < 0 ? n_pass : (uint32_t)pass;
+    for (uint32_t s = 0; s < S; ++s) {
+      uint64_t q = quant[r * S + s];
+      if (!q) continue;
+      counts[uniq0 + s] += 1;
+      counts[cat0 + (uint64_t)cat * S + s] += q;
+      if (pass == canon_pass) {
+        counts[(uint64_t)ref_id[r] * S + s] += q;
+        counts[(uint64_t)M * S + (uint64_t)ref_id[r] * S + s] += q;
+      } else if (pass == isomir_pass) {
+        counts[(uint64_t)ref_id[r] * S + s] += q;
+      }
+    }
+  }
+}

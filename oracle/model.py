@@ -1,0 +1,181 @@
+"""ctypes bindings of oracle/_build/liboracle.so (bowtie_model.c + fm_cpu.c).
+
+TEST INFRASTRUCTURE, see oracle/__init__.py.  `build()` compiles the C sources
+with gcc; nothing here touches a GPU.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile oracle/*.c -> oracle/_build/liboracle.so (gcc -O2 -fopenmp)."""
+    srcs = [os.path.join(_HERE, f) for f in ("bowtie_model.c", "fm_cpu.c", "Makefile")]
+    stale = (not os.path.exists(_SO)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_align_batch.restype = None
+        _lib.orc_align_all_best.restype = C.c_int
+        _lib.orc_run_cascade.restype = None
+        _lib.orc_tally.restype = None
+    return _lib
+
+
+class Library:
+    """One reference library as the model sees it: names + ASCII sequences."""
+
+    def __init__(self, names, seqs):
+        self.names = list(names)
+        self.seqs = [s.upper() for s in seqs]
+        self.concat = "".join(self.seqs).encode("ascii")
+        off = np.zeros(len(self.seqs) + 1, dtype=np.uint32)
+        np.cumsum([len(s) for s in self.seqs], out=off[1:])
+        self.off = off
+
+    @classmethod
+    def from_fasta(cls, path):
+        names, seqs = [], []
+        with open(path) as fh:
+            for line in fh:
+                line = line.strip()
+                if not line:
+                    continue
+                if line[0] == ">":
+                    names.append(line[1:].split()[0])
+                    seqs.append([])
+                else:
+                    seqs[-1].append(line)
+        return cls(names, ["".join(s) for s in seqs])
+
+
+def align_batch(library, reads, seed_len, max_mm_seed, max_mm_total):
+    """Exhaustive-scan alignment of ASCII reads; returns (ref, pos, mm) int32
+    arrays with -1 for unaligned reads."""
+    n = len(reads)
+    out_ref = np.full(n, -1, dtype=np.int32)
+    out_pos = np.full(n, -1, dtype=np.int32)
+    out_mm = np.full(n, -1, dtype=np.int32)
+    if n == 0:
+        return out_ref, out_pos, out_mm
+    blob = "".join(reads).upper().encode("ascii")
+    off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum([len(r) for r in reads], out=off[1:])
+    lib().orc_align_batch(
+        C.c_char_p(library.concat), library.off.ctypes.data_as(C.c_void_p),
+        C.c_uint32(len(library.names)), C.c_char_p(blob), off.ctypes.data_as(C.c_void_p),
+        C.c_uint64(n), C.c_int(seed_len), C.c_int(max_mm_seed), C.c_int(max_mm_total),
+        out_ref.ctypes.data_as(C.c_void_p), out_pos.ctypes.data_as(C.c_void_p),
+        out_mm.ctypes.data_as(C.c_void_p))
+    return out_ref, out_pos, out_mm
+
+
+def align_all_best(library, read, seed_len, max_mm_seed, max_mm_total, cap=4096):
+    """Every alignment of the best stratum, in (entry, offset) order."""
+    refs = np.zeros(cap, dtype=np.int32)
+    poss = np.zeros(cap, dtype=np.int32)
+    mm = C.c_int32(-1)
+    r = read.upper().encode("ascii")
+    k = lib().orc_align_all_best(
+        C.c_char_p(library.concat), library.off.ctypes.data_as(C.c_void_p),
+        C.c_uint32(len(library.names)), C.c_char_p(r), C.c_int(len(r)), C.c_int(seed_len),
+        C.c_int(max_mm_seed), C.c_int(max_mm_total), refs.ctypes.data_as(C.c_void_p),
+        poss.ctypes.data_as(C.c_void_p), C.c_int(cap), C.byref(mm))
+    k = min(k, cap)
+    return [(int(refs[i]), int(poss[i])) for i in range(k)], int(mm.value)
+
+
+# ---------------------------------------------------------------------------
+# fm_cpu.c: the host-core port of the seed-and-verify matcher
+# ---------------------------------------------------------------------------
+class _OrcLib(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in
+                ("blocks", "text", "sa", "seg_start", "seg_ref", "seg_off", "chunk_seg")] + \
+               [("n", C.c_uint32), ("primary", C.c_uint32), ("C", C.c_uint32 * 4)]
+
+
+class _OrcPass(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in
+                ("lib", "seed_len", "max_mm_seed", "max_mm_total", "trim5", "trim3", "min_len",
+                 "max_len", "poly_t", "reserved")]
+
+
+def fm_cascade(lib_views, passes, reads, lens, nmask=None, wstop=0, threads=None,
+               want_steps=False):
+    """Run the CPU port.
+
+    lib_views: list of dicts with numpy arrays blocks/text/sa/seg_start/seg_ref/
+               seg_off/chunk_seg and ints n, primary, C (as mirge_amd index views).
+    passes   : list of dicts with the mrg_pass_cfg fields.
+    reads    : uint64 [W, n] SoA words; lens uint8 [n]; nmask like reads or None.
+    Returns dict(pass_id, ref_id, pos, mm, stats[n_pass,4], steps_per_read|None).
+    """
+    reads = np.ascontiguousarray(reads, dtype=np.uint64)
+    W, n = reads.shape
+    lens = np.ascontiguousarray(lens, dtype=np.uint8)
+    keep = []
+    libs = (_OrcLib * len(lib_views))()
+    for i, v in enumerate(lib_views):
+        for k in ("blocks", "text", "sa", "seg_start", "seg_ref", "seg_off", "chunk_seg"):
+            a = np.ascontiguousarray(v[k], dtype=np.uint32)
+            keep.append(a)
+            setattr(libs[i], k, a.ctypes.data)
+        libs[i].n = int(v["n"])
+        libs[i].primary = int(v["primary"])
+        for c in range(4):
+            libs[i].C[c] = int(v["C"][c])
+    ps = (_OrcPass * len(passes))()
+    for i, p in enumerate(passes):
+        for k, _ in _OrcPass._fields_:
+            setattr(ps[i], k, int(p.get(k, 0)))
+    pass_id = np.empty(n, dtype=np.int8)
+    ref_id = np.empty(n, dtype=np.int32)
+    pos = np.empty(n, dtype=np.int32)
+    mm = np.empty(n, dtype=np.uint8)
+    stats = np.zeros((len(passes), 4), dtype=np.uint64)
+    steps = np.zeros(n, dtype=np.uint32) if want_steps else None
+    nm = None if nmask is None else np.ascontiguousarray(nmask, dtype=np.uint64)
+    old = os.environ.get("OMP_NUM_THREADS")
+    if threads:
+        os.environ["OMP_NUM_THREADS"] = str(threads)
+        try:
+            C.CDLL("libgomp.so.1").omp_set_num_threads(int(threads))
+        except OSError:
+            pass
+    lib().orc_run_cascade(
+        libs, ps, C.c_int(len(passes)), reads.ctypes.data_as(C.c_void_p), C.c_int(W),
+        lens.ctypes.data_as(C.c_void_p), None if nm is None else nm.ctypes.data_as(C.c_void_p),
+        C.c_uint64(n), C.c_uint32(wstop), pass_id.ctypes.data_as(C.c_void_p),
+        ref_id.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p),
+        mm.ctypes.data_as(C.c_void_p), stats.ctypes.data_as(C.c_void_p),
+        None if steps is None else steps.ctypes.data_as(C.c_void_p))
+    if threads and old is not None:
+        os.environ["OMP_NUM_THREADS"] = old
+    return dict(pass_id=pass_id, ref_id=ref_id, pos=pos, mm=mm, stats=stats, steps_per_read=steps)
+
+
+def tally(pass_id, ref_id, quant, n_mirna, n_pass, canon_pass, isomir_pass):
+    quant = np.ascontiguousarray(quant, dtype=np.uint32)
+    n, S = quant.shape
+    counts = np.zeros(2 * n_mirna * S + (n_pass + 1) * S + S, dtype=np.uint64)
+    lib().orc_tally(
+        np.ascontiguousarray(pass_id, dtype=np.int8).ctypes.data_as(C.c_void_p),
+        np.ascontiguousarray(ref_id, dtype=np.int32).ctypes.data_as(C.c_void_p),
+        quant.ctypes.data_as(C.c_void_p), C.c_uint64(n), C.c_uint32(S), C.c_uint32(n_mirna),
+        C.c_uint32(n_pass), C.c_int(canon_pass), C.c_int(isomir_pass),
+        counts.ctypes.data_as(C.c_void_p))
+    return counts

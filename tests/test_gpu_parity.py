@@ -1,0 +1,120 @@
+"""GPU parity (-m gpu): the HIP path, called through the C-ABI, against the
+oracle on the same seeded inputs.  Bit-exact: every array is integer."""
+import numpy as np
+import pytest
+
+from oracle import cascade, model
+from tests.util import LIB_ORDER, World
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world(native_lib, oracle_lib):
+    return World(scale=0.05, n_fixed=20000, n_var=3000)
+
+
+@pytest.fixture(scope="module")
+def engine(world):
+    from mirge_amd.engine import Engine
+    eng = Engine(0)
+    for k in LIB_ORDER:
+        eng.add_library(k, world.index[k])
+    return eng
+
+
+def run_gpu(engine, world, quant=None, **opts):
+    from mirge_amd.engine import ReadSet
+    for k, v in opts.items():
+        engine.set_option(k, v)
+    rs = ReadSet(world.words, world.lens, world.nmask, quant, device=engine.device)
+    res = engine.cascade(rs, engine.mirge_passes())
+    return rs, res
+
+
+def assert_same(res, ref):
+    got = res.to_host()
+    for name, a in zip(("pass_id", "ref_id", "pos", "mm"), got):
+        assert np.array_equal(a, ref[name]), name
+    for i, st in enumerate(res.stats):
+        assert st["processed"] == int(ref["stats"][i][0])
+        assert st["aligned"] == int(ref["stats"][i][1])
+        assert st["steps"] == int(ref["stats"][i][2])
+        assert st["candidates"] == int(ref["stats"][i][3])
+
+
+def test_cascade_matches_cpu_port_all_lds_modes(engine, world):
+    ref = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask)
+    # default residency (blocks+text in LDS where they fit), blocks only, nothing staged
+    for budget in (160 * 1024, 24 * 1024, 0):
+        _, res = run_gpu(engine, world, lds_budget=budget, wstop=0)
+        assert_same(res, ref)
+    engine.set_option("lds_budget", 160 * 1024)
+
+
+def test_cascade_matches_exhaustive_scan(engine, world):
+    """Against the independent model of bowtie's rules (subset, it is O(N*text))."""
+    _, res = run_gpu(engine, world, lds_budget=160 * 1024, wstop=0)
+    pass_id, ref_id, pos, mm = res.to_host()
+    sub = np.random.default_rng(5).choice(len(world.reads), 4000, replace=False)
+    reads = [world.reads[i] for i in sub]
+    libs = {k: model.Library(*world.libs.libs[k]) for k in LIB_ORDER}
+    seq_dic = {r: cascade.new_seq_record(r, 1) for r in reads}
+    log_dic = {"quantStats": [{}], "annotStats": []}
+    align = {}
+    cascade.run_annotation_pipeline(seq_dic, libs, log_dic, align_dic=align)
+    for i, r in zip(sub, reads):
+        got = None if pass_id[i] < 0 else (int(pass_id[i]), int(ref_id[i]), int(pos[i]), int(mm[i]))
+        assert align.get(r) == got, r
+
+
+def test_early_stop_same_results_fewer_steps(engine, world):
+    ref = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask, wstop=2)
+    _, res = run_gpu(engine, world, wstop=2)
+    assert_same(res, ref)
+    engine.set_option("wstop", 0)
+
+
+def test_tally_matches_oracle(engine, world):
+    from mirge_amd import synth
+    from mirge_amd.engine import split_counts
+    for S in (1, 3):
+        quant = synth.synth_quant(len(world.lens), n_samples=S)
+        rs, res = run_gpu(engine, world, quant=quant)
+        counts = engine.tally(rs, res, world.n_mirna).cpu().numpy()
+        pass_id, ref_id, _, _ = res.to_host()
+        want = model.tally(pass_id, ref_id, quant, world.n_mirna, 9, 0, 8)
+        assert np.array_equal(counts.astype(np.uint64), want)
+        q, c, cat, uniq = split_counts(counts, world.n_mirna, S, 9)
+        assert int(cat.sum()) == int(quant.sum())           # every read lands in one category
+        assert np.array_equal(uniq, (quant != 0).sum(axis=0))
+
+
+def test_host_buffer_entry_point(engine, world):
+    from mirge_amd import synth
+    quant = synth.synth_quant(len(world.lens))
+    out = engine.annotate_host(world.words, world.lens, world.nmask, engine.mirge_passes(),
+                               quant=quant, n_mirna=world.n_mirna)
+    ref = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask)
+    for k in ("pass_id", "ref_id", "pos", "mm"):
+        assert np.array_equal(out[k], ref[k]), k
+    want = model.tally(ref["pass_id"], ref["ref_id"], quant, world.n_mirna, 9, 0, 8)
+    assert np.array_equal(out["counts"], want)
+
+
+def test_empty_and_tiny_inputs(engine, world):
+    from mirge_amd import pack
+    from mirge_amd.engine import ReadSet
+    for reads in ([], ["ACGTACGTACGTACGTAC"], ["TTTTTTTTTTTTTTTTTTTT", "NNNNNNNNNNNNNNNNNN", "ACG"]):
+        if reads:
+            w, l, nm = pack.pack_reads(reads)
+        else:
+            w, l, nm = np.zeros((1, 0), np.uint64), np.zeros(0, np.uint8), None
+        rs = ReadSet(w, l, nm, np.ones((len(reads), 1), np.uint32), device=engine.device)
+        res = engine.cascade(rs, engine.mirge_passes())
+        ref = model.fm_cascade(world.views, world.passes, w, l, nm)
+        got = res.to_host()
+        for name, a in zip(("pass_id", "ref_id", "pos", "mm"), got):
+            assert np.array_equal(a, ref[name]), (reads, name)
+        counts = engine.tally(rs, res, world.n_mirna).cpu().numpy()
+        assert int(counts[2 * world.n_mirna:2 * world.n_mirna + 10].sum()) == len(reads)

@@ -1,0 +1,87 @@
+"""CPU suite: the exhaustive-scan model, the FM port and the index builder agree.
+
+(The aligner boundary is PARITY UNPINNED against bowtie itself -- see
+oracle/__init__.py; these tests pin our two independent restatements to each
+other and the index layout to a naive construction.)"""
+import numpy as np
+import pytest
+
+from oracle import cascade, model
+from tests.util import LIB_ORDER, World
+
+
+@pytest.fixture(scope="module")
+def world(native_lib, oracle_lib):
+    return World()
+
+
+def test_suffix_array_and_bwt_match_naive(native_lib):
+    from mirge_amd.index import FmIndex
+    rng = np.random.default_rng(3)
+    seqs = ["".join("ACGT"[c] for c in rng.integers(0, 4, int(L))) for L in rng.integers(1, 90, 40)]
+    seqs[3] = seqs[3][:5] + "NNN" + seqs[3][5:]
+    seqs[7] = "A" * 70          # low complexity
+    seqs[8] = seqs[7]           # exact duplicate entry
+    ix = FmIndex.build(["e%d" % i for i in range(len(seqs))], seqs)
+    v = ix.view()
+    text = "".join(s.replace("N", "") for s in seqs)
+    assert v["n"] == len(text)
+    t = text + "$"
+    naive = sorted(range(len(t)), key=lambda i: t[i:])
+    assert list(v["sa"]) == naive
+    # occ blocks reproduce rank over the BWT
+    bwt = [t[i - 1] if i else "$" for i in naive]
+    blocks = v["blocks"].reshape(-1, 8)
+    for c, ch in enumerate("ACGT"):
+        run = 0
+        for i, b in enumerate(bwt):
+            if i % 64 == 0:
+                assert blocks[i // 64][c] == run
+            run += b == ch
+        assert v["C"][c] == 1 + sum(x < ch for x in text)
+    assert bwt[v["primary"]] == "$"
+    # bowtie-inspect equivalents
+    assert [ix.sequence(i) for i in range(len(seqs))] == seqs
+    assert ix.names == ["e%d" % i for i in range(len(seqs))]
+
+
+def test_index_roundtrip_file(native_lib, tmp_path):
+    from mirge_amd.index import FmIndex
+    ix = FmIndex.build(["a", "b"], ["ACGTTGCANNACGT", "GGGTTTAAACCC"])
+    p = str(tmp_path / "x.mrgfm")
+    ix.save(p)
+    iy = FmIndex.load(p)
+    va, vb = ix.view(), iy.view()
+    for k in ("blocks", "text", "sa", "seg_start", "seg_ref", "seg_off", "chunk_seg"):
+        assert np.array_equal(va[k], vb[k])
+    assert iy.names == ["a", "b"] and iy.sequence(0) == "ACGTTGCANNACGT"
+
+
+def test_fm_port_equals_exhaustive_scan(world):
+    """Every read: same claiming pass, entry, offset and mismatch count; same
+    per-pass processed/aligned counters (runAnnotationPipeline.py:648-650)."""
+    res = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask)
+    libs = {k: model.Library(*world.libs.libs[k]) for k in LIB_ORDER}
+    seq_dic = {r: cascade.new_seq_record(r, 1) for r in world.reads}
+    log_dic = {"quantStats": [{}], "annotStats": []}
+    align = {}
+    cascade.run_annotation_pipeline(seq_dic, libs, log_dic, align_dic=align)
+    for i, r in enumerate(world.reads):
+        got = None
+        if res["pass_id"][i] >= 0:
+            got = (int(res["pass_id"][i]), int(res["ref_id"][i]), int(res["pos"][i]), int(res["mm"][i]))
+        assert align.get(r) == got, r
+    for i, st in enumerate(log_dic["annotStats"]):
+        assert st["readsProcessed"] == int(res["stats"][i][0])
+        assert st["readsAligned"] == int(res["stats"][i][1])
+    # every pass of the cascade claimed something, so all nine policies were exercised
+    assert all(int(res["stats"][i][1]) > 0 for i in range(9))
+
+
+def test_early_stop_width_does_not_change_results(world):
+    base = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask)
+    for wstop in (1, 4, 64):
+        alt = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask, wstop=wstop)
+        for k in ("pass_id", "ref_id", "pos", "mm"):
+            assert np.array_equal(base[k], alt[k])
+        assert int(alt["stats"][:, 2].sum()) < int(base["stats"][:, 2].sum())

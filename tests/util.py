@@ -1,0 +1,50 @@
+"""Shared builders for the test suite: a small synthetic world (libraries,
+indexes, reads) and adapters between the columnar product API and the oracle."""
+import numpy as np
+
+from mirge_amd import pack, synth
+from mirge_amd.engine import MIRGE_PASS_TABLE
+from mirge_amd.index import FmIndex
+
+LIB_ORDER = list(synth.LIB_KEYS)
+
+
+def pass_dicts(spike_in=False, order=LIB_ORDER):
+    rows = MIRGE_PASS_TABLE[:10 if spike_in else 9]
+    return [dict(lib=order.index(k), min_len=a, max_len=b, seed_len=s, max_mm_seed=ms,
+                 max_mm_total=mt, trim5=t5, trim3=t3, poly_t=pt)
+            for (k, a, b, s, ms, mt, t5, t3, pt) in rows]
+
+
+def mixed_reads(libs, n_fixed=3000, n_var=500, seed=1, with_n=True):
+    """22-mers from the standard mixture plus variable-length (16..44 nt) reads cut
+    from hairpin / miRNA / ncRNA entries with 0-2 edits (some of them N)."""
+    reads = [synth.codes_to_str(c) for c in synth.synth_reads(libs, n_fixed, seed=seed + 354)]
+    rng = np.random.default_rng(seed)
+    alphabet = "ACGTN" if with_n else "ACGT"
+    for _ in range(n_var):
+        key = ["hairpin", "mirna", "ncrna_others", "pre_trna"][int(rng.integers(0, 4))]
+        seqs = libs.libs[key][1]
+        s = seqs[int(rng.integers(0, len(seqs)))]
+        ln = int(rng.integers(16, 45))
+        if len(s) < ln:
+            continue
+        o = int(rng.integers(0, len(s) - ln + 1))
+        r = list(s[o:o + ln])
+        for _ in range(int(rng.integers(0, 3))):
+            r[int(rng.integers(0, ln))] = alphabet[int(rng.integers(0, len(alphabet)))]
+        if rng.random() < 0.2:
+            r += list("T" * int(rng.integers(3, 7)))
+        reads.append("".join(r)[:60])
+    return list(dict.fromkeys(reads))
+
+
+class World:
+    def __init__(self, scale=0.03, seed=20181, n_fixed=3000, n_var=500, with_n=True):
+        self.libs = synth.SynthLibraries(seed=seed, scale=scale)
+        self.index = {k: FmIndex.build(*self.libs.libs[k]) for k in LIB_ORDER}
+        self.views = [self.index[k].view() for k in LIB_ORDER]
+        self.reads = mixed_reads(self.libs, n_fixed, n_var, with_n=with_n)
+        self.words, self.lens, self.nmask = pack.pack_reads(self.reads)
+        self.passes = pass_dicts()
+        self.n_mirna = self.index["mirna"].n_ref
