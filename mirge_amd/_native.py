@@ -88,6 +88,23 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process: torch wheels bundle their own libamdhip64
+    (SONAME libamdhip64.so.7, the name this library needs), and the streams and
+    device pointers the host passes in come from torch.  Loading torch's copy
+    first makes the dynamic loader bind libmirge_amd.so to it instead of
+    opening a second runtime from /opt/rocm, which then finds no GPU."""
+    if os.environ.get("MIRGE_AMD_STANDALONE_HIP") == "1":
+        return
+    try:
+        import torch
+    except ImportError:
+        return
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load libmirge_amd.so; raises (never falls back) when it is absent."""
     global _lib
@@ -97,6 +114,7 @@ def load():
         raise ImportError(
             "%s not found: build it with `make -C mirge_amd/csrc` (hipcc --offload-arch=gfx950). "
             "mirge_amd has no CPU fallback." % LIB_PATH)
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

@@ -312,9 +312,9 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
                     const mrg_pass_cfg* passes, uint32_t n_pass, int8_t* d_pass_id,
                     int32_t* d_ref_id, int32_t* d_pos, uint8_t* d_mm, uint64_t* d_pass_counts,
                     void* d_workspace, uint64_t workspace_bytes, void* stream_) {
-  if (!ctx || !passes || !d_pass_id || !d_ref_id || !d_pos || !d_mm || !d_workspace)
-    return fail(MRG_ERR_ARG, "mrg_cascade_run: null argument");
-  if (n && (!d_reads || !d_lens)) return fail(MRG_ERR_ARG, "mrg_cascade_run: null read buffers");
+  if (!ctx || !passes || !d_workspace) return fail(MRG_ERR_ARG, "mrg_cascade_run: null argument");
+  if (n && (!d_reads || !d_lens || !d_pass_id || !d_ref_id || !d_pos || !d_mm))
+    return fail(MRG_ERR_ARG, "mrg_cascade_run: null read/output buffers");
   if (n_pass == 0 || n_pass > MRG_MAX_PASSES)
     return fail(MRG_ERR_ARG, "mrg_cascade_run: n_pass %u not in [1,%d]", n_pass, MRG_MAX_PASSES);
   if (words_per_read != 1 && words_per_read != 2 && words_per_read != 4)
@@ -491,9 +491,9 @@ int mrg_annotate_host(mrg_ctx* ctx, const uint64_t* reads, uint32_t words_per_re
                       int32_t* pos, uint8_t* mm, mrg_pass_stats* stats, const uint32_t* quant,
                       uint32_t n_samples, uint32_t n_mirna, int32_t canon_pass, int32_t isomir_pass,
                       uint64_t* counts) {
-  if (!ctx || !passes || !pass_id || !ref_id || !pos || !mm)
-    return fail(MRG_ERR_ARG, "mrg_annotate_host: null argument");
-  if (n && (!reads || !lens)) return fail(MRG_ERR_ARG, "mrg_annotate_host: null read buffers");
+  if (!ctx || !passes) return fail(MRG_ERR_ARG, "mrg_annotate_host: null argument");
+  if (n && (!reads || !lens || !pass_id || !ref_id || !pos || !mm))
+    return fail(MRG_ERR_ARG, "mrg_annotate_host: null read/output buffers");
   HIP_TRY(hipSetDevice(ctx->device));
   struct Bufs {
     std::vector<void*> v;
