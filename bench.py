@@ -65,28 +65,27 @@ def main():
     keys = list(synth.LIB_KEYS) if args.workload == "cascade" else ["mirna"]
 
     # ---- libraries + indexes (host; identical on every rank) ----
+    # index construction (C++, releases the GIL) overlaps with read generation below
+    from concurrent.futures import ThreadPoolExecutor
     t0 = time.time()
     libs = synth.SynthLibraries(seed=20181, scale=args.scale)
-    index = {}
-    for k in keys:
-        t1 = time.time()
-        index[k] = FmIndex.build(*libs.libs[k])
-        log(rank, "index %-13s %9d bp  %6.1f s" % (k, libs.total_bases(k), time.time() - t1))
-    log(rank, "libraries+indexes %.1f s" % (time.time() - t0))
+    pool = ThreadPoolExecutor(max_workers=len(keys))
+    futures = {k: pool.submit(FmIndex.build, *libs.libs[k]) for k in keys}
 
     # ---- this rank's shard of reads (seeded per rank), packed, moved to HBM once ----
-    t0 = time.time()
     mix = None if args.workload == "cascade" else synth.EXACT_ONLY_MIX
     words = np.empty((1, n_reads), dtype=np.uint64)
     chunk = 10_000_000
     for lo in range(0, n_reads, chunk):
         m = min(chunk, n_reads - lo)
-        codes = synth.synth_reads(libs, m, seed=355 + 1000 * rank + lo // chunk, mix=mix)
-        w, _, _ = pack.pack_codes(codes, 1)
-        words[:, lo:lo + m] = w
+        words[0, lo:lo + m] = synth.synth_reads_packed(libs, m, seed=355 + 1000 * rank + lo // chunk, mix=mix)
     lens = np.full(n_reads, 22, dtype=np.uint8)
     quant = synth.synth_quant(n_reads, args.samples, seed=355 + rank)
     log(rank, "reads: %d x 22 nt generated+packed in %.1f s" % (n_reads, time.time() - t0))
+    index = {k: f.result() for k, f in futures.items()}
+    pool.shutdown()
+    log(rank, "libraries + indexes (%s bp) ready after %.1f s" %
+        (", ".join("%s %d" % (k, libs.total_bases(k)) for k in keys), time.time() - t0))
 
     eng = Engine(local_rank)
     for k in keys:

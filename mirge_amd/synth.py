@@ -153,28 +153,49 @@ DEFAULT_MIX = dict(mirna_exact=0.55, isomir=0.15, trna=0.05, snorna=0.05, rrna_n
 EXACT_ONLY_MIX = dict(mirna_exact=0.02, random=0.98)  # config 2: "collapsed unique" is mostly misses
 
 
-def _cut(rng, codes, starts, entries, offs, L):
-    base = starts[entries] + offs
-    return codes[base[:, None] + np.arange(L)[None, :]]
+_WINDOW_CACHE = {}
 
 
-def _substitute(rng, mat, frac):
-    m = mat.shape[0]
-    pick = np.nonzero(rng.random(m) < frac)[0]
-    col = rng.integers(0, mat.shape[1], pick.size)
-    mat[pick, col] = (mat[pick, col] + rng.integers(1, 4, pick.size)) & 3
-    return mat
+def _cut_packed(codes, base, L):
+    """2-bit pack codes[base : base+L] for every element of `base` (uint64 per read)."""
+    if codes.shape[0] <= (1 << 21):
+        # small library: pack a 32-base window at every text position once, then gather
+        key = (codes.ctypes.data, codes.shape[0])
+        win = _WINDOW_CACHE.get(key)
+        if win is None:
+            pad = np.concatenate([codes, np.zeros(32, dtype=np.uint8)]).astype(np.uint64)
+            win = np.zeros(codes.shape[0], dtype=np.uint64)
+            for i in range(32):
+                win |= pad[i:i + codes.shape[0]] << np.uint64(2 * i)
+            _WINDOW_CACHE[key] = win
+        return win[base] & np.uint64((1 << (2 * L)) - 1)
+    w = np.zeros(base.shape[0], dtype=np.uint64)
+    for i in range(L):
+        w |= codes[base + i].astype(np.uint64) << np.uint64(2 * i)
+    return w
 
 
-def synth_reads(libs, n, seed=355, L=22, mix=None, zipf_s=1.1):
-    """Returns uint8 codes [n, L] (values 0..3) drawn from the mixture, shuffled."""
+def _xor_at(words, rows, cols, delta):
+    """Substitute base `cols` of reads `rows`: code ^= delta (delta in 1..3)."""
+    words[rows] ^= delta.astype(np.uint64) << (2 * cols).astype(np.uint64)
+
+
+def _set_at(words, rows, col, value):
+    sh = np.uint64(2 * col)
+    words[rows] = (words[rows] & ~(np.uint64(3) << sh)) | (value.astype(np.uint64) << sh)
+
+
+def synth_reads_packed(libs, n, seed=355, L=22, mix=None, zipf_s=1.1):
+    """Packed reads (uint64 [n], L <= 32 bases each) drawn from the mixture, shuffled."""
+    if L > 32:
+        raise ValueError("synthetic reads are at most 32 nt")
     rng = np.random.default_rng(seed)
     mix = dict(DEFAULT_MIX if mix is None else mix)
     keys = list(mix)
     frac = np.array([mix[k] for k in keys], dtype=np.float64)
     counts = np.floor(frac / frac.sum() * n).astype(np.int64)
     counts[0] += n - counts.sum()
-    out = np.empty((n, L), dtype=np.uint8)
+    out = np.empty(n, dtype=np.uint64)
     at = 0
 
     def sample_sub(key, m, length, zipf=False):
@@ -197,6 +218,11 @@ def synth_reads(libs, n, seed=355, L=22, mix=None, zipf_s=1.1):
         off = (rng.random(m) * (room + 1)).astype(np.int64)
         return codes, starts, ent, off
 
+    def substituted(words, frac_sub, length):
+        pick = np.nonzero(rng.random(words.shape[0]) < frac_sub)[0]
+        _xor_at(words, pick, rng.integers(0, length, pick.size), rng.integers(1, 4, pick.size))
+        return words
+
     for k, m in zip(keys, counts):
         m = int(m)
         if m == 0:
@@ -205,48 +231,49 @@ def synth_reads(libs, n, seed=355, L=22, mix=None, zipf_s=1.1):
             codes, starts, ent, _ = sample_sub("mirna", m, L, zipf=True)
             lens = np.diff(starts)[ent]
             off = np.clip(2 + rng.integers(-2, 3, m), 0, lens - L)
-            blk = _cut(rng, codes, starts, ent, off, L)
+            blk = _cut_packed(codes, starts[ent] + off, L)
         elif k == "isomir":
             codes, starts, ent, _ = sample_sub("mirna", m, L, zipf=True)
             lens = np.diff(starts)[ent]
             off = np.clip(2 + rng.integers(-1, 2, m), 0, lens - L)
-            blk = _cut(rng, codes, starts, ent, off, L).copy()
+            blk = _cut_packed(codes, starts[ent] + off, L)
             kind = rng.integers(0, 3, m)
-            # 0: non-templated 3' addition (last base replaced by A or T)
-            add = np.nonzero(kind == 0)[0]
-            blk[add, L - 1] = np.where(rng.random(add.size) < 0.5, 0, 3)
-            # 1: one internal substitution
-            sub = np.nonzero(kind == 1)[0]
-            col = rng.integers(3, L - 4, sub.size)
-            blk[sub, col] = (blk[sub, col] + rng.integers(1, 4, sub.size)) & 3
-            # 2: substitution + addition
-            both = np.nonzero(kind == 2)[0]
-            col = rng.integers(3, L - 4, both.size)
-            blk[both, col] = (blk[both, col] + rng.integers(1, 4, both.size)) & 3
-            blk[both, L - 1] = np.where(rng.random(both.size) < 0.5, 0, 3)
+            # 0: non-templated 3' addition (last base replaced by A or T); 1: one internal
+            # substitution; 2: both
+            add = np.nonzero(kind != 1)[0]
+            _set_at(blk, add, L - 1, np.where(rng.random(add.size) < 0.5, 0, 3))
+            sub = np.nonzero(kind != 0)[0]
+            _xor_at(blk, sub, rng.integers(3, L - 4, sub.size), rng.integers(1, 4, sub.size))
         elif k in ("trna", "snorna", "mrna"):
             key = {"trna": "mature_trna", "snorna": "snorna", "mrna": "mrna"}[k]
             codes, starts, ent, off = sample_sub(key, m, L)
-            blk = _substitute(rng, _cut(rng, codes, starts, ent, off, L).copy(), 0.3)
+            blk = substituted(_cut_packed(codes, starts[ent] + off, L), 0.3, L)
         elif k == "rrna_ncrna":
             h = m // 2
             c1, s1, e1, o1 = sample_sub("rrna", h, L)
             c2, s2, e2, o2 = sample_sub("ncrna_others", m - h, L)
-            blk = np.concatenate([_cut(rng, c1, s1, e1, o1, L), _cut(rng, c2, s2, e2, o2, L)])
-            blk = _substitute(rng, blk.copy(), 0.3)
+            blk = np.concatenate([_cut_packed(c1, s1[e1] + o1, L), _cut_packed(c2, s2[e2] + o2, L)])
+            blk = substituted(blk, 0.3, L)
         elif k == "polyt":
             tail = 4
             codes, starts, ent, off = sample_sub("pre_trna", m, L - tail)
-            blk = np.full((m, L), 3, dtype=np.uint8)
-            blk[:, :L - tail] = _cut(rng, codes, starts, ent, off, L - tail)
+            blk = _cut_packed(codes, starts[ent] + off, L - tail)
+            for i in range(L - tail, L):
+                blk |= np.uint64(3) << np.uint64(2 * i)
         elif k == "random":
-            blk = rng.integers(0, 4, (m, L), dtype=np.uint8)
+            blk = rng.integers(0, 1 << (2 * L), m, dtype=np.uint64)
         else:
             raise KeyError(k)
         out[at:at + m] = blk
         at += m
-    rng.shuffle(out, axis=0)
-    return out
+    return out[rng.permutation(n)]
+
+
+def synth_reads(libs, n, seed=355, L=22, mix=None, zipf_s=1.1):
+    """Same reads as uint8 codes [n, L] (small inputs: tests, smoke)."""
+    w = synth_reads_packed(libs, n, seed=seed, L=L, mix=mix, zipf_s=zipf_s)
+    sh = (2 * np.arange(L)).astype(np.uint64)
+    return ((w[:, None] >> sh[None, :]) & np.uint64(3)).astype(np.uint8)
 
 
 def synth_quant(n, n_samples=1, seed=355):
