@@ -396,24 +396,26 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     // residency decision: blocks + text, blocks only, or nothing in LDS
     const uint64_t blk_bytes = (uint64_t)l.nblk * 32, txt_bytes = (uint64_t)l.text_words * 4;
     int lds_mode = 0;
-    uint32_t lds_bytes = 0;
-    if (blk_bytes + txt_bytes <= (uint64_t)ctx->lds_budget) {
+    uint32_t lds_bytes = 0;  // library bytes staged; the survivor ring comes on top
+    const uint64_t room = ctx->lds_budget > (int64_t)mrg::kStageBytes
+                              ? (uint64_t)ctx->lds_budget - mrg::kStageBytes : 0;
+    if (blk_bytes + txt_bytes <= room) {
       lds_mode = 2;
       lds_bytes = (uint32_t)(blk_bytes + txt_bytes);
-    } else if (blk_bytes <= (uint64_t)ctx->lds_budget) {
+    } else if (blk_bytes <= room) {
       lds_mode = 1;
       lds_bytes = (uint32_t)blk_bytes;
     }
     uint32_t grid;
     if (lds_mode) {
       // 1024-thread workgroups; two per CU when two staged copies fit
-      uint32_t per_cu = (lds_bytes * 2 <= 160 * 1024) ? 2 : 1;
+      uint32_t per_cu = ((lds_bytes + mrg::kStageBytes) * 2 <= 160 * 1024) ? 2 : 1;
       grid = (uint32_t)ctx->n_cu * per_cu;
     } else {
       grid = (uint32_t)ctx->n_cu * (uint32_t)ctx->blocks_per_cu_global;
     }
     ctx->last_lds[i] = lds_bytes;
-    if (n) HIP_TRY(mrg::launch_match(p, words_per_read, lds_mode, grid, lds_bytes, stream));
+    if (n) HIP_TRY(mrg::launch_match(p, words_per_read, lds_mode, grid, lds_bytes + mrg::kStageBytes, stream));
     HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
   }
   if (d_pass_counts) HIP_TRY(mrg::launch_export_pass_counts(stats, n_pass, d_pass_counts, stream));

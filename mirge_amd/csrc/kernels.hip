@@ -134,7 +134,16 @@ match_kernel(const MatchParams p) {
     uint4* dst = reinterpret_cast<uint4*>(smem + blk_words);
     for (uint32_t i = threadIdx.x; i < p.text_words / 4; i += BLOCK) dst[i] = src[i];
   }
-  if (LDSI || LDST) __syncthreads();
+
+  // survivor staging ring (kStageCap entries) + per-wave counts (two parities) + the
+  // reserved global base; sits after the library
+  const uint32_t lib_words = (LDSI ? blk_words : 0u) + (LDST ? p.text_words : 0u);
+  uint32_t* stage = smem + lib_words;
+  uint32_t* stage_ctl = stage + kStageCap;
+  __syncthreads();
+  // block-uniform ring cursors: [ring_head, ring_tail) is staged but not yet in HBM
+  uint32_t ring_head = 0, ring_tail = 0, iter = 0;
+  const uint32_t wave = threadIdx.x >> 6;
 
   Lib<LDSI, LDST> lib;
   lib.gblocks = p.blocks;
@@ -157,21 +166,21 @@ match_kernel(const MatchParams p) {
     uint32_t r = 0;
     uint64_t rd[W], nm[W];
     uint32_t L0 = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) rd[k] = nm[k] = 0ull;
     if (active) {
       r = p.idx_in ? p.idx_in[t] : t;
       L0 = p.lens[r];
+    }
+    // ---- which reads this pass's FASTA would contain (RAP:543-554, 664-686) ----
+    bool eligible = active && (int32_t)L0 >= p.min_len && (int32_t)L0 <= p.max_len;
+    if (eligible) {
 #pragma unroll
       for (int k = 0; k < W; ++k) {
         rd[k] = p.reads[(size_t)k * p.n_total + r];
         nm[k] = p.nmask ? p.nmask[(size_t)k * p.n_total + r] : 0ull;
       }
-    } else {
-#pragma unroll
-      for (int k = 0; k < W; ++k) rd[k] = nm[k] = 0ull;
     }
-
-    // ---- which reads this pass's FASTA would contain (RAP:543-554, 664-686) ----
-    bool eligible = active && (int32_t)L0 >= p.min_len && (int32_t)L0 <= p.max_len;
     int32_t L = (int32_t)L0;
     if (p.poly_t) {
       // number of trailing T (code 3); an N base is never a T
@@ -259,16 +268,47 @@ match_kernel(const MatchParams p) {
       p.mm[r] = (uint8_t)(best >> 32);
     }
 
-    // ---- survivors of this pass feed the next one (wave-aggregated append) ----
+    // ---- survivors of this pass feed the next one ----
+    // A single global counter takes ~11 ns per atomic whatever the data, so the
+    // append is staged: per iteration every wave publishes its survivor count in
+    // LDS (no atomics), all threads derive the same ring offsets from the 16
+    // counts, and the ring is flushed with ONE global atomic per ~3K survivors.
     if (p.idx_out) {
       const bool survive = active && !aligned;
       const uint64_t mask = __ballot(survive);
-      if (mask) {
-        uint32_t wbase = 0;
-        if (lane == 0) wbase = atomicAdd(p.n_out, (uint32_t)__popcll(mask));
-        wbase = __shfl(wbase, 0, 64);
-        if (survive) p.idx_out[wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = r;
+      uint32_t* wc = stage_ctl + (iter & 1u) * kMaxWaves;
+      if (lane == 0) wc[wave] = (uint32_t)__popcll(mask);
+      __syncthreads();
+      uint32_t my_off = 0, total = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < BLOCK / 64; ++w) {
+        const uint32_t c = wc[w];
+        my_off += (w < wave) ? c : 0u;
+        total += c;
       }
+      if (survive)
+        stage[(ring_tail + my_off + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))) &
+              (kStageCap - 1)] = r;
+      ring_tail += total;
+      if (ring_tail - ring_head > kStageCap - BLOCK) {
+        if (threadIdx.x == 0) stage_ctl[2 * kMaxWaves] = atomicAdd(p.n_out, ring_tail - ring_head);
+        __syncthreads();
+        const uint32_t gbase = stage_ctl[2 * kMaxWaves];
+        for (uint32_t i = ring_head + threadIdx.x; (int32_t)(ring_tail - i) > 0; i += BLOCK)
+          p.idx_out[gbase + (i - ring_head)] = stage[i & (kStageCap - 1)];
+        ring_head = ring_tail;
+      }
+      ++iter;
+    }
+  }
+  if (p.idx_out) {
+    __syncthreads();
+    if (ring_tail != ring_head) {
+      if (threadIdx.x == 0) stage_ctl[2 * kMaxWaves] = atomicAdd(p.n_out, ring_tail - ring_head);
+      __syncthreads();
+      const uint32_t gbase = stage_ctl[2 * kMaxWaves];
+      for (uint32_t i = ring_head + threadIdx.x; (int32_t)(ring_tail - i) > 0; i += BLOCK)
+        p.idx_out[gbase + (i - ring_head)] = stage[i & (kStageCap - 1)];
     }
   }
 
@@ -361,7 +401,7 @@ static hipError_t launch_match_w(const MatchParams& p, int lds_mode, uint32_t gr
   switch (lds_mode) {
     case 2: return launch_match_t<W, true, true>(p, grid, lds_bytes, stream);
     case 1: return launch_match_t<W, true, false>(p, grid, lds_bytes, stream);
-    default: return launch_match_t<W, false, false>(p, grid, 0, stream);
+    default: return launch_match_t<W, false, false>(p, grid, lds_bytes, stream);
   }
 }
 

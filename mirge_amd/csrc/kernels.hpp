@@ -14,6 +14,11 @@ struct MatchBlock {
   static constexpr uint32_t kThreads = LDSI ? 1024u : 256u;
 };
 constexpr uint32_t kTallyThreads = 1024u;
+// Survivor staging ring per match workgroup (power of two) + control words
+// (2 x kMaxWaves per-wave counts, 1 reserved global base, padding).
+constexpr uint32_t kStageCap = 4096u;
+constexpr uint32_t kMaxWaves = 16u;
+constexpr uint32_t kStageBytes = (kStageCap + 2u * kMaxWaves + 4u) * 4u;
 
 struct MatchParams {
   // library (device pointers)
