@@ -36,9 +36,12 @@ def codes_to_str(codes):
 class SynthLibraries:
     """libs[key] = (names, seqs); codes[key] = (concatenated uint8 codes, starts)."""
 
-    def __init__(self, seed=20181, scale=1.0, n_paralogs=60, n_snp=120):
+    def __init__(self, seed=20181, scale=1.0, n_paralogs=60, n_snp=120, shapes=None):
         rng = np.random.default_rng(seed)
         self.libs, self.codes = {}, {}
+        FULL_SHAPES = dict(globals()["FULL_SHAPES"])
+        if shapes:
+            FULL_SHAPES.update(shapes)
 
         def sc(n, lo=4):
             return max(lo, int(round(n * scale)))

@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the REFERENCE's own Python for everything around
+the aligner (run only in the build container; /root/reference is read here and
+nowhere else).
+
+What it does
+  1. copies /root/reference/src/mirge to a scratch dir OUTSIDE the repo, strips
+     CRLF and converts the Python-2 hot-path modules with the stdlib lib2to3
+     (SURVEY.md Appendix A);
+  2. stubs Biopython (absent from the image; only SeqIO.parse is reached);
+  3. puts stand-in `bowtie` / `bowtie-inspect` executables in a scratch bin dir.
+     bowtie 1 itself is unavailable, so the stand-in answers each invocation with
+     oracle/bowtie_model.c (exhaustive scan of bowtie's published rules) in the
+     argv / SAM / stderr-log shape the reference parses
+     (runAnnotationPipeline.py:9-28);  with `-a` it lists the best-stratum
+     alignments so that the LAST line -- the one parseAlignment keeps (:27) -- is
+     the lowest (entry, offset), the product's documented tie rule;
+  4. runs quantReads -> runAnnotationPipeline -> summarize -> miRNAmerge -> filter
+     from the reference on a small seeded world and writes inputs + resulting
+     seqDic / mirDic / logDic to tests/golden/cascade_small.json.
+
+Nothing from the reference (source, converted source, bytecode) is written into
+the repository: only data.
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/src/mirge"
+HOT = ["runAnnotationPipeline", "summarize", "miRNAmerge", "filter", "quantReads",
+       "writeDataToCSV", "extractPreMiRName", "parseArgument"]
+
+BOWTIE_STANDIN = r'''#!/usr/bin/env python3
+import os, sys
+sys.path.insert(0, %(root)r)
+from oracle import model
+
+def main():
+    argv = sys.argv[1:]
+    prog = os.path.basename(sys.argv[0])
+    if prog == "bowtie-inspect":
+        names_only = "-n" in argv
+        prefix = [a for a in argv if not a.startswith("-")][0]
+        lib = model.Library.from_fasta(prefix + ".fa")
+        for n, s in zip(lib.names, lib.seqs):
+            sys.stdout.write(n + "\n" if names_only else ">%%s\n%%s\n" %% (n, s))
+        return 0
+    mode, mm, t5, t3, all_best = "n", 2, 0, 0, False
+    pos = []
+    i = 0
+    while i < len(argv):
+        a = argv[i]
+        if a in ("--threads", "-n", "-v", "-5", "-3"):
+            v = int(argv[i + 1]); i += 2
+            if a == "-n": mode, mm = "n", v
+            elif a == "-v": mode, mm = "v", v
+            elif a == "-5": t5 = v
+            elif a == "-3": t3 = v
+            continue
+        if a == "-a": all_best = True
+        elif a.startswith("-"): pass          # -f --norc -S --best --strata --phred64-quals
+        else: pos.append(a)
+        i += 1
+    prefix, fasta = pos[0], pos[1]
+    lib = model.Library.from_fasta(prefix + ".fa")
+    reads = [l.strip() for l in open(fasta) if l.strip() and l[0] != ">"]
+    seed_len, mm_seed, mm_total = (28, mm, 2) if mode == "n" else (1 << 20, mm, mm)
+    trimmed = [r[t5:len(r) - t3] if t3 else r[t5:] for r in reads]
+    ref, p0, nm = model.align_batch(lib, trimmed, seed_len, mm_seed, mm_total)
+    out = sys.stdout
+    for n in lib.names:
+        out.write("@SQ\tSN:%%s\tLN:1\n" %% n)
+    aligned = 0
+    for k, r in enumerate(reads):
+        qual = "I" * len(trimmed[k])
+        if ref[k] < 0:
+            out.write("%%s\t4\t*\t0\t0\t*\t*\t0\t0\t%%s\t%%s\tXM:i:0\n" %% (r, trimmed[k], qual))
+            continue
+        aligned += 1
+        hits = [(int(ref[k]), int(p0[k]))]
+        if all_best:
+            hits, _ = model.align_all_best(lib, trimmed[k], seed_len, mm_seed, mm_total)
+            hits = hits[::-1]                 # last line = lowest (entry, offset)
+        for (e, o) in hits:
+            out.write("%%s\t0\t%%s\t%%d\t255\t%%dM\t*\t0\t0\t%%s\t%%s\tXA:i:%%d\tNM:i:%%d\n" %%
+                      (r, lib.names[e], o + 1, len(trimmed[k]), trimmed[k], qual, nm[k], nm[k]))
+    sys.stderr.write("# reads processed: %%d\n" %% len(reads))
+    pct = 100.0 * aligned / max(1, len(reads))
+    sys.stderr.write("# reads with at least one reported alignment: %%d (%%.2f%%%%)\n" %% (aligned, pct))
+    sys.stderr.write("# reads that failed to align: %%d (%%.2f%%%%)\n" %% (len(reads) - aligned, 100 - pct))
+    return 0
+
+sys.exit(main())
+'''
+
+SHAPES = {"mirna": 70, "hairpin": (40, 60, 110), "mature_trna": (10, 72, 76), "pre_trna": (12, 25, 60),
+          "snorna": (10, 70, 200), "rrna": [121, 157, 400], "ncrna_others": (30, 100, 300),
+          "mrna": (30, 300, 800)}
+
+
+def stub_bio():
+    bio = types.ModuleType("Bio")
+    seqio = types.ModuleType("Bio.SeqIO")
+    seqm = types.ModuleType("Bio.Seq")
+    pw = types.ModuleType("Bio.pairwise2")
+    alpha = types.ModuleType("Bio.Alphabet")
+
+    class Rec(object):
+        def __init__(self, i, s):
+            self.id, self.seq = i, s
+
+    def parse(path, fmt):
+        name, chunks = None, []
+        for line in open(path):
+            line = line.strip()
+            if line.startswith(">"):
+                if name is not None:
+                    yield Rec(name, "".join(chunks))
+                name, chunks = line[1:].split()[0], []
+            elif line:
+                chunks.append(line)
+        if name is not None:
+            yield Rec(name, "".join(chunks))
+
+    seqio.parse = parse
+    seqm.Seq = object
+    alpha.IUPAC = None
+    alpha.Gapped = None
+    bio.SeqIO, bio.pairwise2, bio.Seq, bio.Alphabet = seqio, pw, seqm, alpha
+    for m in (bio, seqio, seqm, pw, alpha):
+        sys.modules[m.__name__] = m
+
+
+def build_world():
+    import numpy as np
+    from mirge_amd import synth
+    libs = synth.SynthLibraries(seed=77, scale=1.0, n_paralogs=6, n_snp=8, shapes=SHAPES)
+    rng = np.random.default_rng(5)
+    samples = []
+    for si in range(2):
+        codes = synth.synth_reads(libs, 1400, seed=900 + si, zipf_s=1.3)
+        reads = [synth.codes_to_str(c) for c in codes]
+        # variable-length reads: hairpin (>25 nt, pass 1), miRNA arms +-, N-containing, poly-T trailers
+        for _ in range(260):
+            key = ["hairpin", "hairpin", "mirna", "ncrna_others", "pre_trna", "mrna"][int(rng.integers(0, 6))]
+            seqs = libs.libs[key][1]
+            s = seqs[int(rng.integers(0, len(seqs)))]
+            ln = int(rng.integers(16, 41))
+            if len(s) < ln:
+                continue
+            o = int(rng.integers(0, len(s) - ln + 1))
+            r = list(s[o:o + ln])
+            for _ in range(int(rng.integers(0, 3))):
+                r[int(rng.integers(0, ln))] = "ACGTN"[int(rng.integers(0, 5))]
+            if key == "pre_trna" or rng.random() < 0.1:
+                r += list("T" * int(rng.integers(3, 7)))
+            reads.append("".join(r))
+        samples.append(reads)
+    return libs, samples
+
+
+def main():
+    scratch = tempfile.mkdtemp(prefix="mirge_golden_")
+    try:
+        pkg = os.path.join(scratch, "mirge")
+        shutil.copytree(REF, pkg)
+        subprocess.run(["chmod", "-R", "u+w", pkg], check=True)
+        for dp, _, fns in os.walk(pkg):
+            for fn in fns:
+                if fn.endswith(".py"):
+                    p = os.path.join(dp, fn)
+                    data = open(p, "rb").read().replace(b"\r\n", b"\n")
+                    open(p, "wb").write(data)
+        subprocess.run([sys.executable, "-m", "lib2to3", "-w", "-n"] +
+                       [os.path.join(pkg, "utils", m + ".py") for m in HOT],
+                       check=True, capture_output=True)
+        bindir = os.path.join(scratch, "bin")
+        os.makedirs(bindir)
+        for prog in ("bowtie", "bowtie-inspect"):
+            p = os.path.join(bindir, prog)
+            open(p, "w").write(BOWTIE_STANDIN % {"root": ROOT})
+            os.chmod(p, 0o755)
+
+        libs, samples = build_world()
+        libroot = os.path.join(scratch, "libs")
+        prefix = libs.write_layout(libroot, species="syn", db="miRBase")
+        outdir = os.path.join(scratch, "out")
+        os.makedirs(outdir)
+
+        stub_bio()
+        sys.path.insert(0, scratch)
+        from mirge.utils.quantReads import quantReads
+        from mirge.utils.runAnnotationPipeline import runAnnotationPipeline
+        from mirge.utils.summarize import summarize
+        from mirge.utils.miRNAmerge import miRNAmerge
+        from mirge.utils.filter import filter as ref_filter
+        import copy
+
+        sample_list = ["s0.fastq", "s1.fastq"]
+        seq_dic, len_dic = {}, {}
+        for si, reads in enumerate(samples):
+            fq = os.path.join(outdir, "s%d.trim.fastq" % si)
+            with open(fq, "w") as fh:
+                for k, r in enumerate(reads):
+                    fh.write("@r%d\n%s\n+\n%s\n" % (k, r, "I" * len(r)))
+            quantReads(fq, seq_dic, len_dic, 2, si, sample_list, False, False)
+        log_dic = {"quantStats": [{"filename": s} for s in sample_list], "annotStats": []}
+        annot_names = ["exact miRNA", "hairpin miRNA", "mature tRNA", "primary tRNA", "snoRNA", "rRNA",
+                       "ncrna others", "mRNA", "isomiR miRNA"]
+        ix = lambda k: prefix + k
+        runAnnotationPipeline(bindir, seq_dic, "1", False, annot_names, outdir, log_dic,
+                              ix("mirna_miRBase"), ix("hairpin_miRBase"), ix("mature_trna"), ix("pre_trna"),
+                              ix("snorna"), ix("rrna"), ix("ncrna_others"), ix("mrna"), False, None, False,
+                              None, None, "miRBase", False, None, None, sample_list)
+        mir_dic = {}
+        summarize(seq_dic, sample_list, log_dic, mir_dic, ix("mirna_miRBase"), outdir, False, bindir)
+        after_sum = copy.deepcopy(mir_dic)
+        qs_after_sum = copy.deepcopy(log_dic["quantStats"])
+        name_seq = {}
+        merge_file = os.path.join(libroot, "syn", "annotation.Libs", "syn_merges_miRBase.csv")
+        mirna_fa = os.path.join(libroot, "syn", "fasta.Libs", "syn_mirna_SNP_pseudo_miRBase.fa")
+        miRNAmerge(merge_file, sample_list, mir_dic, mirna_fa, name_seq)
+        after_merge = copy.deepcopy(mir_dic)
+        ref_filter(mir_dic, sample_list, log_dic, "0.1")
+
+        golden = {
+            "about": "captured from the reference's Python (lib2to3 scratch copy) by tests/golden/make_golden.py; "
+                     "aligner = oracle/bowtie_model.c stand-in (parity unpinned vs real bowtie)",
+            "libraries": {k: [list(v[0]), list(v[1])] for k, v in libs.libs.items()},
+            "merges": libs.merges,
+            "samples": samples,
+            "sample_list": sample_list,
+            "cano_ratio": "0.1",
+            "expected": {
+                "seqDic": {s: {"quant": r["quant"], "annot": r["annot"], "length": r["length"]}
+                           for s, r in seq_dic.items()},
+                "readLengthDic": {str(k): v for k, v in len_dic.items()},
+                "annotStats": [{"readsProcessed": a["readsProcessed"], "readsAligned": a["readsAligned"]}
+                               for a in log_dic["annotStats"]],
+                "mirDic_after_summarize": after_sum,
+                "quantStats_after_summarize": [{k: v for k, v in q.items() if k != "filename"}
+                                               for q in qs_after_sum],
+                "mirDic_after_merge": after_merge,
+                "mirNameSeqDic": name_seq,
+                "mirDic_after_filter": mir_dic,
+                "quantStats_after_filter": [{k: v for k, v in q.items() if k != "filename"}
+                                            for q in log_dic["quantStats"]],
+            },
+        }
+        out = os.path.join(ROOT, "tests", "golden", "cascade_small.json")
+        with open(out, "w") as fh:
+            json.dump(golden, fh, separators=(",", ":"), sort_keys=True)
+        print("wrote", out, os.path.getsize(out), "bytes;", len(seq_dic), "unique reads;",
+              "annotStats", golden["expected"]["annotStats"])
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

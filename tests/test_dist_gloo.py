@@ -1,0 +1,92 @@
+"""Multi-process path on CPU (gloo, world_size 2): sharding + the single fused
+all-reduce of mirge_amd.dist give the same count vector as one process, and
+`filter` applied AFTER the reduce equals `filter` on the whole read set
+(it is non-linear, filter.py:7-13, so it must not run per shard)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import model
+from tests.util import World
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world_size, port, payload, out_path):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world_size),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from mirge_amd import dist as mdist
+    r, _, w = mdist.init_process_group("gloo")
+    assert (r, w) == (rank, world_size)
+    pass_id, ref_id, quant, M, n_pass, stats_by_rank = payload
+    lo, hi = mdist.shard_bounds(len(pass_id), rank, world_size)
+    fused, ln = mdist.fused_buffer(None, n_mirna=M, n_samples=quant.shape[1], n_pass=n_pass)
+    local = model.tally(pass_id[lo:hi], ref_id[lo:hi], quant[lo:hi], M, n_pass, 0, 8)
+    fused[:ln] = torch.from_numpy(local.astype(np.int64))
+    fused[ln:] = torch.from_numpy(stats_by_rank[rank].astype(np.int64))
+    mdist.allreduce_counts(fused)
+    if rank == 0:
+        np.save(out_path, fused.numpy())
+    torch.distributed.destroy_process_group()
+
+
+def test_shard_bounds_cover_everything():
+    from mirge_amd.dist import shard_bounds
+    for n in (0, 1, 7, 100, 101):
+        for w in (1, 2, 3, 8):
+            cuts = [shard_bounds(n, r, w) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in cuts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_allreduce_equals_single_process(native_lib, oracle_lib, tmp_path):
+    from mirge_amd import synth
+    from mirge_amd.engine import split_counts
+    world = World(scale=0.02, n_fixed=4000, n_var=300)
+    ref = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask)
+    n = len(world.lens)
+    quant = synth.synth_quant(n, n_samples=2)
+    M, n_pass = world.n_mirna, 9
+    # per-rank per-pass (processed, aligned): rerun the port on each shard
+    from mirge_amd.dist import shard_bounds
+    stats = []
+    for r in range(2):
+        lo, hi = shard_bounds(n, r, 2)
+        nm = None if world.nmask is None else world.nmask[:, lo:hi]
+        part = model.fm_cascade(world.views, world.passes, world.words[:, lo:hi], world.lens[lo:hi], nm)
+        assert np.array_equal(part["pass_id"], ref["pass_id"][lo:hi])  # a read's outcome is local
+        stats.append(part["stats"][:, :2].reshape(-1))
+    out = str(tmp_path / "fused.npy")
+    mp.spawn(_worker, args=(2, _free_port(), (ref["pass_id"], ref["ref_id"], quant, M, n_pass, stats), out),
+             nprocs=2, join=True)
+    fused = np.load(out)
+    whole = model.tally(ref["pass_id"], ref["ref_id"], quant, M, n_pass, 0, 8)
+    ln = len(whole)
+    assert np.array_equal(fused[:ln].astype(np.uint64), whole)
+    assert np.array_equal(fused[ln:], ref["stats"][:, :2].reshape(-1).astype(np.int64))
+
+    # filter after the reduce == filter on the whole set; per-shard filtering differs
+    from mirge_amd import annotate
+    names = world.index["mirna"].names
+
+    def to_dic(counts):
+        q, c, _, _ = split_counts(counts, M, 2, n_pass)
+        return {nm_: {"quant": [int(x) for x in q[i]], "iscan": [int(x) for x in c[i]]}
+                for i, nm_ in enumerate(names)}
+    a, b = to_dic(fused[:ln]), to_dic(whole)
+    la, lb = {"quantStats": [{}, {}]}, {"quantStats": [{}, {}]}
+    annotate.filter(a, ["s0", "s1"], la, "0.1")
+    annotate.filter(b, ["s0", "s1"], lb, "0.1")
+    assert a == b and la == lb

@@ -1,0 +1,69 @@
+"""GPU (-m gpu): the product's reference-shaped host API
+(mirge_amd.annotate.runAnnotationPipeline / summarize / miRNAmerge / filter)
+reproduces the vectors captured from the reference's own Python."""
+import copy
+import json
+import os
+
+import pytest
+
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(ROOT, "tests", "golden", "cascade_small.json")) as fh:
+        return json.load(fh)
+
+
+def test_reference_shaped_pipeline_matches_golden(golden, native_lib, tmp_path):
+    from mirge_amd import annotate
+    from mirge_amd.engine import Engine
+    exp = golden["expected"]
+    ixdir = tmp_path / "index.Libs"
+    ixdir.mkdir()
+    fname = {"mirna": "mirna_miRBase", "hairpin": "hairpin_miRBase"}
+    prefix = {}
+    for key, (names, seqs) in golden["libraries"].items():
+        prefix[key] = str(ixdir / ("syn_" + fname.get(key, key)))
+        with open(prefix[key] + ".fa", "w") as fh:
+            for n, s in zip(names, seqs):
+                fh.write(">%s\n%s\n" % (n, s))
+    names, seqs = golden["libraries"]["mirna"]
+    fa = tmp_path / "mirna_SNP_pseudo.fa"
+    fa.write_text("".join(">%s\n%s\n" % (n, s[2:-6]) for n, s in zip(names, seqs)))
+    merges = tmp_path / "merges.csv"
+    merges.write_text("".join(l + "\n" for l in golden["merges"]))
+
+    sample_list = golden["sample_list"]
+    seq_dic, len_dic = {}, {}
+    for si, reads in enumerate(golden["samples"]):
+        annotate.quantReads(reads, seq_dic, len_dic, len(sample_list), si)
+    log_dic = {"quantStats": [{} for _ in sample_list], "annotStats": []}
+    eng = Engine(0)
+    annot_names = ["exact miRNA", "hairpin miRNA", "mature tRNA", "primary tRNA", "snoRNA", "rRNA",
+                   "ncrna others", "mRNA", "isomiR miRNA"]
+    annotate.runAnnotationPipeline(
+        eng, seq_dic, "1", False, annot_names, str(tmp_path), log_dic, prefix["mirna"],
+        prefix["hairpin"], prefix["mature_trna"], prefix["pre_trna"], prefix["snorna"], prefix["rrna"],
+        prefix["ncrna_others"], prefix["mrna"], False, None, False, None, None, "miRBase", False, None,
+        None, sample_list)
+    assert set(seq_dic) == set(exp["seqDic"])
+    for s, rec in seq_dic.items():
+        assert rec["annot"] == exp["seqDic"][s]["annot"], s
+        assert rec["quant"] == exp["seqDic"][s]["quant"]
+    got_stats = [{k: a[k] for k in ("readsProcessed", "readsAligned")} for a in log_dic["annotStats"]]
+    assert got_stats == exp["annotStats"]
+
+    mir_dic = {}
+    annotate.summarize(seq_dic, sample_list, log_dic, mir_dic, prefix["mirna"], str(tmp_path), False, eng)
+    assert mir_dic == exp["mirDic_after_summarize"]
+    assert log_dic["quantStats"] == exp["quantStats_after_summarize"]
+    name_seq = {}
+    annotate.miRNAmerge(str(merges), sample_list, mir_dic, str(fa), name_seq)
+    assert mir_dic == exp["mirDic_after_merge"]
+    annotate.filter(mir_dic, sample_list, log_dic, golden["cano_ratio"])
+    assert mir_dic == exp["mirDic_after_filter"]
+    assert log_dic["quantStats"] == exp["quantStats_after_filter"]
