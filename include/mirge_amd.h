@@ -78,12 +78,13 @@ typedef struct mrg_index_info {
   uint32_t n_ref;      /* library entries (histogram bins for the miRNA lib) */
   uint32_t n_seg;      /* N-free segments */
   uint32_t n_bases;    /* concatenated text length (without sentinel) */
-  uint32_t n_blocks;   /* 32-byte occ blocks (64 BWT symbols each) */
+  uint32_t n_blocks;   /* 16-byte occ blocks (32 BWT symbols each) */
+  uint32_t n_super;    /* superblocks (65536 BWT symbols each), 4 words each */
   uint32_t primary;    /* BWT row holding the sentinel */
   uint32_t text_words; /* 2-bit packed text, 32-bit words incl. padding */
   uint32_t C[4];       /* first BWT row of each symbol */
-  uint64_t bytes_fm;   /* n_blocks * 32 */
-  uint64_t bytes_sa;   /* (n_bases + 1) * 4 */
+  uint64_t bytes_fm;   /* n_blocks * 16 + n_super * 16 */
+  uint64_t bytes_sa;   /* (n_bases + 1) * 8 */
 } mrg_index_info;
 
 int mrg_index_get_info(const mrg_index *ix, mrg_index_info *info);
@@ -95,9 +96,10 @@ int mrg_index_seq(const mrg_index *ix, uint32_t i, char *buf, uint32_t cap,
 
 /* Raw views for tests and the oracle's CPU port (read-only, index lifetime). */
 typedef struct mrg_index_view {
-  const uint32_t *blocks;    /* n_blocks * 8 words: cnt[4], lo(2), hi(2) */
+  const uint32_t *blocks;    /* n_blocks * 4 words: cnt[4] as uint16, lo, hi */
+  const uint32_t *super;     /* n_super * 4 words: C[c] + count before the superblock */
   const uint32_t *text;      /* text_words */
-  const uint32_t *sa;        /* n_bases + 1 */
+  const uint64_t *sa;        /* n_bases + 1 rows: pos | before<<32 | after<<40 | seg<<48 */
   const uint32_t *seg_start; /* n_seg + 1 */
   const uint32_t *seg_ref;   /* n_seg */
   const uint32_t *seg_off;   /* n_seg */

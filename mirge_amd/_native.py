@@ -35,13 +35,15 @@ class PassStats(C.Structure):
 
 class IndexInfo(C.Structure):
     _fields_ = [("n_ref", C.c_uint32), ("n_seg", C.c_uint32), ("n_bases", C.c_uint32),
-                ("n_blocks", C.c_uint32), ("primary", C.c_uint32), ("text_words", C.c_uint32),
+                ("n_blocks", C.c_uint32), ("n_super", C.c_uint32), ("primary", C.c_uint32),
+                ("text_words", C.c_uint32),
                 ("C", C.c_uint32 * 4), ("bytes_fm", C.c_uint64), ("bytes_sa", C.c_uint64)]
 
 
 class IndexView(C.Structure):
-    _fields_ = [(k, C.POINTER(C.c_uint32)) for k in
-                ("blocks", "text", "sa", "seg_start", "seg_ref", "seg_off", "chunk_seg")]
+    _fields_ = [("blocks", C.POINTER(C.c_uint32)), ("super", C.POINTER(C.c_uint32)),
+                ("text", C.POINTER(C.c_uint32)), ("sa", C.POINTER(C.c_uint64))] + \
+               [(k, C.POINTER(C.c_uint32)) for k in ("seg_start", "seg_ref", "seg_off", "chunk_seg")]
 
 
 # name -> (restype, argtypes); every symbol include/mirge_amd.h declares

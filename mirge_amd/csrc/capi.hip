@@ -41,10 +41,10 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 struct DevLib {
-  uint32_t *blocks = nullptr, *text = nullptr, *sa = nullptr, *seg_start = nullptr,
+  uint32_t *blocks = nullptr, *super = nullptr, *text = nullptr, *seg_start = nullptr,
            *seg_ref = nullptr, *seg_off = nullptr, *chunk_seg = nullptr;
-  uint32_t n = 0, nblk = 0, primary = 0, text_words = 0, n_seg = 0, n_ref = 0;
-  uint32_t C[4] = {0, 0, 0, 0};
+  uint64_t* sa = nullptr;
+  uint32_t n = 0, nblk = 0, nsup = 0, primary = 0, text_words = 0, n_seg = 0, n_ref = 0;
 };
 
 template <class T>
@@ -69,7 +69,6 @@ struct mrg_ctx {
   std::string arch;
   int64_t lds_budget = 160 * 1024;
   int64_t wstop = 0;
-  int64_t blocks_per_cu_global = 8;
   std::vector<DevLib> libs;
   // last run
   hipStream_t last_stream = nullptr;
@@ -153,11 +152,12 @@ int mrg_index_get_info(const mrg_index* h, mrg_index_info* info) {
   info->n_seg = (uint32_t)ix.seg_ref.size();
   info->n_bases = ix.n;
   info->n_blocks = (uint32_t)ix.blocks.size();
+  info->n_super = (uint32_t)(ix.super.size() / 4);
   info->primary = ix.primary;
   info->text_words = (uint32_t)ix.text.size();
   for (int c = 0; c < 4; ++c) info->C[c] = ix.C[c];
-  info->bytes_fm = (uint64_t)ix.blocks.size() * 32;
-  info->bytes_sa = (uint64_t)ix.sa.size() * 4;
+  info->bytes_fm = (uint64_t)ix.blocks.size() * 16 + (uint64_t)ix.super.size() * 4;
+  info->bytes_sa = (uint64_t)ix.sa.size() * 8;
   return MRG_OK;
 }
 
@@ -183,6 +183,7 @@ int mrg_index_get_view(const mrg_index* h, mrg_index_view* v) {
   if (!h || !v) return fail(MRG_ERR_ARG, "mrg_index_get_view: null argument");
   const mrg::FmIndex& ix = h->ix;
   v->blocks = reinterpret_cast<const uint32_t*>(ix.blocks.data());
+  v->super = ix.super.data();
   v->text = ix.text.data();
   v->sa = ix.sa.data();
   v->seg_start = ix.seg_start.data();
@@ -225,6 +226,7 @@ void mrg_ctx_destroy(mrg_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   for (DevLib& l : ctx->libs) {
     (void)hipFree(l.blocks);
+    (void)hipFree(l.super);
     (void)hipFree(l.text);
     (void)hipFree(l.sa);
     (void)hipFree(l.seg_start);
@@ -247,11 +249,12 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
   l.primary = ix.primary;
   l.n_seg = (uint32_t)ix.seg_ref.size();
   l.n_ref = (uint32_t)ix.names.size();
-  for (int c = 0; c < 4; ++c) l.C[c] = ix.C[c];
+  l.nsup = (uint32_t)(ix.super.size() / 4);
   std::vector<uint32_t> blk(reinterpret_cast<const uint32_t*>(ix.blocks.data()),
-                            reinterpret_cast<const uint32_t*>(ix.blocks.data()) + ix.blocks.size() * 8);
+                            reinterpret_cast<const uint32_t*>(ix.blocks.data()) + ix.blocks.size() * 4);
   int rc;
   if ((rc = upload(&l.blocks, blk, 4))) return rc;
+  if ((rc = upload(&l.super, ix.super, 4))) return rc;
   // text is staged into LDS 16 B at a time: round its word count up to 4
   l.text_words = (uint32_t)((ix.text.size() + 3) / 4 * 4);
   if ((rc = upload(&l.text, ix.text, 4))) return rc;
@@ -274,9 +277,6 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "wstop") {
     if (value < 0) return fail(MRG_ERR_ARG, "wstop must be >= 0");
     ctx->wstop = value;
-  } else if (k == "blocks_per_cu_global") {
-    if (value < 1 || value > 8) return fail(MRG_ERR_ARG, "blocks_per_cu_global must be in [1,8]");
-    ctx->blocks_per_cu_global = value;
   } else {
     return fail(MRG_ERR_ARG, "mrg_ctx_set_option: unknown key '%s'", key);
   }
@@ -358,6 +358,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     const DevLib& l = ctx->libs[c.lib];
     mrg::MatchParams p;
     p.blocks = l.blocks;
+    p.super = l.super;
     p.text = l.text;
     p.sa = l.sa;
     p.seg_start = l.seg_start;
@@ -366,9 +367,10 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     p.chunk_seg = l.chunk_seg;
     p.n = l.n;
     p.nblk = l.nblk;
+    p.nsup = l.nsup;
     p.primary = l.primary;
     p.text_words = l.text_words;
-    for (int k = 0; k < 4; ++k) p.C[k] = l.C[k];
+    p.simple_segs = (l.n_seg == l.n_ref) ? 1u : 0u;
     p.reads = d_reads;
     p.lens = d_lens;
     p.nmask = d_nmask;
@@ -393,29 +395,40 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     p.pass_index = (int32_t)i;
     p.wstop = (uint32_t)ctx->wstop;
 
-    // residency decision: blocks + text, blocks only, or nothing in LDS
-    const uint64_t blk_bytes = (uint64_t)l.nblk * 32, txt_bytes = (uint64_t)l.text_words * 4;
+    // residency decision: blocks + text, blocks only, or nothing in LDS.  The
+    // superblock table always rides along (16 B per 65536 bp) and the survivor
+    // ring comes on top; prefer a layout that lets two workgroups share a CU.
+    const uint64_t blk_bytes = (uint64_t)l.nblk * 16, txt_bytes = (uint64_t)l.text_words * 4;
+    const uint64_t sup_bytes = (uint64_t)l.nsup * 16;
+    const uint64_t budget = (uint64_t)ctx->lds_budget;
     int lds_mode = 0;
-    uint32_t lds_bytes = 0;  // library bytes staged; the survivor ring comes on top
-    const uint64_t room = ctx->lds_budget > (int64_t)mrg::kStageBytes
-                              ? (uint64_t)ctx->lds_budget - mrg::kStageBytes : 0;
-    if (blk_bytes + txt_bytes <= room) {
+    uint64_t lib_bytes = 0;
+    if (sup_bytes + blk_bytes + txt_bytes + mrg::stage_bytes(mrg::kStageCapMin) <= budget) {
       lds_mode = 2;
-      lds_bytes = (uint32_t)(blk_bytes + txt_bytes);
-    } else if (blk_bytes <= room) {
+      lib_bytes = blk_bytes + txt_bytes;
+    } else if (sup_bytes + blk_bytes + mrg::stage_bytes(mrg::kStageCapMin) <= budget) {
       lds_mode = 1;
-      lds_bytes = (uint32_t)blk_bytes;
+      lib_bytes = blk_bytes;
+    } else if (sup_bytes + mrg::stage_bytes(mrg::kStageCapMin) > budget) {
+      return fail(MRG_ERR_ARG, "mrg_cascade_run: lds_budget %lld cannot hold the %llu-byte superblock "
+                  "table of library %d", (long long)ctx->lds_budget, (unsigned long long)sup_bytes, c.lib);
     }
-    uint32_t grid;
-    if (lds_mode) {
-      // 1024-thread workgroups; two per CU when two staged copies fit
-      uint32_t per_cu = ((lds_bytes + mrg::kStageBytes) * 2 <= 160 * 1024) ? 2 : 1;
-      grid = (uint32_t)ctx->n_cu * per_cu;
-    } else {
-      grid = (uint32_t)ctx->n_cu * (uint32_t)ctx->blocks_per_cu_global;
-    }
+    const uint32_t threads = 1024u;
+    uint32_t stage_cap = mrg::kStageCapMax;
+    const uint64_t fixed = sup_bytes + lib_bytes;
+    // two resident workgroups per CU beat a deeper ring; otherwise take the big ring
+    if ((fixed + mrg::stage_bytes(mrg::kStageCapMax)) * 2 > 160 * 1024 &&
+        (fixed + mrg::stage_bytes(mrg::kStageCapMin)) * 2 <= 160 * 1024)
+      stage_cap = mrg::kStageCapMin;
+    while (stage_cap > mrg::kStageCapMin && fixed + mrg::stage_bytes(stage_cap) > budget) stage_cap >>= 1;
+    if (stage_cap < 2 * threads) stage_cap = 2 * threads;
+    const uint32_t lds_total = (uint32_t)(fixed + mrg::stage_bytes(stage_cap));
+    p.stage_cap = stage_cap;
+    const uint32_t lds_bytes = (uint32_t)lib_bytes;
+    const uint32_t per_cu = (lds_total * 2u <= 160u * 1024u) ? 2u : 1u;
+    const uint32_t grid = (uint32_t)ctx->n_cu * per_cu;
     ctx->last_lds[i] = lds_bytes;
-    if (n) HIP_TRY(mrg::launch_match(p, words_per_read, lds_mode, grid, lds_bytes + mrg::kStageBytes, stream));
+    if (n) HIP_TRY(mrg::launch_match(p, words_per_read, lds_mode, grid, lds_total, stream));
     HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
   }
   if (d_pass_counts) HIP_TRY(mrg::launch_export_pass_counts(stats, n_pass, d_pass_counts, stream));

@@ -173,7 +173,8 @@ static inline int base_code(char ch) {
   }
 }
 
-static void finish_from_codes(const std::vector<uint8_t>& codes, FmIndex& ix) {
+static void finish_from_codes(const std::vector<uint8_t>& codes, FmIndex& ix,
+                              std::vector<uint32_t>& sa32) {
   // codes: text bases 0..3, length n.
   const uint32_t n = (uint32_t)codes.size();
   ix.n = n;
@@ -186,40 +187,49 @@ static void finish_from_codes(const std::vector<uint8_t>& codes, FmIndex& ix) {
     std::vector<int32_t> sa(n + 1);
     Sais<uint8_t> top{t.data(), sa.data(), (int32_t)(n + 1), 5, {}, {}};
     top.run();
-    ix.sa.resize(n + 1);
-    for (uint32_t i = 0; i <= n; ++i) ix.sa[i] = (uint32_t)sa[i];
+    sa32.resize(n + 1);
+    for (uint32_t i = 0; i <= n; ++i) sa32[i] = (uint32_t)sa[i];
   }
 
-  // BWT -> occ blocks
+  // symbol totals first: the superblock entries carry C[c]
+  uint32_t tot[4] = {0, 0, 0, 0};
+  for (uint32_t i = 0; i < n; ++i) ++tot[codes[i]];
+  uint32_t sum = 1;  // row 0 is the sentinel suffix
+  for (int c = 0; c < 4; ++c) {
+    ix.C[c] = sum;
+    sum += tot[c];
+  }
+
+  // BWT -> occ blocks + superblocks
   const uint32_t m = n + 1;
-  const uint32_t nblk = (m >> 6) + 1;
+  const uint32_t nblk = (m >> 5) + 1;
+  const uint32_t nsup = (m >> kSuperShift) + 1;
   ix.blocks.assign(nblk, OccBlock{{0, 0, 0, 0}, 0, 0});
-  uint32_t run[4] = {0, 0, 0, 0};
+  ix.super.assign((size_t)nsup * 4, 0);
+  uint32_t run[4] = {0, 0, 0, 0}, sup_base[4] = {0, 0, 0, 0};
   ix.primary = 0;
-  for (uint32_t i = 0; i < m; ++i) {
-    if ((i & 63) == 0) {
-      OccBlock& b = ix.blocks[i >> 6];
-      for (int c = 0; c < 4; ++c) b.cnt[c] = run[c];
+  for (uint32_t i = 0; i <= m; ++i) {
+    if ((i & ((1u << kSuperShift) - 1)) == 0 && (i >> kSuperShift) < nsup) {
+      for (int c = 0; c < 4; ++c) {
+        sup_base[c] = run[c];
+        ix.super[(size_t)(i >> kSuperShift) * 4 + c] = ix.C[c] + run[c];
+      }
     }
-    uint32_t p = ix.sa[i];
+    if ((i & 31) == 0 && (i >> 5) < nblk) {
+      OccBlock& b = ix.blocks[i >> 5];
+      for (int c = 0; c < 4; ++c) b.cnt[c] = (uint16_t)(run[c] - sup_base[c]);
+    }
+    if (i >= m) break;
+    uint32_t p = sa32[i];
     if (p == 0) {
       ix.primary = i;  // sentinel row: stored as symbol 0, never counted
       continue;
     }
     uint32_t c = codes[p - 1];
-    OccBlock& b = ix.blocks[i >> 6];
-    b.lo |= (uint64_t)(c & 1) << (i & 63);
-    b.hi |= (uint64_t)((c >> 1) & 1) << (i & 63);
+    OccBlock& b = ix.blocks[i >> 5];
+    b.lo |= (uint32_t)(c & 1) << (i & 31);
+    b.hi |= (uint32_t)((c >> 1) & 1) << (i & 31);
     ++run[c];
-  }
-  if ((m & 63) == 0) {
-    OccBlock& b = ix.blocks[m >> 6];
-    for (int c = 0; c < 4; ++c) b.cnt[c] = run[c];
-  }
-  uint32_t sum = 1;  // row 0 is the sentinel suffix
-  for (int c = 0; c < 4; ++c) {
-    ix.C[c] = sum;
-    sum += run[c];
   }
 
   // packed text, padded so a 64-bit window can be read at any base
@@ -271,7 +281,8 @@ void build_index(const std::vector<std::string>& names,
   }
   ix.seg_start.push_back((uint32_t)codes.size());
 
-  finish_from_codes(codes, ix);
+  std::vector<uint32_t> sa32;
+  finish_from_codes(codes, ix, sa32);
 
   // chunk -> segment map for O(1) locate
   const uint32_t nchunk = (ix.n >> 5) + 2;
@@ -282,6 +293,26 @@ void build_index(const std::vector<std::string>& names,
     uint64_t p = (uint64_t)ch << 5;
     while (sgi + 1 < nseg && ix.seg_start[sgi + 1] <= p) ++sgi;
     ix.chunk_seg[ch] = sgi;
+  }
+
+  // 8-byte suffix-array rows: position + distance to both ends of its segment
+  std::vector<uint32_t> seg_of(ix.n);
+  for (uint32_t sg = 0; sg < nseg; ++sg)
+    for (uint32_t p = ix.seg_start[sg]; p < ix.seg_start[sg + 1]; ++p) seg_of[p] = sg;
+  ix.sa.resize(sa32.size());
+  for (size_t i = 0; i < sa32.size(); ++i) {
+    const uint32_t p = sa32[i];
+    uint64_t row = p;
+    if (p < ix.n) {
+      const uint32_t sg = seg_of[p];
+      const uint32_t before = std::min<uint32_t>(255u, p - ix.seg_start[sg]);
+      const uint32_t after = std::min<uint32_t>(255u, ix.seg_start[sg + 1] - p);
+      const uint32_t sid = nseg <= 0xFFFFu ? sg : 0xFFFFu;
+      row |= (uint64_t)before << 32 | (uint64_t)after << 40 | (uint64_t)sid << 48;
+    } else {
+      row |= (uint64_t)0xFFFFu << 48;
+    }
+    ix.sa[i] = row;
   }
 }
 
@@ -302,7 +333,7 @@ std::string entry_sequence(const FmIndex& ix, uint32_t r) {
 // Serialisation ("MRGFM1\0\0" + counts + raw arrays)
 // ---------------------------------------------------------------------------
 namespace {
-const char kMagic[8] = {'M', 'R', 'G', 'F', 'M', '1', 0, 0};
+const char kMagic[8] = {'M', 'R', 'G', 'F', 'M', '2', 0, 0};
 
 template <class T>
 void put_vec(std::ofstream& o, const std::vector<T>& v) {
@@ -336,6 +367,7 @@ void save_index(const FmIndex& ix, const std::string& path) {
   }
   put_vec(o, ix.ref_len);
   put_vec(o, ix.blocks);
+  put_vec(o, ix.super);
   put_vec(o, ix.text);
   put_vec(o, ix.sa);
   put_vec(o, ix.seg_start);
@@ -371,13 +403,15 @@ void load_index(const std::string& path, FmIndex& ix) {
   }
   get_vec(in, ix.ref_len);
   get_vec(in, ix.blocks);
+  get_vec(in, ix.super);
   get_vec(in, ix.text);
   get_vec(in, ix.sa);
   get_vec(in, ix.seg_start);
   get_vec(in, ix.seg_ref);
   get_vec(in, ix.seg_off);
   get_vec(in, ix.chunk_seg);
-  if (ix.sa.size() != (size_t)ix.n + 1 || ix.blocks.size() != (size_t)((ix.n + 1) >> 6) + 1)
+  if (ix.sa.size() != (size_t)ix.n + 1 || ix.blocks.size() != (size_t)((ix.n + 1) >> 5) + 1 ||
+      ix.super.size() != ((size_t)((ix.n + 1) >> kSuperShift) + 1) * 4)
     throw std::runtime_error("index file inconsistent");
 }
 

@@ -6,11 +6,17 @@
 // kernel, not a reader of bowtie's.
 //
 // Layout (all little-endian, what is uploaded to HBM verbatim):
-//   blocks   32 B per 64 BWT symbols: uint32 cnt[4] (symbols before the block,
-//            sentinel excluded), uint64 lo (bit0 plane), uint64 hi (bit1 plane)
+//   blocks   16 B per 32 BWT symbols, so ONE 16-byte load answers a rank query:
+//            uint16 cnt[4] (symbols before the block, relative to its 65536-symbol
+//            superblock, sentinel excluded), uint32 lo (bit0 plane), uint32 hi
+//            (bit1 plane).  Same 0.5 B/bp as the canonical 32 B / 64 bp block.
+//   super    uint32[4] per 65536 BWT symbols: C[c] + symbols c before the superblock
 //   text     2 bits/base, 16 bases per uint32, base p in bits [2(p&15), +1]
-//   sa       full suffix array of text+'$' (sa[0] = n): HBM is 288 GB, so the
-//            locate step is one load instead of a sampled-SA walk
+//   sa       full suffix array of text+'$' (HBM is 288 GB, so locate is one load,
+//            not a sampled-SA walk), 8 B per row: bits 0-31 text position,
+//            32-39 bases back to the start of its N-free segment (clamped 255),
+//            40-47 bases to the end of the segment (clamped 255), 48-63 segment
+//            id (0xFFFF when the library has more segments than that)
 //   seg_*    N-free segments of the entries; an alignment must sit in one
 //   chunk_seg[p>>5] = segment holding text position (p & ~31)
 #pragma once
@@ -21,11 +27,12 @@
 namespace mrg {
 
 struct OccBlock {
-  uint32_t cnt[4];
-  uint64_t lo;
-  uint64_t hi;
+  uint16_t cnt[4];
+  uint32_t lo;
+  uint32_t hi;
 };
-static_assert(sizeof(OccBlock) == 32, "occ block must be 32 bytes");
+static_assert(sizeof(OccBlock) == 16, "occ block must be 16 bytes");
+constexpr uint32_t kSuperShift = 16;  // superblock = 65536 BWT symbols
 
 struct FmIndex {
   std::vector<std::string> names;
@@ -35,8 +42,9 @@ struct FmIndex {
   uint32_t primary = 0;
   uint32_t C[4] = {0, 0, 0, 0};
   std::vector<OccBlock> blocks;
+  std::vector<uint32_t> super;  // 4 per superblock
   std::vector<uint32_t> text;
-  std::vector<uint32_t> sa;
+  std::vector<uint64_t> sa;
   std::vector<uint32_t> seg_start, seg_ref, seg_off, chunk_seg;
 };
 

@@ -38,44 +38,34 @@ __device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
   return v;
 }
 
-// Access to one library, index blocks / text either in LDS or in global memory.
+// Access to one library: occ blocks / text either in LDS or in global memory; the
+// superblock table is always in LDS.
 template <bool LDSI, bool LDST>
 struct Lib {
   const uint32_t* __restrict__ gblocks;
   const uint32_t* __restrict__ gtext;
   const uint32_t* sblocks;  // LDS
   const uint32_t* stext;    // LDS
+  const uint32_t* ssuper;   // LDS
   uint32_t primary;
-  uint32_t C0, C1, C2, C3;
 
-  // first BWT row of symbol c (selects, so nothing is indexed at run time)
-  __device__ __forceinline__ uint32_t first_row(uint32_t c) const {
-    const uint32_t a = (c & 1) ? C1 : C0, b = (c & 1) ? C3 : C2;
-    return (c & 2) ? b : a;
+  __device__ __forceinline__ uint4 block(uint32_t b) const {
+    if (LDSI) return *reinterpret_cast<const uint4*>(sblocks + b * 4);
+    return *reinterpret_cast<const uint4*>(gblocks + (size_t)b * 4);
   }
 
-  __device__ __forceinline__ uint32_t occ(uint32_t c, uint32_t i) const {
-    const uint32_t b = i >> 6, r = i & 63;
-    uint32_t cnt;
-    uint64_t lo, hi;
-    if (LDSI) {
-      const uint32_t* blk = sblocks + b * 8;
-      cnt = blk[c];
-      const uint4 v = *reinterpret_cast<const uint4*>(blk + 4);
-      lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
-      hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
-    } else {
-      const uint32_t* blk = gblocks + (size_t)b * 8;
-      cnt = blk[c];
-      const uint4 v = *reinterpret_cast<const uint4*>(blk + 4);
-      lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
-      hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
-    }
-    uint64_t e = ((c & 1) ? lo : ~lo) & ((c & 2) ? hi : ~hi);
-    e &= (1ull << r) - 1ull;
-    uint32_t o = cnt + (uint32_t)__popcll(e);
+  // first BWT row of the c-suffixes + rank of c before row i, from the block `v`
+  // holding row i (one 16-byte load per query; shared by lo and hi when they sit
+  // in the same block)
+  __device__ __forceinline__ uint32_t lf(uint32_t c, uint32_t i, const uint4& v) const {
+    const uint32_t r = i & 31;
+    const uint32_t pair = (c & 2) ? v.y : v.x;
+    const uint32_t cnt = (c & 1) ? (pair >> 16) : (pair & 0xffffu);
+    uint32_t e = ((c & 1) ? v.z : ~v.z) & ((c & 2) ? v.w : ~v.w);
+    e &= (1u << r) - 1u;
+    uint32_t o = ssuper[(i >> 16) * 4 + c] + cnt + (uint32_t)__popc(e);
     // the sentinel row is stored as symbol 0 inside its own block only
-    o -= (uint32_t)((c == 0) & (i > primary) & (b == (primary >> 6)));
+    o -= (uint32_t)((c == 0) & (i > primary) & ((i >> 5) == (primary >> 5)));
     return o;
   }
 
@@ -117,29 +107,37 @@ __device__ __forceinline__ void shift_out_5p(uint64_t (&rd)[W], uint32_t t) {
 }  // namespace
 
 template <int W, bool LDSI, bool LDST>
-__global__ void __launch_bounds__(MatchBlock<LDSI>::kThreads)
+__global__ void __launch_bounds__(MatchBlock<LDSI>::kThreads, (W == 1 ? 8 : 4))
 match_kernel(const MatchParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   constexpr uint32_t BLOCK = MatchBlock<LDSI>::kThreads;
 
-  // ---- stage the library into LDS (16 B per lane per trip) ----
-  const uint32_t blk_words = p.nblk * 8;
+  // ---- LDS carve: [superblocks][occ blocks][text][survivor ring][ring control] ----
+  const uint32_t sup_words = p.nsup * 4;
+  const uint32_t blk_words = LDSI ? p.nblk * 4 : 0u;
+  const uint32_t txt_words = LDST ? p.text_words : 0u;
+  uint32_t* ssuper = smem;
+  uint32_t* sblocks = ssuper + sup_words;
+  uint32_t* stext = sblocks + blk_words;
+  uint32_t* stage = stext + txt_words;
+  const uint32_t stage_mask = p.stage_cap - 1u;
+  uint32_t* stage_ctl = stage + p.stage_cap;
+  {
+    // 16 B per lane per trip
+    const uint4* src = reinterpret_cast<const uint4*>(p.super);
+    uint4* dst = reinterpret_cast<uint4*>(ssuper);
+    for (uint32_t i = threadIdx.x; i < sup_words / 4; i += BLOCK) dst[i] = src[i];
+  }
   if (LDSI) {
     const uint4* src = reinterpret_cast<const uint4*>(p.blocks);
-    uint4* dst = reinterpret_cast<uint4*>(smem);
+    uint4* dst = reinterpret_cast<uint4*>(sblocks);
     for (uint32_t i = threadIdx.x; i < blk_words / 4; i += BLOCK) dst[i] = src[i];
   }
   if (LDST) {
     const uint4* src = reinterpret_cast<const uint4*>(p.text);
-    uint4* dst = reinterpret_cast<uint4*>(smem + blk_words);
-    for (uint32_t i = threadIdx.x; i < p.text_words / 4; i += BLOCK) dst[i] = src[i];
+    uint4* dst = reinterpret_cast<uint4*>(stext);
+    for (uint32_t i = threadIdx.x; i < txt_words / 4; i += BLOCK) dst[i] = src[i];
   }
-
-  // survivor staging ring (kStageCap entries) + per-wave counts (two parities) + the
-  // reserved global base; sits after the library
-  const uint32_t lib_words = (LDSI ? blk_words : 0u) + (LDST ? p.text_words : 0u);
-  uint32_t* stage = smem + lib_words;
-  uint32_t* stage_ctl = stage + kStageCap;
   __syncthreads();
   // block-uniform ring cursors: [ring_head, ring_tail) is staged but not yet in HBM
   uint32_t ring_head = 0, ring_tail = 0, iter = 0;
@@ -148,17 +146,15 @@ match_kernel(const MatchParams p) {
   Lib<LDSI, LDST> lib;
   lib.gblocks = p.blocks;
   lib.gtext = p.text;
-  lib.sblocks = smem;
-  lib.stext = smem + blk_words;
+  lib.sblocks = sblocks;
+  lib.stext = stext;
+  lib.ssuper = ssuper;
   lib.primary = p.primary;
-  lib.C0 = p.C[0];
-  lib.C1 = p.C[1];
-  lib.C2 = p.C[2];
-  lib.C3 = p.C[3];
 
   const uint32_t n_in = p.idx_in ? *p.n_in : p.n_total;
   const uint32_t lane = threadIdx.x & 63;
-  uint64_t c_processed = 0, c_aligned = 0, c_steps = 0, c_cands = 0;
+  // per-lane tallies (a lane handles a few hundred reads per launch: 32 bits suffice)
+  uint32_t c_processed = 0, c_aligned = 0, c_steps = 0, c_cands = 0;
 
   for (uint32_t base = blockIdx.x * BLOCK; base < n_in; base += gridDim.x * BLOCK) {
     const uint32_t t = base + threadIdx.x;
@@ -201,6 +197,7 @@ match_kernel(const MatchParams p) {
     if (eligible) ++c_processed;
 
     uint64_t best = ~0ull;  // (mm << 32) | text position
+    uint32_t best_seg = 0xFFFFu;
     if (eligible && L > p.max_mm_seed) {
       const int32_t R = min(L, p.seed_len);
       const int32_t K = p.max_mm_seed + 1;
@@ -222,22 +219,27 @@ match_kernel(const MatchParams p) {
         while (j > a && hi > lo && (hi - lo) > p.wstop) {
           --j;
           const uint32_t c = (uint32_t)(pick_word<W>(rd, (uint32_t)j >> 5) >> ((j & 31) * 2)) & 3u;
-          const uint32_t cc = lib.first_row(c);
-          lo = cc + lib.occ(c, lo);
-          hi = cc + lib.occ(c, hi);
+          const uint4 vl = lib.block(lo >> 5);
+          uint4 vh = vl;
+          if ((hi >> 5) != (lo >> 5)) vh = lib.block(hi >> 5);
+          lo = lib.lf(c, lo, vl);
+          hi = lib.lf(c, hi, vh);
           ++c_steps;
         }
         // ---- locate + verify every occurrence ----
         for (uint32_t i = lo; i < hi; ++i) {
-          const int32_t s = (int32_t)p.sa[i] - j;
+          const uint64_t row = p.sa[i];
           ++c_cands;
-          if (s < 0 || (uint32_t)(s + L) > p.n) continue;
+          // the alignment [pos - j, pos - j + L) must stay inside the N-free segment
+          const uint32_t before = (uint32_t)(row >> 32) & 255u, after = (uint32_t)(row >> 40) & 255u;
+          if ((uint32_t)j > before || (uint32_t)(L - j) > after) continue;
+          const uint32_t s = (uint32_t)row - (uint32_t)j;
           uint32_t mm_total = 0, mm_seed = 0;
 #pragma unroll
           for (int w = 0; w < W; ++w) {
             const int32_t nb = min(32, L - 32 * w);
             if (nb > 0) {
-              const uint64_t x = lib.window((uint32_t)s + 32u * w) ^ rd[w];
+              const uint64_t x = lib.window(s + 32u * w) ^ rd[w];
               const uint64_t m = (((x | (x >> 1)) & kOdd) | nm[w]) & low_bits(2 * nb);
               mm_total += (uint32_t)__popcll(m);
               const int32_t ns = min(nb, max(0, p.seed_len - 32 * w));
@@ -245,12 +247,11 @@ match_kernel(const MatchParams p) {
             }
           }
           if ((int32_t)mm_seed > p.max_mm_seed || (int32_t)mm_total > p.max_mm_total) continue;
-          const uint64_t key = ((uint64_t)mm_total << 32) | (uint32_t)s;
-          if (key >= best) continue;
-          // the alignment must sit inside one N-free segment of one entry
-          uint32_t sg = p.chunk_seg[(uint32_t)s >> 5];
-          while (p.seg_start[sg + 1] <= (uint32_t)s) ++sg;
-          if ((uint32_t)(s + L) <= p.seg_start[sg + 1]) best = key;
+          const uint64_t key = ((uint64_t)mm_total << 32) | s;
+          if (key < best) {
+            best = key;
+            best_seg = (uint32_t)(row >> 48);
+          }
         }
         if ((best >> 32) == 0ull) break;  // an exact hit is always seen by piece 0
       }
@@ -260,11 +261,20 @@ match_kernel(const MatchParams p) {
     if (aligned) {
       ++c_aligned;
       const uint32_t s = (uint32_t)best;
-      uint32_t sg = p.chunk_seg[s >> 5];
-      while (p.seg_start[sg + 1] <= s) ++sg;
+      uint32_t sg = best_seg;
+      if (sg == 0xFFFFu) {  // more than 65535 segments: walk the chunk map
+        sg = p.chunk_seg[s >> 5];
+        while (p.seg_start[sg + 1] <= s) ++sg;
+      }
+      const uint32_t seg0 = p.seg_start[sg];
+      uint32_t ref = sg, off = 0;
+      if (!p.simple_segs) {
+        ref = p.seg_ref[sg];
+        off = p.seg_off[sg];
+      }
       p.pass_id[r] = (int8_t)p.pass_index;
-      p.ref_id[r] = (int32_t)p.seg_ref[sg];
-      p.pos[r] = (int32_t)(s - p.seg_start[sg] + p.seg_off[sg]);
+      p.ref_id[r] = (int32_t)ref;
+      p.pos[r] = (int32_t)(s - seg0 + off);
       p.mm[r] = (uint8_t)(best >> 32);
     }
 
@@ -288,14 +298,14 @@ match_kernel(const MatchParams p) {
       }
       if (survive)
         stage[(ring_tail + my_off + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))) &
-              (kStageCap - 1)] = r;
+              stage_mask] = r;
       ring_tail += total;
-      if (ring_tail - ring_head > kStageCap - BLOCK) {
+      if (ring_tail - ring_head > p.stage_cap - BLOCK) {
         if (threadIdx.x == 0) stage_ctl[2 * kMaxWaves] = atomicAdd(p.n_out, ring_tail - ring_head);
         __syncthreads();
         const uint32_t gbase = stage_ctl[2 * kMaxWaves];
         for (uint32_t i = ring_head + threadIdx.x; (int32_t)(ring_tail - i) > 0; i += BLOCK)
-          p.idx_out[gbase + (i - ring_head)] = stage[i & (kStageCap - 1)];
+          p.idx_out[gbase + (i - ring_head)] = stage[i & stage_mask];
         ring_head = ring_tail;
       }
       ++iter;
@@ -308,19 +318,17 @@ match_kernel(const MatchParams p) {
       __syncthreads();
       const uint32_t gbase = stage_ctl[2 * kMaxWaves];
       for (uint32_t i = ring_head + threadIdx.x; (int32_t)(ring_tail - i) > 0; i += BLOCK)
-        p.idx_out[gbase + (i - ring_head)] = stage[i & (kStageCap - 1)];
+        p.idx_out[gbase + (i - ring_head)] = stage[i & stage_mask];
     }
   }
 
-  c_processed = wave_sum(c_processed);
-  c_aligned = wave_sum(c_aligned);
-  c_steps = wave_sum(c_steps);
-  c_cands = wave_sum(c_cands);
+  const uint64_t t_processed = wave_sum(c_processed), t_aligned = wave_sum(c_aligned);
+  const uint64_t t_steps = wave_sum(c_steps), t_cands = wave_sum(c_cands);
   if (lane == 0) {
-    if (c_processed) atomicAdd((unsigned long long*)&p.counters[0], (unsigned long long)c_processed);
-    if (c_aligned) atomicAdd((unsigned long long*)&p.counters[1], (unsigned long long)c_aligned);
-    if (c_steps) atomicAdd((unsigned long long*)&p.counters[2], (unsigned long long)c_steps);
-    if (c_cands) atomicAdd((unsigned long long*)&p.counters[3], (unsigned long long)c_cands);
+    if (t_processed) atomicAdd((unsigned long long*)&p.counters[0], (unsigned long long)t_processed);
+    if (t_aligned) atomicAdd((unsigned long long*)&p.counters[1], (unsigned long long)t_aligned);
+    if (t_steps) atomicAdd((unsigned long long*)&p.counters[2], (unsigned long long)t_steps);
+    if (t_cands) atomicAdd((unsigned long long*)&p.counters[3], (unsigned long long)t_cands);
   }
 }
 

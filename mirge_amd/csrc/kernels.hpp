@@ -6,31 +6,34 @@
 
 namespace mrg {
 
-// LDS-staged variants run one 1024-thread workgroup per staged copy (16 waves
-// share one copy of the library); the HBM/L2-served variant uses 256-thread
-// workgroups at full occupancy to cover gather latency.
+// Match workgroups are 1024 threads: 16 waves share one staged copy of the
+// library (or, for HBM-served libraries, of its superblock table) and one
+// survivor ring; two workgroups per CU give the full 32 waves.
 template <bool LDSI>
 struct MatchBlock {
-  static constexpr uint32_t kThreads = LDSI ? 1024u : 256u;
+  static constexpr uint32_t kThreads = 1024u;
 };
 constexpr uint32_t kTallyThreads = 1024u;
-// Survivor staging ring per match workgroup (power of two) + control words
-// (2 x kMaxWaves per-wave counts, 1 reserved global base, padding).
-constexpr uint32_t kStageCap = 4096u;
+// Survivor staging ring per match workgroup (a power of two >= 2 * threads) +
+// control words (2 x kMaxWaves per-wave counts, 1 reserved global base, padding).
+constexpr uint32_t kStageCapMax = 4096u;
+constexpr uint32_t kStageCapMin = 2048u;
 constexpr uint32_t kMaxWaves = 16u;
-constexpr uint32_t kStageBytes = (kStageCap + 2u * kMaxWaves + 4u) * 4u;
+constexpr uint32_t stage_bytes(uint32_t cap) { return (cap + 2u * kMaxWaves + 4u) * 4u; }
 
 struct MatchParams {
   // library (device pointers)
-  const uint32_t* blocks;
+  const uint32_t* blocks;  // 16 B per 32 BWT symbols
+  const uint32_t* super;   // 16 B per 65536 BWT symbols
   const uint32_t* text;
-  const uint32_t* sa;
+  const uint64_t* sa;      // 8 B rows: pos | before<<32 | after<<40 | seg<<48
   const uint32_t* seg_start;
   const uint32_t* seg_ref;
   const uint32_t* seg_off;
   const uint32_t* chunk_seg;
-  uint32_t n, nblk, primary, text_words;
-  uint32_t C[4];
+  uint32_t n, nblk, nsup, primary, text_words;
+  uint32_t simple_segs;  // every entry is one N-free segment: seg == entry, offset 0
+  uint32_t stage_cap;    // survivor ring entries (power of two)
   // reads
   const uint64_t* reads;
   const uint8_t* lens;

@@ -156,21 +156,19 @@ DEFAULT_MIX = dict(mirna_exact=0.55, isomir=0.15, trna=0.05, snorna=0.05, rrna_n
 EXACT_ONLY_MIX = dict(mirna_exact=0.02, random=0.98)  # config 2: "collapsed unique" is mostly misses
 
 
-_WINDOW_CACHE = {}
-
-
-def _cut_packed(codes, base, L):
-    """2-bit pack codes[base : base+L] for every element of `base` (uint64 per read)."""
-    if codes.shape[0] <= (1 << 21):
+def _cut_packed(codes, base, L, cache=None):
+    """2-bit pack codes[base : base+L] for every element of `base` (uint64 per read).
+    `cache` (a dict owned by the library object) keeps the per-position windows of a
+    small library between calls."""
+    if codes.shape[0] <= (1 << 21) and cache is not None:
         # small library: pack a 32-base window at every text position once, then gather
-        key = (codes.ctypes.data, codes.shape[0])
-        win = _WINDOW_CACHE.get(key)
+        win = cache.get("win")
         if win is None:
             pad = np.concatenate([codes, np.zeros(32, dtype=np.uint8)]).astype(np.uint64)
             win = np.zeros(codes.shape[0], dtype=np.uint64)
             for i in range(32):
                 win |= pad[i:i + codes.shape[0]] << np.uint64(2 * i)
-            _WINDOW_CACHE[key] = win
+            cache["win"] = win
         return win[base] & np.uint64((1 << (2 * L)) - 1)
     w = np.zeros(base.shape[0], dtype=np.uint64)
     for i in range(L):
@@ -200,6 +198,10 @@ def synth_reads_packed(libs, n, seed=355, L=22, mix=None, zipf_s=1.1):
     counts[0] += n - counts.sum()
     out = np.empty(n, dtype=np.uint64)
     at = 0
+    caches = libs.__dict__.setdefault("_window_caches", {})
+
+    def cut(key, base, length):
+        return _cut_packed(libs.codes[key][0], base, length, caches.setdefault(key, {}))
 
     def sample_sub(key, m, length, zipf=False):
         codes, starts = libs.codes[key]
@@ -234,12 +236,12 @@ def synth_reads_packed(libs, n, seed=355, L=22, mix=None, zipf_s=1.1):
             codes, starts, ent, _ = sample_sub("mirna", m, L, zipf=True)
             lens = np.diff(starts)[ent]
             off = np.clip(2 + rng.integers(-2, 3, m), 0, lens - L)
-            blk = _cut_packed(codes, starts[ent] + off, L)
+            blk = cut("mirna", starts[ent] + off, L)
         elif k == "isomir":
             codes, starts, ent, _ = sample_sub("mirna", m, L, zipf=True)
             lens = np.diff(starts)[ent]
             off = np.clip(2 + rng.integers(-1, 2, m), 0, lens - L)
-            blk = _cut_packed(codes, starts[ent] + off, L)
+            blk = cut("mirna", starts[ent] + off, L)
             kind = rng.integers(0, 3, m)
             # 0: non-templated 3' addition (last base replaced by A or T); 1: one internal
             # substitution; 2: both
@@ -250,17 +252,17 @@ def synth_reads_packed(libs, n, seed=355, L=22, mix=None, zipf_s=1.1):
         elif k in ("trna", "snorna", "mrna"):
             key = {"trna": "mature_trna", "snorna": "snorna", "mrna": "mrna"}[k]
             codes, starts, ent, off = sample_sub(key, m, L)
-            blk = substituted(_cut_packed(codes, starts[ent] + off, L), 0.3, L)
+            blk = substituted(cut(key, starts[ent] + off, L), 0.3, L)
         elif k == "rrna_ncrna":
             h = m // 2
             c1, s1, e1, o1 = sample_sub("rrna", h, L)
             c2, s2, e2, o2 = sample_sub("ncrna_others", m - h, L)
-            blk = np.concatenate([_cut_packed(c1, s1[e1] + o1, L), _cut_packed(c2, s2[e2] + o2, L)])
+            blk = np.concatenate([cut("rrna", s1[e1] + o1, L), cut("ncrna_others", s2[e2] + o2, L)])
             blk = substituted(blk, 0.3, L)
         elif k == "polyt":
             tail = 4
             codes, starts, ent, off = sample_sub("pre_trna", m, L - tail)
-            blk = _cut_packed(codes, starts[ent] + off, L - tail)
+            blk = cut("pre_trna", starts[ent] + off, L - tail)
             for i in range(L - tail, L):
                 blk |= np.uint64(3) << np.uint64(2 * i)
         elif k == "random":

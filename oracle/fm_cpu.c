@@ -21,9 +21,10 @@
 #include <string.h>
 
 typedef struct {
-  const uint32_t *blocks, *text, *sa, *seg_start, *seg_ref, *seg_off, *chunk_seg;
+  const uint32_t *blocks, *super, *text;
+  const uint64_t *sa;
+  const uint32_t *seg_start, *seg_ref, *seg_off, *chunk_seg;
   uint32_t n, primary;
-  uint32_t C[4];
 } orc_lib;
 
 typedef struct {
@@ -37,15 +38,17 @@ static inline uint64_t low_bits(int nbits) {
   return nbits >= 64 ? ~0ull : (nbits <= 0 ? 0ull : ((1ull << nbits) - 1ull));
 }
 
-static inline uint32_t occ(const orc_lib *l, uint32_t c, uint32_t i) {
-  uint32_t b = i >> 6, r = i & 63;
-  const uint32_t *blk = l->blocks + (size_t)b * 8;
-  uint64_t lo = (uint64_t)blk[4] | ((uint64_t)blk[5] << 32);
-  uint64_t hi = (uint64_t)blk[6] | ((uint64_t)blk[7] << 32);
-  uint64_t e = ((c & 1) ? lo : ~lo) & ((c & 2) ? hi : ~hi);
-  e &= (1ull << r) - 1ull;
-  uint32_t o = blk[c] + (uint32_t)__builtin_popcountll(e);
-  if (c == 0 && i > l->primary && b == (l->primary >> 6)) --o;
+/* first BWT row of the c-suffixes + rank of c before row i (16-byte block per 32
+ * rows: uint16 cnt[4] relative to the 65536-row superblock, bit planes lo/hi) */
+static inline uint32_t lf(const orc_lib *l, uint32_t c, uint32_t i) {
+  uint32_t b = i >> 5, r = i & 31;
+  const uint32_t *blk = l->blocks + (size_t)b * 4;
+  uint32_t pair = (c & 2) ? blk[1] : blk[0];
+  uint32_t cnt = (c & 1) ? (pair >> 16) : (pair & 0xffffu);
+  uint32_t e = ((c & 1) ? blk[2] : ~blk[2]) & ((c & 2) ? blk[3] : ~blk[3]);
+  e &= (1u << r) - 1u;
+  uint32_t o = l->super[(size_t)(i >> 16) * 4 + c] + cnt + (uint32_t)__builtin_popcount(e);
+  if (c == 0 && i > l->primary && b == (l->primary >> 5)) --o;
   return o;
 }
 
@@ -81,20 +84,22 @@ static int match_one(const orc_lib *l, const orc_pass *p, const uint64_t *rd, co
     while (j > a && hi > lo && (hi - lo) > wstop) {
       --j;
       uint32_t c = (uint32_t)(rd[j >> 5] >> ((j & 31) * 2)) & 3u;
-      lo = l->C[c] + occ(l, c, lo);
-      hi = l->C[c] + occ(l, c, hi);
+      lo = lf(l, c, lo);
+      hi = lf(l, c, hi);
       ++*steps;
     }
     for (uint32_t i = lo; i < hi; ++i) {
-      int64_t s = (int64_t)l->sa[i] - j;
+      uint64_t row = l->sa[i];
+      uint32_t before = (uint32_t)(row >> 32) & 255u, after = (uint32_t)(row >> 40) & 255u;
       ++*cands;
-      if (s < 0 || (uint64_t)(s + L) > l->n) continue;
+      if ((uint32_t)j > before || (uint32_t)(L - j) > after) continue;
+      uint32_t s = (uint32_t)row - (uint32_t)j;
       int mm_total = 0, mm_seed = 0;
       for (int w = 0; w < W; ++w) {
         int nb = L - 32 * w;
         if (nb > 32) nb = 32;
         if (nb <= 0) break;
-        uint64_t x = window(l, (uint32_t)s + 32u * w) ^ rd[w];
+        uint64_t x = window(l, s + 32u * w) ^ rd[w];
         uint64_t m = (((x | (x >> 1)) & ODD) | nm[w]) & low_bits(2 * nb);
         mm_total += __builtin_popcountll(m);
         int ns = p->seed_len - 32 * w;
@@ -102,11 +107,8 @@ static int match_one(const orc_lib *l, const orc_pass *p, const uint64_t *rd, co
         mm_seed += __builtin_popcountll(m & low_bits(2 * ns));
       }
       if (mm_seed > p->max_mm_seed || mm_total > p->max_mm_total) continue;
-      uint64_t cand = ((uint64_t)mm_total << 32) | (uint32_t)s;
-      if (cand >= best) continue;
-      uint32_t sg = l->chunk_seg[(uint32_t)s >> 5];
-      while (l->seg_start[sg + 1] <= (uint32_t)s) ++sg;
-      if ((uint32_t)(s + L) <= l->seg_start[sg + 1]) best = cand;
+      uint64_t cand = ((uint64_t)mm_total << 32) | s;
+      if (cand < best) best = cand;
     }
     if ((best >> 32) == 0) break;
   }

@@ -104,8 +104,8 @@ def align_all_best(library, read, seed_len, max_mm_seed, max_mm_total, cap=4096)
 # ---------------------------------------------------------------------------
 class _OrcLib(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in
-                ("blocks", "text", "sa", "seg_start", "seg_ref", "seg_off", "chunk_seg")] + \
-               [("n", C.c_uint32), ("primary", C.c_uint32), ("C", C.c_uint32 * 4)]
+                ("blocks", "super", "text", "sa", "seg_start", "seg_ref", "seg_off", "chunk_seg")] + \
+               [("n", C.c_uint32), ("primary", C.c_uint32)]
 
 
 class _OrcPass(C.Structure):
@@ -118,8 +118,8 @@ def fm_cascade(lib_views, passes, reads, lens, nmask=None, wstop=0, threads=None
                want_steps=False):
     """Run the CPU port.
 
-    lib_views: list of dicts with numpy arrays blocks/text/sa/seg_start/seg_ref/
-               seg_off/chunk_seg and ints n, primary, C (as mirge_amd index views).
+    lib_views: list of dicts with numpy arrays blocks/super/text/sa/seg_start/
+               seg_ref/seg_off/chunk_seg and ints n, primary (as mirge_amd index views).
     passes   : list of dicts with the mrg_pass_cfg fields.
     reads    : uint64 [W, n] SoA words; lens uint8 [n]; nmask like reads or None.
     Returns dict(pass_id, ref_id, pos, mm, stats[n_pass,4], steps_per_read|None).
@@ -130,14 +130,12 @@ def fm_cascade(lib_views, passes, reads, lens, nmask=None, wstop=0, threads=None
     keep = []
     libs = (_OrcLib * len(lib_views))()
     for i, v in enumerate(lib_views):
-        for k in ("blocks", "text", "sa", "seg_start", "seg_ref", "seg_off", "chunk_seg"):
-            a = np.ascontiguousarray(v[k], dtype=np.uint32)
+        for k in ("blocks", "super", "text", "sa", "seg_start", "seg_ref", "seg_off", "chunk_seg"):
+            a = np.ascontiguousarray(v[k], dtype=np.uint64 if k == "sa" else np.uint32)
             keep.append(a)
             setattr(libs[i], k, a.ctypes.data)
         libs[i].n = int(v["n"])
         libs[i].primary = int(v["primary"])
-        for c in range(4):
-            libs[i].C[c] = int(v["C"][c])
     ps = (_OrcPass * len(passes))()
     for i, p in enumerate(passes):
         for k, _ in _OrcPass._fields_:

@@ -28,18 +28,35 @@ def test_suffix_array_and_bwt_match_naive(native_lib):
     assert v["n"] == len(text)
     t = text + "$"
     naive = sorted(range(len(t)), key=lambda i: t[i:])
-    assert list(v["sa"]) == naive
-    # occ blocks reproduce rank over the BWT
+    sa = v["sa"]
+    assert [int(x) & 0xFFFFFFFF for x in sa] == naive
+    # occ blocks (16 B / 32 rows, uint16 counts relative to the superblock) + superblocks
+    # reproduce C[c] + rank over the BWT
     bwt = [t[i - 1] if i else "$" for i in naive]
-    blocks = v["blocks"].reshape(-1, 8)
+    blocks = v["blocks"].reshape(-1, 4)
+    sup = v["super"].reshape(-1, 4)
     for c, ch in enumerate("ACGT"):
+        first_row = 1 + sum(x < ch for x in text)
+        assert v["C"][c] == first_row
         run = 0
         for i, b in enumerate(bwt):
-            if i % 64 == 0:
-                assert blocks[i // 64][c] == run
+            if i % 32 == 0:
+                pair = int(blocks[i // 32][c >> 1])
+                cnt = (pair >> 16) if (c & 1) else (pair & 0xFFFF)
+                assert int(sup[i >> 16][c]) + cnt == first_row + run
             run += b == ch
-        assert v["C"][c] == 1 + sum(x < ch for x in text)
     assert bwt[v["primary"]] == "$"
+    # suffix-array rows carry the distance to both ends of their N-free segment
+    seg_start = [int(x) for x in v["seg_start"]]
+    for row in sa:
+        row = int(row)
+        p = row & 0xFFFFFFFF
+        if p == len(text):
+            continue
+        sg = max(k for k in range(len(seg_start) - 1) if seg_start[k] <= p)
+        assert (row >> 32) & 255 == min(255, p - seg_start[sg])
+        assert (row >> 40) & 255 == min(255, seg_start[sg + 1] - p)
+        assert (row >> 48) == sg
     # bowtie-inspect equivalents
     assert [ix.sequence(i) for i in range(len(seqs))] == seqs
     assert ix.names == ["e%d" % i for i in range(len(seqs))]
@@ -52,7 +69,7 @@ def test_index_roundtrip_file(native_lib, tmp_path):
     ix.save(p)
     iy = FmIndex.load(p)
     va, vb = ix.view(), iy.view()
-    for k in ("blocks", "text", "sa", "seg_start", "seg_ref", "seg_off", "chunk_seg"):
+    for k in ("blocks", "super", "text", "sa", "seg_start", "seg_ref", "seg_off", "chunk_seg"):
         assert np.array_equal(va[k], vb[k])
     assert iy.names == ["a", "b"] and iy.sequence(0) == "ACGTTGCANNACGT"
 
