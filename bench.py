@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wstop", type=int, default=None)
+    ap.add_argument("--no-ftab", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -92,6 +93,8 @@ def main():
         eng.add_library(k, index[k])
     if args.wstop is not None:
         eng.set_option("wstop", args.wstop)
+    if args.no_ftab:
+        eng.set_option("ftab", 0)
     if args.workload == "cascade":
         passes = eng.mirge_passes()
         table = MIRGE_PASS_TABLE[:9]
@@ -177,7 +180,7 @@ def main():
         b = 16.0 * s["processed"] + 64.0 * s["steps"]
         passes_report.append(dict(
             lib=table[i][0], ms=round(float(per_pass_ms[i]), 4), processed=s["processed"],
-            aligned=s["aligned"], steps=s["steps"], candidates=s["candidates"],
+            aligned=s["aligned"], steps=s["steps"], candidates=s["candidates"], lookups=s["lookups"],
             lds_bytes=s["lds_bytes"],
             alg_gbs=round(b / max(per_pass_ms[i], 1e-9) / 1e6, 1)))
 
@@ -190,9 +193,10 @@ def main():
         pd = [dict(lib=keys.index(k), min_len=a, max_len=b, seed_len=s_, max_mm_seed=ms, max_mm_total=mt,
                    trim5=t5, trim3=t3, poly_t=pt) for (k, a, b, s_, ms, mt, t5, t3, pt) in table]
         views = [index[k].view() for k in keys]
-        wst = args.wstop or 0
+        wst = 2 if args.wstop is None else args.wstop
         t1 = time.perf_counter()
-        ref = model.fm_cascade(views, pd, words[:, :m], lens[:m], None, wstop=wst, threads=cores)
+        ref = model.fm_cascade(views, pd, words[:, :m], lens[:m], None, wstop=wst, threads=cores,
+                               ftab=not args.no_ftab)
         cnt = model.tally(ref["pass_id"], ref["ref_id"], quant[:m], M, n_pass, canon, iso)
         dt = time.perf_counter() - t1
         # parity gate on the same sample: identical assignments before any number is reported

@@ -82,6 +82,7 @@ typedef struct mrg_index_info {
   uint32_t n_super;    /* superblocks (65536 BWT symbols each), 4 words each */
   uint32_t primary;    /* BWT row holding the sentinel */
   uint32_t text_words; /* 2-bit packed text, 32-bit words incl. padding */
+  uint32_t ftab_k;     /* k of the k-mer jump table (2 * 4^k words) */
   uint32_t C[4];       /* first BWT row of each symbol */
   uint64_t bytes_fm;   /* n_blocks * 16 + n_super * 16 */
   uint64_t bytes_sa;   /* (n_bases + 1) * 8 */
@@ -100,6 +101,7 @@ typedef struct mrg_index_view {
   const uint32_t *super;     /* n_super * 4 words: C[c] + count before the superblock */
   const uint32_t *text;      /* text_words */
   const uint64_t *sa;        /* n_bases + 1 rows: pos | before<<32 | after<<40 | seg<<48 */
+  const uint32_t *ftab;      /* 2 * 4^ftab_k words: BWT interval [lo,hi) of every k-mer */
   const uint32_t *seg_start; /* n_seg + 1 */
   const uint32_t *seg_ref;   /* n_seg */
   const uint32_t *seg_off;   /* n_seg */
@@ -115,9 +117,12 @@ int mrg_ctx_create(int device, mrg_ctx **out);
 void mrg_ctx_destroy(mrg_ctx *ctx);
 /* Upload one library; *lib_id is what mrg_pass_cfg.lib refers to. */
 int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
-/* Tunables (all have defaults): "lds_budget" bytes of LDS a match workgroup
- * may use for a staged library; "wstop" interval width at which a seed search
- * stops narrowing and hands over to verification (0 = never). */
+/* Tunables (all have defaults): "lds_budget" = most bytes of LDS a match
+ * workgroup may spend on a staged library (occ blocks + packed text; 0 serves
+ * every library from HBM/L2); "wstop" = interval width at which a seed search
+ * stops narrowing and hands the occurrences to verification (0 = narrow to the
+ * end of the piece); "ftab" = 1/0 use the k-mer jump table for the first k steps
+ * of a seed search. */
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);
 int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,
                         char *arch, uint32_t arch_cap);
@@ -141,6 +146,7 @@ typedef struct mrg_pass_stats {
   uint64_t aligned;    /* "# reads with at least one reported alignment" */
   uint64_t steps;      /* FM backward-extension (LF) steps executed */
   uint64_t candidates; /* seed occurrences verified against the text */
+  uint64_t lookups;    /* k-mer jump-table loads (each replaces ftab_k LF steps) */
   float ms;            /* device time of the pass (the reference's cpuTime) */
   uint32_t lds_bytes;  /* LDS staged for this pass (0 = index served from HBM/L2) */
 } mrg_pass_stats;

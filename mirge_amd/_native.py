@@ -30,19 +30,21 @@ class PassCfg(C.Structure):
 
 class PassStats(C.Structure):
     _fields_ = [("processed", C.c_uint64), ("aligned", C.c_uint64), ("steps", C.c_uint64),
-                ("candidates", C.c_uint64), ("ms", C.c_float), ("lds_bytes", C.c_uint32)]
+                ("candidates", C.c_uint64), ("lookups", C.c_uint64), ("ms", C.c_float),
+                ("lds_bytes", C.c_uint32)]
 
 
 class IndexInfo(C.Structure):
     _fields_ = [("n_ref", C.c_uint32), ("n_seg", C.c_uint32), ("n_bases", C.c_uint32),
                 ("n_blocks", C.c_uint32), ("n_super", C.c_uint32), ("primary", C.c_uint32),
-                ("text_words", C.c_uint32),
+                ("text_words", C.c_uint32), ("ftab_k", C.c_uint32),
                 ("C", C.c_uint32 * 4), ("bytes_fm", C.c_uint64), ("bytes_sa", C.c_uint64)]
 
 
 class IndexView(C.Structure):
     _fields_ = [("blocks", C.POINTER(C.c_uint32)), ("super", C.POINTER(C.c_uint32)),
-                ("text", C.POINTER(C.c_uint32)), ("sa", C.POINTER(C.c_uint64))] + \
+                ("text", C.POINTER(C.c_uint32)), ("sa", C.POINTER(C.c_uint64)),
+                ("ftab", C.POINTER(C.c_uint32))] + \
                [(k, C.POINTER(C.c_uint32)) for k in ("seg_start", "seg_ref", "seg_off", "chunk_seg")]
 
 

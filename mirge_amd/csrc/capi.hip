@@ -44,6 +44,8 @@ struct DevLib {
   uint32_t *blocks = nullptr, *super = nullptr, *text = nullptr, *seg_start = nullptr,
            *seg_ref = nullptr, *seg_off = nullptr, *chunk_seg = nullptr;
   uint64_t* sa = nullptr;
+  uint32_t* ftab = nullptr;
+  uint32_t ftab_k = 0;
   uint32_t n = 0, nblk = 0, nsup = 0, primary = 0, text_words = 0, n_seg = 0, n_ref = 0;
 };
 
@@ -58,7 +60,7 @@ int upload(T** dst, const std::vector<T>& v, size_t pad_to_multiple = 1) {
   return MRG_OK;
 }
 
-constexpr uint32_t kStatsPerPass = 4;
+constexpr uint32_t kStatsPerPass = 5;
 
 }  // namespace
 
@@ -68,7 +70,8 @@ struct mrg_ctx {
   uint64_t hbm_bytes = 0;
   std::string arch;
   int64_t lds_budget = 160 * 1024;
-  int64_t wstop = 0;
+  int64_t wstop = 2;
+  int64_t use_ftab = 1;
   std::vector<DevLib> libs;
   // last run
   hipStream_t last_stream = nullptr;
@@ -155,6 +158,7 @@ int mrg_index_get_info(const mrg_index* h, mrg_index_info* info) {
   info->n_super = (uint32_t)(ix.super.size() / 4);
   info->primary = ix.primary;
   info->text_words = (uint32_t)ix.text.size();
+  info->ftab_k = ix.ftab_k;
   for (int c = 0; c < 4; ++c) info->C[c] = ix.C[c];
   info->bytes_fm = (uint64_t)ix.blocks.size() * 16 + (uint64_t)ix.super.size() * 4;
   info->bytes_sa = (uint64_t)ix.sa.size() * 8;
@@ -186,6 +190,7 @@ int mrg_index_get_view(const mrg_index* h, mrg_index_view* v) {
   v->super = ix.super.data();
   v->text = ix.text.data();
   v->sa = ix.sa.data();
+  v->ftab = ix.ftab.data();
   v->seg_start = ix.seg_start.data();
   v->seg_ref = ix.seg_ref.data();
   v->seg_off = ix.seg_off.data();
@@ -229,6 +234,7 @@ void mrg_ctx_destroy(mrg_ctx* ctx) {
     (void)hipFree(l.super);
     (void)hipFree(l.text);
     (void)hipFree(l.sa);
+    (void)hipFree(l.ftab);
     (void)hipFree(l.seg_start);
     (void)hipFree(l.seg_ref);
     (void)hipFree(l.seg_off);
@@ -259,6 +265,8 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
   l.text_words = (uint32_t)((ix.text.size() + 3) / 4 * 4);
   if ((rc = upload(&l.text, ix.text, 4))) return rc;
   if ((rc = upload(&l.sa, ix.sa))) return rc;
+  l.ftab_k = ix.ftab_k;
+  if ((rc = upload(&l.ftab, ix.ftab))) return rc;
   if ((rc = upload(&l.seg_start, ix.seg_start))) return rc;
   if ((rc = upload(&l.seg_ref, ix.seg_ref))) return rc;
   if ((rc = upload(&l.seg_off, ix.seg_off))) return rc;
@@ -277,6 +285,8 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "wstop") {
     if (value < 0) return fail(MRG_ERR_ARG, "wstop must be >= 0");
     ctx->wstop = value;
+  } else if (k == "ftab") {
+    ctx->use_ftab = value != 0;
   } else {
     return fail(MRG_ERR_ARG, "mrg_ctx_set_option: unknown key '%s'", key);
   }
@@ -361,6 +371,8 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     p.super = l.super;
     p.text = l.text;
     p.sa = l.sa;
+    p.ftab = l.ftab;
+    p.ftab_k = ctx->use_ftab ? l.ftab_k : 0u;
     p.seg_start = l.seg_start;
     p.seg_ref = l.seg_ref;
     p.seg_off = l.seg_off;
@@ -402,16 +414,17 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     const uint64_t sup_bytes = (uint64_t)l.nsup * 16;
     const uint64_t budget = (uint64_t)ctx->lds_budget;
     int lds_mode = 0;
-    uint64_t lib_bytes = 0;
-    if (sup_bytes + blk_bytes + txt_bytes + mrg::stage_bytes(mrg::kStageCapMin) <= budget) {
+    uint64_t lib_bytes = 0;  // staged library bytes, capped by the "lds_budget" option
+    const uint64_t hard = 160 * 1024, overhead = sup_bytes + mrg::stage_bytes(mrg::kStageCapMin);
+    if (overhead > hard)
+      return fail(MRG_ERR_ARG, "mrg_cascade_run: the %llu-byte superblock table of library %d does not "
+                  "fit LDS", (unsigned long long)sup_bytes, c.lib);
+    if (blk_bytes + txt_bytes <= budget && overhead + blk_bytes + txt_bytes <= hard) {
       lds_mode = 2;
       lib_bytes = blk_bytes + txt_bytes;
-    } else if (sup_bytes + blk_bytes + mrg::stage_bytes(mrg::kStageCapMin) <= budget) {
+    } else if (blk_bytes <= budget && overhead + blk_bytes <= hard) {
       lds_mode = 1;
       lib_bytes = blk_bytes;
-    } else if (sup_bytes + mrg::stage_bytes(mrg::kStageCapMin) > budget) {
-      return fail(MRG_ERR_ARG, "mrg_cascade_run: lds_budget %lld cannot hold the %llu-byte superblock "
-                  "table of library %d", (long long)ctx->lds_budget, (unsigned long long)sup_bytes, c.lib);
     }
     const uint32_t threads = 1024u;
     uint32_t stage_cap = mrg::kStageCapMax;
@@ -420,7 +433,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     if ((fixed + mrg::stage_bytes(mrg::kStageCapMax)) * 2 > 160 * 1024 &&
         (fixed + mrg::stage_bytes(mrg::kStageCapMin)) * 2 <= 160 * 1024)
       stage_cap = mrg::kStageCapMin;
-    while (stage_cap > mrg::kStageCapMin && fixed + mrg::stage_bytes(stage_cap) > budget) stage_cap >>= 1;
+    while (stage_cap > mrg::kStageCapMin && fixed + mrg::stage_bytes(stage_cap) > hard) stage_cap >>= 1;
     if (stage_cap < 2 * threads) stage_cap = 2 * threads;
     const uint32_t lds_total = (uint32_t)(fixed + mrg::stage_bytes(stage_cap));
     p.stage_cap = stage_cap;
@@ -452,6 +465,7 @@ int mrg_cascade_stats(mrg_ctx* ctx, mrg_pass_stats* out, uint32_t n_pass) {
     out[i].aligned = host[i * kStatsPerPass + 1];
     out[i].steps = host[i * kStatsPerPass + 2];
     out[i].candidates = host[i * kStatsPerPass + 3];
+    out[i].lookups = host[i * kStatsPerPass + 4];
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
     out[i].ms = ms;

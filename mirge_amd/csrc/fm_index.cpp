@@ -295,6 +295,28 @@ void build_index(const std::vector<std::string>& names,
     ix.chunk_seg[ch] = sgi;
   }
 
+  // k-mer jump table: rows whose suffix starts with the k-mer are contiguous
+  {
+    const uint32_t k = ix.n >= (1u << 22) ? 10u : 8u;
+    ix.ftab_k = k;
+    ix.ftab.assign((size_t)2 << (2 * k), 0);
+    const uint64_t kmask = (1ull << (2 * k)) - 1;
+    uint64_t prev = ~0ull;
+    for (size_t i = 0; i < sa32.size(); ++i) {
+      const uint32_t p = sa32[i];
+      if ((uint64_t)p + k > ix.n) continue;
+      const uint32_t w = p >> 4, sh = (p & 15) * 2;
+      uint64_t win = (uint64_t)ix.text[w] | ((uint64_t)ix.text[w + 1] << 32);
+      win = sh ? (win >> sh) | ((uint64_t)ix.text[w + 2] << (64 - sh)) : win;
+      const uint64_t code = win & kmask;
+      if (code != prev) {
+        ix.ftab[2 * code] = (uint32_t)i;
+        prev = code;
+      }
+      ix.ftab[2 * code + 1] = (uint32_t)i + 1;
+    }
+  }
+
   // 8-byte suffix-array rows: position + distance to both ends of its segment
   std::vector<uint32_t> seg_of(ix.n);
   for (uint32_t sg = 0; sg < nseg; ++sg)
@@ -333,7 +355,7 @@ std::string entry_sequence(const FmIndex& ix, uint32_t r) {
 // Serialisation ("MRGFM1\0\0" + counts + raw arrays)
 // ---------------------------------------------------------------------------
 namespace {
-const char kMagic[8] = {'M', 'R', 'G', 'F', 'M', '2', 0, 0};
+const char kMagic[8] = {'M', 'R', 'G', 'F', 'M', '3', 0, 0};
 
 template <class T>
 void put_vec(std::ofstream& o, const std::vector<T>& v) {
@@ -357,7 +379,7 @@ void save_index(const FmIndex& ix, const std::string& path) {
   if (!o) throw std::runtime_error("cannot write " + path);
   o.write(kMagic, 8);
   uint32_t hdr[8] = {ix.n, ix.primary, ix.C[0], ix.C[1], ix.C[2], ix.C[3],
-                     (uint32_t)ix.names.size(), 0};
+                     (uint32_t)ix.names.size(), ix.ftab_k};
   o.write((const char*)hdr, sizeof(hdr));
   for (size_t r = 0; r < ix.names.size(); ++r) {
     uint32_t l = (uint32_t)ix.names[r].size();
@@ -370,6 +392,7 @@ void save_index(const FmIndex& ix, const std::string& path) {
   put_vec(o, ix.super);
   put_vec(o, ix.text);
   put_vec(o, ix.sa);
+  put_vec(o, ix.ftab);
   put_vec(o, ix.seg_start);
   put_vec(o, ix.seg_ref);
   put_vec(o, ix.seg_off);
@@ -391,6 +414,7 @@ void load_index(const std::string& path, FmIndex& ix) {
   ix.primary = hdr[1];
   for (int c = 0; c < 4; ++c) ix.C[c] = hdr[2 + c];
   uint32_t nref = hdr[6];
+  ix.ftab_k = hdr[7];
   ix.names.resize(nref);
   ix.ref_n_runs.resize(nref);
   for (uint32_t r = 0; r < nref; ++r) {
@@ -406,12 +430,14 @@ void load_index(const std::string& path, FmIndex& ix) {
   get_vec(in, ix.super);
   get_vec(in, ix.text);
   get_vec(in, ix.sa);
+  get_vec(in, ix.ftab);
   get_vec(in, ix.seg_start);
   get_vec(in, ix.seg_ref);
   get_vec(in, ix.seg_off);
   get_vec(in, ix.chunk_seg);
   if (ix.sa.size() != (size_t)ix.n + 1 || ix.blocks.size() != (size_t)((ix.n + 1) >> 5) + 1 ||
-      ix.super.size() != ((size_t)((ix.n + 1) >> kSuperShift) + 1) * 4)
+      ix.super.size() != ((size_t)((ix.n + 1) >> kSuperShift) + 1) * 4 ||
+      ix.ftab_k > 12 || ix.ftab.size() != ((size_t)2 << (2 * ix.ftab_k)))
     throw std::runtime_error("index file inconsistent");
 }
 

@@ -154,7 +154,7 @@ match_kernel(const MatchParams p) {
   const uint32_t n_in = p.idx_in ? *p.n_in : p.n_total;
   const uint32_t lane = threadIdx.x & 63;
   // per-lane tallies (a lane handles a few hundred reads per launch: 32 bits suffice)
-  uint32_t c_processed = 0, c_aligned = 0, c_steps = 0, c_cands = 0;
+  uint32_t c_processed = 0, c_aligned = 0, c_steps = 0, c_cands = 0, c_lookups = 0;
 
   for (uint32_t base = blockIdx.x * BLOCK; base < n_in; base += gridDim.x * BLOCK) {
     const uint32_t t = base + threadIdx.x;
@@ -216,6 +216,18 @@ match_kernel(const MatchParams p) {
         // ---- exact backward search of read[a,b) ----
         uint32_t lo = 0, hi = p.n + 1;
         int32_t j = b;
+        if (p.ftab_k && b - a >= (int32_t)p.ftab_k) {
+          // the piece's last k bases in one load: BWT interval of that k-mer
+          j = b - (int32_t)p.ftab_k;
+          uint64_t code = pick_word<W>(rd, (uint32_t)j >> 5) >> ((j & 31) * 2);
+          if (W > 1 && (j & 31) + (int32_t)p.ftab_k > 32)
+            code |= pick_word<W>(rd, ((uint32_t)j >> 5) + 1) << (64 - (j & 31) * 2);
+          code &= (1ull << (2 * p.ftab_k)) - 1ull;
+          const uint2 iv = *reinterpret_cast<const uint2*>(p.ftab + 2 * code);
+          lo = iv.x;
+          hi = iv.y;
+          ++c_lookups;
+        }
         while (j > a && hi > lo && (hi - lo) > p.wstop) {
           --j;
           const uint32_t c = (uint32_t)(pick_word<W>(rd, (uint32_t)j >> 5) >> ((j & 31) * 2)) & 3u;
@@ -324,11 +336,13 @@ match_kernel(const MatchParams p) {
 
   const uint64_t t_processed = wave_sum(c_processed), t_aligned = wave_sum(c_aligned);
   const uint64_t t_steps = wave_sum(c_steps), t_cands = wave_sum(c_cands);
+  const uint64_t t_lookups = wave_sum(c_lookups);
   if (lane == 0) {
     if (t_processed) atomicAdd((unsigned long long*)&p.counters[0], (unsigned long long)t_processed);
     if (t_aligned) atomicAdd((unsigned long long*)&p.counters[1], (unsigned long long)t_aligned);
     if (t_steps) atomicAdd((unsigned long long*)&p.counters[2], (unsigned long long)t_steps);
     if (t_cands) atomicAdd((unsigned long long*)&p.counters[3], (unsigned long long)t_cands);
+    if (t_lookups) atomicAdd((unsigned long long*)&p.counters[4], (unsigned long long)t_lookups);
   }
 }
 
@@ -381,8 +395,8 @@ __global__ void export_pass_counts_kernel(const uint64_t* stats, uint32_t n_pass
                                           uint64_t* out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_pass) {
-    out[2 * i] = stats[4 * i];
-    out[2 * i + 1] = stats[4 * i + 1];
+    out[2 * i] = stats[5 * i];
+    out[2 * i + 1] = stats[5 * i + 1];
   }
 }
 

@@ -27,6 +27,8 @@ struct MatchParams {
   const uint32_t* super;   // 16 B per 65536 BWT symbols
   const uint32_t* text;
   const uint64_t* sa;      // 8 B rows: pos | before<<32 | after<<40 | seg<<48
+  const uint32_t* ftab;    // k-mer jump table: lo, hi per k-mer
+  uint32_t ftab_k;         // 0 = do not use it
   const uint32_t* seg_start;
   const uint32_t* seg_ref;
   const uint32_t* seg_off;
@@ -48,7 +50,7 @@ struct MatchParams {
   int32_t* ref_id;
   int32_t* pos;
   uint8_t* mm;
-  uint64_t* counters;  // processed, aligned, steps, candidates of this pass
+  uint64_t* counters;  // processed, aligned, steps, candidates, lookups of this pass
   // policy
   int32_t seed_len, max_mm_seed, max_mm_total, trim5, trim3, min_len, max_len, poly_t;
   int32_t pass_index;

@@ -184,7 +184,8 @@ class Engine:
         st = (PassStats * n_pass)()
         check(self._lib.mrg_cascade_stats(self._h, st, n_pass))
         return [dict(processed=int(s.processed), aligned=int(s.aligned), steps=int(s.steps),
-                     candidates=int(s.candidates), ms=float(s.ms), lds_bytes=int(s.lds_bytes))
+                     candidates=int(s.candidates), lookups=int(s.lookups), ms=float(s.ms),
+                     lds_bytes=int(s.lds_bytes))
                 for s in st]
 
     def counts_len(self, n_mirna, n_samples, n_pass):
@@ -237,7 +238,8 @@ class Engine:
             mm.ctypes.data, st, None if q is None else q.ctypes.data, S, n_mirna, canon_pass,
             isomir_pass, None if counts is None else counts.ctypes.data))
         stats = [dict(processed=int(s.processed), aligned=int(s.aligned), steps=int(s.steps),
-                      candidates=int(s.candidates), ms=float(s.ms), lds_bytes=int(s.lds_bytes))
+                      candidates=int(s.candidates), lookups=int(s.lookups), ms=float(s.ms),
+                     lds_bytes=int(s.lds_bytes))
                  for s in st]
         return dict(pass_id=pass_id, ref_id=ref_id, pos=pos, mm=mm, stats=stats, counts=counts)
 

@@ -23,8 +23,9 @@
 typedef struct {
   const uint32_t *blocks, *super, *text;
   const uint64_t *sa;
+  const uint32_t *ftab; /* k-mer jump table: lo, hi per k-mer */
   const uint32_t *seg_start, *seg_ref, *seg_off, *chunk_seg;
-  uint32_t n, primary;
+  uint32_t n, primary, ftab_k;
 } orc_lib;
 
 typedef struct {
@@ -67,8 +68,8 @@ static void shift5(uint64_t *rd, int W, int t) {
 
 /* Returns 1 if aligned; *key = (mm << 32) | text position. */
 static int match_one(const orc_lib *l, const orc_pass *p, const uint64_t *rd, const uint64_t *nm,
-                     int W, int L, uint32_t wstop, uint64_t *key, uint64_t *steps,
-                     uint64_t *cands) {
+                     int W, int L, uint32_t wstop, int use_ftab, uint64_t *key, uint64_t *steps,
+                     uint64_t *cands, uint64_t *lookups) {
   uint64_t best = ~0ull;
   if (L <= p->max_mm_seed) return 0;
   int R = L < p->seed_len ? L : p->seed_len;
@@ -81,6 +82,16 @@ static int match_one(const orc_lib *l, const orc_pass *p, const uint64_t *rd, co
     if (has_n) continue;
     uint32_t lo = 0, hi = l->n + 1;
     int j = b;
+    if (use_ftab && l->ftab_k && b - a >= (int)l->ftab_k) {
+      /* the piece's last k bases in one load */
+      uint64_t code = 0;
+      j = b - (int)l->ftab_k;
+      for (int t = 0; t < (int)l->ftab_k; ++t)
+        code |= ((rd[(j + t) >> 5] >> (((j + t) & 31) * 2)) & 3ull) << (2 * t);
+      lo = l->ftab[2 * code];
+      hi = l->ftab[2 * code + 1];
+      ++*lookups;
+    }
     while (j > a && hi > lo && (hi - lo) > wstop) {
       --j;
       uint32_t c = (uint32_t)(rd[j >> 5] >> ((j & 31) * 2)) & 3u;
@@ -119,14 +130,14 @@ static int match_one(const orc_lib *l, const orc_pass *p, const uint64_t *rd, co
 
 /*
  * reads: SoA words (reads[w*n + r]), nmask same shape or NULL.
- * stats: per pass {processed, aligned, steps, candidates}.
+ * stats: per pass {processed, aligned, steps, candidates, lookups}.
  * per_read_steps (optional, n entries): LF steps summed over the passes.
  */
 void orc_run_cascade(const orc_lib *libs, const orc_pass *passes, int n_pass, const uint64_t *reads,
                      int W, const uint8_t *lens, const uint64_t *nmask, uint64_t n, uint32_t wstop,
-                     int8_t *pass_id, int32_t *ref_id, int32_t *pos, uint8_t *mm, uint64_t *stats,
+                     int use_ftab, int8_t *pass_id, int32_t *ref_id, int32_t *pos, uint8_t *mm, uint64_t *stats,
                      uint32_t *per_read_steps) {
-  memset(stats, 0, sizeof(uint64_t) * 4 * (size_t)n_pass);
+  memset(stats, 0, sizeof(uint64_t) * 5 * (size_t)n_pass);
   for (uint64_t r = 0; r < n; ++r) {
     pass_id[r] = -1;
     ref_id[r] = -1;
@@ -137,8 +148,8 @@ void orc_run_cascade(const orc_lib *libs, const orc_pass *passes, int n_pass, co
   for (int pi = 0; pi < n_pass; ++pi) {
     const orc_pass *p = &passes[pi];
     const orc_lib *l = &libs[p->lib];
-    uint64_t processed = 0, aligned = 0, steps = 0, cands = 0;
-#pragma omp parallel for schedule(dynamic, 4096) reduction(+ : processed, aligned, steps, cands)
+    uint64_t processed = 0, aligned = 0, steps = 0, cands = 0, lookups = 0;
+#pragma omp parallel for schedule(dynamic, 4096) reduction(+ : processed, aligned, steps, cands, lookups)
     for (int64_t r = 0; r < (int64_t)n; ++r) {
       if (pass_id[r] >= 0) continue;
       int L = lens[r];
@@ -163,10 +174,11 @@ void orc_run_cascade(const orc_lib *libs, const orc_pass *passes, int n_pass, co
       shift5(rd, W, p->trim5);
       shift5(nm, W, p->trim5);
       ++processed;
-      uint64_t key = 0, st = 0, cd = 0;
-      int ok = L > 0 && match_one(l, p, rd, nm, W, L, wstop, &key, &st, &cd);
+      uint64_t key = 0, st = 0, cd = 0, lk = 0;
+      int ok = L > 0 && match_one(l, p, rd, nm, W, L, wstop, use_ftab, &key, &st, &cd, &lk);
       steps += st;
       cands += cd;
+      lookups += lk;
       if (per_read_steps) per_read_steps[r] += (uint32_t)st;
       if (ok) {
         uint32_t s = (uint32_t)key;
@@ -179,10 +191,11 @@ void orc_run_cascade(const orc_lib *libs, const orc_pass *passes, int n_pass, co
         ++aligned;
       }
     }
-    stats[4 * pi + 0] = processed;
-    stats[4 * pi + 1] = aligned;
-    stats[4 * pi + 2] = steps;
-    stats[4 * pi + 3] = cands;
+    stats[5 * pi + 0] = processed;
+    stats[5 * pi + 1] = aligned;
+    stats[5 * pi + 2] = steps;
+    stats[5 * pi + 3] = cands;
+    stats[5 * pi + 4] = lookups;
   }
 }
 

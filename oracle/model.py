@@ -104,8 +104,9 @@ def align_all_best(library, read, seed_len, max_mm_seed, max_mm_total, cap=4096)
 # ---------------------------------------------------------------------------
 class _OrcLib(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in
-                ("blocks", "super", "text", "sa", "seg_start", "seg_ref", "seg_off", "chunk_seg")] + \
-               [("n", C.c_uint32), ("primary", C.c_uint32)]
+                ("blocks", "super", "text", "sa", "ftab", "seg_start", "seg_ref", "seg_off",
+                 "chunk_seg")] + \
+               [("n", C.c_uint32), ("primary", C.c_uint32), ("ftab_k", C.c_uint32)]
 
 
 class _OrcPass(C.Structure):
@@ -115,14 +116,16 @@ class _OrcPass(C.Structure):
 
 
 def fm_cascade(lib_views, passes, reads, lens, nmask=None, wstop=0, threads=None,
-               want_steps=False):
+               want_steps=False, ftab=False):
     """Run the CPU port.
 
     lib_views: list of dicts with numpy arrays blocks/super/text/sa/seg_start/
                seg_ref/seg_off/chunk_seg and ints n, primary (as mirge_amd index views).
     passes   : list of dicts with the mrg_pass_cfg fields.
     reads    : uint64 [W, n] SoA words; lens uint8 [n]; nmask like reads or None.
-    Returns dict(pass_id, ref_id, pos, mm, stats[n_pass,4], steps_per_read|None).
+    wstop / ftab: the same search shortcuts the GPU context options select.
+    Returns dict(pass_id, ref_id, pos, mm, stats[n_pass,5] = processed, aligned, steps,
+    candidates, lookups; steps_per_read|None).
     """
     reads = np.ascontiguousarray(reads, dtype=np.uint64)
     W, n = reads.shape
@@ -130,12 +133,14 @@ def fm_cascade(lib_views, passes, reads, lens, nmask=None, wstop=0, threads=None
     keep = []
     libs = (_OrcLib * len(lib_views))()
     for i, v in enumerate(lib_views):
-        for k in ("blocks", "super", "text", "sa", "seg_start", "seg_ref", "seg_off", "chunk_seg"):
+        for k in ("blocks", "super", "text", "sa", "ftab", "seg_start", "seg_ref", "seg_off",
+                  "chunk_seg"):
             a = np.ascontiguousarray(v[k], dtype=np.uint64 if k == "sa" else np.uint32)
             keep.append(a)
             setattr(libs[i], k, a.ctypes.data)
         libs[i].n = int(v["n"])
         libs[i].primary = int(v["primary"])
+        libs[i].ftab_k = int(v["ftab_k"])
     ps = (_OrcPass * len(passes))()
     for i, p in enumerate(passes):
         for k, _ in _OrcPass._fields_:
@@ -144,7 +149,7 @@ def fm_cascade(lib_views, passes, reads, lens, nmask=None, wstop=0, threads=None
     ref_id = np.empty(n, dtype=np.int32)
     pos = np.empty(n, dtype=np.int32)
     mm = np.empty(n, dtype=np.uint8)
-    stats = np.zeros((len(passes), 4), dtype=np.uint64)
+    stats = np.zeros((len(passes), 5), dtype=np.uint64)
     steps = np.zeros(n, dtype=np.uint32) if want_steps else None
     nm = None if nmask is None else np.ascontiguousarray(nmask, dtype=np.uint64)
     old = os.environ.get("OMP_NUM_THREADS")
@@ -157,7 +162,8 @@ def fm_cascade(lib_views, passes, reads, lens, nmask=None, wstop=0, threads=None
     lib().orc_run_cascade(
         libs, ps, C.c_int(len(passes)), reads.ctypes.data_as(C.c_void_p), C.c_int(W),
         lens.ctypes.data_as(C.c_void_p), None if nm is None else nm.ctypes.data_as(C.c_void_p),
-        C.c_uint64(n), C.c_uint32(wstop), pass_id.ctypes.data_as(C.c_void_p),
+        C.c_uint64(n), C.c_uint32(wstop), C.c_int(1 if ftab else 0),
+        pass_id.ctypes.data_as(C.c_void_p),
         ref_id.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p),
         mm.ctypes.data_as(C.c_void_p), stats.ctypes.data_as(C.c_void_p),
         None if steps is None else steps.ctypes.data_as(C.c_void_p))

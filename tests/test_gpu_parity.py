@@ -41,20 +41,39 @@ def assert_same(res, ref):
         assert st["aligned"] == int(ref["stats"][i][1])
         assert st["steps"] == int(ref["stats"][i][2])
         assert st["candidates"] == int(ref["stats"][i][3])
+        assert st["lookups"] == int(ref["stats"][i][4])
 
 
 def test_cascade_matches_cpu_port_all_lds_modes(engine, world):
     ref = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask)
     # default residency (blocks+text in LDS where they fit), blocks only, nothing staged
-    for budget in (160 * 1024, 24 * 1024, 0):
-        _, res = run_gpu(engine, world, lds_budget=budget, wstop=0)
+    for budget in (160 * 1024, 12 * 1024, 0):
+        _, res = run_gpu(engine, world, lds_budget=budget, wstop=0, ftab=0)
         assert_same(res, ref)
+        modes = [s["lds_bytes"] for s in res.stats]
+        assert (max(modes) == 0) == (budget == 0)
     engine.set_option("lds_budget", 160 * 1024)
+
+
+def test_search_shortcuts_same_results_fewer_steps(engine, world):
+    """The k-mer jump table and the early hand-over to verification change how many
+    LF steps run, never an assignment; step / candidate / lookup counts equal the port's."""
+    base = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask)
+    for wstop, ftab in ((0, 1), (2, 0), (2, 1), (16, 1)):
+        ref = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask,
+                               wstop=wstop, ftab=bool(ftab))
+        for k in ("pass_id", "ref_id", "pos", "mm"):
+            assert np.array_equal(base[k], ref[k])
+        _, res = run_gpu(engine, world, wstop=wstop, ftab=ftab)
+        assert_same(res, ref)
+        assert sum(s["steps"] for s in res.stats) < int(base["stats"][:, 2].sum())
+    engine.set_option("wstop", 2)
+    engine.set_option("ftab", 1)
 
 
 def test_cascade_matches_exhaustive_scan(engine, world):
     """Against the independent model of bowtie's rules (subset, it is O(N*text))."""
-    _, res = run_gpu(engine, world, lds_budget=160 * 1024, wstop=0)
+    _, res = run_gpu(engine, world, lds_budget=160 * 1024)
     pass_id, ref_id, pos, mm = res.to_host()
     sub = np.random.default_rng(5).choice(len(world.reads), 4000, replace=False)
     reads = [world.reads[i] for i in sub]
@@ -66,13 +85,6 @@ def test_cascade_matches_exhaustive_scan(engine, world):
     for i, r in zip(sub, reads):
         got = None if pass_id[i] < 0 else (int(pass_id[i]), int(ref_id[i]), int(pos[i]), int(mm[i]))
         assert align.get(r) == got, r
-
-
-def test_early_stop_same_results_fewer_steps(engine, world):
-    ref = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask, wstop=2)
-    _, res = run_gpu(engine, world, wstop=2)
-    assert_same(res, ref)
-    engine.set_option("wstop", 0)
 
 
 def test_tally_matches_oracle(engine, world):

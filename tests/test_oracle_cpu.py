@@ -95,10 +95,38 @@ def test_fm_port_equals_exhaustive_scan(world):
     assert all(int(res["stats"][i][1]) > 0 for i in range(9))
 
 
-def test_early_stop_width_does_not_change_results(world):
+def test_search_shortcuts_do_not_change_results(world):
     base = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask)
-    for wstop in (1, 4, 64):
-        alt = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask, wstop=wstop)
+    for wstop, ftab in ((1, False), (4, False), (64, False), (0, True), (2, True)):
+        alt = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask,
+                               wstop=wstop, ftab=ftab)
         for k in ("pass_id", "ref_id", "pos", "mm"):
             assert np.array_equal(base[k], alt[k])
         assert int(alt["stats"][:, 2].sum()) < int(base["stats"][:, 2].sum())
+        assert (int(alt["stats"][:, 4].sum()) > 0) == ftab
+
+
+def test_jump_table_equals_backward_search(native_lib):
+    """ftab[k-mer] is the BWT interval a step-by-step backward search ends in."""
+    from mirge_amd.index import FmIndex
+    rng = np.random.default_rng(11)
+    seqs = ["".join("ACGT"[c] for c in rng.integers(0, 4, int(L))) for L in rng.integers(20, 400, 60)]
+    ix = FmIndex.build(["e%d" % i for i in range(len(seqs))], seqs)
+    v = ix.view()
+    k = v["ftab_k"]
+    assert k == 8 and len(v["ftab"]) == 2 * 4 ** k
+    text = "".join(seqs)
+    sa = [int(x) & 0xFFFFFFFF for x in v["sa"]]
+    for _ in range(300):
+        if rng.random() < 0.7:
+            p = int(rng.integers(0, len(text) - k))
+            kmer = text[p:p + k]
+        else:
+            kmer = "".join("ACGT"[c] for c in rng.integers(0, 4, k))
+        code = sum("ACGT".index(ch) << (2 * t) for t, ch in enumerate(kmer))
+        lo, hi = int(v["ftab"][2 * code]), int(v["ftab"][2 * code + 1])
+        rows = [i for i, s in enumerate(sa) if text[s:s + k] == kmer]
+        if rows:
+            assert (lo, hi) == (rows[0], rows[-1] + 1)
+        else:
+            assert lo == hi
