@@ -72,6 +72,7 @@ struct mrg_ctx {
   int64_t lds_budget = 160 * 1024;
   int64_t wstop = 2;
   int64_t use_ftab = 1;
+  int64_t force_lds_mode = -1;
   std::vector<DevLib> libs;
   // last run
   hipStream_t last_stream = nullptr;
@@ -285,6 +286,9 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "wstop") {
     if (value < 0) return fail(MRG_ERR_ARG, "wstop must be >= 0");
     ctx->wstop = value;
+  } else if (k == "force_lds_mode") {
+    if (value < -1 || value > 3) return fail(MRG_ERR_ARG, "force_lds_mode must be in [-1,3]");
+    ctx->force_lds_mode = value;
   } else if (k == "ftab") {
     ctx->use_ftab = value != 0;
   } else {
@@ -305,10 +309,12 @@ int mrg_ctx_device_info(const mrg_ctx* ctx, int32_t* n_cu, uint64_t* hbm_bytes, 
 }
 
 // --------------------------------------------------------------- cascade
-// workspace: [idx A: n u32][idx B: n u32][list counts: MRG_MAX_PASSES+1 u32, padded]
-//            [stats: MRG_MAX_PASSES * 4 u64]
-static uint64_t ws_idx_bytes(uint64_t n) { return ((n * 4 + 255) / 256) * 256; }
-static const uint64_t kWsCountsBytes = 256;
+// workspace: [idx A][idx B]  (each n + kMaxSegments*1024 u32: segmented survivor lists)
+//            [segment counts A, B: kMaxSegments u32 each][stats: MRG_MAX_PASSES * 5 u64]
+static uint64_t ws_idx_bytes(uint64_t n) {
+  return (((n + (uint64_t)mrg::kMaxSegments * 1024) * 4 + 255) / 256) * 256;
+}
+static const uint64_t kWsCountsBytes = 2 * mrg::kMaxSegments * 4;
 static const uint64_t kWsStatsBytes = MRG_MAX_PASSES * kStatsPerPass * 8;
 
 int mrg_cascade_workspace_bytes(uint64_t n, uint64_t* bytes) {
@@ -354,13 +360,10 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
   uint32_t* idx[2] = {(uint32_t*)ws, (uint32_t*)(ws + ws_idx_bytes(n))};
   uint32_t* counts = (uint32_t*)(ws + 2 * ws_idx_bytes(n));
   uint64_t* stats = (uint64_t*)(ws + 2 * ws_idx_bytes(n) + kWsCountsBytes);
-  HIP_TRY(hipMemsetAsync(counts, 0, kWsCountsBytes + kWsStatsBytes, stream));
-  if (n) {
-    HIP_TRY(hipMemsetAsync(d_pass_id, 0xFF, n, stream));
-    HIP_TRY(hipMemsetAsync(d_ref_id, 0xFF, n * 4, stream));
-    HIP_TRY(hipMemsetAsync(d_pos, 0xFF, n * 4, stream));
-    HIP_TRY(hipMemsetAsync(d_mm, 0, n, stream));
-  }
+  // per-pass counters only; the outputs need no memset (the last pass writes the
+  // "unannotated" values for whatever it does not claim)
+  HIP_TRY(hipMemsetAsync(stats, 0, kWsStatsBytes, stream));
+  uint32_t prev_grid = 0, prev_seg_cap = 0;
 
   HIP_TRY(hipEventRecord(ctx->ev[0], stream));
   for (uint32_t i = 0; i < n_pass; ++i) {
@@ -388,9 +391,11 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     p.nmask = d_nmask;
     p.n_total = (uint32_t)n;
     p.idx_in = i == 0 ? nullptr : idx[(i - 1) & 1];
-    p.n_in = i == 0 ? nullptr : counts + (i - 1);
+    p.in_count = counts + ((i - 1) & 1) * mrg::kMaxSegments;
+    p.in_nseg = prev_grid;
+    p.in_seg_cap = prev_seg_cap;
     p.idx_out = (i + 1 < n_pass) ? idx[i & 1] : nullptr;
-    p.n_out = counts + i;
+    p.out_count = counts + (i & 1) * mrg::kMaxSegments;
     p.pass_id = d_pass_id;
     p.ref_id = d_ref_id;
     p.pos = d_pos;
@@ -407,42 +412,55 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     p.pass_index = (int32_t)i;
     p.wstop = (uint32_t)ctx->wstop;
 
-    // residency decision: blocks + text, blocks only, or nothing in LDS.  The
-    // superblock table always rides along (16 B per 65536 bp) and the survivor
-    // ring comes on top; prefer a layout that lets two workgroups share a CU.
+    // residency decision.  The superblock table (16 B per 65536 bp) and the segment
+    // prefix always sit in LDS.  With the jump table most seed searches need few LF
+    // steps, so the packed text (read by every verification) is the first thing worth
+    // staging and two resident workgroups per CU (<= 80 KB each) beat a fuller LDS:
+    //   2 = blocks + text, 3 = text only, 1 = blocks only, 0 = nothing.
     const uint64_t blk_bytes = (uint64_t)l.nblk * 16, txt_bytes = (uint64_t)l.text_words * 4;
-    const uint64_t sup_bytes = (uint64_t)l.nsup * 16;
-    const uint64_t budget = (uint64_t)ctx->lds_budget;
-    int lds_mode = 0;
-    uint64_t lib_bytes = 0;  // staged library bytes, capped by the "lds_budget" option
-    const uint64_t hard = 160 * 1024, overhead = sup_bytes + mrg::stage_bytes(mrg::kStageCapMin);
+    const uint64_t overhead = (uint64_t)l.nsup * 16 + mrg::kMatchCtlBytes;
+    const uint64_t budget = (uint64_t)ctx->lds_budget, hard = 160 * 1024, half = 80 * 1024;
     if (overhead > hard)
-      return fail(MRG_ERR_ARG, "mrg_cascade_run: the %llu-byte superblock table of library %d does not "
-                  "fit LDS", (unsigned long long)sup_bytes, c.lib);
-    if (blk_bytes + txt_bytes <= budget && overhead + blk_bytes + txt_bytes <= hard) {
+      return fail(MRG_ERR_ARG, "mrg_cascade_run: the superblock table of library %d does not fit LDS", c.lib);
+    int lds_mode = 0;
+    uint64_t lib_bytes = 0;
+    if (blk_bytes + txt_bytes <= budget && overhead + blk_bytes + txt_bytes <= half) {
       lds_mode = 2;
       lib_bytes = blk_bytes + txt_bytes;
+    } else if (txt_bytes <= budget && overhead + txt_bytes <= half) {
+      lds_mode = 3;
+      lib_bytes = txt_bytes;
+    } else if (blk_bytes + txt_bytes <= budget && overhead + blk_bytes + txt_bytes <= hard) {
+      lds_mode = 2;
+      lib_bytes = blk_bytes + txt_bytes;
+    } else if (txt_bytes <= budget && overhead + txt_bytes <= hard) {
+      lds_mode = 3;
+      lib_bytes = txt_bytes;
     } else if (blk_bytes <= budget && overhead + blk_bytes <= hard) {
       lds_mode = 1;
       lib_bytes = blk_bytes;
     }
-    const uint32_t threads = 1024u;
-    uint32_t stage_cap = mrg::kStageCapMax;
-    const uint64_t fixed = sup_bytes + lib_bytes;
-    // two resident workgroups per CU beat a deeper ring; otherwise take the big ring
-    if ((fixed + mrg::stage_bytes(mrg::kStageCapMax)) * 2 > 160 * 1024 &&
-        (fixed + mrg::stage_bytes(mrg::kStageCapMin)) * 2 <= 160 * 1024)
-      stage_cap = mrg::kStageCapMin;
-    while (stage_cap > mrg::kStageCapMin && fixed + mrg::stage_bytes(stage_cap) > hard) stage_cap >>= 1;
-    if (stage_cap < 2 * threads) stage_cap = 2 * threads;
-    const uint32_t lds_total = (uint32_t)(fixed + mrg::stage_bytes(stage_cap));
-    p.stage_cap = stage_cap;
+    if (ctx->force_lds_mode >= 0) {  // test hook: exercise a specific kernel variant
+      const int m = (int)ctx->force_lds_mode;
+      const uint64_t need = (m == 2 ? blk_bytes + txt_bytes : m == 3 ? txt_bytes : m == 1 ? blk_bytes : 0);
+      if (overhead + need <= hard) {
+        lds_mode = m;
+        lib_bytes = need;
+      }
+    }
+    const uint32_t lds_total = (uint32_t)(overhead + lib_bytes);
     const uint32_t lds_bytes = (uint32_t)lib_bytes;
     const uint32_t per_cu = (lds_total * 2u <= 160u * 1024u) ? 2u : 1u;
-    const uint32_t grid = (uint32_t)ctx->n_cu * per_cu;
+    uint32_t grid = (uint32_t)ctx->n_cu * per_cu;
+    if (grid > mrg::kMaxSegments) grid = mrg::kMaxSegments;
+    // a workgroup's segment must hold every read it may be offered
+    const uint32_t seg_cap = (uint32_t)(((n + 1024ull * grid - 1) / (1024ull * grid)) * 1024ull);
+    p.out_seg_cap = seg_cap;
     ctx->last_lds[i] = lds_bytes;
     if (n) HIP_TRY(mrg::launch_match(p, words_per_read, lds_mode, grid, lds_total, stream));
     HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
+    prev_grid = grid;
+    prev_seg_cap = seg_cap;
   }
   if (d_pass_counts) HIP_TRY(mrg::launch_export_pass_counts(stats, n_pass, d_pass_counts, stream));
   ctx->last_stream = stream;

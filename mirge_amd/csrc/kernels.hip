@@ -112,16 +112,15 @@ match_kernel(const MatchParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   constexpr uint32_t BLOCK = MatchBlock<LDSI>::kThreads;
 
-  // ---- LDS carve: [superblocks][occ blocks][text][survivor ring][ring control] ----
+  // ---- LDS carve: [superblocks][occ blocks][text][segment prefix][control] ----
   const uint32_t sup_words = p.nsup * 4;
   const uint32_t blk_words = LDSI ? p.nblk * 4 : 0u;
   const uint32_t txt_words = LDST ? p.text_words : 0u;
   uint32_t* ssuper = smem;
   uint32_t* sblocks = ssuper + sup_words;
   uint32_t* stext = sblocks + blk_words;
-  uint32_t* stage = stext + txt_words;
-  const uint32_t stage_mask = p.stage_cap - 1u;
-  uint32_t* stage_ctl = stage + p.stage_cap;
+  uint32_t* seg_prefix = stext + txt_words;     // kMaxSegments + 1 entries
+  uint32_t* ctl = seg_prefix + kMaxSegments + 1;  // [0] = survivors appended by this workgroup
   {
     // 16 B per lane per trip
     const uint4* src = reinterpret_cast<const uint4*>(p.super);
@@ -138,10 +137,36 @@ match_kernel(const MatchParams p) {
     uint4* dst = reinterpret_cast<uint4*>(stext);
     for (uint32_t i = threadIdx.x; i < txt_words / 4; i += BLOCK) dst[i] = src[i];
   }
+  // The input list is the producer pass's per-workgroup segments; an exclusive prefix
+  // over their lengths turns them into one logical list every workgroup strides over.
+  if (threadIdx.x == 0) ctl[0] = 0u;
+  if (p.idx_in) {
+    if (threadIdx.x < 64) {
+      // one wave scans <= kMaxSegments counts: 8 per lane, then a wave prefix
+      uint32_t local[kMaxSegments / 64];
+      uint32_t sum = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < kMaxSegments / 64; ++k) {
+        const uint32_t sgi = threadIdx.x * (kMaxSegments / 64) + k;
+        local[k] = sgi < p.in_nseg ? p.in_count[sgi] : 0u;
+        sum += local[k];
+      }
+      uint32_t incl = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if ((int)threadIdx.x >= off) incl += v;
+      }
+      uint32_t run = incl - sum;
+#pragma unroll
+      for (uint32_t k = 0; k < kMaxSegments / 64; ++k) {
+        seg_prefix[threadIdx.x * (kMaxSegments / 64) + k] = run;
+        run += local[k];
+      }
+      if (threadIdx.x == 63) seg_prefix[kMaxSegments] = run;
+    }
+  }
   __syncthreads();
-  // block-uniform ring cursors: [ring_head, ring_tail) is staged but not yet in HBM
-  uint32_t ring_head = 0, ring_tail = 0, iter = 0;
-  const uint32_t wave = threadIdx.x >> 6;
 
   Lib<LDSI, LDST> lib;
   lib.gblocks = p.blocks;
@@ -151,7 +176,7 @@ match_kernel(const MatchParams p) {
   lib.ssuper = ssuper;
   lib.primary = p.primary;
 
-  const uint32_t n_in = p.idx_in ? *p.n_in : p.n_total;
+  const uint32_t n_in = p.idx_in ? seg_prefix[kMaxSegments] : p.n_total;
   const uint32_t lane = threadIdx.x & 63;
   // per-lane tallies (a lane handles a few hundred reads per launch: 32 bits suffice)
   uint32_t c_processed = 0, c_aligned = 0, c_steps = 0, c_cands = 0, c_lookups = 0;
@@ -165,7 +190,16 @@ match_kernel(const MatchParams p) {
 #pragma unroll
     for (int k = 0; k < W; ++k) rd[k] = nm[k] = 0ull;
     if (active) {
-      r = p.idx_in ? p.idx_in[t] : t;
+      r = t;
+      if (p.idx_in) {
+        // logical index t -> (segment, offset): last segment whose prefix is <= t
+        uint32_t lo_s = 0, hi_s = p.in_nseg;
+        while (hi_s - lo_s > 1) {
+          const uint32_t mid = (lo_s + hi_s) >> 1;
+          if (seg_prefix[mid] <= t) lo_s = mid; else hi_s = mid;
+        }
+        r = p.idx_in[(size_t)lo_s * p.in_seg_cap + (t - seg_prefix[lo_s])];
+      }
       L0 = p.lens[r];
     }
     // ---- which reads this pass's FASTA would contain (RAP:543-554, 664-686) ----
@@ -197,7 +231,7 @@ match_kernel(const MatchParams p) {
     if (eligible) ++c_processed;
 
     uint64_t best = ~0ull;  // (mm << 32) | text position
-    uint32_t best_seg = 0xFFFFu;
+    uint32_t best_seg = 0xFFFFu, best_before = 255u;
     if (eligible && L > p.max_mm_seed) {
       const int32_t R = min(L, p.seed_len);
       const int32_t K = p.max_mm_seed + 1;
@@ -263,6 +297,7 @@ match_kernel(const MatchParams p) {
           if (key < best) {
             best = key;
             best_seg = (uint32_t)(row >> 48);
+            best_before = before < 255u ? before - (uint32_t)j : 255u;
           }
         }
         if ((best >> 32) == 0ull) break;  // an exact hit is always seen by piece 0
@@ -278,60 +313,49 @@ match_kernel(const MatchParams p) {
         sg = p.chunk_seg[s >> 5];
         while (p.seg_start[sg + 1] <= s) ++sg;
       }
-      const uint32_t seg0 = p.seg_start[sg];
-      uint32_t ref = sg, off = 0;
-      if (!p.simple_segs) {
-        ref = p.seg_ref[sg];
-        off = p.seg_off[sg];
+      uint32_t ref = sg, pos;
+      if (p.simple_segs && best_before < 255u) {
+        pos = best_before;  // offset of the alignment start inside its entry, from the SA row
+      } else {
+        uint32_t off = 0;
+        if (!p.simple_segs) {
+          ref = p.seg_ref[sg];
+          off = p.seg_off[sg];
+        }
+        pos = s - p.seg_start[sg] + off;
       }
       p.pass_id[r] = (int8_t)p.pass_index;
       p.ref_id[r] = (int32_t)ref;
-      p.pos[r] = (int32_t)(s - seg0 + off);
+      p.pos[r] = (int32_t)pos;
       p.mm[r] = (uint8_t)(best >> 32);
+    } else if (active && !p.idx_out) {
+      // last pass: whatever is still unclaimed stays unannotated (no memset needed)
+      p.pass_id[r] = (int8_t)-1;
+      p.ref_id[r] = -1;
+      p.pos[r] = -1;
+      p.mm[r] = 0;
     }
 
     // ---- survivors of this pass feed the next one ----
-    // A single global counter takes ~11 ns per atomic whatever the data, so the
-    // append is staged: per iteration every wave publishes its survivor count in
-    // LDS (no atomics), all threads derive the same ring offsets from the 16
-    // counts, and the ring is flushed with ONE global atomic per ~3K survivors.
+    // Each workgroup owns a private segment of the output list: a wave reserves its
+    // slots with ONE LDS atomic and writes them straight to HBM.  No global atomics
+    // (a single address sustains only ~11 ns per atomic) and no barrier in the loop.
     if (p.idx_out) {
       const bool survive = active && !aligned;
       const uint64_t mask = __ballot(survive);
-      uint32_t* wc = stage_ctl + (iter & 1u) * kMaxWaves;
-      if (lane == 0) wc[wave] = (uint32_t)__popcll(mask);
-      __syncthreads();
-      uint32_t my_off = 0, total = 0;
-#pragma unroll
-      for (uint32_t w = 0; w < BLOCK / 64; ++w) {
-        const uint32_t c = wc[w];
-        my_off += (w < wave) ? c : 0u;
-        total += c;
+      if (mask) {
+        uint32_t wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&ctl[0], (uint32_t)__popcll(mask));
+        wbase = __shfl(wbase, 0, 64);
+        if (survive)
+          p.idx_out[(size_t)blockIdx.x * p.out_seg_cap + wbase +
+                    (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = r;
       }
-      if (survive)
-        stage[(ring_tail + my_off + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))) &
-              stage_mask] = r;
-      ring_tail += total;
-      if (ring_tail - ring_head > p.stage_cap - BLOCK) {
-        if (threadIdx.x == 0) stage_ctl[2 * kMaxWaves] = atomicAdd(p.n_out, ring_tail - ring_head);
-        __syncthreads();
-        const uint32_t gbase = stage_ctl[2 * kMaxWaves];
-        for (uint32_t i = ring_head + threadIdx.x; (int32_t)(ring_tail - i) > 0; i += BLOCK)
-          p.idx_out[gbase + (i - ring_head)] = stage[i & stage_mask];
-        ring_head = ring_tail;
-      }
-      ++iter;
     }
   }
   if (p.idx_out) {
     __syncthreads();
-    if (ring_tail != ring_head) {
-      if (threadIdx.x == 0) stage_ctl[2 * kMaxWaves] = atomicAdd(p.n_out, ring_tail - ring_head);
-      __syncthreads();
-      const uint32_t gbase = stage_ctl[2 * kMaxWaves];
-      for (uint32_t i = ring_head + threadIdx.x; (int32_t)(ring_tail - i) > 0; i += BLOCK)
-        p.idx_out[gbase + (i - ring_head)] = stage[i & stage_mask];
-    }
+    if (threadIdx.x == 0) p.out_count[blockIdx.x] = ctl[0];
   }
 
   const uint64_t t_processed = wave_sum(c_processed), t_aligned = wave_sum(c_aligned);
@@ -421,6 +445,7 @@ template <int W>
 static hipError_t launch_match_w(const MatchParams& p, int lds_mode, uint32_t grid,
                                  uint32_t lds_bytes, hipStream_t stream) {
   switch (lds_mode) {
+    case 3: return launch_match_t<W, false, true>(p, grid, lds_bytes, stream);
     case 2: return launch_match_t<W, true, true>(p, grid, lds_bytes, stream);
     case 1: return launch_match_t<W, true, false>(p, grid, lds_bytes, stream);
     default: return launch_match_t<W, false, false>(p, grid, lds_bytes, stream);

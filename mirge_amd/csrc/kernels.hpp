@@ -14,12 +14,9 @@ struct MatchBlock {
   static constexpr uint32_t kThreads = 1024u;
 };
 constexpr uint32_t kTallyThreads = 1024u;
-// Survivor staging ring per match workgroup (a power of two >= 2 * threads) +
-// control words (2 x kMaxWaves per-wave counts, 1 reserved global base, padding).
-constexpr uint32_t kStageCapMax = 4096u;
-constexpr uint32_t kStageCapMin = 2048u;
-constexpr uint32_t kMaxWaves = 16u;
-constexpr uint32_t stage_bytes(uint32_t cap) { return (cap + 2u * kMaxWaves + 4u) * 4u; }
+// Survivor lists are segmented: workgroup b of the producing pass owns segment b.
+constexpr uint32_t kMaxSegments = 512u;
+constexpr uint32_t kMatchCtlBytes = (kMaxSegments + 1u + 3u) * 4u;  // prefix + control words
 
 struct MatchParams {
   // library (device pointers)
@@ -35,16 +32,17 @@ struct MatchParams {
   const uint32_t* chunk_seg;
   uint32_t n, nblk, nsup, primary, text_words;
   uint32_t simple_segs;  // every entry is one N-free segment: seg == entry, offset 0
-  uint32_t stage_cap;    // survivor ring entries (power of two)
   // reads
   const uint64_t* reads;
   const uint8_t* lens;
   const uint64_t* nmask;  // may be null
-  uint32_t n_total;       // SoA stride and identity list length
-  const uint32_t* idx_in; // null = identity list of n_total reads
-  const uint32_t* n_in;
-  uint32_t* idx_out;      // null on the last pass
-  uint32_t* n_out;
+  uint32_t n_total;          // SoA stride and identity list length
+  const uint32_t* idx_in;    // null = identity list of n_total reads
+  const uint32_t* in_count;  // entries in each of the producer's segments
+  uint32_t in_nseg, in_seg_cap;
+  uint32_t* idx_out;         // null on the last pass
+  uint32_t* out_count;       // [gridDim.x]
+  uint32_t out_seg_cap;
   // outputs
   int8_t* pass_id;
   int32_t* ref_id;
@@ -67,7 +65,8 @@ struct TallyParams {
   uint64_t* counts;
 };
 
-// lds_mode: 0 = index in HBM/L2, 1 = occ blocks in LDS, 2 = occ blocks + text in LDS
+// lds_mode: 0 = index in HBM/L2, 1 = occ blocks in LDS, 2 = occ blocks + text in LDS,
+//           3 = text only in LDS (occ blocks from L2)
 hipError_t launch_match(const MatchParams& p, uint32_t words_per_read, int lds_mode,
                         uint32_t grid, uint32_t lds_bytes, hipStream_t stream);
 hipError_t launch_tally(const TallyParams& p, bool lds_hist, uint32_t grid,

@@ -46,12 +46,21 @@ def assert_same(res, ref):
 
 def test_cascade_matches_cpu_port_all_lds_modes(engine, world):
     ref = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask)
-    # default residency (blocks+text in LDS where they fit), blocks only, nothing staged
-    for budget in (160 * 1024, 12 * 1024, 0):
-        _, res = run_gpu(engine, world, lds_budget=budget, wstop=0, ftab=0)
+    # every kernel variant: nothing staged, occ blocks, blocks + text, text only, and the
+    # driver's own residency choice
+    for mode in (0, 1, 2, 3, -1):
+        _, res = run_gpu(engine, world, force_lds_mode=mode, wstop=0, ftab=0)
         assert_same(res, ref)
-        modes = [s["lds_bytes"] for s in res.stats]
-        assert (max(modes) == 0) == (budget == 0)
+        staged = [s["lds_bytes"] for s in res.stats]
+        if mode == 0:
+            assert max(staged) == 0
+        elif mode > 0:
+            assert min(staged) > 0
+    engine.set_option("force_lds_mode", -1)
+    # the LDS budget option alone can also switch staging off
+    _, res = run_gpu(engine, world, lds_budget=0, wstop=0, ftab=0)
+    assert_same(res, ref)
+    assert max(s["lds_bytes"] for s in res.stats) == 0
     engine.set_option("lds_budget", 160 * 1024)
 
 
