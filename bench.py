@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wstop", type=int, default=None)
     ap.add_argument("--no-ftab", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
     args = ap.parse_args()
 
     import torch
@@ -95,6 +96,9 @@ def main():
         eng.set_option("wstop", args.wstop)
     if args.no_ftab:
         eng.set_option("ftab", 0)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
     if args.workload == "cascade":
         passes = eng.mirge_passes()
         table = MIRGE_PASS_TABLE[:9]

@@ -73,6 +73,7 @@ struct mrg_ctx {
   int64_t wstop = 2;
   int64_t use_ftab = 1;
   int64_t force_lds_mode = -1;
+  int64_t prefer_two_blocks = 1;
   std::vector<DevLib> libs;
   // last run
   hipStream_t last_stream = nullptr;
@@ -286,6 +287,8 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "wstop") {
     if (value < 0) return fail(MRG_ERR_ARG, "wstop must be >= 0");
     ctx->wstop = value;
+  } else if (k == "prefer_two_blocks") {
+    ctx->prefer_two_blocks = value != 0;
   } else if (k == "force_lds_mode") {
     if (value < -1 || value > 3) return fail(MRG_ERR_ARG, "force_lds_mode must be in [-1,3]");
     ctx->force_lds_mode = value;
@@ -427,7 +430,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     if (blk_bytes + txt_bytes <= budget && overhead + blk_bytes + txt_bytes <= half) {
       lds_mode = 2;
       lib_bytes = blk_bytes + txt_bytes;
-    } else if (txt_bytes <= budget && overhead + txt_bytes <= half) {
+    } else if (ctx->prefer_two_blocks && txt_bytes <= budget && overhead + txt_bytes <= half) {
       lds_mode = 3;
       lib_bytes = txt_bytes;
     } else if (blk_bytes + txt_bytes <= budget && overhead + blk_bytes + txt_bytes <= hard) {

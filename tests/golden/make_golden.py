@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 REF = "/root/reference/src/mirge"
 HOT = ["runAnnotationPipeline", "summarize", "miRNAmerge", "filter", "quantReads",
-       "writeDataToCSV", "extractPreMiRName", "parseArgument"]
+       "writeDataToCSV", "extractPreMiRName", "parseArgument", "generateReport"]
 
 BOWTIE_STANDIN = r'''#!/usr/bin/env python3
 import os, sys
@@ -137,6 +137,65 @@ def stub_bio():
         sys.modules[m.__name__] = m
 
 
+def stub_reportlab():
+    """reportlab is absent; generateReport.py writes annotation.report.csv and closes it
+    before it builds the PDF, so inert stand-ins for the drawing classes are enough."""
+    class Any(object):
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return Any()
+
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            v = Any()
+            object.__setattr__(self, name, v)
+            return v
+
+        def __setattr__(self, name, value):
+            object.__setattr__(self, name, value)
+
+        def __getitem__(self, k):
+            return Any()
+
+        def __setitem__(self, k, v):
+            pass
+
+        def __mul__(self, o):
+            return 1.0
+
+        __rmul__ = __mul__
+
+    names = {
+        "reportlab": [], "reportlab.graphics": [], "reportlab.graphics.charts": [],
+        "reportlab.graphics.charts.textlabels": ["Label"],
+        "reportlab.graphics.shapes": ["Drawing", "_DrawingEditorMixin"],
+        "reportlab.graphics.charts.barcharts": ["VerticalBarChart", "HorizontalBarChart"],
+        "reportlab.lib": ["colors"], "reportlab.lib.units": [], "reportlab.platypus": [],
+        "reportlab.platypus.flowables": ["Image", "Spacer", "PageBreak"],
+        "reportlab.platypus.paragraph": ["Paragraph"],
+        "reportlab.platypus.doctemplate": ["SimpleDocTemplate"],
+        "reportlab.lib.styles": [], "reportlab.lib.formatters": ["DecimalFormatter"],
+        "reportlab.platypus.tables": ["Table", "TableStyle", "GRID_STYLE", "BOX_STYLE", "LABELED_GRID_STYLE",
+                                      "COLORED_GRID_STYLE", "LIST_STYLE", "LongTable"],
+    }
+    for modname, attrs in names.items():
+        m = types.ModuleType(modname)
+        for a in attrs:
+            setattr(m, a, type(a, (Any,), {}) if a[0].isupper() or a[0] == "_" else Any())
+        sys.modules[modname] = m
+    sys.modules["reportlab.lib.units"].inch = 72.0
+    sys.modules["reportlab.lib.styles"].getSampleStyleSheet = lambda: Any()
+    sys.modules["reportlab.lib"].colors = Any()
+
+    class Mixin(object):
+        def _add(self, obj, value, name=None, validate=None, desc=None):
+            object.__setattr__(obj, name, value)
+    sys.modules["reportlab.graphics.shapes"]._DrawingEditorMixin = Mixin
+
+
 def build_world():
     import numpy as np
     from mirge_amd import synth
@@ -228,6 +287,33 @@ def main():
         miRNAmerge(merge_file, sample_list, mir_dic, mirna_fa, name_seq)
         after_merge = copy.deepcopy(mir_dic)
         ref_filter(mir_dic, sample_list, log_dic, "0.1")
+        after_filter = copy.deepcopy(mir_dic)
+        qs_after_filter = copy.deepcopy(log_dic["quantStats"])
+
+        # ---- table writers (writeDataToCSV.py with -di; generateReport.py's CSV) ----
+        stub_reportlab()
+        from mirge.utils.generateReport import generateReport
+        from mirge.utils.writeDataToCSV import writeDataToCSV, calcEntropy
+        for si, reads in enumerate(samples):
+            log_dic["quantStats"][si]["totalReads"] = len(reads) + 17 * (si + 1)
+            log_dic["quantStats"][si]["trimmedReads"] = len(reads)
+        for a in log_dic["annotStats"]:
+            a.setdefault("cpuTime", 0.0)
+        generateReport(outdir, sample_list, len_dic, log_dic, annot_names, seq_dic, False)
+        merged_name = {}
+        for line in libs.merges:
+            f = line.split(",")
+            for m in f[1:]:
+                merged_name[m] = f[0]
+        writeDataToCSV(outdir, annot_names, sample_list, True, False, log_dic, copy.deepcopy(seq_dic),
+                       copy.deepcopy(mir_dic), name_seq, merged_name, bindir, None, "1", False, [], False,
+                       False, None, "miRBase", False, None, None, None, None, None, None, None, None)
+        tables = {}
+        for fn in ("mapped.csv", "unmapped.csv", "miR.Counts.csv", "miR.RPM.csv", "isomirs.csv",
+                   "isomirs.samples.csv", "annotation.report.csv"):
+            with open(os.path.join(outdir, fn)) as fh:
+                tables[fn] = fh.read().split("\n")
+        entropy_kat = [[v, calcEntropy(v)] for v in ([10, 10], [1, 1, 8], [0, 5, 15], [7], [1, 1], [3, 0, 9, 27])]
 
         golden = {
             "about": "captured from the reference's Python (lib2to3 scratch copy) by tests/golden/make_golden.py; "
@@ -248,9 +334,13 @@ def main():
                                                for q in qs_after_sum],
                 "mirDic_after_merge": after_merge,
                 "mirNameSeqDic": name_seq,
-                "mirDic_after_filter": mir_dic,
+                "mirDic_after_filter": after_filter,
                 "quantStats_after_filter": [{k: v for k, v in q.items() if k != "filename"}
-                                            for q in log_dic["quantStats"]],
+                                            for q in qs_after_filter],
+                "totalReads": [q["totalReads"] for q in log_dic["quantStats"]],
+                "trimmedReads": [q["trimmedReads"] for q in log_dic["quantStats"]],
+                "tables": tables,
+                "calcEntropy": entropy_kat,
             },
         }
         out = os.path.join(ROOT, "tests", "golden", "cascade_small.json")
