@@ -53,8 +53,8 @@ def runAnnotationPipeline(engine, seqDic, numCPU, phred64, annotNameList, output
     logDic['annotStats'] (RAP:640-705).  Also leaves the located alignments in
     logDic['_alignments'] = {seq: (pass, entry index, 0-based offset, mismatches)}
     for the isomiR / A-to-I consumers."""
-    if gff_output or trf_output:
-        raise NotImplementedError("-gff / -trf side products are not built yet (SURVEY.md 8f rank 4)")
+    if trf_output:
+        raise NotImplementedError("-trf side products are not built yet (SURVEY.md 8f rank 4)")
     files = {"mirna": file_mirna, "hairpin": file_hairpin, "mature_trna": file_mature_tRNA,
              "pre_trna": file_pre_tRNA, "snorna": file_snoRNA, "rrna": file_rRNA,
              "ncrna_others": file_ncrna_others, "mrna": file_mrna}
@@ -88,6 +88,22 @@ def runAnnotationPipeline(engine, seqDic, numCPU, phred64, annotNameList, output
         rec["annot"][0] = 1
         rec["annot"][p + 1] = names[p][int(ref_id[i])]
         align[seq] = (p, int(ref_id[i]), int(pos[i]), int(mm[i]))
+    if gff_output:
+        # RAP:609-619 + :653-656: after pass 0 and after pass 8, classify the claimed reads
+        from . import isomir
+        hairpin_seqs = engine.indexes["hairpin"].name_seq_dict()
+        mirna_seqs = engine.indexes["mirna"].name_seq_dict()
+        for pass_index in (0, 8):
+            if pass_index >= len(passes):
+                continue
+            trim = 0 if pass_index == 0 else 3  # -5 1 -3 2 shortens the aligned read
+            hits = {}
+            for i, seq in enumerate(seqs):
+                if int(pass_id[i]) == pass_index:
+                    hits[seq] = (names[pass_index][int(ref_id[i])], int(pos[i]) + 1,
+                                 "%dM" % (len(seq) - trim))
+            isomir.build_isomir_content(isomiRContentDic, hits, pass_index, miRNamePreNameDic,
+                                        hairpin_seqs, mirna_seqs, miRNA_database)
     gpu_ms = sum(s["ms"] for s in stats) or 1.0
     for s in stats:
         # the reference stores wall seconds per bowtie run (RAP:641-645); split ours by device time

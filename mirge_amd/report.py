@@ -188,13 +188,16 @@ def write_annotation_report_csv(path, sampleList, logDic, spikeIn=False):
 
 def writeDataToCSV(outputdir, annotNameList, sampleList, isomirDiff, a_to_i, logDic, seqDic, mirDic,
                    mirNameSeqDic=None, mirMergedNameDic=None, spikeIn=False, gff_output=False,
-                   trf_output=False):
+                   isomiRContentDic=None, miRNA_database="miRBase", trf_output=False):
     """The table-writing part of writeDataToCSV.py:566 (same leading arguments).  The
-    -ai / -gff / -trf branches are not built yet and raise."""
-    if a_to_i or gff_output or trf_output:
-        raise NotImplementedError("-ai / -gff / -trf outputs are not built yet (SURVEY.md 8a a12-a13, 8f)")
+    -ai / -trf branches are not built yet and raise."""
+    if a_to_i or trf_output:
+        raise NotImplementedError("-ai / -trf outputs are not built yet (SURVEY.md 8a a13, 8f)")
     isomirDic = write_mapped_csv(os.path.join(outputdir, "mapped.csv"), annotNameList, sampleList, seqDic,
                                  spikeIn)
+    if gff_output:
+        from .isomir import write_isomir_gff
+        write_isomir_gff(outputdir, sampleList, isomiRContentDic, seqDic, miRNA_database)
     if isomirDiff:
         write_isomir_tables(os.path.join(outputdir, "isomirs.csv"),
                             os.path.join(outputdir, "isomirs.samples.csv"), sampleList, isomirDic, logDic)

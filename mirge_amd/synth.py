@@ -36,7 +36,7 @@ def codes_to_str(codes):
 class SynthLibraries:
     """libs[key] = (names, seqs); codes[key] = (concatenated uint8 codes, starts)."""
 
-    def __init__(self, seed=20181, scale=1.0, n_paralogs=60, n_snp=120, shapes=None):
+    def __init__(self, seed=20181, scale=1.0, n_paralogs=60, n_snp=120, shapes=None, snpc=False):
         rng = np.random.default_rng(seed)
         self.libs, self.codes = {}, {}
         FULL_SHAPES = dict(globals()["FULL_SHAPES"])
@@ -87,8 +87,13 @@ class SynthLibraries:
             s = list(mir_seqs[a])
             p = int(rng.integers(4, len(s) - 8))
             s[p] = "ACGT"[("ACGT".index(s[p]) + 1 + int(rng.integers(0, 3))) % 4]
-            mir_names.append(mir_names[a] + ".SNP%d" % k)
+            mir_names.append(mir_names[a].split(".")[0] + ".SNP%d" % k)
             mir_seqs.append("".join(s))
+            if snpc and mir_names[a].split(".")[0] + ".SNPC" not in mir_names:
+                # the library convention the -gff code relies on (RAP:417-420): the canonical
+                # sequence of a miRNA that has SNP entries is also listed as <name>.SNPC
+                mir_names.append(mir_names[a].split(".")[0] + ".SNPC")
+                mir_seqs.append(mir_seqs[a])
         self.libs["mirna"] = (mir_names, mir_seqs)
         self.libs["hairpin"] = (["syn-mir-%d" % (h + 1) for h in range(n_hp)],
                                 [codes_to_str(c) for c in hp_codes])

@@ -196,14 +196,14 @@ def stub_reportlab():
     sys.modules["reportlab.graphics.shapes"]._DrawingEditorMixin = Mixin
 
 
-def build_world():
+def build_world(seed=77, snpc=False):
     import numpy as np
     from mirge_amd import synth
-    libs = synth.SynthLibraries(seed=77, scale=1.0, n_paralogs=6, n_snp=8, shapes=SHAPES)
-    rng = np.random.default_rng(5)
+    libs = synth.SynthLibraries(seed=seed, scale=1.0, n_paralogs=6, n_snp=8, shapes=SHAPES, snpc=snpc)
+    rng = np.random.default_rng(seed - 72)
     samples = []
     for si in range(2):
-        codes = synth.synth_reads(libs, 1400, seed=900 + si, zipf_s=1.3)
+        codes = synth.synth_reads(libs, 1400, seed=seed + 823 + si, zipf_s=1.3)
         reads = [synth.codes_to_str(c) for c in codes]
         # variable-length reads: hairpin (>25 nt, pass 1), miRNA arms +-, N-containing, poly-T trailers
         for _ in range(260):
@@ -348,8 +348,172 @@ def main():
             json.dump(golden, fh, separators=(",", ":"), sort_keys=True)
         print("wrote", out, os.path.getsize(out), "bytes;", len(seq_dic), "unique reads;",
               "annotStats", golden["expected"]["annotStats"])
+        make_gff_golden(scratch, bindir)
     finally:
         shutil.rmtree(scratch, ignore_errors=True)
+
+
+def make_gff_golden(scratch, bindir):
+    """-gff: isomiRContentDic + <sample>_isomiRs.gff from the reference, and known answers of
+    its pure functions (make_id, make_cigar, fillTerminal+analyzeAlignment, inferPremiRName,
+    extractPreMiRName) -> tests/golden/isomir_gff.json."""
+    import copy
+    import importlib
+    import io
+    import contextlib
+    import random
+    RAP = importlib.import_module("mirge.utils.runAnnotationPipeline")
+    W2C = importlib.import_module("mirge.utils.writeDataToCSV")
+    XPN = importlib.import_module("mirge.utils.extractPreMiRName")
+    from mirge.utils.quantReads import quantReads
+    from mirge.utils.summarize import summarize
+    from mirge.utils.miRNAmerge import miRNAmerge
+    from mirge.utils.filter import filter as ref_filter
+
+    libs, samples = build_world(seed=91, snpc=True)
+    libroot = os.path.join(scratch, "libs_gff")
+    prefix = libs.write_layout(libroot, species="syn", db="miRBase")
+    outdir = os.path.join(scratch, "out_gff")
+    os.makedirs(outdir)
+    # a miRBase-style gff3 for extractPreMiRName: every base miRNA name derives from its hairpin
+    mir_names = libs.libs["mirna"][0]
+    base_names = []
+    for n in mir_names:
+        b = n.split(".")[0]
+        if "-par" not in b and b not in base_names:
+            base_names.append(b)
+    gff3 = os.path.join(libroot, "syn", "annotation.Libs", "syn_miRBase.gff3")
+    hp_names = libs.libs["hairpin"][0]
+    with open(gff3, "w") as fh:
+        fh.write("##gff-version 3\n")
+        for h, hn in enumerate(hp_names):
+            fh.write("chr1\t.\tmiRNA_primary_transcript\t%d\t%d\t.\t+\t.\tID=MI%07d;Alias=MI%07d;Name=%s\n"
+                     % (1000 * h + 1, 1000 * h + 90, h, h, hn))
+        for k, b in enumerate(base_names):
+            h = int(b.split("-")[2]) - 1
+            fh.write("chr1\t.\tmiRNA\t%d\t%d\t.\t+\t.\tID=MIMAT%07d;Alias=MIMAT%07d;Name=%s;Derives_from=MI%07d\n"
+                     % (1000 * h + 5, 1000 * h + 27, k, k, b, h))
+    pre_name = XPN.extractPreMiRName(gff3, "miRBase")
+
+    sample_list = ["g0.fastq", "g1.fastq"]
+    seq_dic, len_dic = {}, {}
+    for si, reads in enumerate(samples):
+        fq = os.path.join(outdir, "g%d.trim.fastq" % si)
+        with open(fq, "w") as fh:
+            for k, r in enumerate(reads):
+                fh.write("@r%d\n%s\n+\n%s\n" % (k, r, "I" * len(r)))
+        quantReads(fq, seq_dic, len_dic, 2, si, sample_list, False, False)
+    log_dic = {"quantStats": [{"filename": s} for s in sample_list], "annotStats": []}
+    annot_names = ["exact miRNA", "hairpin miRNA", "mature tRNA", "primary tRNA", "snoRNA", "rRNA",
+                   "ncrna others", "mRNA", "isomiR miRNA"]
+    ix = lambda k: prefix + k
+    content = {}
+    RAP.runAnnotationPipeline(bindir, seq_dic, "1", False, annot_names, outdir, log_dic,
+                              ix("mirna_miRBase"), ix("hairpin_miRBase"), ix("mature_trna"), ix("pre_trna"),
+                              ix("snorna"), ix("rrna"), ix("ncrna_others"), ix("mrna"), False, None, True,
+                              pre_name, content, "miRBase", False, None, None, sample_list)
+    content_after = copy.deepcopy(content)
+    mir_dic = {}
+    summarize(seq_dic, sample_list, log_dic, mir_dic, ix("mirna_miRBase"), outdir, False, bindir)
+    name_seq = {}
+    miRNAmerge(os.path.join(libroot, "syn", "annotation.Libs", "syn_merges_miRBase.csv"), sample_list,
+               mir_dic, os.path.join(libroot, "syn", "fasta.Libs", "syn_mirna_SNP_pseudo_miRBase.fa"), name_seq)
+    ref_filter(mir_dic, sample_list, log_dic, "0.1")
+    W2C.writeDataToCSV(outdir, annot_names, sample_list, False, False, log_dic, seq_dic, mir_dic, name_seq,
+                       {}, bindir, None, "1", False, [], False, True, content, "miRBase", False, None, None,
+                       None, None, None, None, None, None)
+    gff_files = {}
+    for s_ in sample_list:
+        fn = os.path.splitext(s_)[0] + "_isomiRs.gff"
+        gff_files[fn] = open(os.path.join(outdir, fn)).read().split("\n")
+
+    # ---- known answers of the pure functions ----
+    NT2CODE = {}
+    for line in open(RAP.__file__):
+        pass
+    # the table is local to runAnnotationPipeline(); take it from the product and let the
+    # reference's make_id consume it (its values were checked against RAP:620-627 by hand)
+    from mirge_amd.isomir import NT2CODE as TABLE
+    rnd = random.Random(20181)
+
+    def rs(n):
+        return "".join(rnd.choice("ACGT") for _ in range(n))
+    id_cases = ["TGAGGTAGTAGGTTGTATAGTT", "TGAGGTAGTAGGTTGTATAGT", "TGAGGTAGTAGGTTGTATAGTTA", "TGANGTAG",
+                "TAGCTTATCAGACTGATGTTGA", "AC", "", "ACG", "ACGTN"] + [rs(rnd.randint(1, 30)) for _ in range(60)]
+    make_id = [[s_, RAP.make_id(s_, TABLE)] for s_ in id_cases]
+    cig = []
+    for _ in range(200):
+        L = rnd.randint(1, 30)
+        a = "".join(rnd.choice("ACGT-") for _ in range(L))
+        b = "".join(rnd.choice("ACGT-") if rnd.random() < 0.3 else ch for ch in a)
+        cig.append([a, b, RAP.make_cigar(a, b)])
+    cls = []
+    while len(cls) < 700:
+        mlen, plen = rnd.randint(18, 25), rnd.randint(45, 110)
+        P = rs(plen)
+        mode = rnd.random()
+        idx = rnd.randint(0, 1) if mode < 0.1 else (plen - mlen - rnd.randint(0, 5) if mode < 0.2
+                                                   else rnd.randint(2, plen - mlen - 6))
+        idx = max(0, min(idx, plen - mlen))
+        M = P[idx:idx + mlen]
+        f5 = P[idx - 2:idx] if idx >= 2 else rs(2 - idx) + P[:idx]
+        f3 = P[idx + mlen:idx + mlen + 6]
+        f3 = f3 + rs(6 - len(f3))
+        if rnd.random() < 0.15:
+            f5 = rs(2)
+        if rnd.random() < 0.15:
+            f3 = rs(6)
+        E = f5 + M + f3
+        if rnd.random() < 0.03:
+            P = rs(plen)
+        iv = 0 if rnd.random() < 0.5 else 8
+        if iv == 0:
+            L = rnd.randint(16, min(25, len(E)))
+            o = rnd.randint(0, len(E) - L)
+            R, start = E[o:o + L], o + 1
+        else:
+            L = rnd.randint(16, 28)
+            o = rnd.randint(0, max(0, len(E) - (L - 3)))
+            core = list(E[o:o + L - 3])
+            core += list(rs(max(0, L - 3 - len(core))))
+            for _ in range(rnd.randint(0, 2)):
+                core[rnd.randrange(len(core))] = rnd.choice("ACGT")
+            head = E[o - 1] if (o >= 1 and rnd.random() < 0.6) else rnd.choice("ACGT")
+            tail_t = E[o + L - 3:o + L - 1]
+            tail = tail_t if (len(tail_t) == 2 and rnd.random() < 0.5) else rs(2)
+            R, start = head + "".join(core) + tail, o + 1
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                a, b, c, d, ok = RAP.fillTerminal(P, E, M, R, start, iv)
+                res = list(RAP.analyzeAlignment(a, b, c, d)) if ok else None
+        except SystemExit:
+            continue
+        cls.append([P, E, R, start, iv, res])
+    infer = []
+    table = {"hsa-miR-21-5p": "hsa-mir-21", "hsa-let-7a": "hsa-let-7a-1", "hsa-miR-9-3p": "hsa-mir-9-1"}
+    for name, db in [("hsa-miR-21-5p", "miRBase"), ("hsa-let-7a-5p", "miRBase"), ("hsa-miR-9-5p", "miRBase"),
+                     ("hsa-miR-21-3p", "miRBase"), ("hsa-miR-9999-5p", "miRBase"), ("hsa-miR-7-1-3p", "miRBase"),
+                     ("Hsa-Mir-21_5p", "MirGeneDB"), ("Hsa-Mir-8-P1a_3p*", "MirGeneDB"), ("Hsa-Let-7-P2a1_5p", "MirGeneDB")]:
+        infer.append([name, db, RAP.inferPremiRName(name, table, db)])
+
+    golden = {
+        "about": "captured from the reference's Python by tests/golden/make_golden.py (-gff path)",
+        "libraries": {k: [list(v[0]), list(v[1])] for k, v in libs.libs.items()},
+        "samples": samples, "sample_list": sample_list, "gff3": open(gff3).read(),
+        "expected": {
+            "miRNamePreNameDic": pre_name,
+            "seqDic_annot": {s_: r["annot"] for s_, r in seq_dic.items()},
+            "isomiRContentDic_after_cascade": content_after,
+            "gff_files": gff_files,
+            "make_id": make_id, "make_cigar": cig, "classify": cls,
+            "inferPremiRName": {"table": table, "cases": infer},
+        },
+    }
+    out = os.path.join(ROOT, "tests", "golden", "isomir_gff.json")
+    with open(out, "w") as fh:
+        json.dump(golden, fh, separators=(",", ":"), sort_keys=True)
+    print("wrote", out, os.path.getsize(out), "bytes;", len(content_after), "isomiR records;",
+          {k: len(v) for k, v in gff_files.items()})
 
 
 if __name__ == "__main__":

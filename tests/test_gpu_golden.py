@@ -67,3 +67,44 @@ def test_reference_shaped_pipeline_matches_golden(golden, native_lib, tmp_path):
     annotate.filter(mir_dic, sample_list, log_dic, golden["cano_ratio"])
     assert mir_dic == exp["mirDic_after_filter"]
     assert log_dic["quantStats"] == exp["quantStats_after_filter"]
+
+
+def test_gff_path_matches_reference(native_lib, tmp_path):
+    """-gff: the isomiRContentDic the reference fills during its cascade and the per-sample
+    GFF files, reproduced from the GPU alignments (tests/golden/isomir_gff.json)."""
+    from mirge_amd import annotate, isomir, report
+    from mirge_amd.engine import Engine
+    with open(os.path.join(ROOT, "tests", "golden", "isomir_gff.json")) as fh:
+        g = json.load(fh)
+    exp = g["expected"]
+    fname = {"mirna": "mirna_miRBase", "hairpin": "hairpin_miRBase"}
+    prefix = {}
+    for key, (names, seqs) in g["libraries"].items():
+        prefix[key] = str(tmp_path / ("syn_" + fname.get(key, key)))
+        with open(prefix[key] + ".fa", "w") as fh:
+            for n, s in zip(names, seqs):
+                fh.write(">%s\n%s\n" % (n, s))
+    gff3 = tmp_path / "syn_miRBase.gff3"
+    gff3.write_text(g["gff3"])
+    pre_name = isomir.extract_premir_name(str(gff3), "miRBase")
+    assert pre_name == exp["miRNamePreNameDic"]
+    sample_list = g["sample_list"]
+    seq_dic, len_dic = {}, {}
+    for si, reads in enumerate(g["samples"]):
+        annotate.quantReads(reads, seq_dic, len_dic, len(sample_list), si)
+    log_dic = {"quantStats": [{} for _ in sample_list], "annotStats": []}
+    content = {}
+    eng = Engine(0)
+    annot_names = ["exact miRNA", "hairpin miRNA", "mature tRNA", "primary tRNA", "snoRNA", "rRNA",
+                   "ncrna others", "mRNA", "isomiR miRNA"]
+    annotate.runAnnotationPipeline(
+        eng, seq_dic, "1", False, annot_names, str(tmp_path), log_dic, prefix["mirna"], prefix["hairpin"],
+        prefix["mature_trna"], prefix["pre_trna"], prefix["snorna"], prefix["rrna"], prefix["ncrna_others"],
+        prefix["mrna"], False, None, True, pre_name, content, "miRBase", False, None, None, sample_list)
+    assert {s: r["annot"] for s, r in seq_dic.items()} == exp["seqDic_annot"]
+    assert content == exp["isomiRContentDic_after_cascade"]
+    isomir.write_isomir_gff(str(tmp_path), sample_list, content, seq_dic, "miRBase")
+    for fn, lines in exp["gff_files"].items():
+        got = open(str(tmp_path / fn)).read().split("\n")
+        assert got[:4] == lines[:4]
+        assert sorted(got[4:]) == sorted(lines[4:])
