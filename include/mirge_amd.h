@@ -207,6 +207,45 @@ int mrg_annotate_host(mrg_ctx *ctx, const uint64_t *reads, uint32_t words_per_re
                       uint32_t n_samples, uint32_t n_mirna, int32_t canon_pass,
                       int32_t isomir_pass, uint64_t *counts);
 
+/* ------------------------------------------------------------------ *
+ * Ingest: FASTQ -> packed reads (host), raw reads -> unique reads with
+ * per-sample counts (device).  Replaces trim_file with `-ad none`
+ * (utils/trim_file.py:89-134: 3' quality trimming at Q10, 16-nt minimum)
+ * and quantReads (utils/quantReads.py:3-24).
+ * ------------------------------------------------------------------ */
+typedef struct mrg_fastq mrg_fastq;
+typedef struct mrg_fastq_info {
+  uint64_t n_total;        /* records read ("totalReads") */
+  uint64_t n_kept;         /* records kept after trimming ("trimmedReads") */
+  int32_t phred;           /* 33 or 64, as trim_file.py:104-106 reports it */
+  uint32_t words_per_read; /* 1, 2 or 4 */
+  uint32_t max_len;
+  int32_t has_n;
+} mrg_fastq_info;
+/* Plain or gzip FASTQ.  qual_cutoff 10 and min_len 16 are the reference's values. */
+int mrg_fastq_load(const char *path, int32_t qual_cutoff, int32_t min_len, mrg_fastq **out);
+int mrg_fastq_get_info(const mrg_fastq *fq, mrg_fastq_info *info);
+/* Copy the packed reads out, widened to words_per_read words (>= the file's own);
+ * nmask may be NULL when has_n is 0. */
+int mrg_fastq_copy(const mrg_fastq *fq, uint32_t words_per_read, uint64_t *words, uint8_t *lens,
+                   uint64_t *nmask);
+void mrg_fastq_free(mrg_fastq *fq);
+
+/*
+ * Collapse n raw reads (device arrays, layout as for mrg_cascade_run; d_sample gives the
+ * sample of each read or is NULL for one sample) into unique reads:
+ *   d_u_reads [words_per_read][cap], d_u_lens [cap], d_u_nmask ([..][cap] or NULL),
+ *   d_quant [n_unique][n_samples] (uint32), d_len_hist [256][n_samples] (uint64, the
+ *   reference's readLengthDic), *n_unique on the host.  cap >= n is always enough.
+ * max_len is a hint (0 = unknown) that lets reads of <= 29 nt sort in one pass.
+ * Uniques come out ordered by (length, bases); the call synchronises `stream`.
+ */
+int mrg_collapse_run(mrg_ctx *ctx, const uint64_t *d_reads, uint32_t words_per_read,
+                     const uint8_t *d_lens, const uint64_t *d_nmask, const uint16_t *d_sample,
+                     uint64_t n, uint32_t n_samples, uint32_t max_len, uint64_t cap,
+                     uint64_t *d_u_reads, uint8_t *d_u_lens, uint64_t *d_u_nmask, uint32_t *d_quant,
+                     uint64_t *d_len_hist, uint64_t *n_unique, void *stream);
+
 /* Packing helper used by hosts without numpy: ASCII reads -> SoA words. */
 int mrg_pack_reads(const char *const *seqs, uint64_t n, uint32_t words_per_read,
                    uint64_t *reads, uint8_t *lens, uint64_t *nmask, int *has_n);

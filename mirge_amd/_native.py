@@ -41,6 +41,11 @@ class IndexInfo(C.Structure):
                 ("C", C.c_uint32 * 4), ("bytes_fm", C.c_uint64), ("bytes_sa", C.c_uint64)]
 
 
+class FastqInfo(C.Structure):
+    _fields_ = [("n_total", C.c_uint64), ("n_kept", C.c_uint64), ("phred", C.c_int32),
+                ("words_per_read", C.c_uint32), ("max_len", C.c_uint32), ("has_n", C.c_int32)]
+
+
 class IndexView(C.Structure):
     _fields_ = [("blocks", C.POINTER(C.c_uint32)), ("super", C.POINTER(C.c_uint32)),
                 ("text", C.POINTER(C.c_uint32)), ("sa", C.POINTER(C.c_uint64)),
@@ -85,6 +90,13 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PassStats),
                                     C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
                                     C.c_void_p]),
+    "mrg_fastq_load": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "mrg_fastq_get_info": (C.c_int, [C.c_void_p, C.POINTER(FastqInfo)]),
+    "mrg_fastq_copy": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mrg_fastq_free": (None, [C.c_void_p]),
+    "mrg_collapse_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
     "mrg_pack_reads": (C.c_int, [C.POINTER(C.c_char_p), C.c_uint64, C.c_uint32, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
 }

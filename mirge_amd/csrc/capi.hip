@@ -11,11 +11,15 @@
 #include <vector>
 
 #include "../../include/mirge_amd.h"
+#include "fastq.hpp"
 #include "fm_index.hpp"
 #include "kernels.hpp"
 
 struct mrg_index {
   mrg::FmIndex ix;
+};
+struct mrg_fastq {
+  mrg::FastqData d;
 };
 
 namespace {
@@ -607,6 +611,82 @@ int mrg_annotate_host(mrg_ctx* ctx, const uint64_t* reads, uint32_t words_per_re
     HIP_TRY(hipMemcpy(pos, d_pos, n * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(mm, d_mm, n, hipMemcpyDeviceToHost));
   }
+  return MRG_OK;
+}
+
+// -------------------------------------------------------------- ingest
+int mrg_fastq_load(const char* path, int32_t qual_cutoff, int32_t min_len, mrg_fastq** out) {
+  if (!path || !out) return fail(MRG_ERR_ARG, "mrg_fastq_load: null argument");
+  try {
+    auto h = std::make_unique<mrg_fastq>();
+    mrg::load_fastq(path, qual_cutoff, min_len, h->d);
+    *out = h.release();
+    return MRG_OK;
+  } catch (const std::bad_alloc&) {
+    return fail(MRG_ERR_NOMEM, "mrg_fastq_load: out of memory");
+  } catch (const std::exception& e) {
+    return fail(MRG_ERR_IO, "mrg_fastq_load: %s", e.what());
+  }
+}
+
+int mrg_fastq_get_info(const mrg_fastq* fq, mrg_fastq_info* info) {
+  if (!fq || !info) return fail(MRG_ERR_ARG, "mrg_fastq_get_info: null argument");
+  info->n_total = fq->d.n_total;
+  info->n_kept = fq->d.n_kept;
+  info->phred = fq->d.phred;
+  info->words_per_read = fq->d.words_per_read;
+  info->max_len = fq->d.max_len;
+  info->has_n = fq->d.has_n ? 1 : 0;
+  return MRG_OK;
+}
+
+int mrg_fastq_copy(const mrg_fastq* fq, uint32_t words_per_read, uint64_t* words, uint8_t* lens,
+                   uint64_t* nmask) {
+  if (!fq || (fq->d.n_kept && (!words || !lens))) return fail(MRG_ERR_ARG, "mrg_fastq_copy: null argument");
+  const mrg::FastqData& d = fq->d;
+  if (words_per_read < d.words_per_read || words_per_read > MRG_MAX_WORDS)
+    return fail(MRG_ERR_ARG, "mrg_fastq_copy: words_per_read %u, file needs %u", words_per_read, d.words_per_read);
+  if (d.has_n && !nmask) return fail(MRG_ERR_ARG, "mrg_fastq_copy: the file has N bases, nmask is required");
+  const size_t n = d.n_kept;
+  for (uint32_t w = 0; w < words_per_read; ++w) {
+    if (w < d.words_per_read) {
+      std::memcpy(words + (size_t)w * n, d.words.data() + (size_t)w * n, n * 8);
+      if (nmask) std::memcpy(nmask + (size_t)w * n, d.nmask.data() + (size_t)w * n, n * 8);
+    } else {
+      std::memset(words + (size_t)w * n, 0, n * 8);
+      if (nmask) std::memset(nmask + (size_t)w * n, 0, n * 8);
+    }
+  }
+  if (n) std::memcpy(lens, d.lens.data(), n);
+  return MRG_OK;
+}
+
+void mrg_fastq_free(mrg_fastq* fq) { delete fq; }
+
+int mrg_collapse_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_read, const uint8_t* d_lens,
+                     const uint64_t* d_nmask, const uint16_t* d_sample, uint64_t n, uint32_t n_samples,
+                     uint32_t max_len, uint64_t cap, uint64_t* d_u_reads, uint8_t* d_u_lens,
+                     uint64_t* d_u_nmask, uint32_t* d_quant, uint64_t* d_len_hist, uint64_t* n_unique,
+                     void* stream) {
+  if (!ctx || !n_unique || !d_len_hist) return fail(MRG_ERR_ARG, "mrg_collapse_run: null argument");
+  if (n && (!d_reads || !d_lens || !d_u_reads || !d_u_lens || !d_quant))
+    return fail(MRG_ERR_ARG, "mrg_collapse_run: null buffers");
+  if (n_samples == 0 || n_samples > 65535) return fail(MRG_ERR_ARG, "mrg_collapse_run: n_samples out of range");
+  if (n_samples > 1 && n && !d_sample) return fail(MRG_ERR_ARG, "mrg_collapse_run: d_sample required for >1 samples");
+  if (words_per_read == 0 || words_per_read > MRG_MAX_WORDS)
+    return fail(MRG_ERR_ARG, "mrg_collapse_run: bad words_per_read");
+  if (n >= 0x7fffffffull) return fail(MRG_ERR_ARG, "mrg_collapse_run: at most 2^31-2 reads per call");
+  if (d_nmask && !d_u_nmask) return fail(MRG_ERR_ARG, "mrg_collapse_run: d_u_nmask required with d_nmask");
+  HIP_TRY(hipSetDevice(ctx->device));
+  uint32_t nu = 0;
+  hipError_t e = mrg::collapse_reads(d_reads, words_per_read, d_lens, d_nmask, d_sample, (uint32_t)n, n_samples,
+                                     max_len, cap, d_u_reads, d_u_lens, d_u_nmask, d_quant, d_len_hist, &nu,
+                                     (hipStream_t)stream);
+  if (e == hipErrorInvalidValue)
+    return fail(MRG_ERR_ARG, "mrg_collapse_run: cap %llu is smaller than the number of unique reads",
+                (unsigned long long)cap);
+  if (e != hipSuccess) return fail(MRG_ERR_HIP, "mrg_collapse_run: %s", hipGetErrorString(e));
+  *n_unique = nu;
   return MRG_OK;
 }
 

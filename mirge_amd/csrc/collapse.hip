@@ -1,0 +1,251 @@
+// Collapse of raw reads into unique sequences with per-sample counts on the GPU.
+//
+// Reference role: quantReads (utils/quantReads.py:3-24) -- a Python dict keyed by the
+// read string, one increment per FASTQ record, plus the read-length histogram
+// (readLengthDic).  Here: stable LSD radix sort (hipCUB) of read ids by
+// (sample, packed words, N mask, length), head flags on the sorted order, a scan for
+// the unique id, and run lengths for the counts.  No atomics on read keys, so a
+// sequence that makes up 30 % of a sample (miRNA-seq is that skewed) costs nothing
+// extra, and the result is deterministic: uniques come out ordered by (length, bases).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace mrg {
+
+namespace {
+
+constexpr int kT = 256;
+
+__global__ void iota_kernel(uint32_t* idx, uint32_t n) {
+  uint32_t i = blockIdx.x * kT + threadIdx.x;
+  if (i < n) idx[i] = i;
+}
+
+// key[i] = column[idx[i]]  (column of uint64, uint16 or uint8, widened)
+template <class T>
+__global__ void gather_key_kernel(const T* __restrict__ col, const uint32_t* __restrict__ idx,
+                                  uint64_t* __restrict__ key, uint32_t n) {
+  uint32_t i = blockIdx.x * kT + threadIdx.x;
+  if (i < n) key[i] = (uint64_t)col[idx[i]];
+}
+
+// fused key for reads of at most 29 nt in one word: length in the top 6 bits
+__global__ void gather_fused_key_kernel(const uint64_t* __restrict__ words, const uint8_t* __restrict__ lens,
+                                        const uint32_t* __restrict__ idx, uint64_t* __restrict__ key,
+                                        uint32_t n) {
+  uint32_t i = blockIdx.x * kT + threadIdx.x;
+  if (i < n) {
+    const uint32_t r = idx[i];
+    key[i] = words[r] | ((uint64_t)lens[r] << 58);
+  }
+}
+
+struct CollapseCols {
+  const uint64_t* words;  // [W][n]
+  const uint64_t* nmask;  // [W][n] or null
+  const uint8_t* lens;
+  const uint16_t* sample;  // null when one sample
+  uint32_t W, n;
+};
+
+__device__ __forceinline__ bool same_read(const CollapseCols& c, uint32_t a, uint32_t b) {
+  if (c.lens[a] != c.lens[b]) return false;
+  for (uint32_t w = 0; w < c.W; ++w) {
+    if (c.words[(size_t)w * c.n + a] != c.words[(size_t)w * c.n + b]) return false;
+    if (c.nmask && c.nmask[(size_t)w * c.n + a] != c.nmask[(size_t)w * c.n + b]) return false;
+  }
+  return true;
+}
+
+// head flags on the sorted order: new unique read / new (read, sample) run
+__global__ void head_flags_kernel(CollapseCols c, const uint32_t* __restrict__ idx,
+                                  uint32_t* __restrict__ new_read, uint8_t* __restrict__ new_run) {
+  uint32_t i = blockIdx.x * kT + threadIdx.x;
+  if (i >= c.n) return;
+  bool nr = true, ns = true;
+  if (i > 0) {
+    const uint32_t a = idx[i], b = idx[i - 1];
+    nr = !same_read(c, a, b);
+    ns = nr || (c.sample && c.sample[a] != c.sample[b]);
+  }
+  new_read[i] = nr ? 1u : 0u;
+  new_run[i] = ns ? 1u : 0u;
+}
+
+// one thread per (read, sample) run: its length is the count
+__global__ void emit_kernel(CollapseCols c, const uint32_t* __restrict__ idx,
+                            const uint32_t* __restrict__ uid_incl, const uint32_t* __restrict__ run_start,
+                            const uint32_t* __restrict__ n_runs_ptr, uint32_t n_samples, uint64_t cap,
+                            uint64_t* __restrict__ u_words, uint8_t* __restrict__ u_lens,
+                            uint64_t* __restrict__ u_nmask, uint32_t* __restrict__ quant) {
+  const uint32_t k = blockIdx.x * kT + threadIdx.x;
+  const uint32_t n_runs = *n_runs_ptr;
+  if (k >= n_runs) return;
+  const uint32_t i = run_start[k];
+  const uint32_t end = (k + 1 < n_runs) ? run_start[k + 1] : c.n;
+  const uint32_t r = idx[i];
+  const uint32_t uid = uid_incl[i] - 1;
+  const uint32_t s = c.sample ? c.sample[r] : 0u;
+  quant[(size_t)uid * n_samples + s] = end - i;
+  // the first run of a unique read also writes the read itself
+  if (i == 0 || uid_incl[i - 1] != uid_incl[i]) {
+    u_lens[uid] = c.lens[r];
+    for (uint32_t w = 0; w < c.W; ++w) {
+      u_words[(size_t)w * cap + uid] = c.words[(size_t)w * c.n + r];
+      if (u_nmask) u_nmask[(size_t)w * cap + uid] = c.nmask ? c.nmask[(size_t)w * c.n + r] : 0ull;
+    }
+  }
+}
+
+// readLengthDic (QNT:17-21): reads per (length, sample).  Nearly every read has the
+// same length, so the bins are privatised in LDS per workgroup (one hot global
+// address would serialise at ~11 ns per atomic).
+template <bool LDSH>
+__global__ void length_hist_kernel(const uint8_t* __restrict__ lens, const uint16_t* __restrict__ sample,
+                                   uint32_t n, uint32_t n_samples, unsigned long long* __restrict__ hist) {
+  extern __shared__ uint32_t lhist[];
+  const uint32_t bins = 256u * n_samples;
+  if (LDSH) {
+    for (uint32_t b = threadIdx.x; b < bins; b += kT) lhist[b] = 0u;
+    __syncthreads();
+  }
+  for (uint32_t i = blockIdx.x * kT + threadIdx.x; i < n; i += gridDim.x * kT) {
+    const uint32_t b = (uint32_t)lens[i] * n_samples + (sample ? sample[i] : 0u);
+    if (LDSH) atomicAdd(&lhist[b], 1u);
+    else atomicAdd(&hist[b], 1ull);
+  }
+  if (LDSH) {
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < bins; b += kT)
+      if (lhist[b]) atomicAdd(&hist[b], (unsigned long long)lhist[b]);
+  }
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  template <class T>
+  T* as() {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+#define CK(expr)                       \
+  do {                                 \
+    hipError_t e_ = (expr);            \
+    if (e_ != hipSuccess) return e_;   \
+  } while (0)
+
+}  // namespace
+
+hipError_t collapse_reads(const uint64_t* d_reads, uint32_t W, const uint8_t* d_lens,
+                          const uint64_t* d_nmask, const uint16_t* d_sample, uint32_t n,
+                          uint32_t n_samples, uint32_t max_len, uint64_t cap, uint64_t* d_u_words,
+                          uint8_t* d_u_lens, uint64_t* d_u_nmask, uint32_t* d_quant,
+                          uint64_t* d_len_hist, uint32_t* h_n_unique, hipStream_t stream) {
+  *h_n_unique = 0;
+  CK(hipMemsetAsync(d_len_hist, 0, (size_t)256 * n_samples * 8, stream));
+  if (n == 0) return hipStreamSynchronize(stream);
+  const uint32_t grid = (n + kT - 1) / kT;
+  DevBuf idx0, idx1, key0, key1, flags_read, flags_run, uid, starts, n_runs, temp;
+  CK(idx0.alloc((size_t)n * 4));
+  CK(idx1.alloc((size_t)n * 4));
+  CK(key0.alloc((size_t)n * 8));
+  CK(key1.alloc((size_t)n * 8));
+  CK(flags_read.alloc((size_t)n * 4));
+  CK(flags_run.alloc((size_t)n));
+  CK(uid.alloc((size_t)n * 4));
+  CK(starts.alloc((size_t)n * 4));
+  CK(n_runs.alloc(4));
+
+  hipcub::DoubleBuffer<uint64_t> keys(key0.as<uint64_t>(), key1.as<uint64_t>());
+  hipcub::DoubleBuffer<uint32_t> vals(idx0.as<uint32_t>(), idx1.as<uint32_t>());
+  size_t temp_bytes = 0, need = 0;
+  CK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys, vals, (int)n, 0, 64, stream));
+  temp_bytes = need;
+  CK(hipcub::DeviceScan::InclusiveSum(nullptr, need, flags_read.as<uint32_t>(), uid.as<uint32_t>(), (int)n, stream));
+  if (need > temp_bytes) temp_bytes = need;
+  CK(hipcub::DeviceSelect::Flagged(nullptr, need, hipcub::CountingInputIterator<uint32_t>(0),
+                                   flags_run.as<uint8_t>(), starts.as<uint32_t>(), n_runs.as<uint32_t>(),
+                                   (int)n, stream));
+  if (need > temp_bytes) temp_bytes = need;
+  CK(temp.alloc(temp_bytes));
+
+  hipLaunchKernelGGL(iota_kernel, dim3(grid), dim3(kT), 0, stream, vals.Current(), n);
+
+  auto sort_pass = [&](int bits) -> hipError_t {
+    size_t tb = temp_bytes;
+    return hipcub::DeviceRadixSort::SortPairs(temp.p, tb, keys, vals, (int)n, 0, bits, stream);
+  };
+  // least significant column first (stable sorts): sample, words, N mask, length
+  if (d_sample && n_samples > 1) {
+    hipLaunchKernelGGL(gather_key_kernel<uint16_t>, dim3(grid), dim3(kT), 0, stream, d_sample, vals.Current(),
+                       keys.Current(), n);
+    CK(sort_pass(16));
+  }
+  const bool fused = (W == 1 && max_len > 0 && max_len <= 29 && !d_nmask);
+  if (fused) {
+    hipLaunchKernelGGL(gather_fused_key_kernel, dim3(grid), dim3(kT), 0, stream, d_reads, d_lens,
+                       vals.Current(), keys.Current(), n);
+    CK(sort_pass(64));
+  } else {
+    for (uint32_t w = 0; w < W; ++w) {
+      hipLaunchKernelGGL(gather_key_kernel<uint64_t>, dim3(grid), dim3(kT), 0, stream,
+                         d_reads + (size_t)w * n, vals.Current(), keys.Current(), n);
+      CK(sort_pass(64));
+    }
+    if (d_nmask)
+      for (uint32_t w = 0; w < W; ++w) {
+        hipLaunchKernelGGL(gather_key_kernel<uint64_t>, dim3(grid), dim3(kT), 0, stream,
+                           d_nmask + (size_t)w * n, vals.Current(), keys.Current(), n);
+        CK(sort_pass(64));
+      }
+    hipLaunchKernelGGL(gather_key_kernel<uint8_t>, dim3(grid), dim3(kT), 0, stream, d_lens, vals.Current(),
+                       keys.Current(), n);
+    CK(sort_pass(8));
+  }
+
+  CollapseCols c{d_reads, d_nmask, d_lens, (d_sample && n_samples > 1) ? d_sample : nullptr, W, n};
+  hipLaunchKernelGGL(head_flags_kernel, dim3(grid), dim3(kT), 0, stream, c, vals.Current(),
+                     flags_read.as<uint32_t>(), flags_run.as<uint8_t>());
+  {
+    size_t tb = temp_bytes;
+    CK(hipcub::DeviceScan::InclusiveSum(temp.p, tb, flags_read.as<uint32_t>(), uid.as<uint32_t>(), (int)n, stream));
+    tb = temp_bytes;
+    CK(hipcub::DeviceSelect::Flagged(temp.p, tb, hipcub::CountingInputIterator<uint32_t>(0),
+                                     flags_run.as<uint8_t>(), starts.as<uint32_t>(), n_runs.as<uint32_t>(),
+                                     (int)n, stream));
+  }
+  uint32_t n_unique = 0;
+  CK(hipMemcpyAsync(&n_unique, uid.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+  CK(hipStreamSynchronize(stream));
+  if (n_unique > cap) return hipErrorInvalidValue;
+  CK(hipMemsetAsync(d_quant, 0, (size_t)n_unique * n_samples * 4, stream));
+  hipLaunchKernelGGL(emit_kernel, dim3(grid), dim3(kT), 0, stream, c, vals.Current(), uid.as<uint32_t>(),
+                     starts.as<uint32_t>(), n_runs.as<uint32_t>(), n_samples, cap, d_u_words, d_u_lens,
+                     d_u_nmask, d_quant);
+  {
+    const uint16_t* smp = (d_sample && n_samples > 1) ? d_sample : nullptr;
+    auto* hist = reinterpret_cast<unsigned long long*>(d_len_hist);
+    const uint32_t lds = 256u * n_samples * 4u;
+    if (lds <= 48u * 1024u)
+      hipLaunchKernelGGL(length_hist_kernel<true>, dim3(min(grid, 1024u)), dim3(kT), lds, stream, d_lens, smp,
+                         n, n_samples, hist);
+    else
+      hipLaunchKernelGGL(length_hist_kernel<false>, dim3(min(grid, 1024u)), dim3(kT), 0, stream, d_lens, smp,
+                         n, n_samples, hist);
+  }
+  CK(hipGetLastError());
+  CK(hipStreamSynchronize(stream));
+  *h_n_unique = n_unique;
+  return hipSuccess;
+}
+
+}  // namespace mrg

@@ -71,6 +71,12 @@ hipError_t launch_match(const MatchParams& p, uint32_t words_per_read, int lds_m
                         uint32_t grid, uint32_t lds_bytes, hipStream_t stream);
 hipError_t launch_tally(const TallyParams& p, bool lds_hist, uint32_t grid,
                         uint32_t lds_bytes, hipStream_t stream);
+// collapse.hip: raw reads -> unique reads + per-sample counts + length histogram
+hipError_t collapse_reads(const uint64_t* d_reads, uint32_t W, const uint8_t* d_lens,
+                          const uint64_t* d_nmask, const uint16_t* d_sample, uint32_t n,
+                          uint32_t n_samples, uint32_t max_len, uint64_t cap, uint64_t* d_u_words,
+                          uint8_t* d_u_lens, uint64_t* d_u_nmask, uint32_t* d_quant,
+                          uint64_t* d_len_hist, uint32_t* h_n_unique, hipStream_t stream);
 hipError_t launch_export_pass_counts(const uint64_t* stats, uint32_t n_pass, uint64_t* out,
                                      hipStream_t stream);
 

@@ -1,0 +1,110 @@
+"""FASTQ ingest (host, CPU test) and GPU collapse against the oracle and the vectors
+captured from the reference's quantReads."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from mirge_amd import ingest, pack
+from oracle import cascade
+from oracle import ingest as oingest
+from tests.conftest import ROOT
+
+
+def write_fastq(path, rng, n, phred_base=33, gz=False, first_hi=False):
+    opener = gzip.open if gz else open
+    with opener(path, "wt") as fh:
+        for i in range(n):
+            L = int(rng.integers(10, 60))
+            seq = "".join("ACGTN"[int(c)] for c in rng.choice(5, L, p=[0.245, 0.245, 0.245, 0.245, 0.02]))
+            q = rng.integers(20, 41, L)
+            cut = int(rng.integers(0, L + 1))
+            q[cut:] = rng.integers(0, 14, L - cut)       # a low-quality tail
+            if rng.random() < 0.2:
+                q[int(rng.integers(0, L))] = 2             # an isolated bad base
+            if first_hi and i == 0:
+                q[:] = 45                                    # chr > 74 at base 33 -> "phred64" sniffed
+            fh.write("@r%d extra\n%s\n+\n%s\n" % (i, seq, "".join(chr(int(x) + phred_base) for x in q)))
+
+
+@pytest.mark.parametrize("gz,first_hi", [(False, False), (True, False), (False, True)])
+def test_fastq_loader_matches_oracle(native_lib, tmp_path, gz, first_hi):
+    rng = np.random.default_rng(3)
+    p = str(tmp_path / ("x.fastq.gz" if gz else "x.fastq"))
+    write_fastq(p, rng, 3000, gz=gz, first_hi=first_hi)
+    want, total, phred = oingest.load_fastq(p)
+    got = ingest.load_fastq(p)
+    assert (got["total"], got["kept"], got["phred"]) == (total, len(want), phred)
+    assert pack.unpack_reads(got["words"], got["lens"], got["nmask"]) == want
+    assert 0 < len(want) < total
+
+
+def test_quality_trim_rule_known_answers():
+    q = lambda s: "".join(chr(x + 33) for x in s)
+    t = oingest.quality_trim_3p
+    assert t(q([30] * 20)) == 20                    # nothing to trim
+    assert t(q([30] * 15 + [2] * 5)) == 15          # low tail goes
+    assert t(q([30] * 10 + [5, 30, 5, 5])) == 12    # the walk stops at the first good base
+    assert t(q([30] * 10 + [5, 12, 5, 5])) == 10    # a mediocre base does not rescue the tail
+    assert t(q([30] * 10 + [5, 30, 30, 30, 5])) == 14
+    assert t(q([2] * 8)) == 0
+    assert t("") == 0
+
+
+def test_fastq_errors(native_lib, tmp_path):
+    from mirge_amd._native import MirgeAmdError
+    bad = tmp_path / "bad.fastq"
+    bad.write_text("@r0\nACGT\n+\nII\n")
+    with pytest.raises(MirgeAmdError):
+        ingest.load_fastq(str(bad))
+    with pytest.raises(MirgeAmdError):
+        ingest.load_fastq(str(tmp_path / "missing.fastq"))
+
+
+@pytest.mark.gpu
+def test_gpu_collapse_matches_quantReads_golden(native_lib):
+    from mirge_amd.engine import Engine
+    with open(os.path.join(ROOT, "tests", "golden", "cascade_small.json")) as fh:
+        g = json.load(fh)
+    reads, sample = [], []
+    for si, rs in enumerate(g["samples"]):
+        reads += rs
+        sample += [si] * len(rs)
+    order = np.random.default_rng(1).permutation(len(reads))
+    reads = [reads[i] for i in order]
+    sample = np.array(sample, dtype=np.uint16)[order]
+    words, lens, nmask = pack.pack_reads(reads)
+    eng = Engine(0)
+    out = ingest.collapse(eng, words, lens, nmask, sample, n_samples=2)
+    uniq = pack.unpack_reads(out["words"], out["lens"], out["nmask"])
+    exp = g["expected"]["seqDic"]
+    assert len(uniq) == len(set(uniq)) == len(exp)
+    for s, q in zip(uniq, out["quant"]):
+        assert [int(x) for x in q] == exp[s]["quant"], s
+    assert {str(k): v for k, v in out["length_hist"].items()} == g["expected"]["readLengthDic"]
+    # deterministic order: by length, then packed bases
+    keys = [(int(l), [int(w) for w in out["words"][::-1, i]]) for i, l in enumerate(out["lens"])]
+    assert all(keys[i][0] <= keys[i + 1][0] for i in range(len(keys) - 1))
+
+
+@pytest.mark.gpu
+def test_gpu_collapse_fused_and_general_paths(native_lib):
+    from mirge_amd import synth
+    from mirge_amd.engine import Engine
+    eng = Engine(0)
+    libs = synth.SynthLibraries(scale=0.02)
+    w = synth.synth_reads_packed(libs, 300000, zipf_s=1.3)
+    lens = np.full(w.shape[0], 22, dtype=np.uint8)
+    for n_samples in (1, 3):
+        sample = (np.arange(w.shape[0]) % n_samples).astype(np.uint16)
+        want, _ = cascade.collapse([[int(x) for x in w[sample == s]] for s in range(n_samples)])
+        for max_len in (22, 0):   # 22 -> single fused 64-bit sort; 0 -> general multi-pass path
+            out = ingest.collapse(eng, w[None, :], lens, None, sample, n_samples=n_samples, max_len=max_len)
+            assert out["words"].shape[1] == len(want)
+            for key, q in zip(out["words"][0], out["quant"]):
+                assert [int(x) for x in q] == want[int(key)]["quant"]
+    # empty input
+    out = ingest.collapse(eng, np.zeros((1, 0), np.uint64), np.zeros(0, np.uint8))
+    assert out["words"].shape == (1, 0) and out["quant"].shape[0] == 0
