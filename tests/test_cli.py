@@ -1,0 +1,95 @@
+"""The annotate command line: flag surface (CPU) and an end-to-end run from FASTQ files on
+the GPU, checked table by table against the oracle pipeline."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+from mirge_amd import cli
+
+
+def test_annotate_flags_match_reference_parser():
+    """parseArgument.py:31-53: same flags, string-typed -cpu / -ex defaults."""
+    ap = cli.build_parser()
+    a = ap.parse_args(["annotate", "-s", "a.fastq", "b.fastq.gz", "-lib", "/L", "-sp", "human", "-pb", "/x"])
+    assert a.sampleList == ["a.fastq", "b.fastq.gz"] and a.cpu == "1" and a.canoRatio == "0.1"
+    assert a.miRNA_database == "miRBase" and a.adapter == "none" and not a.gff_output
+    a = ap.parse_args(["annotate", "-s", "x.fastq", "-lib", "/L", "-sp", "mouse", "-d", "MirGeneDB", "-ex", "0.2",
+                       "-di", "-gff", "-tcf", "-cpu", "4", "-phred64", "-ai", "-trf", "-spikeIn"])
+    assert (a.miRNA_database, a.canoRatio, a.cpu) == ("MirGeneDB", "0.2", "4")
+    assert a.diff_isomirs and a.gff_output and a.trimmed_collapsed_fa and a.phred64 and a.a_to_i
+
+
+def test_sample_list_resolution(tmp_path):
+    f1, f2 = tmp_path / "a.fastq", tmp_path / "b.fastq.gz"
+    f1.write_text("")
+    f2.write_text("")
+    assert cli.resolve_samples([str(f1), str(f2)]) == [str(f1), str(f2)]
+    lst = tmp_path / "samples.txt"
+    lst.write_text("%s\n%s\n%s\n" % (f1, f2, f1))
+    assert cli.resolve_samples([str(lst)]) == [str(f1), str(f2)]
+    with pytest.raises(SystemExit):
+        cli.resolve_samples([str(tmp_path / "missing.fastq")])
+    with pytest.raises(SystemExit):
+        cli.resolve_samples([str(f1), str(lst)])
+
+
+def write_fastq(path, reads, rng):
+    with open(path, "w") as fh:
+        for i, r in enumerate(reads):
+            q = rng.integers(25, 41, len(r))
+            if rng.random() < 0.3:                       # a low-quality 3' tail that gets trimmed
+                r = r + "ACGT"[int(rng.integers(0, 4))] * 3
+                q = np.concatenate([q, [2, 2, 2]])
+            fh.write("@r%d\n%s\n+\n%s\n" % (i, r, "".join(chr(int(x) + 33) for x in q)))
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_against_oracle(native_lib, oracle_lib, tmp_path):
+    from mirge_amd import report, synth
+    from oracle import cascade, ingest as oingest, model
+    from tests.golden.make_golden import SHAPES
+    rng = np.random.default_rng(8)
+    libs = synth.SynthLibraries(seed=123, scale=1.0, n_paralogs=6, n_snp=8, shapes=SHAPES)
+    libs.write_layout(str(tmp_path / "libs"), species="syn", db="miRBase")
+    fastqs = []
+    for si in range(2):
+        reads = [synth.codes_to_str(c) for c in synth.synth_reads(libs, 1500, seed=40 + si, zipf_s=1.3)]
+        reads += ["ACGTNACGTTAGCATCGATCGA", "TTTTTTTTTTTTTTTTTTTT", "ACGTACGTAC"]      # N, poly-T, too short
+        p = str(tmp_path / ("s%d.fastq" % si))
+        write_fastq(p, reads, rng)
+        fastqs.append(p)
+    out = cli.annotate_main(cli.build_parser().parse_args(
+        ["annotate", "-s"] + fastqs + ["-lib", str(tmp_path / "libs"), "-sp", "syn", "-o", str(tmp_path),
+                                       "-di", "-tcf"]))
+    # ---- the same run through the oracle ----
+    kept = [oingest.load_fastq(p)[0] for p in fastqs]
+    seq_dic, len_dic = cascade.collapse(kept)
+    olibs = {k: model.Library(*libs.libs[k]) for k in libs.libs}
+    log = {"quantStats": [{} for _ in fastqs], "annotStats": []}
+    cascade.run_annotation_pipeline(seq_dic, olibs, log)
+    mir = {}
+    cascade.summarize(seq_dic, ["s0.fastq", "s1.fastq"], log, mir, olibs["mirna"].names)
+    cascade.mirna_merge(libs.merges, ["s0.fastq", "s1.fastq"], mir)
+    cascade.filter_mirnas(mir, ["s0.fastq", "s1.fastq"], log, "0.1")
+    assert {s: r["annot"] for s, r in out["seqDic"].items()} == {s: r["annot"] for s, r in seq_dic.items()}
+    assert {s: r["quant"] for s, r in out["seqDic"].items()} == {s: r["quant"] for s, r in seq_dic.items()}
+    assert out["mirDic"] == mir
+    assert out["readLengthDic"] == len_dic
+    for a, b in zip(out["logDic"]["quantStats"], log["quantStats"]):
+        for k, v in b.items():
+            assert a[k] == v, k
+    for a, b in zip(out["logDic"]["annotStats"], log["annotStats"]):
+        assert (a["readsProcessed"], a["readsAligned"]) == (b["readsProcessed"], b["readsAligned"])
+    # ---- files: written by the (golden-tested) writers from identical state ----
+    want_dir = tmp_path / "want"
+    want_dir.mkdir()
+    wl = copy.deepcopy(out["logDic"])
+    report.writeDataToCSV(str(want_dir), cli.ANNOT_NAMES, ["s0.fastq", "s1.fastq"], True, False, wl, seq_dic, mir)
+    for fn in ("mapped.csv", "unmapped.csv", "miR.Counts.csv", "miR.RPM.csv", "isomirs.csv", "isomirs.samples.csv"):
+        got = sorted(open(os.path.join(out["outdir"], fn)).read().split("\n"))
+        assert got == sorted(open(str(want_dir / fn)).read().split("\n")), fn
+    rep = open(os.path.join(out["outdir"], "annotation.report.csv")).read().split("\n")
+    assert rep[1].split(",")[:3] == ["s0.fastq", "1503", str(len(kept[0]))]
+    assert os.path.exists(os.path.join(out["outdir"], "s0.trim.collapse.fa"))

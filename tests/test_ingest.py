@@ -99,12 +99,16 @@ def test_gpu_collapse_fused_and_general_paths(native_lib):
     lens = np.full(w.shape[0], 22, dtype=np.uint8)
     for n_samples in (1, 3):
         sample = (np.arange(w.shape[0]) % n_samples).astype(np.uint16)
-        want, _ = cascade.collapse([[int(x) for x in w[sample == s]] for s in range(n_samples)])
+        # a dict keyed by the read, one increment per record, as quantReads.py:9-16 does
+        want = {}
+        for key, s in zip(w.tolist(), sample.tolist()):
+            want.setdefault(key, [0] * n_samples)[s] += 1
         for max_len in (22, 0):   # 22 -> single fused 64-bit sort; 0 -> general multi-pass path
             out = ingest.collapse(eng, w[None, :], lens, None, sample, n_samples=n_samples, max_len=max_len)
             assert out["words"].shape[1] == len(want)
-            for key, q in zip(out["words"][0], out["quant"]):
-                assert [int(x) for x in q] == want[int(key)]["quant"]
+            for key, q in zip(out["words"][0].tolist(), out["quant"].tolist()):
+                assert q == want[key]
+            assert out["length_hist"] == {22: [int((sample == s).sum()) for s in range(n_samples)]}
     # empty input
     out = ingest.collapse(eng, np.zeros((1, 0), np.uint64), np.zeros(0, np.uint8))
     assert out["words"].shape == (1, 0) and out["quant"].shape[0] == 0
