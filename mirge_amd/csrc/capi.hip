@@ -352,7 +352,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     const mrg_pass_cfg& c = passes[i];
     if (c.lib < 0 || (size_t)c.lib >= ctx->libs.size())
       return fail(MRG_ERR_ARG, "mrg_cascade_run: pass %u names unknown library %d", i, c.lib);
-    if (c.max_mm_seed < 0 || c.max_mm_seed > 2 || c.max_mm_total < c.max_mm_seed || c.trim5 < 0 ||
+    if (c.max_mm_seed < 0 || c.max_mm_seed > 3 || c.max_mm_total < c.max_mm_seed || c.trim5 < 0 ||
         c.trim5 > 31 || c.trim3 < 0 || c.seed_len < 1)
       return fail(MRG_ERR_ARG, "mrg_cascade_run: pass %u has an invalid policy", i);
   }

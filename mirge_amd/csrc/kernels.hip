@@ -26,7 +26,6 @@ namespace mrg {
 namespace {
 
 constexpr uint64_t kOdd = 0x5555555555555555ull;
-constexpr int kMaxPieces = 3;  // pass 9 of the cascade (-v 2) needs three
 
 __device__ __forceinline__ uint64_t low_bits(uint32_t nbits) {
   // nbits in [0,64]
@@ -222,53 +221,34 @@ match_kernel(const MatchParams p) {
     if (eligible && L > p.max_mm_seed) {
       const int32_t R = min(L, p.seed_len);
       const int32_t K = p.max_mm_seed + 1;
-      // The K (<= kMaxPieces) pigeonhole pieces of a read are independent, and the kernel
-      // is bound by the latency of dependent gathers, so they advance together: all
-      // jump-table loads first, then the (few) remaining LF steps piece by piece, then ONE
-      // merged loop over the candidate rows so the suffix-array rows and text windows of
-      // different pieces are in flight at the same time.
-      int32_t pa[kMaxPieces], pj[kMaxPieces];
-      uint32_t plo[kMaxPieces], phi[kMaxPieces];
-      uint2 tab[kMaxPieces];
-      bool live[kMaxPieces], via_tab[kMaxPieces];
-#pragma unroll
-      for (int k = 0; k < kMaxPieces; ++k) {
-        live[k] = k < K;
-        pa[k] = live[k] ? (R * k) / K : 0;
-        const int32_t b = live[k] ? (R * (k + 1)) / K : 0;
-        pj[k] = b;
-        if (live[k] && p.nmask) {
+      for (int32_t k = 0; k < K; ++k) {
+        const int32_t a = (R * k) / K, b = (R * (k + 1)) / K;
+        if (p.nmask) {
           // a piece holding an N can never be the exact one
           bool has_n = false;
 #pragma unroll
           for (int w = 0; w < W; ++w) {
-            const int32_t lo_b = max(pa[k] - 32 * w, 0), hi_b = min(b - 32 * w, 32);
+            const int32_t lo_b = max(a - 32 * w, 0), hi_b = min(b - 32 * w, 32);
             if (hi_b > lo_b) has_n |= (nm[w] & low_bits(2 * hi_b) & ~low_bits(2 * lo_b)) != 0ull;
           }
-          live[k] = !has_n;
+          if (has_n) continue;
         }
-        via_tab[k] = live[k] && p.ftab_k && b - pa[k] >= (int32_t)p.ftab_k;
-        tab[k] = make_uint2(0u, 0u);
-        if (via_tab[k]) {
+        // ---- exact backward search of read[a,b) ----
+        uint32_t lo = 0, hi = p.n + 1;
+        int32_t j = b;
+        if (p.ftab_k && b - a >= (int32_t)p.ftab_k) {
           // the piece's last k bases in one load: BWT interval of that k-mer
-          const int32_t j = b - (int32_t)p.ftab_k;
+          j = b - (int32_t)p.ftab_k;
           uint64_t code = pick_word<W>(rd, (uint32_t)j >> 5) >> ((j & 31) * 2);
           if (W > 1 && (j & 31) + (int32_t)p.ftab_k > 32)
             code |= pick_word<W>(rd, ((uint32_t)j >> 5) + 1) << (64 - (j & 31) * 2);
           code &= (1ull << (2 * p.ftab_k)) - 1ull;
-          tab[k] = *reinterpret_cast<const uint2*>(p.ftab + 2 * code);
-          pj[k] = j;
+          const uint2 iv = *reinterpret_cast<const uint2*>(p.ftab + 2 * code);
+          lo = iv.x;
+          hi = iv.y;
           ++c_lookups;
         }
-      }
-      uint32_t wmax = 0;
-#pragma unroll
-      for (int k = 0; k < kMaxPieces; ++k) {
-        // ---- exact backward search of what the jump table left of read[a,b) ----
-        uint32_t lo = via_tab[k] ? tab[k].x : 0u;
-        uint32_t hi = via_tab[k] ? tab[k].y : (live[k] ? p.n + 1 : 0u);
-        int32_t j = pj[k];
-        while (j > pa[k] && hi > lo && (hi - lo) > p.wstop) {
+        while (j > a && hi > lo && (hi - lo) > p.wstop) {
           --j;
           const uint32_t c = (uint32_t)(pick_word<W>(rd, (uint32_t)j >> 5) >> ((j & 31) * 2)) & 3u;
           const uint4 vl = lib.block(lo >> 5);
@@ -278,44 +258,20 @@ match_kernel(const MatchParams p) {
           hi = lib.lf(c, hi, vh);
           ++c_steps;
         }
-        if (hi < lo) hi = lo;
-        plo[k] = lo;
-        phi[k] = hi;
-        pj[k] = j;
-        wmax = max(wmax, hi - lo);
-      }
-      // ---- locate + verify: row t of every piece per trip ----
-      for (uint32_t t = 0; t < wmax; ++t) {
-        uint64_t row[kMaxPieces];
-        bool ok[kMaxPieces];
-#pragma unroll
-        for (int k = 0; k < kMaxPieces; ++k) {
-          ok[k] = plo[k] + t < phi[k];
-          row[k] = ok[k] ? p.sa[plo[k] + t] : 0ull;
-        }
-        uint32_t s_[kMaxPieces];
-        uint64_t win[kMaxPieces][W];
-#pragma unroll
-        for (int k = 0; k < kMaxPieces; ++k) {
-          if (ok[k]) {
-            ++c_cands;
-            // the alignment [pos - j, pos - j + L) must stay inside the N-free segment
-            const uint32_t before = (uint32_t)(row[k] >> 32) & 255u, after = (uint32_t)(row[k] >> 40) & 255u;
-            ok[k] = (uint32_t)pj[k] <= before && (uint32_t)(L - pj[k]) <= after;
-          }
-          s_[k] = (uint32_t)row[k] - (uint32_t)pj[k];
-#pragma unroll
-          for (int w = 0; w < W; ++w) win[k][w] = (ok[k] && L > 32 * w) ? lib.window(s_[k] + 32u * w) : 0ull;
-        }
-#pragma unroll
-        for (int k = 0; k < kMaxPieces; ++k) {
-          if (!ok[k]) continue;
+        // ---- locate + verify every occurrence ----
+        for (uint32_t i = lo; i < hi; ++i) {
+          const uint64_t row = p.sa[i];
+          ++c_cands;
+          // the alignment [pos - j, pos - j + L) must stay inside the N-free segment
+          const uint32_t before = (uint32_t)(row >> 32) & 255u, after = (uint32_t)(row >> 40) & 255u;
+          if ((uint32_t)j > before || (uint32_t)(L - j) > after) continue;
+          const uint32_t s = (uint32_t)row - (uint32_t)j;
           uint32_t mm_total = 0, mm_seed = 0;
 #pragma unroll
           for (int w = 0; w < W; ++w) {
             const int32_t nb = min(32, L - 32 * w);
             if (nb > 0) {
-              const uint64_t x = win[k][w] ^ rd[w];
+              const uint64_t x = lib.window(s + 32u * w) ^ rd[w];
               const uint64_t m = (((x | (x >> 1)) & kOdd) | nm[w]) & low_bits(2 * nb);
               mm_total += (uint32_t)__popcll(m);
               const int32_t ns = min(nb, max(0, p.seed_len - 32 * w));
@@ -323,14 +279,14 @@ match_kernel(const MatchParams p) {
             }
           }
           if ((int32_t)mm_seed > p.max_mm_seed || (int32_t)mm_total > p.max_mm_total) continue;
-          const uint64_t key = ((uint64_t)mm_total << 32) | s_[k];
+          const uint64_t key = ((uint64_t)mm_total << 32) | s;
           if (key < best) {
-            const uint32_t before = (uint32_t)(row[k] >> 32) & 255u;
             best = key;
-            best_seg = (uint32_t)(row[k] >> 48);
-            best_before = before < 255u ? before - (uint32_t)pj[k] : 255u;
+            best_seg = (uint32_t)(row >> 48);
+            best_before = before < 255u ? before - (uint32_t)j : 255u;
           }
         }
+        if ((best >> 32) == 0ull) break;  // an exact hit is always seen by piece 0
       }
     }
 

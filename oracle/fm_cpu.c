@@ -121,6 +121,7 @@ static int match_one(const orc_lib *l, const orc_pass *p, const uint64_t *rd, co
       uint64_t cand = ((uint64_t)mm_total << 32) | s;
       if (cand < best) best = cand;
     }
+    if ((best >> 32) == 0) break;
   }
   if (best == ~0ull) return 0;
   *key = best;
