@@ -82,7 +82,7 @@ typedef struct mrg_index_info {
   uint32_t n_super;    /* superblocks (65536 BWT symbols each), 4 words each */
   uint32_t primary;    /* BWT row holding the sentinel */
   uint32_t text_words; /* 2-bit packed text, 32-bit words incl. padding */
-  uint32_t ftab_k;     /* k of the k-mer jump table (2 * 4^k words) */
+  uint32_t ftab_k;     /* k of the main k-mer jump table; k = 6 and k = 4 tables follow it */
   uint32_t C[4];       /* first BWT row of each symbol */
   uint64_t bytes_fm;   /* n_blocks * 16 + n_super * 16 */
   uint64_t bytes_sa;   /* (n_bases + 1) * 8 */
@@ -101,7 +101,7 @@ typedef struct mrg_index_view {
   const uint32_t *super;     /* n_super * 4 words: C[c] + count before the superblock */
   const uint32_t *text;      /* text_words */
   const uint64_t *sa;        /* n_bases + 1 rows: pos | before<<32 | after<<40 | seg<<48 */
-  const uint32_t *ftab;      /* 2 * 4^ftab_k words: BWT interval [lo,hi) of every k-mer */
+  const uint32_t *ftab;      /* BWT interval [lo,hi) of every k-mer: 2*4^ftab_k + 2*4^6 + 2*4^4 words */
   const uint32_t *seg_start; /* n_seg + 1 */
   const uint32_t *seg_ref;   /* n_seg */
   const uint32_t *seg_off;   /* n_seg */

@@ -295,25 +295,35 @@ void build_index(const std::vector<std::string>& names,
     ix.chunk_seg[ch] = sgi;
   }
 
-  // k-mer jump table: rows whose suffix starts with the k-mer are contiguous
+  // k-mer jump tables: rows whose suffix starts with the k-mer are contiguous.  The main
+  // table (k = 8, or 10 for libraries >= 4 Mbp) is followed by a k = 6 and a k = 4 table
+  // for the short pigeonhole pieces of the 2-mismatch pass (6-7 bases of a 19-mer).
   {
-    const uint32_t k = ix.n >= (1u << 22) ? 10u : 8u;
-    ix.ftab_k = k;
-    ix.ftab.assign((size_t)2 << (2 * k), 0);
-    const uint64_t kmask = (1ull << (2 * k)) - 1;
-    uint64_t prev = ~0ull;
-    for (size_t i = 0; i < sa32.size(); ++i) {
-      const uint32_t p = sa32[i];
-      if ((uint64_t)p + k > ix.n) continue;
-      const uint32_t w = p >> 4, sh = (p & 15) * 2;
-      uint64_t win = (uint64_t)ix.text[w] | ((uint64_t)ix.text[w + 1] << 32);
-      win = sh ? (win >> sh) | ((uint64_t)ix.text[w + 2] << (64 - sh)) : win;
-      const uint64_t code = win & kmask;
-      if (code != prev) {
-        ix.ftab[2 * code] = (uint32_t)i;
-        prev = code;
+    const uint32_t k_main = ix.n >= (1u << 22) ? 10u : 8u;
+    ix.ftab_k = k_main;
+    const uint32_t ks[3] = {k_main, 6u, 4u};
+    size_t total = 0;
+    for (uint32_t k : ks) total += (size_t)2 << (2 * k);
+    ix.ftab.assign(total, 0);
+    size_t base = 0;
+    for (uint32_t k : ks) {
+      const uint64_t kmask = (1ull << (2 * k)) - 1;
+      uint64_t prev = ~0ull;
+      uint32_t* tab = ix.ftab.data() + base;
+      for (size_t i = 0; i < sa32.size(); ++i) {
+        const uint32_t p = sa32[i];
+        if ((uint64_t)p + k > ix.n) continue;
+        const uint32_t w = p >> 4, sh = (p & 15) * 2;
+        uint64_t win = (uint64_t)ix.text[w] | ((uint64_t)ix.text[w + 1] << 32);
+        win = sh ? (win >> sh) | ((uint64_t)ix.text[w + 2] << (64 - sh)) : win;
+        const uint64_t code = win & kmask;
+        if (code != prev) {
+          tab[2 * code] = (uint32_t)i;
+          prev = code;
+        }
+        tab[2 * code + 1] = (uint32_t)i + 1;
       }
-      ix.ftab[2 * code + 1] = (uint32_t)i + 1;
+      base += (size_t)2 << (2 * k);
     }
   }
 
@@ -355,7 +365,7 @@ std::string entry_sequence(const FmIndex& ix, uint32_t r) {
 // Serialisation ("MRGFM1\0\0" + counts + raw arrays)
 // ---------------------------------------------------------------------------
 namespace {
-const char kMagic[8] = {'M', 'R', 'G', 'F', 'M', '3', 0, 0};
+const char kMagic[8] = {'M', 'R', 'G', 'F', 'M', '4', 0, 0};
 
 template <class T>
 void put_vec(std::ofstream& o, const std::vector<T>& v) {
@@ -437,7 +447,7 @@ void load_index(const std::string& path, FmIndex& ix) {
   get_vec(in, ix.chunk_seg);
   if (ix.sa.size() != (size_t)ix.n + 1 || ix.blocks.size() != (size_t)((ix.n + 1) >> 5) + 1 ||
       ix.super.size() != ((size_t)((ix.n + 1) >> kSuperShift) + 1) * 4 ||
-      ix.ftab_k > 12 || ix.ftab.size() != ((size_t)2 << (2 * ix.ftab_k)))
+      ix.ftab_k > 12 || ix.ftab.size() != ((size_t)2 << (2 * ix.ftab_k)) + (2u << 12) + (2u << 8))
     throw std::runtime_error("index file inconsistent");
 }
 

@@ -17,9 +17,10 @@
 //            32-39 bases back to the start of its N-free segment (clamped 255),
 //            40-47 bases to the end of the segment (clamped 255), 48-63 segment
 //            id (0xFFFF when the library has more segments than that)
-//   ftab     jump table: for every k-mer (k = 8, or 10 for libraries >= 4 Mbp; code =
+//   ftab     jump tables: for every k-mer (k = 8, or 10 for libraries >= 4 Mbp; code =
 //            sum base(t) << 2t) the BWT interval [lo,hi) a backward search of it
-//            ends in, so the first k steps of a seed search are one 8-byte load
+//            ends in, so the first k steps of a seed search are one 8-byte load;
+//            followed by a k = 6 and a k = 4 table for short seed pieces
 //   seg_*    N-free segments of the entries; an alignment must sit in one
 //   chunk_seg[p>>5] = segment holding text position (p & ~31)
 #pragma once
@@ -49,7 +50,7 @@ struct FmIndex {
   std::vector<uint32_t> text;
   std::vector<uint64_t> sa;
   uint32_t ftab_k = 0;
-  std::vector<uint32_t> ftab;  // 2 * 4^k: lo, hi
+  std::vector<uint32_t> ftab;  // lo, hi per k-mer: main table (4^k), then k = 6, then k = 4
   std::vector<uint32_t> seg_start, seg_ref, seg_off, chunk_seg;
 };
 

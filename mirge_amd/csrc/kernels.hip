@@ -236,14 +236,19 @@ match_kernel(const MatchParams p) {
         // ---- exact backward search of read[a,b) ----
         uint32_t lo = 0, hi = p.n + 1;
         int32_t j = b;
-        if (p.ftab_k && b - a >= (int32_t)p.ftab_k) {
-          // the piece's last k bases in one load: BWT interval of that k-mer
-          j = b - (int32_t)p.ftab_k;
+        if (p.ftab_k && b - a >= 4) {
+          // the piece's last k bases in one load: BWT interval of that k-mer (largest
+          // table the piece is long enough for: main k, then 6, then 4)
+          const int32_t plen = b - a;
+          const uint32_t k = plen >= (int32_t)p.ftab_k ? p.ftab_k : (plen >= 6 ? 6u : 4u);
+          const uint32_t tab_off = plen >= (int32_t)p.ftab_k ? 0u
+                                   : (2u << (2 * p.ftab_k)) + (plen >= 6 ? 0u : (2u << 12));
+          j = b - (int32_t)k;
           uint64_t code = pick_word<W>(rd, (uint32_t)j >> 5) >> ((j & 31) * 2);
-          if (W > 1 && (j & 31) + (int32_t)p.ftab_k > 32)
+          if (W > 1 && (j & 31) + (int32_t)k > 32)
             code |= pick_word<W>(rd, ((uint32_t)j >> 5) + 1) << (64 - (j & 31) * 2);
-          code &= (1ull << (2 * p.ftab_k)) - 1ull;
-          const uint2 iv = *reinterpret_cast<const uint2*>(p.ftab + 2 * code);
+          code &= (1ull << (2 * k)) - 1ull;
+          const uint2 iv = *reinterpret_cast<const uint2*>(p.ftab + tab_off + 2 * code);
           lo = iv.x;
           hi = iv.y;
           ++c_lookups;
@@ -357,9 +362,32 @@ match_kernel(const MatchParams p) {
 }
 
 // ---------------------------------------------------------------------------
-// Tally (SUM:34-66): privatised LDS histogram per workgroup, flushed with one
-// global atomic per non-zero bin.  `LDSH` = the bins fit in LDS.
+// Tally (SUM:34-66).  Bins are privatised in LDS per workgroup (`LDSH`) and flushed
+// with one global atomic per non-zero bin.  miRNA-seq is dominated by a handful of
+// miRNAs, so before touching LDS each wave aggregates: the lanes that hit the same bin
+// as the wave's first pending lane are summed with a wave reduction and ONE lane adds
+// the total (a few rounds catch the hot bins; the tail goes lane by lane).
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ void wave_aggregated_add(unsigned long long* h, bool valid, uint32_t bin,
+                                                    unsigned long long val, uint32_t lane) {
+  uint64_t pending = __ballot(valid);
+#pragma unroll 1
+  for (int round = 0; round < 4 && pending; ++round) {
+    const int leader = __ffsll((long long)pending) - 1;
+    const uint32_t lbin = (uint32_t)__shfl((int)bin, leader, 64);
+    const bool mine = valid && bin == lbin;
+    const uint64_t grp = __ballot(mine);
+    unsigned long long v = mine ? val : 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    v = __shfl(v, 0, 64);
+    if ((int)lane == leader) atomicAdd(&h[lbin], v);
+    pending &= ~grp;
+    valid = valid && !mine;
+  }
+  if (valid) atomicAdd(&h[bin], val);
+}
+
 template <bool LDSH>
 __global__ void __launch_bounds__(kTallyThreads) tally_kernel(const TallyParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -373,23 +401,23 @@ __global__ void __launch_bounds__(kTallyThreads) tally_kernel(const TallyParams 
     __syncthreads();
   }
   unsigned long long* h = LDSH ? hist : g;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t n_round = ((p.n + kTallyThreads - 1) / kTallyThreads) * kTallyThreads;
 
-  for (uint64_t r = (uint64_t)blockIdx.x * kTallyThreads + threadIdx.x; r < p.n;
+  for (uint64_t r = (uint64_t)blockIdx.x * kTallyThreads + threadIdx.x; r < n_round;
        r += (uint64_t)gridDim.x * kTallyThreads) {
-    const int32_t pass = p.pass_id[r];
-    const int32_t ref = (pass == p.canon_pass || pass == p.isomir_pass) ? p.ref_id[r] : 0;
+    const bool active = r < p.n;  // whole waves stay in the loop: the aggregation uses ballots
+    const int32_t pass = active ? p.pass_id[r] : -1;
+    const bool canon = active && pass == p.canon_pass, iso = active && pass == p.isomir_pass;
+    const uint32_t ref = (canon || iso) ? (uint32_t)p.ref_id[r] : 0u;
     const uint32_t cat = pass < 0 ? p.n_pass : (uint32_t)pass;
     for (uint32_t s = 0; s < S; ++s) {
-      const unsigned long long q = p.quant[r * S + s];
-      if (q == 0ull) continue;
-      atomicAdd(&h[uniq0 + s], 1ull);
-      atomicAdd(&h[cat0 + cat * S + s], q);
-      if (pass == p.canon_pass) {
-        atomicAdd(&h[(uint32_t)ref * S + s], q);
-        atomicAdd(&h[M * S + (uint32_t)ref * S + s], q);
-      } else if (pass == p.isomir_pass) {
-        atomicAdd(&h[(uint32_t)ref * S + s], q);
-      }
+      const unsigned long long q = active ? p.quant[r * S + s] : 0ull;
+      const bool hit = q != 0ull;
+      wave_aggregated_add(h, hit, uniq0 + s, 1ull, lane);
+      wave_aggregated_add(h, hit, cat0 + cat * S + s, q, lane);
+      wave_aggregated_add(h, hit && (canon || iso), ref * S + s, q, lane);
+      wave_aggregated_add(h, hit && canon, M * S + ref * S + s, q, lane);
     }
   }
   if (LDSH) {

@@ -82,14 +82,17 @@ static int match_one(const orc_lib *l, const orc_pass *p, const uint64_t *rd, co
     if (has_n) continue;
     uint32_t lo = 0, hi = l->n + 1;
     int j = b;
-    if (use_ftab && l->ftab_k && b - a >= (int)l->ftab_k) {
-      /* the piece's last k bases in one load */
+    if (use_ftab && l->ftab_k && b - a >= 4) {
+      /* the piece's last k bases in one load: main table, else the k = 6 / k = 4 ones */
+      int plen = b - a;
+      int k = plen >= (int)l->ftab_k ? (int)l->ftab_k : (plen >= 6 ? 6 : 4);
+      size_t off = plen >= (int)l->ftab_k ? 0 : ((size_t)2 << (2 * l->ftab_k)) + (plen >= 6 ? 0 : (2u << 12));
       uint64_t code = 0;
-      j = b - (int)l->ftab_k;
-      for (int t = 0; t < (int)l->ftab_k; ++t)
+      j = b - k;
+      for (int t = 0; t < k; ++t)
         code |= ((rd[(j + t) >> 5] >> (((j + t) & 31) * 2)) & 3ull) << (2 * t);
-      lo = l->ftab[2 * code];
-      hi = l->ftab[2 * code + 1];
+      lo = l->ftab[off + 2 * code];
+      hi = l->ftab[off + 2 * code + 1];
       ++*lookups;
     }
     while (j > a && hi > lo && (hi - lo) > wstop) {
