@@ -263,33 +263,50 @@ match_kernel(const MatchParams p) {
           hi = lib.lf(c, hi, vh);
           ++c_steps;
         }
-        // ---- locate + verify every occurrence ----
-        for (uint32_t i = lo; i < hi; ++i) {
-          const uint64_t row = p.sa[i];
-          ++c_cands;
+        // ---- locate + verify every occurrence (four suffix-array rows per trip: they
+        // mostly share a cache line and their loads overlap) ----
+        const uint32_t need_before = (uint32_t)j, need_after = (uint32_t)(L - j);
+        auto verify = [&](const uint64_t row) {
           // the alignment [pos - j, pos - j + L) must stay inside the N-free segment
           const uint32_t before = (uint32_t)(row >> 32) & 255u, after = (uint32_t)(row >> 40) & 255u;
-          if ((uint32_t)j > before || (uint32_t)(L - j) > after) continue;
-          const uint32_t s = (uint32_t)row - (uint32_t)j;
+          if ((need_before > before) | (need_after > after)) return;
+          const uint32_t s = (uint32_t)row - need_before;
           uint32_t mm_total = 0, mm_seed = 0;
 #pragma unroll
           for (int w = 0; w < W; ++w) {
             const int32_t nb = min(32, L - 32 * w);
             if (nb > 0) {
               const uint64_t x = lib.window(s + 32u * w) ^ rd[w];
-              const uint64_t m = (((x | (x >> 1)) & kOdd) | nm[w]) & low_bits(2 * nb);
+              uint64_t m = (x | (x >> 1)) & kOdd;
+              if (p.nmask) m |= nm[w];
+              m &= low_bits(2 * nb);
               mm_total += (uint32_t)__popcll(m);
-              const int32_t ns = min(nb, max(0, p.seed_len - 32 * w));
-              mm_seed += (uint32_t)__popcll(m & low_bits(2 * ns));
+              // seed mismatches only differ from the total for reads longer than the seed
+              if (L > p.seed_len) {
+                const int32_t ns = min(nb, max(0, p.seed_len - 32 * w));
+                mm_seed += (uint32_t)__popcll(m & low_bits(2 * ns));
+              }
             }
           }
-          if ((int32_t)mm_seed > p.max_mm_seed || (int32_t)mm_total > p.max_mm_total) continue;
+          if (L <= p.seed_len) mm_seed = mm_total;
+          if (((int32_t)mm_seed > p.max_mm_seed) | ((int32_t)mm_total > p.max_mm_total)) return;
           const uint64_t key = ((uint64_t)mm_total << 32) | s;
           if (key < best) {
             best = key;
             best_seg = (uint32_t)(row >> 48);
-            best_before = before < 255u ? before - (uint32_t)j : 255u;
+            best_before = before < 255u ? before - need_before : 255u;
           }
+        };
+        c_cands += hi > lo ? hi - lo : 0u;
+        for (uint32_t i = lo; i < hi; i += 4) {
+          const uint64_t row0 = p.sa[i];
+          const uint64_t row1 = (i + 1 < hi) ? p.sa[i + 1] : 0ull;
+          const uint64_t row2 = (i + 2 < hi) ? p.sa[i + 2] : 0ull;
+          const uint64_t row3 = (i + 3 < hi) ? p.sa[i + 3] : 0ull;
+          verify(row0);
+          if (i + 1 < hi) verify(row1);
+          if (i + 2 < hi) verify(row2);
+          if (i + 3 < hi) verify(row3);
         }
         if ((best >> 32) == 0ull) break;  // an exact hit is always seen by piece 0
       }
