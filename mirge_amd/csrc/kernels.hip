@@ -26,6 +26,7 @@ namespace mrg {
 namespace {
 
 constexpr uint64_t kOdd = 0x5555555555555555ull;
+constexpr uint32_t kRowsPerTrip = 4;  // suffix-array rows loaded together in the candidate loop
 
 __device__ __forceinline__ uint64_t low_bits(uint32_t nbits) {
   // nbits in [0,64]
@@ -85,6 +86,11 @@ struct Lib {
     return (lo64 >> sh) | ((((uint64_t)w2) << 1) << (63 - sh));
   }
 };
+
+// x / K for the piece counts a pass can have (1..3), x < 65536: no integer-divide sequence
+__device__ __forceinline__ int32_t div_pieces(int32_t x, int32_t K) {
+  return K == 1 ? x : (K == 2 ? (x >> 1) : (int32_t)(((uint32_t)x * 43691u) >> 17));
+}
 
 template <int W>
 __device__ __forceinline__ uint64_t pick_word(const uint64_t (&rd)[W], uint32_t w) {
@@ -222,7 +228,7 @@ match_kernel(const MatchParams p) {
       const int32_t R = min(L, p.seed_len);
       const int32_t K = p.max_mm_seed + 1;
       for (int32_t k = 0; k < K; ++k) {
-        const int32_t a = (R * k) / K, b = (R * (k + 1)) / K;
+        const int32_t a = div_pieces(R * k, K), b = div_pieces(R * (k + 1), K);
         if (p.nmask) {
           // a piece holding an N can never be the exact one
           bool has_n = false;
@@ -298,15 +304,13 @@ match_kernel(const MatchParams p) {
           }
         };
         c_cands += hi > lo ? hi - lo : 0u;
-        for (uint32_t i = lo; i < hi; i += 4) {
-          const uint64_t row0 = p.sa[i];
-          const uint64_t row1 = (i + 1 < hi) ? p.sa[i + 1] : 0ull;
-          const uint64_t row2 = (i + 2 < hi) ? p.sa[i + 2] : 0ull;
-          const uint64_t row3 = (i + 3 < hi) ? p.sa[i + 3] : 0ull;
-          verify(row0);
-          if (i + 1 < hi) verify(row1);
-          if (i + 2 < hi) verify(row2);
-          if (i + 3 < hi) verify(row3);
+        for (uint32_t i = lo; i < hi; i += kRowsPerTrip) {
+          uint64_t rows[kRowsPerTrip];
+#pragma unroll
+          for (uint32_t u = 0; u < kRowsPerTrip; ++u) rows[u] = (i + u < hi) ? p.sa[i + u] : 0ull;
+#pragma unroll
+          for (uint32_t u = 0; u < kRowsPerTrip; ++u)
+            if (i + u < hi) verify(rows[u]);
         }
         if ((best >> 32) == 0ull) break;  // an exact hit is always seen by piece 0
       }
