@@ -41,7 +41,8 @@ def main():
     ap.add_argument("--reads-per-gpu", type=int, default=None)
     ap.add_argument("--scale", type=float, default=1.0, help="library size factor (1.0 = SURVEY 8d shapes)")
     ap.add_argument("--samples", type=int, default=1)
-    ap.add_argument("--cpu-sample", type=int, default=2_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=100_000_000,
+                    help="reads of rank 0's shard the CPU port re-annotates (baseline + parity gate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wstop", type=int, default=None)
     ap.add_argument("--no-ftab", action="store_true")
@@ -166,7 +167,8 @@ def main():
 
     groups = {}
     for i, s in enumerate(st):
-        name = "mrg::match_kernel<1, %s>" % ("true, true" if s["lds_bytes"] else "false, false")
+        name = "mrg::match_kernel<1, %s>" % {0: "false, false", 1: "true, false", 2: "true, true",
+                                             3: "false, true"}[s["lds_mode"]]
         g = groups.setdefault(name, dict(ms=0.0, bytes=0.0, sbytes=0.0, launches=0, passes=[]))
         g["ms"] += per_pass_ms[i]
         g["bytes"] += alg_bytes(s)
@@ -199,7 +201,7 @@ def main():
         passes_report.append(dict(
             lib=table[i][0], ms=round(float(per_pass_ms[i]), 4), processed=s["processed"],
             aligned=s["aligned"], steps=s["steps"], candidates=s["candidates"], lookups=s["lookups"],
-            lds_bytes=s["lds_bytes"],
+            lds_bytes=s["lds_bytes"], kernel="match_kernel<1,%s>" % ["hbm", "blocks", "blocks+text", "text"][s["lds_mode"]],
             alg_gbs=round(alg_bytes(s) / max(per_pass_ms[i], 1e-9) / 1e6, 1)))
 
     # ---- CPU baseline: the oracle's port on a bounded sample, all host cores ----

@@ -148,7 +148,9 @@ typedef struct mrg_pass_stats {
   uint64_t candidates; /* seed occurrences verified against the text */
   uint64_t lookups;    /* k-mer jump-table loads (each replaces ftab_k LF steps) */
   float ms;            /* device time of the pass (the reference's cpuTime) */
-  uint32_t lds_bytes;  /* LDS staged for this pass (0 = index served from HBM/L2) */
+  uint32_t lds_bytes;  /* library bytes staged in LDS for this pass (0 = served from HBM/L2) */
+  uint32_t lds_mode;   /* 0 nothing, 1 occ blocks, 2 occ blocks + text, 3 text only: names the
+                          match_kernel<W, blocks, text> instantiation that ran */
 } mrg_pass_stats;
 
 /* Bytes of device workspace mrg_cascade_run needs for n reads. */

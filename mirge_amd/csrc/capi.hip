@@ -84,6 +84,7 @@ struct mrg_ctx {
   uint64_t* last_stats_dev = nullptr;
   uint32_t last_n_pass = 0;
   uint32_t last_lds[MRG_MAX_PASSES] = {0};
+  uint32_t last_mode[MRG_MAX_PASSES] = {0};
   hipEvent_t ev[MRG_MAX_PASSES + 1] = {nullptr};
   bool ev_ready = false;
 };
@@ -464,6 +465,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     const uint32_t seg_cap = (uint32_t)(((n + 1024ull * grid - 1) / (1024ull * grid)) * 1024ull);
     p.out_seg_cap = seg_cap;
     ctx->last_lds[i] = lds_bytes;
+    ctx->last_mode[i] = (uint32_t)lds_mode;
     if (n) HIP_TRY(mrg::launch_match(p, words_per_read, lds_mode, grid, lds_total, stream));
     HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
     prev_grid = grid;
@@ -495,6 +497,7 @@ int mrg_cascade_stats(mrg_ctx* ctx, mrg_pass_stats* out, uint32_t n_pass) {
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
     out[i].ms = ms;
     out[i].lds_bytes = ctx->last_lds[i];
+    out[i].lds_mode = ctx->last_mode[i];
   }
   return MRG_OK;
 }
