@@ -411,7 +411,9 @@ __global__ void __launch_bounds__(kTallyThreads) tally_kernel(const TallyParams 
        r += (uint64_t)gridDim.x * kTallyThreads) {
     const bool active = r < p.n;  // whole waves stay in the loop: ballots below
     const int32_t pass = active ? p.pass_id[r] : -1;
-    const bool canon = active && pass == p.canon_pass, iso = active && pass == p.isomir_pass;
+    // an unclaimed read (pass -1) must not match a disabled (-1) canon/isomiR pass
+    const bool canon = active && pass >= 0 && pass == p.canon_pass;
+    const bool iso = active && pass >= 0 && pass == p.isomir_pass;
     const uint32_t ref = (canon || iso) ? (uint32_t)p.ref_id[r] : 0u;
     const uint32_t cat = pass < 0 ? p.n_pass : (uint32_t)pass;
     for (uint32_t s = 0; s < S; ++s) {

@@ -215,10 +215,10 @@ void orc_tally(const int8_t *pass_id, const int32_t *ref_id, const uint32_t *qua
       if (!q) continue;
       counts[uniq0 + s] += 1;
       counts[cat0 + (uint64_t)cat * S + s] += q;
-      if (pass == canon_pass) {
+      if (pass >= 0 && pass == canon_pass) {
         counts[(uint64_t)ref_id[r] * S + s] += q;
         counts[(uint64_t)M * S + (uint64_t)ref_id[r] * S + s] += q;
-      } else if (pass == isomir_pass) {
+      } else if (pass >= 0 && pass == isomir_pass) {
         counts[(uint64_t)ref_id[r] * S + s] += q;
       }
     }

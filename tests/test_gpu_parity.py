@@ -111,6 +111,23 @@ def test_tally_matches_oracle(engine, world):
         assert np.array_equal(uniq, (quant != 0).sum(axis=0))
 
 
+def test_tally_with_isomir_pass_disabled(engine, world):
+    """A single-pass cascade (BASELINE configs[1]) tallies with isomir_pass = -1: unclaimed
+    reads (pass -1) must not be mistaken for it."""
+    from mirge_amd import synth
+    from mirge_amd.engine import ReadSet
+    quant = synth.synth_quant(len(world.lens))
+    rs = ReadSet(world.words, world.lens, world.nmask, quant, device=engine.device)
+    passes = engine.make_passes([dict(lib="mirna", min_len=0, max_len=25, seed_len=28, max_mm_seed=0,
+                                      max_mm_total=2)])
+    res = engine.cascade(rs, passes)
+    counts = engine.tally(rs, res, world.n_mirna, 0, -1).cpu().numpy()
+    pass_id, ref_id, _, _ = res.to_host()
+    assert pass_id.min() == -1 and pass_id.max() == 0
+    want = model.tally(pass_id, ref_id, quant, world.n_mirna, 1, 0, -1)
+    assert np.array_equal(counts.astype(np.uint64), want)
+
+
 def test_host_buffer_entry_point(engine, world):
     from mirge_amd import synth
     quant = synth.synth_quant(len(world.lens))
