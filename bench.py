@@ -206,7 +206,7 @@ def main():
 
     # ---- CPU baseline: the oracle's port on a bounded sample, all host cores ----
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N=1 only
         from oracle import model
         m = min(args.cpu_sample, n_reads)
         cores = os.cpu_count() or 1

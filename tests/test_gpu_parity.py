@@ -156,3 +156,39 @@ def test_empty_and_tiny_inputs(engine, world):
             assert np.array_equal(a, ref[name]), (reads, name)
         counts = engine.tally(rs, res, world.n_mirna).cpu().numpy()
         assert int(counts[2 * world.n_mirna:2 * world.n_mirna + 10].sum()) == len(reads)
+
+
+def test_spike_in_cascade_and_many_samples(engine, world, native_lib):
+    """Ten-pass cascade (-spikeIn, RAP:574-586) and a sample count whose histogram does not
+    fit LDS (the tally then uses global atomics)."""
+    from mirge_amd import pack, synth
+    from mirge_amd.engine import MIRGE_PASS_TABLE, ReadSet, split_counts
+    from mirge_amd.index import FmIndex
+    rng = np.random.default_rng(77)
+    names = ["spike-%d" % i for i in range(12)]
+    seqs = ["".join("ACGT"[c] for c in rng.integers(0, 4, 40)) for _ in names]
+    spike = FmIndex.build(names, seqs)
+    engine.add_library("spike-in", spike)
+    reads = list(world.reads[:4000]) + [s[5:27] for s in seqs] + [s[:18] for s in seqs]
+    w, l, nm = pack.pack_reads(reads)
+    passes = engine.mirge_passes(spike_in=True)
+    assert len(passes) == 10
+    S = 40
+    quant = synth.synth_quant(len(reads), n_samples=S)
+    rs = ReadSet(w, l, nm, quant, device=engine.device)
+    res = engine.cascade(rs, passes)
+    views = world.views + [spike.view()]
+    order = LIB_ORDER + ["spike-in"]
+    pd = [dict(lib=order.index(k), min_len=a, max_len=b, seed_len=s_, max_mm_seed=ms, max_mm_total=mt,
+               trim5=t5, trim3=t3, poly_t=pt) for (k, a, b, s_, ms, mt, t5, t3, pt) in MIRGE_PASS_TABLE]
+    ref = model.fm_cascade(views, pd, w, l, nm, wstop=2, ftab=True)
+    got = res.to_host()
+    for name, a in zip(("pass_id", "ref_id", "pos", "mm"), got):
+        assert np.array_equal(a, ref[name]), name
+    assert int((got[0] == 9).sum()) >= 20          # the spike-in pass claimed its reads
+    counts = engine.tally(rs, res, world.n_mirna).cpu().numpy()
+    assert 2 * world.n_mirna * S * 8 > 160 * 1024   # too big for LDS: global-atomic variant
+    want = model.tally(ref["pass_id"], ref["ref_id"], quant, world.n_mirna, 10, 0, 8)
+    assert np.array_equal(counts.astype(np.uint64), want)
+    q, c, cat, uniq = split_counts(counts, world.n_mirna, S, 10)
+    assert int(cat[9].sum()) == int(quant[got[0] == 9].sum())
