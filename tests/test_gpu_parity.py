@@ -173,7 +173,7 @@ def test_spike_in_cascade_and_many_samples(engine, world, native_lib):
     w, l, nm = pack.pack_reads(reads)
     passes = engine.mirge_passes(spike_in=True)
     assert len(passes) == 10
-    S = 40
+    S = 96
     quant = synth.synth_quant(len(reads), n_samples=S)
     rs = ReadSet(w, l, nm, quant, device=engine.device)
     res = engine.cascade(rs, passes)
