@@ -192,3 +192,43 @@ def test_spike_in_cascade_and_many_samples(engine, world, native_lib):
     assert np.array_equal(counts.astype(np.uint64), want)
     q, c, cat, uniq = split_counts(counts, world.n_mirna, S, 10)
     assert int(cat[9].sum()) == int(quant[got[0] == 9].sum())
+
+
+def test_low_complexity_library_and_reads(native_lib, oracle_lib):
+    """Repeats: poly-A tails, tandem repeats and duplicated entries make seed intervals
+    hundreds of rows wide; results must still equal the exhaustive scan (lowest entry,
+    lowest offset among equally good alignments)."""
+    from mirge_amd import pack
+    from mirge_amd.engine import Engine, ReadSet
+    from mirge_amd.index import FmIndex
+    rng = np.random.default_rng(5)
+
+    def rnd(n):
+        return "".join("ACGT"[c] for c in rng.integers(0, 4, n))
+    seqs = [rnd(60) + "A" * int(rng.integers(20, 60)) for _ in range(40)]          # poly-A tails
+    seqs += [("ACGT" * 30)[:int(rng.integers(40, 120))] for _ in range(10)]          # tandem repeat
+    seqs += [rnd(30) + "CACACACACACACACACACACACACACA" + rnd(10) for _ in range(10)]
+    seqs += [seqs[3], seqs[3], "A" * 200, "T" * 90]                                   # duplicates, homopolymers
+    names = ["rep%d" % i for i in range(len(seqs))]
+    ix = FmIndex.build(names, seqs)
+    reads = ["A" * L for L in (16, 22, 25, 30, 40)] + ["A" * 21 + "C", "C" + "A" * 21, "ACGT" * 6,
+             "CGTA" * 5 + "CG", "CA" * 12, "AC" * 11 + "G", "T" * 22, "T" * 19 + "AAA", "G" * 22,
+             seqs[3][40:62], seqs[3][50:75], "A" * 10 + "N" + "A" * 11]
+    reads += [s[int(o):int(o) + 22] for s in seqs[:30] for o in rng.integers(0, len(s) - 22, 3)]
+    reads = list(dict.fromkeys(reads))
+    w, l, nm = pack.pack_reads(reads)
+    eng = Engine(0)
+    eng.add_library("rep", ix)
+    lib = model.Library(names, seqs)
+    for (seed_len, mm_seed, mm_total, t5, t3) in ((28, 0, 2, 0, 0), (28, 1, 2, 0, 0), (1024, 1, 1, 0, 0),
+                                                  (1024, 2, 2, 1, 2)):
+        passes = eng.make_passes([dict(lib="rep", seed_len=seed_len, max_mm_seed=mm_seed,
+                                       max_mm_total=mm_total, trim5=t5, trim3=t3)])
+        res = eng.cascade(ReadSet(w, l, nm, None, device=eng.device), passes)
+        pass_id, ref_id, pos, mm = res.to_host()
+        trimmed = [r[t5:len(r) - t3] if t3 else r[t5:] for r in reads]
+        want_ref, want_pos, want_mm = model.align_batch(lib, trimmed, seed_len, mm_seed, mm_total)
+        for i, r in enumerate(reads):
+            got = (int(ref_id[i]), int(pos[i]), int(mm[i])) if pass_id[i] == 0 else (-1, -1, -1)
+            assert got == (int(want_ref[i]), int(want_pos[i]), int(want_mm[i])), (r, seed_len, mm_seed)
+        assert max(s["candidates"] for s in res.stats) > 2000   # the wide-interval path ran
