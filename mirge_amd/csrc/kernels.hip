@@ -27,6 +27,7 @@ namespace {
 
 constexpr uint64_t kOdd = 0x5555555555555555ull;
 constexpr uint32_t kRowsPerTrip = 4;  // suffix-array rows loaded together in the candidate loop
+constexpr uint32_t kWideRows = 256;   // wider seed intervals are verified by the whole wave
 
 __device__ __forceinline__ uint64_t low_bits(uint32_t nbits) {
   // nbits in [0,64]
@@ -110,6 +111,45 @@ __device__ __forceinline__ void shift_out_5p(uint64_t (&rd)[W], uint32_t t) {
   rd[W - 1] >>= sh;
 }
 
+// One suffix-array row as a candidate alignment of a read whose seed search stopped with
+// `need_before` read bases left of the row's text position and `need_after` from it on.
+// Updates (best, best_seg, best_before) when the alignment is valid and better.
+template <int W, class LibT>
+__device__ __forceinline__ void verify_row(const LibT& lib, const MatchParams& p, const uint64_t row,
+                                           const uint64_t (&rd)[W], const uint64_t (&nm)[W], int32_t L,
+                                           uint32_t need_before, uint32_t need_after, uint64_t& best,
+                                           uint32_t& best_seg, uint32_t& best_before) {
+  // the alignment [pos - j, pos - j + L) must stay inside the N-free segment
+  const uint32_t before = (uint32_t)(row >> 32) & 255u, after = (uint32_t)(row >> 40) & 255u;
+  if ((need_before > before) | (need_after > after)) return;
+  const uint32_t s = (uint32_t)row - need_before;
+  uint32_t mm_total = 0, mm_seed = 0;
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    const int32_t nb = min(32, L - 32 * w);
+    if (nb > 0) {
+      const uint64_t x = lib.window(s + 32u * w) ^ rd[w];
+      uint64_t m = (x | (x >> 1)) & kOdd;
+      if (p.nmask) m |= nm[w];
+      m &= low_bits(2 * nb);
+      mm_total += (uint32_t)__popcll(m);
+      // seed mismatches only differ from the total for reads longer than the seed
+      if (L > p.seed_len) {
+        const int32_t ns = min(nb, max(0, p.seed_len - 32 * w));
+        mm_seed += (uint32_t)__popcll(m & low_bits(2 * ns));
+      }
+    }
+  }
+  if (L <= p.seed_len) mm_seed = mm_total;
+  if (((int32_t)mm_seed > p.max_mm_seed) | ((int32_t)mm_total > p.max_mm_total)) return;
+  const uint64_t key = ((uint64_t)mm_total << 32) | s;
+  if (key < best) {
+    best = key;
+    best_seg = (uint32_t)(row >> 48);
+    best_before = before < 255u ? before - need_before : 255u;
+  }
+}
+
 }  // namespace
 
 template <int W, bool LDSI, bool LDST>
@@ -127,6 +167,7 @@ match_kernel(const MatchParams p) {
   uint32_t* stext = sblocks + blk_words;
   uint32_t* seg_count = stext + txt_words;  // kMaxSegments entries
   uint32_t* ctl = seg_count + kMaxSegments; // [0] survivors appended here, [1] longest input segment
+  uint32_t* wave_slots = ctl + 4;           // 16 B per wave: minimum of a wave-wide verification
   {
     // 16 B per lane per trip
     const uint4* src = reinterpret_cast<const uint4*>(p.super);
@@ -174,7 +215,7 @@ match_kernel(const MatchParams p) {
   lib.ssuper = ssuper;
   lib.primary = p.primary;
 
-  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // per-lane tallies (a lane handles a few hundred reads per launch: 32 bits suffice)
   uint32_t c_processed = 0, c_aligned = 0, c_steps = 0, c_cands = 0, c_lookups = 0;
 
@@ -269,48 +310,59 @@ match_kernel(const MatchParams p) {
           hi = lib.lf(c, hi, vh);
           ++c_steps;
         }
-        // ---- locate + verify every occurrence (four suffix-array rows per trip: they
-        // mostly share a cache line and their loads overlap) ----
+        // ---- locate + verify every occurrence ----
         const uint32_t need_before = (uint32_t)j, need_after = (uint32_t)(L - j);
-        auto verify = [&](const uint64_t row) {
-          // the alignment [pos - j, pos - j + L) must stay inside the N-free segment
-          const uint32_t before = (uint32_t)(row >> 32) & 255u, after = (uint32_t)(row >> 40) & 255u;
-          if ((need_before > before) | (need_after > after)) return;
-          const uint32_t s = (uint32_t)row - need_before;
-          uint32_t mm_total = 0, mm_seed = 0;
+        const uint32_t width = hi > lo ? hi - lo : 0u;
+        c_cands += width;
+        const bool wide = width > kWideRows;
+        if (!wide) {
+          // four suffix-array rows per trip: they mostly share a cache line and their loads overlap
+          for (uint32_t i = lo; i < hi; i += kRowsPerTrip) {
+            uint64_t rows[kRowsPerTrip];
+#pragma unroll
+            for (uint32_t u = 0; u < kRowsPerTrip; ++u) rows[u] = (i + u < hi) ? p.sa[i + u] : 0ull;
+#pragma unroll
+            for (uint32_t u = 0; u < kRowsPerTrip; ++u)
+              if (i + u < hi)
+                verify_row<W>(lib, p, rows[u], rd, nm, L, need_before, need_after, best, best_seg, best_before);
+          }
+        }
+        // A low-complexity seed (poly-A, repeats) can match 10^3..10^6 rows; one lane walking
+        // them would stall its wave for that long.  Such intervals are verified by the whole
+        // wave instead: the owner's read is broadcast, every lane takes rows lo+lane, +64, ...
+        // (coalesced suffix-array reads) and the minimum is combined through LDS.
+        uint64_t wide_mask = __ballot(wide);
+        while (wide_mask) {
+          const int src = __ffsll((long long)wide_mask) - 1;
+          wide_mask &= wide_mask - 1;
+          uint64_t o_rd[W], o_nm[W];
 #pragma unroll
           for (int w = 0; w < W; ++w) {
-            const int32_t nb = min(32, L - 32 * w);
-            if (nb > 0) {
-              const uint64_t x = lib.window(s + 32u * w) ^ rd[w];
-              uint64_t m = (x | (x >> 1)) & kOdd;
-              if (p.nmask) m |= nm[w];
-              m &= low_bits(2 * nb);
-              mm_total += (uint32_t)__popcll(m);
-              // seed mismatches only differ from the total for reads longer than the seed
-              if (L > p.seed_len) {
-                const int32_t ns = min(nb, max(0, p.seed_len - 32 * w));
-                mm_seed += (uint32_t)__popcll(m & low_bits(2 * ns));
-              }
+            o_rd[w] = __shfl(rd[w], src, 64);
+            o_nm[w] = __shfl(nm[w], src, 64);
+          }
+          const uint32_t o_lo = __shfl(lo, src, 64), o_hi = __shfl(hi, src, 64);
+          const int32_t o_L = __shfl(L, src, 64);
+          const uint32_t o_nb = __shfl(need_before, src, 64), o_na = __shfl(need_after, src, 64);
+          uint64_t w_best = ~0ull;
+          uint32_t w_seg = 0xFFFFu, w_before = 255u;
+          for (uint32_t i = o_lo + lane; i < o_hi; i += 64)
+            verify_row<W>(lib, p, p.sa[i], o_rd, o_nm, o_L, o_nb, o_na, w_best, w_seg, w_before);
+          unsigned long long* slot = reinterpret_cast<unsigned long long*>(wave_slots) + 2 * wave;
+          if ((int)lane == src) {
+            slot[0] = ~0ull;
+            slot[1] = 0ull;
+          }
+          if (w_best != ~0ull) atomicMin(&slot[0], (unsigned long long)w_best);
+          if (w_best != ~0ull && slot[0] == w_best) slot[1] = ((unsigned long long)w_seg << 32) | w_before;
+          if ((int)lane == src) {
+            const uint64_t got = slot[0];
+            if (got < best) {
+              best = got;
+              best_seg = (uint32_t)(slot[1] >> 32);
+              best_before = (uint32_t)slot[1];
             }
           }
-          if (L <= p.seed_len) mm_seed = mm_total;
-          if (((int32_t)mm_seed > p.max_mm_seed) | ((int32_t)mm_total > p.max_mm_total)) return;
-          const uint64_t key = ((uint64_t)mm_total << 32) | s;
-          if (key < best) {
-            best = key;
-            best_seg = (uint32_t)(row >> 48);
-            best_before = before < 255u ? before - need_before : 255u;
-          }
-        };
-        c_cands += hi > lo ? hi - lo : 0u;
-        for (uint32_t i = lo; i < hi; i += kRowsPerTrip) {
-          uint64_t rows[kRowsPerTrip];
-#pragma unroll
-          for (uint32_t u = 0; u < kRowsPerTrip; ++u) rows[u] = (i + u < hi) ? p.sa[i + u] : 0ull;
-#pragma unroll
-          for (uint32_t u = 0; u < kRowsPerTrip; ++u)
-            if (i + u < hi) verify(rows[u]);
         }
         if ((best >> 32) == 0ull) break;  // an exact hit is always seen by piece 0
       }

@@ -16,7 +16,8 @@ struct MatchBlock {
 constexpr uint32_t kTallyThreads = 1024u;
 // Survivor lists are segmented: workgroup b of the producing pass owns segment b.
 constexpr uint32_t kMaxSegments = 512u;
-constexpr uint32_t kMatchCtlBytes = (kMaxSegments + 4u) * 4u;  // segment lengths + control words
+constexpr uint32_t kMatchCtlBytes = (kMaxSegments + 4u + 4u * 16u) * 4u;  // segment lengths, control
+                                                                       // words, 16 B per wave
 
 struct MatchParams {
   // library (device pointers)
