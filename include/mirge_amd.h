@@ -122,7 +122,8 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * every library from HBM/L2); "wstop" = interval width at which a seed search
  * stops narrowing and hands the occurrences to verification (0 = narrow to the
  * end of the piece); "ftab" = 1/0 use the k-mer jump table for the first k steps
- * of a seed search. */
+ * of a seed search; "wide_rows" = seed intervals wider than this many rows are
+ * verified cooperatively by the whole wave (default 256). */
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);
 int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,
                         char *arch, uint32_t arch_cap);

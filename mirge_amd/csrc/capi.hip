@@ -77,6 +77,7 @@ struct mrg_ctx {
   int64_t wstop = 2;
   int64_t use_ftab = 1;
   int64_t force_lds_mode = -1;
+  int64_t wide_rows = 256;
   int64_t prefer_two_blocks = 1;
   std::vector<DevLib> libs;
   // last run
@@ -292,6 +293,9 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "wstop") {
     if (value < 0) return fail(MRG_ERR_ARG, "wstop must be >= 0");
     ctx->wstop = value;
+  } else if (k == "wide_rows") {
+    if (value < 1) return fail(MRG_ERR_ARG, "wide_rows must be >= 1");
+    ctx->wide_rows = value;
   } else if (k == "prefer_two_blocks") {
     ctx->prefer_two_blocks = value != 0;
   } else if (k == "force_lds_mode") {
@@ -419,6 +423,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     p.poly_t = c.poly_t;
     p.pass_index = (int32_t)i;
     p.wstop = (uint32_t)ctx->wstop;
+    p.wide_rows = (uint32_t)ctx->wide_rows;
 
     // residency decision.  The superblock table (16 B per 65536 bp) and the segment
     // prefix always sit in LDS.  With the jump table most seed searches need few LF

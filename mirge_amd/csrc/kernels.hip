@@ -27,7 +27,6 @@ namespace {
 
 constexpr uint64_t kOdd = 0x5555555555555555ull;
 constexpr uint32_t kRowsPerTrip = 4;  // suffix-array rows loaded together in the candidate loop
-constexpr uint32_t kWideRows = 256;   // wider seed intervals are verified by the whole wave
 
 __device__ __forceinline__ uint64_t low_bits(uint32_t nbits) {
   // nbits in [0,64]
@@ -314,7 +313,7 @@ match_kernel(const MatchParams p) {
         const uint32_t need_before = (uint32_t)j, need_after = (uint32_t)(L - j);
         const uint32_t width = hi > lo ? hi - lo : 0u;
         c_cands += width;
-        const bool wide = width > kWideRows;
+        const bool wide = width > p.wide_rows;
         if (!wide) {
           // four suffix-array rows per trip: they mostly share a cache line and their loads overlap
           for (uint32_t i = lo; i < hi; i += kRowsPerTrip) {
@@ -346,7 +345,12 @@ match_kernel(const MatchParams p) {
           const uint32_t o_nb = __shfl(need_before, src, 64), o_na = __shfl(need_after, src, 64);
           uint64_t w_best = ~0ull;
           uint32_t w_seg = 0xFFFFu, w_before = 255u;
-          for (uint32_t i = o_lo + lane; i < o_hi; i += 64)
+          // only the lanes still in this loop can help (others left it with a result or
+          // were never offered a read): deal the rows over exactly those
+          const uint64_t helpers = __ballot(true);
+          const uint32_t n_help = (uint32_t)__popcll(helpers);
+          const uint32_t my_rank = (uint32_t)__popcll(helpers & ((1ull << lane) - 1ull));
+          for (uint32_t i = o_lo + my_rank; i < o_hi; i += n_help)
             verify_row<W>(lib, p, p.sa[i], o_rd, o_nm, o_L, o_nb, o_na, w_best, w_seg, w_before);
           unsigned long long* slot = reinterpret_cast<unsigned long long*>(wave_slots) + 2 * wave;
           if ((int)lane == src) {

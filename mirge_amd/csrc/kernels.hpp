@@ -54,6 +54,7 @@ struct MatchParams {
   int32_t seed_len, max_mm_seed, max_mm_total, trim5, trim3, min_len, max_len, poly_t;
   int32_t pass_index;
   uint32_t wstop;
+  uint32_t wide_rows;  // seed intervals wider than this are verified by the whole wave
 };
 
 struct TallyParams {

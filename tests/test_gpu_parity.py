@@ -68,16 +68,18 @@ def test_search_shortcuts_same_results_fewer_steps(engine, world):
     """The k-mer jump table and the early hand-over to verification change how many
     LF steps run, never an assignment; step / candidate / lookup counts equal the port's."""
     base = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask)
-    for wstop, ftab in ((0, 1), (2, 0), (2, 1), (16, 1)):
+    for wstop, ftab, wide in ((0, 1, 256), (2, 0, 256), (2, 1, 256), (16, 1, 256), (16, 1, 1), (2, 1, 3)):
         ref = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask,
                                wstop=wstop, ftab=bool(ftab))
         for k in ("pass_id", "ref_id", "pos", "mm"):
             assert np.array_equal(base[k], ref[k])
-        _, res = run_gpu(engine, world, wstop=wstop, ftab=ftab)
+        # wide_rows = 1 / 3 pushes nearly every interval through the wave-wide verification
+        _, res = run_gpu(engine, world, wstop=wstop, ftab=ftab, wide_rows=wide)
         assert_same(res, ref)
         assert sum(s["steps"] for s in res.stats) < int(base["stats"][:, 2].sum())
     engine.set_option("wstop", 2)
     engine.set_option("ftab", 1)
+    engine.set_option("wide_rows", 256)
 
 
 def test_cascade_matches_exhaustive_scan(engine, world):
@@ -221,8 +223,10 @@ def test_low_complexity_library_and_reads(native_lib, oracle_lib):
     eng = Engine(0)
     eng.add_library("rep", ix)
     lib = model.Library(names, seqs)
-    for (seed_len, mm_seed, mm_total, t5, t3) in ((28, 0, 2, 0, 0), (28, 1, 2, 0, 0), (1024, 1, 1, 0, 0),
-                                                  (1024, 2, 2, 1, 2)):
+    for (seed_len, mm_seed, mm_total, t5, t3, wide) in ((28, 0, 2, 0, 0, 256), (28, 1, 2, 0, 0, 256),
+                                                        (1024, 1, 1, 0, 0, 256), (1024, 2, 2, 1, 2, 256),
+                                                        (28, 1, 2, 0, 0, 100000), (1024, 2, 2, 1, 2, 8)):
+        eng.set_option("wide_rows", wide)
         passes = eng.make_passes([dict(lib="rep", seed_len=seed_len, max_mm_seed=mm_seed,
                                        max_mm_total=mm_total, trim5=t5, trim3=t3)])
         res = eng.cascade(ReadSet(w, l, nm, None, device=eng.device), passes)
