@@ -296,10 +296,14 @@ void build_index(const std::vector<std::string>& names,
   }
 
   // k-mer jump tables: rows whose suffix starts with the k-mer are contiguous.  The main
-  // table (k = 8, or 10 for libraries >= 4 Mbp) is followed by a k = 6 and a k = 4 table
+  // table (k = 8..12 by library size) is followed by a k = 6 and a k = 4 table
   // for the short pigeonhole pieces of the 2-mismatch pass (6-7 bases of a 19-mer).
   {
-    const uint32_t k_main = ix.n >= (1u << 22) ? 10u : 8u;
+    // k = ceil(log4 n), so the interval the table returns is about one row; at most 11
+    // (the two seed pieces of a 22-nt read) unless the library is >= 64 Mbp, at least 8
+    uint32_t k_main = 8;
+    while (k_main < 11 && (1ull << (2 * k_main)) < ix.n) ++k_main;
+    if (ix.n >= (1u << 26)) k_main = 12;
     ix.ftab_k = k_main;
     const uint32_t ks[3] = {k_main, 6u, 4u};
     size_t total = 0;

@@ -17,7 +17,7 @@
 //            32-39 bases back to the start of its N-free segment (clamped 255),
 //            40-47 bases to the end of the segment (clamped 255), 48-63 segment
 //            id (0xFFFF when the library has more segments than that)
-//   ftab     jump tables: for every k-mer (k = 8, or 10 for libraries >= 4 Mbp; code =
+//   ftab     jump tables: for every k-mer (k = ceil(log4 n) in 8..11, 12 from 64 Mbp; code =
 //            sum base(t) << 2t) the BWT interval [lo,hi) a backward search of it
 //            ends in, so the first k steps of a seed search are one 8-byte load;
 //            followed by a k = 6 and a k = 4 table for short seed pieces
