@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wstop", type=int, default=None)
     ap.add_argument("--no-ftab", action="store_true")
+    ap.add_argument("--sorted", action="store_true",
+                    help="feed the reads in the order the GPU collapse emits uniques (sorted by packed key)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
     args = ap.parse_args()
 
@@ -82,6 +84,8 @@ def main():
     for lo in range(0, n_reads, chunk):
         m = min(chunk, n_reads - lo)
         words[0, lo:lo + m] = synth.synth_reads_packed(libs, m, seed=355 + 1000 * rank + lo // chunk, mix=mix)
+    if args.sorted:
+        words[0].sort()
     lens = np.full(n_reads, 22, dtype=np.uint8)
     quant = synth.synth_quant(n_reads, args.samples, seed=355 + rank)
     log(rank, "reads: %d x 22 nt generated+packed in %.1f s" % (n_reads, time.time() - t0))
