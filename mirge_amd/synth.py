@@ -147,8 +147,14 @@ class SynthLibraries:
                     fh.write(">%s\n%s\n" % (n, s))
         names, seqs = self.libs["mirna"]
         with open(os.path.join(fa, "%s_mirna_SNP_pseudo_%s.fa" % (species, db)), "w") as fh:
+            mature = {}
             for n, s in zip(names, seqs):
+                mature[n] = s[2:-6]
                 fh.write(">%s\n%s\n" % (n, s[2:-6]))
+            # merged names are listed too (the -ai path looks them up, W2C:1295)
+            for line in self.merges:
+                f = line.split(",")
+                fh.write(">%s\n%s\n" % (f[0], mature[f[1]]))
         with open(os.path.join(an, "%s_merges_%s.csv" % (species, db)), "w") as fh:
             for line in self.merges:
                 fh.write(line + "\n")

@@ -133,3 +133,78 @@ int orc_align_all_best(const char *lib, const uint32_t *lib_off, uint32_t n_ref,
   }
   return count;
 }
+
+
+/* Best stratum of one read against one library (forward strand): fewest total
+ * mismatches among the valid alignments and how many alignments reach it.  Used for the
+ * genome filters of the -ai path (writeDataToCSV.py:1263, :1488: `-n N -a -3 2`, where the
+ * reference keeps a read when its minimum-mismatch alignment is unique, :1277-1287). */
+void orc_best_stratum(const char *lib, const uint32_t *lib_off, uint32_t n_ref, const char *read,
+                      int len, int seed_len, int max_mm_seed, int max_mm_total, int32_t *out_mm,
+                      int64_t *out_count) {
+  int best = 1 << 30;
+  int64_t count = 0;
+  if (len > max_mm_seed && len > 0) {
+    int seed = len < seed_len ? len : seed_len;
+    for (uint32_t e = 0; e < n_ref; ++e) {
+      const char *ref = lib + lib_off[e];
+      int rlen = (int)(lib_off[e + 1] - lib_off[e]);
+      for (int o = 0; o + len <= rlen; ++o) {
+        int mm_seed = 0, mm_total = 0, ok = 1;
+        for (int i = 0; i < len && ok; ++i) {
+          char rc = ref[o + i];
+          if (!is_acgt(rc)) ok = 0;
+          else if (read[i] != rc || !is_acgt(read[i])) {
+            ++mm_total;
+            if (i < seed) ++mm_seed;
+            if (mm_total > max_mm_total || mm_seed > max_mm_seed) ok = 0;
+          }
+        }
+        if (!ok) continue;
+        if (mm_total < best) {
+          best = mm_total;
+          count = 1;
+        } else if (mm_total == best) {
+          ++count;
+        }
+      }
+    }
+  }
+  *out_mm = count ? best : 255;
+  *out_count = count;
+}
+
+/* Every valid alignment of one read (forward strand) with its mismatch count, in
+ * (entry, offset) order: what `bowtie -a` without --best/--strata lists.  Returns the
+ * number found; fills at most cap. */
+int orc_list_valid(const char *lib, const uint32_t *lib_off, uint32_t n_ref, const char *read, int len,
+                   int seed_len, int max_mm_seed, int max_mm_total, int32_t *refs, int32_t *poss,
+                   int32_t *mms, int cap) {
+  int count = 0;
+  if (len <= max_mm_seed || len <= 0) return 0;
+  int seed = len < seed_len ? len : seed_len;
+  for (uint32_t e = 0; e < n_ref; ++e) {
+    const char *ref = lib + lib_off[e];
+    int rlen = (int)(lib_off[e + 1] - lib_off[e]);
+    for (int o = 0; o + len <= rlen; ++o) {
+      int mm_seed = 0, mm_total = 0, ok = 1;
+      for (int i = 0; i < len && ok; ++i) {
+        char rc = ref[o + i];
+        if (!is_acgt(rc)) ok = 0;
+        else if (read[i] != rc || !is_acgt(read[i])) {
+          ++mm_total;
+          if (i < seed) ++mm_seed;
+          if (mm_total > max_mm_total || mm_seed > max_mm_seed) ok = 0;
+        }
+      }
+      if (!ok) continue;
+      if (count < cap) {
+        refs[count] = (int32_t)e;
+        poss[count] = o;
+        mms[count] = mm_total;
+      }
+      ++count;
+    }
+  }
+  return count;
+}

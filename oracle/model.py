@@ -99,6 +99,71 @@ def align_all_best(library, read, seed_len, max_mm_seed, max_mm_total, cap=4096)
     return [(int(refs[i]), int(poss[i])) for i in range(k)], int(mm.value)
 
 
+def best_stratum(library, read, seed_len, max_mm_seed, max_mm_total):
+    """(fewest mismatches, number of alignments reaching it) on the forward strand;
+    (255, 0) when nothing aligns."""
+    mm = C.c_int32(255)
+    cnt = C.c_int64(0)
+    r = read.upper().encode("ascii")
+    f = lib().orc_best_stratum
+    f.restype = None
+    f(C.c_char_p(library.concat), library.off.ctypes.data_as(C.c_void_p), C.c_uint32(len(library.names)),
+      C.c_char_p(r), C.c_int(len(r)), C.c_int(seed_len), C.c_int(max_mm_seed), C.c_int(max_mm_total),
+      C.byref(mm), C.byref(cnt))
+    return int(mm.value), int(cnt.value)
+
+
+def list_valid(library, read, seed_len, max_mm_seed, max_mm_total, cap=65536):
+    """[(entry, offset, mismatches)] of every valid forward-strand alignment (`bowtie -a`)."""
+    refs = np.zeros(cap, dtype=np.int32)
+    poss = np.zeros(cap, dtype=np.int32)
+    mms = np.zeros(cap, dtype=np.int32)
+    r = read.upper().encode("ascii")
+    f = lib().orc_list_valid
+    f.restype = C.c_int
+    k = f(C.c_char_p(library.concat), library.off.ctypes.data_as(C.c_void_p), C.c_uint32(len(library.names)),
+          C.c_char_p(r), C.c_int(len(r)), C.c_int(seed_len), C.c_int(max_mm_seed), C.c_int(max_mm_total),
+          refs.ctypes.data_as(C.c_void_p), poss.ctypes.data_as(C.c_void_p), mms.ctypes.data_as(C.c_void_p),
+          C.c_int(cap))
+    return [(int(refs[i]), int(poss[i]), int(mms[i])) for i in range(min(k, cap))]
+
+
+_COMP = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+
+def revcomp(s):
+    return "".join(_COMP.get(ch, "N") for ch in reversed(s))
+
+
+class ScanGenome:
+    """The two genome bowtie runs of the -ai path (writeDataToCSV.py:1263, :1488) answered by
+    exhaustive scan: both strands, 3' 2 nt trimmed, -n 1 / -n 0."""
+
+    def __init__(self, library):
+        self.library = library
+
+    def _best(self, read, max_mm_seed):
+        t = read[:-2]
+        a = best_stratum(self.library, t, 28, max_mm_seed, 2)
+        b = best_stratum(self.library, revcomp(t), 28, max_mm_seed, 2)
+        if a[0] < b[0]:
+            return a
+        if b[0] < a[0]:
+            return b
+        return (a[0], a[1] + b[1])
+
+    def unique_best(self, reads):
+        out = set()
+        for r in set(reads):
+            mm, cnt = self._best(r, 1)
+            if mm < 255 and cnt == 1:
+                out.add(r)
+        return out
+
+    def exact_hit(self, reads):
+        return {r for r in set(reads) if self._best(r, 0)[0] < 255}
+
+
 # ---------------------------------------------------------------------------
 # fm_cpu.c: the host-core port of the seed-and-verify matcher
 # ---------------------------------------------------------------------------

@@ -72,6 +72,28 @@ def main():
     reads = [l.strip() for l in open(fasta) if l.strip() and l[0] != ">"]
     seed_len, mm_seed, mm_total = (28, mm, 2) if mode == "n" else (1 << 20, mm, mm)
     trimmed = [r[t5:len(r) - t3] if t3 else r[t5:] for r in reads]
+    if "-S" not in argv:
+        # bowtie's default output (the two genome runs of writeDataToCSV.py:1263/:1488 pass no -S):
+        # one line per alignment, aligned reads only, both strands unless --norc, last column
+        # = mismatch descriptors ("offset:ref>read", comma separated)
+        aligned = 0
+        for k, r in enumerate(reads):
+            hit = False
+            for strand, q in (("+", trimmed[k]), ("-", model.revcomp(trimmed[k]))):
+                if strand == "-" and "--norc" in argv:
+                    continue
+                found = model.list_valid(lib, q, seed_len, mm_seed, mm_total)
+                if not all_best:
+                    found = found[:1]
+                for (e, o, nmm) in found:
+                    ref = lib.seqs[e][o:o + len(q)]
+                    desc = ",".join("%%d:%%s>%%s" %% (i, ref[i], q[i]) for i in range(len(q)) if ref[i] != q[i])
+                    sys.stdout.write("\t".join([r, strand, lib.names[e], str(o), q, "I" * len(q), "0", desc]) + "\n")
+                    hit = True
+            aligned += hit
+        sys.stderr.write("# reads processed: %%d\n# reads with at least one reported alignment: %%d (0.00%%%%)\n"
+                         %% (len(reads), aligned))
+        return 0
     ref, p0, nm = model.align_batch(lib, trimmed, seed_len, mm_seed, mm_total)
     out = sys.stdout
     for n in lib.names:
@@ -349,8 +371,146 @@ def main():
         print("wrote", out, os.path.getsize(out), "bytes;", len(seq_dic), "unique reads;",
               "annotStats", golden["expected"]["annotStats"])
         make_gff_golden(scratch, bindir)
+        make_a2i_golden(scratch, bindir)
     finally:
         shutil.rmtree(scratch, ignore_errors=True)
+
+
+def make_a2i_golden(scratch, bindir):
+    """-ai: a2IEditing.report.csv / .newform.csv / .detail.txt from the reference
+    (writeDataToCSV.py:1221-1594) -> tests/golden/a2i.json.  pairwise2 is answered by
+    mirge_amd.a2i.local_pair (Biopython is absent: parity unpinned for it), the genome bowtie
+    runs by the stand-in; the three Python-2 integer divisions `/7)+1` of :1428,:1467,... are
+    rewritten `//` in the scratch copy (lib2to3 leaves them)."""
+    import copy
+    import importlib
+    import numpy as np
+    from mirge_amd import a2i as my_a2i
+    from mirge_amd import synth
+    os.environ["LC_ALL"] = "C"      # the reference sorts its table with sort(1), W2C:1444
+    w2c_path = os.path.join(scratch, "mirge", "utils", "writeDataToCSV.py")
+    src = open(w2c_path).read().replace("(len(content)-9)/7)+1", "(len(content)-9)//7)+1")
+    open(w2c_path, "w").write(src)
+    pw = sys.modules["Bio.pairwise2"]
+
+    class _Align(object):
+        @staticmethod
+        def localms(a, b, match, mismatch, gap_open, gap_ext):
+            t, s_ = my_a2i.local_pair(a, b, match, mismatch)
+            return [(t, s_, 0, 0, len(t))]
+    pw.align = _Align
+    for m in ("mirge.utils.writeDataToCSV",):
+        sys.modules.pop(m, None)
+    W2C = importlib.import_module("mirge.utils.writeDataToCSV")
+    RAP = importlib.import_module("mirge.utils.runAnnotationPipeline")
+    from mirge.utils.quantReads import quantReads
+    from mirge.utils.summarize import summarize
+    from mirge.utils.miRNAmerge import miRNAmerge
+    from mirge.utils.filter import filter as ref_filter
+
+    libs = synth.SynthLibraries(seed=55, scale=1.0, n_paralogs=4, n_snp=0, shapes=SHAPES)
+    rng = np.random.default_rng(17)
+    mir_names, mir_seqs = libs.libs["mirna"]
+    hp_names, hp_seqs = libs.libs["hairpin"]
+
+    def rs(n):
+        return "".join("ACGT"[c] for c in rng.integers(0, 4, n))
+    # genome: every hairpin once (its miRNAs map uniquely), some twice (their reads are not
+    # unique), random filler, and a few already-edited matures (those sites must be dropped)
+    edit_targets = []
+    for j in range(0, 40, 2):
+        mature = mir_seqs[j][2:-6]
+        a_pos = [i for i, ch in enumerate(mature[:len(mature) - 5]) if ch == "A"]
+        if a_pos:
+            edit_targets.append((j, a_pos[int(rng.integers(0, len(a_pos)))]))
+    chroms = []
+    for c in range(4):
+        parts = []
+        for h in range(c, len(hp_seqs), 4):
+            parts += [rs(int(rng.integers(200, 600))), hp_seqs[h]]
+            if h % 9 == 0:
+                parts += [rs(150), hp_seqs[h]]
+        parts.append(rs(400))
+        chroms.append("".join(parts))
+    for (j, p) in edit_targets[:4]:
+        m = mir_seqs[j][2:-6]
+        chroms[0] += rs(100) + m[:p] + "G" + m[p + 1:] + rs(100)
+    chroms[1] = chroms[1] + synth.codes_to_str(np.array([0, 1, 2, 3] * 40, dtype=np.uint8))
+    # reverse-strand copy of one hairpin: still one locus for its reads... and a second, RC, copy of another
+    chroms[2] += rs(80) + my_a2i.revcomp(hp_seqs[7]) + rs(80)
+    libs.libs["genome"] = (["chr%d" % (c + 1) for c in range(4)], chroms)
+
+    samples = []
+    for si in range(2):
+        reads = [synth.codes_to_str(c) for c in synth.synth_reads(libs, 1500, seed=300 + si, zipf_s=1.2)]
+        for (j, p) in edit_targets:
+            m = mir_seqs[j][2:-6]
+            n_can = int(rng.integers(60, 260))
+            n_edit = int(rng.integers(0, 30)) if rng.random() < 0.8 else 0
+            reads += [m] * n_can + [m[:p] + "G" + m[p + 1:]] * n_edit
+            reads += [m[:-1]] * int(rng.integers(0, 8)) + [m + "A"] * int(rng.integers(0, 8))
+            if rng.random() < 0.5:      # a second, weaker site on the same miRNA
+                a_pos = [i for i, ch in enumerate(m[:len(m) - 5]) if ch == "A" and i != p]
+                if a_pos:
+                    q = a_pos[0]
+                    reads += [m[:q] + "G" + m[q + 1:]] * int(rng.integers(1, 6))
+        reads = [r for r in reads if len(r) >= 16]
+        order = rng.permutation(len(reads))
+        samples.append([reads[i] for i in order])
+
+    libroot = os.path.join(scratch, "libs_a2i")
+    prefix = libs.write_layout(libroot, species="syn", db="miRBase")
+    outdir = os.path.join(scratch, "out_a2i")
+    os.makedirs(outdir)
+    sample_list = ["a0.fastq", "a1.fastq"]
+    seq_dic, len_dic = {}, {}
+    for si, reads in enumerate(samples):
+        fq = os.path.join(outdir, "a%d.trim.fastq" % si)
+        with open(fq, "w") as fh:
+            for k, r in enumerate(reads):
+                fh.write("@r%d\n%s\n+\n%s\n" % (k, r, "I" * len(r)))
+        quantReads(fq, seq_dic, len_dic, 2, si, sample_list, False, False)
+    log_dic = {"quantStats": [{"filename": s} for s in sample_list], "annotStats": []}
+    annot_names = ["exact miRNA", "hairpin miRNA", "mature tRNA", "primary tRNA", "snoRNA", "rRNA",
+                   "ncrna others", "mRNA", "isomiR miRNA"]
+    ix = lambda k: prefix + k
+    RAP.runAnnotationPipeline(bindir, seq_dic, "1", False, annot_names, outdir, log_dic,
+                              ix("mirna_miRBase"), ix("hairpin_miRBase"), ix("mature_trna"), ix("pre_trna"),
+                              ix("snorna"), ix("rrna"), ix("ncrna_others"), ix("mrna"), False, None, False,
+                              None, None, "miRBase", False, None, None, sample_list)
+    mir_dic, name_seq = {}, {}
+    summarize(seq_dic, sample_list, log_dic, mir_dic, ix("mirna_miRBase"), outdir, False, bindir)
+    miRNAmerge(os.path.join(libroot, "syn", "annotation.Libs", "syn_merges_miRBase.csv"), sample_list,
+               mir_dic, os.path.join(libroot, "syn", "fasta.Libs", "syn_mirna_SNP_pseudo_miRBase.fa"), name_seq)
+    ref_filter(mir_dic, sample_list, log_dic, "0.1")
+    merged_name = {}
+    for line in libs.merges:
+        f = line.split(",")
+        for m in f[1:]:
+            merged_name[m] = f[0]
+    removed = [mir_names[edit_targets[5][0]]] if len(edit_targets) > 5 else []
+    state_in = {"seqDic": copy.deepcopy(seq_dic), "mirDic": copy.deepcopy(mir_dic),
+                "quantStats": [{k: v for k, v in q.items() if k != "filename"} for q in log_dic["quantStats"]]}
+    W2C.writeDataToCSV(outdir, annot_names, sample_list, False, True, log_dic, seq_dic, mir_dic, name_seq,
+                       merged_name, bindir, ix("genome"), "1", False, removed, False, False, None, "miRBase",
+                       False, None, None, None, None, None, None, None, None)
+    files = {}
+    for fn in ("a2IEditing.report.csv", "a2IEditing.report.newform.csv", "a2IEditing.detail.txt"):
+        files[fn] = open(os.path.join(outdir, fn)).read().split("\n")
+    golden = {
+        "about": "captured from the reference's Python (-ai path) by tests/golden/make_golden.py; "
+                 "pairwise2 and the genome bowtie runs are stand-ins (parity unpinned for both)",
+        "libraries": {k: [list(v[0]), list(v[1])] for k, v in libs.libs.items()},
+        "merges": libs.merges, "samples": samples, "sample_list": sample_list,
+        "mirNameSeqDic": name_seq, "mirMergedNameDic": merged_name, "removedMiRNAList": removed,
+        "state": state_in,
+        "expected": {"files": files},
+    }
+    out = os.path.join(ROOT, "tests", "golden", "a2i.json")
+    with open(out, "w") as fh:
+        json.dump(golden, fh, separators=(",", ":"), sort_keys=True)
+    print("wrote", out, os.path.getsize(out), "bytes; report rows", len(files["a2IEditing.report.csv"]) - 2,
+          "newform rows", len(files["a2IEditing.report.newform.csv"]) - 2)
 
 
 def make_gff_golden(scratch, bindir):

@@ -1,0 +1,93 @@
+"""mirge_amd.a2i (the -ai A-to-I tally) against the reference's own run
+(tests/golden/a2i.json; pairwise2 and the genome bowtie runs are stand-ins there)."""
+import copy
+import json
+import os
+
+import pytest
+
+from mirge_amd import a2i
+from tests.conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(ROOT, "tests", "golden", "a2i.json")) as fh:
+        return json.load(fh)
+
+
+def run_report(golden, genome, outdir):
+    st = golden["state"]
+    log_dic = {"quantStats": copy.deepcopy(st["quantStats"])}
+    return a2i.a_to_i_report(str(outdir), golden["sample_list"], log_dic, st["seqDic"], st["mirDic"],
+                             golden["mirNameSeqDic"], golden["mirMergedNameDic"], golden["removedMiRNAList"],
+                             genome)
+
+
+def check_files(golden, outdir):
+    exp = golden["expected"]["files"]
+    fn = "a2IEditing.report.csv"
+    assert open(os.path.join(str(outdir), fn)).read().split("\n") == exp[fn], fn
+    # newform: identical but for the log2RPM column, which the reference prints with Python 2's
+    # 12-digit str(float) (the golden was captured under Python 3: 17 digits)
+    fn = "a2IEditing.report.newform.csv"
+    got = open(os.path.join(str(outdir), fn)).read().split("\n")
+    assert len(got) == len(exp[fn]) and got[0] == exp[fn][0]
+    for g, w in zip(got[1:], exp[fn][1:]):
+        gc, wc = g.split(","), w.split(",")
+        assert gc[:-1] == wc[:-1]
+        if gc[-1] != wc[-1]:
+            assert abs(float(gc[-1]) - float(wc[-1])) < 1e-10 and len(gc[-1]) <= 14
+    # the detail file is written miRNA by miRNA in dict order (arbitrary in the reference)
+    got = open(os.path.join(str(outdir), "a2IEditing.detail.txt")).read().split("\n")
+    assert sorted(got) == sorted(exp["a2IEditing.detail.txt"])
+    assert len(exp["a2IEditing.report.csv"]) > 10
+
+
+def test_report_with_exhaustive_scan_genome(golden, oracle_lib, tmp_path):
+    from oracle import model
+    genome = model.ScanGenome(model.Library(*golden["libraries"]["genome"]))
+    run_report(golden, genome, tmp_path)
+    check_files(golden, tmp_path)
+
+
+def test_judge_align_known_answers():
+    t = "TGAGGTAGTAGGTTGTATAGTT"
+    j = lambda s: a2i.judge_align(*a2i.local_pair(t, s))
+    assert j(t) is True
+    assert j(t[2:]) is False                  # read starting 2 nt late
+    assert j(t[:8] + "CC" + t[10:]) is False  # 2 internal mismatches
+    assert j(t[1:]) is True and j(t[:9] + "G" + t[10:]) is True
+    assert a2i.refine_name("a0.fastq") == "a0" and a2i.refine_name("x.fastq.gz") == "x.gz"
+
+
+def test_local_pair_is_the_best_ungapped_diagonal():
+    t = "TGAGGTAGTAGGTTGTATAGTT"
+    assert a2i.local_pair(t, "GAGGTAGTAGGTTGTATAGTTA") == (t + "-", "-GAGGTAGTAGGTTGTATAGTTA")
+    assert a2i.local_pair(t, "TT" + t) == ("--" + t, "TT" + t)
+    frame, states = a2i.align_to_target(t, [t, "A" + t, t[1:] + "CC"])
+    assert len({len(x) for x in frame}) == 1 and frame[0].strip("-") == t and states == [True, True, True]
+
+
+@pytest.mark.gpu
+def test_report_with_gpu_genome_filters(golden, native_lib, oracle_lib, tmp_path):
+    """The two genome runs on the GPU (both strands, best-stratum multiplicity) give the same
+    retained / removed sets as the exhaustive scan, hence the same report."""
+    from mirge_amd.engine import Engine
+    from mirge_amd.index import FmIndex
+    from oracle import model
+    eng = Engine(0)
+    names, seqs = golden["libraries"]["genome"]
+    keys = []
+    for n, s in zip(names, seqs):           # one library per chromosome
+        eng.add_library("genome:" + n, FmIndex.build([n], [s]))
+        keys.append("genome:" + n)
+    gpu = a2i.EngineGenome(eng, keys)
+    scan = model.ScanGenome(model.Library(names, seqs))
+    reads = [s for s, r in golden["state"]["seqDic"].items() if r["annot"][1] != "" or r["annot"][9] != ""]
+    reads += ["ACGT" * 6, "ACGTACGTACGTACGTACGTAC", "TTTTTTTTTTTTTTTTTTTTTT"]
+    assert gpu.unique_best(reads) == scan.unique_best(reads)
+    assert gpu.exact_hit(reads) == scan.exact_hit(reads)
+    assert 0 < len(scan.unique_best(reads)) < len(set(reads))
+    run_report(golden, gpu, tmp_path)
+    check_files(golden, tmp_path)
