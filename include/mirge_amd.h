@@ -198,6 +198,20 @@ int mrg_tally_run(mrg_ctx *ctx, const int8_t *d_pass_id, const int32_t *d_ref_id
                   int32_t isomir_pass, uint64_t *d_counts, void *stream);
 
 /*
+ * Best stratum of every read against ONE library, forward strand only: d_best_mm[r] = fewest
+ * mismatches of a valid alignment (255 = the read does not align), d_count[r] = number of
+ * alignments reaching it (saturates at 255; also 255 when a seed is too repetitive to be
+ * walked).  Replaces the genome bowtie runs of the -ai path (utils/writeDataToCSV.py:1263
+ * `-n 1 -f -a -3 2` and :1488 `-n 0 -f -a -3 2`), which only ask "is the best hit unique"
+ * (:1277-1287) and "does it align" (:1491-1496); the host trims the 3' 2 nt, submits each
+ * read and its reverse complement, and sums over the chromosome libraries.
+ */
+int mrg_count_best(mrg_ctx *ctx, const uint64_t *d_reads, uint32_t words_per_read,
+                   const uint8_t *d_lens, const uint64_t *d_nmask, uint64_t n, int32_t lib,
+                   int32_t seed_len, int32_t max_mm_seed, int32_t max_mm_total,
+                   uint8_t *d_best_mm, uint8_t *d_count, void *stream);
+
+/*
  * Host-buffer convenience for a caller without its own device allocator (the
  * ctypes stub of INTEGRATION.md): H2D, cascade, tally, D2H in one call.
  * counts may be NULL (then quant/n_samples are ignored).

@@ -546,6 +546,50 @@ int mrg_tally_run(mrg_ctx* ctx, const int8_t* d_pass_id, const int32_t* d_ref_id
   return MRG_OK;
 }
 
+// ------------------------------------------------------------ count best
+int mrg_count_best(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_read, const uint8_t* d_lens,
+                   const uint64_t* d_nmask, uint64_t n, int32_t lib, int32_t seed_len, int32_t max_mm_seed,
+                   int32_t max_mm_total, uint8_t* d_best_mm, uint8_t* d_count, void* stream) {
+  if (!ctx) return fail(MRG_ERR_ARG, "mrg_count_best: null argument");
+  if (n && (!d_reads || !d_lens || !d_best_mm || !d_count)) return fail(MRG_ERR_ARG, "mrg_count_best: null buffers");
+  if (lib < 0 || (size_t)lib >= ctx->libs.size()) return fail(MRG_ERR_ARG, "mrg_count_best: unknown library %d", lib);
+  if (words_per_read != 1 && words_per_read != 2 && words_per_read != 4)
+    return fail(MRG_ERR_ARG, "mrg_count_best: words_per_read must be 1, 2 or 4");
+  if (max_mm_seed < 0 || max_mm_seed > 2 || max_mm_total < max_mm_seed || seed_len < 1)
+    return fail(MRG_ERR_ARG, "mrg_count_best: invalid policy");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (n == 0) return MRG_OK;
+  const DevLib& l = ctx->libs[lib];
+  const uint64_t lds = (uint64_t)l.nsup * 16;
+  if (lds > 160 * 1024) return fail(MRG_ERR_ARG, "mrg_count_best: library too large for one call (split it)");
+  mrg::CountParams p;
+  p.blocks = l.blocks;
+  p.super = l.super;
+  p.text = l.text;
+  p.sa = l.sa;
+  p.ftab = l.ftab;
+  p.ftab_k = ctx->use_ftab ? l.ftab_k : 0u;
+  p.n = l.n;
+  p.nsup = l.nsup;
+  p.primary = l.primary;
+  p.reads = d_reads;
+  p.lens = d_lens;
+  p.nmask = d_nmask;
+  p.n_reads = n;
+  p.seed_len = seed_len;
+  p.max_mm_seed = max_mm_seed;
+  p.max_mm_total = max_mm_total;
+  p.wstop = (uint32_t)ctx->wstop;
+  p.max_rows = 4096u;
+  p.best_mm = d_best_mm;
+  p.count = d_count;
+  const uint64_t want = (n + mrg::kCountThreads - 1) / mrg::kCountThreads;
+  const uint32_t per_cu = lds ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, (160 * 1024) / lds)) : 8u;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)ctx->n_cu * per_cu);
+  HIP_TRY(mrg::launch_count(p, words_per_read, grid, (uint32_t)lds, (hipStream_t)stream));
+  return MRG_OK;
+}
+
 // ----------------------------------------------------- host convenience
 int mrg_annotate_host(mrg_ctx* ctx, const uint64_t* reads, uint32_t words_per_read,
                       const uint8_t* lens, const uint64_t* nmask, uint64_t n,

@@ -439,6 +439,140 @@ match_kernel(const MatchParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// count_kernel: best stratum of every read against one library -- fewest mismatches of a
+// valid alignment and how many alignments reach it.  Replaces the two genome bowtie runs
+// of the -ai path (writeDataToCSV.py:1263 `-n 1 -a -3 2`, :1488 `-n 0 -a -3 2`), whose
+// only use is "is the best hit unique" (:1277-1287) / "does it align at all" (:1491-1496).
+// Same seed-and-verify as match_kernel, library served from HBM/L2 (a chromosome), no
+// survivor lists.  An alignment can sit in the candidate rows of several pieces; it is
+// counted at the first piece whose searched bases it matches exactly.
+// ---------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(kCountThreads) count_kernel(const CountParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(p.super);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    for (uint32_t i = threadIdx.x; i < p.nsup; i += kCountThreads) dst[i] = src[i];
+  }
+  __syncthreads();
+  Lib<false, false> lib;
+  lib.gblocks = p.blocks;
+  lib.gtext = p.text;
+  lib.sblocks = nullptr;
+  lib.stext = nullptr;
+  lib.ssuper = smem;
+  lib.primary = p.primary;
+
+  for (uint64_t r = (uint64_t)blockIdx.x * kCountThreads + threadIdx.x; r < p.n_reads;
+       r += (uint64_t)gridDim.x * kCountThreads) {
+    uint64_t rd[W], nm[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      rd[k] = p.reads[(size_t)k * p.n_reads + r];
+      nm[k] = p.nmask ? p.nmask[(size_t)k * p.n_reads + r] : 0ull;
+    }
+    const int32_t L = (int32_t)p.lens[r];
+    uint32_t best_mm = 255u, count = 0u;
+    if (L > p.max_mm_seed) {
+      const int32_t R = min(L, p.seed_len);
+      const int32_t K = p.max_mm_seed + 1;
+      int32_t stop_[3] = {0, 0, 0}, end_[3] = {0, 0, 0};
+      bool listed[3] = {false, false, false};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (k >= K) continue;
+        const int32_t a = div_pieces(R * k, K), b = div_pieces(R * (k + 1), K);
+        bool has_n = false;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          const int32_t lo_b = max(a - 32 * w, 0), hi_b = min(b - 32 * w, 32);
+          if (hi_b > lo_b) has_n |= (nm[w] & low_bits(2 * hi_b) & ~low_bits(2 * lo_b)) != 0ull;
+        }
+        if (has_n) continue;
+        uint32_t lo = 0, hi = p.n + 1;
+        int32_t j = b;
+        if (p.ftab_k && b - a >= 4) {
+          const int32_t plen = b - a;
+          const uint32_t kk = plen >= (int32_t)p.ftab_k ? p.ftab_k : (plen >= 6 ? 6u : 4u);
+          const uint32_t tab_off = plen >= (int32_t)p.ftab_k ? 0u
+                                   : (2u << (2 * p.ftab_k)) + (plen >= 6 ? 0u : (2u << 12));
+          j = b - (int32_t)kk;
+          uint64_t code = pick_word<W>(rd, (uint32_t)j >> 5) >> ((j & 31) * 2);
+          if (W > 1 && (j & 31) + (int32_t)kk > 32)
+            code |= pick_word<W>(rd, ((uint32_t)j >> 5) + 1) << (64 - (j & 31) * 2);
+          code &= (1ull << (2 * kk)) - 1ull;
+          const uint2 iv = *reinterpret_cast<const uint2*>(p.ftab + tab_off + 2 * code);
+          lo = iv.x;
+          hi = iv.y;
+        }
+        while (j > a && hi > lo && (hi - lo) > p.wstop) {
+          --j;
+          const uint32_t c = (uint32_t)(pick_word<W>(rd, (uint32_t)j >> 5) >> ((j & 31) * 2)) & 3u;
+          const uint4 vl = lib.block(lo >> 5);
+          uint4 vh = vl;
+          if ((hi >> 5) != (lo >> 5)) vh = lib.block(hi >> 5);
+          lo = lib.lf(c, lo, vl);
+          hi = lib.lf(c, hi, vh);
+        }
+        stop_[k] = j;
+        end_[k] = b;
+        listed[k] = true;
+        if (hi > lo && hi - lo > p.max_rows) {
+          // a seed this repetitive cannot have a unique best hit; do not walk 10^5+ rows
+          count = 255u;
+          hi = lo + p.max_rows;
+        }
+        const uint32_t need_before = (uint32_t)j, need_after = (uint32_t)(L - j);
+        for (uint32_t i = lo; i < hi; ++i) {
+          const uint64_t row = p.sa[i];
+          const uint32_t before = (uint32_t)(row >> 32) & 255u, after = (uint32_t)(row >> 40) & 255u;
+          if ((need_before > before) | (need_after > after)) continue;
+          const uint32_t s = (uint32_t)row - need_before;
+          uint64_t m[W];
+          uint32_t mm_total = 0, mm_seed = 0;
+#pragma unroll
+          for (int w = 0; w < W; ++w) {
+            m[w] = 0ull;
+            const int32_t nb = min(32, L - 32 * w);
+            if (nb > 0) {
+              const uint64_t x = lib.window(s + 32u * w) ^ rd[w];
+              m[w] = (((x | (x >> 1)) & kOdd) | nm[w]) & low_bits(2 * nb);
+              mm_total += (uint32_t)__popcll(m[w]);
+              const int32_t ns = min(nb, max(0, p.seed_len - 32 * w));
+              mm_seed += (uint32_t)__popcll(m[w] & low_bits(2 * ns));
+            }
+          }
+          if (((int32_t)mm_seed > p.max_mm_seed) | ((int32_t)mm_total > p.max_mm_total)) continue;
+          // already counted if an earlier piece's searched bases match exactly here
+          bool seen = false;
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            if (q >= k || !listed[q]) continue;
+            bool exact = true;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+              const int32_t lo_b = max(stop_[q] - 32 * w, 0), hi_b = min(end_[q] - 32 * w, 32);
+              if (hi_b > lo_b) exact &= (m[w] & low_bits(2 * hi_b) & ~low_bits(2 * lo_b)) == 0ull;
+            }
+            seen |= exact;
+          }
+          if (seen) continue;
+          if (mm_total < best_mm) {
+            best_mm = mm_total;
+            if (count != 255u) count = 1u;
+          } else if (mm_total == best_mm && count < 255u) {
+            ++count;
+          }
+        }
+      }
+    }
+    p.best_mm[r] = (uint8_t)best_mm;
+    p.count[r] = (uint8_t)(best_mm == 255u ? 0u : count);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Tally (SUM:34-66).  Bins are privatised in LDS per workgroup (`LDSH`) and flushed
 // with one global atomic per non-zero bin.  trimmedUniq, the one bin every lane hits,
 // is aggregated across the wave (a ballot popcount, one add per wave).  Category and
@@ -552,6 +686,17 @@ hipError_t launch_tally(const TallyParams& p, bool lds_hist, uint32_t grid,
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kTallyThreads), lds_bytes, stream, p);
   } else {
     hipLaunchKernelGGL(tally_kernel<false>, dim3(grid), dim3(kTallyThreads), 0, stream, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_count(const CountParams& p, uint32_t words_per_read, uint32_t grid, uint32_t lds_bytes,
+                        hipStream_t stream) {
+  switch (words_per_read) {
+    case 1: hipLaunchKernelGGL(count_kernel<1>, dim3(grid), dim3(kCountThreads), lds_bytes, stream, p); break;
+    case 2: hipLaunchKernelGGL(count_kernel<2>, dim3(grid), dim3(kCountThreads), lds_bytes, stream, p); break;
+    case 4: hipLaunchKernelGGL(count_kernel<4>, dim3(grid), dim3(kCountThreads), lds_bytes, stream, p); break;
+    default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }

@@ -57,6 +57,25 @@ struct MatchParams {
   uint32_t wide_rows;  // seed intervals wider than this are verified by the whole wave
 };
 
+constexpr uint32_t kCountThreads = 256u;
+
+struct CountParams {
+  const uint32_t* blocks;
+  const uint32_t* super;
+  const uint32_t* text;
+  const uint64_t* sa;
+  const uint32_t* ftab;
+  uint32_t ftab_k, n, nsup, primary;
+  const uint64_t* reads;
+  const uint8_t* lens;
+  const uint64_t* nmask;
+  uint64_t n_reads;
+  int32_t seed_len, max_mm_seed, max_mm_total;
+  uint32_t wstop, max_rows;
+  uint8_t* best_mm;
+  uint8_t* count;
+};
+
 struct TallyParams {
   const int8_t* pass_id;
   const int32_t* ref_id;
@@ -79,6 +98,8 @@ hipError_t collapse_reads(const uint64_t* d_reads, uint32_t W, const uint8_t* d_
                           uint32_t n_samples, uint32_t max_len, uint64_t cap, uint64_t* d_u_words,
                           uint8_t* d_u_lens, uint64_t* d_u_nmask, uint32_t* d_quant,
                           uint64_t* d_len_hist, uint32_t* h_n_unique, hipStream_t stream);
+hipError_t launch_count(const CountParams& p, uint32_t words_per_read, uint32_t grid, uint32_t lds_bytes,
+                        hipStream_t stream);
 hipError_t launch_export_pass_counts(const uint64_t* stats, uint32_t n_pass, uint64_t* out,
                                      hipStream_t stream);
 

@@ -209,6 +209,20 @@ class Engine:
             self._stream_ptr()))
         return counts
 
+    def count_best(self, reads, lib, seed_len=28, max_mm_seed=1, max_mm_total=2):
+        """Best stratum of every read of a ReadSet against one library, forward strand:
+        (fewest mismatches or 255, alignments reaching it, saturating) as host uint8 arrays.
+        The -ai genome filters of writeDataToCSV.py:1263/:1488 (see mirge_amd.a2i)."""
+        torch = _torch()
+        mm = torch.empty(reads.n, dtype=torch.uint8, device=self.device)
+        cnt = torch.empty(reads.n, dtype=torch.uint8, device=self.device)
+        lid = self.libs[lib] if isinstance(lib, str) else int(lib)
+        check(self._lib.mrg_count_best(
+            self._h, reads.words.data_ptr(), reads.W, reads.lens.data_ptr(),
+            reads.nmask.data_ptr() if reads.nmask is not None else None, reads.n, lid, int(seed_len),
+            int(max_mm_seed), int(max_mm_total), mm.data_ptr(), cnt.data_ptr(), self._stream_ptr()))
+        return mm.cpu().numpy(), cnt.cpu().numpy()
+
     # ------------------------------------------------------------------
     def annotate_host(self, words, lens, nmask, passes, quant=None, n_mirna=0,
                       canon_pass=CANON_PASS, isomir_pass=ISOMIR_PASS):

@@ -237,3 +237,55 @@ def test_low_complexity_library_and_reads(native_lib, oracle_lib):
             got = (int(ref_id[i]), int(pos[i]), int(mm[i])) if pass_id[i] == 0 else (-1, -1, -1)
             assert got == (int(want_ref[i]), int(want_pos[i]), int(want_mm[i])), (r, seed_len, mm_seed)
         assert max(s["candidates"] for s in res.stats) > 20000   # the wave-wide verification ran
+
+
+@pytest.mark.gpu
+def test_count_best_matches_exhaustive_scan(native_lib, oracle_lib):
+    """mrg_count_best (the -ai genome filters, W2C:1263/:1488): best mismatch count and its
+    multiplicity equal the exhaustive scan, on a library with planted repeats so that one
+    alignment is reachable from several pigeonhole pieces and one read has several best hits."""
+    from mirge_amd.engine import Engine, ReadSet
+    from mirge_amd.index import FmIndex
+    from mirge_amd import pack
+    rng = np.random.default_rng(77)
+    def rnd(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+    unit = rnd(40)
+    mut = list(unit)
+    mut[7] = "A" if mut[7] != "A" else "C"
+    mut2 = list(unit)
+    mut2[30] = "G" if mut2[30] != "G" else "T"
+    seqs = [rnd(3000) + unit + rnd(500) + "".join(mut) + rnd(700) + unit + rnd(100),
+            rnd(1200) + "".join(mut2) + "N" + rnd(800) + "A" * 60 + rnd(300) + "ACGT" * 20 + rnd(50),
+            unit[:30]]
+    names = ["chrA", "chrB", "chrC"]
+    olib = model.Library(names, seqs)
+    eng = Engine(0)
+    eng.add_library("g", FmIndex.build(names, seqs))
+    reads = []
+    for s in seqs[:2]:
+        for _ in range(300):
+            L = int(rng.integers(14, 41))
+            o = int(rng.integers(0, len(s) - L))
+            r = list(s[o:o + L].replace("N", "A"))
+            for _ in range(int(rng.integers(0, 4))):
+                k = int(rng.integers(0, L))
+                r[k] = "ACGT"[int(rng.integers(0, 4))]
+            reads.append("".join(r))
+    for L in (16, 20, 22, 28, 30, 33, 40):
+        for o in (0, 3, 8):
+            if o + L <= 40:
+                reads += [unit[o:o + L], "".join(mut)[o:o + L], "".join(mut2)[o:o + L]]
+    reads += ["A" * 20, "A" * 35, "ACGT" * 6, "ACGTACGTACGTACGTACGTAC", "ACGTNACGTACGTACGTACG", rnd(25), "AC", "A"]
+    words, lens, nmask = pack.pack_reads(reads)
+    rs = ReadSet(words, lens, nmask, None, device=eng.device)
+    for seed_len, n_seed, n_total in ((28, 1, 2), (28, 0, 2), (28, 2, 2), (20, 1, 1), (64, 0, 0)):
+        for opts in ({}, {"wstop": 0, "ftab": 0}):
+            for k, v in {"wstop": 2, "ftab": 1, **opts}.items():
+                eng.set_option(k, v)
+            mm, cnt = eng.count_best(rs, "g", seed_len=seed_len, max_mm_seed=n_seed, max_mm_total=n_total)
+            for i, r in enumerate(reads):
+                em, ec = model.best_stratum(olib, r, seed_len, n_seed, n_total)
+                assert (int(mm[i]), int(cnt[i])) == (em, min(ec, 255)), (r, seed_len, n_seed, n_total, opts)
+    eng.set_option("wstop", 2)
+    eng.set_option("ftab", 1)
