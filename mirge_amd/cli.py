@@ -9,7 +9,9 @@ Same flags, library directory layout (MAIN:108-112, :262-281) and output tables
     (build with `python -m mirge_amd.build_index`);
   * `-ad` must be `none`: adapter removal is cutadapt's (not built); 3' quality
     trimming and the 16-nt minimum are applied as the reference does;
-  * `-ai`, `-trf`, `-spikeIn`'s extra outputs and the PDF report are not produced.
+  * `-ai` reads the genome from `<sp>_genome.mrgfm` / `.fa` or `<sp>_genome.partNNN.mrgfm`
+    (`build_index --max-bases 500000000`) and answers the two genome bowtie runs on the GPU;
+  * `-trf`, `-spikeIn`'s extra outputs and the PDF report are not produced.
 Call order follows MAIN:346-389.
 """
 import argparse
@@ -91,8 +93,8 @@ def annotate_main(args):
     if args.adapter != "none":
         _die("-ad %s: adapter removal is not built in mirge_amd; trim adapters first and use -ad none"
              % args.adapter)
-    if args.a_to_i or args.trf_output:
-        _die("-ai / -trf are not built in mirge_amd yet")
+    if args.trf_output:
+        _die("-trf is not built in mirge_amd")
     sp, lib = args.species, args.libraryPath
     index_dir = os.path.join(lib, sp, "index.Libs")
     mirna_fa = os.path.join(lib, sp, "fasta.Libs", "%s_mirna_SNP_pseudo_%s.fa" % (sp, db))
@@ -128,6 +130,28 @@ def annotate_main(args):
     S = len(sample_list)
 
     engine = Engine(args.gpu)
+    genome, removed_ai = None, []
+    if args.a_to_i:  # MAIN:136-146, :277
+        from . import a2i
+        from .index import FmIndex
+        rep = os.path.join(lib, sp, "annotation.Libs", "%s_miRNAs_in_repetitive_element_%s.csv" % (sp, db))
+        if os.path.isfile(rep):
+            with open(rep) as fh:
+                for line in fh:
+                    name = line.strip().split(",")[0]
+                    if name not in removed_ai:
+                        removed_ai.append(name)
+        try:
+            parts = FmIndex.open_prefix_parts(os.path.join(index_dir, "%s_genome" % sp))
+        except FileNotFoundError:
+            print("The index file of %s_genome (.mrgfm, .fa or .partNNN.mrgfm) is not located at %s, "
+                  "please check it." % (sp, index_dir))
+            sys.exit(1)
+        keys = []
+        for k, ix in enumerate(parts):
+            engine.add_library("genome:%d" % k, ix)
+            keys.append("genome:%d" % k)
+        genome = a2i.EngineGenome(engine, keys)
     log_dic = {"quantStats": [], "annotStats": []}
     t0 = time.time()
     words_all, lens_all, nmask_all, sample_all = [], [], [], []
@@ -192,8 +216,9 @@ def annotate_main(args):
     annotate.miRNAmerge(merge_file, sample_list, mir_dic, mirna_fa, name_seq)
     annotate.filter(mir_dic, sample_list, log_dic, args.canoRatio)
     report.write_annotation_report_csv(os.path.join(outdir, "annotation.report.csv"), sample_list, log_dic, spike)
-    report.writeDataToCSV(outdir, names, sample_list, args.diff_isomirs, False, log_dic, seq_dic, mir_dic,
-                          name_seq, merged_name, spike, args.gff_output, content, db)
+    report.writeDataToCSV(outdir, names, sample_list, args.diff_isomirs, args.a_to_i, log_dic, seq_dic, mir_dic,
+                          name_seq, merged_name, spike, args.gff_output, content, db, genome=genome,
+                          removedMiRNAList=removed_ai)
     print("Summary Complete (%.2f sec)" % (time.time() - t3))
     print("Annotation of miRge2.0 Completed (%.2f sec)" % (time.time() - t0))
     return dict(outdir=outdir, seqDic=seq_dic, mirDic=mir_dic, logDic=log_dic, readLengthDic=read_len_dic)

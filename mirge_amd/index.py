@@ -63,6 +63,19 @@ class FmIndex:
         raise FileNotFoundError(
             "no %s.mrgfm or %s.fa: build one with `python -m mirge_amd.build_index`" % (prefix, prefix))
 
+    @classmethod
+    def open_prefix_parts(cls, prefix):
+        """A library too large for one 32-bit index (the genome, MAIN:277): `<prefix>.mrgfm` /
+        `<prefix>.fa` if present, else every `<prefix>.partNNN.mrgfm` written by
+        `python -m mirge_amd.build_index --max-bases`."""
+        import glob
+        if any(os.path.isfile(prefix + e) for e in (".mrgfm", ".fa", ".fasta")):
+            return [cls.open_prefix(prefix)]
+        parts = sorted(glob.glob(glob.escape(prefix) + ".part[0-9]*.mrgfm"))
+        if not parts:
+            raise FileNotFoundError("no %s.mrgfm, %s.fa or %s.partNNN.mrgfm" % (prefix, prefix, prefix))
+        return [cls.load(p) for p in parts]
+
     def save(self, path):
         check(self._lib.mrg_index_save(self._h, os.fsencode(path)))
 

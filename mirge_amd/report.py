@@ -188,11 +188,15 @@ def write_annotation_report_csv(path, sampleList, logDic, spikeIn=False):
 
 def writeDataToCSV(outputdir, annotNameList, sampleList, isomirDiff, a_to_i, logDic, seqDic, mirDic,
                    mirNameSeqDic=None, mirMergedNameDic=None, spikeIn=False, gff_output=False,
-                   isomiRContentDic=None, miRNA_database="miRBase", trf_output=False):
-    """The table-writing part of writeDataToCSV.py:566 (same leading arguments).  The
-    -ai / -trf branches are not built yet and raise."""
-    if a_to_i or trf_output:
-        raise NotImplementedError("-ai / -trf outputs are not built yet (SURVEY.md 8a a13, 8f)")
+                   isomiRContentDic=None, miRNA_database="miRBase", trf_output=False, genome=None,
+                   removedMiRNAList=None):
+    """The table-writing part of writeDataToCSV.py:566 (same leading arguments).  `genome`
+    stands in for (bowtieBinary, genome_index): an object answering the two genome runs of
+    the -ai block (mirge_amd.a2i.EngineGenome).  The -trf branch is not built and raises."""
+    if trf_output:
+        raise NotImplementedError("-trf outputs are not built (SURVEY.md 8f)")
+    if a_to_i and genome is None:
+        raise ValueError("a_to_i needs a genome (mirge_amd.a2i.EngineGenome)")
     isomirDic = write_mapped_csv(os.path.join(outputdir, "mapped.csv"), annotNameList, sampleList, seqDic,
                                  spikeIn)
     if gff_output:
@@ -204,4 +208,8 @@ def writeDataToCSV(outputdir, annotNameList, sampleList, isomirDiff, a_to_i, log
     write_unmapped_csv(os.path.join(outputdir, "unmapped.csv"), annotNameList, sampleList, seqDic, spikeIn)
     write_counts_csv(os.path.join(outputdir, "miR.Counts.csv"), sampleList, mirDic, logDic)
     write_rpm_csv(os.path.join(outputdir, "miR.RPM.csv"), sampleList, mirDic, logDic)
+    if a_to_i:  # W2C:1221
+        from .a2i import a_to_i_report
+        a_to_i_report(outputdir, sampleList, logDic, seqDic, mirDic, mirNameSeqDic, mirMergedNameDic,
+                      removedMiRNAList or [], genome)
     return isomirDic

@@ -91,3 +91,35 @@ def test_report_with_gpu_genome_filters(golden, native_lib, oracle_lib, tmp_path
     assert 0 < len(scan.unique_best(reads)) < len(set(reads))
     run_report(golden, gpu, tmp_path)
     check_files(golden, tmp_path)
+
+
+@pytest.mark.gpu
+def test_cli_ai_from_fastq_matches_reference_files(golden, native_lib, tmp_path):
+    """`annotate -ai` end to end from FASTQ: collapse, cascade, tally and the two genome filters on
+    the GPU, genome split into parts (build_index --max-bases) -> the reference's a2IEditing files."""
+    import types
+    from mirge_amd import build_index, cli, synth
+    ns = types.SimpleNamespace(libs={k: tuple(v) for k, v in golden["libraries"].items()},
+                               merges=golden["merges"])
+    root = str(tmp_path / "libs")
+    synth.SynthLibraries.write_layout(ns, root, species="syn", db="miRBase")
+    gfa = os.path.join(root, "syn", "index.Libs", "syn_genome.fa")
+    longest = max(len(s) for s in golden["libraries"]["genome"][1])
+    assert build_index.main([gfa, "--max-bases", str(longest + 10)]) == 0
+    os.remove(gfa)
+    assert len([f for f in os.listdir(os.path.dirname(gfa)) if ".part" in f]) >= 2
+    with open(os.path.join(root, "syn", "annotation.Libs", "syn_miRNAs_in_repetitive_element_miRBase.csv"), "w") as fh:
+        for n in golden["removedMiRNAList"]:
+            fh.write("%s,x\n" % n)
+    fastqs = []
+    for name, reads in zip(golden["sample_list"], golden["samples"]):
+        p = str(tmp_path / name)
+        with open(p, "w") as fh:
+            for k, r in enumerate(reads):
+                fh.write("@r%d\n%s\n+\n%s\n" % (k, r, "I" * len(r)))
+        fastqs.append(p)
+    out = cli.annotate_main(cli.build_parser().parse_args(
+        ["annotate", "-s"] + fastqs + ["-lib", root, "-sp", "syn", "-o", str(tmp_path), "-ai"]))
+    st = golden["state"]
+    assert {s: r["annot"] for s, r in out["seqDic"].items()} == {s: r["annot"] for s, r in st["seqDic"].items()}
+    check_files(golden, out["outdir"])
