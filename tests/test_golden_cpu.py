@@ -68,7 +68,10 @@ def test_product_host_functions_merge_filter_collapse(golden, tmp_path):
     exp = golden["expected"]
     names, seqs = golden["libraries"]["mirna"]
     fa = tmp_path / "mirna.fa"
-    fa.write_text("".join(">%s\n%s\n" % (n, s[2:-6]) for n, s in zip(names, seqs)))
+    mature = {n: s[2:-6] for n, s in zip(names, seqs)}
+    # as SynthLibraries.write_layout: the SNP_pseudo FASTA lists merged names too (W2C:1295)
+    fa.write_text("".join(">%s\n%s\n" % (n, mature[n]) for n in names) +
+                  "".join(">%s\n%s\n" % (l.split(",")[0], mature[l.split(",")[1]]) for l in golden["merges"]))
     merges = tmp_path / "merges.csv"
     merges.write_text("".join(l + "\n" for l in golden["merges"]))
     mir_dic = copy.deepcopy(exp["mirDic_after_summarize"])
