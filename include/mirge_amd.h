@@ -212,6 +212,27 @@ int mrg_count_best(mrg_ctx *ctx, const uint64_t *d_reads, uint32_t words_per_rea
                    uint8_t *d_best_mm, uint8_t *d_count, void *stream);
 
 /*
+ * Every alignment of each read's best stratum against one library: what `bowtie -a --best
+ * --strata` prints (flags of every cascade command line, runAnnotationPipeline.py:577-599) and
+ * parseAlignment3 (RAP:41-52) collects for the tRF tables (RAP:657-660, :698-701).  Two sweeps so
+ * the caller owns the output buffers:
+ *   mrg_list_best_count  d_best_mm[n] (255 = unaligned), d_offsets[n+1] = exclusive prefix of
+ *                        the stratum sizes, *total = d_offsets[n]; synchronises the stream;
+ *   mrg_list_best_fill   alignment k of read r at d_ref/d_pos[d_offsets[r] + k] (entry index,
+ *                        0-based offset in the entry; order within a read unspecified); slots
+ *                        >= cap are not written.
+ */
+int mrg_list_best_count(mrg_ctx *ctx, const uint64_t *d_reads, uint32_t words_per_read,
+                        const uint8_t *d_lens, const uint64_t *d_nmask, uint64_t n, int32_t lib,
+                        int32_t seed_len, int32_t max_mm_seed, int32_t max_mm_total,
+                        uint8_t *d_best_mm, uint64_t *d_offsets, uint64_t *total, void *stream);
+int mrg_list_best_fill(mrg_ctx *ctx, const uint64_t *d_reads, uint32_t words_per_read,
+                       const uint8_t *d_lens, const uint64_t *d_nmask, uint64_t n, int32_t lib,
+                       int32_t seed_len, int32_t max_mm_seed, int32_t max_mm_total,
+                       const uint8_t *d_best_mm, const uint64_t *d_offsets, uint64_t cap,
+                       int32_t *d_ref, int32_t *d_pos, void *stream);
+
+/*
  * Host-buffer convenience for a caller without its own device allocator (the
  * ctypes stub of INTEGRATION.md): H2D, cascade, tally, D2H in one call.
  * counts may be NULL (then quant/n_samples are ignored).

@@ -88,6 +88,12 @@ SIGNATURES = {
     "mrg_count_best": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
                                  C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),
+    "mrg_list_best_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                      C.POINTER(C.c_uint64), C.c_void_p]),
+    "mrg_list_best_fill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
+                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mrg_annotate_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                     C.c_uint64, C.POINTER(PassCfg), C.c_uint32, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PassStats),

@@ -547,46 +547,121 @@ int mrg_tally_run(mrg_ctx* ctx, const int8_t* d_pass_id, const int32_t* d_ref_id
 }
 
 // ------------------------------------------------------------ count best
+namespace {
+
+int fill_count_params(mrg_ctx* ctx, const char* who, const uint64_t* d_reads, uint32_t words_per_read,
+                      const uint8_t* d_lens, const uint64_t* d_nmask, uint64_t n, int32_t lib, int32_t seed_len,
+                      int32_t max_mm_seed, int32_t max_mm_total, mrg::CountParams* p, uint32_t* grid,
+                      uint32_t* lds_bytes) {
+  if (!ctx) return fail(MRG_ERR_ARG, "%s: null argument", who);
+  if (n && (!d_reads || !d_lens)) return fail(MRG_ERR_ARG, "%s: null buffers", who);
+  if (lib < 0 || (size_t)lib >= ctx->libs.size()) return fail(MRG_ERR_ARG, "%s: unknown library %d", who, lib);
+  if (words_per_read != 1 && words_per_read != 2 && words_per_read != 4)
+    return fail(MRG_ERR_ARG, "%s: words_per_read must be 1, 2 or 4", who);
+  if (max_mm_seed < 0 || max_mm_seed > 2 || max_mm_total < max_mm_seed || seed_len < 1)
+    return fail(MRG_ERR_ARG, "%s: invalid policy", who);
+  if (n >= 0x7fffffffull) return fail(MRG_ERR_ARG, "%s: too many reads for one call", who);
+  const DevLib& l = ctx->libs[lib];
+  const uint64_t lds = (uint64_t)l.nsup * 16;
+  if (lds > 160 * 1024) return fail(MRG_ERR_ARG, "%s: library too large for one call (split it)", who);
+  std::memset(p, 0, sizeof(*p));
+  p->blocks = l.blocks;
+  p->super = l.super;
+  p->text = l.text;
+  p->sa = l.sa;
+  p->ftab = l.ftab;
+  p->ftab_k = ctx->use_ftab ? l.ftab_k : 0u;
+  p->n = l.n;
+  p->nsup = l.nsup;
+  p->primary = l.primary;
+  p->seg_start = l.seg_start;
+  p->seg_ref = l.seg_ref;
+  p->seg_off = l.seg_off;
+  p->chunk_seg = l.chunk_seg;
+  p->reads = d_reads;
+  p->lens = d_lens;
+  p->nmask = d_nmask;
+  p->n_reads = n;
+  p->seed_len = seed_len;
+  p->max_mm_seed = max_mm_seed;
+  p->max_mm_total = max_mm_total;
+  p->wstop = (uint32_t)ctx->wstop;
+  p->max_rows = 4096u;
+  const uint64_t want = (n + mrg::kCountThreads - 1) / mrg::kCountThreads;
+  const uint32_t per_cu = lds ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, (160 * 1024) / lds)) : 8u;
+  *grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)ctx->n_cu * per_cu));
+  *lds_bytes = (uint32_t)lds;
+  return MRG_OK;
+}
+
+}  // namespace
+
 int mrg_count_best(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_read, const uint8_t* d_lens,
                    const uint64_t* d_nmask, uint64_t n, int32_t lib, int32_t seed_len, int32_t max_mm_seed,
                    int32_t max_mm_total, uint8_t* d_best_mm, uint8_t* d_count, void* stream) {
-  if (!ctx) return fail(MRG_ERR_ARG, "mrg_count_best: null argument");
-  if (n && (!d_reads || !d_lens || !d_best_mm || !d_count)) return fail(MRG_ERR_ARG, "mrg_count_best: null buffers");
-  if (lib < 0 || (size_t)lib >= ctx->libs.size()) return fail(MRG_ERR_ARG, "mrg_count_best: unknown library %d", lib);
-  if (words_per_read != 1 && words_per_read != 2 && words_per_read != 4)
-    return fail(MRG_ERR_ARG, "mrg_count_best: words_per_read must be 1, 2 or 4");
-  if (max_mm_seed < 0 || max_mm_seed > 2 || max_mm_total < max_mm_seed || seed_len < 1)
-    return fail(MRG_ERR_ARG, "mrg_count_best: invalid policy");
+  mrg::CountParams p;
+  uint32_t grid = 0, lds = 0;
+  int rc = fill_count_params(ctx, "mrg_count_best", d_reads, words_per_read, d_lens, d_nmask, n, lib, seed_len,
+                             max_mm_seed, max_mm_total, &p, &grid, &lds);
+  if (rc != MRG_OK) return rc;
+  if (n && (!d_best_mm || !d_count)) return fail(MRG_ERR_ARG, "mrg_count_best: null buffers");
   HIP_TRY(hipSetDevice(ctx->device));
   if (n == 0) return MRG_OK;
-  const DevLib& l = ctx->libs[lib];
-  const uint64_t lds = (uint64_t)l.nsup * 16;
-  if (lds > 160 * 1024) return fail(MRG_ERR_ARG, "mrg_count_best: library too large for one call (split it)");
-  mrg::CountParams p;
-  p.blocks = l.blocks;
-  p.super = l.super;
-  p.text = l.text;
-  p.sa = l.sa;
-  p.ftab = l.ftab;
-  p.ftab_k = ctx->use_ftab ? l.ftab_k : 0u;
-  p.n = l.n;
-  p.nsup = l.nsup;
-  p.primary = l.primary;
-  p.reads = d_reads;
-  p.lens = d_lens;
-  p.nmask = d_nmask;
-  p.n_reads = n;
-  p.seed_len = seed_len;
-  p.max_mm_seed = max_mm_seed;
-  p.max_mm_total = max_mm_total;
-  p.wstop = (uint32_t)ctx->wstop;
-  p.max_rows = 4096u;
   p.best_mm = d_best_mm;
   p.count = d_count;
-  const uint64_t want = (n + mrg::kCountThreads - 1) / mrg::kCountThreads;
-  const uint32_t per_cu = lds ? (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(8, (160 * 1024) / lds)) : 8u;
-  const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)ctx->n_cu * per_cu);
-  HIP_TRY(mrg::launch_count(p, words_per_read, grid, (uint32_t)lds, (hipStream_t)stream));
+  HIP_TRY(mrg::launch_count(p, words_per_read, grid, lds, (hipStream_t)stream));
+  return MRG_OK;
+}
+
+int mrg_list_best_count(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_read, const uint8_t* d_lens,
+                        const uint64_t* d_nmask, uint64_t n, int32_t lib, int32_t seed_len, int32_t max_mm_seed,
+                        int32_t max_mm_total, uint8_t* d_best_mm, uint64_t* d_offsets, uint64_t* total,
+                        void* stream) {
+  mrg::CountParams p;
+  uint32_t grid = 0, lds = 0;
+  int rc = fill_count_params(ctx, "mrg_list_best_count", d_reads, words_per_read, d_lens, d_nmask, n, lib,
+                             seed_len, max_mm_seed, max_mm_total, &p, &grid, &lds);
+  if (rc != MRG_OK) return rc;
+  if (!d_offsets || !total || (n && !d_best_mm)) return fail(MRG_ERR_ARG, "mrg_list_best_count: null buffers");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t* cnt = nullptr;
+  HIP_TRY(hipMalloc((void**)&cnt, (n + 1) * sizeof(uint32_t)));
+  hipError_t e = hipMemsetAsync(cnt, 0, (n + 1) * sizeof(uint32_t), st);
+  if (e == hipSuccess && n) {
+    p.best_mm = d_best_mm;
+    p.count32 = cnt;
+    p.max_rows = 1u << 20;
+    e = mrg::launch_count(p, words_per_read, grid, lds, st);
+  }
+  if (e == hipSuccess) e = mrg::exclusive_sum_u32_u64(cnt, d_offsets, n + 1, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(total, d_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(cnt);
+  HIP_TRY(e);
+  return MRG_OK;
+}
+
+int mrg_list_best_fill(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_read, const uint8_t* d_lens,
+                       const uint64_t* d_nmask, uint64_t n, int32_t lib, int32_t seed_len, int32_t max_mm_seed,
+                       int32_t max_mm_total, const uint8_t* d_best_mm, const uint64_t* d_offsets, uint64_t cap,
+                       int32_t* d_ref, int32_t* d_pos, void* stream) {
+  mrg::CountParams p;
+  uint32_t grid = 0, lds = 0;
+  int rc = fill_count_params(ctx, "mrg_list_best_fill", d_reads, words_per_read, d_lens, d_nmask, n, lib,
+                             seed_len, max_mm_seed, max_mm_total, &p, &grid, &lds);
+  if (rc != MRG_OK) return rc;
+  if (n && (!d_best_mm || !d_offsets)) return fail(MRG_ERR_ARG, "mrg_list_best_fill: null buffers");
+  if (cap && (!d_ref || !d_pos)) return fail(MRG_ERR_ARG, "mrg_list_best_fill: null output buffers");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (n == 0 || cap == 0) return MRG_OK;
+  p.best_mm = const_cast<uint8_t*>(d_best_mm);
+  p.offsets = d_offsets;
+  p.out_ref = d_ref;
+  p.out_pos = d_pos;
+  p.out_cap = cap;
+  p.max_rows = 1u << 20;
+  HIP_TRY(mrg::launch_count(p, words_per_read, grid, lds, (hipStream_t)stream));
   return MRG_OK;
 }
 

@@ -248,4 +248,24 @@ hipError_t collapse_reads(const uint64_t* d_reads, uint32_t W, const uint8_t* d_
   return hipSuccess;
 }
 
+
+// Exclusive prefix sum of n+1 uint32 values into uint64 (out[n] = total when in[n] == 0):
+// offsets of the per-read alignment lists of mrg_list_best.
+struct U32ToU64 {
+  __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; }
+};
+hipError_t exclusive_sum_u32_u64(const uint32_t* in, uint64_t* out, uint64_t n_plus_1, hipStream_t stream) {
+  hipcub::TransformInputIterator<uint64_t, U32ToU64, const uint32_t*> it(in, U32ToU64());
+  size_t need = 0;
+  hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, need, it, out, (int)n_plus_1, stream);
+  if (e != hipSuccess) return e;
+  void* tmp = nullptr;
+  e = hipMalloc(&tmp, need ? need : 16);
+  if (e != hipSuccess) return e;
+  e = hipcub::DeviceScan::ExclusiveSum(tmp, need, it, out, (int)n_plus_1, stream);
+  hipError_t e2 = hipStreamSynchronize(stream);
+  (void)hipFree(tmp);
+  return e != hipSuccess ? e : e2;
+}
+
 }  // namespace mrg

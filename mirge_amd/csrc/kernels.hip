@@ -447,7 +447,10 @@ match_kernel(const MatchParams p) {
 // survivor lists.  An alignment can sit in the candidate rows of several pieces; it is
 // counted at the first piece whose searched bases it matches exactly.
 // ---------------------------------------------------------------------------
-template <int W>
+// LIST = second sweep of mrg_list_best: the best stratum of each read is known, every alignment
+// in it is written at offsets[r] + k (what `-a --best --strata` prints, RAP:577-599, consumed by
+// parseAlignment3 RAP:41-52 for the tRF tables).
+template <int W, bool LIST>
 __global__ void __launch_bounds__(kCountThreads) count_kernel(const CountParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   {
@@ -474,7 +477,9 @@ __global__ void __launch_bounds__(kCountThreads) count_kernel(const CountParams 
     }
     const int32_t L = (int32_t)p.lens[r];
     uint32_t best_mm = 255u, count = 0u;
-    if (L > p.max_mm_seed) {
+    const uint32_t want_mm = LIST ? (uint32_t)p.best_mm[r] : 0u;
+    const uint64_t out_base = LIST ? p.offsets[r] : 0ull;
+    if (L > p.max_mm_seed && (!LIST || want_mm != 255u)) {
       const int32_t R = min(L, p.seed_len);
       const int32_t K = p.max_mm_seed + 1;
       int32_t stop_[3] = {0, 0, 0}, end_[3] = {0, 0, 0};
@@ -520,7 +525,7 @@ __global__ void __launch_bounds__(kCountThreads) count_kernel(const CountParams 
         listed[k] = true;
         if (hi > lo && hi - lo > p.max_rows) {
           // a seed this repetitive cannot have a unique best hit; do not walk 10^5+ rows
-          count = 255u;
+          if (!LIST && !p.count32) count = 255u;
           hi = lo + p.max_rows;
         }
         const uint32_t need_before = (uint32_t)j, need_after = (uint32_t)(L - j);
@@ -558,17 +563,31 @@ __global__ void __launch_bounds__(kCountThreads) count_kernel(const CountParams 
             seen |= exact;
           }
           if (seen) continue;
-          if (mm_total < best_mm) {
+          if (LIST) {
+            if (mm_total != want_mm) continue;
+            const uint64_t slot = out_base + count++;
+            if (slot >= p.out_cap) continue;
+            uint32_t sg = (uint32_t)(row >> 48);
+            if (sg == 0xFFFFu) {
+              sg = p.chunk_seg[s >> 5];
+              while (p.seg_start[sg + 1] <= s) ++sg;
+            }
+            p.out_ref[slot] = (int32_t)p.seg_ref[sg];
+            p.out_pos[slot] = (int32_t)(s - p.seg_start[sg] + p.seg_off[sg]);
+          } else if (mm_total < best_mm) {
             best_mm = mm_total;
-            if (count != 255u) count = 1u;
-          } else if (mm_total == best_mm && count < 255u) {
+            if (count != 255u || p.count32) count = 1u;
+          } else if (mm_total == best_mm && (count < 255u || p.count32)) {
             ++count;
           }
         }
       }
     }
-    p.best_mm[r] = (uint8_t)best_mm;
-    p.count[r] = (uint8_t)(best_mm == 255u ? 0u : count);
+    if (!LIST) {
+      p.best_mm[r] = (uint8_t)best_mm;
+      if (p.count32) p.count32[r] = best_mm == 255u ? 0u : count;
+      else p.count[r] = (uint8_t)(best_mm == 255u ? 0u : count);
+    }
   }
 }
 
@@ -692,12 +711,18 @@ hipError_t launch_tally(const TallyParams& p, bool lds_hist, uint32_t grid,
 
 hipError_t launch_count(const CountParams& p, uint32_t words_per_read, uint32_t grid, uint32_t lds_bytes,
                         hipStream_t stream) {
+#define MRG_COUNT(W_)                                                                                     \
+  if (p.out_ref)                                                                                         \
+    hipLaunchKernelGGL((count_kernel<W_, true>), dim3(grid), dim3(kCountThreads), lds_bytes, stream, p); \
+  else                                                                                                   \
+    hipLaunchKernelGGL((count_kernel<W_, false>), dim3(grid), dim3(kCountThreads), lds_bytes, stream, p);
   switch (words_per_read) {
-    case 1: hipLaunchKernelGGL(count_kernel<1>, dim3(grid), dim3(kCountThreads), lds_bytes, stream, p); break;
-    case 2: hipLaunchKernelGGL(count_kernel<2>, dim3(grid), dim3(kCountThreads), lds_bytes, stream, p); break;
-    case 4: hipLaunchKernelGGL(count_kernel<4>, dim3(grid), dim3(kCountThreads), lds_bytes, stream, p); break;
+    case 1: MRG_COUNT(1) break;
+    case 2: MRG_COUNT(2) break;
+    case 4: MRG_COUNT(4) break;
     default: return hipErrorInvalidValue;
   }
+#undef MRG_COUNT
   return hipGetLastError();
 }
 

@@ -72,8 +72,15 @@ struct CountParams {
   uint64_t n_reads;
   int32_t seed_len, max_mm_seed, max_mm_total;
   uint32_t wstop, max_rows;
-  uint8_t* best_mm;
-  uint8_t* count;
+  uint8_t* best_mm;   // written by the count sweep, read by the list sweep
+  uint8_t* count;     // saturating, or
+  uint32_t* count32;  // exact (when non-null)
+  // list sweep (out_ref != null)
+  const uint32_t *seg_start, *seg_ref, *seg_off, *chunk_seg;
+  const uint64_t* offsets;
+  int32_t* out_ref;
+  int32_t* out_pos;
+  uint64_t out_cap;
 };
 
 struct TallyParams {
@@ -100,6 +107,7 @@ hipError_t collapse_reads(const uint64_t* d_reads, uint32_t W, const uint8_t* d_
                           uint64_t* d_len_hist, uint32_t* h_n_unique, hipStream_t stream);
 hipError_t launch_count(const CountParams& p, uint32_t words_per_read, uint32_t grid, uint32_t lds_bytes,
                         hipStream_t stream);
+hipError_t exclusive_sum_u32_u64(const uint32_t* in, uint64_t* out, uint64_t n_plus_1, hipStream_t stream);
 hipError_t launch_export_pass_counts(const uint64_t* stats, uint32_t n_pass, uint64_t* out,
                                      hipStream_t stream);
 

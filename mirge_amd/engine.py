@@ -223,6 +223,35 @@ class Engine:
             int(max_mm_seed), int(max_mm_total), mm.data_ptr(), cnt.data_ptr(), self._stream_ptr()))
         return mm.cpu().numpy(), cnt.cpu().numpy()
 
+    def list_best(self, reads, lib, seed_len=28, max_mm_seed=0, max_mm_total=0):
+        """`-a --best --strata` (RAP:577-599; parseAlignment3 RAP:41-52): every alignment of each
+        read's best stratum.  Returns host arrays (best_mm[n], offsets[n+1], ref[total],
+        pos[total]); read r owns ref/pos[offsets[r]:offsets[r+1]], sorted by (entry, offset)."""
+        torch = _torch()
+        n = reads.n
+        mm = torch.empty(n, dtype=torch.uint8, device=self.device)
+        off = torch.empty(n + 1, dtype=torch.int64, device=self.device)
+        lid = self.libs[lib] if isinstance(lib, str) else int(lib)
+        nm = reads.nmask.data_ptr() if reads.nmask is not None else None
+        total = C.c_uint64(0)
+        check(self._lib.mrg_list_best_count(
+            self._h, reads.words.data_ptr(), reads.W, reads.lens.data_ptr(), nm, n, lid, int(seed_len),
+            int(max_mm_seed), int(max_mm_total), mm.data_ptr(), off.data_ptr(), C.byref(total),
+            self._stream_ptr()))
+        t = int(total.value)
+        ref = torch.empty(max(t, 1), dtype=torch.int32, device=self.device)
+        pos = torch.empty(max(t, 1), dtype=torch.int32, device=self.device)
+        check(self._lib.mrg_list_best_fill(
+            self._h, reads.words.data_ptr(), reads.W, reads.lens.data_ptr(), nm, n, lid, int(seed_len),
+            int(max_mm_seed), int(max_mm_total), mm.data_ptr(), off.data_ptr(), t, ref.data_ptr(),
+            pos.data_ptr(), self._stream_ptr()))
+        off_h = off.cpu().numpy()
+        ref_h, pos_h = ref.cpu().numpy()[:t], pos.cpu().numpy()[:t]
+        # canonical order inside each read: (entry, offset)
+        owner = np.repeat(np.arange(n, dtype=np.int64), np.diff(off_h))
+        order = np.lexsort((pos_h, ref_h, owner))
+        return mm.cpu().numpy(), off_h, ref_h[order], pos_h[order]
+
     # ------------------------------------------------------------------
     def annotate_host(self, words, lens, nmask, passes, quant=None, n_mirna=0,
                       canon_pass=CANON_PASS, isomir_pass=ISOMIR_PASS):

@@ -239,11 +239,9 @@ def test_low_complexity_library_and_reads(native_lib, oracle_lib):
         assert max(s["candidates"] for s in res.stats) > 20000   # the wave-wide verification ran
 
 
-@pytest.mark.gpu
-def test_count_best_matches_exhaustive_scan(native_lib, oracle_lib):
-    """mrg_count_best (the -ai genome filters, W2C:1263/:1488): best mismatch count and its
-    multiplicity equal the exhaustive scan, on a library with planted repeats so that one
-    alignment is reachable from several pigeonhole pieces and one read has several best hits."""
+def _repeat_world():
+    """A library with planted repeats (one alignment reachable from several pigeonhole pieces,
+    reads with several best hits), an N, low-complexity runs, and reads cut from it."""
     from mirge_amd.engine import Engine, ReadSet
     from mirge_amd.index import FmIndex
     from mirge_amd import pack
@@ -279,6 +277,40 @@ def test_count_best_matches_exhaustive_scan(native_lib, oracle_lib):
     reads += ["A" * 20, "A" * 35, "ACGT" * 6, "ACGTACGTACGTACGTACGTAC", "ACGTNACGTACGTACGTACG", rnd(25), "AC", "A"]
     words, lens, nmask = pack.pack_reads(reads)
     rs = ReadSet(words, lens, nmask, None, device=eng.device)
+    return eng, olib, reads, rs
+
+
+@pytest.mark.gpu
+def test_list_best_matches_exhaustive_scan(native_lib, oracle_lib):
+    """mrg_list_best_count/fill (`-a --best --strata`, parseAlignment3 RAP:41-52): the same
+    (entry, offset) lists as the exhaustive scan."""
+    eng, olib, reads, rs = _repeat_world()
+    for seed_len, n_seed, n_total in ((64, 1, 1), (64, 0, 0), (28, 1, 2), (64, 2, 2)):
+        for opts in ({}, {"wstop": 0, "ftab": 0}):
+            for k, v in {"wstop": 2, "ftab": 1, **opts}.items():
+                eng.set_option(k, v)
+            mm, off, ref, pos = eng.list_best(rs, "g", seed_len=seed_len, max_mm_seed=n_seed, max_mm_total=n_total)
+            assert off[0] == 0 and off[-1] == len(ref) == len(pos)
+            multi = 0
+            for i, r in enumerate(reads):
+                want, want_mm = model.align_all_best(olib, r, seed_len, n_seed, n_total)
+                got = list(zip(ref[off[i]:off[i + 1]].tolist(), pos[off[i]:off[i + 1]].tolist()))
+                if not want:
+                    assert mm[i] == 255 and got == [], r
+                else:
+                    assert int(mm[i]) == want_mm and got == want, (r, seed_len, n_seed, n_total, opts)
+                    multi += len(got) > 1
+            assert multi > 20
+    eng.set_option("wstop", 2)
+    eng.set_option("ftab", 1)
+
+
+@pytest.mark.gpu
+def test_count_best_matches_exhaustive_scan(native_lib, oracle_lib):
+    """mrg_count_best (the -ai genome filters, W2C:1263/:1488): best mismatch count and its
+    multiplicity equal the exhaustive scan, on a library with planted repeats so that one
+    alignment is reachable from several pigeonhole pieces and one read has several best hits."""
+    eng, olib, reads, rs = _repeat_world()
     for seed_len, n_seed, n_total in ((28, 1, 2), (28, 0, 2), (28, 2, 2), (20, 1, 1), (64, 0, 0)):
         for opts in ({}, {"wstop": 0, "ftab": 0}):
             for k, v in {"wstop": 2, "ftab": 1, **opts}.items():
