@@ -53,8 +53,6 @@ def runAnnotationPipeline(engine, seqDic, numCPU, phred64, annotNameList, output
     logDic['annotStats'] (RAP:640-705).  Also leaves the located alignments in
     logDic['_alignments'] = {seq: (pass, entry index, 0-based offset, mismatches)}
     for the isomiR / A-to-I consumers."""
-    if trf_output:
-        raise NotImplementedError("-trf side products are not built yet (SURVEY.md 8f rank 4)")
     files = {"mirna": file_mirna, "hairpin": file_hairpin, "mature_trna": file_mature_tRNA,
              "pre_trna": file_pre_tRNA, "snorna": file_snoRNA, "rrna": file_rRNA,
              "ncrna_others": file_ncrna_others, "mrna": file_mrna}
@@ -104,6 +102,11 @@ def runAnnotationPipeline(engine, seqDic, numCPU, phred64, annotNameList, output
                                  "%dM" % (len(seq) - trim))
             isomir.build_isomir_content(isomiRContentDic, hits, pass_index, miRNamePreNameDic,
                                         hairpin_seqs, mirna_seqs, miRNA_database)
+    if trf_output:
+        # RAP:629-634, :657-660, :698-701: `-a --best --strata` listings of the two tRNA passes
+        from . import trf
+        trf.collect_trf_content(trfContentDic, seqDic, sampleList, trnaStruDic,
+                                engine.indexes["pre_trna"].name_seq_dict(), trf.engine_lister(engine))
     gpu_ms = sum(s["ms"] for s in stats) or 1.0
     for s in stats:
         # the reference stores wall seconds per bowtie run (RAP:641-645); split ours by device time

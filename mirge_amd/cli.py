@@ -11,7 +11,9 @@ Same flags, library directory layout (MAIN:108-112, :262-281) and output tables
     trimming and the 16-nt minimum are applied as the reference does;
   * `-ai` reads the genome from `<sp>_genome.mrgfm` / `.fa` or `<sp>_genome.partNNN.mrgfm`
     (`build_index --max-bases 500000000`) and answers the two genome bowtie runs on the GPU;
-  * `-trf`, `-spikeIn`'s extra outputs and the PDF report are not produced.
+  * `-trf` writes `tRFs.potential.report.tsv`, `tRF.Counts.csv`, `tRF.RP100K.csv` and
+    `discarded.reads.summary.assigningtRFs.csv`; the per-sample clustering reports
+    (`tRFs.samples.tmp/`), `-spikeIn`'s extra outputs and the PDF report are not produced.
 Call order follows MAIN:346-389.
 """
 import argparse
@@ -93,9 +95,14 @@ def annotate_main(args):
     if args.adapter != "none":
         _die("-ad %s: adapter removal is not built in mirge_amd; trim adapters first and use -ad none"
              % args.adapter)
-    if args.trf_output:
-        _die("-trf is not built in mirge_amd")
     sp, lib = args.species, args.libraryPath
+    if args.trf_output and sp != "human":  # MAIN:161-163
+        _die("tRF detection is only supported for the species of human. Please check it.")
+    trf_tables, trf_content = None, None
+    if args.trf_output:
+        from . import trf
+        trf_tables = trf.load_trf_tables(lib, sp)
+        trf_content = {}
     index_dir = os.path.join(lib, sp, "index.Libs")
     mirna_fa = os.path.join(lib, sp, "fasta.Libs", "%s_mirna_SNP_pseudo_%s.fa" % (sp, db))
     merge_file = os.path.join(lib, sp, "annotation.Libs", "%s_merges_%s.csv" % (sp, db))
@@ -207,7 +214,7 @@ def annotate_main(args):
         engine, seq_dic, args.cpu, args.phred64, names, outdir, log_dic, prefix["mirna_" + db],
         prefix["hairpin_" + db], prefix["mature_trna"], prefix["pre_trna"], prefix["snorna"], prefix["rrna"],
         prefix["ncrna_others"], prefix["mrna"], spike, prefix.get("spike-in"), args.gff_output, pre_name,
-        content, db, False, None, None, sample_list)
+        content, db, args.trf_output, trf_tables["trnaStruDic"] if trf_tables else None, trf_content, sample_list)
     print("All annotation cycles completed (%.2f sec).\n" % (time.time() - t2))
     print("Summarizing and tabulating results...")
     t3 = time.time()
@@ -217,8 +224,10 @@ def annotate_main(args):
     annotate.filter(mir_dic, sample_list, log_dic, args.canoRatio)
     report.write_annotation_report_csv(os.path.join(outdir, "annotation.report.csv"), sample_list, log_dic, spike)
     report.writeDataToCSV(outdir, names, sample_list, args.diff_isomirs, args.a_to_i, log_dic, seq_dic, mir_dic,
-                          name_seq, merged_name, spike, args.gff_output, content, db, genome=genome,
-                          removedMiRNAList=removed_ai)
+                          name_seq, merged_name, spike, args.gff_output, content, db, args.trf_output,
+                          genome=genome, removedMiRNAList=removed_ai, trfContentDic=trf_content,
+                          trf_tables=trf_tables,
+                          pretrnaNameSeqDic=engine.indexes["pre_trna"].name_seq_dict() if args.trf_output else None)
     print("Summary Complete (%.2f sec)" % (time.time() - t3))
     print("Annotation of miRge2.0 Completed (%.2f sec)" % (time.time() - t0))
     return dict(outdir=outdir, seqDic=seq_dic, mirDic=mir_dic, logDic=log_dic, readLengthDic=read_len_dic)

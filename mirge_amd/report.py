@@ -189,12 +189,15 @@ def write_annotation_report_csv(path, sampleList, logDic, spikeIn=False):
 def writeDataToCSV(outputdir, annotNameList, sampleList, isomirDiff, a_to_i, logDic, seqDic, mirDic,
                    mirNameSeqDic=None, mirMergedNameDic=None, spikeIn=False, gff_output=False,
                    isomiRContentDic=None, miRNA_database="miRBase", trf_output=False, genome=None,
-                   removedMiRNAList=None):
+                   removedMiRNAList=None, trfContentDic=None, trf_tables=None, pretrnaNameSeqDic=None):
     """The table-writing part of writeDataToCSV.py:566 (same leading arguments).  `genome`
     stands in for (bowtieBinary, genome_index): an object answering the two genome runs of
-    the -ai block (mirge_amd.a2i.EngineGenome).  The -trf branch is not built and raises."""
-    if trf_output:
-        raise NotImplementedError("-trf outputs are not built (SURVEY.md 8f)")
+    the -ai block (mirge_amd.a2i.EngineGenome).  `trf_tables` = mirge_amd.trf.load_trf_tables(...)
+    stands in for the six tRF table arguments, `pretrnaNameSeqDic` for (bowtieBinary,
+    file_pre_tRNA).  Of the -trf branch the report / count tables are written (mirge_amd.trf),
+    the per-sample clustering reports are not."""
+    if trf_output and (trfContentDic is None or trf_tables is None or pretrnaNameSeqDic is None):
+        raise ValueError("trf_output needs trfContentDic, trf_tables and pretrnaNameSeqDic")
     if a_to_i and genome is None:
         raise ValueError("a_to_i needs a genome (mirge_amd.a2i.EngineGenome)")
     isomirDic = write_mapped_csv(os.path.join(outputdir, "mapped.csv"), annotNameList, sampleList, seqDic,
@@ -202,6 +205,9 @@ def writeDataToCSV(outputdir, annotNameList, sampleList, isomirDiff, a_to_i, log
     if gff_output:
         from .isomir import write_isomir_gff
         write_isomir_gff(outputdir, sampleList, isomiRContentDic, seqDic, miRNA_database)
+    if trf_output:  # W2C:648
+        from .trf import write_trf_tables
+        write_trf_tables(outputdir, sampleList, logDic, trfContentDic, trf_tables, pretrnaNameSeqDic)
     if isomirDiff:
         write_isomir_tables(os.path.join(outputdir, "isomirs.csv"),
                             os.path.join(outputdir, "isomirs.samples.csv"), sampleList, isomirDic, logDic)

@@ -372,6 +372,7 @@ def main():
               "annotStats", golden["expected"]["annotStats"])
         make_gff_golden(scratch, bindir)
         make_a2i_golden(scratch, bindir)
+        make_trf_golden(scratch, bindir)
     finally:
         shutil.rmtree(scratch, ignore_errors=True)
 
@@ -511,6 +512,174 @@ def make_a2i_golden(scratch, bindir):
         json.dump(golden, fh, separators=(",", ":"), sort_keys=True)
     print("wrote", out, os.path.getsize(out), "bytes; report rows", len(files["a2IEditing.report.csv"]) - 2,
           "newform rows", len(files["a2IEditing.report.newform.csv"]) - 2)
+
+
+def build_trf_world(seed=131):
+    """A tRNA world for -trf: mature tRNAs with miRge-style names (one exact duplicate, one
+    1-mismatch isodecoder, one 'Und' type), their `pre_<name>_trailer` entries, the five
+    annotation tables of MAIN:164-251 as text, and reads of every tRF type."""
+    import numpy as np
+    from mirge_amd import synth
+    libs = synth.SynthLibraries(seed=seed, scale=1.0, n_paralogs=4, n_snp=4, shapes=SHAPES)
+    rng = np.random.default_rng(seed + 5)
+
+    def rs(n):
+        return "".join("ACGT"[c] for c in rng.integers(0, 4, n))
+    aa_list = [("Ala", "AGC"), ("Gly", "GCC"), ("Gly", "GCC"), ("Leu", "CAA"), ("Leu", "CAA"), ("Val", "TAC"),
+               ("Und", "NNN"), ("Ser", "AGA"), ("iMet", "CAT"), ("Cys", "GCA")]
+    names, seqs = [], []
+    for k, (aa, ac) in enumerate(aa_list):
+        names.append("Homo_sapiens_tRNA-%s-%s-%d-1" % (aa, ac, k + 1))
+        seqs.append(rs(int(rng.integers(72, 77))))
+    seqs[2] = seqs[1]                                            # exact duplicate (de-duplicated list)
+    alt = "A" if seqs[3][60] != "A" else "C"
+    seqs[4] = seqs[3][:60] + alt + seqs[3][61:]                 # isodecoder, 1 mismatch
+    pre_names = ["pre_%s_trailer" % n for n in names]
+    pre_seqs = [s[-10:] + rs(int(rng.integers(18, 36))) for s in seqs]
+    pre_seqs[2] = pre_seqs[1]
+    libs.libs["mature_trna"] = (names, seqs)
+    libs.libs["pre_trna"] = (pre_names, pre_seqs)
+    tables = {}
+    tables["_trna.str"] = "".join(">%s\n%s\n%s\n" % (n, s, "." * 33 + "XXX" + "." * (len(s) - 36))
+                                  for n, s in zip(names, seqs))
+    tables["_trna_aminoacid_anticodon.csv"] = "".join(
+        "%s,%s,%s\n" % (n, aa, ac) for n, (aa, ac) in list(zip(names, aa_list)) + list(zip(pre_names, aa_list)))
+    tables["_trna_deduplicated_list.csv"] = "unique,duplicates\n%s,%s\n%s,%s\n" % (
+        names[1], names[2], pre_names[1], pre_names[2])
+    infor, merges = ["cluster,a,b,position,sequence,tRNA sequence"], []
+    for t in (0, 1, 3, 4, 5, 7, 8):
+        n, s = names[t], seqs[t]
+        infor.append("%s_Cluster1,x,x,1-30,%s,%s" % (n, s[:30], s))
+        infor.append("%s_Cluster2,x,x,%d-%d,%s,%s" % (n, len(s) - 23, len(s), s[-24:], s))
+        if t == 3:                                               # the Leu pair shares one 5' entity
+            merges.append("%s_%s_5p,%s_Cluster1/%s_Cluster1" % (names[3], names[4], names[3], names[4]))
+        elif t != 4:
+            merges.append("%s_5p,%s_Cluster1" % (n, n))
+        merges.append("%s_3p,%s_Cluster2" % (n, n))
+    for t in (0, 1, 5):
+        n, s = pre_names[t], pre_seqs[t]
+        infor.append("%s_Cluster1,x,x,1-20,%s,%s" % (n, s[:20], s))
+        merges.append("%s_tRF1,%s_Cluster1" % (n, n))
+    tables["_tRF_infor.csv"] = "\n".join(infor) + "\n"
+    tables["_tRF_merges.csv"] = "\n".join(merges) + "\n"
+    samples = []
+    for si in range(2):
+        reads = [synth.codes_to_str(c) for c in synth.synth_reads(libs, 900, seed=seed + 40 + si, zipf_s=1.3)]
+        for t, s in enumerate(seqs):
+            n = len(s)
+            frags = [(0, n), (0, 32), (0, 34), (0, 20), (0, 26), (n - 22, n), (n - 30, n - 1), (33, n), (34, n - 2),
+                     (10, 35), (25, 50), (int(rng.integers(1, 20)), int(rng.integers(40, 70)))]
+            for (a, b) in frags:
+                if rng.random() < 0.25:
+                    continue
+                r = s[a:b]
+                cnt = int(rng.integers(1, 30))
+                reads += [r] * cnt
+                if rng.random() < 0.4:                       # one mismatch
+                    k = int(rng.integers(0, len(r)))
+                    reads += [r[:k] + ("A" if r[k] != "A" else "G") + r[k + 1:]] * int(rng.integers(1, 6))
+        for t, s in enumerate(pre_seqs):
+            for a in (0, 0, 2, 6):
+                ln = int(rng.integers(12, min(26, len(s) - a)))
+                reads += [s[a:a + ln] + "T" * int(rng.integers(3, 6))] * int(rng.integers(1, 15))
+        order = rng.permutation(len(reads))
+        samples.append([reads[i] for i in order if len(reads[i]) >= 16])
+    return libs, tables, samples
+
+
+def make_trf_golden(scratch, bindir):
+    """-trf: trfContentDic after the cascade (RAP:657-660, :698-701) and tRFs.potential.report.tsv,
+    tRF.Counts.csv, tRF.RP100K.csv, discarded.reads.summary.assigningtRFs.csv (W2C:648-800) from
+    the reference -> tests/golden/trf.json.  `random.choice` (W2C:708) is pinned to `min` on a
+    sorted list while the reference runs; the table dictionaries of MAIN:164-251 (inline code of
+    main(), not importable) are loaded by mirge_amd.trf.load_trf_tables."""
+    import copy
+    import importlib
+    import random
+    from mirge_amd import trf as my_trf
+    RAP = importlib.import_module("mirge.utils.runAnnotationPipeline")
+    W2C = importlib.import_module("mirge.utils.writeDataToCSV")
+    from mirge.utils.quantReads import quantReads
+    from mirge.utils.summarize import summarize
+    from mirge.utils.miRNAmerge import miRNAmerge
+    from mirge.utils.filter import filter as ref_filter
+
+    libs, tables_txt, samples = build_trf_world()
+    libroot = os.path.join(scratch, "libs_trf")
+    prefix = libs.write_layout(libroot, species="human", db="miRBase")
+    for suffix, text in tables_txt.items():
+        with open(os.path.join(libroot, "human", "annotation.Libs", "human" + suffix), "w") as fh:
+            fh.write(text)
+    t = my_trf.load_trf_tables(libroot, "human")
+    outdir = os.path.join(scratch, "out_trf")
+    os.makedirs(outdir)
+    sample_list = ["t0.fastq", "t1.fastq"]
+    seq_dic, len_dic = {}, {}
+    for si, reads in enumerate(samples):
+        fq = os.path.join(outdir, "t%d.trim.fastq" % si)
+        with open(fq, "w") as fh:
+            for k, r in enumerate(reads):
+                fh.write("@r%d\n%s\n+\n%s\n" % (k, r, "I" * len(r)))
+        quantReads(fq, seq_dic, len_dic, 2, si, sample_list, False, False)
+    log_dic = {"quantStats": [{"filename": s} for s in sample_list], "annotStats": []}
+    annot_names = ["exact miRNA", "hairpin miRNA", "mature tRNA", "primary tRNA", "snoRNA", "rRNA",
+                   "ncrna others", "mRNA", "isomiR miRNA"]
+    ix = lambda k: prefix + k
+    trf_content = {}
+    RAP.runAnnotationPipeline(bindir, seq_dic, "1", False, annot_names, outdir, log_dic,
+                              ix("mirna_miRBase"), ix("hairpin_miRBase"), ix("mature_trna"), ix("pre_trna"),
+                              ix("snorna"), ix("rrna"), ix("ncrna_others"), ix("mrna"), False, None, False,
+                              None, None, "miRBase", True, t["trnaStruDic"], trf_content, sample_list)
+    content_after_cascade = copy.deepcopy(trf_content)
+    mir_dic, name_seq = {}, {}
+    summarize(seq_dic, sample_list, log_dic, mir_dic, ix("mirna_miRBase"), outdir, False, bindir)
+    miRNAmerge(os.path.join(libroot, "human", "annotation.Libs", "human_merges_miRBase.csv"), sample_list,
+               mir_dic, os.path.join(libroot, "human", "fasta.Libs", "human_mirna_SNP_pseudo_miRBase.fa"), name_seq)
+    ref_filter(mir_dic, sample_list, log_dic, "0.1")
+    merged_name = {}
+    for line in libs.merges:
+        f = line.split(",")
+        for m in f[1:]:
+            merged_name[m] = f[0]
+    quant_stats = [{k: v for k, v in q.items() if k != "filename"} for q in log_dic["quantStats"]]
+    real_choice = random.choice
+    random.choice = lambda seq: min(seq)
+    try:
+        W2C.writeDataToCSV(outdir, annot_names, sample_list, False, False, log_dic, seq_dic, mir_dic, name_seq,
+                           merged_name, bindir, None, "1", False, [], False, False, None, "miRBase", True,
+                           trf_content, t["trnaStruDic"], ix("pre_trna"), t["duptRNA2UniqueDic"],
+                           t["trnaAAanticodonDic"], t["tRNAtrfDic"], t["trfMergedNameDic"], t["trfMergedList"])
+    finally:
+        random.choice = real_choice
+    files = {}
+    for fn in ("tRFs.potential.report.tsv", "tRF.Counts.csv", "tRF.RP100K.csv",
+               "discarded.reads.summary.assigningtRFs.csv"):
+        files[fn] = open(os.path.join(outdir, fn)).read().split("\n")
+    names, seqs = libs.libs["mature_trna"]
+    kat = []
+    for (start, ln) in ((0, len(seqs[0])), (0, 33), (0, 20), (33, len(seqs[0]) - 33), (50, len(seqs[0]) - 50),
+                        (10, 20), (0, 31), (0, 36), (32, len(seqs[0]) - 34), (37, len(seqs[0]) - 37)):
+        kat.append([start, ln, RAP.trfTypes("A" * ln, names[0], start, t["trnaStruDic"], {})])
+    dist_kat = []
+    a = W2C.addDashNew("ACGTACGTAC", 30, 3, 12)
+    for (s, st, en) in (("ACGTACGTAC", 3, 12), ("ACGAACGTAC", 3, 12), ("CGTACGTACGG", 4, 14), ("TTACGTAC", 1, 8)):
+        b = W2C.addDashNew(s, 30, st, en)
+        dist_kat.append([a, b, W2C.getDistance2(a, b), list(W2C.coordinate(b))])
+    golden = {
+        "about": "captured from the reference's Python (-trf path) by tests/golden/make_golden.py; bowtie is "
+                 "the stand-in (parity unpinned), random.choice pinned to min",
+        "libraries": {k: [list(v[0]), list(v[1])] for k, v in libs.libs.items()},
+        "merges": libs.merges, "tables": tables_txt, "samples": samples, "sample_list": sample_list,
+        "state": {"seqDic": {s: {"quant": r["quant"], "annot": r["annot"]} for s, r in seq_dic.items()},
+                  "quantStats": quant_stats},
+        "expected": {"trfContentDic_after_cascade": content_after_cascade, "files": files,
+                     "trfTypes": kat, "distance": dist_kat},
+    }
+    out = os.path.join(ROOT, "tests", "golden", "trf.json")
+    with open(out, "w") as fh:
+        json.dump(golden, fh, separators=(",", ":"), sort_keys=True)
+    print("wrote", out, os.path.getsize(out), "bytes; tRF reads", len(content_after_cascade),
+          "report rows", len(files["tRFs.potential.report.tsv"]) - 2)
 
 
 def make_gff_golden(scratch, bindir):
