@@ -260,8 +260,17 @@ typedef struct mrg_fastq_info {
   uint32_t max_len;
   int32_t has_n;
 } mrg_fastq_info;
-/* Plain or gzip FASTQ.  qual_cutoff 10 and min_len 16 are the reference's values. */
-int mrg_fastq_load(const char *path, int32_t qual_cutoff, int32_t min_len, mrg_fastq **out);
+/* Plain or gzip FASTQ.  qual_cutoff 10 and min_len 16 are the reference's values
+ * (trim_file.py:30,33).  adapter = the `-ad` value after __main__.py:123-127: NULL or "none",
+ * "+N" (UnconditionalCutter, trim_file.py:34-35) or one or more comma-separated 3' adapter
+ * sequences (AdapterCutter at error rate 0.12, trim_file.py:38-41). */
+int mrg_fastq_load(const char *path, int32_t qual_cutoff, int32_t min_len, const char *adapter,
+                   mrg_fastq **out);
+/* cutadapt's 3' adapter search on one upper-case read (the AdapterCutter step above, exposed
+ * for callers that trim outside a FASTQ file and for the tests): out6 = found, read_start
+ * (where the read is cut), read_stop, adapter_stop, matches, errors. */
+int mrg_adapter_locate(const char *adapter, const char *read, double max_error_rate,
+                       int32_t min_overlap, int32_t *out6);
 int mrg_fastq_get_info(const mrg_fastq *fq, mrg_fastq_info *info);
 /* Copy the packed reads out, widened to words_per_read words (>= the file's own);
  * nmask may be NULL when has_n is 0. */

@@ -7,8 +7,8 @@ Same flags, library directory layout (MAIN:108-112, :262-281) and output tables
   * `-pb` is accepted and ignored (no bowtie); `--gpu` picks the device;
   * index files are `<prefix>.mrgfm` or `<prefix>.fa` instead of `<prefix>.*.ebwt`
     (build with `python -m mirge_amd.build_index`);
-  * `-ad` must be `none`: adapter removal is cutadapt's (not built); 3' quality
-    trimming and the 16-nt minimum are applied as the reference does;
+  * `-ad illumina|ion|<sequence>|+N` is applied as trim_file.py does (3' quality trimming,
+    cutadapt's 3' adapter search restated, 16-nt minimum);
   * `-ai` reads the genome from `<sp>_genome.mrgfm` / `.fa` or `<sp>_genome.partNNN.mrgfm`
     (`build_index --max-bases 500000000`) and answers the two genome bowtie runs on the GPU;
   * `-trf` writes `tRFs.potential.report.tsv`, `tRF.Counts.csv`, `tRF.RP100K.csv` and
@@ -92,9 +92,6 @@ def annotate_main(args):
     db = {"mirbase": "miRBase", "mirgenedb": "MirGeneDB"}.get(args.miRNA_database.lower())
     if db is None:
         _die("The value of parameter '-d' is invalid. Please check it")
-    if args.adapter != "none":
-        _die("-ad %s: adapter removal is not built in mirge_amd; trim adapters first and use -ad none"
-             % args.adapter)
     sp, lib = args.species, args.libraryPath
     if args.trf_output and sp != "human":  # MAIN:161-163
         _die("tRF detection is only supported for the species of human. Please check it.")
@@ -167,7 +164,7 @@ def annotate_main(args):
     for i, path in enumerate(raw):
         print("Performing quantitation analysis of %s..." % sample_list[i])
         t1 = time.time()
-        fq = ingest.load_fastq(os.path.abspath(path))
+        fq = ingest.load_fastq(os.path.abspath(path), adapter=args.adapter)
         loaded.append(fq)
         W = max(W, fq["words"].shape[0])
         any_n = any_n or fq["nmask"] is not None

@@ -742,11 +742,29 @@ int mrg_annotate_host(mrg_ctx* ctx, const uint64_t* reads, uint32_t words_per_re
 }
 
 // -------------------------------------------------------------- ingest
-int mrg_fastq_load(const char* path, int32_t qual_cutoff, int32_t min_len, mrg_fastq** out) {
+int mrg_adapter_locate(const char* adapter, const char* read, double max_error_rate, int32_t min_overlap,
+                       int32_t* out6) {
+  if (!adapter || !read || !out6) return fail(MRG_ERR_ARG, "mrg_adapter_locate: null argument");
+  try {
+    const mrg::AdapterMatch m =
+        mrg::locate_adapter_3p(adapter, read, std::strlen(read), max_error_rate, min_overlap);
+    out6[0] = m.found ? 1 : 0;
+    out6[1] = (int32_t)m.read_start;
+    out6[2] = (int32_t)m.read_stop;
+    out6[3] = m.adapter_stop;
+    out6[4] = m.matches;
+    out6[5] = m.errors;
+    return MRG_OK;
+  } catch (const std::exception& e) {
+    return fail(MRG_ERR_NOMEM, "mrg_adapter_locate: %s", e.what());
+  }
+}
+
+int mrg_fastq_load(const char* path, int32_t qual_cutoff, int32_t min_len, const char* adapter, mrg_fastq** out) {
   if (!path || !out) return fail(MRG_ERR_ARG, "mrg_fastq_load: null argument");
   try {
     auto h = std::make_unique<mrg_fastq>();
-    mrg::load_fastq(path, qual_cutoff, min_len, h->d);
+    mrg::load_fastq(path, qual_cutoff, min_len, adapter, h->d);
     *out = h.release();
     return MRG_OK;
   } catch (const std::bad_alloc&) {

@@ -1,17 +1,26 @@
 // FASTQ ingest on the host: parse (plain or gzip), 3' quality trimming, minimum length,
 // 2-bit packing into the structure-of-arrays layout the kernels read.
 //
-// Reference role: trim_file (utils/trim_file.py:89-134) with `-ad none`, whose only
-// modifier is cutadapt's QualityTrimmer(0, 10, phred) followed by the 16-nt minimum
-// (:30-33, :52), and the FASTQ read loop of quantReads (utils/quantReads.py:4-24).
-// cutadapt is a third-party dependency that is absent from the image (parity unpinned):
-// its published 3' rule (BWA's) is restated -- walk from the 3' end accumulating
-// (cutoff - q), stop when the sum turns negative, cut at the position of the maximum.
-// Adapter removal (cutadapt's error-tolerant matching) is not built.
+// Reference role: trim_file (utils/trim_file.py:89-134): cutadapt's QualityTrimmer(0, 10,
+// phred), then UnconditionalCutter for `-ad +N` or AdapterCutter(error rate 0.12) for an
+// adapter sequence (:30-41), then the 16-nt minimum (:33, :52); and the FASTQ read loop of
+// quantReads (utils/quantReads.py:4-24).
+// cutadapt (v1.11-1.16, README.md:49) is a third-party dependency that is absent from the
+// image (parity unpinned); its published algorithms are restated:
+//   * 3' quality rule (BWA's): walk from the 3' end accumulating (cutoff - q), stop when the
+//     sum turns negative, cut at the position of the maximum;
+//   * 3' adapter (`-a`): leftmost exact occurrence if there is one, else the semiglobal
+//     alignment of Aligner.locate (unit costs, adapter may start anywhere in the read and may
+//     run off its 3' end; among end points with overlap >= 3 and errors <= 0.12 * overlap the
+//     one with most matches, then fewest errors, first found wins); the read is cut where the
+//     adapter starts.  With several comma-separated adapters the one with most matches wins.
 #include "fastq.hpp"
 
 #include <zlib.h>
 
+#include <algorithm>
+#include <cctype>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -83,8 +92,136 @@ size_t quality_trim_3p(const char* qual, size_t len, int cutoff, int base) {
   return stop;
 }
 
-void load_fastq(const std::string& path, int qual_cutoff, int min_len, FastqData& out) {
+AdapterMatch locate_adapter_3p(const std::string& adapter, const char* read, size_t n, double max_error_rate,
+                               int min_overlap) {
+  AdapterMatch none;
+  const int m = (int)adapter.size();
+  if (m == 0) return none;
+  // exact occurrence first (Adapter.match_to)
+  if (n >= (size_t)m) {
+    for (size_t p = 0; p + m <= n; ++p)
+      if (std::memcmp(read + p, adapter.data(), (size_t)m) == 0) {
+        AdapterMatch r;
+        r.found = true;
+        r.read_start = p;
+        r.read_stop = p + m;
+        r.adapter_stop = m;
+        r.matches = m;
+        r.errors = 0;
+        return r;
+      }
+  }
+  struct Entry {
+    int cost, matches, origin;
+  };
+  const int k = (int)(max_error_rate * m);
+  std::vector<Entry> col((size_t)m + 1);
+  for (int i = 0; i <= m; ++i) col[i] = Entry{i, 0, 0};  // adapter must start at its base 0; free start in the read
+  int best_cost = m + (int)n, best_matches = 0, best_origin = 0, best_ref_stop = m;
+  size_t best_query_stop = n;
+  auto consider = [&](int i, size_t j) {
+    const int length = i + std::min(col[i].origin, 0);
+    const int cost = col[i].cost, matches = col[i].matches;
+    if (length >= min_overlap && cost <= length * max_error_rate &&
+        (matches > best_matches || (matches == best_matches && cost < best_cost))) {
+      best_matches = matches;
+      best_cost = cost;
+      best_origin = col[i].origin;
+      best_ref_stop = i;
+      best_query_stop = j;
+      return true;
+    }
+    return false;
+  };
+  int last = std::min(m, k + 1);
+  bool exact_full = false;
+  for (size_t j = 1; j <= n && !exact_full; ++j) {
+    Entry diag = col[0];
+    col[0].origin = (int)j;
+    const char c = read[j - 1];
+    for (int i = 1; i <= last; ++i) {
+      Entry cur;
+      if (adapter[i - 1] == c) {
+        cur = Entry{diag.cost, diag.matches + 1, diag.origin};
+      } else {
+        const int c_diag = diag.cost + 1, c_del = col[i].cost + 1, c_ins = col[i - 1].cost + 1;
+        if (c_diag <= c_del && c_diag <= c_ins) cur = Entry{c_diag, diag.matches, diag.origin};
+        else if (c_ins <= c_del) cur = Entry{c_ins, col[i - 1].matches, col[i - 1].origin};
+        else cur = Entry{c_del, col[i].matches, col[i].origin};
+      }
+      diag = col[i];
+      col[i] = cur;
+    }
+    while (last >= 0 && col[last].cost > k) --last;
+    if (last < m) {
+      ++last;
+    } else if (consider(m, j) && best_cost == 0 && best_matches == m) {
+      exact_full = true;
+    }
+  }
+  if (!exact_full) {
+    // adapter running off the 3' end of the read: any row of the last column.  Rows beyond
+    // `last` were not updated in the final columns; like the original they are still examined.
+    for (int i = 0; i <= m; ++i) consider(i, n);
+  }
+  if (best_cost == m + (int)n) return none;
+  AdapterMatch r;
+  r.found = true;
+  r.read_start = best_origin >= 0 ? (size_t)best_origin : 0;
+  r.read_stop = best_query_stop;
+  r.adapter_stop = best_ref_stop;
+  r.matches = best_matches;
+  r.errors = best_cost;
+  return r;
+}
+
+TrimSpec parse_trim_spec(const char* adapter) {
+  TrimSpec t;
+  if (!adapter || !*adapter || std::strcmp(adapter, "none") == 0) return t;
+  std::string a(adapter);
+  if (a[0] == '+') {  // trim_file.py:34-35: UnconditionalCutter(int(adapter))
+    char* end = nullptr;
+    long v = std::strtol(a.c_str(), &end, 10);
+    if (!end || *end) throw std::runtime_error("-ad " + a + ": not an integer");
+    t.cut = (int)v;
+    return t;
+  }
+  size_t at = 0;
+  while (at <= a.size()) {
+    size_t comma = a.find(',', at);
+    if (comma == std::string::npos) comma = a.size();
+    std::string one = a.substr(at, comma - at);
+    for (char& ch : one) ch = (char)std::toupper((unsigned char)ch);
+    if (!one.empty()) t.adapters.push_back(one);
+    at = comma + 1;
+  }
+  return t;
+}
+
+size_t apply_trim_spec(const TrimSpec& t, std::string& read) {
+  if (t.cut > 0) {
+    read.erase(0, std::min(read.size(), (size_t)t.cut));
+  } else if (t.cut < 0) {
+    const size_t drop = std::min(read.size(), (size_t)(-t.cut));
+    read.resize(read.size() - drop);
+  }
+  if (!t.adapters.empty()) {
+    std::string upper(read);
+    for (char& ch : upper) ch = (char)std::toupper((unsigned char)ch);
+    AdapterMatch best;
+    for (const std::string& a : t.adapters) {
+      AdapterMatch mt = locate_adapter_3p(a, upper.data(), upper.size(), 0.12, std::min<int>(3, (int)a.size()));
+      if (mt.found && (!best.found || mt.matches > best.matches)) best = mt;
+    }
+    if (best.found) read.resize(best.read_start);
+  }
+  return read.size();
+}
+
+void load_fastq(const std::string& path, int qual_cutoff, int min_len, const char* adapter, FastqData& out) {
   out = FastqData();
+  const TrimSpec spec = parse_trim_spec(adapter);
+  const bool modify = spec.cut != 0 || !spec.adapters.empty();
   LineReader rd(path);
   std::string name, seq, plus, qual;
   std::vector<std::string> kept_seq;
@@ -107,6 +244,10 @@ void load_fastq(const std::string& path, int qual_cutoff, int min_len, FastqData
     }
     ++out.n_total;
     size_t stop = quality_trim_3p(qual.data(), qual.size(), qual_cutoff, worker_phred64 ? 64 : 33);
+    if (modify) {
+      seq.resize(stop);
+      stop = apply_trim_spec(spec, seq);
+    }
     if ((int)stop < min_len) continue;
     if (stop > 32 * 4) throw std::runtime_error(path + ": a trimmed read of " + std::to_string(stop) + " nt exceeds the 128-nt limit");
     kept_seq.emplace_back(seq.data(), stop);

@@ -18,6 +18,24 @@ struct FastqData {
 
 // Index of the first base cut from the 3' end (cutadapt / BWA rule).
 size_t quality_trim_3p(const char* qual, size_t len, int cutoff, int base);
-void load_fastq(const std::string& path, int qual_cutoff, int min_len, FastqData& out);
+
+// cutadapt's 3' adapter search (`-a ADAPTER`): see fastq.cpp.
+struct AdapterMatch {
+  bool found = false;
+  size_t read_start = 0, read_stop = 0;  // the read is cut at read_start
+  int adapter_stop = 0, matches = 0, errors = 0;
+};
+AdapterMatch locate_adapter_3p(const std::string& adapter, const char* read, size_t n, double max_error_rate,
+                               int min_overlap);
+
+// `-ad` after MAIN:123-127: "none", "+N" (drop the first N bases), or adapter[,adapter...].
+struct TrimSpec {
+  int cut = 0;
+  std::vector<std::string> adapters;
+};
+TrimSpec parse_trim_spec(const char* adapter);
+size_t apply_trim_spec(const TrimSpec& spec, std::string& read);  // returns the new length
+
+void load_fastq(const std::string& path, int qual_cutoff, int min_len, const char* adapter, FastqData& out);
 
 }  // namespace mrg

@@ -1,12 +1,13 @@
 """FASTQ ingest and collapse.
 
-  load_fastq   trim_file with `-ad none` (utils/trim_file.py:89-134): 3' quality trimming
-               at Q10 (cutadapt's / BWA's rule), 16-nt minimum, phred sniffing (:104-106)
+  load_fastq   trim_file (utils/trim_file.py:89-134): 3' quality trimming at Q10 (cutadapt's /
+               BWA's rule), `-ad` adapter removal (cutadapt's 3' adapter search at error rate
+               0.12, or `+N`), 16-nt minimum, phred sniffing (:104-106)
   collapse     quantReads (utils/quantReads.py:3-24): unique reads, per-sample counts and the
                read-length histogram, on the GPU (hipCUB radix sort + scans)
 
-Adapter removal (`-ad illumina|ion|<seq>`) is cutadapt's error-tolerant matching and is
-not built; such inputs must arrive adapter-trimmed.
+cutadapt is absent from the image: both rules are restated from its published algorithms
+(parity unpinned, see csrc/fastq.cpp).
 """
 import ctypes as C
 import os
@@ -20,11 +21,30 @@ QUAL_CUTOFF = 10  # trim_file.py:30
 MIN_LENGTH = 16   # trim_file.py:33
 
 
-def load_fastq(path, words_per_read=None, qual_cutoff=QUAL_CUTOFF, min_len=MIN_LENGTH):
+def resolve_adapter(adapter):
+    """MAIN:123-127: the `-ad` keywords."""
+    if adapter == "illumina":
+        return "TGGAATTCTCGGGTGCCAAGGAACTCCAG"
+    if adapter == "ion":
+        return "11"     # the reference passes this on as an adapter *sequence*; it never matches
+    return adapter
+
+
+def adapter_locate(adapter, read, max_error_rate=0.12, min_overlap=3):
+    """cutadapt's 3' adapter search on one read: None or (read_start, read_stop, adapter_stop,
+    matches, errors); the read is cut at read_start."""
+    out = (C.c_int32 * 6)()
+    check(_native.load().mrg_adapter_locate(adapter.upper().encode(), read.upper().encode(), max_error_rate,
+                                            min(min_overlap, len(adapter)), out))
+    return tuple(out[1:6]) if out[0] else None
+
+
+def load_fastq(path, words_per_read=None, qual_cutoff=QUAL_CUTOFF, min_len=MIN_LENGTH, adapter="none"):
     """Returns dict(words [W, n], lens, nmask|None, total, kept, phred, max_len)."""
     lib = _native.load()
     h = C.c_void_p()
-    check(lib.mrg_fastq_load(os.fsencode(path), qual_cutoff, min_len, C.byref(h)))
+    check(lib.mrg_fastq_load(os.fsencode(path), qual_cutoff, min_len, resolve_adapter(adapter).encode(),
+                             C.byref(h)))
     try:
         info = _native.FastqInfo()
         check(lib.mrg_fastq_get_info(h, C.byref(info)))

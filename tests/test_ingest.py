@@ -53,6 +53,94 @@ def test_quality_trim_rule_known_answers():
     assert t("") == 0
 
 
+ILLUMINA = "TGGAATTCTCGGGTGCCAAGGAACTCCAG"       # MAIN:125
+
+
+def test_adapter_rule_known_answers(native_lib):
+    """cutadapt's documented 3' adapter behaviour (min overlap 3, 12 % errors, indels allowed),
+    same answers from the product (C++) and the oracle restatement."""
+    ins = "ACGTTGCAAGCTTGACCTGA"                      # 20 nt without adapter-like content
+    cases = [
+        (ins + ILLUMINA + "ACGT", 20),                 # whole adapter inside the read
+        (ins + ILLUMINA[:8], 20),                      # an 8-nt adapter prefix at the 3' end
+        (ins + ILLUMINA[:3], 20),                      # 3 nt: the minimum overlap
+        (ins + ILLUMINA[:2], None),                    # 2 nt: left alone
+        (ins + ILLUMINA[:10] + "A" + ILLUMINA[11:], 20),          # one substitution in 29 nt
+        (ins + ILLUMINA[:12] + ILLUMINA[13:] + "CC", 20),         # one base deleted from the adapter
+        (ins + ILLUMINA[:12] + "A" + ILLUMINA[12:], 20),          # one base inserted
+        (ins + ILLUMINA[:4] + "C" + ILLUMINA[5:10], 20),          # 1 error in a 10-nt overlap: 1 <= 1.2
+        (ins + ILLUMINA[:4] + "C" + ILLUMINA[5:8], None),         # 1 error in 8 nt: 1 > 0.96
+        (ins, None),
+        ("", None),
+        (ILLUMINA, 0),
+        (ins + ILLUMINA + ins + ILLUMINA, 20),         # leftmost exact occurrence
+    ]
+    for read, cut in cases:
+        got = ingest.adapter_locate(ILLUMINA, read)
+        want = oingest.locate_adapter_3p(ILLUMINA, read)
+        assert got == want, read
+        assert (None if got is None else got[0]) == cut, read
+    assert ingest.adapter_locate("11", ins + "ACGT") is None        # `-ad ion` (MAIN:127) never matches
+    assert oingest.trim_read("ACGTACGTACGT", "+3") == "TACGTACGT"
+
+
+def test_adapter_search_matches_oracle_on_random_reads(native_lib):
+    rng = np.random.default_rng(12)
+    adapters = [ILLUMINA, "AGATCGGAAGAGC", "ACGT", "TTTTTTTTTT"]
+    hits = 0
+    for it in range(4000):
+        ad = adapters[it % len(adapters)]
+        L = int(rng.integers(0, 60))
+        read = "".join("ACGTN"[int(c)] for c in rng.choice(5, L, p=[0.245, 0.245, 0.245, 0.245, 0.02]))
+        if rng.random() < 0.7:                          # plant a (possibly damaged, possibly cut) adapter
+            a = list(ad[:int(rng.integers(1, len(ad) + 1))] if rng.random() < 0.5 else ad)
+            for _ in range(int(rng.integers(0, 4))):
+                op, k = int(rng.integers(0, 3)), int(rng.integers(0, len(a))) if a else 0
+                if not a:
+                    break
+                if op == 0:
+                    a[k] = "ACGT"[int(rng.integers(0, 4))]
+                elif op == 1:
+                    del a[k]
+                else:
+                    a.insert(k, "ACGT"[int(rng.integers(0, 4))])
+            tail = "" if rng.random() < 0.5 else "".join("ACGT"[int(c)] for c in rng.integers(0, 4, int(rng.integers(0, 12))))
+            read = read + "".join(a) + tail
+        got = ingest.adapter_locate(ad, read)
+        assert got == oingest.locate_adapter_3p(ad, read), (ad, read)
+        hits += got is not None
+    assert 1000 < hits < 3900
+
+
+@pytest.mark.parametrize("adapter", ["illumina", "ion", "+4", "AGATCGGAAGAGC,TGGAATTCTCGGGTGCC"])
+def test_fastq_loader_with_adapter_matches_oracle(native_lib, tmp_path, adapter):
+    rng = np.random.default_rng(5)
+    p = str(tmp_path / "a.fastq")
+    with open(p, "w") as fh:
+        for i in range(2000):
+            L = int(rng.integers(14, 30))
+            seq = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, L))
+            r = rng.random()
+            if r < 0.6:
+                seq += ILLUMINA[:int(rng.integers(1, 30))]
+            elif r < 0.8:
+                seq += "AGATCGGAAGAGC" + "ACGT"[int(rng.integers(0, 4))] * int(rng.integers(0, 5))
+            q = rng.integers(25, 41, len(seq))
+            if rng.random() < 0.3:
+                q[-int(rng.integers(1, 6)):] = 3
+            fh.write("@r%d\n%s\n+\n%s\n" % (i, seq, "".join(chr(int(x) + 33) for x in q)))
+    resolved = ingest.resolve_adapter(adapter)
+    want, total, phred = oingest.load_fastq(p, adapter=resolved)
+    got = ingest.load_fastq(p, adapter=adapter)
+    assert (got["total"], got["kept"], got["phred"]) == (total, len(want), phred)
+    assert pack.unpack_reads(got["words"], got["lens"], got["nmask"]) == want
+    plain = ingest.load_fastq(p)
+    if adapter == "ion":
+        assert got["kept"] == plain["kept"] and (got["lens"] == plain["lens"]).all()
+    else:
+        assert got["lens"].sum() < plain["lens"].sum()
+
+
 def test_fastq_errors(native_lib, tmp_path):
     from mirge_amd._native import MirgeAmdError
     bad = tmp_path / "bad.fastq"
