@@ -82,7 +82,8 @@ typedef struct mrg_index_info {
   uint32_t n_super;    /* superblocks (65536 BWT symbols each), 4 words each */
   uint32_t primary;    /* BWT row holding the sentinel */
   uint32_t text_words; /* 2-bit packed text, 32-bit words incl. padding */
-  uint32_t ftab_k;     /* k of the main k-mer jump table; k = 6 and k = 4 tables follow it */
+  uint8_t ftab_ks[4];  /* k of each k-mer jump table, largest first, 0 = absent: {big 12..14 or 0,
+                        * main 8..11, 6, 4} */
   uint32_t C[4];       /* first BWT row of each symbol */
   uint64_t bytes_fm;   /* n_blocks * 16 + n_super * 16 */
   uint64_t bytes_sa;   /* (n_bases + 1) * 8 */
@@ -101,7 +102,8 @@ typedef struct mrg_index_view {
   const uint32_t *super;     /* n_super * 4 words: C[c] + count before the superblock */
   const uint32_t *text;      /* text_words */
   const uint64_t *sa;        /* n_bases + 1 rows: pos | before<<32 | after<<40 | seg<<48 */
-  const uint32_t *ftab;      /* BWT interval [lo,hi) of every k-mer: 2*4^ftab_k + 2*4^6 + 2*4^4 words */
+  const uint32_t *ftab;      /* BWT interval [lo,hi) of every k-mer: the tables of ftab_ks back to
+                              * back, 2*4^k words each */
   const uint32_t *seg_start; /* n_seg + 1 */
   const uint32_t *seg_ref;   /* n_seg */
   const uint32_t *seg_off;   /* n_seg */
@@ -147,7 +149,7 @@ typedef struct mrg_pass_stats {
   uint64_t aligned;    /* "# reads with at least one reported alignment" */
   uint64_t steps;      /* FM backward-extension (LF) steps executed */
   uint64_t candidates; /* seed occurrences verified against the text */
-  uint64_t lookups;    /* k-mer jump-table loads (each replaces ftab_k LF steps) */
+  uint64_t lookups;    /* k-mer jump-table loads (each replaces k LF steps) */
   float ms;            /* device time of the pass (the reference's cpuTime) */
   uint32_t lds_bytes;  /* library bytes staged in LDS for this pass (0 = served from HBM/L2) */
   uint32_t lds_mode;   /* 0 nothing, 1 occ blocks, 2 occ blocks + text, 3 text only: names the

@@ -37,7 +37,7 @@ class PassStats(C.Structure):
 class IndexInfo(C.Structure):
     _fields_ = [("n_ref", C.c_uint32), ("n_seg", C.c_uint32), ("n_bases", C.c_uint32),
                 ("n_blocks", C.c_uint32), ("n_super", C.c_uint32), ("primary", C.c_uint32),
-                ("text_words", C.c_uint32), ("ftab_k", C.c_uint32),
+                ("text_words", C.c_uint32), ("ftab_ks", C.c_uint8 * 4),
                 ("C", C.c_uint32 * 4), ("bytes_fm", C.c_uint64), ("bytes_sa", C.c_uint64)]
 
 

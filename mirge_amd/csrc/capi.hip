@@ -49,7 +49,7 @@ struct DevLib {
            *seg_ref = nullptr, *seg_off = nullptr, *chunk_seg = nullptr;
   uint64_t* sa = nullptr;
   uint32_t* ftab = nullptr;
-  uint32_t ftab_k = 0;
+  mrg::JumpTables tabs = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   uint32_t n = 0, nblk = 0, nsup = 0, primary = 0, text_words = 0, n_seg = 0, n_ref = 0;
 };
 
@@ -166,7 +166,7 @@ int mrg_index_get_info(const mrg_index* h, mrg_index_info* info) {
   info->n_super = (uint32_t)(ix.super.size() / 4);
   info->primary = ix.primary;
   info->text_words = (uint32_t)ix.text.size();
-  info->ftab_k = ix.ftab_k;
+  for (int t = 0; t < 4; ++t) info->ftab_ks[t] = ix.ftab_ks[t];
   for (int c = 0; c < 4; ++c) info->C[c] = ix.C[c];
   info->bytes_fm = (uint64_t)ix.blocks.size() * 16 + (uint64_t)ix.super.size() * 4;
   info->bytes_sa = (uint64_t)ix.sa.size() * 8;
@@ -273,7 +273,20 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
   l.text_words = (uint32_t)((ix.text.size() + 3) / 4 * 4);
   if ((rc = upload(&l.text, ix.text, 4))) return rc;
   if ((rc = upload(&l.sa, ix.sa))) return rc;
-  l.ftab_k = ix.ftab_k;
+  {
+    // ascending k for the kernels; ix.ftab_ks is in storage order (largest first, 0 = absent)
+    uint32_t off = 0, offs[4];
+    for (int t = 0; t < 4; ++t) {
+      offs[t] = off;
+      if (ix.ftab_ks[t]) off += 2u << (2 * ix.ftab_ks[t]);
+    }
+    for (int i = 0; i < 4; ++i) {
+      int t = 3 - i;
+      if (!ix.ftab_ks[t]) t = 1;  // no big table: the main one again
+      l.tabs.k[i] = ix.ftab_ks[t];
+      l.tabs.off[i] = offs[t];
+    }
+  }
   if ((rc = upload(&l.ftab, ix.ftab))) return rc;
   if ((rc = upload(&l.seg_start, ix.seg_start))) return rc;
   if ((rc = upload(&l.seg_ref, ix.seg_ref))) return rc;
@@ -387,7 +400,8 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     p.text = l.text;
     p.sa = l.sa;
     p.ftab = l.ftab;
-    p.ftab_k = ctx->use_ftab ? l.ftab_k : 0u;
+    p.tabs = l.tabs;
+    if (!ctx->use_ftab) p.tabs.k[0] = 0u;
     p.seg_start = l.seg_start;
     p.seg_ref = l.seg_ref;
     p.seg_off = l.seg_off;
@@ -570,7 +584,8 @@ int fill_count_params(mrg_ctx* ctx, const char* who, const uint64_t* d_reads, ui
   p->text = l.text;
   p->sa = l.sa;
   p->ftab = l.ftab;
-  p->ftab_k = ctx->use_ftab ? l.ftab_k : 0u;
+  p->tabs = l.tabs;
+  if (!ctx->use_ftab) p->tabs.k[0] = 0u;
   p->n = l.n;
   p->nsup = l.nsup;
   p->primary = l.primary;

@@ -239,6 +239,49 @@ static void finish_from_codes(const std::vector<uint8_t>& codes, FmIndex& ix,
     ix.text[p >> 4] |= (uint32_t)codes[p] << ((p & 15) * 2);
 }
 
+// k-mer jump tables: rows whose suffix starts with the k-mer are contiguous, so the BWT
+// interval a backward search of the k-mer ends in is tabulated.  A seed piece uses the largest
+// table it is long enough for:
+//   ks[0]  "big"  k = ceil(log4 n) when that exceeds 11 (12..14): for whole-read seeds
+//          (`-n 0`) on large libraries the interval is then about one row and no LF step --
+//          two random 16-byte block loads each -- is left;  2 * 4^k words (2.1 GB at k = 14)
+//   ks[1]  "main" k = ceil(log4 n) clamped to 8..11 (11 = a seed piece of a 22-nt read)
+//   ks[2], ks[3]  k = 6 and k = 4 for the short pieces of the 2-mismatch pass (6-7 of 19 nt)
+// Derived data: rebuilt on load, not stored in the index file.
+void build_jump_tables(FmIndex& ix) {
+  uint32_t k_log = 1;
+  while (k_log < 14 && (1ull << (2 * k_log)) < ix.n) ++k_log;
+  ix.ftab_ks[0] = k_log > 11 ? (uint8_t)k_log : 0;
+  ix.ftab_ks[1] = (uint8_t)std::min(11u, std::max(8u, k_log));
+  ix.ftab_ks[2] = 6;
+  ix.ftab_ks[3] = 4;
+  size_t total = 0;
+  for (uint8_t k : ix.ftab_ks)
+    if (k) total += (size_t)2 << (2 * k);
+  ix.ftab.assign(total, 0);
+  size_t base = 0;
+  for (uint8_t k : ix.ftab_ks) {
+    if (!k) continue;
+    const uint64_t kmask = (1ull << (2 * k)) - 1;
+    uint64_t prev = ~0ull;
+    uint32_t* tab = ix.ftab.data() + base;
+    for (size_t i = 0; i < ix.sa.size(); ++i) {
+      const uint32_t p = (uint32_t)ix.sa[i];
+      if ((uint64_t)p + k > ix.n) continue;
+      const uint32_t w = p >> 4, sh = (p & 15) * 2;
+      uint64_t win = (uint64_t)ix.text[w] | ((uint64_t)ix.text[w + 1] << 32);
+      win = sh ? (win >> sh) | ((uint64_t)ix.text[w + 2] << (64 - sh)) : win;
+      const uint64_t code = win & kmask;
+      if (code != prev) {
+        tab[2 * code] = (uint32_t)i;
+        prev = code;
+      }
+      tab[2 * code + 1] = (uint32_t)i + 1;
+    }
+    base += (size_t)2 << (2 * k);
+  }
+}
+
 void build_index(const std::vector<std::string>& names,
                  const std::vector<std::string>& seqs, FmIndex& ix) {
   if (names.size() != seqs.size()) throw std::runtime_error("names/seqs size mismatch");
@@ -295,42 +338,6 @@ void build_index(const std::vector<std::string>& names,
     ix.chunk_seg[ch] = sgi;
   }
 
-  // k-mer jump tables: rows whose suffix starts with the k-mer are contiguous.  The main
-  // table (k = 8..12 by library size) is followed by a k = 6 and a k = 4 table
-  // for the short pigeonhole pieces of the 2-mismatch pass (6-7 bases of a 19-mer).
-  {
-    // k = ceil(log4 n), so the interval the table returns is about one row; at most 11
-    // (the two seed pieces of a 22-nt read) unless the library is >= 64 Mbp, at least 8
-    uint32_t k_main = 8;
-    while (k_main < 11 && (1ull << (2 * k_main)) < ix.n) ++k_main;
-    if (ix.n >= (1u << 26)) k_main = 12;
-    ix.ftab_k = k_main;
-    const uint32_t ks[3] = {k_main, 6u, 4u};
-    size_t total = 0;
-    for (uint32_t k : ks) total += (size_t)2 << (2 * k);
-    ix.ftab.assign(total, 0);
-    size_t base = 0;
-    for (uint32_t k : ks) {
-      const uint64_t kmask = (1ull << (2 * k)) - 1;
-      uint64_t prev = ~0ull;
-      uint32_t* tab = ix.ftab.data() + base;
-      for (size_t i = 0; i < sa32.size(); ++i) {
-        const uint32_t p = sa32[i];
-        if ((uint64_t)p + k > ix.n) continue;
-        const uint32_t w = p >> 4, sh = (p & 15) * 2;
-        uint64_t win = (uint64_t)ix.text[w] | ((uint64_t)ix.text[w + 1] << 32);
-        win = sh ? (win >> sh) | ((uint64_t)ix.text[w + 2] << (64 - sh)) : win;
-        const uint64_t code = win & kmask;
-        if (code != prev) {
-          tab[2 * code] = (uint32_t)i;
-          prev = code;
-        }
-        tab[2 * code + 1] = (uint32_t)i + 1;
-      }
-      base += (size_t)2 << (2 * k);
-    }
-  }
-
   // 8-byte suffix-array rows: position + distance to both ends of its segment
   std::vector<uint32_t> seg_of(ix.n);
   for (uint32_t sg = 0; sg < nseg; ++sg)
@@ -350,6 +357,7 @@ void build_index(const std::vector<std::string>& names,
     }
     ix.sa[i] = row;
   }
+  build_jump_tables(ix);
 }
 
 std::string entry_sequence(const FmIndex& ix, uint32_t r) {
@@ -369,7 +377,7 @@ std::string entry_sequence(const FmIndex& ix, uint32_t r) {
 // Serialisation ("MRGFM1\0\0" + counts + raw arrays)
 // ---------------------------------------------------------------------------
 namespace {
-const char kMagic[8] = {'M', 'R', 'G', 'F', 'M', '4', 0, 0};
+const char kMagic[8] = {'M', 'R', 'G', 'F', 'M', '5', 0, 0};
 
 template <class T>
 void put_vec(std::ofstream& o, const std::vector<T>& v) {
@@ -393,7 +401,7 @@ void save_index(const FmIndex& ix, const std::string& path) {
   if (!o) throw std::runtime_error("cannot write " + path);
   o.write(kMagic, 8);
   uint32_t hdr[8] = {ix.n, ix.primary, ix.C[0], ix.C[1], ix.C[2], ix.C[3],
-                     (uint32_t)ix.names.size(), ix.ftab_k};
+                     (uint32_t)ix.names.size(), 0u};
   o.write((const char*)hdr, sizeof(hdr));
   for (size_t r = 0; r < ix.names.size(); ++r) {
     uint32_t l = (uint32_t)ix.names[r].size();
@@ -406,7 +414,6 @@ void save_index(const FmIndex& ix, const std::string& path) {
   put_vec(o, ix.super);
   put_vec(o, ix.text);
   put_vec(o, ix.sa);
-  put_vec(o, ix.ftab);
   put_vec(o, ix.seg_start);
   put_vec(o, ix.seg_ref);
   put_vec(o, ix.seg_off);
@@ -428,7 +435,6 @@ void load_index(const std::string& path, FmIndex& ix) {
   ix.primary = hdr[1];
   for (int c = 0; c < 4; ++c) ix.C[c] = hdr[2 + c];
   uint32_t nref = hdr[6];
-  ix.ftab_k = hdr[7];
   ix.names.resize(nref);
   ix.ref_n_runs.resize(nref);
   for (uint32_t r = 0; r < nref; ++r) {
@@ -444,15 +450,15 @@ void load_index(const std::string& path, FmIndex& ix) {
   get_vec(in, ix.super);
   get_vec(in, ix.text);
   get_vec(in, ix.sa);
-  get_vec(in, ix.ftab);
   get_vec(in, ix.seg_start);
   get_vec(in, ix.seg_ref);
   get_vec(in, ix.seg_off);
   get_vec(in, ix.chunk_seg);
   if (ix.sa.size() != (size_t)ix.n + 1 || ix.blocks.size() != (size_t)((ix.n + 1) >> 5) + 1 ||
       ix.super.size() != ((size_t)((ix.n + 1) >> kSuperShift) + 1) * 4 ||
-      ix.ftab_k > 12 || ix.ftab.size() != ((size_t)2 << (2 * ix.ftab_k)) + (2u << 12) + (2u << 8))
+      ix.text.size() < (size_t)(ix.n >> 4) + 3)
     throw std::runtime_error("index file inconsistent");
+  build_jump_tables(ix);
 }
 
 }  // namespace mrg

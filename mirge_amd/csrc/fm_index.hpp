@@ -17,10 +17,11 @@
 //            32-39 bases back to the start of its N-free segment (clamped 255),
 //            40-47 bases to the end of the segment (clamped 255), 48-63 segment
 //            id (0xFFFF when the library has more segments than that)
-//   ftab     jump tables: for every k-mer (k = ceil(log4 n) in 8..11, 12 from 64 Mbp; code =
-//            sum base(t) << 2t) the BWT interval [lo,hi) a backward search of it
-//            ends in, so the first k steps of a seed search are one 8-byte load;
-//            followed by a k = 6 and a k = 4 table for short seed pieces
+//   ftab     jump tables: for every k-mer (code = sum base(t) << 2t) the BWT interval [lo,hi)
+//            a backward search of it ends in, so the first k steps of a seed search are one
+//            8-byte load.  Up to four tables, largest k first (ftab_ks): an optional big one
+//            (k = 12..14 = ceil(log4 n)) for whole-read seeds on large libraries, the main one
+//            (k = 8..11), k = 6 and k = 4 for short seed pieces
 //   seg_*    N-free segments of the entries; an alignment must sit in one
 //   chunk_seg[p>>5] = segment holding text position (p & ~31)
 #pragma once
@@ -49,8 +50,8 @@ struct FmIndex {
   std::vector<uint32_t> super;  // 4 per superblock
   std::vector<uint32_t> text;
   std::vector<uint64_t> sa;
-  uint32_t ftab_k = 0;
-  std::vector<uint32_t> ftab;  // lo, hi per k-mer: main table (4^k), then k = 6, then k = 4
+  uint8_t ftab_ks[4] = {0, 0, 0, 0};  // k of each table, descending; 0 = table absent
+  std::vector<uint32_t> ftab;         // lo, hi per k-mer, the tables of ftab_ks back to back
   std::vector<uint32_t> seg_start, seg_ref, seg_off, chunk_seg;
 };
 
@@ -59,6 +60,7 @@ void build_index(const std::vector<std::string>& names,
                  const std::vector<std::string>& seqs, FmIndex& out);
 void read_fasta(const std::string& path, std::vector<std::string>& names,
                 std::vector<std::string>& seqs);
+void build_jump_tables(FmIndex& ix);  // from sa + text
 void save_index(const FmIndex& ix, const std::string& path);
 void load_index(const std::string& path, FmIndex& ix);
 std::string entry_sequence(const FmIndex& ix, uint32_t i);

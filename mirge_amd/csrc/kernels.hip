@@ -87,6 +87,20 @@ struct Lib {
   }
 };
 
+// The largest jump table a seed piece of `plen` bases is long enough for: its k (0 = none) and
+// its word offset.
+__device__ __forceinline__ uint32_t pick_table(const JumpTables& t, int32_t plen, uint32_t& word_off) {
+  uint32_t k = plen >= (int32_t)t.k[0] ? t.k[0] : 0u;
+  word_off = t.off[0];
+#pragma unroll
+  for (int i = 1; i < 4; ++i) {
+    const bool take = plen >= (int32_t)t.k[i];
+    k = take ? t.k[i] : k;
+    word_off = take ? t.off[i] : word_off;
+  }
+  return k;
+}
+
 // x / K for the piece counts a pass can have (1..3), x < 65536: no integer-divide sequence
 __device__ __forceinline__ int32_t div_pieces(int32_t x, int32_t K) {
   return K == 1 ? x : (K == 2 ? (x >> 1) : (int32_t)(((uint32_t)x * 43691u) >> 17));
@@ -282,18 +296,16 @@ match_kernel(const MatchParams p) {
         // ---- exact backward search of read[a,b) ----
         uint32_t lo = 0, hi = p.n + 1;
         int32_t j = b;
-        if (p.ftab_k && b - a >= 4) {
+        uint32_t tab_off = 0;
+        const uint32_t tk = p.tabs.k[0] ? pick_table(p.tabs, b - a, tab_off) : 0u;
+        if (tk) {
           // the piece's last k bases in one load: BWT interval of that k-mer (largest
-          // table the piece is long enough for: main k, then 6, then 4)
-          const int32_t plen = b - a;
-          const uint32_t k = plen >= (int32_t)p.ftab_k ? p.ftab_k : (plen >= 6 ? 6u : 4u);
-          const uint32_t tab_off = plen >= (int32_t)p.ftab_k ? 0u
-                                   : (2u << (2 * p.ftab_k)) + (plen >= 6 ? 0u : (2u << 12));
-          j = b - (int32_t)k;
+          // table the piece is long enough for)
+          j = b - (int32_t)tk;
           uint64_t code = pick_word<W>(rd, (uint32_t)j >> 5) >> ((j & 31) * 2);
-          if (W > 1 && (j & 31) + (int32_t)k > 32)
+          if (W > 1 && (j & 31) + (int32_t)tk > 32)
             code |= pick_word<W>(rd, ((uint32_t)j >> 5) + 1) << (64 - (j & 31) * 2);
-          code &= (1ull << (2 * k)) - 1ull;
+          code &= (1ull << (2 * tk)) - 1ull;
           const uint2 iv = *reinterpret_cast<const uint2*>(p.ftab + tab_off + 2 * code);
           lo = iv.x;
           hi = iv.y;
@@ -497,11 +509,9 @@ __global__ void __launch_bounds__(kCountThreads) count_kernel(const CountParams 
         if (has_n) continue;
         uint32_t lo = 0, hi = p.n + 1;
         int32_t j = b;
-        if (p.ftab_k && b - a >= 4) {
-          const int32_t plen = b - a;
-          const uint32_t kk = plen >= (int32_t)p.ftab_k ? p.ftab_k : (plen >= 6 ? 6u : 4u);
-          const uint32_t tab_off = plen >= (int32_t)p.ftab_k ? 0u
-                                   : (2u << (2 * p.ftab_k)) + (plen >= 6 ? 0u : (2u << 12));
+        uint32_t tab_off = 0;
+        const uint32_t kk = p.tabs.k[0] ? pick_table(p.tabs, b - a, tab_off) : 0u;
+        if (kk) {
           j = b - (int32_t)kk;
           uint64_t code = pick_word<W>(rd, (uint32_t)j >> 5) >> ((j & 31) * 2);
           if (W > 1 && (j & 31) + (int32_t)kk > 32)

@@ -19,14 +19,21 @@ constexpr uint32_t kMaxSegments = 512u;
 constexpr uint32_t kMatchCtlBytes = (kMaxSegments + 4u + 4u * 16u) * 4u;  // segment lengths, control
                                                                        // words, 16 B per wave
 
+// The jump tables of one library in ascending k (k[0] = 0: tables not used; a missing big table
+// repeats the main one), with the word offset of each inside `ftab`.
+struct JumpTables {
+  uint32_t k[4];
+  uint32_t off[4];
+};
+
 struct MatchParams {
   // library (device pointers)
   const uint32_t* blocks;  // 16 B per 32 BWT symbols
   const uint32_t* super;   // 16 B per 65536 BWT symbols
   const uint32_t* text;
   const uint64_t* sa;      // 8 B rows: pos | before<<32 | after<<40 | seg<<48
-  const uint32_t* ftab;    // k-mer jump table: lo, hi per k-mer
-  uint32_t ftab_k;         // 0 = do not use it
+  const uint32_t* ftab;    // k-mer jump tables: lo, hi per k-mer
+  JumpTables tabs;
   const uint32_t* seg_start;
   const uint32_t* seg_ref;
   const uint32_t* seg_off;
@@ -65,7 +72,8 @@ struct CountParams {
   const uint32_t* text;
   const uint64_t* sa;
   const uint32_t* ftab;
-  uint32_t ftab_k, n, nsup, primary;
+  JumpTables tabs;
+  uint32_t n, nsup, primary;
   const uint64_t* reads;
   const uint8_t* lens;
   const uint64_t* nmask;

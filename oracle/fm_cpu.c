@@ -23,9 +23,10 @@
 typedef struct {
   const uint32_t *blocks, *super, *text;
   const uint64_t *sa;
-  const uint32_t *ftab; /* k-mer jump table: lo, hi per k-mer */
+  const uint32_t *ftab; /* k-mer jump tables: lo, hi per k-mer, tables back to back */
   const uint32_t *seg_start, *seg_ref, *seg_off, *chunk_seg;
-  uint32_t n, primary, ftab_k;
+  uint32_t n, primary;
+  uint8_t ftab_ks[4]; /* k of each table, largest first, 0 = absent */
 } orc_lib;
 
 typedef struct {
@@ -82,11 +83,18 @@ static int match_one(const orc_lib *l, const orc_pass *p, const uint64_t *rd, co
     if (has_n) continue;
     uint32_t lo = 0, hi = l->n + 1;
     int j = b;
-    if (use_ftab && l->ftab_k && b - a >= 4) {
-      /* the piece's last k bases in one load: main table, else the k = 6 / k = 4 ones */
-      int plen = b - a;
-      int k = plen >= (int)l->ftab_k ? (int)l->ftab_k : (plen >= 6 ? 6 : 4);
-      size_t off = plen >= (int)l->ftab_k ? 0 : ((size_t)2 << (2 * l->ftab_k)) + (plen >= 6 ? 0 : (2u << 12));
+    /* the piece's last k bases in one load: the largest table the piece is long enough for */
+    int k = 0;
+    size_t off = 0, next_off = 0;
+    for (int t = 0; use_ftab && t < 4; ++t) {
+      int kt = l->ftab_ks[t];
+      if (!k && kt && b - a >= kt) {
+        k = kt;
+        off = next_off;
+      }
+      if (kt) next_off += (size_t)2 << (2 * kt);
+    }
+    if (k) {
       uint64_t code = 0;
       j = b - k;
       for (int t = 0; t < k; ++t)

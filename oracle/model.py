@@ -171,7 +171,7 @@ class _OrcLib(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in
                 ("blocks", "super", "text", "sa", "ftab", "seg_start", "seg_ref", "seg_off",
                  "chunk_seg")] + \
-               [("n", C.c_uint32), ("primary", C.c_uint32), ("ftab_k", C.c_uint32)]
+               [("n", C.c_uint32), ("primary", C.c_uint32), ("ftab_ks", C.c_uint8 * 4)]
 
 
 class _OrcPass(C.Structure):
@@ -205,7 +205,8 @@ def fm_cascade(lib_views, passes, reads, lens, nmask=None, wstop=0, threads=None
             setattr(libs[i], k, a.ctypes.data)
         libs[i].n = int(v["n"])
         libs[i].primary = int(v["primary"])
-        libs[i].ftab_k = int(v["ftab_k"])
+        for t, k in enumerate(v["ftab_ks"]):
+            libs[i].ftab_ks[t] = int(k)
     ps = (_OrcPass * len(passes))()
     for i, p in enumerate(passes):
         for k, _ in _OrcPass._fields_:

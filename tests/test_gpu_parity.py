@@ -321,3 +321,35 @@ def test_count_best_matches_exhaustive_scan(native_lib, oracle_lib):
                 assert (int(mm[i]), int(cnt[i])) == (em, min(ec, 255)), (r, seed_len, n_seed, n_total, opts)
     eng.set_option("wstop", 2)
     eng.set_option("ftab", 1)
+
+
+@pytest.mark.gpu
+def test_big_library_jump_tables(native_lib, oracle_lib):
+    """A 4.8 Mbp library served from HBM with the k = 12 / 11 / 6 / 4 tables: GPU = CPU port,
+    for W = 1 and W = 2 reads."""
+    from mirge_amd import pack
+    from mirge_amd.engine import Engine, ReadSet
+    from mirge_amd.index import FmIndex
+    from tests.util import BIG_PASSES, big_library_case
+    names, seqs, reads = big_library_case()
+    ix = FmIndex.build(names, seqs)
+    eng = Engine(0)
+    eng.add_library("big", ix)
+    w, l, nm = pack.pack_reads(reads)
+    assert w.shape[0] == 2
+    ref = model.fm_cascade([ix.view()], BIG_PASSES, w, l, nm, wstop=2, ftab=True)
+    rs = ReadSet(w, l, nm, None, device=eng.device)
+    res = eng.cascade(rs, eng.make_passes([dict(p, lib="big") for p in BIG_PASSES]))
+    for name, a in zip(("pass_id", "ref_id", "pos", "mm"), res.to_host()):
+        assert np.array_equal(a, ref[name]), name
+    for i, st in enumerate(res.stats):
+        assert [st[k] for k in ("processed", "aligned", "steps", "candidates", "lookups")] == \
+            [int(x) for x in ref["stats"][i]]
+    short = [r for r in reads if len(r) <= 32]
+    w1, l1, nm1 = pack.pack_reads(short)
+    assert w1.shape[0] == 1
+    ref1 = model.fm_cascade([ix.view()], BIG_PASSES, w1, l1, nm1, wstop=2, ftab=True)
+    res1 = eng.cascade(ReadSet(w1, l1, nm1, None, device=eng.device),
+                       eng.make_passes([dict(p, lib="big") for p in BIG_PASSES]))
+    for name, a in zip(("pass_id", "ref_id", "pos", "mm"), res1.to_host()):
+        assert np.array_equal(a, ref1[name]), name

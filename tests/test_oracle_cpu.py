@@ -113,7 +113,7 @@ def test_jump_table_equals_backward_search(native_lib):
     seqs = ["".join("ACGT"[c] for c in rng.integers(0, 4, int(L))) for L in rng.integers(20, 400, 60)]
     ix = FmIndex.build(["e%d" % i for i in range(len(seqs))], seqs)
     v = ix.view()
-    assert v["ftab_k"] == 8 and len(v["ftab"]) == 2 * (4 ** 8 + 4 ** 6 + 4 ** 4)
+    assert v["ftab_ks"] == [0, 8, 6, 4] and len(v["ftab"]) == 2 * (4 ** 8 + 4 ** 6 + 4 ** 4)
     text = "".join(seqs)
     sa = [int(x) & 0xFFFFFFFF for x in v["sa"]]
     for trial in range(450):
@@ -130,3 +130,22 @@ def test_jump_table_equals_backward_search(native_lib):
             assert (lo, hi) == (rows[0], rows[-1] + 1)
         else:
             assert lo == hi
+
+
+def test_big_jump_table_same_results(native_lib, oracle_lib):
+    """A library beyond 4^11 bases gets the k = 12 table (whole-read seeds) next to the k = 11 one
+    (pieces of a 22-nt read); results equal the plain backward search."""
+    from mirge_amd import pack
+    from mirge_amd.index import FmIndex
+    from tests.util import BIG_PASSES, big_library_case
+    names, seqs, reads = big_library_case()
+    ix = FmIndex.build(names, seqs)
+    v = ix.view()
+    assert v["ftab_ks"] == [12, 11, 6, 4] and len(v["ftab"]) == 2 * (4 ** 12 + 4 ** 11 + 4 ** 6 + 4 ** 4)
+    w, l, nm = pack.pack_reads(reads)
+    base = model.fm_cascade([v], BIG_PASSES, w, l, nm)
+    alt = model.fm_cascade([v], BIG_PASSES, w, l, nm, wstop=2, ftab=True)
+    for k in ("pass_id", "ref_id", "pos", "mm"):
+        assert np.array_equal(base[k], alt[k]), k
+    assert all(int(alt["stats"][i][1]) > 100 for i in range(3))
+    assert int(alt["stats"][:, 2].sum()) < int(base["stats"][:, 2].sum()) // 4

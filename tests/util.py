@@ -48,3 +48,29 @@ class World:
         self.words, self.lens, self.nmask = pack.pack_reads(self.reads)
         self.passes = pass_dicts()
         self.n_mirna = self.index["mirna"].n_ref
+
+
+def big_library_case(seed=9, n_entries=12, entry_len=400_000, n_reads=6000):
+    """A library past 4^11 bases, so its index carries the big (k = 12) jump table, and reads cut
+    from it (exact, 1-2 substitutions, random).  Returns (names, seqs, reads)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = [acgt[rng.integers(0, 4, entry_len)].tobytes().decode() for _ in range(n_entries)]
+    names = ["big%d" % i for i in range(n_entries)]
+    reads = []
+    for _ in range(n_reads):
+        s = seqs[int(rng.integers(0, n_entries))]
+        L = int(rng.integers(16, 41))
+        o = int(rng.integers(0, entry_len - L))
+        r = list(s[o:o + L])
+        for _ in range(int(rng.integers(0, 3))):
+            r[int(rng.integers(0, L))] = "ACGT"[int(rng.integers(0, 4))]
+        reads.append("".join(r))
+    reads += ["".join("ACGT"[c] for c in rng.integers(0, 4, 22)) for _ in range(500)]
+    return names, seqs, reads
+
+
+BIG_PASSES = [dict(lib=0, seed_len=28, max_mm_seed=0, max_mm_total=2, min_len=0, max_len=25),     # -n 0: k = 12
+              dict(lib=0, seed_len=28, max_mm_seed=1, max_mm_total=2, min_len=0, max_len=255),    # -n 1: 11-nt pieces
+              dict(lib=0, seed_len=1024, max_mm_seed=2, max_mm_total=2, min_len=0, max_len=255)]  # -v 2: short pieces
