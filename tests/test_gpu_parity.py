@@ -353,3 +353,47 @@ def test_big_library_jump_tables(native_lib, oracle_lib):
                        eng.make_passes([dict(p, lib="big") for p in BIG_PASSES]))
     for name, a in zip(("pass_id", "ref_id", "pos", "mm"), res1.to_host()):
         assert np.array_equal(a, ref1[name]), name
+
+
+@pytest.mark.gpu
+def test_count_and_list_best_on_a_20mbp_library(native_lib, oracle_lib):
+    """mrg_count_best / mrg_list_best against a library served from HBM with the k = 13 jump
+    table (a genome part in miniature): a sample of reads equals the exhaustive scan."""
+    from mirge_amd import pack
+    from mirge_amd.engine import Engine, ReadSet
+    from mirge_amd.index import FmIndex
+    rng = np.random.default_rng(21)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    unit = acgt[rng.integers(0, 4, 30)].tobytes().decode()
+    seqs = []
+    for c in range(4):
+        body = acgt[rng.integers(0, 4, 5_000_000)].tobytes().decode()
+        cut = int(rng.integers(1000, 4_000_000))
+        seqs.append(body[:cut] + unit + body[cut:])          # one 30-mer present in every chromosome
+    names = ["chr%d" % (c + 1) for c in range(4)]
+    ix = FmIndex.build(names, seqs)
+    assert list(ix.info.ftab_ks) == [13, 11, 6, 4]
+    eng = Engine(0)
+    eng.add_library("g", ix)
+    reads = [unit[:20], unit[5:27], unit[:10] + "A" + unit[11:24]]
+    for _ in range(37):
+        s = seqs[int(rng.integers(0, 4))]
+        L = int(rng.integers(18, 31))
+        o = int(rng.integers(0, len(s) - L))
+        r = list(s[o:o + L])
+        for _ in range(int(rng.integers(0, 3))):
+            r[int(rng.integers(0, L))] = "ACGT"[int(rng.integers(0, 4))]
+        reads.append("".join(r))
+    olib = model.Library(names, seqs)
+    w, l, nm = pack.pack_reads(reads)
+    rs = ReadSet(w, l, nm, None, device=eng.device)
+    for n_seed in (0, 1):
+        mm, cnt = eng.count_best(rs, "g", seed_len=28, max_mm_seed=n_seed, max_mm_total=2)
+        bm, off, ref, pos = eng.list_best(rs, "g", seed_len=28, max_mm_seed=n_seed, max_mm_total=2)
+        for i, r in enumerate(reads):
+            em, ec = model.best_stratum(olib, r, 28, n_seed, 2)
+            assert (int(mm[i]), int(cnt[i])) == (em, min(ec, 255)), (r, n_seed)
+            want, _ = model.align_all_best(olib, r, 28, n_seed, 2)
+            got = list(zip(ref[off[i]:off[i + 1]].tolist(), pos[off[i]:off[i + 1]].tolist()))
+            assert int(bm[i]) == em and got == want, (r, n_seed)
+        assert int(cnt[0]) >= 4 and int(cnt[1]) >= 4
