@@ -265,9 +265,11 @@ typedef struct mrg_fastq_info {
 /* Plain or gzip FASTQ.  qual_cutoff 10 and min_len 16 are the reference's values
  * (trim_file.py:30,33).  adapter = the `-ad` value after __main__.py:123-127: NULL or "none",
  * "+N" (UnconditionalCutter, trim_file.py:34-35) or one or more comma-separated 3' adapter
- * sequences (AdapterCutter at error rate 0.12, trim_file.py:38-41). */
+ * sequences (AdapterCutter at error rate 0.12, trim_file.py:38-41).  threads = trimming worker
+ * threads (the reference's `-cpu` worker processes, trim_file.py:93-98); <= 0 picks one per
+ * hardware thread, at most 32.  One thread inflates and splits records, the workers trim. */
 int mrg_fastq_load(const char *path, int32_t qual_cutoff, int32_t min_len, const char *adapter,
-                   mrg_fastq **out);
+                   int32_t threads, mrg_fastq **out);
 /* cutadapt's 3' adapter search on one upper-case read (the AdapterCutter step above, exposed
  * for callers that trim outside a FASTQ file and for the tests): out6 = found, read_start
  * (where the read is cut), read_stop, adapter_stop, matches, errors. */

@@ -161,15 +161,27 @@ def annotate_main(args):
     words_all, lens_all, nmask_all, sample_all = [], [], [], []
     any_n, W = False, 1
     loaded = []
-    for i, path in enumerate(raw):
-        print("Performing quantitation analysis of %s..." % sample_list[i])
+    # trim_file per sample (MAIN:346-372); `-cpu` threads are shared out over the samples, which are
+    # read concurrently (one inflate/record-splitting thread each plus its trimming workers)
+    from concurrent.futures import ThreadPoolExecutor
+    n_cpu = max(1, int(args.cpu))
+    n_jobs = max(1, min(len(raw), n_cpu))
+
+    def load_one(i):
         t1 = time.time()
-        fq = ingest.load_fastq(os.path.abspath(path), adapter=args.adapter)
+        fq = ingest.load_fastq(os.path.abspath(raw[i]), adapter=args.adapter, threads=max(1, n_cpu // n_jobs))
+        return fq, time.time() - t1
+
+    for name in sample_list:
+        print("Performing quantitation analysis of %s..." % name)
+    with ThreadPoolExecutor(max_workers=n_jobs) as pool:
+        results = list(pool.map(load_one, range(len(raw))))
+    for i, (fq, dt) in enumerate(results):
         loaded.append(fq)
         W = max(W, fq["words"].shape[0])
         any_n = any_n or fq["nmask"] is not None
         log_dic["quantStats"].append({"filename": sample_list[i], "totalReads": fq["total"],
-                                      "trimmedReads": fq["kept"], "cpuTime-trim": time.time() - t1,
+                                      "trimmedReads": fq["kept"], "cpuTime-trim": dt,
                                       "cpuTime-uniq": 0.0})
     t1 = time.time()
     for i, fq in enumerate(loaded):

@@ -775,11 +775,12 @@ int mrg_adapter_locate(const char* adapter, const char* read, double max_error_r
   }
 }
 
-int mrg_fastq_load(const char* path, int32_t qual_cutoff, int32_t min_len, const char* adapter, mrg_fastq** out) {
+int mrg_fastq_load(const char* path, int32_t qual_cutoff, int32_t min_len, const char* adapter, int32_t threads,
+                   mrg_fastq** out) {
   if (!path || !out) return fail(MRG_ERR_ARG, "mrg_fastq_load: null argument");
   try {
     auto h = std::make_unique<mrg_fastq>();
-    mrg::load_fastq(path, qual_cutoff, min_len, adapter, h->d);
+    mrg::load_fastq(path, qual_cutoff, min_len, adapter, threads, h->d);
     *out = h.release();
     return MRG_OK;
   } catch (const std::bad_alloc&) {

@@ -19,7 +19,13 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -28,40 +34,65 @@ namespace mrg {
 
 namespace {
 
-struct LineReader {
+// Records straight out of the inflate buffer: four memchr per record, no per-line copies.
+struct RecordReader {
   gzFile f;
   std::vector<char> buf;
   size_t pos = 0, end = 0;
-  explicit LineReader(const std::string& path) : buf(1 << 20) {
+  bool at_eof = false;
+  explicit RecordReader(const std::string& path) : buf(8u << 20) {
     f = gzopen(path.c_str(), "rb");
     if (!f) throw std::runtime_error("cannot open " + path);
     gzbuffer(f, 1 << 20);
   }
-  ~LineReader() {
+  ~RecordReader() {
     if (f) gzclose(f);
   }
-  bool fill() {
-    int got = gzread(f, buf.data(), (unsigned)buf.size());
+  // keep the unread tail, append more input; false when nothing more arrives
+  bool refill() {
+    if (at_eof) return false;
+    if (pos > 0) {
+      std::memmove(buf.data(), buf.data() + pos, end - pos);
+      end -= pos;
+      pos = 0;
+    }
+    if (end == buf.size()) buf.resize(buf.size() * 2);  // a line longer than the buffer
+    const int got = gzread(f, buf.data() + end, (unsigned)std::min<size_t>(buf.size() - end, 1u << 30));
     if (got < 0) throw std::runtime_error("read error (corrupt gzip?)");
-    pos = 0;
-    end = (size_t)got;
-    return got > 0;
+    if (got == 0) {
+      at_eof = true;
+      return false;
+    }
+    end += (size_t)got;
+    return true;
   }
-  // next line without its terminator; false at EOF
-  bool next(std::string& line) {
-    line.clear();
+  // One line [*s, *s + *n) without its terminator (CR stripped); false at end of input.
+  // `from` is an offset from pos so that earlier lines of the same record stay valid: callers
+  // re-derive their pointers after a refill (it may move the buffer).
+  bool line_at(size_t from, size_t* start, size_t* len, size_t* next) {
     for (;;) {
-      if (pos == end && !fill()) return !line.empty();
-      const char* s = buf.data() + pos;
-      const char* nl = (const char*)memchr(s, '\n', end - pos);
-      if (nl) {
-        line.append(s, nl - s);
-        pos += (size_t)(nl - s) + 1;
-        if (!line.empty() && line.back() == '\r') line.pop_back();
+      const char* base = buf.data() + pos;
+      const size_t avail = end - pos;
+      if (from < avail) {
+        const char* nl = (const char*)std::memchr(base + from, '\n', avail - from);
+        if (nl) {
+          size_t n = (size_t)(nl - (base + from));
+          *next = from + n + 1;
+          if (n && base[from + n - 1] == '\r') --n;
+          *start = from;
+          *len = n;
+          return true;
+        }
+      }
+      if (!refill()) {
+        if (from >= end - pos) return false;
+        size_t n = (end - pos) - from;  // last line without a newline
+        *next = from + n;
+        if (n && buf[pos + from + n - 1] == '\r') --n;
+        *start = from;
+        *len = n;
         return true;
       }
-      line.append(s, end - pos);
-      pos = end;
     }
   }
 };
@@ -218,63 +249,203 @@ size_t apply_trim_spec(const TrimSpec& t, std::string& read) {
   return read.size();
 }
 
-void load_fastq(const std::string& path, int qual_cutoff, int min_len, const char* adapter, FastqData& out) {
+namespace {
+
+// A block of consecutive records.  The reader fills seq/qual/off, a worker trims every record and
+// leaves only what survives (bases back to back + lengths).
+struct Batch {
+  std::vector<char> seq, qual;
+  std::vector<uint32_t> off;  // record i = [off[i], off[i+1])
+  std::string kept;
+  std::vector<uint8_t> kept_len;
+  uint32_t max_len = 0;
+  bool has_n = false;
+  std::string error;
+};
+
+void trim_batch(Batch& b, const TrimSpec& spec, int qual_cutoff, int base, int min_len) {
+  const bool modify = spec.cut != 0 || !spec.adapters.empty();
+  const size_t n = b.off.size() - 1;
+  b.kept.reserve(b.seq.size() / 2);
+  b.kept_len.reserve(n);
+  std::string tmp;
+  for (size_t i = 0; i < n; ++i) {
+    const char* sq = b.seq.data() + b.off[i];
+    const size_t len = b.off[i + 1] - b.off[i];
+    size_t stop = quality_trim_3p(b.qual.data() + b.off[i], len, qual_cutoff, base);
+    if (modify) {
+      tmp.assign(sq, stop);
+      stop = apply_trim_spec(spec, tmp);
+      sq = tmp.data();
+    }
+    if ((int)stop < min_len) continue;
+    if (stop > 32 * 4) {
+      b.error = "a trimmed read of " + std::to_string(stop) + " nt exceeds the 128-nt limit";
+      return;
+    }
+    b.kept.append(sq, stop);
+    b.kept_len.push_back((uint8_t)stop);
+    if (stop > b.max_len) b.max_len = (uint32_t)stop;
+  }
+  std::vector<char>().swap(b.seq);
+  std::vector<char>().swap(b.qual);
+  std::vector<uint32_t>().swap(b.off);
+}
+
+}  // namespace
+
+// Reader (this thread: inflate + split into records) -> workers (trim) -> parallel 2-bit packing.
+// The reference does the same with cutadapt worker processes (trim_file.py:24-66, `-cpu`).
+void load_fastq(const std::string& path, int qual_cutoff, int min_len, const char* adapter, int threads,
+                FastqData& out) {
   out = FastqData();
   const TrimSpec spec = parse_trim_spec(adapter);
-  const bool modify = spec.cut != 0 || !spec.adapters.empty();
-  LineReader rd(path);
-  std::string name, seq, plus, qual;
-  std::vector<std::string> kept_seq;
-  bool worker_phred64 = false, any64 = false;
-  while (rd.next(name)) {
-    if (name.empty()) continue;
-    if (name[0] != '@') throw std::runtime_error(path + ": record " + std::to_string(out.n_total + 1) + " does not start with '@'");
-    if (!rd.next(seq) || !rd.next(plus) || !rd.next(qual))
-      throw std::runtime_error(path + ": truncated record " + std::to_string(out.n_total + 1));
-    if (seq.size() != qual.size())
+  if (threads <= 0) threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+  constexpr size_t kBatchRecords = 1 << 15;
+
+  std::deque<std::unique_ptr<Batch>> batches;  // in file order; stable addresses
+  std::mutex mu;
+  std::condition_variable cv;
+  size_t next_job = 0;
+  bool eof = false;
+  int base = 33;
+  auto worker = [&]() {
+    for (;;) {
+      Batch* job = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return next_job < batches.size() || eof; });
+        if (next_job >= batches.size()) return;
+        job = batches[next_job++].get();
+      }
+      try {
+        trim_batch(*job, spec, qual_cutoff, base, min_len);
+      } catch (const std::exception& e) {
+        job->error = e.what();
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  struct Joiner {
+    std::vector<std::thread>& p;
+    std::mutex& m;
+    std::condition_variable& c;
+    bool& eof;
+    ~Joiner() {
+      {
+        std::lock_guard<std::mutex> lk(m);
+        eof = true;
+      }
+      c.notify_all();
+      for (auto& t : p)
+        if (t.joinable()) t.join();
+    }
+  } joiner{pool, mu, cv, eof};
+
+  RecordReader rd(path);
+  bool any64 = false;
+  std::unique_ptr<Batch> cur(new Batch());
+  cur->off.push_back(0);
+  auto flush = [&]() {
+    if (cur->off.size() == 1) return;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      batches.push_back(std::move(cur));
+    }
+    cv.notify_one();
+    cur.reset(new Batch());
+    cur->off.push_back(0);
+  };
+  for (;;) {
+    size_t st[4], ln[4], nx = 0;
+    if (!rd.line_at(0, &st[0], &ln[0], &nx)) break;
+    if (ln[0] == 0) {  // blank line between records
+      rd.pos += nx;
+      continue;
+    }
+    bool whole = true;
+    for (int k = 1; k < 4 && whole; ++k) whole = rd.line_at(nx, &st[k], &ln[k], &nx);
+    const char* rec = rd.buf.data() + rd.pos;  // valid now: no refill after the last line_at
+    if (rec[st[0]] != '@') throw std::runtime_error(path + ": record " + std::to_string(out.n_total + 1) + " does not start with '@'");
+    if (!whole) throw std::runtime_error(path + ": truncated record " + std::to_string(out.n_total + 1));
+    if (ln[1] != ln[3])
       throw std::runtime_error(path + ": sequence and quality lengths differ in record " + std::to_string(out.n_total + 1));
+    const char* seq = rec + st[1];
+    const char* qual = rec + st[3];
     // trim_file.py:104-106 sniffs the first 1000 records for a quality character > 'J' (74);
     // the trimming workers are created while the first record is being read (:107-110), so
     // only that record decides the base they trim with
     if (out.n_total < 1000) {
       bool hi = false;
-      for (char c : qual) hi |= (unsigned char)c > 74;
+      for (size_t i = 0; i < ln[3]; ++i) hi |= (unsigned char)qual[i] > 74;
       if (hi) any64 = true;
-      if (out.n_total == 0) worker_phred64 = hi;
+      if (out.n_total == 0) {
+        base = hi ? 64 : 33;
+        for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+      }
     }
     ++out.n_total;
-    size_t stop = quality_trim_3p(qual.data(), qual.size(), qual_cutoff, worker_phred64 ? 64 : 33);
-    if (modify) {
-      seq.resize(stop);
-      stop = apply_trim_spec(spec, seq);
-    }
-    if ((int)stop < min_len) continue;
-    if (stop > 32 * 4) throw std::runtime_error(path + ": a trimmed read of " + std::to_string(stop) + " nt exceeds the 128-nt limit");
-    kept_seq.emplace_back(seq.data(), stop);
-    if (stop > out.max_len) out.max_len = (uint32_t)stop;
+    cur->seq.insert(cur->seq.end(), seq, seq + ln[1]);
+    cur->qual.insert(cur->qual.end(), qual, qual + ln[3]);
+    cur->off.push_back((uint32_t)cur->seq.size());
+    rd.pos += nx;
+    if (cur->off.size() > kBatchRecords) flush();
   }
+  flush();
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    eof = true;
+  }
+  cv.notify_all();
+  for (auto& t : pool) t.join();
+  pool.clear();
+
   out.phred = any64 ? 64 : 33;
-  out.n_kept = kept_seq.size();
+  std::vector<uint64_t> first(batches.size() + 1, 0);
+  for (size_t b = 0; b < batches.size(); ++b) {
+    if (!batches[b]->error.empty()) throw std::runtime_error(path + ": " + batches[b]->error);
+    first[b + 1] = first[b] + batches[b]->kept_len.size();
+    out.max_len = std::max(out.max_len, batches[b]->max_len);
+  }
+  out.n_kept = first.back();
   out.words_per_read = out.max_len <= 32 ? 1 : (out.max_len <= 64 ? 2 : 4);
   const uint32_t W = out.words_per_read;
   const uint64_t n = out.n_kept;
   out.words.assign((size_t)W * n, 0);
   out.nmask.assign((size_t)W * n, 0);
   out.lens.resize(n);
-  for (uint64_t r = 0; r < n; ++r) {
-    const std::string& s = kept_seq[r];
-    out.lens[r] = (uint8_t)s.size();
-    for (size_t i = 0; i < s.size(); ++i) {
-      int c = code_of(s[i]);
-      const size_t at = (size_t)(i >> 5) * n + r;
-      if (c < 0) {
-        out.nmask[at] |= 1ull << ((i & 31) * 2);
-        out.has_n = true;
-      } else {
-        out.words[at] |= (uint64_t)c << ((i & 31) * 2);
+  std::atomic<size_t> next_pack{0};
+  auto packer = [&]() {
+    for (;;) {
+      const size_t b = next_pack.fetch_add(1);
+      if (b >= batches.size()) return;
+      Batch& bt = *batches[b];
+      const char* p = bt.kept.data();
+      uint64_t r = first[b];
+      for (uint8_t len : bt.kept_len) {
+        out.lens[r] = len;
+        for (uint32_t w = 0; w < W && 32u * w < len; ++w) {
+          uint64_t word = 0, mask = 0;
+          const uint32_t nb = std::min<uint32_t>(32, len - 32 * w);
+          for (uint32_t i = 0; i < nb; ++i) {
+            const int c = code_of(p[32 * w + i]);
+            if (c < 0) mask |= 1ull << (2 * i);
+            else word |= (uint64_t)c << (2 * i);
+          }
+          out.words[(size_t)w * n + r] = word;
+          out.nmask[(size_t)w * n + r] = mask;
+          if (mask) bt.has_n = true;
+        }
+        p += len;
+        ++r;
       }
+      std::string().swap(bt.kept);
     }
-  }
+  };
+  for (int t = 0; t < threads; ++t) pool.emplace_back(packer);
+  for (auto& t : pool) t.join();
+  pool.clear();
+  for (auto& b : batches) out.has_n |= b->has_n;
 }
 
 }  // namespace mrg

@@ -36,6 +36,8 @@ struct TrimSpec {
 TrimSpec parse_trim_spec(const char* adapter);
 size_t apply_trim_spec(const TrimSpec& spec, std::string& read);  // returns the new length
 
-void load_fastq(const std::string& path, int qual_cutoff, int min_len, const char* adapter, FastqData& out);
+// threads <= 0: one per hardware thread, at most 32
+void load_fastq(const std::string& path, int qual_cutoff, int min_len, const char* adapter, int threads,
+                FastqData& out);
 
 }  // namespace mrg

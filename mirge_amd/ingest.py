@@ -39,12 +39,13 @@ def adapter_locate(adapter, read, max_error_rate=0.12, min_overlap=3):
     return tuple(out[1:6]) if out[0] else None
 
 
-def load_fastq(path, words_per_read=None, qual_cutoff=QUAL_CUTOFF, min_len=MIN_LENGTH, adapter="none"):
+def load_fastq(path, words_per_read=None, qual_cutoff=QUAL_CUTOFF, min_len=MIN_LENGTH, adapter="none",
+               threads=0):
     """Returns dict(words [W, n], lens, nmask|None, total, kept, phred, max_len)."""
     lib = _native.load()
     h = C.c_void_p()
     check(lib.mrg_fastq_load(os.fsencode(path), qual_cutoff, min_len, resolve_adapter(adapter).encode(),
-                             C.byref(h)))
+                             int(threads), C.byref(h)))
     try:
         info = _native.FastqInfo()
         check(lib.mrg_fastq_get_info(h, C.byref(info)))
