@@ -13,7 +13,7 @@ Same flags, library directory layout (MAIN:108-112, :262-281) and output tables
     (`build_index --max-bases 500000000`) and answers the two genome bowtie runs on the GPU;
   * `-trf` writes `tRFs.potential.report.tsv`, `tRF.Counts.csv`, `tRF.RP100K.csv` and
     `discarded.reads.summary.assigningtRFs.csv`; the per-sample clustering reports
-    (`tRFs.samples.tmp/`), `-spikeIn`'s extra outputs and the PDF report are not produced.
+    (`tRFs.samples.tmp/`) and the PDF report are not produced.
 Call order follows MAIN:346-389.
 """
 import argparse

@@ -373,6 +373,7 @@ def main():
         make_gff_golden(scratch, bindir)
         make_a2i_golden(scratch, bindir)
         make_trf_golden(scratch, bindir)
+        make_flags_golden(scratch, bindir)
     finally:
         shutil.rmtree(scratch, ignore_errors=True)
 
@@ -680,6 +681,93 @@ def make_trf_golden(scratch, bindir):
         json.dump(golden, fh, separators=(",", ":"), sort_keys=True)
     print("wrote", out, os.path.getsize(out), "bytes; tRF reads", len(content_after_cascade),
           "report rows", len(files["tRFs.potential.report.tsv"]) - 2)
+
+
+def make_flags_golden(scratch, bindir):
+    """-spikeIn and -tcf: the ten-pass cascade, `spikeInReads`, the extra annot column of
+    mapped.csv / unmapped.csv, the spike-in column of annotation.report.csv and
+    `<sample>.trim.collapse.fa` (QNT:26-44) from the reference -> tests/golden/flags.json."""
+    import copy
+    import importlib
+    import numpy as np
+    from mirge_amd import synth
+    RAP = importlib.import_module("mirge.utils.runAnnotationPipeline")
+    W2C = importlib.import_module("mirge.utils.writeDataToCSV")
+    from mirge.utils.quantReads import quantReads
+    from mirge.utils.summarize import summarize
+    from mirge.utils.miRNAmerge import miRNAmerge
+    from mirge.utils.filter import filter as ref_filter
+    from mirge.utils.generateReport import generateReport
+
+    libs = synth.SynthLibraries(seed=404, scale=1.0, n_paralogs=4, n_snp=4, shapes=SHAPES)
+    rng = np.random.default_rng(44)
+    spike_seqs = ["".join("ACGT"[c] for c in rng.integers(0, 4, 40)) for _ in range(8)]
+    libs.libs["spike-in"] = (["spike-%d" % i for i in range(8)], spike_seqs)
+    samples = []
+    for si in range(2):
+        reads = [synth.codes_to_str(c) for c in synth.synth_reads(libs, 1200, seed=500 + si, zipf_s=1.3)]
+        for s in spike_seqs:
+            reads += [s[4:26]] * int(rng.integers(1, 9)) + [s[:18]] * int(rng.integers(0, 4))
+            reads += [s[10:20] + "A" + s[21:34]]                  # one mismatch: -n 0 does not take it
+        order = rng.permutation(len(reads))
+        samples.append([reads[i] for i in order])
+    libroot = os.path.join(scratch, "libs_flags")
+    prefix = libs.write_layout(libroot, species="syn", db="miRBase")
+    outdir = os.path.join(scratch, "out_flags")
+    os.makedirs(outdir)
+    sample_list = ["f0.fastq", "f1.fastq"]
+    seq_dic, len_dic = {}, {}
+    for si, reads in enumerate(samples):
+        fq = os.path.join(outdir, "f%d.trim.fastq" % si)
+        with open(fq, "w") as fh:
+            for k, r in enumerate(reads):
+                fh.write("@r%d\n%s\n+\n%s\n" % (k, r, "I" * len(r)))
+        quantReads(fq, seq_dic, len_dic, 2, si, sample_list, True, True)
+    log_dic = {"quantStats": [{"filename": s, "totalReads": len(samples[i]) + 5, "trimmedReads": len(samples[i]),
+                               "cpuTime-trim": 0.0, "cpuTime-uniq": 0.0} for i, s in enumerate(sample_list)],
+               "annotStats": []}
+    annot_names = ["exact miRNA", "hairpin miRNA", "mature tRNA", "primary tRNA", "snoRNA", "rRNA",
+                   "ncrna others", "mRNA", "isomiR miRNA", "spike-in"]
+    ix = lambda k: prefix + k
+    RAP.runAnnotationPipeline(bindir, seq_dic, "1", False, annot_names, outdir, log_dic,
+                              ix("mirna_miRBase"), ix("hairpin_miRBase"), ix("mature_trna"), ix("pre_trna"),
+                              ix("snorna"), ix("rrna"), ix("ncrna_others"), ix("mrna"), True, ix("spike-in"), False,
+                              None, None, "miRBase", False, None, None, sample_list)
+    mir_dic, name_seq = {}, {}
+    summarize(seq_dic, sample_list, log_dic, mir_dic, ix("mirna_miRBase"), outdir, True, bindir)
+    miRNAmerge(os.path.join(libroot, "syn", "annotation.Libs", "syn_merges_miRBase.csv"), sample_list,
+               mir_dic, os.path.join(libroot, "syn", "fasta.Libs", "syn_mirna_SNP_pseudo_miRBase.fa"), name_seq)
+    ref_filter(mir_dic, sample_list, log_dic, "0.1")
+    for a in log_dic["annotStats"]:
+        a.setdefault("cpuTime", 0.0)
+    generateReport(outdir, sample_list, len_dic, log_dic, annot_names, seq_dic, True)
+    merged_name = {}
+    for line in libs.merges:
+        f = line.split(",")
+        for m in f[1:]:
+            merged_name[m] = f[0]
+    W2C.writeDataToCSV(outdir, annot_names, sample_list, False, False, log_dic, copy.deepcopy(seq_dic),
+                       copy.deepcopy(mir_dic), name_seq, merged_name, bindir, None, "1", False, [], True,
+                       False, None, "miRBase", False, None, None, None, None, None, None, None, None)
+    files = {}
+    for fn in ("mapped.csv", "unmapped.csv", "miR.Counts.csv", "miR.RPM.csv", "annotation.report.csv",
+               "f0.trim.collapse.fa", "f1.trim.collapse.fa"):
+        files[fn] = open(os.path.join(outdir, fn)).read().split("\n")
+    golden = {
+        "about": "captured from the reference's Python (-spikeIn -tcf) by tests/golden/make_golden.py; bowtie "
+                 "is the stand-in (parity unpinned)",
+        "libraries": {k: [list(v[0]), list(v[1])] for k, v in libs.libs.items()},
+        "merges": libs.merges, "samples": samples, "sample_list": sample_list,
+        "expected": {"files": files,
+                     "annotStats": [{"readsProcessed": a["readsProcessed"], "readsAligned": a["readsAligned"]}
+                                    for a in log_dic["annotStats"]],
+                     "spikeInReads": [q["spikeInReads"] for q in log_dic["quantStats"]]},
+    }
+    out = os.path.join(ROOT, "tests", "golden", "flags.json")
+    with open(out, "w") as fh:
+        json.dump(golden, fh, separators=(",", ":"), sort_keys=True)
+    print("wrote", out, os.path.getsize(out), "bytes; spikeInReads", golden["expected"]["spikeInReads"],
+          "pass 10:", golden["expected"]["annotStats"][9])
 
 
 def make_gff_golden(scratch, bindir):

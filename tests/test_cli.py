@@ -93,3 +93,48 @@ def test_cli_end_to_end_against_oracle(native_lib, oracle_lib, tmp_path):
     rep = open(os.path.join(out["outdir"], "annotation.report.csv")).read().split("\n")
     assert rep[1].split(",")[:3] == ["s0.fastq", "1503", str(len(kept[0]))]
     assert os.path.exists(os.path.join(out["outdir"], "s0.trim.collapse.fa"))
+
+
+@pytest.mark.gpu
+def test_cli_spikein_tcf_matches_reference_files(native_lib, tmp_path):
+    """`annotate -spikeIn -tcf` from FASTQ: ten-pass cascade, spike-in column, `.trim.collapse.fa`
+    -> the files of the reference's own run (tests/golden/flags.json)."""
+    import json
+    import types
+    from mirge_amd import synth
+    from tests.conftest import ROOT
+    with open(os.path.join(ROOT, "tests", "golden", "flags.json")) as fh:
+        golden = json.load(fh)
+    ns = types.SimpleNamespace(libs={k: tuple(v) for k, v in golden["libraries"].items()}, merges=golden["merges"])
+    root = str(tmp_path / "libs")
+    synth.SynthLibraries.write_layout(ns, root, species="syn", db="miRBase")
+    fastqs = []
+    for name, reads in zip(golden["sample_list"], golden["samples"]):
+        p = str(tmp_path / name)
+        with open(p, "w") as fh:
+            for k, r in enumerate(reads):
+                fh.write("@r%d\n%s\n+\n%s\n" % (k, r, "I" * len(r)))
+            for k in range(5):                      # five reads below the 16-nt minimum (totalReads - trimmedReads)
+                fh.write("@short%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % k)
+        fastqs.append(p)
+    out = cli.annotate_main(cli.build_parser().parse_args(
+        ["annotate", "-s"] + fastqs + ["-lib", root, "-sp", "syn", "-o", str(tmp_path), "-spikeIn", "-tcf"]))
+    exp = golden["expected"]
+    for a, b in zip(out["logDic"]["annotStats"], exp["annotStats"]):
+        assert (a["readsProcessed"], a["readsAligned"]) == (b["readsProcessed"], b["readsAligned"])
+    assert [q["spikeInReads"] for q in out["logDic"]["quantStats"]] == exp["spikeInReads"]
+    for fn, want in exp["files"].items():
+        got = open(os.path.join(out["outdir"], fn)).read().split("\n")
+        if fn in ("mapped.csv", "unmapped.csv"):      # row order = dict order of the collapse
+            assert got[0] == want[0] and sorted(got) == sorted(want), fn
+        elif fn == "miR.RPM.csv":
+            # Python 2 prints str(float) with 12 significant digits (reproduced by the product);
+            # the golden was captured under Python 3 (17 digits)
+            assert got[0] == want[0] and len(got) == len(want)
+            for g, w in zip(got[1:], want[1:]):
+                gf, wf = g.split(","), w.split(",")
+                assert gf[0] == wf[0] and len(gf) == len(wf)
+                for a, b in zip(gf[1:], wf[1:]):
+                    assert abs(float(a) - float(b)) <= 1e-9 * max(1.0, abs(float(b))) and len(a) <= 14
+        else:
+            assert got == want, fn
