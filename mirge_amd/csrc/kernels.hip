@@ -165,7 +165,9 @@ __device__ __forceinline__ void verify_row(const LibT& lib, const MatchParams& p
 
 }  // namespace
 
-template <int W, bool LDSI, bool LDST>
+// STRATA: the 2-mismatch policy (three seed pieces) with its stratum-first search; a separate
+// instantiation so that the other passes keep the plain piece loop.
+template <int W, bool LDSI, bool LDST, bool STRATA>
 __global__ void __launch_bounds__(MatchBlock<LDSI>::kThreads, (W == 1 ? 8 : 4))
 match_kernel(const MatchParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -280,7 +282,13 @@ match_kernel(const MatchParams p) {
     uint32_t best_seg = 0xFFFFu, best_before = 255u;
     if (eligible && L > p.max_mm_seed) {
       const int32_t R = min(L, p.seed_len);
-      const int32_t K = p.max_mm_seed + 1;
+      const int32_t Kfull = p.max_mm_seed + 1;
+      // Stratum first (2-mismatch policies only): a search with K pieces finds EVERY alignment with
+      // fewer than K seed mismatches, so when the 1-piece (exact) or the 2-piece search already
+      // yields a best hit below its own bound, that hit is final and the 3-piece search -- ~15
+      // candidates per 6-base piece -- is not run.  Most isomiRs are exact or 1-mismatch matches
+      // of the flanked library entry.
+      for (int32_t K = (STRATA ? 1 : Kfull); K <= Kfull; ++K) {
       for (int32_t k = 0; k < K; ++k) {
         const int32_t a = div_pieces(R * k, K), b = div_pieces(R * (k + 1), K);
         if (p.nmask) {
@@ -381,6 +389,8 @@ match_kernel(const MatchParams p) {
           }
         }
         if ((best >> 32) == 0ull) break;  // an exact hit is always seen by piece 0
+      }
+      if ((uint32_t)(best >> 32) < (uint32_t)K) break;  // complete below K mismatches (unaligned = 2^32 - 1)
       }
     }
 
@@ -667,10 +677,10 @@ __global__ void export_pass_counts_kernel(const uint64_t* stats, uint32_t n_pass
 // ---------------------------------------------------------------------------
 // Launch helpers (host)
 // ---------------------------------------------------------------------------
-template <int W, bool LDSI, bool LDST>
-static hipError_t launch_match_t(const MatchParams& p, uint32_t grid, uint32_t lds_bytes,
+template <int W, bool LDSI, bool LDST, bool STRATA>
+static hipError_t launch_match_s(const MatchParams& p, uint32_t grid, uint32_t lds_bytes,
                                  hipStream_t stream) {
-  auto kern = match_kernel<W, LDSI, LDST>;
+  auto kern = match_kernel<W, LDSI, LDST, STRATA>;
   if (lds_bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -679,6 +689,13 @@ static hipError_t launch_match_t(const MatchParams& p, uint32_t grid, uint32_t l
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(MatchBlock<LDSI>::kThreads), lds_bytes, stream, p);
   return hipGetLastError();
+}
+
+template <int W, bool LDSI, bool LDST>
+static hipError_t launch_match_t(const MatchParams& p, uint32_t grid, uint32_t lds_bytes,
+                                 hipStream_t stream) {
+  return p.max_mm_seed == 2 ? launch_match_s<W, LDSI, LDST, true>(p, grid, lds_bytes, stream)
+                            : launch_match_s<W, LDSI, LDST, false>(p, grid, lds_bytes, stream);
 }
 
 template <int W>

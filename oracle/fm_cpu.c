@@ -74,9 +74,12 @@ static int match_one(const orc_lib *l, const orc_pass *p, const uint64_t *rd, co
   uint64_t best = ~0ull;
   if (L <= p->max_mm_seed) return 0;
   int R = L < p->seed_len ? L : p->seed_len;
-  int K = p->max_mm_seed + 1;
-  for (int k = 0; k < K; ++k) {
-    int a = (R * k) / K, b = (R * (k + 1)) / K;
+  int Kfull = p->max_mm_seed + 1;
+  /* stratum first for 2-mismatch policies: K pieces find every alignment with < K seed mismatches,
+   * so a best hit below that bound is final and the more expensive search is skipped */
+  for (int K = (Kfull == 3 ? 1 : Kfull); K <= Kfull; ++K) {
+  for (int pc = 0; pc < K; ++pc) {
+    int a = (R * pc) / K, b = (R * (pc + 1)) / K;
     int has_n = 0;
     for (int i = a; i < b; ++i)
       if ((nm[i >> 5] >> ((i & 31) * 2)) & 1) has_n = 1;
@@ -133,6 +136,8 @@ static int match_one(const orc_lib *l, const orc_pass *p, const uint64_t *rd, co
       if (cand < best) best = cand;
     }
     if ((best >> 32) == 0) break;
+  }
+  if ((uint32_t)(best >> 32) < (uint32_t)K) break;
   }
   if (best == ~0ull) return 0;
   *key = best;
