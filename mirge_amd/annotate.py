@@ -155,7 +155,16 @@ def summarize(seqDic, sampleList, logDic, mirDic, file_mirna, outputdir, spikeIn
     r.ref_id = torch.from_numpy(ref_id).to(dev)
     r.n_pass = n_pass
     counts = engine.tally(rs, r, M, CANON_PASS, ISOMIR_PASS).cpu().numpy()
-    q, c, cat, uniq = split_counts(counts, M, S, n_pass)
+    summarize_from_counts(counts, mir_names, sampleList, logDic, mirDic, spikeIn)
+
+
+def summarize_from_counts(counts, mir_names, sampleList, logDic, mirDic, spikeIn=False):
+    """The bookkeeping of SUM:12-66 from the fused count vector of mrg_tally_run
+    ([mir_quant | mir_iscan | category totals | trimmedUniq]): fills mirDic and
+    logDic['quantStats'][i] (which must exist)."""
+    S, M = len(sampleList), len(mir_names)
+    n_pass = 10 if spikeIn else 9
+    q, c, cat, uniq = split_counts(np.asarray(counts), M, S, n_pass)
     for i, name in enumerate(mir_names):
         mirDic[name] = {"quant": [int(x) for x in q[i]], "iscan": [int(x) for x in c[i]]}
     for s in range(S):

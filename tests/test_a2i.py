@@ -123,3 +123,50 @@ def test_cli_ai_from_fastq_matches_reference_files(golden, native_lib, tmp_path)
     st = golden["state"]
     assert {s: r["annot"] for s, r in out["seqDic"].items()} == {s: r["annot"] for s, r in st["seqDic"].items()}
     check_files(golden, out["outdir"])
+
+
+@pytest.mark.gpu
+def test_columnar_path_gives_the_same_a2i_report(golden, native_lib, tmp_path):
+    """mirge_amd.columnar: arrays instead of seqDic through cascade, tally, merge and filter; only
+    the reads the -ai block groups become dict records -> the reference's files."""
+    import types
+    import numpy as np
+    from mirge_amd import columnar, ingest, pack, synth
+    from mirge_amd.engine import Engine
+    from mirge_amd.index import FmIndex
+    ns = types.SimpleNamespace(libs={k: tuple(v) for k, v in golden["libraries"].items()}, merges=golden["merges"])
+    root = str(tmp_path / "libs")
+    prefix = synth.SynthLibraries.write_layout(ns, root, species="syn", db="miRBase")
+    eng = Engine(0)
+    for key, stem in (("mirna", "mirna_miRBase"), ("hairpin", "hairpin_miRBase"), ("mature_trna", "mature_trna"),
+                      ("pre_trna", "pre_trna"), ("snorna", "snorna"), ("rrna", "rrna"),
+                      ("ncrna_others", "ncrna_others"), ("mrna", "mrna")):
+        eng.add_library(key, FmIndex.open_prefix(prefix + stem))
+    keys = []
+    for n, s in zip(*golden["libraries"]["genome"]):
+        eng.add_library("genome:" + n, FmIndex.build([n], [s]))
+        keys.append("genome:" + n)
+    # raw reads of both samples -> packed -> GPU collapse (arrays, no dict)
+    reads, sample = [], []
+    for si, rs in enumerate(golden["samples"]):
+        reads += rs
+        sample += [si] * len(rs)
+    w, l, nm = pack.pack_reads(reads)
+    col = ingest.collapse(eng, w, l, nm, np.array(sample, dtype=np.uint16), n_samples=2, max_len=int(l.max()))
+    cols = columnar.annotate_columns(eng, col["words"], col["lens"], col["nmask"], col["quant"])
+    mir_dic, log_dic, name_seq = columnar.tables_from_columns(
+        eng, cols, golden["sample_list"], os.path.join(root, "syn", "annotation.Libs", "syn_merges_miRBase.csv"),
+        os.path.join(root, "syn", "fasta.Libs", "syn_mirna_SNP_pseudo_miRBase.fa"), "0.1")
+    st = golden["state"]
+    assert mir_dic == st["mirDic"]
+    for a, b in zip(log_dic["quantStats"], st["quantStats"]):
+        for k, v in b.items():
+            assert a[k] == v, k
+    sub = columnar.mirna_read_subset(eng, cols, col["words"], col["lens"], col["nmask"], col["quant"], log_dic,
+                                     for_a2i=True)
+    full = {s: r for s, r in st["seqDic"].items() if r["annot"][1] != "" or r["annot"][9] != ""}
+    assert 0 < len(sub) <= len(full) and all(full[s]["annot"] == r["annot"] and full[s]["quant"] == r["quant"]
+                                              for s, r in sub.items())
+    a2i.a_to_i_report(str(tmp_path), golden["sample_list"], log_dic, sub, mir_dic, name_seq,
+                      golden["mirMergedNameDic"], golden["removedMiRNAList"], a2i.EngineGenome(eng, keys))
+    check_files(golden, tmp_path)
