@@ -171,8 +171,10 @@ def main():
 
     groups = {}
     for i, s in enumerate(st):
-        name = "mrg::match_kernel<1, %s>" % {0: "false, false", 1: "true, false", 2: "true, true",
-                                             3: "false, true"}[s["lds_mode"]]
+        # <W, occ blocks in LDS, text in LDS, stratum-first (the 2-mismatch policy)>
+        name = "mrg::match_kernel<1, %s, %s>" % (
+            {0: "false, false", 1: "true, false", 2: "true, true", 3: "false, true"}[s["lds_mode"]],
+            "true" if table[i][4] == 2 else "false")
         g = groups.setdefault(name, dict(ms=0.0, bytes=0.0, sbytes=0.0, launches=0, passes=[]))
         g["ms"] += per_pass_ms[i]
         g["bytes"] += alg_bytes(s)
@@ -205,7 +207,8 @@ def main():
         passes_report.append(dict(
             lib=table[i][0], ms=round(float(per_pass_ms[i]), 4), processed=s["processed"],
             aligned=s["aligned"], steps=s["steps"], candidates=s["candidates"], lookups=s["lookups"],
-            lds_bytes=s["lds_bytes"], kernel="match_kernel<1,%s>" % ["hbm", "blocks", "blocks+text", "text"][s["lds_mode"]],
+            lds_bytes=s["lds_bytes"], kernel="match_kernel<1,%s%s>" % (["hbm", "blocks", "blocks+text", "text"][s["lds_mode"]],
+                                             ",strata" if table[i][4] == 2 else ""),
             alg_gbs=round(alg_bytes(s) / max(per_pass_ms[i], 1e-9) / 1e6, 1)))
 
     # ---- CPU baseline: the oracle's port on a bounded sample, all host cores ----
