@@ -23,12 +23,8 @@ def init_process_group(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        backend = backend or "nccl"
-        kw = {}
-        if backend == "nccl":
-            import torch
-            kw["device_id"] = torch.device("cuda", local_rank)  # binds barrier() to this rank's GPU
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        # the caller has already made LOCAL_RANK its current device (barrier() uses it)
+        dist.init_process_group(backend=backend or "nccl", rank=rank, world_size=world)
     return rank, local_rank, world
 
 
