@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--sorted", action="store_true",
                     help="feed the reads in the order the GPU collapse emits uniques (sorted by packed key)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
+    ap.add_argument("--mix", action="append", default=[],
+                    help="override a fraction of the read mixture, e.g. polyt=0 (experiments; not the headline workload)")
     args = ap.parse_args()
 
     import torch
@@ -79,6 +81,11 @@ def main():
 
     # ---- this rank's shard of reads (seeded per rank), packed, moved to HBM once ----
     mix = None if args.workload == "cascade" else synth.EXACT_ONLY_MIX
+    if args.mix:
+        mix = dict(synth.DEFAULT_MIX if mix is None else mix)
+        for kv in args.mix:
+            k, v = kv.split("=")
+            mix[k] = float(v)
     words = np.empty((1, n_reads), dtype=np.uint64)
     chunk = 10_000_000
     for lo in range(0, n_reads, chunk):
