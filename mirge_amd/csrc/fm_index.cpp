@@ -374,7 +374,7 @@ std::string entry_sequence(const FmIndex& ix, uint32_t r) {
 }
 
 // ---------------------------------------------------------------------------
-// Serialisation ("MRGFM1\0\0" + counts + raw arrays)
+// Serialisation ("MRGFM5\0\0" + counts + raw arrays; the jump tables are rebuilt on load)
 // ---------------------------------------------------------------------------
 namespace {
 const char kMagic[8] = {'M', 'R', 'G', 'F', 'M', '5', 0, 0};
