@@ -102,8 +102,9 @@ typedef struct mrg_index_view {
   const uint32_t *super;     /* n_super * 4 words: C[c] + count before the superblock */
   const uint32_t *text;      /* text_words */
   const uint64_t *sa;        /* n_bases + 1 rows: pos | before<<32 | after<<40 | seg<<48 */
-  const uint32_t *ftab;      /* BWT interval [lo,hi) of every k-mer: the tables of ftab_ks back to
-                              * back, 2*4^k words each */
+  const uint32_t *ftab;      /* jump tables of ftab_ks back to back, 4^k + 1 words each: the rows
+                              * starting with k-mer c (numbered lexicographically, first base
+                              * most significant) are [T[c], T[c+1]) */
   const uint32_t *seg_start; /* n_seg + 1 */
   const uint32_t *seg_ref;   /* n_seg */
   const uint32_t *seg_off;   /* n_seg */

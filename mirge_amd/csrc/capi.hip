@@ -278,7 +278,7 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
     uint32_t off = 0, offs[4];
     for (int t = 0; t < 4; ++t) {
       offs[t] = off;
-      if (ix.ftab_ks[t]) off += 2u << (2 * ix.ftab_ks[t]);
+      if (ix.ftab_ks[t]) off += (1u << (2 * ix.ftab_ks[t])) + 1u;
     }
     for (int i = 0; i < 4; ++i) {
       int t = 3 - i;

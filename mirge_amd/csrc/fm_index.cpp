@@ -239,12 +239,15 @@ static void finish_from_codes(const std::vector<uint8_t>& codes, FmIndex& ix,
     ix.text[p >> 4] |= (uint32_t)codes[p] << ((p & 15) * 2);
 }
 
-// k-mer jump tables: rows whose suffix starts with the k-mer are contiguous, so the BWT
-// interval a backward search of the k-mer ends in is tabulated.  A seed piece uses the largest
-// table it is long enough for:
+// k-mer jump tables.  Rows are sorted by suffix, so with the k-mers numbered in the same
+// (lexicographic) order -- first base most significant -- the rows starting with k-mer c are
+// [T[c], T[c+1]): ONE 4-byte boundary per k-mer.  A suffix shorter than k (at most k-1 rows, at
+// the very end of the text) sorts just before the k-mers it prefixes and is taken as padded with
+// A, so it lands in the interval of the first of them: a candidate that verification discards.
+// A seed piece uses the largest table it is long enough for:
 //   ks[0]  "big"  k = ceil(log4 n) when that exceeds 11 (12..14): for whole-read seeds
 //          (`-n 0`) on large libraries the interval is then about one row and no LF step --
-//          two random 16-byte block loads each -- is left;  2 * 4^k words (2.1 GB at k = 14)
+//          two random 16-byte block loads each -- is left;  4^k + 1 words (1.07 GB at k = 14)
 //   ks[1]  "main" k = ceil(log4 n) clamped to 8..11 (11 = a seed piece of a 22-nt read)
 //   ks[2], ks[3]  k = 6 and k = 4 for the short pieces of the 2-mismatch pass (6-7 of 19 nt)
 // Derived data: rebuilt on load, not stored in the index file.
@@ -257,28 +260,25 @@ void build_jump_tables(FmIndex& ix) {
   ix.ftab_ks[3] = 4;
   size_t total = 0;
   for (uint8_t k : ix.ftab_ks)
-    if (k) total += (size_t)2 << (2 * k);
+    if (k) total += ((size_t)1 << (2 * k)) + 1;
   ix.ftab.assign(total, 0);
+  const uint32_t n_rows = (uint32_t)ix.sa.size();
   size_t base = 0;
   for (uint8_t k : ix.ftab_ks) {
     if (!k) continue;
-    const uint64_t kmask = (1ull << (2 * k)) - 1;
-    uint64_t prev = ~0ull;
+    const uint64_t n_codes = 1ull << (2 * k);
     uint32_t* tab = ix.ftab.data() + base;
-    for (size_t i = 0; i < ix.sa.size(); ++i) {
+    uint64_t next_c = 0;
+    for (uint32_t i = 0; i < n_rows; ++i) {
       const uint32_t p = (uint32_t)ix.sa[i];
-      if ((uint64_t)p + k > ix.n) continue;
-      const uint32_t w = p >> 4, sh = (p & 15) * 2;
-      uint64_t win = (uint64_t)ix.text[w] | ((uint64_t)ix.text[w + 1] << 32);
-      win = sh ? (win >> sh) | ((uint64_t)ix.text[w + 2] << (64 - sh)) : win;
-      const uint64_t code = win & kmask;
-      if (code != prev) {
-        tab[2 * code] = (uint32_t)i;
-        prev = code;
-      }
-      tab[2 * code + 1] = (uint32_t)i + 1;
+      const uint32_t have = std::min<uint32_t>(k, ix.n - std::min(p, ix.n));
+      uint64_t code = 0;  // first base most significant, short suffixes padded with A
+      for (uint32_t t = 0; t < have; ++t)
+        code |= (uint64_t)((ix.text[(p + t) >> 4] >> (((p + t) & 15) * 2)) & 3u) << (2 * (k - 1 - t));
+      while (next_c <= code) tab[next_c++] = i;
     }
-    base += (size_t)2 << (2 * k);
+    while (next_c <= n_codes) tab[next_c++] = n_rows;
+    base += (size_t)n_codes + 1;
   }
 }
 

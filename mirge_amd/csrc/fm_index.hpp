@@ -17,9 +17,11 @@
 //            32-39 bases back to the start of its N-free segment (clamped 255),
 //            40-47 bases to the end of the segment (clamped 255), 48-63 segment
 //            id (0xFFFF when the library has more segments than that)
-//   ftab     jump tables: for every k-mer (code = sum base(t) << 2t) the BWT interval [lo,hi)
-//            a backward search of it ends in, so the first k steps of a seed search are one
-//            8-byte load.  Up to four tables, largest k first (ftab_ks): an optional big one
+//   ftab     jump tables: T[c] = first BWT row whose suffix starts with k-mer c or a later one
+//            (k-mers numbered lexicographically, first base most significant), so the interval
+//            a backward search of the k-mer ends in is [T[c], T[c+1]) and the first k steps of
+//            a seed search are one 8-byte load; 4^k + 1 words per table.  Up to four tables,
+//            largest k first (ftab_ks): an optional big one
 //            (k = 12..14 = ceil(log4 n)) for whole-read seeds on large libraries, the main one
 //            (k = 8..11), k = 6 and k = 4 for short seed pieces
 //   seg_*    N-free segments of the entries; an alignment must sit in one
@@ -51,7 +53,7 @@ struct FmIndex {
   std::vector<uint32_t> text;
   std::vector<uint64_t> sa;
   uint8_t ftab_ks[4] = {0, 0, 0, 0};  // k of each table, descending; 0 = table absent
-  std::vector<uint32_t> ftab;         // lo, hi per k-mer, the tables of ftab_ks back to back
+  std::vector<uint32_t> ftab;         // 4^k + 1 row boundaries per table, the tables of ftab_ks back to back
   std::vector<uint32_t> seg_start, seg_ref, seg_off, chunk_seg;
 };
 

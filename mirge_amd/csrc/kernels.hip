@@ -87,6 +87,13 @@ struct Lib {
   }
 };
 
+// k bases packed first-base-lowest -> their lexicographic number (first base most significant):
+// reverse the order of the 2-bit groups.
+__device__ __forceinline__ uint32_t lex_code(uint64_t code, uint32_t k) {
+  const uint64_t r = __brevll(code) >> (64u - 2u * k);  // groups reversed, bits inside a group swapped
+  return (uint32_t)(((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1));
+}
+
 // The largest jump table a seed piece of `plen` bases is long enough for: its k (0 = none) and
 // its word offset.
 __device__ __forceinline__ uint32_t pick_table(const JumpTables& t, int32_t plen, uint32_t& word_off) {
@@ -314,9 +321,9 @@ match_kernel(const MatchParams p) {
           if (W > 1 && (j & 31) + (int32_t)tk > 32)
             code |= pick_word<W>(rd, ((uint32_t)j >> 5) + 1) << (64 - (j & 31) * 2);
           code &= (1ull << (2 * tk)) - 1ull;
-          const uint2 iv = *reinterpret_cast<const uint2*>(p.ftab + tab_off + 2 * code);
-          lo = iv.x;
-          hi = iv.y;
+          const uint32_t* tab = p.ftab + tab_off + lex_code(code, tk);
+          lo = tab[0];
+          hi = tab[1];
           ++c_lookups;
         }
         while (j > a && hi > lo && (hi - lo) > p.wstop) {
@@ -527,9 +534,9 @@ __global__ void __launch_bounds__(kCountThreads) count_kernel(const CountParams 
           if (W > 1 && (j & 31) + (int32_t)kk > 32)
             code |= pick_word<W>(rd, ((uint32_t)j >> 5) + 1) << (64 - (j & 31) * 2);
           code &= (1ull << (2 * kk)) - 1ull;
-          const uint2 iv = *reinterpret_cast<const uint2*>(p.ftab + tab_off + 2 * code);
-          lo = iv.x;
-          hi = iv.y;
+          const uint32_t* tab = p.ftab + tab_off + lex_code(code, kk);
+          lo = tab[0];
+          hi = tab[1];
         }
         while (j > a && hi > lo && (hi - lo) > p.wstop) {
           --j;

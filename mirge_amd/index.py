@@ -127,7 +127,7 @@ class FmIndex:
         return dict(
             blocks=arr(v.blocks, inf.n_blocks * 4), super=arr(v.super, inf.n_super * 4),
             text=arr(v.text, inf.text_words),
-            sa=arr(v.sa, inf.n_bases + 1), ftab=arr(v.ftab, sum(2 << (2 * k) for k in inf.ftab_ks if k)),
+            sa=arr(v.sa, inf.n_bases + 1), ftab=arr(v.ftab, sum((1 << (2 * k)) + 1 for k in inf.ftab_ks if k)),
             ftab_ks=[int(k) for k in inf.ftab_ks], seg_start=arr(v.seg_start, inf.n_seg + 1),
             seg_ref=arr(v.seg_ref, max(inf.n_seg, 1))[:inf.n_seg],
             seg_off=arr(v.seg_off, max(inf.n_seg, 1))[:inf.n_seg],

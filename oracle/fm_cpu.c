@@ -23,7 +23,7 @@
 typedef struct {
   const uint32_t *blocks, *super, *text;
   const uint64_t *sa;
-  const uint32_t *ftab; /* k-mer jump tables: lo, hi per k-mer, tables back to back */
+  const uint32_t *ftab; /* k-mer jump tables: 4^k + 1 row boundaries each, tables back to back */
   const uint32_t *seg_start, *seg_ref, *seg_off, *chunk_seg;
   uint32_t n, primary;
   uint8_t ftab_ks[4]; /* k of each table, largest first, 0 = absent */
@@ -95,15 +95,15 @@ static int match_one(const orc_lib *l, const orc_pass *p, const uint64_t *rd, co
         k = kt;
         off = next_off;
       }
-      if (kt) next_off += (size_t)2 << (2 * kt);
+      if (kt) next_off += ((size_t)1 << (2 * kt)) + 1;
     }
     if (k) {
       uint64_t code = 0;
       j = b - k;
-      for (int t = 0; t < k; ++t)
-        code |= ((rd[(j + t) >> 5] >> (((j + t) & 31) * 2)) & 3ull) << (2 * t);
-      lo = l->ftab[off + 2 * code];
-      hi = l->ftab[off + 2 * code + 1];
+      for (int t = 0; t < k; ++t) /* lexicographic number: first base most significant */
+        code |= ((rd[(j + t) >> 5] >> (((j + t) & 31) * 2)) & 3ull) << (2 * (k - 1 - t));
+      lo = l->ftab[off + code];
+      hi = l->ftab[off + code + 1];
       ++*lookups;
     }
     while (j > a && hi > lo && (hi - lo) > wstop) {

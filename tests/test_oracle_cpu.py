@@ -107,29 +107,33 @@ def test_search_shortcuts_do_not_change_results(world):
 
 
 def test_jump_table_equals_backward_search(native_lib):
-    """ftab[k-mer] is the BWT interval a step-by-step backward search ends in."""
+    """[T[c], T[c+1]) is the BWT interval a step-by-step backward search of k-mer c ends in, plus
+    at most the few suffixes shorter than k that the k-mer continues (end of the text)."""
     from mirge_amd.index import FmIndex
     rng = np.random.default_rng(11)
     seqs = ["".join("ACGT"[c] for c in rng.integers(0, 4, int(L))) for L in rng.integers(20, 400, 60)]
     ix = FmIndex.build(["e%d" % i for i in range(len(seqs))], seqs)
     v = ix.view()
-    assert v["ftab_ks"] == [0, 8, 6, 4] and len(v["ftab"]) == 2 * (4 ** 8 + 4 ** 6 + 4 ** 4)
+    assert v["ftab_ks"] == [0, 8, 6, 4] and len(v["ftab"]) == (4 ** 8 + 1) + (4 ** 6 + 1) + (4 ** 4 + 1)
     text = "".join(seqs)
     sa = [int(x) & 0xFFFFFFFF for x in v["sa"]]
+    tail = text[-8:]
     for trial in range(450):
-        k, off = ((8, 0), (6, 2 * 4 ** 8), (4, 2 * (4 ** 8 + 4 ** 6)))[trial % 3]
-        if rng.random() < 0.7:
+        k, off = ((8, 0), (6, 4 ** 8 + 1), (4, 4 ** 8 + 1 + 4 ** 6 + 1))[trial % 3]
+        if trial < 12:
+            kmer = (tail[-(trial % 7 + 1):] + "A" * 8)[:k]      # continues a too-short suffix
+        elif rng.random() < 0.7:
             p = int(rng.integers(0, len(text) - k))
             kmer = text[p:p + k]
         else:
             kmer = "".join("ACGT"[c] for c in rng.integers(0, 4, k))
-        code = sum("ACGT".index(ch) << (2 * t) for t, ch in enumerate(kmer))
-        lo, hi = int(v["ftab"][off + 2 * code]), int(v["ftab"][off + 2 * code + 1])
+        code = sum("ACGT".index(ch) << (2 * (k - 1 - t)) for t, ch in enumerate(kmer))
+        lo, hi = int(v["ftab"][off + code]), int(v["ftab"][off + code + 1])
         rows = [i for i, s in enumerate(sa) if text[s:s + k] == kmer]
-        if rows:
-            assert (lo, hi) == (rows[0], rows[-1] + 1)
-        else:
-            assert lo == hi
+        extra = [i for i in range(lo, hi) if i not in rows]
+        assert set(rows) <= set(range(lo, hi))
+        assert all(len(text) - sa[i] < k for i in extra) and len(extra) < k + 1     # only short suffixes
+    assert int(v["ftab"][0]) == 0 and int(v["ftab"][4 ** 8]) == len(sa)
 
 
 def test_big_jump_table_same_results(native_lib, oracle_lib):
@@ -141,7 +145,7 @@ def test_big_jump_table_same_results(native_lib, oracle_lib):
     names, seqs, reads = big_library_case()
     ix = FmIndex.build(names, seqs)
     v = ix.view()
-    assert v["ftab_ks"] == [12, 11, 6, 4] and len(v["ftab"]) == 2 * (4 ** 12 + 4 ** 11 + 4 ** 6 + 4 ** 4)
+    assert v["ftab_ks"] == [12, 11, 6, 4] and len(v["ftab"]) == 4 ** 12 + 4 ** 11 + 4 ** 6 + 4 ** 4 + 4
     w, l, nm = pack.pack_reads(reads)
     base = model.fm_cascade([v], BIG_PASSES, w, l, nm)
     alt = model.fm_cascade([v], BIG_PASSES, w, l, nm, wstop=2, ftab=True)
