@@ -95,7 +95,7 @@ def main():
         q = bytes(acgt[trimmed[i]])
         want = sum(s.count(q) for s in seqs)   # non-overlapping count: fine for random 20-mers
         assert int(cnt1[i]) == min(want, 255) and int(cnt0[i]) == min(want, 255), (i, want, cnt1[i])
-    hbm = inf.bytes_fm + inf.bytes_sa + sum(2 << (2 * k) for k in inf.ftab_ks if k) * 4 + (inf.text_words * 4)
+    hbm = inf.bytes_fm + inf.bytes_sa + sum((1 << (2 * k)) + 1 for k in inf.ftab_ks if k) * 4 + (inf.text_words * 4)
     print(json.dumps({
         "check": "genome part at scale", "bases": int(inf.n_bases), "ftab_ks": [int(k) for k in inf.ftab_ks],
         "index_build_s": round(t_build, 1), "hbm_bytes": int(hbm),
