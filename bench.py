@@ -37,7 +37,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["cascade", "exact"], default="cascade")
+    ap.add_argument("--workload", choices=["cascade", "exact", "varlen"], default="cascade",
+                    help="cascade = headline (100 M x 22 nt, configs[2]/[3]); exact = configs[1]; varlen = "
+                         "secondary run with lengths U{16..40} (hairpin pass, two-word reads; SURVEY.md 8d)")
     ap.add_argument("--reads-per-gpu", type=int, default=None)
     ap.add_argument("--scale", type=float, default=1.0, help="library size factor (1.0 = SURVEY 8d shapes)")
     ap.add_argument("--samples", type=int, default=1)
@@ -68,8 +70,8 @@ def main():
     from mirge_amd.engine import Engine, ReadSet, MIRGE_PASS_TABLE
     from mirge_amd.index import FmIndex
 
-    n_reads = args.reads_per_gpu or (100_000_000 if args.workload == "cascade" else 10_000_000)
-    keys = list(synth.LIB_KEYS) if args.workload == "cascade" else ["mirna"]
+    n_reads = args.reads_per_gpu or {"cascade": 100_000_000, "exact": 10_000_000, "varlen": 20_000_000}[args.workload]
+    keys = ["mirna"] if args.workload == "exact" else list(synth.LIB_KEYS)
 
     # ---- libraries + indexes (host; identical on every rank) ----
     # index construction (C++, releases the GIL) overlaps with read generation below
@@ -86,16 +88,25 @@ def main():
         for kv in args.mix:
             k, v = kv.split("=")
             mix[k] = float(v)
-    words = np.empty((1, n_reads), dtype=np.uint64)
     chunk = 10_000_000
-    for lo in range(0, n_reads, chunk):
-        m = min(chunk, n_reads - lo)
-        words[0, lo:lo + m] = synth.synth_reads_packed(libs, m, seed=355 + 1000 * rank + lo // chunk, mix=mix)
-    if args.sorted:
-        words[0].sort()
-    lens = np.full(n_reads, 22, dtype=np.uint8)
+    if args.workload == "varlen":
+        words = np.empty((2, n_reads), dtype=np.uint64)
+        lens = np.empty(n_reads, dtype=np.uint8)
+        for lo in range(0, n_reads, chunk):
+            m = min(chunk, n_reads - lo)
+            words[:, lo:lo + m], lens[lo:lo + m] = synth.synth_reads_varlen(
+                libs, m, seed=977 + 1000 * rank + lo // chunk)
+    else:
+        words = np.empty((1, n_reads), dtype=np.uint64)
+        for lo in range(0, n_reads, chunk):
+            m = min(chunk, n_reads - lo)
+            words[0, lo:lo + m] = synth.synth_reads_packed(libs, m, seed=355 + 1000 * rank + lo // chunk, mix=mix)
+        if args.sorted:
+            words[0].sort()
+        lens = np.full(n_reads, 22, dtype=np.uint8)
     quant = synth.synth_quant(n_reads, args.samples, seed=355 + rank)
-    log(rank, "reads: %d x 22 nt generated+packed in %.1f s" % (n_reads, time.time() - t0))
+    log(rank, "reads: %d (%s) generated+packed in %.1f s" %
+        (n_reads, "16..40 nt" if args.workload == "varlen" else "22 nt", time.time() - t0))
     index = {k: f.result() for k, f in futures.items()}
     pool.shutdown()
     log(rank, "libraries + indexes (%s bp) ready after %.1f s" %
@@ -111,7 +122,7 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         eng.set_option(k, int(v))
-    if args.workload == "cascade":
+    if args.workload in ("cascade", "varlen"):
         passes = eng.mirge_passes()
         table = MIRGE_PASS_TABLE[:9]
         canon, iso = 0, 8
@@ -179,8 +190,8 @@ def main():
     groups = {}
     for i, s in enumerate(st):
         # <W, occ blocks in LDS, text in LDS, stratum-first (the 2-mismatch policy)>
-        name = "mrg::match_kernel<1, %s, %s>" % (
-            {0: "false, false", 1: "true, false", 2: "true, true", 3: "false, true"}[s["lds_mode"]],
+        name = "mrg::match_kernel<%d, %s, %s>" % (
+            rs.W, {0: "false, false", 1: "true, false", 2: "true, true", 3: "false, true"}[s["lds_mode"]],
             "true" if table[i][4] == 2 else "false")
         g = groups.setdefault(name, dict(ms=0.0, bytes=0.0, sbytes=0.0, launches=0, passes=[]))
         g["ms"] += per_pass_ms[i]
@@ -214,7 +225,7 @@ def main():
         passes_report.append(dict(
             lib=table[i][0], ms=round(float(per_pass_ms[i]), 4), processed=s["processed"],
             aligned=s["aligned"], steps=s["steps"], candidates=s["candidates"], lookups=s["lookups"],
-            lds_bytes=s["lds_bytes"], kernel="match_kernel<1,%s%s>" % (["hbm", "blocks", "blocks+text", "text"][s["lds_mode"]],
+            lds_bytes=s["lds_bytes"], kernel="match_kernel<%d,%s%s>" % (rs.W, ["hbm", "blocks", "blocks+text", "text"][s["lds_mode"]],
                                              ",strata" if table[i][4] == 2 else ""),
             alg_gbs=round(alg_bytes(s) / max(per_pass_ms[i], 1e-9) / 1e6, 1)))
 
@@ -255,12 +266,15 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u64/u32 (2-bit packed bases, integer rank/popcount)",
-        "data": "synthetic (seeded libraries + 22 nt reads, SURVEY.md 8d)",
+        "data": "synthetic (seeded libraries + %s reads, SURVEY.md 8d)" %
+                ("16..40 nt" if args.workload == "varlen" else "22 nt"),
         "config": {
-            "workload": ("100 M x 22 nt reads per GPU, full 9-pass cascade over 8 synthetic human-sized "
-                         "libraries + isomiR/count tally (BASELINE configs[2]/[3])"
-                         if args.workload == "cascade" else
-                         "10 M x 22 nt unique reads per GPU, exact match vs miRNA library (BASELINE configs[1])"),
+            "workload": {
+                "cascade": "100 M x 22 nt reads per GPU, full 9-pass cascade over 8 synthetic human-sized "
+                           "libraries + isomiR/count tally (BASELINE configs[2]/[3])",
+                "exact": "10 M x 22 nt unique reads per GPU, exact match vs miRNA library (BASELINE configs[1])",
+                "varlen": "SECONDARY (not the headline): reads of 16..40 nt, two words per read, full 9-pass "
+                          "cascade incl. the hairpin pass (SURVEY.md 8d)"}[args.workload],
             "reads_per_gpu": n_reads, "libraries_scale": args.scale, "samples": args.samples,
             "parallelism": "read shards x%d, one RCCL all-reduce of the count vector" % world,
         },

@@ -285,6 +285,83 @@ def synth_reads_packed(libs, n, seed=355, L=22, mix=None, zipf_s=1.1):
     return out[rng.permutation(n)]
 
 
+VARLEN_MIX = dict(hairpin=0.35, mirna=0.25, snorna=0.1, ncrna_others=0.1, mrna=0.1, pre_trna_t=0.05, random=0.05)
+
+
+def synth_reads_varlen(libs, n, seed=977, min_len=16, max_len=40, mix=None):
+    """Variable-length reads ("a secondary run with lengths U{16..40}" so that the
+    hairpin pass, the length windows and two-word reads are exercised; not the headline workload).
+    Substrings of library entries with 0-1 substitution, poly-T trailers, random reads.
+    Returns (words uint64 [2, n], lens uint8 [n])."""
+    rng = np.random.default_rng(seed)
+    mix = dict(VARLEN_MIX if mix is None else mix)
+    keys = list(mix)
+    frac = np.array([mix[k] for k in keys], dtype=np.float64)
+    counts = np.floor(frac / frac.sum() * n).astype(np.int64)
+    counts[0] += n - counts.sum()
+    words = np.zeros((2, n), dtype=np.uint64)
+    lens = rng.integers(min_len, max_len + 1, n).astype(np.int64)
+    at = 0
+    for k, m in zip(keys, counts):
+        m = int(m)
+        if m == 0:
+            continue
+        sl = slice(at, at + m)
+        L = lens[sl]
+        if k == "random":
+            codes_src, base = None, None
+            w0 = rng.integers(0, 1 << 63, m, dtype=np.uint64) << np.uint64(1) | rng.integers(0, 2, m, dtype=np.uint64)
+            w1 = rng.integers(0, 1 << 32, m, dtype=np.uint64)
+        else:
+            key = "pre_trna" if k == "pre_trna_t" else k
+            codes, starts = libs.codes[key]
+            el = np.diff(starts)
+            tail = rng.integers(3, 7, m) if k == "pre_trna_t" else np.zeros(m, dtype=np.int64)
+            body = L - tail
+            if k == "pre_trna_t":
+                body = np.clip(body, 11, None)
+                L = body + tail
+                lens[sl] = L
+            ent = np.searchsorted(starts, rng.integers(0, starts[-1], m), side="right") - 1
+            bad = el[ent] < body
+            if bad.any():
+                # re-draw among entries long enough for the longest request
+                ok_ent = np.nonzero(el >= body.max())[0]
+                if ok_ent.size == 0:
+                    ok_ent = np.array([int(np.argmax(el))])
+                    body = np.minimum(body, el.max())
+                    L = body + tail
+                    lens[sl] = L
+                ent[bad] = ok_ent[rng.integers(0, ok_ent.size, int(bad.sum()))]
+            off = (rng.random(m) * (el[ent] - body + 1)).astype(np.int64)
+            base = starts[ent] + off
+            pad = np.concatenate([codes, np.zeros(64, dtype=np.uint8)])
+            w0 = np.zeros(m, dtype=np.uint64)
+            w1 = np.zeros(m, dtype=np.uint64)
+            for i in range(int(L.max())):
+                c = np.where(i < body, pad[base + i], 3).astype(np.uint64)   # beyond the body: the T tail
+                c = np.where(i < L, c, 0).astype(np.uint64)
+                if i < 32:
+                    w0 |= c << np.uint64(2 * i)
+                else:
+                    w1 |= c << np.uint64(2 * (i - 32))
+            sub = np.nonzero(rng.random(m) < 0.3)[0]
+            col = (rng.random(sub.size) * body[sub]).astype(np.int64)
+            delta = rng.integers(1, 4, sub.size).astype(np.uint64)
+            lo = col < 32
+            w0[sub[lo]] ^= delta[lo] << (2 * col[lo]).astype(np.uint64)
+            w1[sub[~lo]] ^= delta[~lo] << (2 * (col[~lo] - 32)).astype(np.uint64)
+        # clear everything beyond each read's length
+        Lc = lens[sl]
+        m0 = np.where(Lc >= 32, np.uint64(0xFFFFFFFFFFFFFFFF), (np.uint64(1) << (2 * np.minimum(Lc, 31)).astype(np.uint64)) - np.uint64(1))
+        m1 = np.where(Lc > 32, (np.uint64(1) << (2 * np.clip(Lc - 32, 0, 31)).astype(np.uint64)) - np.uint64(1), np.uint64(0))
+        words[0, sl] = w0 & m0
+        words[1, sl] = w1 & m1
+        at += m
+    perm = rng.permutation(n)
+    return np.ascontiguousarray(words[:, perm]), lens[perm].astype(np.uint8)
+
+
 def synth_reads(libs, n, seed=355, L=22, mix=None, zipf_s=1.1):
     """Same reads as uint8 codes [n, L] (small inputs: tests, smoke)."""
     w = synth_reads_packed(libs, n, seed=seed, L=L, mix=mix, zipf_s=zipf_s)
