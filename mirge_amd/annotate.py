@@ -34,13 +34,18 @@ CATEGORY_KEYS = ["mirnaReads", "hairpinReads", "maturetrnaReads", "pretrnaReads"
 
 
 def _ensure_libraries(engine, files):
-    """files: {library key: index prefix}.  Loads/builds and uploads each once."""
-    for key, prefix in files.items():
-        tag = "%s@%s" % (key, prefix)
-        if getattr(engine, "_loaded_tags", {}).get(key) == tag:
-            continue
-        engine.add_library(key, FmIndex.open_prefix(prefix))
-        engine.__dict__.setdefault("_loaded_tags", {})[key] = tag
+    """files: {library key: index prefix}.  Loads/builds (concurrently: the native calls release
+    the GIL) and uploads each once."""
+    tags = engine.__dict__.setdefault("_loaded_tags", {})
+    todo = [(key, prefix) for key, prefix in files.items() if tags.get(key) != "%s@%s" % (key, prefix)]
+    if not todo:
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(todo)) as pool:
+        opened = list(pool.map(lambda kp: FmIndex.open_prefix(kp[1]), todo))
+    for (key, prefix), ix in zip(todo, opened):
+        engine.add_library(key, ix)
+        tags[key] = "%s@%s" % (key, prefix)
 
 
 def runAnnotationPipeline(engine, seqDic, numCPU, phred64, annotNameList, outputdir, logDic,

@@ -204,9 +204,9 @@ def annotate_main(args):
         q["cpuTime-uniq"] = (time.time() - t1) / S
     seqs = pack.unpack_reads(col["words"], col["lens"], col["nmask"])
     spike = bool(args.spikeIn)
-    seq_dic = {s: {"quant": [int(x) for x in col["quant"][i]],
-                   "annot": [0] + [""] * (10 if spike else 9), "length": len(s)}
-               for i, s in enumerate(seqs)}
+    width = 10 if spike else 9
+    seq_dic = {s: {"quant": q, "annot": [0] + [""] * width, "length": len(s)}
+               for s, q in zip(seqs, col["quant"].tolist())}
     read_len_dic = col["length_hist"]
     if args.trimmed_collapsed_fa:  # QNT:26-44
         for i, name in enumerate(sample_list):

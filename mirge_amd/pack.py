@@ -77,18 +77,24 @@ def pack_reads(seqs, W=None):
 
 
 def unpack_reads(words, lens, nmask=None):
-    """Inverse of pack_reads (for reports and tests)."""
+    """Inverse of pack_reads (reports, tests, the dict-shaped host path): vectorised over reads."""
     words = np.asarray(words, dtype=np.uint64)
     W, n = words.shape
-    out = []
-    for r in range(n):
-        L = int(lens[r])
-        chars = []
-        for i in range(L):
-            w, sh = i >> 5, (i & 31) * 2
-            if nmask is not None and (int(nmask[w, r]) >> sh) & 1:
-                chars.append("N")
-            else:
-                chars.append("ACGT"[(int(words[w, r]) >> sh) & 3])
-        out.append("".join(chars))
-    return out
+    lens = np.asarray(lens).astype(np.int64)
+    if n == 0:
+        return []
+    width = int(lens.max()) if n else 0
+    if width == 0:
+        return [""] * n
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    chars = np.empty((n, width), dtype=np.uint8)
+    for w in range((width + 31) // 32):
+        nb = min(32, width - 32 * w)
+        sh = (2 * np.arange(nb)).astype(np.uint64)
+        grid = letters[((words[w][:, None] >> sh[None, :]) & np.uint64(3)).astype(np.uint8)]
+        if nmask is not None:
+            isn = ((np.asarray(nmask, dtype=np.uint64)[w][:, None] >> sh[None, :]) & np.uint64(1)).astype(bool)
+            grid[isn] = ord("N")
+        chars[:, 32 * w:32 * w + nb] = grid
+    blob = chars.tobytes()
+    return [blob[r * width:r * width + L].decode("ascii") for r, L in enumerate(lens.tolist())]
