@@ -109,6 +109,9 @@ typedef struct mrg_index_view {
   const uint32_t *seg_ref;   /* n_seg */
   const uint32_t *seg_off;   /* n_seg */
   const uint32_t *chunk_seg; /* (n_bases >> 5) + 2 */
+  const uint32_t *ctx;       /* NULL, or for libraries of >= 2^20 bases one word per suffix-array
+                              * row: bits 0-15 the 8 bases left of the row's position (the nearest
+                              * in the top two), bits 16-31 the bases 8..15 after it */
 } mrg_index_view;
 int mrg_index_get_view(const mrg_index *ix, mrg_index_view *view);
 
@@ -126,7 +129,9 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * stops narrowing and hands the occurrences to verification (0 = narrow to the
  * end of the piece); "ftab" = 1/0 use the k-mer jump table for the first k steps
  * of a seed search; "wide_rows" = seed intervals wider than this many rows are
- * verified cooperatively by the whole wave (default 256). */
+ * verified cooperatively by the whole wave (default 256); "ctx_wide_rows" = the same
+ * threshold for libraries of >= 2^20 bases, whose cooperative path drops most rows by their
+ * stored text context (default 32). */
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);
 int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,
                         char *arch, uint32_t arch_cap);

@@ -48,6 +48,7 @@ struct DevLib {
   uint32_t *blocks = nullptr, *super = nullptr, *text = nullptr, *seg_start = nullptr,
            *seg_ref = nullptr, *seg_off = nullptr, *chunk_seg = nullptr;
   uint64_t* sa = nullptr;
+  uint32_t* ctx = nullptr;
   uint32_t* ftab = nullptr;
   mrg::JumpTables tabs = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   uint32_t n = 0, nblk = 0, nsup = 0, primary = 0, text_words = 0, n_seg = 0, n_ref = 0;
@@ -78,6 +79,7 @@ struct mrg_ctx {
   int64_t use_ftab = 1;
   int64_t force_lds_mode = -1;
   int64_t wide_rows = 256;
+  int64_t ctx_wide_rows = 32;
   int64_t prefer_two_blocks = 1;
   std::vector<DevLib> libs;
   // last run
@@ -199,6 +201,7 @@ int mrg_index_get_view(const mrg_index* h, mrg_index_view* v) {
   v->text = ix.text.data();
   v->sa = ix.sa.data();
   v->ftab = ix.ftab.data();
+  v->ctx = ix.ctx.empty() ? nullptr : ix.ctx.data();
   v->seg_start = ix.seg_start.data();
   v->seg_ref = ix.seg_ref.data();
   v->seg_off = ix.seg_off.data();
@@ -243,6 +246,7 @@ void mrg_ctx_destroy(mrg_ctx* ctx) {
     (void)hipFree(l.text);
     (void)hipFree(l.sa);
     (void)hipFree(l.ftab);
+    (void)hipFree(l.ctx);
     (void)hipFree(l.seg_start);
     (void)hipFree(l.seg_ref);
     (void)hipFree(l.seg_off);
@@ -288,6 +292,7 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
     }
   }
   if ((rc = upload(&l.ftab, ix.ftab))) return rc;
+  if (!ix.ctx.empty() && (rc = upload(&l.ctx, ix.ctx))) return rc;
   if ((rc = upload(&l.seg_start, ix.seg_start))) return rc;
   if ((rc = upload(&l.seg_ref, ix.seg_ref))) return rc;
   if ((rc = upload(&l.seg_off, ix.seg_off))) return rc;
@@ -306,6 +311,9 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "wstop") {
     if (value < 0) return fail(MRG_ERR_ARG, "wstop must be >= 0");
     ctx->wstop = value;
+  } else if (k == "ctx_wide_rows") {
+    if (value < 1) return fail(MRG_ERR_ARG, "ctx_wide_rows must be >= 1");
+    ctx->ctx_wide_rows = value;
   } else if (k == "wide_rows") {
     if (value < 1) return fail(MRG_ERR_ARG, "wide_rows must be >= 1");
     ctx->wide_rows = value;
@@ -399,6 +407,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     p.super = l.super;
     p.text = l.text;
     p.sa = l.sa;
+    p.ctx = l.ctx;
     p.ftab = l.ftab;
     p.tabs = l.tabs;
     if (!ctx->use_ftab) p.tabs.k[0] = 0u;
@@ -437,7 +446,9 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     p.poly_t = c.poly_t;
     p.pass_index = (int32_t)i;
     p.wstop = (uint32_t)ctx->wstop;
-    p.wide_rows = (uint32_t)ctx->wide_rows;
+    // a large library's wide intervals are pre-filtered by row context in the cooperative path:
+    // send them there early (lane-serial verification of 100+ rows is what hurts short reads)
+    p.wide_rows = l.ctx ? (uint32_t)std::min<int64_t>(ctx->wide_rows, ctx->ctx_wide_rows) : (uint32_t)ctx->wide_rows;
 
     // residency decision.  The superblock table (16 B per 65536 bp) and the segment
     // prefix always sit in LDS.  With the jump table most seed searches need few LF
@@ -583,6 +594,7 @@ int fill_count_params(mrg_ctx* ctx, const char* who, const uint64_t* d_reads, ui
   p->super = l.super;
   p->text = l.text;
   p->sa = l.sa;
+  p->ctx = l.ctx;
   p->ftab = l.ftab;
   p->tabs = l.tabs;
   if (!ctx->use_ftab) p->tabs.k[0] = 0u;

@@ -282,6 +282,22 @@ void build_jump_tables(FmIndex& ix) {
   }
 }
 
+void build_row_context(FmIndex& ix) {
+  ix.ctx.clear();
+  if (ix.n < (1u << 20)) return;
+  auto base_at = [&](uint64_t q) -> uint32_t {
+    return q < ix.n ? (ix.text[q >> 4] >> ((q & 15) * 2)) & 3u : 0u;
+  };
+  ix.ctx.resize(ix.sa.size());
+  for (size_t i = 0; i < ix.sa.size(); ++i) {
+    const uint32_t p = (uint32_t)ix.sa[i];
+    uint32_t left = 0, right = 0;
+    for (uint32_t d = 1; d <= 8 && d <= p; ++d) left |= base_at(p - d) << (16 - 2 * d);
+    for (uint32_t d = 0; d < 8; ++d) right |= base_at((uint64_t)p + 8 + d) << (2 * d);
+    ix.ctx[i] = left | right << 16;
+  }
+}
+
 void build_index(const std::vector<std::string>& names,
                  const std::vector<std::string>& seqs, FmIndex& ix) {
   if (names.size() != seqs.size()) throw std::runtime_error("names/seqs size mismatch");
@@ -358,6 +374,7 @@ void build_index(const std::vector<std::string>& names,
     ix.sa[i] = row;
   }
   build_jump_tables(ix);
+  build_row_context(ix);
 }
 
 std::string entry_sequence(const FmIndex& ix, uint32_t r) {
@@ -459,6 +476,7 @@ void load_index(const std::string& path, FmIndex& ix) {
       ix.text.size() < (size_t)(ix.n >> 4) + 3)
     throw std::runtime_error("index file inconsistent");
   build_jump_tables(ix);
+  build_row_context(ix);
 }
 
 }  // namespace mrg

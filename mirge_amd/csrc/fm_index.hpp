@@ -52,6 +52,13 @@ struct FmIndex {
   std::vector<uint32_t> super;  // 4 per superblock
   std::vector<uint32_t> text;
   std::vector<uint64_t> sa;
+  // Libraries of >= 2^20 bases (their text cannot be staged in LDS) also get one 32-bit word of
+  // text context per suffix-array row: bits 0-15 the 8 bases left of the row's position
+  // (text[p-1] in the top two), bits 16-31 the 8 bases text[p+8 .. p+16) (text[p+8] in the low
+  // two).  A short seed piece matches hundreds of rows of such a library; with the context a
+  // candidate whose visible bases already show more mismatches than the pass allows is dropped
+  // without touching its suffix-array row or the text.  Derived data, rebuilt on load.
+  std::vector<uint32_t> ctx;
   uint8_t ftab_ks[4] = {0, 0, 0, 0};  // k of each table, descending; 0 = table absent
   std::vector<uint32_t> ftab;         // 4^k + 1 row boundaries per table, the tables of ftab_ks back to back
   std::vector<uint32_t> seg_start, seg_ref, seg_off, chunk_seg;
@@ -63,6 +70,7 @@ void build_index(const std::vector<std::string>& names,
 void read_fasta(const std::string& path, std::vector<std::string>& names,
                 std::vector<std::string>& seqs);
 void build_jump_tables(FmIndex& ix);  // from sa + text
+void build_row_context(FmIndex& ix);  // from sa + text
 void save_index(const FmIndex& ix, const std::string& path);
 void load_index(const std::string& path, FmIndex& ix);
 std::string entry_sequence(const FmIndex& ix, uint32_t i);

@@ -131,6 +131,48 @@ __device__ __forceinline__ void shift_out_5p(uint64_t (&rd)[W], uint32_t t) {
   rd[W - 1] >>= sh;
 }
 
+// 2c bits of the read starting at base `at` (c <= 8).
+template <int W>
+__device__ __forceinline__ uint32_t read_bits(const uint64_t (&rd)[W], uint32_t at, uint32_t c) {
+  uint64_t v = pick_word<W>(rd, at >> 5) >> ((at & 31u) * 2u);
+  if (W > 1 && (at & 31u) + c > 32u) v |= pick_word<W>(rd, (at >> 5) + 1u) << (64u - (at & 31u) * 2u);
+  return (uint32_t)v & ((1u << (2u * c)) - 1u);
+}
+
+// Row context (FmIndex::ctx) of the candidates of one seed interval: all of them have `need_before`
+// read bases left of the row's position and `need_after` from it on, so what the read expects in
+// the context word -- the <= 8 bases before the position (bits 0-15, nearest in the top two) and
+// the bases 8..15 after it (bits 16-31) -- is computed once: (want, mask).  The mismatches a row's
+// word then shows are a lower bound of the alignment's (a read N counts as a match, bases across
+// a segment end only occur in alignments that are invalid anyway): "more than the pass allows"
+// is final.
+template <int W>
+__device__ __forceinline__ uint2 context_probe(const uint64_t (&rd)[W], uint32_t need_before, uint32_t need_after) {
+  uint32_t want = 0, mask = 0;
+  const uint32_t c = min(need_before, 8u);
+  if (c) {
+    want = read_bits<W>(rd, need_before - c, c) << (16u - 2u * c);
+    mask = ((1u << (2u * c)) - 1u) << (16u - 2u * c);
+  }
+  if (need_after > 8u) {
+    const uint32_t c2 = min(need_after, 16u) - 8u;
+    want |= read_bits<W>(rd, need_before + 8u, c2) << 16;
+    mask |= ((1u << (2u * c2)) - 1u) << 16;
+  }
+  return make_uint2(want, mask);
+}
+
+__device__ __forceinline__ uint32_t context_mismatches(uint32_t ctx, uint2 probe) {
+  const uint32_t x = (ctx ^ probe.x) & probe.y;
+  return (uint32_t)__popc((x | (x >> 1)) & 0x55555555u);
+}
+
+// count_kernel pre-filters intervals at least this wide with the row context (narrower ones are
+// cheaper to verify directly: the context word would be one more load per row).  match_kernel
+// uses the context in its wave-cooperative path, which large libraries enter from
+// MatchParams::wide_rows = 32 rows on.
+constexpr uint32_t kCtxMinRows = 8u;
+
 // One suffix-array row as a candidate alignment of a read whose seed search stopped with
 // `need_before` read bases left of the row's text position and `need_after` from it on.
 // Updates (best, best_seg, best_before) when the alignment is valid and better.
@@ -174,7 +216,8 @@ __device__ __forceinline__ void verify_row(const LibT& lib, const MatchParams& p
 
 // STRATA: the 2-mismatch policy (three seed pieces) with its stratum-first search; a separate
 // instantiation so that the other passes keep the plain piece loop.
-template <int W, bool LDSI, bool LDST, bool STRATA>
+// CTX: the library has a row-context array (>= 2^20 bases; never together with LDST).
+template <int W, bool LDSI, bool LDST, bool STRATA, bool CTX>
 __global__ void __launch_bounds__(MatchBlock<LDSI>::kThreads, (W == 1 ? 8 : 4))
 match_kernel(const MatchParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -377,8 +420,11 @@ match_kernel(const MatchParams p) {
           const uint64_t helpers = __ballot(true);
           const uint32_t n_help = (uint32_t)__popcll(helpers);
           const uint32_t my_rank = (uint32_t)__popcll(helpers & ((1ull << lane) - 1ull));
-          for (uint32_t i = o_lo + my_rank; i < o_hi; i += n_help)
+          const uint2 probe = CTX ? context_probe<W>(o_rd, o_nb, o_na) : make_uint2(0u, 0u);
+          for (uint32_t i = o_lo + my_rank; i < o_hi; i += n_help) {
+            if (CTX && (int32_t)context_mismatches(p.ctx[i], probe) > p.max_mm_total) continue;
             verify_row<W>(lib, p, p.sa[i], o_rd, o_nm, o_L, o_nb, o_na, w_best, w_seg, w_before);
+          }
           unsigned long long* slot = reinterpret_cast<unsigned long long*>(wave_slots) + 2 * wave;
           if ((int)lane == src) {
             slot[0] = ~0ull;
@@ -556,7 +602,10 @@ __global__ void __launch_bounds__(kCountThreads) count_kernel(const CountParams 
           hi = lo + p.max_rows;
         }
         const uint32_t need_before = (uint32_t)j, need_after = (uint32_t)(L - j);
+        const bool prefilter = p.ctx && hi - lo >= kCtxMinRows;
+        const uint2 probe = prefilter ? context_probe<W>(rd, need_before, need_after) : make_uint2(0u, 0u);
         for (uint32_t i = lo; i < hi; ++i) {
+          if (prefilter && (int32_t)context_mismatches(p.ctx[i], probe) > p.max_mm_total) continue;
           const uint64_t row = p.sa[i];
           const uint32_t before = (uint32_t)(row >> 32) & 255u, after = (uint32_t)(row >> 40) & 255u;
           if ((need_before > before) | (need_after > after)) continue;
@@ -684,10 +733,10 @@ __global__ void export_pass_counts_kernel(const uint64_t* stats, uint32_t n_pass
 // ---------------------------------------------------------------------------
 // Launch helpers (host)
 // ---------------------------------------------------------------------------
-template <int W, bool LDSI, bool LDST, bool STRATA>
-static hipError_t launch_match_s(const MatchParams& p, uint32_t grid, uint32_t lds_bytes,
+template <int W, bool LDSI, bool LDST, bool STRATA, bool CTX>
+static hipError_t launch_match_x(const MatchParams& p, uint32_t grid, uint32_t lds_bytes,
                                  hipStream_t stream) {
-  auto kern = match_kernel<W, LDSI, LDST, STRATA>;
+  auto kern = match_kernel<W, LDSI, LDST, STRATA, CTX>;
   if (lds_bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -696,6 +745,14 @@ static hipError_t launch_match_s(const MatchParams& p, uint32_t grid, uint32_t l
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(MatchBlock<LDSI>::kThreads), lds_bytes, stream, p);
   return hipGetLastError();
+}
+
+template <int W, bool LDSI, bool LDST, bool STRATA>
+static hipError_t launch_match_s(const MatchParams& p, uint32_t grid, uint32_t lds_bytes,
+                                 hipStream_t stream) {
+  // a library with a row-context array is too large for its text to be staged in LDS
+  if (p.ctx && !LDST) return launch_match_x<W, LDSI, false, STRATA, true>(p, grid, lds_bytes, stream);
+  return launch_match_x<W, LDSI, LDST, STRATA, false>(p, grid, lds_bytes, stream);
 }
 
 template <int W, bool LDSI, bool LDST>

@@ -32,6 +32,7 @@ struct MatchParams {
   const uint32_t* super;   // 16 B per 65536 BWT symbols
   const uint32_t* text;
   const uint64_t* sa;      // 8 B rows: pos | before<<32 | after<<40 | seg<<48
+  const uint32_t* ctx;     // per-row text context of a large library (null otherwise)
   const uint32_t* ftab;    // k-mer jump tables: lo, hi per k-mer
   JumpTables tabs;
   const uint32_t* seg_start;
@@ -71,6 +72,7 @@ struct CountParams {
   const uint32_t* super;
   const uint32_t* text;
   const uint64_t* sa;
+  const uint32_t* ctx;
   const uint32_t* ftab;
   JumpTables tabs;
   uint32_t n, nsup, primary;

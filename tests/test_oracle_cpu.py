@@ -153,3 +153,31 @@ def test_big_jump_table_same_results(native_lib, oracle_lib):
         assert np.array_equal(base[k], alt[k]), k
     assert all(int(alt["stats"][i][1]) > 100 for i in range(3))
     assert int(alt["stats"][:, 2].sum()) < int(base["stats"][:, 2].sum()) // 4
+    # context rows (>= 2^20 bases): the port against the exhaustive scan on the reads that touch
+    # entry boundaries and the planted N
+    from tests.util import special_reads_of_big_case
+    # the row-context array of a library of >= 2^20 bases: 8 bases left of each row's position and
+    # the bases 8..15 after it, as stored text (entries back to back, N-free segments only)
+    text_codes = np.concatenate([np.frombuffer(s.replace("N", "").encode(), dtype=np.uint8) for s in seqs])
+    lut = np.zeros(256, dtype=np.uint32)
+    lut[ord("C")], lut[ord("G")], lut[ord("T")] = 1, 2, 3
+    tc = np.concatenate([np.zeros(8, np.uint32), lut[text_codes], np.zeros(24, np.uint32)])
+    pos = (v["sa"] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    sample = np.random.default_rng(1).integers(0, len(pos), 5000)
+    for i in sample:
+        p0 = int(pos[i]) + 8                       # index into the padded array
+        left = sum(int(tc[p0 - d]) << (16 - 2 * d) for d in range(1, 9))
+        right = sum(int(tc[p0 + 8 + d]) << (2 * d) for d in range(8))
+        assert int(v["ctx"][i]) == (left | right << 16), i
+    olib = model.Library(names, seqs)
+    special = special_reads_of_big_case(reads)
+    sw, sl, sn = pack.pack_reads(special, 2)
+    for pol in BIG_PASSES:
+        got = model.fm_cascade([v], [dict(pol, min_len=0, max_len=255)], sw, sl, sn, wstop=2, ftab=True)
+        ref, pos, mm = model.align_batch(olib, special, pol["seed_len"], pol["max_mm_seed"], pol["max_mm_total"])
+        want_pass = np.where(ref >= 0, 0, -1)
+        assert np.array_equal(got["pass_id"], want_pass)
+        hit = ref >= 0
+        assert np.array_equal(got["ref_id"][hit], ref[hit]) and np.array_equal(got["pos"][hit], pos[hit])
+        assert np.array_equal(got["mm"][hit], mm[hit])
+    assert hit.sum() > 20 and (~hit).sum() > 3

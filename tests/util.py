@@ -68,7 +68,25 @@ def big_library_case(seed=9, n_entries=12, entry_len=400_000, n_reads=6000):
             r[int(rng.integers(0, L))] = "ACGT"[int(rng.integers(0, 4))]
         reads.append("".join(r))
     reads += ["".join("ACGT"[c] for c in rng.integers(0, 4, 22)) for _ in range(500)]
+    # an N inside two entries (three N-free segments each side) and reads that would only align
+    # across an entry boundary, across the N, right at an entry's first / last bases
+    for e in (2, 7):
+        s = seqs[e]
+        seqs[e] = s[:123_457] + "N" + s[123_458:]
+    for e in (2, 7):
+        s = seqs[e]
+        for L in (18, 22, 30):
+            reads += [s[123_457 - L + 4:123_457 + 4].replace("N", "A"), s[123_458:123_458 + L],
+                      s[123_457 - L:123_457], s[:L], s[-L:], s[1:L + 1], s[-L - 1:-1]]
+    for e in range(3):
+        for L in (18, 22, 30):
+            reads.append(seqs[e][-(L // 2):] + seqs[e + 1][:L - L // 2])
     return names, seqs, reads
+
+
+def special_reads_of_big_case(reads):
+    """The boundary reads appended last by big_library_case."""
+    return reads[-(2 * 3 * 7 + 3 * 3):]
 
 
 BIG_PASSES = [dict(lib=0, seed_len=28, max_mm_seed=0, max_mm_total=2, min_len=0, max_len=25),     # -n 0: k = 12
