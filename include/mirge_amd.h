@@ -129,7 +129,7 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * stops narrowing and hands the occurrences to verification (0 = narrow to the
  * end of the piece); "ftab" = 1/0 use the k-mer jump table for the first k steps
  * of a seed search; "wide_rows" = seed intervals wider than this many rows are
- * verified cooperatively by the whole wave (default 256); "ctx_wide_rows" = the same
+ * verified cooperatively by the whole wave (default 64); "ctx_wide_rows" = the same
  * threshold for libraries of >= 2^20 bases, whose cooperative path drops most rows by their
  * stored text context (default 32). */
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);

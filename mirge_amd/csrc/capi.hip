@@ -78,7 +78,7 @@ struct mrg_ctx {
   int64_t wstop = 2;
   int64_t use_ftab = 1;
   int64_t force_lds_mode = -1;
-  int64_t wide_rows = 256;
+  int64_t wide_rows = 64;
   int64_t ctx_wide_rows = 32;
   int64_t prefer_two_blocks = 1;
   std::vector<DevLib> libs;

@@ -79,7 +79,7 @@ def test_search_shortcuts_same_results_fewer_steps(engine, world):
         assert sum(s["steps"] for s in res.stats) < int(base["stats"][:, 2].sum())
     engine.set_option("wstop", 2)
     engine.set_option("ftab", 1)
-    engine.set_option("wide_rows", 256)
+    engine.set_option("wide_rows", 64)
 
 
 def test_cascade_matches_exhaustive_scan(engine, world):
