@@ -240,7 +240,8 @@ def main():
         pd = [dict(lib=keys.index(k), min_len=a, max_len=b, seed_len=s_, max_mm_seed=ms, max_mm_total=mt,
                    trim5=t5, trim3=t3, poly_t=pt) for (k, a, b, s_, ms, mt, t5, t3, pt) in table]
         views = [index[k].view() for k in keys]
-        wst = 2 if args.wstop is None else args.wstop
+        from mirge_amd.engine import DEFAULT_WSTOP
+        wst = DEFAULT_WSTOP if args.wstop is None else args.wstop
         t1 = time.perf_counter()
         ref = model.fm_cascade(views, pd, words[:, :m], lens[:m], None, wstop=wst, threads=cores,
                                ftab=not args.no_ftab)

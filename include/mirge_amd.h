@@ -127,7 +127,7 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * workgroup may spend on a staged library (occ blocks + packed text; 0 serves
  * every library from HBM/L2); "wstop" = interval width at which a seed search
  * stops narrowing and hands the occurrences to verification (0 = narrow to the
- * end of the piece); "ftab" = 1/0 use the k-mer jump table for the first k steps
+ * end of the piece; default 8); "ftab" = 1/0 use the k-mer jump table for the first k steps
  * of a seed search; "wide_rows" = seed intervals wider than this many rows are
  * verified cooperatively by the whole wave (default 64); "ctx_wide_rows" = the same
  * threshold for libraries of >= 2^20 bases, whose cooperative path drops most rows by their

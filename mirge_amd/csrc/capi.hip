@@ -75,7 +75,7 @@ struct mrg_ctx {
   uint64_t hbm_bytes = 0;
   std::string arch;
   int64_t lds_budget = 160 * 1024;
-  int64_t wstop = 2;
+  int64_t wstop = 8;
   int64_t use_ftab = 1;
   int64_t force_lds_mode = -1;
   int64_t wide_rows = 64;

@@ -16,6 +16,7 @@ from . import _native
 from ._native import PassCfg, PassStats, check
 
 V_MODE_SEED = 1024  # "-v": the seed region is the whole read
+DEFAULT_WSTOP = 8    # the context's default "wstop" option (mrg_ctx_set_option)
 
 # The nine (ten) bowtie command lines of runAnnotationPipeline.py:577-599 / :688:
 # (library key, min_len, max_len, seed_len, max_mm_seed, max_mm_total, trim5, trim3, poly_t)

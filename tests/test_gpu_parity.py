@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import cascade, model
+from mirge_amd.engine import DEFAULT_WSTOP
 from tests.util import LIB_ORDER, World
 
 pytestmark = pytest.mark.gpu
@@ -77,7 +78,7 @@ def test_search_shortcuts_same_results_fewer_steps(engine, world):
         _, res = run_gpu(engine, world, wstop=wstop, ftab=ftab, wide_rows=wide)
         assert_same(res, ref)
         assert sum(s["steps"] for s in res.stats) < int(base["stats"][:, 2].sum())
-    engine.set_option("wstop", 2)
+    engine.set_option("wstop", DEFAULT_WSTOP)
     engine.set_option("ftab", 1)
     engine.set_option("wide_rows", 64)
 
@@ -183,7 +184,7 @@ def test_spike_in_cascade_and_many_samples(engine, world, native_lib):
     order = LIB_ORDER + ["spike-in"]
     pd = [dict(lib=order.index(k), min_len=a, max_len=b, seed_len=s_, max_mm_seed=ms, max_mm_total=mt,
                trim5=t5, trim3=t3, poly_t=pt) for (k, a, b, s_, ms, mt, t5, t3, pt) in MIRGE_PASS_TABLE]
-    ref = model.fm_cascade(views, pd, w, l, nm, wstop=2, ftab=True)
+    ref = model.fm_cascade(views, pd, w, l, nm, wstop=DEFAULT_WSTOP, ftab=True)
     got = res.to_host()
     for name, a in zip(("pass_id", "ref_id", "pos", "mm"), got):
         assert np.array_equal(a, ref[name]), name
@@ -287,7 +288,7 @@ def test_list_best_matches_exhaustive_scan(native_lib, oracle_lib):
     eng, olib, reads, rs = _repeat_world()
     for seed_len, n_seed, n_total in ((64, 1, 1), (64, 0, 0), (28, 1, 2), (64, 2, 2)):
         for opts in ({}, {"wstop": 0, "ftab": 0}):
-            for k, v in {"wstop": 2, "ftab": 1, **opts}.items():
+            for k, v in {"wstop": DEFAULT_WSTOP, "ftab": 1, **opts}.items():
                 eng.set_option(k, v)
             mm, off, ref, pos = eng.list_best(rs, "g", seed_len=seed_len, max_mm_seed=n_seed, max_mm_total=n_total)
             assert off[0] == 0 and off[-1] == len(ref) == len(pos)
@@ -301,7 +302,7 @@ def test_list_best_matches_exhaustive_scan(native_lib, oracle_lib):
                     assert int(mm[i]) == want_mm and got == want, (r, seed_len, n_seed, n_total, opts)
                     multi += len(got) > 1
             assert multi > 20
-    eng.set_option("wstop", 2)
+    eng.set_option("wstop", DEFAULT_WSTOP)
     eng.set_option("ftab", 1)
 
 
@@ -313,13 +314,13 @@ def test_count_best_matches_exhaustive_scan(native_lib, oracle_lib):
     eng, olib, reads, rs = _repeat_world()
     for seed_len, n_seed, n_total in ((28, 1, 2), (28, 0, 2), (28, 2, 2), (20, 1, 1), (64, 0, 0)):
         for opts in ({}, {"wstop": 0, "ftab": 0}):
-            for k, v in {"wstop": 2, "ftab": 1, **opts}.items():
+            for k, v in {"wstop": DEFAULT_WSTOP, "ftab": 1, **opts}.items():
                 eng.set_option(k, v)
             mm, cnt = eng.count_best(rs, "g", seed_len=seed_len, max_mm_seed=n_seed, max_mm_total=n_total)
             for i, r in enumerate(reads):
                 em, ec = model.best_stratum(olib, r, seed_len, n_seed, n_total)
                 assert (int(mm[i]), int(cnt[i])) == (em, min(ec, 255)), (r, seed_len, n_seed, n_total, opts)
-    eng.set_option("wstop", 2)
+    eng.set_option("wstop", DEFAULT_WSTOP)
     eng.set_option("ftab", 1)
 
 
@@ -337,7 +338,7 @@ def test_big_library_jump_tables(native_lib, oracle_lib):
     eng.add_library("big", ix)
     w, l, nm = pack.pack_reads(reads)
     assert w.shape[0] == 2
-    ref = model.fm_cascade([ix.view()], BIG_PASSES, w, l, nm, wstop=2, ftab=True)
+    ref = model.fm_cascade([ix.view()], BIG_PASSES, w, l, nm, wstop=DEFAULT_WSTOP, ftab=True)
     rs = ReadSet(w, l, nm, None, device=eng.device)
     res = eng.cascade(rs, eng.make_passes([dict(p, lib="big") for p in BIG_PASSES]))
     for name, a in zip(("pass_id", "ref_id", "pos", "mm"), res.to_host()):
@@ -348,7 +349,7 @@ def test_big_library_jump_tables(native_lib, oracle_lib):
     short = [r for r in reads if len(r) <= 32]
     w1, l1, nm1 = pack.pack_reads(short)
     assert w1.shape[0] == 1
-    ref1 = model.fm_cascade([ix.view()], BIG_PASSES, w1, l1, nm1, wstop=2, ftab=True)
+    ref1 = model.fm_cascade([ix.view()], BIG_PASSES, w1, l1, nm1, wstop=DEFAULT_WSTOP, ftab=True)
     res1 = eng.cascade(ReadSet(w1, l1, nm1, None, device=eng.device),
                        eng.make_passes([dict(p, lib="big") for p in BIG_PASSES]))
     for name, a in zip(("pass_id", "ref_id", "pos", "mm"), res1.to_host()):
