@@ -26,7 +26,13 @@ namespace mrg {
 namespace {
 
 constexpr uint64_t kOdd = 0x5555555555555555ull;
-constexpr uint32_t kRowsPerTrip = 4;  // suffix-array rows loaded together in the candidate loop
+// suffix-array rows loaded together in the candidate loop: 4 when the text windows come from LDS,
+// 8 when they are HBM/L2 loads themselves (more of them in flight; measured: pass 6 -0.1 ms, the
+// LDS-text passes +5 % with 8)
+template <bool LDST>
+struct RowsPerTrip {
+  static constexpr uint32_t value = LDST ? 4u : 8u;
+};
 
 __device__ __forceinline__ uint64_t low_bits(uint32_t nbits) {
   // nbits in [0,64]
@@ -386,6 +392,7 @@ match_kernel(const MatchParams p) {
         const bool wide = width > p.wide_rows;
         if (!wide) {
           // four suffix-array rows per trip: they mostly share a cache line and their loads overlap
+          constexpr uint32_t kRowsPerTrip = RowsPerTrip<LDST>::value;
           for (uint32_t i = lo; i < hi; i += kRowsPerTrip) {
             uint64_t rows[kRowsPerTrip];
 #pragma unroll
