@@ -21,8 +21,9 @@
 //            (k-mers numbered lexicographically, first base most significant), so the interval
 //            a backward search of the k-mer ends in is [T[c], T[c+1]) and the first k steps of
 //            a seed search are one 8-byte load; 4^k + 1 words per table.  Up to four tables,
-//            largest k first (ftab_ks): an optional big one
-//            (k = 12..14 = ceil(log4 n)) for whole-read seeds on large libraries, the main one
+//            largest k first (ftab_ks): an optional bigger one
+//            (k = 12..14 = ceil(log4 n) for whole-read seeds on large libraries, main + 1 on
+//            small ones), the main one
 //            (k = 8..11), k = 6 and k = 4 for short seed pieces
 //   seg_*    N-free segments of the entries; an alignment must sit in one
 //   chunk_seg[p>>5] = segment holding text position (p & ~31)

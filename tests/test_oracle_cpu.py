@@ -114,14 +114,15 @@ def test_jump_table_equals_backward_search(native_lib):
     seqs = ["".join("ACGT"[c] for c in rng.integers(0, 4, int(L))) for L in rng.integers(20, 400, 60)]
     ix = FmIndex.build(["e%d" % i for i in range(len(seqs))], seqs)
     v = ix.view()
-    assert v["ftab_ks"] == [0, 8, 6, 4] and len(v["ftab"]) == (4 ** 8 + 1) + (4 ** 6 + 1) + (4 ** 4 + 1)
+    assert v["ftab_ks"] == [9, 8, 6, 4] and len(v["ftab"]) == (4 ** 9 + 1) + (4 ** 8 + 1) + (4 ** 6 + 1) + (4 ** 4 + 1)
     text = "".join(seqs)
     sa = [int(x) & 0xFFFFFFFF for x in v["sa"]]
-    tail = text[-8:]
+    tail = text[-9:]
     for trial in range(450):
-        k, off = ((8, 0), (6, 4 ** 8 + 1), (4, 4 ** 8 + 1 + 4 ** 6 + 1))[trial % 3]
+        base = 4 ** 9 + 1
+        k, off = ((8, base), (6, base + 4 ** 8 + 1), (4, base + 4 ** 8 + 1 + 4 ** 6 + 1), (9, 0))[trial % 4]
         if trial < 12:
-            kmer = (tail[-(trial % 7 + 1):] + "A" * 8)[:k]      # continues a too-short suffix
+            kmer = (tail[-(trial % 7 + 1):] + "A" * 9)[:k]      # continues a too-short suffix
         elif rng.random() < 0.7:
             p = int(rng.integers(0, len(text) - k))
             kmer = text[p:p + k]
@@ -133,7 +134,7 @@ def test_jump_table_equals_backward_search(native_lib):
         extra = [i for i in range(lo, hi) if i not in rows]
         assert set(rows) <= set(range(lo, hi))
         assert all(len(text) - sa[i] < k for i in extra) and len(extra) < k + 1     # only short suffixes
-    assert int(v["ftab"][0]) == 0 and int(v["ftab"][4 ** 8]) == len(sa)
+    assert int(v["ftab"][0]) == 0 and int(v["ftab"][4 ** 9]) == len(sa)
 
 
 def test_big_jump_table_same_results(native_lib, oracle_lib):
