@@ -6,7 +6,9 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <stdexcept>
+#include <thread>
 
 namespace mrg {
 
@@ -254,6 +256,48 @@ static void finish_from_codes(const std::vector<uint8_t>& codes, FmIndex& ix,
 //   ks[1]  "main" k = ceil(log4 n) clamped to 8..11 (11 = a seed piece of a 22-nt read)
 //   ks[2], ks[3]  k = 6 and k = 4 for the short pieces of the 2-mismatch pass (6-7 of 19 nt)
 // Derived data: rebuilt on load, not stored in the index file.
+namespace {
+
+// 32 bases starting at text position q (first base in the low two bits); positions past the end
+// read as A (the text array is padded with zero words).
+inline uint64_t window64(const FmIndex& ix, uint64_t q) {
+  const size_t w = q >> 4;
+  const uint32_t sh = (uint32_t)(q & 15) * 2;
+  const size_t nw = ix.text.size();
+  const uint64_t t0 = w < nw ? ix.text[w] : 0, t1 = w + 1 < nw ? ix.text[w + 1] : 0, t2 = w + 2 < nw ? ix.text[w + 2] : 0;
+  const uint64_t lo = t0 | (t1 << 32);
+  return sh ? (lo >> sh) | (t2 << (64 - sh)) : lo;
+}
+
+// reverse the order of the low k 2-bit groups of x (first base becomes most significant)
+inline uint64_t reverse_pairs(uint64_t x, uint32_t k) {
+  x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+  x = __builtin_bswap64(x);
+  return x >> (64 - 2 * k);
+}
+
+void fill_jump_table(const FmIndex& ix, uint32_t k, uint32_t* tab) {
+  const uint64_t n_codes = 1ull << (2 * k), kmask = n_codes - 1;
+  const uint32_t n_rows = (uint32_t)ix.sa.size();
+  uint64_t next_c = 0;
+  for (uint32_t i = 0; i < n_rows; ++i) {
+    const uint32_t p = (uint32_t)ix.sa[i];
+    // first base most significant; a suffix shorter than k is padded with A (bases past the end
+    // of the text read as A, but the last text word may hold real padding only past n)
+    uint64_t win = window64(ix, p) & kmask;
+    if ((uint64_t)p + k > ix.n) {
+      const uint32_t have = p < ix.n ? ix.n - p : 0;
+      win &= have ? ((1ull << (2 * have)) - 1) : 0ull;
+    }
+    const uint64_t code = reverse_pairs(win, k);
+    while (next_c <= code) tab[next_c++] = i;
+  }
+  while (next_c <= n_codes) tab[next_c++] = n_rows;
+}
+
+}  // namespace
+
 void build_jump_tables(FmIndex& ix) {
   uint32_t k_log = 1;
   while (k_log < 14 && (1ull << (2 * k_log)) < ix.n) ++k_log;
@@ -261,44 +305,47 @@ void build_jump_tables(FmIndex& ix) {
   ix.ftab_ks[0] = k_log > 11 ? (uint8_t)k_log : (ix.ftab_ks[1] < 11 ? (uint8_t)(ix.ftab_ks[1] + 1) : 0);
   ix.ftab_ks[2] = 6;
   ix.ftab_ks[3] = 4;
-  size_t total = 0;
-  for (uint8_t k : ix.ftab_ks)
-    if (k) total += ((size_t)1 << (2 * k)) + 1;
-  ix.ftab.assign(total, 0);
-  const uint32_t n_rows = (uint32_t)ix.sa.size();
-  size_t base = 0;
-  for (uint8_t k : ix.ftab_ks) {
-    if (!k) continue;
-    const uint64_t n_codes = 1ull << (2 * k);
-    uint32_t* tab = ix.ftab.data() + base;
-    uint64_t next_c = 0;
-    for (uint32_t i = 0; i < n_rows; ++i) {
-      const uint32_t p = (uint32_t)ix.sa[i];
-      const uint32_t have = std::min<uint32_t>(k, ix.n - std::min(p, ix.n));
-      uint64_t code = 0;  // first base most significant, short suffixes padded with A
-      for (uint32_t t = 0; t < have; ++t)
-        code |= (uint64_t)((ix.text[(p + t) >> 4] >> (((p + t) & 15) * 2)) & 3u) << (2 * (k - 1 - t));
-      while (next_c <= code) tab[next_c++] = i;
-    }
-    while (next_c <= n_codes) tab[next_c++] = n_rows;
-    base += (size_t)n_codes + 1;
+  size_t total = 0, base[4] = {0, 0, 0, 0};
+  for (int t = 0; t < 4; ++t) {
+    base[t] = total;
+    if (ix.ftab_ks[t]) total += ((size_t)1 << (2 * ix.ftab_ks[t])) + 1;
   }
+  ix.ftab.assign(total, 0);
+  // the tables are independent linear passes over the suffix array: one thread each
+  std::vector<std::thread> pool;
+  for (int t = 0; t < 4; ++t)
+    if (ix.ftab_ks[t])
+      pool.emplace_back(fill_jump_table, std::cref(ix), (uint32_t)ix.ftab_ks[t], ix.ftab.data() + base[t]);
+  for (auto& th : pool) th.join();
 }
 
 void build_row_context(FmIndex& ix) {
   ix.ctx.clear();
   if (ix.n < (1u << 20)) return;
-  auto base_at = [&](uint64_t q) -> uint32_t {
-    return q < ix.n ? (ix.text[q >> 4] >> ((q & 15) * 2)) & 3u : 0u;
-  };
   ix.ctx.resize(ix.sa.size());
-  for (size_t i = 0; i < ix.sa.size(); ++i) {
-    const uint32_t p = (uint32_t)ix.sa[i];
-    uint32_t left = 0, right = 0;
-    for (uint32_t d = 1; d <= 8 && d <= p; ++d) left |= base_at(p - d) << (16 - 2 * d);
-    for (uint32_t d = 0; d < 8; ++d) right |= base_at((uint64_t)p + 8 + d) << (2 * d);
-    ix.ctx[i] = left | right << 16;
-  }
+  const size_t n_rows = ix.sa.size();
+  const unsigned n_threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < n_threads; ++t)
+    pool.emplace_back([&ix, n_rows, n_threads, t] {
+      for (size_t i = n_rows * t / n_threads; i < n_rows * (t + 1) / n_threads; ++i) {
+        const uint32_t p = (uint32_t)ix.sa[i];
+        // left: text[p-8 .. p) with text[p-1] in the top two bits = the 16-bit window at p - 8
+        // (bases before the start of the text read as A)
+        uint32_t left;
+        if (p >= 8) {
+          left = (uint32_t)window64(ix, (uint64_t)p - 8) & 0xFFFFu;
+        } else {
+          left = ((uint32_t)window64(ix, 0) & ((1u << (2 * p)) - 1u)) << (16 - 2 * p);
+        }
+        uint32_t right = (uint32_t)window64(ix, (uint64_t)p + 8) & 0xFFFFu;
+        const uint64_t end = (uint64_t)p + 8;
+        if (end >= ix.n) right = 0;
+        else if (end + 8 > ix.n) right &= (1u << (2 * (uint32_t)(ix.n - end))) - 1u;
+        ix.ctx[i] = left | right << 16;
+      }
+    });
+  for (auto& th : pool) th.join();
 }
 
 void build_index(const std::vector<std::string>& names,
