@@ -112,6 +112,9 @@ typedef struct mrg_index_view {
   const uint32_t *ctx;       /* NULL, or for libraries of >= 2^20 bases one word per suffix-array
                               * row: bits 0-15 the 8 bases left of the row's position (the nearest
                               * in the top two), bits 16-31 the bases 8..15 after it */
+  const uint32_t *kbits;     /* NULL, or for libraries of at most 170 000 bases the presence bitmap of
+                              * their 9-mers: 4^9 bits, bit c = 9-mer with code c (first base in
+                              * the low two bits) occurs */
 } mrg_index_view;
 int mrg_index_get_view(const mrg_index *ix, mrg_index_view *view);
 
@@ -129,7 +132,9 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * stops narrowing and hands the occurrences to verification (0 = narrow to the
  * end of the piece; default 8); "ftab" = 1/0 use the k-mer jump table for the first k steps
  * of a seed search; "wide_rows" = seed intervals wider than this many rows are
- * verified cooperatively by the whole wave (default 64); "ctx_wide_rows" = the same
+ * verified cooperatively by the whole wave (default 64); "kmer_filter" = 1/0 stage a small
+ * library's 9-mer presence bitmap in LDS and skip the jump-table load of a seed piece whose
+ * last 9 bases do not occur in the library (default 1); "ctx_wide_rows" = the same
  * threshold for libraries of >= 2^20 bases, whose cooperative path drops most rows by their
  * stored text context (default 32). */
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);

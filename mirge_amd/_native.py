@@ -50,7 +50,7 @@ class IndexView(C.Structure):
     _fields_ = [("blocks", C.POINTER(C.c_uint32)), ("super", C.POINTER(C.c_uint32)),
                 ("text", C.POINTER(C.c_uint32)), ("sa", C.POINTER(C.c_uint64)),
                 ("ftab", C.POINTER(C.c_uint32))] + \
-               [(k, C.POINTER(C.c_uint32)) for k in ("seg_start", "seg_ref", "seg_off", "chunk_seg", "ctx")]
+               [(k, C.POINTER(C.c_uint32)) for k in ("seg_start", "seg_ref", "seg_off", "chunk_seg", "ctx", "kbits")]
 
 
 # name -> (restype, argtypes); every symbol include/mirge_amd.h declares

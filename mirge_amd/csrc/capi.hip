@@ -49,6 +49,7 @@ struct DevLib {
            *seg_ref = nullptr, *seg_off = nullptr, *chunk_seg = nullptr;
   uint64_t* sa = nullptr;
   uint32_t* ctx = nullptr;
+  uint32_t* kbits = nullptr;
   uint32_t* ftab = nullptr;
   mrg::JumpTables tabs = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   uint32_t n = 0, nblk = 0, nsup = 0, primary = 0, text_words = 0, n_seg = 0, n_ref = 0;
@@ -79,6 +80,7 @@ struct mrg_ctx {
   int64_t use_ftab = 1;
   int64_t force_lds_mode = -1;
   int64_t wide_rows = 64;
+  int64_t kmer_filter = 1;
   int64_t ctx_wide_rows = 32;
   int64_t prefer_two_blocks = 1;
   std::vector<DevLib> libs;
@@ -202,6 +204,7 @@ int mrg_index_get_view(const mrg_index* h, mrg_index_view* v) {
   v->sa = ix.sa.data();
   v->ftab = ix.ftab.data();
   v->ctx = ix.ctx.empty() ? nullptr : ix.ctx.data();
+  v->kbits = ix.kbits.empty() ? nullptr : ix.kbits.data();
   v->seg_start = ix.seg_start.data();
   v->seg_ref = ix.seg_ref.data();
   v->seg_off = ix.seg_off.data();
@@ -247,6 +250,7 @@ void mrg_ctx_destroy(mrg_ctx* ctx) {
     (void)hipFree(l.sa);
     (void)hipFree(l.ftab);
     (void)hipFree(l.ctx);
+    (void)hipFree(l.kbits);
     (void)hipFree(l.seg_start);
     (void)hipFree(l.seg_ref);
     (void)hipFree(l.seg_off);
@@ -293,6 +297,7 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
   }
   if ((rc = upload(&l.ftab, ix.ftab))) return rc;
   if (!ix.ctx.empty() && (rc = upload(&l.ctx, ix.ctx))) return rc;
+  if (!ix.kbits.empty() && (rc = upload(&l.kbits, ix.kbits))) return rc;
   if ((rc = upload(&l.seg_start, ix.seg_start))) return rc;
   if ((rc = upload(&l.seg_ref, ix.seg_ref))) return rc;
   if ((rc = upload(&l.seg_off, ix.seg_off))) return rc;
@@ -314,6 +319,8 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "ctx_wide_rows") {
     if (value < 1) return fail(MRG_ERR_ARG, "ctx_wide_rows must be >= 1");
     ctx->ctx_wide_rows = value;
+  } else if (k == "kmer_filter") {
+    ctx->kmer_filter = value != 0;
   } else if (k == "wide_rows") {
     if (value < 1) return fail(MRG_ERR_ARG, "wide_rows must be >= 1");
     ctx->wide_rows = value;
@@ -456,7 +463,12 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     // staging and two resident workgroups per CU (<= 80 KB each) beat a fuller LDS:
     //   2 = blocks + text, 3 = text only, 1 = blocks only, 0 = nothing.
     const uint64_t blk_bytes = (uint64_t)l.nblk * 16, txt_bytes = (uint64_t)l.text_words * 4;
-    const uint64_t overhead = (uint64_t)l.nsup * 16 + mrg::kMatchCtlBytes;
+    // a small library's 9-mer bitmap (32 KB; only built for libraries whose text leaves room for
+    // it next to a second workgroup) rides in LDS ("kmer_filter" = 0 switches it off)
+    const uint64_t kb_bytes = (l.kbits && ctx->kmer_filter) ? (uint64_t)mrg::kKmerBitsWords * 4 : 0;
+    const bool use_kbits = kb_bytes != 0;
+    p.kbits = use_kbits ? l.kbits : nullptr;
+    const uint64_t overhead = (uint64_t)l.nsup * 16 + mrg::kMatchCtlBytes + (use_kbits ? kb_bytes : 0);
     const uint64_t budget = (uint64_t)ctx->lds_budget, hard = 160 * 1024, half = 80 * 1024;
     if (overhead > hard)
       return fail(MRG_ERR_ARG, "mrg_cascade_run: the superblock table of library %d does not fit LDS", c.lib);

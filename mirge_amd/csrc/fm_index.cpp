@@ -319,6 +319,17 @@ void build_jump_tables(FmIndex& ix) {
   for (auto& th : pool) th.join();
 }
 
+void build_kmer_bits(FmIndex& ix) {
+  ix.kbits.clear();
+  if (ix.n > kKmerBitsMaxBases || ix.n < kIndexKmerBitsK) return;
+  ix.kbits.assign(kIndexKmerBitsWords, 0);
+  const uint32_t mask = (1u << (2 * kIndexKmerBitsK)) - 1u;
+  for (uint32_t p = 0; p + kIndexKmerBitsK <= ix.n; ++p) {
+    const uint32_t c = (uint32_t)window64(ix, p) & mask;
+    ix.kbits[c >> 5] |= 1u << (c & 31);
+  }
+}
+
 void build_row_context(FmIndex& ix) {
   ix.ctx.clear();
   if (ix.n < (1u << 20)) return;
@@ -425,6 +436,7 @@ void build_index(const std::vector<std::string>& names,
   }
   build_jump_tables(ix);
   build_row_context(ix);
+  build_kmer_bits(ix);
 }
 
 std::string entry_sequence(const FmIndex& ix, uint32_t r) {
@@ -527,6 +539,7 @@ void load_index(const std::string& path, FmIndex& ix) {
     throw std::runtime_error("index file inconsistent");
   build_jump_tables(ix);
   build_row_context(ix);
+  build_kmer_bits(ix);
 }
 
 }  // namespace mrg

@@ -60,6 +60,11 @@ struct FmIndex {
   // candidate whose visible bases already show more mismatches than the pass allows is dropped
   // without touching its suffix-array row or the text.  Derived data, rebuilt on load.
   std::vector<uint32_t> ctx;
+  // Libraries of at most kKmerBitsMaxBases bases: presence bitmap of their 9-mers (4^9 bits = 32 KB; bit c =
+  // some text position starts the 9-mer with code c, first base in the low two bits).  Staged in
+  // LDS, it answers "this seed piece cannot occur" for most pieces of reads that do not come
+  // from the library -- without the jump-table load, a random L2 request.  Derived data.
+  std::vector<uint32_t> kbits;
   uint8_t ftab_ks[4] = {0, 0, 0, 0};  // k of each table, descending; 0 = table absent
   std::vector<uint32_t> ftab;         // 4^k + 1 row boundaries per table, the tables of ftab_ks back to back
   std::vector<uint32_t> seg_start, seg_ref, seg_off, chunk_seg;
@@ -72,6 +77,12 @@ void read_fasta(const std::string& path, std::vector<std::string>& names,
                 std::vector<std::string>& seqs);
 void build_jump_tables(FmIndex& ix);  // from sa + text
 void build_row_context(FmIndex& ix);  // from sa + text
+void build_kmer_bits(FmIndex& ix);    // from text
+// largest library that gets the bitmap: its packed text (n / 4 bytes) plus the 32 KB bitmap must
+// leave room for two match workgroups per CU (80 KB each incl. ~4 KB of control data)
+constexpr uint32_t kKmerBitsMaxBases = 170000;
+constexpr uint32_t kIndexKmerBitsK = 9;  // = mrg::kKmerBitsK in kernels.hpp
+constexpr uint32_t kIndexKmerBitsWords = (1u << (2 * kIndexKmerBitsK)) / 32u;
 void save_index(const FmIndex& ix, const std::string& path);
 void load_index(const std::string& path, FmIndex& ix);
 std::string entry_sequence(const FmIndex& ix, uint32_t i);

@@ -223,7 +223,7 @@ __device__ __forceinline__ void verify_row(const LibT& lib, const MatchParams& p
 // STRATA: the 2-mismatch policy (three seed pieces) with its stratum-first search; a separate
 // instantiation so that the other passes keep the plain piece loop.
 // CTX: the library has a row-context array (>= 2^20 bases; never together with LDST).
-template <int W, bool LDSI, bool LDST, bool STRATA, bool CTX>
+template <int W, bool LDSI, bool LDST, bool STRATA, bool CTX, bool KBITS>
 __global__ void __launch_bounds__(MatchBlock<LDSI>::kThreads, (W == 1 ? 8 : 4))
 match_kernel(const MatchParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -236,7 +236,8 @@ match_kernel(const MatchParams p) {
   uint32_t* ssuper = smem;
   uint32_t* sblocks = ssuper + sup_words;
   uint32_t* stext = sblocks + blk_words;
-  uint32_t* seg_count = stext + txt_words;  // kMaxSegments entries
+  uint32_t* skbits = stext + txt_words;
+  uint32_t* seg_count = skbits + (KBITS ? kKmerBitsWords : 0u);  // kMaxSegments entries
   uint32_t* ctl = seg_count + kMaxSegments; // [0] survivors appended here, [1] longest input segment
   uint32_t* wave_slots = ctl + 4;           // 16 B per wave: minimum of a wave-wide verification
   {
@@ -254,6 +255,11 @@ match_kernel(const MatchParams p) {
     const uint4* src = reinterpret_cast<const uint4*>(p.text);
     uint4* dst = reinterpret_cast<uint4*>(stext);
     for (uint32_t i = threadIdx.x; i < txt_words / 4; i += BLOCK) dst[i] = src[i];
+  }
+  if (KBITS) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.kbits);
+    uint4* dst = reinterpret_cast<uint4*>(skbits);
+    for (uint32_t i = threadIdx.x; i < kKmerBitsWords / 4; i += BLOCK) dst[i] = src[i];
   }
   // The input list is the producer pass's per-workgroup segments.  Consumers walk
   // them round-robin (chunk c -> segment c % nseg, depth c / nseg): the workgroups
@@ -356,6 +362,15 @@ match_kernel(const MatchParams p) {
             if (hi_b > lo_b) has_n |= (nm[w] & low_bits(2 * hi_b) & ~low_bits(2 * lo_b)) != 0ull;
           }
           if (has_n) continue;
+        }
+        if (KBITS && b - a >= (int32_t)kKmerBitsK) {
+          // the piece's last 9 bases do not occur in the library: the piece cannot match, and
+          // an LDS bit test has answered it instead of a jump-table load (a random L2 request)
+          const uint32_t at = (uint32_t)b - kKmerBitsK;
+          uint64_t v = pick_word<W>(rd, at >> 5) >> ((at & 31u) * 2u);
+          if (W > 1 && (at & 31u) + kKmerBitsK > 32u) v |= pick_word<W>(rd, (at >> 5) + 1u) << (64u - (at & 31u) * 2u);
+          const uint32_t c9 = (uint32_t)v & ((1u << (2u * kKmerBitsK)) - 1u);
+          if (((skbits[c9 >> 5] >> (c9 & 31u)) & 1u) == 0u) continue;
         }
         // ---- exact backward search of read[a,b) ----
         uint32_t lo = 0, hi = p.n + 1;
@@ -740,10 +755,10 @@ __global__ void export_pass_counts_kernel(const uint64_t* stats, uint32_t n_pass
 // ---------------------------------------------------------------------------
 // Launch helpers (host)
 // ---------------------------------------------------------------------------
-template <int W, bool LDSI, bool LDST, bool STRATA, bool CTX>
-static hipError_t launch_match_x(const MatchParams& p, uint32_t grid, uint32_t lds_bytes,
+template <int W, bool LDSI, bool LDST, bool STRATA, bool CTX, bool KBITS>
+static hipError_t launch_match_k(const MatchParams& p, uint32_t grid, uint32_t lds_bytes,
                                  hipStream_t stream) {
-  auto kern = match_kernel<W, LDSI, LDST, STRATA, CTX>;
+  auto kern = match_kernel<W, LDSI, LDST, STRATA, CTX, KBITS>;
   if (lds_bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -752,6 +767,14 @@ static hipError_t launch_match_x(const MatchParams& p, uint32_t grid, uint32_t l
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(MatchBlock<LDSI>::kThreads), lds_bytes, stream, p);
   return hipGetLastError();
+}
+
+template <int W, bool LDSI, bool LDST, bool STRATA, bool CTX>
+static hipError_t launch_match_x(const MatchParams& p, uint32_t grid, uint32_t lds_bytes,
+                                 hipStream_t stream) {
+  // the bitmap exists for small libraries and is used when the launch reserved LDS for it
+  return p.kbits ? launch_match_k<W, LDSI, LDST, STRATA, CTX, true>(p, grid, lds_bytes, stream)
+                 : launch_match_k<W, LDSI, LDST, STRATA, CTX, false>(p, grid, lds_bytes, stream);
 }
 
 template <int W, bool LDSI, bool LDST, bool STRATA>

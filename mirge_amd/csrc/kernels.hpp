@@ -14,6 +14,9 @@ struct MatchBlock {
   static constexpr uint32_t kThreads = 1024u;
 };
 constexpr uint32_t kTallyThreads = 1024u;
+// 9-mer presence bitmap of a small library (FmIndex::kbits): 4^9 bits
+constexpr uint32_t kKmerBitsK = 9u;
+constexpr uint32_t kKmerBitsWords = (1u << (2u * kKmerBitsK)) / 32u;
 // Survivor lists are segmented: workgroup b of the producing pass owns segment b.
 constexpr uint32_t kMaxSegments = 512u;
 constexpr uint32_t kMatchCtlBytes = (kMaxSegments + 4u + 4u * 16u) * 4u;  // segment lengths, control
@@ -33,6 +36,7 @@ struct MatchParams {
   const uint32_t* text;
   const uint64_t* sa;      // 8 B rows: pos | before<<32 | after<<40 | seg<<48
   const uint32_t* ctx;     // per-row text context of a large library (null otherwise)
+  const uint32_t* kbits;   // 9-mer presence bitmap of a small library, staged in LDS (null = not used)
   const uint32_t* ftab;    // k-mer jump tables: lo, hi per k-mer
   JumpTables tabs;
   const uint32_t* seg_start;

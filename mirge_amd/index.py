@@ -133,5 +133,6 @@ class FmIndex:
             seg_off=arr(v.seg_off, max(inf.n_seg, 1))[:inf.n_seg],
             chunk_seg=arr(v.chunk_seg, (inf.n_bases >> 5) + 2),
             ctx=arr(v.ctx, inf.n_bases + 1) if v.ctx else None,
+            kbits=arr(v.kbits, (1 << 18) // 32) if v.kbits else None,
             n=int(inf.n_bases), primary=int(inf.primary), C=[int(c) for c in inf.C],
             _owner=self)

@@ -25,6 +25,7 @@ typedef struct {
   const uint64_t *sa;
   const uint32_t *ftab; /* k-mer jump tables: 4^k + 1 row boundaries each, tables back to back */
   const uint32_t *seg_start, *seg_ref, *seg_off, *chunk_seg;
+  const uint32_t *kbits; /* NULL or the 9-mer presence bitmap of a small library */
   uint32_t n, primary;
   uint8_t ftab_ks[4]; /* k of each table, largest first, 0 = absent */
 } orc_lib;
@@ -84,6 +85,13 @@ static int match_one(const orc_lib *l, const orc_pass *p, const uint64_t *rd, co
     for (int i = a; i < b; ++i)
       if ((nm[i >> 5] >> ((i & 31) * 2)) & 1) has_n = 1;
     if (has_n) continue;
+    if (l->kbits && b - a >= 9) {
+      /* the piece's last 9 bases do not occur in the library: it cannot match */
+      uint32_t c9 = 0;
+      for (int t = 0; t < 9; ++t)
+        c9 |= (uint32_t)((rd[(b - 9 + t) >> 5] >> (((b - 9 + t) & 31) * 2)) & 3ull) << (2 * t);
+      if (!((l->kbits[c9 >> 5] >> (c9 & 31)) & 1u)) continue;
+    }
     uint32_t lo = 0, hi = l->n + 1;
     int j = b;
     /* the piece's last k bases in one load: the largest table the piece is long enough for */

@@ -170,7 +170,7 @@ class ScanGenome:
 class _OrcLib(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in
                 ("blocks", "super", "text", "sa", "ftab", "seg_start", "seg_ref", "seg_off",
-                 "chunk_seg")] + \
+                 "chunk_seg", "kbits")] + \
                [("n", C.c_uint32), ("primary", C.c_uint32), ("ftab_ks", C.c_uint8 * 4)]
 
 
@@ -181,14 +181,14 @@ class _OrcPass(C.Structure):
 
 
 def fm_cascade(lib_views, passes, reads, lens, nmask=None, wstop=0, threads=None,
-               want_steps=False, ftab=False):
+               want_steps=False, ftab=False, kmer_filter=True):
     """Run the CPU port.
 
     lib_views: list of dicts with numpy arrays blocks/super/text/sa/seg_start/
                seg_ref/seg_off/chunk_seg and ints n, primary (as mirge_amd index views).
     passes   : list of dicts with the mrg_pass_cfg fields.
     reads    : uint64 [W, n] SoA words; lens uint8 [n]; nmask like reads or None.
-    wstop / ftab: the same search shortcuts the GPU context options select.
+    wstop / ftab / kmer_filter: the same search shortcuts the GPU context options select.
     Returns dict(pass_id, ref_id, pos, mm, stats[n_pass,5] = processed, aligned, steps,
     candidates, lookups; steps_per_read|None).
     """
@@ -203,6 +203,11 @@ def fm_cascade(lib_views, passes, reads, lens, nmask=None, wstop=0, threads=None
             a = np.ascontiguousarray(v[k], dtype=np.uint64 if k == "sa" else np.uint32)
             keep.append(a)
             setattr(libs[i], k, a.ctypes.data)
+        kb = v.get("kbits") if kmer_filter else None
+        if kb is not None:
+            kb = np.ascontiguousarray(kb, dtype=np.uint32)
+            keep.append(kb)
+            libs[i].kbits = kb.ctypes.data
         libs[i].n = int(v["n"])
         libs[i].primary = int(v["primary"])
         for t, k in enumerate(v["ftab_ks"]):

@@ -58,6 +58,11 @@ def test_cascade_matches_cpu_port_all_lds_modes(engine, world):
         elif mode > 0:
             assert staged[0] > 0 and staged[8] > 0  # the miRNA library always fits
     engine.set_option("force_lds_mode", -1)
+    # without the 9-mer presence bitmap: same assignments, more jump-table loads (the port without it)
+    ref_nf = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask, kmer_filter=False)
+    _, res = run_gpu(engine, world, kmer_filter=0, wstop=0, ftab=0)
+    assert_same(res, ref_nf)
+    engine.set_option("kmer_filter", 1)
     # the LDS budget option alone can also switch staging off
     _, res = run_gpu(engine, world, lds_budget=0, wstop=0, ftab=0)
     assert_same(res, ref)

@@ -137,6 +137,24 @@ def test_jump_table_equals_backward_search(native_lib):
     assert int(v["ftab"][0]) == 0 and int(v["ftab"][4 ** 9]) == len(sa)
 
 
+def test_kmer_bitmap_is_exact_and_changes_no_result(world):
+    """The 9-mer presence bitmap of a small library: bit c set iff the 9-mer occurs in the stored
+    text; with it the port skips jump-table loads but assigns the same."""
+    v = world.views[0]
+    assert v["kbits"] is not None
+    assert [w["kbits"] is not None for w in world.views] == [w["n"] <= 170000 for w in world.views]
+    text = "".join(s.replace("N", "") for s in world.libs.libs["mirna"][1])
+    have = {sum("ACGT".index(ch) << (2 * t) for t, ch in enumerate(text[p:p + 9])) for p in range(len(text) - 8)}
+    bits = np.unpackbits(v["kbits"].view(np.uint8), bitorder="little")
+    assert set(np.nonzero(bits)[0].tolist()) == have
+    on = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask, wstop=8, ftab=True)
+    off = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask, wstop=8, ftab=True,
+                           kmer_filter=False)
+    for k in ("pass_id", "ref_id", "pos", "mm"):
+        assert np.array_equal(on[k], off[k])
+    assert int(on["stats"][:, 4].sum()) < int(off["stats"][:, 4].sum()) * 0.7     # far fewer table loads
+
+
 def test_big_jump_table_same_results(native_lib, oracle_lib):
     """A library beyond 4^11 bases gets the k = 12 table (whole-read seeds) next to the k = 11 one
     (pieces of a 22-nt read); results equal the plain backward search."""
