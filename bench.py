@@ -191,13 +191,13 @@ def main():
     for i, s in enumerate(st):
         # <W, occ blocks in LDS, text in LDS, stratum-first (the 2-mismatch policy), row context
         # (libraries of >= 2^20 bases, never with the text in LDS)>
-        # ..., 9-mer bitmap in LDS (libraries of at most 170 000 bases)>
+        # ..., 9-mer bitmap in LDS (libraries of at most 190 000 bases)>
         nb = index[table[i][0]].info.n_bases
         has_ctx = nb >= (1 << 20) and s["lds_mode"] in (0, 1)
         name = "mrg::match_kernel<%d, %s, %s, %s, %s>" % (
             rs.W, {0: "false, false", 1: "true, false", 2: "true, true", 3: "false, true"}[s["lds_mode"]],
             "true" if table[i][4] == 2 else "false", "true" if has_ctx else "false",
-            "true" if nb <= 170000 else "false")
+            "true" if nb <= 190000 else "false")
         g = groups.setdefault(name, dict(ms=0.0, bytes=0.0, sbytes=0.0, launches=0, passes=[]))
         g["ms"] += per_pass_ms[i]
         g["bytes"] += alg_bytes(s)

@@ -112,7 +112,7 @@ typedef struct mrg_index_view {
   const uint32_t *ctx;       /* NULL, or for libraries of >= 2^20 bases one word per suffix-array
                               * row: bits 0-15 the 8 bases left of the row's position (the nearest
                               * in the top two), bits 16-31 the bases 8..15 after it */
-  const uint32_t *kbits;     /* NULL, or for libraries of at most 170 000 bases the presence bitmap of
+  const uint32_t *kbits;     /* NULL, or for libraries of at most 190 000 bases the presence bitmap of
                               * their 9-mers: 4^9 bits, bit c = 9-mer with code c (first base in
                               * the low two bits) occurs */
 } mrg_index_view;

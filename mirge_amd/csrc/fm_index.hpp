@@ -79,8 +79,8 @@ void build_jump_tables(FmIndex& ix);  // from sa + text
 void build_row_context(FmIndex& ix);  // from sa + text
 void build_kmer_bits(FmIndex& ix);    // from text
 // largest library that gets the bitmap: its packed text (n / 4 bytes) plus the 32 KB bitmap must
-// leave room for two match workgroups per CU (80 KB each incl. ~4 KB of control data)
-constexpr uint32_t kKmerBitsMaxBases = 170000;
+// leave room for two match workgroups per CU (80 KB each incl. < 1 KB of control data)
+constexpr uint32_t kKmerBitsMaxBases = 190000;
 constexpr uint32_t kIndexKmerBitsK = 9;  // = mrg::kKmerBitsK in kernels.hpp
 constexpr uint32_t kIndexKmerBitsWords = (1u << (2 * kIndexKmerBitsK)) / 32u;
 void save_index(const FmIndex& ix, const std::string& path);

@@ -229,7 +229,7 @@ match_kernel(const MatchParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   constexpr uint32_t BLOCK = MatchBlock<LDSI>::kThreads;
 
-  // ---- LDS carve: [superblocks][occ blocks][text][segment prefix][control] ----
+  // ---- LDS carve: [superblocks][occ blocks][text][9-mer bitmap][control] ----
   const uint32_t sup_words = p.nsup * 4;
   const uint32_t blk_words = LDSI ? p.nblk * 4 : 0u;
   const uint32_t txt_words = LDST ? p.text_words : 0u;
@@ -237,8 +237,7 @@ match_kernel(const MatchParams p) {
   uint32_t* sblocks = ssuper + sup_words;
   uint32_t* stext = sblocks + blk_words;
   uint32_t* skbits = stext + txt_words;
-  uint32_t* seg_count = skbits + (KBITS ? kKmerBitsWords : 0u);  // kMaxSegments entries
-  uint32_t* ctl = seg_count + kMaxSegments; // [0] survivors appended here, [1] longest input segment
+  uint32_t* ctl = skbits + (KBITS ? kKmerBitsWords : 0u);  // [0] survivors appended here, [1] longest input segment
   uint32_t* wave_slots = ctl + 4;           // 16 B per wave: minimum of a wave-wide verification
   {
     // 16 B per lane per trip
@@ -275,7 +274,6 @@ match_kernel(const MatchParams p) {
     uint32_t mx = 0;
     for (uint32_t sgi = threadIdx.x; sgi < p.in_nseg; sgi += BLOCK) {
       const uint32_t cnt = p.in_count[sgi];
-      seg_count[sgi] = cnt;
       mx = max(mx, cnt);
     }
 #pragma unroll
@@ -302,7 +300,8 @@ match_kernel(const MatchParams p) {
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     const uint32_t sgi = chunk % in_nseg, depth = chunk / in_nseg;
     const uint32_t t = depth * BLOCK + threadIdx.x;
-    const bool active = t < (p.idx_in ? seg_count[sgi] : p.n_total);
+    // (the segment length is a workgroup-uniform load of a 2 KB array: not worth 2 KB of LDS)
+    const bool active = t < (p.idx_in ? p.in_count[sgi] : p.n_total);
     uint32_t r = 0;
     uint64_t rd[W], nm[W];
     uint32_t L0 = 0;
