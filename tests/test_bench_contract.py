@@ -1,0 +1,45 @@
+"""bench.py's output contract (one JSON line with the driver's keys plus `roofline` and
+`cpu_baseline`) on a small configuration."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                          "--reads-per-gpu", "300000", "--scale", "0.05", "--cpu-sample", "300000"] + list(extra),
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "exactly one line on stdout"
+    return json.loads(lines[0])
+
+
+def test_headline_line_has_the_contract_keys():
+    d = run_bench()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and "workload" in d["config"]
+    assert abs(d["value"] - 300000 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["kernel"].startswith("mrg::match_kernel<1,")
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "identical" in c["parity"]
+    assert len(d["passes"]) == 9 and d["passes"][0]["processed"] == 300000
+
+
+def test_secondary_workloads_run_and_agree_with_the_port():
+    for wl in ("exact", "varlen"):
+        d = run_bench("--workload", wl)
+        assert "identical" in d["cpu_baseline"]["parity"], wl
+        assert d["config"]["reads_per_gpu"] == 300000
