@@ -35,9 +35,10 @@ def test_sample_list_resolution(tmp_path):
         cli.resolve_samples([str(f1), str(lst)])
 
 
-def write_fastq(path, reads, rng):
+def write_fastq(path, reads, rng, adapter=""):
     with open(path, "w") as fh:
         for i, r in enumerate(reads):
+            r = (r + adapter)[:max(len(r), 50)] if adapter else r
             q = rng.integers(25, 41, len(r))
             if rng.random() < 0.3:                       # a low-quality 3' tail that gets trimmed
                 r = r + "ACGT"[int(rng.integers(0, 4))] * 3
@@ -46,7 +47,8 @@ def write_fastq(path, reads, rng):
 
 
 @pytest.mark.gpu
-def test_cli_end_to_end_against_oracle(native_lib, oracle_lib, tmp_path):
+@pytest.mark.parametrize("adapter", ["none", "illumina"])
+def test_cli_end_to_end_against_oracle(native_lib, oracle_lib, tmp_path, adapter):
     from mirge_amd import report, synth
     from oracle import cascade, ingest as oingest, model
     from tests.golden.make_golden import SHAPES
@@ -58,13 +60,15 @@ def test_cli_end_to_end_against_oracle(native_lib, oracle_lib, tmp_path):
         reads = [synth.codes_to_str(c) for c in synth.synth_reads(libs, 1500, seed=40 + si, zipf_s=1.3)]
         reads += ["ACGTNACGTTAGCATCGATCGA", "TTTTTTTTTTTTTTTTTTTT", "ACGTACGTAC"]      # N, poly-T, too short
         p = str(tmp_path / ("s%d.fastq" % si))
-        write_fastq(p, reads, rng)
+        # raw small-RNA reads carry the 3' adapter: 50-cycle reads, insert + adapter prefix
+        write_fastq(p, reads, rng, adapter="TGGAATTCTCGGGTGCCAAGGAACTCCAGTCAC" if adapter == "illumina" else "")
         fastqs.append(p)
     out = cli.annotate_main(cli.build_parser().parse_args(
         ["annotate", "-s"] + fastqs + ["-lib", str(tmp_path / "libs"), "-sp", "syn", "-o", str(tmp_path),
-                                       "-di", "-tcf"]))
+                                       "-di", "-tcf", "-ad", adapter, "-cpu", "3"]))
     # ---- the same run through the oracle ----
-    kept = [oingest.load_fastq(p)[0] for p in fastqs]
+    from mirge_amd.ingest import resolve_adapter
+    kept = [oingest.load_fastq(p, adapter=resolve_adapter(adapter))[0] for p in fastqs]
     seq_dic, len_dic = cascade.collapse(kept)
     olibs = {k: model.Library(*libs.libs[k]) for k in libs.libs}
     log = {"quantStats": [{} for _ in fastqs], "annotStats": []}
@@ -92,6 +96,8 @@ def test_cli_end_to_end_against_oracle(native_lib, oracle_lib, tmp_path):
         assert got == sorted(open(str(want_dir / fn)).read().split("\n")), fn
     rep = open(os.path.join(out["outdir"], "annotation.report.csv")).read().split("\n")
     assert rep[1].split(",")[:3] == ["s0.fastq", "1503", str(len(kept[0]))]
+    if adapter == "illumina":      # the adapter was found and cut: the kept reads are the inserts again
+        assert sum(len(r) <= 26 for r in kept[0]) > 0.95 * len(kept[0])
     assert os.path.exists(os.path.join(out["outdir"], "s0.trim.collapse.fa"))
 
 
