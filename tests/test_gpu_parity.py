@@ -403,3 +403,48 @@ def test_count_and_list_best_on_a_20mbp_library(native_lib, oracle_lib):
             got = list(zip(ref[off[i]:off[i + 1]].tolist(), pos[off[i]:off[i + 1]].tolist()))
             assert int(bm[i]) == em and got == want, (r, n_seed)
         assert int(cnt[0]) >= 4 and int(cnt[1]) >= 4
+
+
+@pytest.mark.gpu
+def test_long_reads_four_words(native_lib, oracle_lib):
+    """Reads of 65..128 nt (four packed words, the W = 4 instantiations): cascade = CPU port, and
+    the port = the exhaustive scan on the same reads (seed rule: mismatches beyond the first 28
+    bases count only towards the total)."""
+    from mirge_amd import pack
+    from mirge_amd.engine import Engine, ReadSet
+    from tests.util import World, pass_dicts
+    w = World(with_n=True, n_fixed=200, n_var=50)
+    rng = np.random.default_rng(31)
+    reads = []
+    for key in ("mrna", "ncrna_others", "hairpin", "snorna", "mature_trna"):
+        for s in w.libs.libs[key][1]:
+            if len(s) < 66:
+                continue
+            for _ in range(6):
+                L = int(rng.integers(65, min(128, len(s)) + 1))
+                o = int(rng.integers(0, len(s) - L + 1))
+                r = list(s[o:o + L])
+                for _ in range(int(rng.integers(0, 4))):
+                    r[int(rng.integers(0, L))] = "ACGTN"[int(rng.integers(0, 5))]
+                reads.append("".join(r))
+    reads = list(dict.fromkeys(reads))[:3000]
+    words, lens, nmask = pack.pack_reads(reads)
+    assert words.shape[0] == 4 and int(lens.max()) > 120
+    ref = model.fm_cascade(w.views, pass_dicts(), words, lens, nmask, wstop=DEFAULT_WSTOP, ftab=True)
+    eng = Engine(0)
+    for k in LIB_ORDER:
+        eng.add_library(k, w.index[k])
+    res = eng.cascade(ReadSet(words, lens, nmask, None, device=eng.device), eng.mirge_passes())
+    assert_same(res, ref)
+    assert sum(int(ref["stats"][i][1]) for i in range(9)) > len(reads) // 3
+    # the port against the exhaustive-scan cascade on a subset
+    olibs = {k: model.Library(*w.libs.libs[k]) for k in LIB_ORDER}
+    sub = reads[:400]
+    seq_dic = {r: {"quant": [1], "annot": [0] + [""] * 9, "length": len(r)} for r in sub}
+    align = {}
+    cascade.run_annotation_pipeline(seq_dic, olibs, {"annotStats": []}, align_dic=align)
+    for i, r in enumerate(sub):
+        got = None
+        if ref["pass_id"][i] >= 0:
+            got = (int(ref["pass_id"][i]), int(ref["ref_id"][i]), int(ref["pos"][i]), int(ref["mm"][i]))
+        assert align.get(r) == got, r
