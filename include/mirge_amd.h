@@ -132,7 +132,9 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * stops narrowing and hands the occurrences to verification (0 = narrow to the
  * end of the piece; default 8); "ftab" = 1/0 use the k-mer jump table for the first k steps
  * of a seed search; "wide_rows" = seed intervals wider than this many rows are
- * verified cooperatively by the whole wave (default 64); "kmer_filter" = 1/0 stage a small
+ * verified cooperatively by the whole wave (default 64); "hint_min_len" / "hint_max_len" = the
+ * caller's promise that every read of the coming batches has a length in that range (defaults
+ * 0 / 255 = unknown): a pass whose length window excludes the whole range is not launched; "kmer_filter" = 1/0 stage a small
  * library's 9-mer presence bitmap in LDS and skip the jump-table load of a seed piece whose
  * last 9 bases do not occur in the library (default 1); "ctx_wide_rows" = the same
  * threshold for libraries of >= 2^20 bases, whose cooperative path drops most rows by their

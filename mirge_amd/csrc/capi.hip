@@ -80,6 +80,7 @@ struct mrg_ctx {
   int64_t use_ftab = 1;
   int64_t force_lds_mode = -1;
   int64_t wide_rows = 64;
+  int64_t hint_min_len = 0, hint_max_len = 255;  // length range of the reads of the coming batches
   int64_t kmer_filter = 1;
   int64_t ctx_wide_rows = 32;
   int64_t prefer_two_blocks = 1;
@@ -321,6 +322,10 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->ctx_wide_rows = value;
   } else if (k == "kmer_filter") {
     ctx->kmer_filter = value != 0;
+  } else if (k == "hint_min_len") {
+    ctx->hint_min_len = value;
+  } else if (k == "hint_max_len") {
+    ctx->hint_max_len = value;
   } else if (k == "wide_rows") {
     if (value < 1) return fail(MRG_ERR_ARG, "wide_rows must be >= 1");
     ctx->wide_rows = value;
@@ -404,6 +409,8 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
   // "unannotated" values for whatever it does not claim)
   HIP_TRY(hipMemsetAsync(stats, 0, kWsStatsBytes, stream));
   uint32_t prev_grid = 0, prev_seg_cap = 0;
+  int cur_list = 0;        // which of the two list buffers holds the newest survivor list
+  bool have_list = false;  // false: the next pass that runs reads the identity list of all reads
 
   HIP_TRY(hipEventRecord(ctx->ev[0], stream));
   for (uint32_t i = 0; i < n_pass; ++i) {
@@ -432,12 +439,23 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     p.lens = d_lens;
     p.nmask = d_nmask;
     p.n_total = (uint32_t)n;
-    p.idx_in = i == 0 ? nullptr : idx[(i - 1) & 1];
-    p.in_count = counts + ((i - 1) & 1) * mrg::kMaxSegments;
+    // A pass whose length window excludes every read of the batch (caller's hint: e.g. the
+    // hairpin pass, len > 25, on 22-nt reads) would only copy its input list: it is not launched;
+    // its counters stay zero and the next pass reads the same list.  (Never the last pass: that
+    // one writes the "unannotated" values.)
+    if (i + 1 < n_pass && (c.min_len > ctx->hint_max_len || c.max_len < ctx->hint_min_len)) {
+      ctx->last_lds[i] = 0;
+      ctx->last_mode[i] = 0;
+      HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
+      continue;
+    }
+    const int next_list = have_list ? (cur_list ^ 1) : 0;
+    p.idx_in = have_list ? idx[cur_list] : nullptr;
+    p.in_count = counts + cur_list * mrg::kMaxSegments;
     p.in_nseg = prev_grid;
     p.in_seg_cap = prev_seg_cap;
-    p.idx_out = (i + 1 < n_pass) ? idx[i & 1] : nullptr;
-    p.out_count = counts + (i & 1) * mrg::kMaxSegments;
+    p.idx_out = (i + 1 < n_pass) ? idx[next_list] : nullptr;
+    p.out_count = counts + next_list * mrg::kMaxSegments;
     p.pass_id = d_pass_id;
     p.ref_id = d_ref_id;
     p.pos = d_pos;
@@ -510,8 +528,12 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     ctx->last_mode[i] = (uint32_t)lds_mode;
     if (n) HIP_TRY(mrg::launch_match(p, words_per_read, lds_mode, grid, lds_total, stream));
     HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
-    prev_grid = grid;
-    prev_seg_cap = seg_cap;
+    if (p.idx_out) {
+      cur_list = next_list;
+      have_list = true;
+      prev_grid = grid;
+      prev_seg_cap = seg_cap;
+    }
   }
   if (d_pass_counts) HIP_TRY(mrg::launch_export_pass_counts(stats, n_pass, d_pass_counts, stream));
   ctx->last_stream = stream;

@@ -50,7 +50,10 @@ class ReadSet:
         self.W, self.n = words.shape
         self.device = torch.device(device)
         self.words = torch.from_numpy(words.view(np.int64)).to(self.device)
-        self.lens = torch.from_numpy(np.ascontiguousarray(lens, dtype=np.uint8)).to(self.device)
+        lens = np.ascontiguousarray(lens, dtype=np.uint8)
+        self.min_len = int(lens.min()) if lens.size else 0
+        self.max_len = int(lens.max()) if lens.size else 255
+        self.lens = torch.from_numpy(lens).to(self.device)
         self.nmask = None
         if nmask is not None:
             nm = np.ascontiguousarray(nmask, dtype=np.uint64)
@@ -174,6 +177,9 @@ class Engine:
                    torch.zeros(2 * n_pass, dtype=torch.int64, device=dev))
         pass_id, ref_id, pos, mm, pass_counts = out
         ws = self._workspace(n)
+        # the length range of this batch (known on the host): passes whose window excludes it are skipped
+        self.set_option("hint_min_len", reads.min_len)
+        self.set_option("hint_max_len", reads.max_len)
         check(self._lib.mrg_cascade_run(
             self._h, reads.words.data_ptr(), reads.W, reads.lens.data_ptr(),
             reads.nmask.data_ptr() if reads.nmask is not None else None, n, passes, n_pass,

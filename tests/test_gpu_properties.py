@@ -104,3 +104,26 @@ def test_collapse_round_trip(big):
     cu = eng.tally(rs_u, res_u, M).cpu().numpy()
     cr = eng.tally(rs_r, res_r, M).cpu().numpy()
     assert np.array_equal(cu[:-3], cr[:-3])                              # trimmedUniq counts uniques, the rest agrees
+
+
+def test_pass_without_eligible_reads_is_skipped(big):
+    """All reads are 22 nt, so the hairpin pass (len > 25) cannot be offered any: with the host's
+    length hint it is not launched (zero counters, no LDS), and nothing else changes."""
+    eng, libs, words, lens = big
+    m = 500_000
+    w, l = np.ascontiguousarray(words[:, :m]), lens[:m]
+    _, res = run(eng, w, l)
+    a = res.to_host()
+    st = res.stats
+    assert (st[1]["processed"], st[1]["aligned"], st[1]["lds_bytes"]) == (0, 0, 0) and st[1]["ms"] < 0.05
+    # the same batch declared as "lengths unknown": the pass runs (and still claims nothing)
+    from mirge_amd.engine import ReadSet
+    rs = ReadSet(w, l, None, None, device=eng.device)
+    rs.min_len, rs.max_len = 0, 255
+    res2 = eng.cascade(rs, eng.mirge_passes())
+    for x, y in zip(a, res2.to_host()):
+        assert np.array_equal(x, y)
+    st2 = res2.stats
+    assert st2[1]["lds_bytes"] > 0 and st2[1]["processed"] == 0
+    for i in (0, 2, 3, 4, 5, 6, 7, 8):
+        assert (st[i]["processed"], st[i]["aligned"]) == (st2[i]["processed"], st2[i]["aligned"])
