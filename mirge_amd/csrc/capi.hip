@@ -773,8 +773,22 @@ int mrg_annotate_host(mrg_ctx* ctx, const uint64_t* reads, uint32_t words_per_re
     HIP_TRY(hipMemcpy(d_lens, lens, n, hipMemcpyHostToDevice));
     if (nmask) HIP_TRY(hipMemcpy(d_nmask, nmask, rbytes, hipMemcpyHostToDevice));
   }
-  rc = mrg_cascade_run(ctx, d_reads, words_per_read, d_lens, d_nmask, n, passes, n_pass, d_pass, d_ref,
-                       d_pos, d_mm, d_pc, d_ws, ws_bytes, nullptr);
+  {
+    // the lengths are on the host here: give the cascade the exact range of this batch (and put
+    // the caller's own hints back afterwards)
+    const int64_t keep_min = ctx->hint_min_len, keep_max = ctx->hint_max_len;
+    uint8_t lo = 255, hi = 0;
+    for (uint64_t r = 0; r < n; ++r) {
+      lo = std::min(lo, lens[r]);
+      hi = std::max(hi, lens[r]);
+    }
+    ctx->hint_min_len = n ? lo : 0;
+    ctx->hint_max_len = n ? hi : 255;
+    rc = mrg_cascade_run(ctx, d_reads, words_per_read, d_lens, d_nmask, n, passes, n_pass, d_pass, d_ref,
+                         d_pos, d_mm, d_pc, d_ws, ws_bytes, nullptr);
+    ctx->hint_min_len = keep_min;
+    ctx->hint_max_len = keep_max;
+  }
   if (rc) return rc;
   std::vector<mrg_pass_stats> st(n_pass);
   if ((rc = mrg_cascade_stats(ctx, st.data(), n_pass))) return rc;

@@ -177,7 +177,8 @@ class Engine:
                    torch.zeros(2 * n_pass, dtype=torch.int64, device=dev))
         pass_id, ref_id, pos, mm, pass_counts = out
         ws = self._workspace(n)
-        # the length range of this batch (known on the host): passes whose window excludes it are skipped
+        # the length range of this batch (known on the host): passes whose window excludes it are
+        # skipped; set before every run so that a hint never outlives its batch
         self.set_option("hint_min_len", reads.min_len)
         self.set_option("hint_max_len", reads.max_len)
         check(self._lib.mrg_cascade_run(
