@@ -188,7 +188,12 @@ def main():
         return 16.0 * s["processed"] + 64.0 * s["steps"]
 
     groups = {}
+    # a pass whose length window excludes the whole batch is not launched (host length hint)
+    skipped = [s["processed"] == 0 and s["lds_bytes"] == 0 and per_pass_ms[i] < 0.05 and i + 1 < len(st)
+               for i, s in enumerate(st)]
     for i, s in enumerate(st):
+        if skipped[i]:
+            continue
         # <W, occ blocks in LDS, text in LDS, stratum-first (the 2-mismatch policy), row context
         # (libraries of >= 2^20 bases, never with the text in LDS)>
         # ..., 9-mer bitmap in LDS (libraries of at most 190 000 bases)>
@@ -230,7 +235,9 @@ def main():
         passes_report.append(dict(
             lib=table[i][0], ms=round(float(per_pass_ms[i]), 4), processed=s["processed"],
             aligned=s["aligned"], steps=s["steps"], candidates=s["candidates"], lookups=s["lookups"],
-            lds_bytes=s["lds_bytes"], kernel="match_kernel<%d,%s%s>" % (rs.W, ["hbm", "blocks", "blocks+text", "text"][s["lds_mode"]],
+            lds_bytes=s["lds_bytes"],
+            kernel="not launched" if skipped[i] else
+                   "match_kernel<%d,%s%s>" % (rs.W, ["hbm", "blocks", "blocks+text", "text"][s["lds_mode"]],
                                              ",strata" if table[i][4] == 2 else ""),
             alg_gbs=round(alg_bytes(s) / max(per_pass_ms[i], 1e-9) / 1e6, 1)))
 
