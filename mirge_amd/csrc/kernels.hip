@@ -370,6 +370,15 @@ match_kernel(const MatchParams p) {
           if (W > 1 && (at & 31u) + kKmerBitsK > 32u) v |= pick_word<W>(rd, (at >> 5) + 1u) << (64u - (at & 31u) * 2u);
           const uint32_t c9 = (uint32_t)v & ((1u << (2u * kKmerBitsK)) - 1u);
           if (((skbits[c9 >> 5] >> (c9 & 31u)) & 1u) == 0u) continue;
+          if (b - a > (int32_t)kKmerBitsK) {
+            // ... and neither do its first 9 (a second, nearly independent test for longer pieces)
+            const uint32_t at0 = (uint32_t)a;
+            uint64_t v0 = pick_word<W>(rd, at0 >> 5) >> ((at0 & 31u) * 2u);
+            if (W > 1 && (at0 & 31u) + kKmerBitsK > 32u)
+              v0 |= pick_word<W>(rd, (at0 >> 5) + 1u) << (64u - (at0 & 31u) * 2u);
+            const uint32_t c0 = (uint32_t)v0 & ((1u << (2u * kKmerBitsK)) - 1u);
+            if (((skbits[c0 >> 5] >> (c0 & 31u)) & 1u) == 0u) continue;
+          }
         }
         // ---- exact backward search of read[a,b) ----
         uint32_t lo = 0, hi = p.n + 1;

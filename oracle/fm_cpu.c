@@ -91,6 +91,12 @@ static int match_one(const orc_lib *l, const orc_pass *p, const uint64_t *rd, co
       for (int t = 0; t < 9; ++t)
         c9 |= (uint32_t)((rd[(b - 9 + t) >> 5] >> (((b - 9 + t) & 31) * 2)) & 3ull) << (2 * t);
       if (!((l->kbits[c9 >> 5] >> (c9 & 31)) & 1u)) continue;
+      if (b - a > 9) { /* ... nor its first 9 */
+        uint32_t c0 = 0;
+        for (int t = 0; t < 9; ++t)
+          c0 |= (uint32_t)((rd[(a + t) >> 5] >> (((a + t) & 31) * 2)) & 3ull) << (2 * t);
+        if (!((l->kbits[c0 >> 5] >> (c0 & 31)) & 1u)) continue;
+      }
     }
     uint32_t lo = 0, hi = l->n + 1;
     int j = b;
