@@ -138,7 +138,10 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * library's 9-mer presence bitmap in LDS and skip the jump-table load of a seed piece whose
  * last 9 bases do not occur in the library (default 1); "ctx_wide_rows" = the same
  * threshold for libraries of >= 2^20 bases, whose cooperative path drops most rows by their
- * stored text context (default 32). */
+ * stored text context (default 32); "fuse" = 0 one launch per pass, 1 (default)
+ * consecutive passes with at most one seed mismatch after the first launched pass share one
+ * fused launch per run of small (bitmap-filtered) / large libraries, 2 = one group regardless of
+ * library size, 3 = only the small-library runs are fused. */
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);
 int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,
                         char *arch, uint32_t arch_cap);
@@ -163,10 +166,17 @@ typedef struct mrg_pass_stats {
   uint64_t steps;      /* FM backward-extension (LF) steps executed */
   uint64_t candidates; /* seed occurrences verified against the text */
   uint64_t lookups;    /* k-mer jump-table loads (each replaces k LF steps) */
-  float ms;            /* device time of the pass (the reference's cpuTime) */
+  float ms;            /* device time of the pass (the reference's cpuTime); a fused launch is
+                          charged to its first pass, the other passes of the group report 0 */
   uint32_t lds_bytes;  /* library bytes staged in LDS for this pass (0 = served from HBM/L2) */
   uint32_t lds_mode;   /* 0 nothing, 1 occ blocks, 2 occ blocks + text, 3 text only: names the
-                          match_kernel<W, blocks, text> instantiation that ran */
+                          match_kernel<W, blocks, text> instantiation that ran; 4 = the pass ran
+                          inside a fused launch (fused_kernel<W>, only its 9-mer bitmap in LDS) */
+  uint32_t group;      /* index of the first pass of the launch this pass ran in (itself when it
+                          had a launch of its own) */
+  uint32_t kbits_log2; /* log2 of the bits of the 9-mer presence bitmap the pass filtered seed
+                          pieces with (18 = the library's full bitmap, 13..17 = folded for a
+                          fused launch, 0 = no filter) */
 } mrg_pass_stats;
 
 /* Bytes of device workspace mrg_cascade_run needs for n reads. */

@@ -50,6 +50,9 @@ struct DevLib {
   uint64_t* sa = nullptr;
   uint32_t* ctx = nullptr;
   uint32_t* kbits = nullptr;
+  // the 9-mer bitmap folded to 2^17 .. 2^13 bits (bit h = OR of the 9-mers with code & (bits - 1) == h),
+  // one allocation, for fused launches whose LDS cannot hold every library's full bitmap
+  uint32_t* kbits_folds = nullptr;
   uint32_t* ftab = nullptr;
   mrg::JumpTables tabs = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   uint32_t n = 0, nblk = 0, nsup = 0, primary = 0, text_words = 0, n_seg = 0, n_ref = 0;
@@ -84,6 +87,10 @@ struct mrg_ctx {
   int64_t kmer_filter = 1;
   int64_t ctx_wide_rows = 32;
   int64_t prefer_two_blocks = 1;
+  // 0 = one launch per pass; 1 = consecutive passes with at most one seed mismatch share a launch,
+  // small (bitmap-filtered) and large libraries in separate groups; 2 = one group regardless of
+  // library size; 3 = only the small-library runs are fused
+  int64_t fuse = 1;
   std::vector<DevLib> libs;
   // last run
   hipStream_t last_stream = nullptr;
@@ -91,6 +98,8 @@ struct mrg_ctx {
   uint32_t last_n_pass = 0;
   uint32_t last_lds[MRG_MAX_PASSES] = {0};
   uint32_t last_mode[MRG_MAX_PASSES] = {0};
+  uint32_t last_group[MRG_MAX_PASSES] = {0};
+  uint32_t last_kbits_log2[MRG_MAX_PASSES] = {0};
   hipEvent_t ev[MRG_MAX_PASSES + 1] = {nullptr};
   bool ev_ready = false;
 };
@@ -252,6 +261,7 @@ void mrg_ctx_destroy(mrg_ctx* ctx) {
     (void)hipFree(l.ftab);
     (void)hipFree(l.ctx);
     (void)hipFree(l.kbits);
+    (void)hipFree(l.kbits_folds);
     (void)hipFree(l.seg_start);
     (void)hipFree(l.seg_ref);
     (void)hipFree(l.seg_off);
@@ -299,6 +309,17 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
   if ((rc = upload(&l.ftab, ix.ftab))) return rc;
   if (!ix.ctx.empty() && (rc = upload(&l.ctx, ix.ctx))) return rc;
   if (!ix.kbits.empty() && (rc = upload(&l.kbits, ix.kbits))) return rc;
+  if (!ix.kbits.empty()) {
+    // folds of 2^17, 2^16, ... 2^13 bits back to back (word offsets: see fold_offset_words)
+    std::vector<uint32_t> folds, cur = ix.kbits;
+    for (int lg = 17; lg >= 13; --lg) {
+      std::vector<uint32_t> half(cur.size() / 2);
+      for (size_t i = 0; i < half.size(); ++i) half[i] = cur[i] | cur[i + half.size()];
+      folds.insert(folds.end(), half.begin(), half.end());
+      cur.swap(half);
+    }
+    if ((rc = upload(&l.kbits_folds, folds))) return rc;
+  }
   if ((rc = upload(&l.seg_start, ix.seg_start))) return rc;
   if ((rc = upload(&l.seg_ref, ix.seg_ref))) return rc;
   if ((rc = upload(&l.seg_off, ix.seg_off))) return rc;
@@ -336,6 +357,9 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->force_lds_mode = value;
   } else if (k == "ftab") {
     ctx->use_ftab = value != 0;
+  } else if (k == "fuse") {
+    if (value < 0 || value > 3) return fail(MRG_ERR_ARG, "fuse must be in [0,3]");
+    ctx->fuse = value;
   } else {
     return fail(MRG_ERR_ARG, "mrg_ctx_set_option: unknown key '%s'", key);
   }
@@ -413,7 +437,32 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
   bool have_list = false;  // false: the next pass that runs reads the identity list of all reads
 
   HIP_TRY(hipEventRecord(ctx->ev[0], stream));
+
+  // ---- launch plan: which passes run, and which consecutive ones share a (fused) launch ----
+  // A pass whose length window excludes every read of the batch (caller's hint: e.g. the hairpin
+  // pass, len > 25, on 22-nt reads) would only copy its input list: it is not launched; its
+  // counters stay zero and the next pass reads the same list.  (Never the last pass: that one
+  // writes the "unannotated" values.)
+  bool runs[MRG_MAX_PASSES];
   for (uint32_t i = 0; i < n_pass; ++i) {
+    const mrg_pass_cfg& c = passes[i];
+    runs[i] = !(i + 1 < n_pass && (c.min_len > ctx->hint_max_len || c.max_len < ctx->hint_min_len));
+    ctx->last_lds[i] = 0;
+    ctx->last_mode[i] = 0;
+    ctx->last_group[i] = i;
+    ctx->last_kbits_log2[i] = 0;
+  }
+  auto fusable = [&](uint32_t i) {
+    // the first launched pass streams the whole read set and keeps the classic kernel (library
+    // text + full bitmap in LDS); 2-mismatch policies have their own stratum-first instantiation.
+    // (A fused launch counts offered / aligned reads in 16-bit per-lane fields: one workgroup per
+    // CU must see fewer than 65536 chunks.)
+    return ctx->fuse != 0 && passes[i].max_mm_seed <= 1 && n / (1024ull * (uint64_t)std::max(ctx->n_cu, 1)) < 60000ull;
+  };
+  auto small_lib = [&](uint32_t i) { return ctx->libs[passes[i].lib].kbits != nullptr && ctx->kmer_filter; };
+
+  // the classic path: one match_kernel launch for pass i
+  auto run_single = [&](uint32_t i) -> int {
     const mrg_pass_cfg& c = passes[i];
     const DevLib& l = ctx->libs[c.lib];
     mrg::MatchParams p;
@@ -439,16 +488,6 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     p.lens = d_lens;
     p.nmask = d_nmask;
     p.n_total = (uint32_t)n;
-    // A pass whose length window excludes every read of the batch (caller's hint: e.g. the
-    // hairpin pass, len > 25, on 22-nt reads) would only copy its input list: it is not launched;
-    // its counters stay zero and the next pass reads the same list.  (Never the last pass: that
-    // one writes the "unannotated" values.)
-    if (i + 1 < n_pass && (c.min_len > ctx->hint_max_len || c.max_len < ctx->hint_min_len)) {
-      ctx->last_lds[i] = 0;
-      ctx->last_mode[i] = 0;
-      HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
-      continue;
-    }
     const int next_list = have_list ? (cur_list ^ 1) : 0;
     p.idx_in = have_list ? idx[cur_list] : nullptr;
     p.in_count = counts + cur_list * mrg::kMaxSegments;
@@ -526,6 +565,8 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     p.out_seg_cap = seg_cap;
     ctx->last_lds[i] = lds_bytes;
     ctx->last_mode[i] = (uint32_t)lds_mode;
+    ctx->last_group[i] = i;
+    ctx->last_kbits_log2[i] = use_kbits ? 18u : 0u;
     if (n) HIP_TRY(mrg::launch_match(p, words_per_read, lds_mode, grid, lds_total, stream));
     HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
     if (p.idx_out) {
@@ -534,6 +575,180 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
       prev_grid = grid;
       prev_seg_cap = seg_cap;
     }
+    return MRG_OK;
+  };
+
+  // one fused_kernel launch for the running passes among [first, last]
+  auto run_fused = [&](const uint32_t* members, uint32_t n_sub, bool ends_cascade) -> int {
+    mrg::FusedParams fp;
+    std::memset(&fp, 0, sizeof fp);
+    fp.n_sub = n_sub;
+    // bitmap sizes: start from the full 2^18 bits of every small library and halve the one with
+    // the lowest fill until the group fits the LDS of two workgroups per CU
+    uint32_t lg[mrg::kMaxFused];
+    for (uint32_t q = 0; q < n_sub; ++q) lg[q] = small_lib(members[q]) ? 18u : 0u;
+    // one 1024-thread workgroup per CU (128 VGPRs per lane), so the whole LDS is its own
+    const uint64_t fixed = mrg::fused_fixed_lds_bytes();
+    const uint64_t lds_cap = 160 * 1024;
+    const uint64_t budget = lds_cap - fixed;
+    for (;;) {
+      uint64_t tot = 0;
+      for (uint32_t q = 0; q < n_sub; ++q) tot += lg[q] ? (1ull << lg[q]) / 8 : 0;
+      if (tot <= budget) break;
+      int pick = -1;
+      double best_fill = 0;
+      for (uint32_t q = 0; q < n_sub; ++q) {
+        if (lg[q] <= 13u) continue;
+        const double fill = (double)ctx->libs[passes[members[q]].lib].n / (double)(1ull << lg[q]);
+        if (pick < 0 || fill < best_fill) {
+          pick = (int)q;
+          best_fill = fill;
+        }
+      }
+      if (pick < 0) {  // everything at the minimum and still too large: drop the emptiest filter
+        for (uint32_t q = 0; q < n_sub; ++q)
+          if (lg[q]) pick = (int)q;
+        if (pick < 0) break;
+        lg[pick] = 0;
+        continue;
+      }
+      --lg[pick];
+    }
+    uint32_t kb_words = 0;
+    for (uint32_t q = 0; q < n_sub; ++q) {
+      const uint32_t i = members[q];
+      const mrg_pass_cfg& c = passes[i];
+      const DevLib& l = ctx->libs[c.lib];
+      mrg::SubPass& sp = fp.sub[q];
+      sp.blocks = l.blocks;
+      sp.super = l.super;
+      sp.text = l.text;
+      sp.sa = l.sa;
+      sp.ctx = l.ctx;
+      sp.ftab = l.ftab;
+      sp.tabs = l.tabs;
+      if (!ctx->use_ftab) sp.tabs.k[0] = 0u;
+      sp.seg_start = l.seg_start;
+      sp.seg_ref = l.seg_ref;
+      sp.seg_off = l.seg_off;
+      sp.chunk_seg = l.chunk_seg;
+      sp.nmask = d_nmask;
+      sp.counters = stats + (size_t)i * kStatsPerPass;
+      sp.n = l.n;
+      sp.primary = l.primary;
+      sp.simple_segs = (l.n_seg == l.n_ref) ? 1u : 0u;
+      sp.kb_off = kb_words;
+      sp.kb_mask = lg[q] ? (1u << lg[q]) - 1u : 0u;
+      if (lg[q] == 18u) {
+        sp.kbits = l.kbits;
+      } else if (lg[q]) {
+        // folds are stored 2^17 first: word offset of the 2^lg fold
+        uint32_t off = 0;
+        for (uint32_t g = 17; g > lg[q]; --g) off += (1u << g) / 32u;
+        sp.kbits = l.kbits_folds + off;
+      }
+      kb_words += lg[q] ? (1u << lg[q]) / 32u : 0u;
+      sp.wide_rows = l.ctx ? (uint32_t)std::min<int64_t>(ctx->wide_rows, ctx->ctx_wide_rows) : (uint32_t)ctx->wide_rows;
+      sp.seed_len = c.seed_len;
+      sp.max_mm_seed = c.max_mm_seed;
+      sp.max_mm_total = c.max_mm_total;
+      sp.trim5 = c.trim5;
+      sp.trim3 = c.trim3;
+      sp.min_len = c.min_len;
+      sp.max_len = c.max_len;
+      sp.poly_t = c.poly_t;
+      sp.pass_index = (int32_t)i;
+      ctx->last_lds[i] = lg[q] ? (1u << lg[q]) / 8u : 0u;
+      ctx->last_mode[i] = 4u;
+      ctx->last_group[i] = members[0];
+      ctx->last_kbits_log2[i] = lg[q];
+    }
+    fp.kb_words = kb_words;
+    fp.reads = d_reads;
+    fp.lens = d_lens;
+    fp.nmask = d_nmask;
+    fp.n_total = (uint32_t)n;
+    fp.uniform_len = (ctx->hint_min_len == ctx->hint_max_len && ctx->hint_min_len > 0) ? (uint32_t)ctx->hint_min_len : 0u;
+    const int next_list = have_list ? (cur_list ^ 1) : 0;
+    fp.idx_in = have_list ? idx[cur_list] : nullptr;
+    fp.in_count = counts + cur_list * mrg::kMaxSegments;
+    fp.in_nseg = prev_grid;
+    fp.in_seg_cap = prev_seg_cap;
+    fp.idx_out = ends_cascade ? nullptr : idx[next_list];
+    fp.out_count = counts + next_list * mrg::kMaxSegments;
+    fp.pass_id = d_pass_id;
+    fp.ref_id = d_ref_id;
+    fp.pos = d_pos;
+    fp.mm = d_mm;
+    fp.wstop = (uint32_t)ctx->wstop;
+    // rounds: the bitmap-filtered sub-passes of a run are looked up together (few items per read),
+    // every other library gets a round of its own (each unclaimed read has items there)
+    fp.n_rounds = 0;
+    for (uint32_t q = 0; q < n_sub;) {
+      uint32_t e = q + 1;
+      if (lg[q])
+        while (e < n_sub && lg[e] && e - q < mrg::kMaxRoundSubs) ++e;
+      fp.round_first[fp.n_rounds] = (uint8_t)q;
+      fp.round_count[fp.n_rounds] = (uint8_t)(e - q);
+      ++fp.n_rounds;
+      q = e;
+    }
+    const uint32_t lds_total = kb_words * 4u + (uint32_t)fixed;
+    // 128 VGPRs per lane (no spills in the pipelined walk): 16 waves = one workgroup per CU
+    const uint32_t per_cu = 1u;
+    uint32_t grid = (uint32_t)ctx->n_cu * per_cu;
+    if (grid > mrg::kMaxSegments) grid = mrg::kMaxSegments;
+    const uint32_t seg_cap = (uint32_t)(((n + 1024ull * grid - 1) / (1024ull * grid)) * 1024ull);
+    fp.out_seg_cap = seg_cap;
+    if (n) HIP_TRY(mrg::launch_fused(fp, words_per_read, grid, lds_total, stream));
+    for (uint32_t q = 0; q < n_sub; ++q) HIP_TRY(hipEventRecord(ctx->ev[members[q] + 1], stream));
+    if (fp.idx_out) {
+      cur_list = next_list;
+      have_list = true;
+      prev_grid = grid;
+      prev_seg_cap = seg_cap;
+    }
+    return MRG_OK;
+  };
+
+  bool launched_any = false;
+  for (uint32_t i = 0; i < n_pass;) {
+    if (!runs[i]) {
+      HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
+      ++i;
+      continue;
+    }
+    uint32_t members[mrg::kMaxFused];
+    uint32_t n_sub = 0, j = i;
+    if (launched_any && fusable(i)) {
+      const bool cls = small_lib(i);
+      while (j < n_pass && n_sub < mrg::kMaxFused) {
+        if (!runs[j]) {
+          ++j;
+          continue;
+        }
+        if (!fusable(j)) break;
+        if (ctx->fuse != 2 && small_lib(j) != cls) break;
+        if (ctx->fuse == 3 && !cls) break;
+        members[n_sub++] = j++;
+      }
+      // passes skipped by the hint at the end of the run stay with the group (their events are
+      // recorded below); a trailing skipped pass is never the last pass of the cascade
+    }
+    if (n_sub >= 2) {
+      const bool ends = members[n_sub - 1] + 1 == n_pass;
+      // events of hint-skipped passes inside the group
+      int rc = run_fused(members, n_sub, ends);
+      if (rc != MRG_OK) return rc;
+      for (uint32_t q = i; q < j; ++q)
+        if (!runs[q]) HIP_TRY(hipEventRecord(ctx->ev[q + 1], stream));
+      i = j;
+    } else {
+      int rc = run_single(i);
+      if (rc != MRG_OK) return rc;
+      ++i;
+    }
+    launched_any = true;
   }
   if (d_pass_counts) HIP_TRY(mrg::launch_export_pass_counts(stats, n_pass, d_pass_counts, stream));
   ctx->last_stream = stream;
@@ -562,6 +777,8 @@ int mrg_cascade_stats(mrg_ctx* ctx, mrg_pass_stats* out, uint32_t n_pass) {
     out[i].ms = ms;
     out[i].lds_bytes = ctx->last_lds[i];
     out[i].lds_mode = ctx->last_mode[i];
+    out[i].group = ctx->last_group[i];
+    out[i].kbits_log2 = ctx->last_kbits_log2[i];
   }
   return MRG_OK;
 }

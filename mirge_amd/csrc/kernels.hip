@@ -145,6 +145,15 @@ __device__ __forceinline__ uint32_t read_bits(const uint64_t (&rd)[W], uint32_t 
   return (uint32_t)v & ((1u << (2u * c)) - 1u);
 }
 
+
+// the 9 bases of the read starting at base `at`, first base in the low two bits
+template <int W>
+__device__ __forceinline__ uint32_t read_bits9(const uint64_t (&rd)[W], uint32_t at) {
+  uint64_t v = pick_word<W>(rd, at >> 5) >> ((at & 31u) * 2u);
+  if (W > 1 && (at & 31u) + kKmerBitsK > 32u) v |= pick_word<W>(rd, (at >> 5) + 1u) << (64u - (at & 31u) * 2u);
+  return (uint32_t)v & ((1u << (2u * kKmerBitsK)) - 1u);
+}
+
 // Row context (FmIndex::ctx) of the candidates of one seed interval: all of them have `need_before`
 // read bases left of the row's position and `need_after` from it on, so what the read expects in
 // the context word -- the <= 8 bases before the position (bits 0-15, nearest in the top two) and
@@ -182,8 +191,8 @@ constexpr uint32_t kCtxMinRows = 8u;
 // One suffix-array row as a candidate alignment of a read whose seed search stopped with
 // `need_before` read bases left of the row's text position and `need_after` from it on.
 // Updates (best, best_seg, best_before) when the alignment is valid and better.
-template <int W, class LibT>
-__device__ __forceinline__ void verify_row(const LibT& lib, const MatchParams& p, const uint64_t row,
+template <int W, class LibT, class P>
+__device__ __forceinline__ void verify_row(const LibT& lib, const P& p, const uint64_t row,
                                            const uint64_t (&rd)[W], const uint64_t (&nm)[W], int32_t L,
                                            uint32_t need_before, uint32_t need_after, uint64_t& best,
                                            uint32_t& best_seg, uint32_t& best_before) {
@@ -543,6 +552,608 @@ match_kernel(const MatchParams p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// fused_kernel: consecutive cascade passes over ONE walk of the survivor list (see kernels.hpp).
+//
+// What the one-launch-per-pass kernels spend their time on for the libraries after the first is
+// not memory: it is instruction issue.  Every wave walks the list (list entry -> read, two
+// dependent HBM round trips per pass) and then runs all 64 lanes through every seed piece, every
+// jump-table load and a four-way unrolled verification although only one lane in four (small,
+// bitmap-filtered libraries) has anything to look up and a wave waits for its widest interval.
+// Here the work is compacted at three levels:
+//   reads  the walk happens once per group and is software-pipelined two chunks deep;
+//   items  a ROUND = a run of sub-passes (all the bitmap-filtered ones together, each large
+//          library on its own).  Every lane first runs the cheap part of all sub-passes of the
+//          round on its read -- length window, poly-T rule, piece geometry (cached while the
+//          search region does not change), 9-mer bitmap tests in LDS -- and ends up with a bit
+//          mask of (sub-pass, piece) WORK ITEMS that need the index.  The items of the 64 reads
+//          of a wave are compacted (wave prefix sum, owner found by a six-step search over the
+//          prefix): lane i takes item i, fetches the owner's read with a shuffle and that
+//          sub-pass's library pointers from an LDS table, and does the jump-table load and the
+//          (rare) LF steps;
+//   rows   the suffix-array rows of those 64 intervals are compacted the same way: lane i takes
+//          row i of the batch, whoever's interval it belongs to, loads it, verifies it against
+//          the text and folds a valid alignment into the item's 16-byte LDS slot with a 64-bit
+//          atomic min.  A 2-row and a 2000-row interval cost what their rows cost; there is no
+//          "wide interval" special case and no lane idles behind a long one.
+// The owner replays the item results in cascade order: a sub-pass claimed earlier hides the later
+// ones, an exact hit of piece 0 hides piece 1 -- exactly the items the sequential search would not
+// have issued, so the per-pass processed / aligned / steps / candidates / lookups counters stay
+// those of one launch per pass although the work itself was speculative.
+// Libraries are served from L2/HBM (a small one's packed text optionally from LDS); LDS holds the
+// folded 9-mer bitmaps, the sub-pass table, the result slots and the per-pass counters.  128
+// VGPRs per lane (16 waves = one 1024-thread workgroup per CU): the pipelined walk and the
+// per-lane library pointers do not fit 64 without spilling, and with dense lanes 16 waves keep
+// more useful loads in flight than 32 sparse ones.
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr uint32_t kSubWords = 40u;  // LDS words per sub-pass table entry
+enum SubWord : uint32_t {
+  SW_FTAB = 0, SW_SA = 2, SW_TEXT = 4, SW_CTX = 6, SW_BLOCKS = 8, SW_SUPER = 10, SW_TABK = 12, SW_TABOFF = 16,
+  SW_N = 20, SW_PRIMARY = 21, SW_POLICY = 22, SW_TRIMS = 23, SW_TEXT_LDS = 24, SW_SIMPLE = 25, SW_PASSIDX = 26,
+  SW_SEGSTART = 28, SW_SEGREF = 30, SW_SEGOFF = 32, SW_CHUNKSEG = 34
+};
+constexpr uint32_t kNoQ = 0xFFu;
+constexpr uint32_t kRowSlice = 1u << 20;  // rows of one interval taken into one compaction sweep
+
+struct ItemPolicy {  // what verify_row reads
+  int32_t seed_len, max_mm_seed, max_mm_total;
+  const uint64_t* nmask;
+};
+
+// text access of one item: packed text in LDS when the launch staged it, else global
+struct ItemLib {
+  const uint32_t* gtext;
+  const uint32_t* stext;  // null = not staged
+  __device__ __forceinline__ uint64_t window(uint32_t pos) const {
+    const uint32_t i = pos >> 4, sh = (pos & 15) * 2;
+    uint32_t w0, w1, w2;
+    if (stext) {
+      w0 = stext[i];
+      w1 = stext[i + 1];
+      w2 = stext[i + 2];
+    } else {
+      w0 = gtext[i];
+      w1 = gtext[i + 1];
+      w2 = gtext[i + 2];
+    }
+    const uint64_t lo64 = (uint64_t)w0 | ((uint64_t)w1 << 32);
+    return (lo64 >> sh) | ((((uint64_t)w2) << 1) << (63 - sh));
+  }
+};
+
+__device__ __forceinline__ const void* lds_ptr(const uint32_t* tab, uint32_t w) {
+  return reinterpret_cast<const void*>((uint64_t)tab[w] | ((uint64_t)tab[w + 1] << 32));
+}
+
+// number of trailing T of a read (RAP:664-686; an N is never a T)
+template <int W>
+__device__ __forceinline__ int32_t trailing_t(const uint64_t (&rd)[W], const uint64_t (&nm)[W], int32_t L) {
+  int32_t hb = -1;  // highest base that is not T
+#pragma unroll
+  for (int k = W - 1; k >= 0; --k) {
+    const int32_t nb = min(32, max(0, L - 32 * k));
+    const uint64_t x = (~rd[k] | nm[k] | (nm[k] << 1)) & low_bits(2 * nb);
+    if (hb < 0 && x != 0ull) hb = 32 * k + ((63 - __clzll((long long)x)) >> 1);
+  }
+  return L - 1 - hb;
+}
+
+template <int W>
+__device__ __forceinline__ bool piece_has_n(const uint64_t (&nm)[W], int32_t a, int32_t b) {
+  bool has_n = false;
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    const int32_t lo_b = max(a - 32 * w, 0), hi_b = min(b - 32 * w, 32);
+    if (hi_b > lo_b) has_n |= (nm[w] & low_bits(2 * hi_b) & ~low_bits(2 * lo_b)) != 0ull;
+  }
+  return has_n;
+}
+
+// first lane whose inclusive prefix exceeds x (x < total): six shuffles
+__device__ __forceinline__ uint32_t owner_of(uint32_t incl, uint32_t x) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int step = 32; step >= 1; step >>= 1) {
+    const uint32_t v = __shfl(incl, (int)(o + step - 1u), 64);
+    if (v <= x) o += (uint32_t)step;
+  }
+  return o;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(v, d, 64);
+    if ((int)lane >= d) v += up;
+  }
+  return v;
+}
+
+// bits 0..3 of x to bits 0, 16, 32, 48
+__device__ __forceinline__ uint64_t spread4(uint32_t x) {
+  return (uint64_t)(x & 1u) | ((uint64_t)(x & 2u) << 15) | ((uint64_t)(x & 4u) << 30) | ((uint64_t)(x & 8u) << 45);
+}
+
+}  // namespace
+
+template <int W>
+__global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  constexpr uint32_t BLOCK = 1024u;
+  // ---- LDS carve: [bitmaps][texts][sub-pass table][result slots][64-bit counters][control]
+  uint32_t* skb = smem;
+  uint32_t* stab = smem + p.kb_words + p.txt_words;
+  uint4* slots = reinterpret_cast<uint4*>(stab + kMaxFused * kSubWords);  // 64 per wave
+  unsigned long long* cnt64 = reinterpret_cast<unsigned long long*>(slots + BLOCK);
+  uint32_t* ctl = reinterpret_cast<uint32_t*>(cnt64 + kMaxFused * 3u * kFusedCntReplicas);
+  for (uint32_t s = 0; s < p.n_sub; ++s) {
+    const SubPass& sp = p.sub[s];
+    if (sp.kb_mask) {
+      const uint4* src = reinterpret_cast<const uint4*>(sp.kbits);
+      uint4* dst = reinterpret_cast<uint4*>(skb + sp.kb_off);
+      const uint32_t n16 = (sp.kb_mask + 1u) / 128u;
+      for (uint32_t i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
+    }
+    if (sp.text_lds_words) {
+      const uint4* src = reinterpret_cast<const uint4*>(sp.text);
+      uint4* dst = reinterpret_cast<uint4*>(smem + sp.text_lds_off);
+      for (uint32_t i = threadIdx.x; i < sp.text_lds_words / 4u; i += BLOCK) dst[i] = src[i];
+    }
+    if (threadIdx.x == 0) {
+      uint32_t* t = stab + s * kSubWords;
+      auto put = [&](uint32_t w, const void* ptr) {
+        t[w] = (uint32_t)(uint64_t)ptr;
+        t[w + 1] = (uint32_t)((uint64_t)ptr >> 32);
+      };
+      put(SW_FTAB, sp.ftab);
+      put(SW_SA, sp.sa);
+      put(SW_TEXT, sp.text);
+      put(SW_CTX, sp.ctx);
+      put(SW_BLOCKS, sp.blocks);
+      put(SW_SUPER, sp.super);
+      put(SW_SEGSTART, sp.seg_start);
+      put(SW_SEGREF, sp.seg_ref);
+      put(SW_SEGOFF, sp.seg_off);
+      put(SW_CHUNKSEG, sp.chunk_seg);
+      for (int i = 0; i < 4; ++i) {
+        t[SW_TABK + i] = sp.tabs.k[i];
+        t[SW_TABOFF + i] = sp.tabs.off[i];
+      }
+      t[SW_N] = sp.n;
+      t[SW_PRIMARY] = sp.primary;
+      t[SW_POLICY] = (uint32_t)min(sp.seed_len, 0xFFFF) | ((uint32_t)sp.max_mm_seed << 16) | ((uint32_t)sp.max_mm_total << 24);
+      t[SW_TRIMS] = (uint32_t)sp.trim5 | ((uint32_t)sp.trim3 << 8) | (sp.poly_t ? 1u << 16 : 0u);
+      t[SW_TEXT_LDS] = sp.text_lds_words ? sp.text_lds_off : 0xFFFFFFFFu;
+      t[SW_SIMPLE] = sp.simple_segs;
+      t[SW_PASSIDX] = (uint32_t)sp.pass_index;
+    }
+  }
+  for (uint32_t i = threadIdx.x; i < kMaxFused * 3u * kFusedCntReplicas; i += BLOCK) cnt64[i] = 0ull;
+  if (threadIdx.x == 0) {
+    ctl[0] = 0u;
+    ctl[1] = 0u;
+  }
+  __syncthreads();
+  if (p.idx_in) {
+    uint32_t mx = 0;
+    for (uint32_t sgi = threadIdx.x; sgi < p.in_nseg; sgi += BLOCK) mx = max(mx, p.in_count[sgi]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, off, 64));
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(&ctl[1], mx);
+  }
+  __syncthreads();
+
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint4* my_slots = slots + wave * 64u;
+  unsigned long long* my_slot_keys = reinterpret_cast<unsigned long long*>(my_slots);  // key of slot i at [2 i]
+  const bool has_nm = p.nmask != nullptr;
+  const uint32_t in_nseg = p.idx_in ? p.in_nseg : 1u;
+  const uint32_t depth_chunks = p.idx_in ? (ctl[1] + BLOCK - 1) / BLOCK : (p.n_total + BLOCK - 1) / BLOCK;
+  const uint32_t n_chunks = in_nseg * depth_chunks;
+  // per-lane 0/1 counters of the sub-passes, 16 bits each (a lane sees < 65536 reads per launch:
+  // the host falls back to one launch per pass otherwise): [0] sub-passes 0-3, [1] 4-7
+  uint64_t acc_offered[2] = {0ull, 0ull}, acc_aligned[2] = {0ull, 0ull};
+
+  // ---- the walk, software-pipelined: read of chunk + grid and list entry of chunk + 2 grid in flight
+  auto fetch_index = [&](uint32_t chunk, uint32_t& r_out) -> bool {
+    if (chunk >= n_chunks) return false;
+    const uint32_t sgi = chunk % in_nseg, depth = chunk / in_nseg;
+    const uint32_t t = depth * BLOCK + threadIdx.x;
+    const bool act = t < (p.idx_in ? p.in_count[sgi] : p.n_total);
+    r_out = 0;
+    if (act) r_out = p.idx_in ? p.idx_in[(size_t)sgi * p.in_seg_cap + t] : t;
+    return act;
+  };
+  uint32_t r_c = 0, r_b = 0;
+  bool act_b = fetch_index(blockIdx.x, r_b);
+  bool act_c = fetch_index(blockIdx.x + gridDim.x, r_c);
+  uint64_t rd_b[W], nm_b[W];
+  uint32_t L_b = 0;
+#pragma unroll
+  for (int k = 0; k < W; ++k) rd_b[k] = nm_b[k] = 0ull;
+  if (act_b) {
+    L_b = p.uniform_len ? p.uniform_len : (uint32_t)p.lens[r_b];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      rd_b[k] = p.reads[(size_t)k * p.n_total + r_b];
+      nm_b[k] = has_nm ? p.nmask[(size_t)k * p.n_total + r_b] : 0ull;
+    }
+  }
+
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const bool active = act_b;
+    const uint32_t r = r_b;
+    uint64_t rd0[W], nm0[W];
+    const uint32_t L0 = L_b;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      rd0[k] = rd_b[k];
+      nm0[k] = nm_b[k];
+    }
+    act_b = act_c;
+    r_b = r_c;
+    L_b = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) rd_b[k] = nm_b[k] = 0ull;
+    if (act_b) {
+      L_b = p.uniform_len ? p.uniform_len : (uint32_t)p.lens[r_b];
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        rd_b[k] = p.reads[(size_t)k * p.n_total + r_b];
+        nm_b[k] = has_nm ? p.nmask[(size_t)k * p.n_total + r_b] : 0ull;
+      }
+    }
+    act_c = fetch_index(chunk + 2u * gridDim.x, r_c);
+
+    bool claimed = !active;  // lanes without a read never take part
+    // piece geometry of the current search region (R bases, K pieces, 5' trim), reused by every
+    // sub-pass that searches the same region: for reads of at most 28 nt all the -n 1 / -v 1
+    // passes do
+    int32_t g_R = -1, g_K = 0, g_t5 = -1;
+    uint32_t g_code[4] = {0u, 0u, 0u, 0u};  // [2k] first, [2k + 1] last 9-mer of piece k
+    uint32_t g_meta = 0;                    // piece length k at bits 8k, "piece k holds an N" at bit 16 + k
+#pragma unroll 1
+    for (uint32_t rnd = 0; rnd < p.n_rounds; ++rnd) {
+      const uint32_t s0 = p.round_first[rnd], ns = p.round_count[rnd];
+      // ================= phase A: which (sub-pass, piece) items does my read need? =================
+      uint32_t need = 0;   // bit 2q + k: piece k of sub-pass s0 + q goes to the index
+      uint32_t elig = 0;   // bit q: my read is in sub-pass s0 + q's FASTA if nothing claims it before
+#pragma unroll 1
+      for (uint32_t q = 0; q < ns; ++q) {
+        const SubPass& sp = p.sub[s0 + q];
+        bool el = !claimed && (int32_t)L0 >= sp.min_len && (int32_t)L0 <= sp.max_len;
+        int32_t L = (int32_t)L0;
+        if (sp.poly_t) {
+          const int32_t tail = trailing_t<W>(rd0, nm0, L);
+          el = el && tail >= 3 && (L - tail) >= 11;
+          L -= tail;
+        }
+        L -= sp.trim5 + sp.trim3;
+        if (el) elig |= 1u << q;
+        const int32_t R = min(L, sp.seed_len), K = sp.max_mm_seed + 1;
+        const bool go = el && L > sp.max_mm_seed;
+        if (go && (R != g_R || K != g_K || sp.trim5 != g_t5)) {
+          uint64_t rd[W], nm[W];
+#pragma unroll
+          for (int k = 0; k < W; ++k) {
+            rd[k] = rd0[k];
+            nm[k] = nm0[k];
+          }
+          if (sp.trim5) {
+            shift_out_5p<W>(rd, (uint32_t)sp.trim5);
+            if (has_nm) shift_out_5p<W>(nm, (uint32_t)sp.trim5);
+          }
+          g_R = R;
+          g_K = K;
+          g_t5 = sp.trim5;
+          g_meta = 0;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            if (k < K) {
+              const int32_t a = div_pieces(R * k, K), b = div_pieces(R * (k + 1), K);
+              g_meta |= (uint32_t)min(b - a, 255) << (8 * k);
+              if (has_nm && piece_has_n<W>(nm, a, b)) g_meta |= 1u << (16 + k);
+              if (b - a >= (int32_t)kKmerBitsK) {
+                g_code[2 * k] = read_bits9<W>(rd, (uint32_t)a);
+                g_code[2 * k + 1] = read_bits9<W>(rd, (uint32_t)b - kKmerBitsK);
+              }
+            }
+          }
+        }
+        const uint32_t* kb = skb + sp.kb_off;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const uint32_t plen = (g_meta >> (8 * k)) & 0xFFu;
+          bool pass = go && k < K && ((g_meta >> (16 + k)) & 1u) == 0u;
+          if (sp.kb_mask) {
+            const uint32_t cl = g_code[2 * k + 1] & sp.kb_mask, cf = g_code[2 * k] & sp.kb_mask;
+            const uint32_t bl = (kb[cl >> 5] >> (cl & 31u)) & 1u, bf = (kb[cf >> 5] >> (cf & 31u)) & 1u;
+            const bool filt = plen < kKmerBitsK || (bl && (plen == kKmerBitsK || bf));
+            pass = pass && filt;
+          }
+          need |= (pass ? 1u : 0u) << (2u * q + (uint32_t)k);
+        }
+      }
+
+      // ================= phase B: compact the items of the wave, one item per lane =================
+      const uint32_t cnt = (uint32_t)__popc(need);
+      const uint32_t incl = wave_incl_scan(cnt, lane);
+      const uint32_t excl = incl - cnt;
+      const uint32_t total = __shfl(incl, 63, 64);
+
+      // owner-side replay state (cascade order = item order)
+      uint64_t win_key = ~0ull;   // result of the sub-pass that claims the read
+      uint32_t win_q = kNoQ;      // which one
+      uint64_t q_best = ~0ull;    // best result inside the sub-pass being replayed
+      uint32_t q_cur = kNoQ;
+
+      for (uint32_t base = 0; base < total; base += 64u) {
+        const uint32_t item = base + lane;
+        const bool has_item = item < total;
+        uint32_t o = owner_of(incl, item);
+        o = has_item ? o : lane;
+        const uint32_t o_excl = __shfl(excl, (int)o, 64);
+        uint32_t o_need = __shfl(need, (int)o, 64);
+        uint64_t rd[W], nm[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          rd[k] = __shfl(rd0[k], (int)o, 64);
+          nm[k] = has_nm ? __shfl(nm0[k], (int)o, 64) : 0ull;
+        }
+        int32_t L = (int32_t)__shfl(L0, (int)o, 64);
+        uint32_t combo = 0;
+        if (has_item) {
+          for (uint32_t jj = item - o_excl; jj > 0; --jj) o_need &= o_need - 1u;
+          combo = (uint32_t)__ffs((int)o_need) - 1u;
+        }
+        const uint32_t q = combo >> 1, kpiece = combo & 1u;
+        const uint32_t* tab = stab + (s0 + q) * kSubWords;
+        const uint32_t polw = tab[SW_POLICY], trimw = tab[SW_TRIMS];
+        uint32_t c_steps = 0, lo = 0, hi = 0, nb_na = 0;
+        if (has_item) {
+          // the read this sub-pass searches: poly-T strip, then -5 / -3
+          if (trimw >> 16) L -= trailing_t<W>(rd, nm, L);
+          const uint32_t t5 = trimw & 0xFFu;
+          L -= (int32_t)(t5 + ((trimw >> 8) & 0xFFu));
+          if (t5) {
+            shift_out_5p<W>(rd, t5);
+            if (has_nm) shift_out_5p<W>(nm, t5);
+          }
+          const int32_t R = min(L, (int32_t)(polw & 0xFFFFu));
+          const int32_t K = (int32_t)((polw >> 16) & 0xFFu) + 1;
+          const int32_t a = div_pieces(R * (int32_t)kpiece, K), b = div_pieces(R * ((int32_t)kpiece + 1), K);
+          hi = tab[SW_N] + 1u;
+          int32_t j = b;
+          // the largest jump table the piece is long enough for
+          uint32_t tk = 0, tab_off = 0;
+          if (tab[SW_TABK]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const uint32_t ki = tab[SW_TABK + i];
+              const bool take = (b - a) >= (int32_t)ki;
+              tk = take ? ki : tk;
+              tab_off = take ? tab[SW_TABOFF + i] : tab_off;
+            }
+          }
+          if (tk) {
+            j = b - (int32_t)tk;
+            uint64_t code = pick_word<W>(rd, (uint32_t)j >> 5) >> ((j & 31) * 2);
+            if (W > 1 && (j & 31) + (int32_t)tk > 32)
+              code |= pick_word<W>(rd, ((uint32_t)j >> 5) + 1) << (64 - (j & 31) * 2);
+            code &= (1ull << (2 * tk)) - 1ull;
+            const uint32_t* ft = reinterpret_cast<const uint32_t*>(lds_ptr(tab, SW_FTAB)) + tab_off + lex_code(code, tk);
+            lo = ft[0];
+            hi = ft[1];
+            c_steps = 0x80000000u;  // bit 31: the item did a jump-table load
+          }
+          if (j > a && hi > lo && (hi - lo) > p.wstop) {
+            Lib<false, false> lib;
+            lib.gblocks = reinterpret_cast<const uint32_t*>(lds_ptr(tab, SW_BLOCKS));
+            lib.gtext = nullptr;
+            lib.sblocks = nullptr;
+            lib.stext = nullptr;
+            lib.ssuper = reinterpret_cast<const uint32_t*>(lds_ptr(tab, SW_SUPER));
+            lib.primary = tab[SW_PRIMARY];
+            while (j > a && hi > lo && (hi - lo) > p.wstop) {
+              --j;
+              const uint32_t c = (uint32_t)(pick_word<W>(rd, (uint32_t)j >> 5) >> ((j & 31) * 2)) & 3u;
+              const uint4 vl = lib.block(lo >> 5);
+              uint4 vh = vl;
+              if ((hi >> 5) != (lo >> 5)) vh = lib.block(hi >> 5);
+              lo = lib.lf(c, lo, vl);
+              hi = lib.lf(c, hi, vh);
+              ++c_steps;
+            }
+          }
+          nb_na = (uint32_t)j | ((uint32_t)(L - j) << 8);
+        }
+        uint32_t rem = (has_item && hi > lo) ? hi - lo : 0u;
+        // result slot of my item: key = mm:8 | text position:32 | segment:16 | before:8 (all ones = none)
+        my_slots[lane] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, rem, c_steps);
+        __builtin_amdgcn_wave_barrier();
+
+        // ---------- rows: every suffix-array row of the 64 intervals, one per lane ----------
+        while (__ballot(rem != 0u)) {
+          const uint32_t w = min(rem, kRowSlice);
+          const uint32_t rincl = wave_incl_scan(w, lane);
+          const uint32_t rtotal = __shfl(rincl, 63, 64);
+          for (uint32_t rb = 0; rb < rtotal; rb += 64u) {
+            const uint32_t x = rb + lane;
+            const bool has_row = x < rtotal;
+            uint32_t t = owner_of(rincl, x);
+            t = has_row ? t : lane;
+            const uint32_t t_incl = __shfl(rincl, (int)t, 64), t_w = __shfl(w, (int)t, 64);
+            const uint32_t t_lo = __shfl(lo, (int)t, 64);
+            const uint32_t t_nbna = __shfl(nb_na, (int)t, 64);
+            const uint32_t t_q = __shfl(q, (int)t, 64);
+            const int32_t t_L = __shfl(L, (int)t, 64);
+            uint64_t t_rd[W], t_nm[W];
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+              t_rd[k] = __shfl(rd[k], (int)t, 64);
+              t_nm[k] = has_nm ? __shfl(nm[k], (int)t, 64) : 0ull;
+            }
+            if (has_row) {
+              const uint32_t* ttab = stab + (s0 + t_q) * kSubWords;
+              const uint32_t tpol = ttab[SW_POLICY];
+              ItemPolicy pol;
+              pol.seed_len = (int32_t)(tpol & 0xFFFFu);
+              pol.max_mm_seed = (int32_t)((tpol >> 16) & 0xFFu);
+              pol.max_mm_total = (int32_t)(tpol >> 24);
+              pol.nmask = p.nmask;
+              const uint32_t i = t_lo + (x - (t_incl - t_w));
+              const uint32_t need_before = t_nbna & 0xFFu, need_after = t_nbna >> 8;
+              bool keep = true;
+              const uint32_t* ctxp = reinterpret_cast<const uint32_t*>(lds_ptr(ttab, SW_CTX));
+              if (ctxp && t_w >= kCtxMinRows) {
+                // wide interval of a large library: most rows are dropped by their stored context
+                const uint2 probe = context_probe<W>(t_rd, need_before, need_after);
+                keep = (int32_t)context_mismatches(ctxp[i], probe) <= pol.max_mm_total;
+              }
+              if (keep) {
+                ItemLib lib;
+                lib.gtext = reinterpret_cast<const uint32_t*>(lds_ptr(ttab, SW_TEXT));
+                const uint32_t tl = ttab[SW_TEXT_LDS];
+                lib.stext = tl != 0xFFFFFFFFu ? smem + tl : nullptr;
+                const uint64_t row = reinterpret_cast<const uint64_t*>(lds_ptr(ttab, SW_SA))[i];
+                uint64_t best = ~0ull;
+                uint32_t best_seg = 0xFFFFu, best_before = 255u;
+                verify_row<W>(lib, pol, row, t_rd, t_nm, t_L, need_before, need_after, best, best_seg, best_before);
+                if (best != ~0ull) {
+                  const uint64_t key = ((best >> 32) << 56) | ((best & 0xFFFFFFFFull) << 24) |
+                                       ((uint64_t)(best_seg & 0xFFFFu) << 8) | (uint64_t)(best_before & 0xFFu);
+                  atomicMin(&my_slot_keys[2u * t], (unsigned long long)key);
+                }
+              }
+            }
+          }
+          lo += w;
+          rem -= w;
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ================= phase C: owners replay their items of this batch in cascade order =================
+        // my items are [excl, excl + cnt); those inside [base, base + 64) sit in slots item - base
+        {
+          const uint32_t first = max(excl, base), last = min(excl + cnt, base + 64u);
+          uint32_t bits = need;
+          for (uint32_t jj = excl; jj < first && jj < excl + cnt; ++jj) bits &= bits - 1u;  // replayed in earlier batches
+          for (uint32_t it = first; it < last; ++it) {
+            const uint32_t cb = (uint32_t)__ffs((int)bits) - 1u;
+            bits &= bits - 1u;
+            const uint32_t iq = cb >> 1, ik = cb & 1u;
+            const uint4 sv = my_slots[it - base];
+            if (iq != q_cur) {
+              // the previous sub-pass is complete: did it claim the read?
+              if (win_q == kNoQ && q_best != ~0ull) {
+                win_key = q_best;
+                win_q = q_cur;
+              }
+              q_cur = iq;
+              q_best = ~0ull;
+            }
+            if (win_q != kNoQ) continue;                       // claimed before this sub-pass: never issued
+            if (ik == 1u && (q_best >> 56) == 0ull) continue;  // piece 0 was exact: piece 1 never issued
+            const uint64_t key = (uint64_t)sv.x | ((uint64_t)sv.y << 32);
+            q_best = min(q_best, key);
+            unsigned long long* c64 =
+                cnt64 + (size_t)(s0 + iq) * 3u * kFusedCntReplicas + (lane & (kFusedCntReplicas - 1u));
+            if (sv.w & 0x7FFFFFFFu) atomicAdd(c64, (unsigned long long)(sv.w & 0x7FFFFFFFu));
+            if (sv.z) atomicAdd(c64 + kFusedCntReplicas, (unsigned long long)sv.z);
+            if (sv.w & 0x80000000u) atomicAdd(c64 + 2 * kFusedCntReplicas, 1ull);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (win_q == kNoQ && q_best != ~0ull) {
+        win_key = q_best;
+        win_q = q_cur;
+      }
+
+      // ================= phase D: the 0/1 counters of the round and the outputs =================
+      {
+        const uint32_t offered = (elig & (win_q == kNoQ ? 0xFFu : ((2u << win_q) - 1u))) << s0;
+        const uint32_t aligned = (win_q == kNoQ ? 0u : (1u << win_q)) << s0;
+        acc_offered[0] += spread4(offered & 15u);
+        acc_offered[1] += spread4(offered >> 4);
+        acc_aligned[0] += spread4(aligned & 15u);
+        acc_aligned[1] += spread4(aligned >> 4);
+      }
+      if (win_q != kNoQ) {
+        const uint32_t* tab = stab + (s0 + win_q) * kSubWords;
+        const uint32_t st = (uint32_t)(win_key >> 24);
+        uint32_t sg = (uint32_t)(win_key >> 8) & 0xFFFFu;
+        const uint32_t before = (uint32_t)win_key & 0xFFu;
+        const uint32_t* seg_start = reinterpret_cast<const uint32_t*>(lds_ptr(tab, SW_SEGSTART));
+        if (sg == 0xFFFFu) {
+          sg = reinterpret_cast<const uint32_t*>(lds_ptr(tab, SW_CHUNKSEG))[st >> 5];
+          while (seg_start[sg + 1] <= st) ++sg;
+        }
+        const uint32_t simple = tab[SW_SIMPLE];
+        uint32_t ref = sg, pos;
+        if (simple && before < 255u) {
+          pos = before;
+        } else {
+          uint32_t off = 0;
+          if (!simple) {
+            ref = reinterpret_cast<const uint32_t*>(lds_ptr(tab, SW_SEGREF))[sg];
+            off = reinterpret_cast<const uint32_t*>(lds_ptr(tab, SW_SEGOFF))[sg];
+          }
+          pos = st - seg_start[sg] + off;
+        }
+        p.pass_id[r] = (int8_t)tab[SW_PASSIDX];
+        p.ref_id[r] = (int32_t)ref;
+        p.pos[r] = (int32_t)pos;
+        p.mm[r] = (uint8_t)(win_key >> 56);
+        claimed = true;
+      }
+    }
+
+    if (active && !claimed && !p.idx_out) {
+      // the group ends the cascade: whatever is still unclaimed stays unannotated
+      p.pass_id[r] = (int8_t)-1;
+      p.ref_id[r] = -1;
+      p.pos[r] = -1;
+      p.mm[r] = 0;
+    }
+    if (p.idx_out) {
+      const bool survive = active && !claimed;
+      const uint64_t mask = __ballot(survive);
+      if (mask) {
+        uint32_t wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&ctl[0], (uint32_t)__popcll(mask));
+        wbase = __shfl(wbase, 0, 64);
+        if (survive)
+          p.idx_out[(size_t)blockIdx.x * p.out_seg_cap + wbase +
+                    (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = r;
+      }
+    }
+  }
+  // ---- counters: the per-lane 16-bit fields summed over the wave, one global atomic each
+#pragma unroll 1
+  for (uint32_t s = 0; s < p.n_sub; ++s) {
+    const uint64_t of = (acc_offered[s >> 2] >> (16u * (s & 3u))) & 0xFFFFull;
+    const uint64_t al = (acc_aligned[s >> 2] >> (16u * (s & 3u))) & 0xFFFFull;
+    const uint64_t t_of = wave_sum(of), t_al = wave_sum(al);
+    if (lane == 0) {
+      if (t_of) atomicAdd((unsigned long long*)&p.sub[s].counters[0], (unsigned long long)t_of);
+      if (t_al) atomicAdd((unsigned long long*)&p.sub[s].counters[1], (unsigned long long)t_al);
+    }
+  }
+  __syncthreads();
+  if (p.idx_out && threadIdx.x == 0) p.out_count[blockIdx.x] = ctl[0];
+  for (uint32_t i = threadIdx.x; i < p.n_sub * 3u; i += BLOCK) {
+    const uint32_t s = i / 3u, c = i % 3u;
+    unsigned long long v = 0ull;
+    const unsigned long long* src = cnt64 + ((size_t)s * 3u + c) * kFusedCntReplicas;
+    for (uint32_t q = 0; q < kFusedCntReplicas; ++q) v += src[q];
+    if (v) atomicAdd((unsigned long long*)&p.sub[s].counters[2u + c], v);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // count_kernel: best stratum of every read against one library -- fewest mismatches of a
 // valid alignment and how many alignments reach it.  Replaces the two genome bowtie runs
@@ -819,6 +1430,28 @@ hipError_t launch_match(const MatchParams& p, uint32_t words_per_read, int lds_m
     case 4: return launch_match_w<4>(p, lds_mode, grid, lds_bytes, stream);
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t launch_fused(const FusedParams& p, uint32_t words_per_read, uint32_t grid, uint32_t lds_bytes,
+                        hipStream_t stream) {
+#define MRG_FUSED(W_)                                                                                   \
+  {                                                                                                     \
+    auto kern = fused_kernel<W_>;                                                                       \
+    if (lds_bytes > 48 * 1024) {                                                                        \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                           \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);   \
+      if (e != hipSuccess) return e;                                                                    \
+    }                                                                                                   \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds_bytes, stream, p);                             \
+  }
+  switch (words_per_read) {
+    case 1: MRG_FUSED(1) break;
+    case 2: MRG_FUSED(2) break;
+    case 4: MRG_FUSED(4) break;
+    default: return hipErrorInvalidValue;
+  }
+#undef MRG_FUSED
+  return hipGetLastError();
 }
 
 hipError_t launch_tally(const TallyParams& p, bool lds_hist, uint32_t grid,

@@ -68,6 +68,81 @@ struct MatchParams {
   uint32_t wide_rows;  // seed intervals wider than this are verified by the whole wave
 };
 
+// ---------------------------------------------------------------------------
+// Fused launch: several consecutive cascade passes (RAP:636-705 iterations) over ONE walk of
+// the survivor list.  A read that a sub-pass does not claim is offered to the next one while it
+// is still in registers, so the list round trip and the lens[r] / reads[r] gathers -- what the
+// small-library passes spend most of their time on -- happen once per group instead of once
+// per pass.  Libraries are served from L2/HBM (their texts are only touched by the few
+// candidates that survive the filters); LDS holds what answers most reads without any memory
+// request: one folded 9-mer presence bitmap per small library.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kMaxFused = 8u;
+constexpr uint32_t kFusedCntReplicas = 16u;  // LDS slots per 64-bit counter (lane & 15)
+
+struct SubPass {
+  const uint32_t* blocks;
+  const uint32_t* super;  // read from L2 in the rare LF step (not staged)
+  const uint32_t* text;
+  const uint64_t* sa;
+  const uint32_t* ctx;    // row context of a large library (null otherwise)
+  const uint32_t* ftab;
+  const uint32_t* kbits;  // folded 9-mer bitmap to stage (null = no filter)
+  const uint32_t* seg_start;
+  const uint32_t* seg_ref;
+  const uint32_t* seg_off;
+  const uint32_t* chunk_seg;
+  const uint64_t* nmask;  // = FusedParams::nmask (so that verify_row reads one parameter block)
+  uint64_t* counters;     // processed, aligned, steps, candidates, lookups of this pass
+  JumpTables tabs;
+  uint32_t n, primary, simple_segs;
+  uint32_t text_lds_off;    // LDS word offset of the staged packed text (when text_lds_words != 0)
+  uint32_t text_lds_words;  // 0 = the text is read from L2/HBM
+  uint32_t kb_off;   // word offset of the staged bitmap in LDS
+  uint32_t kb_mask;  // bits - 1 of the folded bitmap (bit index = 9-mer code & kb_mask); 0 = none
+  uint32_t wide_rows;
+  int32_t seed_len, max_mm_seed, max_mm_total, trim5, trim3, min_len, max_len, poly_t;
+  int32_t pass_index;
+};
+
+struct FusedParams {
+  SubPass sub[kMaxFused];
+  uint32_t n_sub;
+  uint32_t kb_words;   // LDS words of all staged bitmaps
+  uint32_t txt_words;  // LDS words of all staged texts (right after the bitmaps)
+  const uint64_t* reads;
+  const uint8_t* lens;
+  const uint64_t* nmask;
+  uint32_t n_total;
+  uint32_t uniform_len;      // != 0: every read has this length (lens is not read)
+  const uint32_t* idx_in;
+  const uint32_t* in_count;
+  uint32_t in_nseg, in_seg_cap;
+  uint32_t* idx_out;         // null: the group ends the cascade
+  uint32_t* out_count;
+  uint32_t out_seg_cap;
+  int8_t* pass_id;
+  int32_t* ref_id;
+  int32_t* pos;
+  uint8_t* mm;
+  uint32_t wstop;
+  // rounds: runs of sub-passes whose seed pieces are looked up together (speculatively across the
+  // sub-passes of the run; the owner replays the results in cascade order)
+  uint32_t n_rounds;
+  uint8_t round_first[kMaxFused], round_count[kMaxFused];
+};
+
+// LDS bytes of a fused launch besides the bitmaps: sub-pass table + one 16-byte result slot per
+// thread + counters + control words + wave slots
+constexpr uint32_t fused_fixed_lds_bytes() {
+  return kMaxFused * 40u * 4u + 1024u * 16u + kMaxFused * 3u * kFusedCntReplicas * 8u + 16u;
+}
+// a sub-pass needs two bits of the per-lane item mask: at most this many sub-passes per round
+constexpr uint32_t kMaxRoundSubs = 8u;
+
+hipError_t launch_fused(const FusedParams& p, uint32_t words_per_read, uint32_t grid, uint32_t lds_bytes,
+                        hipStream_t stream);
+
 constexpr uint32_t kCountThreads = 256u;
 
 struct CountParams {

@@ -69,7 +69,8 @@ static void shift5(uint64_t *rd, int W, int t) {
 }
 
 /* Returns 1 if aligned; *key = (mm << 32) | text position. */
-static int match_one(const orc_lib *l, const orc_pass *p, const uint64_t *rd, const uint64_t *nm,
+static int match_one(const orc_lib *l, const orc_pass *p, const uint32_t *kbits, uint32_t kb_mask,
+                     const uint64_t *rd, const uint64_t *nm,
                      int W, int L, uint32_t wstop, int use_ftab, uint64_t *key, uint64_t *steps,
                      uint64_t *cands, uint64_t *lookups) {
   uint64_t best = ~0ull;
@@ -85,17 +86,19 @@ static int match_one(const orc_lib *l, const orc_pass *p, const uint64_t *rd, co
     for (int i = a; i < b; ++i)
       if ((nm[i >> 5] >> ((i & 31) * 2)) & 1) has_n = 1;
     if (has_n) continue;
-    if (l->kbits && b - a >= 9) {
+    if (kbits && b - a >= 9) {
       /* the piece's last 9 bases do not occur in the library: it cannot match */
       uint32_t c9 = 0;
       for (int t = 0; t < 9; ++t)
         c9 |= (uint32_t)((rd[(b - 9 + t) >> 5] >> (((b - 9 + t) & 31) * 2)) & 3ull) << (2 * t);
-      if (!((l->kbits[c9 >> 5] >> (c9 & 31)) & 1u)) continue;
+      c9 &= kb_mask;
+      if (!((kbits[c9 >> 5] >> (c9 & 31)) & 1u)) continue;
       if (b - a > 9) { /* ... nor its first 9 */
         uint32_t c0 = 0;
         for (int t = 0; t < 9; ++t)
           c0 |= (uint32_t)((rd[(a + t) >> 5] >> (((a + t) & 31) * 2)) & 3ull) << (2 * t);
-        if (!((l->kbits[c0 >> 5] >> (c0 & 31)) & 1u)) continue;
+        c0 &= kb_mask;
+        if (!((kbits[c0 >> 5] >> (c0 & 31)) & 1u)) continue;
       }
     }
     uint32_t lo = 0, hi = l->n + 1;
@@ -179,6 +182,20 @@ void orc_run_cascade(const orc_lib *libs, const orc_pass *passes, int n_pass, co
     const orc_pass *p = &passes[pi];
     const orc_lib *l = &libs[p->lib];
     uint64_t processed = 0, aligned = 0, steps = 0, cands = 0, lookups = 0;
+    /* the 9-mer filter of this pass: the library's 4^9-bit bitmap, or -- as a fused GPU launch
+     * stages it -- folded to 2^kbits_log2 bits (bit h = OR of the 9-mers with code & mask == h);
+     * `reserved` carries kbits_log2: 0 = full bitmap, 13..17 = folded, 255 = no filter */
+    uint32_t *folded = NULL;
+    const uint32_t *kbits = l->kbits;
+    uint32_t kb_mask = (1u << 18) - 1u;
+    if (p->reserved == 255) kbits = NULL;
+    if (kbits && p->reserved >= 13 && p->reserved < 18) {
+      uint32_t words = (1u << p->reserved) / 32u;
+      folded = (uint32_t *)calloc(words, 4);
+      for (uint32_t i = 0; i < (1u << 18) / 32u; ++i) folded[i % words] |= l->kbits[i];
+      kbits = folded;
+      kb_mask = (1u << p->reserved) - 1u;
+    }
 #pragma omp parallel for schedule(dynamic, 4096) reduction(+ : processed, aligned, steps, cands, lookups)
     for (int64_t r = 0; r < (int64_t)n; ++r) {
       if (pass_id[r] >= 0) continue;
@@ -205,7 +222,7 @@ void orc_run_cascade(const orc_lib *libs, const orc_pass *passes, int n_pass, co
       shift5(nm, W, p->trim5);
       ++processed;
       uint64_t key = 0, st = 0, cd = 0, lk = 0;
-      int ok = L > 0 && match_one(l, p, rd, nm, W, L, wstop, use_ftab, &key, &st, &cd, &lk);
+      int ok = L > 0 && match_one(l, p, kbits, kb_mask, rd, nm, W, L, wstop, use_ftab, &key, &st, &cd, &lk);
       steps += st;
       cands += cd;
       lookups += lk;
@@ -221,6 +238,7 @@ void orc_run_cascade(const orc_lib *libs, const orc_pass *passes, int n_pass, co
         ++aligned;
       }
     }
+    free(folded);
     stats[5 * pi + 0] = processed;
     stats[5 * pi + 1] = aligned;
     stats[5 * pi + 2] = steps;

@@ -186,7 +186,9 @@ def fm_cascade(lib_views, passes, reads, lens, nmask=None, wstop=0, threads=None
 
     lib_views: list of dicts with numpy arrays blocks/super/text/sa/seg_start/
                seg_ref/seg_off/chunk_seg and ints n, primary (as mirge_amd index views).
-    passes   : list of dicts with the mrg_pass_cfg fields.
+    passes   : list of dicts with the mrg_pass_cfg fields; optional `kbits_log2` (what
+               mrg_pass_stats reports: 18/0 = the library's full 9-mer bitmap when it has one,
+               13..17 = folded as a fused GPU launch stages it).
     reads    : uint64 [W, n] SoA words; lens uint8 [n]; nmask like reads or None.
     wstop / ftab / kmer_filter: the same search shortcuts the GPU context options select.
     Returns dict(pass_id, ref_id, pos, mm, stats[n_pass,5] = processed, aligned, steps,
@@ -216,6 +218,8 @@ def fm_cascade(lib_views, passes, reads, lens, nmask=None, wstop=0, threads=None
     for i, p in enumerate(passes):
         for k, _ in _OrcPass._fields_:
             setattr(ps[i], k, int(p.get(k, 0)))
+        lg = int(p.get("kbits_log2", 0))
+        ps[i].reserved = lg if 13 <= lg < 18 else 0
     pass_id = np.empty(n, dtype=np.int8)
     ref_id = np.empty(n, dtype=np.int32)
     pos = np.empty(n, dtype=np.int32)

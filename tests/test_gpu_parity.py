@@ -26,6 +26,9 @@ def engine(world):
 
 def run_gpu(engine, world, quant=None, **opts):
     from mirge_amd.engine import ReadSet
+    # the match_kernel variants are exercised one launch per pass; the fused launches have their
+    # own test below (and are what every default-option test in this file runs)
+    opts.setdefault("fuse", 0)
     for k, v in opts.items():
         engine.set_option(k, v)
     rs = ReadSet(world.words, world.lens, world.nmask, quant, device=engine.device)
@@ -43,6 +46,37 @@ def assert_same(res, ref):
         assert st["steps"] == int(ref["stats"][i][2])
         assert st["candidates"] == int(ref["stats"][i][3])
         assert st["lookups"] == int(ref["stats"][i][4])
+
+
+def test_fused_launches_match_cpu_port(engine, world):
+    """fuse = 1/2/3: consecutive passes share one walk of the survivor list (fused_kernel); every
+    assignment and all five per-pass counters equal the port's, which filters seed pieces with the
+    same folded 9-mer bitmaps (mrg_pass_stats.kbits_log2) the launch staged."""
+    base = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask,
+                            wstop=DEFAULT_WSTOP, ftab=True)
+    seen_groups = set()
+    for fuse, wstop, ftab, wide in ((1, DEFAULT_WSTOP, 1, 64), (2, DEFAULT_WSTOP, 1, 64), (3, 0, 0, 64),
+                                    (1, 2, 1, 1)):
+        _, res = run_gpu(engine, world, fuse=fuse, wstop=wstop, ftab=ftab, wide_rows=wide)
+        st = res.stats
+        passes = [dict(p, kbits_log2=st[i]["kbits_log2"]) for i, p in enumerate(world.passes)]
+        ref = model.fm_cascade(world.views, passes, world.words, world.lens, world.nmask, wstop=wstop,
+                               ftab=bool(ftab))
+        for k in ("pass_id", "ref_id", "pos", "mm"):
+            assert np.array_equal(base[k], ref[k])  # the filter size never changes an assignment
+        assert_same(res, ref)
+        groups = [s["group"] for s in st]
+        seen_groups.add(tuple(groups))
+        assert groups[0] == 0 and groups[8] == 8            # first pass and the 2-mismatch pass run alone
+        assert groups[2] == groups[3] == groups[4] == groups[5] == 1   # hairpin .. rRNA share a launch
+        assert all(s["lds_mode"] == 4 for s in st[1:6])
+        assert (groups[6] == 1) == (fuse == 2)
+        assert (groups[7] == groups[6]) == (fuse != 3)
+    assert len(seen_groups) == 3
+    engine.set_option("fuse", 1)
+    engine.set_option("wide_rows", 64)
+    engine.set_option("wstop", DEFAULT_WSTOP)
+    engine.set_option("ftab", 1)
 
 
 def test_cascade_matches_cpu_port_all_lds_modes(engine, world):
@@ -430,11 +464,14 @@ def test_long_reads_four_words(native_lib, oracle_lib):
     reads = list(dict.fromkeys(reads))[:3000]
     words, lens, nmask = pack.pack_reads(reads)
     assert words.shape[0] == 4 and int(lens.max()) > 120
-    ref = model.fm_cascade(w.views, pass_dicts(), words, lens, nmask, wstop=DEFAULT_WSTOP, ftab=True)
     eng = Engine(0)
     for k in LIB_ORDER:
         eng.add_library(k, w.index[k])
     res = eng.cascade(ReadSet(words, lens, nmask, None, device=eng.device), eng.mirge_passes())
+    # default options: passes 1..7 run as fused launches with folded bitmaps (stats say which)
+    ref = model.fm_cascade(w.views, [dict(p, kbits_log2=st["kbits_log2"]) for p, st in zip(pass_dicts(), res.stats)],
+                           words, lens, nmask, wstop=DEFAULT_WSTOP, ftab=True)
+    assert any(st["lds_mode"] == 4 for st in res.stats)
     assert_same(res, ref)
     assert sum(int(ref["stats"][i][1]) for i in range(9)) > len(reads) // 3
     # the port against the exhaustive-scan cascade on a subset
