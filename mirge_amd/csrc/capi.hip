@@ -49,6 +49,7 @@ struct DevLib {
            *seg_ref = nullptr, *seg_off = nullptr, *chunk_seg = nullptr;
   uint64_t* sa = nullptr;
   uint32_t* ctx = nullptr;
+  uint32_t* sa16 = nullptr;  // wide rows of a large library (fm_index.hpp: fill_wide_rows)
   uint32_t* kbits = nullptr;
   // the 9-mer bitmap folded to 2^17 .. 2^13 bits (bit h = OR of the 9-mers with code & (bits - 1) == h),
   // one allocation, for fused launches whose LDS cannot hold every library's full bitmap
@@ -91,6 +92,7 @@ struct mrg_ctx {
   // small (bitmap-filtered) and large libraries in separate groups; 2 = one group regardless of
   // library size; 3 = only the small-library runs are fused
   int64_t fuse = 1;
+  int64_t wide_rows_16 = 1;  // libraries of >= 2^20 bases get 16-byte rows with 32 bases of context
   std::vector<DevLib> libs;
   // last run
   hipStream_t last_stream = nullptr;
@@ -260,6 +262,7 @@ void mrg_ctx_destroy(mrg_ctx* ctx) {
     (void)hipFree(l.sa);
     (void)hipFree(l.ftab);
     (void)hipFree(l.ctx);
+    (void)hipFree(l.sa16);
     (void)hipFree(l.kbits);
     (void)hipFree(l.kbits_folds);
     (void)hipFree(l.seg_start);
@@ -308,6 +311,18 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
   }
   if ((rc = upload(&l.ftab, ix.ftab))) return rc;
   if (!ix.ctx.empty() && (rc = upload(&l.ctx, ix.ctx))) return rc;
+  if (ix.n >= mrg::kWideRowMinBases && ctx->wide_rows_16) {
+    // 16-byte rows for the fused launches: filled on the host in chunks, never kept there
+    const size_t n_rows = ix.sa.size(), chunk = 1u << 24;
+    HIP_TRY(hipMalloc((void**)&l.sa16, n_rows * 16));
+    std::vector<uint32_t> buf;
+    for (size_t lo = 0; lo < n_rows; lo += chunk) {
+      const size_t hi = std::min(n_rows, lo + chunk);
+      buf.resize((hi - lo) * 4);
+      mrg::fill_wide_rows(ix, lo, hi, buf.data());
+      HIP_TRY(hipMemcpy(l.sa16 + lo * 4, buf.data(), (hi - lo) * 16, hipMemcpyHostToDevice));
+    }
+  }
   if (!ix.kbits.empty() && (rc = upload(&l.kbits, ix.kbits))) return rc;
   if (!ix.kbits.empty()) {
     // folds of 2^17, 2^16, ... 2^13 bits back to back (word offsets: see fold_offset_words)
@@ -357,6 +372,8 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->force_lds_mode = value;
   } else if (k == "ftab") {
     ctx->use_ftab = value != 0;
+  } else if (k == "wide_rows_16") {
+    ctx->wide_rows_16 = value != 0;  // takes effect for libraries added afterwards
   } else if (k == "fuse") {
     if (value < 0 || value > 3) return fail(MRG_ERR_ARG, "fuse must be in [0,3]");
     ctx->fuse = value;
@@ -625,6 +642,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
       sp.text = l.text;
       sp.sa = l.sa;
       sp.ctx = l.ctx;
+      sp.sa16 = reinterpret_cast<const uint4*>(l.sa16);
       sp.ftab = l.ftab;
       sp.tabs = l.tabs;
       if (!ctx->use_ftab) sp.tabs.k[0] = 0u;

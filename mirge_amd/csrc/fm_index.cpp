@@ -359,6 +359,37 @@ void build_row_context(FmIndex& ix) {
   for (auto& th : pool) th.join();
 }
 
+void fill_wide_rows(const FmIndex& ix, size_t row_lo, size_t row_hi, uint32_t* out) {
+  const unsigned n_threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  std::vector<std::thread> pool;
+  const size_t n = row_hi - row_lo;
+  for (unsigned t = 0; t < n_threads; ++t)
+    pool.emplace_back([&ix, row_lo, n, n_threads, t, out] {
+      for (size_t k = n * t / n_threads; k < n * (t + 1) / n_threads; ++k) {
+        const uint64_t row = ix.sa[row_lo + k];
+        const uint32_t p = (uint32_t)row;
+        // left: text[p-16 .. p), text[p-1] in the top two bits (bases before the text read as A)
+        uint32_t left;
+        if (p >= 16) {
+          left = (uint32_t)window64(ix, (uint64_t)p - 16);
+        } else {
+          left = p ? ((uint32_t)window64(ix, 0) & (uint32_t)((1ull << (2 * p)) - 1ull)) << (32 - 2 * p) : 0u;
+        }
+        // right: text[p+8 .. p+24), text[p+8] in the low two bits (bases past the end read as A)
+        uint32_t right = (uint32_t)window64(ix, (uint64_t)p + kWideRowRightSkip);
+        const uint64_t start = (uint64_t)p + kWideRowRightSkip;
+        if (start >= ix.n) right = 0;
+        else if (start + 16 > ix.n) right &= (uint32_t)((1ull << (2 * (ix.n - start))) - 1ull);
+        uint32_t* o = out + 4 * k;
+        o[0] = (uint32_t)row;
+        o[1] = (uint32_t)(row >> 32);
+        o[2] = left;
+        o[3] = right;
+      }
+    });
+  for (auto& th : pool) th.join();
+}
+
 void build_index(const std::vector<std::string>& names,
                  const std::vector<std::string>& seqs, FmIndex& ix) {
   if (names.size() != seqs.size()) throw std::runtime_error("names/seqs size mismatch");

@@ -78,6 +78,16 @@ void read_fasta(const std::string& path, std::vector<std::string>& names,
 void build_jump_tables(FmIndex& ix);  // from sa + text
 void build_row_context(FmIndex& ix);  // from sa + text
 void build_kmer_bits(FmIndex& ix);    // from text
+// Wide suffix-array rows of a large library (>= kWideRowMinBases; derived, built at upload time
+// and never kept on the host): 16 bytes per row = the 8-byte row of `sa`, the 16 text bases left
+// of its position (text[p-1] in the top two bits) and the 16 bases text[p+8 .. p+24).  One
+// 16-byte load then locates a candidate AND shows 32 of the bases around the seed: for reads of
+// up to 24 nt that is every base the seed did not cover, so a false candidate (2.6 per 11-base
+// piece in an 11 Mbp library) is dropped without its text-window request.  Rows [row_lo, row_hi)
+// into out[4 * (row_hi - row_lo)].
+void fill_wide_rows(const FmIndex& ix, size_t row_lo, size_t row_hi, uint32_t* out);
+constexpr uint32_t kWideRowMinBases = 1u << 20;
+constexpr uint32_t kWideRowRightSkip = 8;
 // largest library that gets the bitmap: its packed text (n / 4 bytes) plus the 32 KB bitmap must
 // leave room for two match workgroups per CU (80 KB each incl. < 1 KB of control data)
 constexpr uint32_t kKmerBitsMaxBases = 190000;

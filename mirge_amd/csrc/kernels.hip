@@ -593,7 +593,7 @@ constexpr uint32_t kSubWords = 40u;  // LDS words per sub-pass table entry
 enum SubWord : uint32_t {
   SW_FTAB = 0, SW_SA = 2, SW_TEXT = 4, SW_CTX = 6, SW_BLOCKS = 8, SW_SUPER = 10, SW_TABK = 12, SW_TABOFF = 16,
   SW_N = 20, SW_PRIMARY = 21, SW_POLICY = 22, SW_TRIMS = 23, SW_TEXT_LDS = 24, SW_SIMPLE = 25, SW_PASSIDX = 26,
-  SW_SEGSTART = 28, SW_SEGREF = 30, SW_SEGOFF = 32, SW_CHUNKSEG = 34
+  SW_SEGSTART = 28, SW_SEGREF = 30, SW_SEGOFF = 32, SW_CHUNKSEG = 34, SW_SA16 = 36
 };
 constexpr uint32_t kNoQ = 0xFFu;
 constexpr uint32_t kRowSlice = 1u << 20;  // rows of one interval taken into one compaction sweep
@@ -650,6 +650,39 @@ __device__ __forceinline__ bool piece_has_n(const uint64_t (&nm)[W], int32_t a, 
     if (hi_b > lo_b) has_n |= (nm[w] & low_bits(2 * hi_b) & ~low_bits(2 * lo_b)) != 0ull;
   }
   return has_n;
+}
+
+// 2c bits of the read starting at base `at` (c <= 16)
+template <int W>
+__device__ __forceinline__ uint32_t read_bits32(const uint64_t (&rd)[W], uint32_t at, uint32_t c) {
+  uint64_t v = pick_word<W>(rd, at >> 5) >> ((at & 31u) * 2u);
+  if (W > 1 && (at & 31u) + c > 32u) v |= pick_word<W>(rd, (at >> 5) + 1u) << (64u - (at & 31u) * 2u);
+  return (uint32_t)(v & low_bits(2u * c));
+}
+
+// Mismatches a wide row's stored context (fm_index.hpp: fill_wide_rows) shows against a read whose
+// seed search stopped with `need_before` read bases left of the row's position and `need_after`
+// from it on: the <= 16 bases before the position and the bases 8..23 after it.  A lower bound of
+// the alignment's mismatches (a read N, code 0, can only add true mismatches; bases across a
+// segment end only occur in alignments that are invalid anyway): "more than the pass allows" is
+// final.
+template <int W>
+__device__ __forceinline__ uint32_t wide_row_mismatches(const uint64_t (&rd)[W], uint32_t need_before,
+                                                        uint32_t need_after, uint32_t left, uint32_t right) {
+  uint32_t mm = 0;
+  const uint32_t c = min(need_before, 16u);
+  if (c) {
+    const uint32_t want = read_bits32<W>(rd, need_before - c, c);
+    const uint32_t x = (left >> (32u - 2u * c)) ^ want;  // c == 16: shift by 0
+    mm += (uint32_t)__popc((x | (x >> 1)) & 0x55555555u & (uint32_t)low_bits(2u * c));
+  }
+  if (need_after > 8u) {
+    const uint32_t c2 = min(need_after, 24u) - 8u;
+    const uint32_t want = read_bits32<W>(rd, need_before + 8u, c2);
+    const uint32_t x = (right ^ want) & (uint32_t)low_bits(2u * c2);
+    mm += (uint32_t)__popc((x | (x >> 1)) & 0x55555555u);
+  }
+  return mm;
 }
 
 // first lane whose inclusive prefix exceeds x (x < total): six shuffles
@@ -718,6 +751,7 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
       put(SW_SEGREF, sp.seg_ref);
       put(SW_SEGOFF, sp.seg_off);
       put(SW_CHUNKSEG, sp.chunk_seg);
+      put(SW_SA16, sp.sa16);
       for (int i = 0; i < 4; ++i) {
         t[SW_TABK + i] = sp.tabs.k[i];
         t[SW_TABOFF + i] = sp.tabs.off[i];
@@ -968,7 +1002,7 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
               ++c_steps;
             }
           }
-          nb_na = (uint32_t)j | ((uint32_t)(L - j) << 8);
+          nb_na = (uint32_t)j | ((uint32_t)(L - j) << 8) | ((uint32_t)min(b - j, 255) << 16);  // + exactly matched bases
         }
         uint32_t rem = (has_item && hi > lo) ? hi - lo : 0u;
         // result slot of my item: key = mm:8 | text position:32 | segment:16 | before:8 (all ones = none)
@@ -1005,28 +1039,49 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
               pol.max_mm_total = (int32_t)(tpol >> 24);
               pol.nmask = p.nmask;
               const uint32_t i = t_lo + (x - (t_incl - t_w));
-              const uint32_t need_before = t_nbna & 0xFFu, need_after = t_nbna >> 8;
-              bool keep = true;
-              const uint32_t* ctxp = reinterpret_cast<const uint32_t*>(lds_ptr(ttab, SW_CTX));
-              if (ctxp && t_w >= kCtxMinRows) {
-                // wide interval of a large library: most rows are dropped by their stored context
-                const uint2 probe = context_probe<W>(t_rd, need_before, need_after);
-                keep = (int32_t)context_mismatches(ctxp[i], probe) <= pol.max_mm_total;
-              }
-              if (keep) {
+              const uint32_t need_before = t_nbna & 0xFFu, need_after = (t_nbna >> 8) & 0xFFu, exact_part = t_nbna >> 16;
+              uint64_t row = 0ull;
+              uint64_t best = ~0ull;
+              uint32_t best_seg = 0xFFFFu, best_before = 255u;
+              const uint4* sa16 = reinterpret_cast<const uint4*>(lds_ptr(ttab, SW_SA16));
+              if (sa16) {
+                // large library: one 16-byte load = the row and 32 bases around the seed; a false
+                // candidate (nearly all of them) never asks for its text window
+                const uint4 wr = sa16[i];
+                row = (uint64_t)wr.x | ((uint64_t)wr.y << 32);
+                const uint32_t mm = wide_row_mismatches<W>(t_rd, need_before, need_after, wr.z, wr.w);
+                bool any_n = false;
+#pragma unroll
+                for (int k = 0; k < W; ++k) any_n |= t_nm[k] != 0ull;
+                if (need_before <= 16u && need_after <= 24u && exact_part >= 8u && !any_n && t_L <= pol.seed_len) {
+                  // the stored context shows every base the exact part of the seed (>= 8 bases from
+                  // the row's position on) does not: `mm` IS the alignment's mismatch count (the
+                  // read lies inside the seed region, so seed and total mismatches coincide)
+                  const uint32_t before = wr.y & 255u, after = (wr.y >> 8) & 255u;
+                  if (need_before <= before && need_after <= after && (int32_t)mm <= pol.max_mm_seed &&
+                      (int32_t)mm <= pol.max_mm_total) {
+                    best = ((uint64_t)mm << 32) | (uint64_t)(wr.x - need_before);
+                    best_seg = wr.y >> 16;
+                    best_before = before < 255u ? before - need_before : 255u;
+                  }
+                } else if ((int32_t)mm <= pol.max_mm_total) {
+                  ItemLib lib;
+                  lib.gtext = reinterpret_cast<const uint32_t*>(lds_ptr(ttab, SW_TEXT));
+                  lib.stext = nullptr;
+                  verify_row<W>(lib, pol, row, t_rd, t_nm, t_L, need_before, need_after, best, best_seg, best_before);
+                }
+              } else {
+                row = reinterpret_cast<const uint64_t*>(lds_ptr(ttab, SW_SA))[i];
                 ItemLib lib;
                 lib.gtext = reinterpret_cast<const uint32_t*>(lds_ptr(ttab, SW_TEXT));
                 const uint32_t tl = ttab[SW_TEXT_LDS];
                 lib.stext = tl != 0xFFFFFFFFu ? smem + tl : nullptr;
-                const uint64_t row = reinterpret_cast<const uint64_t*>(lds_ptr(ttab, SW_SA))[i];
-                uint64_t best = ~0ull;
-                uint32_t best_seg = 0xFFFFu, best_before = 255u;
                 verify_row<W>(lib, pol, row, t_rd, t_nm, t_L, need_before, need_after, best, best_seg, best_before);
-                if (best != ~0ull) {
-                  const uint64_t key = ((best >> 32) << 56) | ((best & 0xFFFFFFFFull) << 24) |
-                                       ((uint64_t)(best_seg & 0xFFFFu) << 8) | (uint64_t)(best_before & 0xFFu);
-                  atomicMin(&my_slot_keys[2u * t], (unsigned long long)key);
-                }
+              }
+              if (best != ~0ull) {
+                const uint64_t key = ((best >> 32) << 56) | ((best & 0xFFFFFFFFull) << 24) |
+                                     ((uint64_t)(best_seg & 0xFFFFu) << 8) | (uint64_t)(best_before & 0xFFu);
+                atomicMin(&my_slot_keys[2u * t], (unsigned long long)key);
               }
             }
           }

