@@ -1,16 +1,28 @@
 #!/usr/bin/env python3
-"""Headline benchmark: M reads/s annotated by the full miRge cascade + tally on
-MI355X, with the FM-index match kernel's roofline and a CPU baseline.
+"""Headline benchmark: M reads/s annotated by the full miRge cascade + tally on MI355X, with the
+roofline of the dominant kernel, a CPU baseline and parity gates.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cascade|exact]
-                    [--reads-per-gpu R] [--scale S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cascade|exact|varlen|a2i]
+                    [--scaling strong|weak] [--reads R] [--scale S]
 
-A step = one pass of the hot path over one batch: the nine-pass cascade
-(runAnnotationPipeline.py:636-705) and the count tally (summarize.py:34-66) over
-the rank's shard of packed reads already resident in HBM, plus -- for N > 1 --
-the single RCCL all-reduce of the fused count vector.  Synthetic libraries and
-reads (mirge_amd.synth); weak scaling: every rank annotates
---reads-per-gpu reads of its own seeded shard.
+A step = one pass of the hot path over one batch already resident in HBM: the nine-pass cascade
+(runAnnotationPipeline.py:636-705), the count tally (summarize.py:34-66) and -- for N > 1 -- the
+single RCCL all-reduce of the fused count vector.  `--workload a2i` adds the A-to-I position
+tally (writeDataToCSV.py:145-229) to the step and uses the mouse-seeded libraries.
+
+Scaling: `strong` (default) = ONE seeded read set of --reads reads (default 100 M = BASELINE
+configs[2]; with N GPUs configs[3]) cut into contiguous shards with mirge_amd.dist.shard_bounds,
+every rank generating only its own shard; `weak` = every rank annotates --reads reads of its own.
+
+Besides the contract keys the JSON line carries
+  roofline      dominant kernel by time; achieved = SURVEY.md 8d bytes (16 B per read offered to a
+                pass + 64 B per LF step) / HIP-event time; peak 8 TB/s
+  cpu_baseline  the oracle's CPU port on a bounded sample (kind "port"), or the reference-shaped
+                bowtie cascade when a real bowtie 1 is on the box (kind "reference")
+  parity        what was compared with what before any number was printed
+  e2e           (N = 1) the same step with the reads starting in pinned host memory and the
+                assignments ending there: H2D and D2H of double-buffered chunks overlap the kernels
+  collapsed     (N = 1, cascade) raw reads -> mrg_collapse_run -> cascade over the unique reads
 """
 import argparse
 import json
@@ -24,7 +36,10 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_ACHIEVABLE_GBS = 6300.0  # what a streaming kernel reaches (same guide); used for the floors only
+
+DEFAULT_READS = {"cascade": 100_000_000, "exact": 10_000_000, "varlen": 20_000_000, "a2i": 50_000_000}
 
 
 def log(rank, *a):
@@ -32,20 +47,71 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def survey_bytes(processed, steps):
+    """16 B of streaming I/O per read offered to a pass (8 B packed read + 4 B count
+    in + 4 B assignment out) + 64 B per LF step (two rank queries on the canonical 32-byte block)."""
+    return 16.0 * processed + 64.0 * steps
+
+
+def extended_bytes(s):
+    """Secondary accounting: + 8 B per jump-table load + 16 B per verified candidate."""
+    return survey_bytes(s["processed"], s["steps"]) + 8.0 * s["lookups"] + 16.0 * s["candidates"]
+
+
+def kernel_name(W, table_row, s, n_bases):
+    """The instantiation rocprofv3 names for the launch pass `s` ran in."""
+    if s["lds_mode"] == 4:
+        return "mrg::fused_kernel<%d>" % W
+    has_ctx = n_bases >= (1 << 20) and s["lds_mode"] in (0, 1)
+    return "mrg::match_kernel<%d, %s, %s, %s, %s>" % (
+        W, {0: "false, false", 1: "true, false", 2: "true, true", 3: "false, true"}[s["lds_mode"]],
+        "true" if table_row[4] == 2 else "false", "true" if has_ctx else "false",
+        "true" if n_bases <= 190000 else "false")
+
+
+def launch_table(st, per_pass_ms, table, index, W):
+    """One entry per kernel launch of the last step (a fused launch covers several passes)."""
+    launches = []
+    for i, s in enumerate(st):
+        skipped = s["processed"] == 0 and s["lds_bytes"] == 0 and per_pass_ms[i] < 0.05 and i + 1 < len(st) \
+            and s["lds_mode"] != 4
+        if skipped:
+            continue
+        if s["group"] != i and launches and launches[-1]["first"] == s["group"]:
+            L = launches[-1]
+        else:
+            L = dict(first=i, passes=[], ms=0.0, processed=0, steps=0, ext=0.0,
+                     kernel=kernel_name(W, table[i], s, index[table[i][0]].info.n_bases))
+            launches.append(L)
+        L["passes"].append(i)
+        L["ms"] += float(per_pass_ms[i])
+        L["processed"] += s["processed"]
+        L["steps"] += s["steps"]
+        L["ext"] += extended_bytes(s)
+    return launches
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["cascade", "exact", "varlen"], default="cascade",
-                    help="cascade = headline (100 M x 22 nt, configs[2]/[3]); exact = configs[1]; varlen = "
-                         "secondary run with lengths U{16..40} (hairpin pass, two-word reads; SURVEY.md 8d)")
-    ap.add_argument("--reads-per-gpu", type=int, default=None)
+    ap.add_argument("--workload", choices=["cascade", "exact", "varlen", "a2i"], default="cascade",
+                    help="cascade = headline (100 M x 22 nt, configs[2]/[3]); exact = configs[1]; varlen = secondary "
+                         "run with lengths U{16..40}; a2i = configs[4] (mouse-seeded libraries, 50 M reads with "
+                         "A->G edits, cascade + tally + A-to-I position tally)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--reads", type=int, default=None, help="reads of the whole job (strong) / per GPU (weak)")
+    ap.add_argument("--reads-per-gpu", type=int, default=None, help="= --scaling weak --reads R")
     ap.add_argument("--scale", type=float, default=1.0, help="library size factor (1.0 = SURVEY 8d shapes)")
     ap.add_argument("--samples", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=100_000_000,
                     help="reads of rank 0's shard the CPU port re-annotates (baseline + parity gate)")
+    ap.add_argument("--scan-sample", type=int, default=2000,
+                    help="distinct reads re-annotated by exhaustive scan of the library texts (no index at all)")
+    ap.add_argument("--bowtie-sample", type=int, default=100_000, help="reads for the bowtie probe, if bowtie exists")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the e2e and collapsed legs")
     ap.add_argument("--wstop", type=int, default=None)
     ap.add_argument("--no-ftab", action="store_true")
     ap.add_argument("--sorted", action="store_true",
@@ -54,6 +120,8 @@ def main():
     ap.add_argument("--mix", action="append", default=[],
                     help="override a fraction of the read mixture, e.g. polyt=0 (experiments; not the headline workload)")
     args = ap.parse_args()
+    if args.reads_per_gpu is not None:
+        args.scaling, args.reads = "weak", args.reads_per_gpu
 
     import torch
     from mirge_amd import dist as mdist
@@ -66,47 +134,52 @@ def main():
     if world > 1:
         mdist.init_process_group("nccl")
 
-    from mirge_amd import pack, synth
-    from mirge_amd.engine import Engine, ReadSet, MIRGE_PASS_TABLE
+    from mirge_amd import synth
+    from mirge_amd.engine import Engine, ReadSet, MIRGE_PASS_TABLE, DEFAULT_WSTOP
     from mirge_amd.index import FmIndex
 
-    n_reads = args.reads_per_gpu or {"cascade": 100_000_000, "exact": 10_000_000, "varlen": 20_000_000}[args.workload]
-    keys = ["mirna"] if args.workload == "exact" else list(synth.LIB_KEYS)
+    wl = args.workload
+    n_job = args.reads or DEFAULT_READS[wl]
+    keys = ["mirna"] if wl == "exact" else list(synth.LIB_KEYS)
 
     # ---- libraries + indexes (host; identical on every rank) ----
-    # index construction (C++, releases the GIL) overlaps with read generation below
     from concurrent.futures import ThreadPoolExecutor
     t0 = time.time()
-    libs = synth.SynthLibraries(seed=20181, scale=args.scale)
+    if wl == "a2i":
+        libs = synth.SynthLibraries(seed=synth.MOUSE_SEED, scale=args.scale, shapes=synth.MOUSE_SHAPES)
+    else:
+        libs = synth.SynthLibraries(seed=20181, scale=args.scale)
     pool = ThreadPoolExecutor(max_workers=len(keys))
     futures = {k: pool.submit(FmIndex.build, *libs.libs[k]) for k in keys}
 
-    # ---- this rank's shard of reads (seeded per rank), packed, moved to HBM once ----
-    mix = None if args.workload == "cascade" else synth.EXACT_ONLY_MIX
+    # ---- this rank's reads ----
+    mix = None
+    if wl == "exact":
+        mix = synth.EXACT_ONLY_MIX
+    elif wl == "a2i":
+        mix = synth.A2I_MIX
     if args.mix:
         mix = dict(synth.DEFAULT_MIX if mix is None else mix)
         for kv in args.mix:
             k, v = kv.split("=")
             mix[k] = float(v)
-    chunk = 10_000_000
-    if args.workload == "varlen":
-        words = np.empty((2, n_reads), dtype=np.uint64)
-        lens = np.empty(n_reads, dtype=np.uint8)
-        for lo in range(0, n_reads, chunk):
-            m = min(chunk, n_reads - lo)
-            words[:, lo:lo + m], lens[lo:lo + m] = synth.synth_reads_varlen(
-                libs, m, seed=977 + 1000 * rank + lo // chunk)
+    if args.scaling == "strong":
+        lo, hi = mdist.shard_bounds(n_job, rank, world)
+        n_total = n_job
+        seed0 = 355
     else:
-        words = np.empty((1, n_reads), dtype=np.uint64)
-        for lo in range(0, n_reads, chunk):
-            m = min(chunk, n_reads - lo)
-            words[0, lo:lo + m] = synth.synth_reads_packed(libs, m, seed=355 + 1000 * rank + lo // chunk, mix=mix)
-        if args.sorted:
-            words[0].sort()
-        lens = np.full(n_reads, 22, dtype=np.uint8)
-    quant = synth.synth_quant(n_reads, args.samples, seed=355 + rank)
-    log(rank, "reads: %d (%s) generated+packed in %.1f s" %
-        (n_reads, "16..40 nt" if args.workload == "varlen" else "22 nt", time.time() - t0))
+        lo, hi = 0, n_job
+        n_total = n_job * world
+        seed0 = 355 + 1000 * rank
+    n_reads = hi - lo
+    words, lens, quant = synth.global_read_slice(
+        libs, n_job, lo, hi, workload=("varlen" if wl == "varlen" else "cascade"),
+        seed0=seed0 + (4000 if wl == "a2i" else 0), mix=mix, n_samples=args.samples)
+    if args.sorted:
+        order = np.argsort(words[0], kind="stable")
+        words, lens, quant = np.ascontiguousarray(words[:, order]), lens[order], quant[order]
+    log(rank, "reads: %d of %d (%s, %s scaling) generated+packed in %.1f s" %
+        (n_reads, n_total, "16..40 nt" if wl == "varlen" else "22 nt", args.scaling, time.time() - t0))
     index = {k: f.result() for k, f in futures.items()}
     pool.shutdown()
     log(rank, "libraries + indexes (%s bp) ready after %.1f s" %
@@ -122,19 +195,21 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         eng.set_option(k, int(v))
-    if args.workload in ("cascade", "varlen"):
+    if wl == "exact":
+        table = MIRGE_PASS_TABLE[:1]
+        passes = eng.make_passes([dict(lib="mirna", min_len=0, max_len=25, seed_len=28, max_mm_seed=0, max_mm_total=2)])
+        canon, iso = 0, -1
+    else:
         passes = eng.mirge_passes()
         table = MIRGE_PASS_TABLE[:9]
         canon, iso = 0, 8
-    else:
-        table = MIRGE_PASS_TABLE[:1]
-        passes = eng.make_passes([dict(lib="mirna", min_len=0, max_len=25, seed_len=28, max_mm_seed=0,
-                                       max_mm_total=2)])
-        canon, iso = 0, -1
     n_pass = len(passes)
     M = index["mirna"].n_ref
+    S = args.samples
     rs = ReadSet(words, lens, None, quant, device=eng.device)
-    fused, ln = mdist.fused_buffer(eng.counts_len(M, args.samples, n_pass), n_pass=n_pass, device=eng.device)
+    n_edit = eng.edit_counts_len("mirna", S) if wl == "a2i" else 0
+    fused, ln = mdist.fused_buffer(eng.counts_len(M, S, n_pass) + n_edit, n_pass=n_pass, device=eng.device)
+    ln_tally = ln - n_edit
     out = (torch.empty(n_reads, dtype=torch.int8, device=eng.device),
            torch.empty(n_reads, dtype=torch.int32, device=eng.device),
            torch.empty(n_reads, dtype=torch.int32, device=eng.device),
@@ -144,7 +219,9 @@ def main():
     def step():
         fused.zero_()
         res = eng.cascade(rs, passes, out=out)
-        eng.tally(rs, res, M, canon, iso, counts=fused[:ln])
+        eng.tally(rs, res, M, canon, iso, counts=fused[:ln_tally])
+        if wl == "a2i":
+            eng.edit_tally(rs, res, "mirna", canon, iso, counts=fused[ln_tally:ln])
         mdist.allreduce_counts(fused)
         return res
 
@@ -170,107 +247,185 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    ms_per_step = elapsed * 1e3 / args.steps
-    value = n_reads * world / (ms_per_step * 1e-3) / 1e6
+    ms_per_step = elapsed * 1e3 / max(args.steps, 1)
+    value = n_total / (ms_per_step * 1e-3) / 1e6
 
     if rank != 0:
         return
 
-    # ---- roofline of the dominant kernel (by instantiation, as rocprof names it) ----
-    # Algorithmic bytes per unit (DESIGN.md "Measurement"): 16 B per read offered to a
-    # pass (8 B packed read + 4 B index/count in + 4 B assignment out), 64 B per LF step
-    # (two rank queries, canonical 32-byte occ block each -- SURVEY.md 8d), 8 B per
-    # jump-table load, 16 B per verified candidate (8 B suffix-array row + 8 B text window).
-    def alg_bytes(s):
-        return 16.0 * s["processed"] + 64.0 * s["steps"] + 8.0 * s["lookups"] + 16.0 * s["candidates"]
-
-    def survey_bytes(s):
-        return 16.0 * s["processed"] + 64.0 * s["steps"]
-
-    groups = {}
-    # a pass whose length window excludes the whole batch is not launched (host length hint)
-    skipped = [s["processed"] == 0 and s["lds_bytes"] == 0 and per_pass_ms[i] < 0.05 and i + 1 < len(st)
-               for i, s in enumerate(st)]
-    for i, s in enumerate(st):
-        if skipped[i]:
-            continue
-        # <W, occ blocks in LDS, text in LDS, stratum-first (the 2-mismatch policy), row context
-        # (libraries of >= 2^20 bases, never with the text in LDS)>
-        # ..., 9-mer bitmap in LDS (libraries of at most 190 000 bases)>
-        nb = index[table[i][0]].info.n_bases
-        has_ctx = nb >= (1 << 20) and s["lds_mode"] in (0, 1)
-        if s["lds_mode"] == 4:
-            name = "mrg::fused_kernel<%d>" % rs.W
-        else:
-            name = "mrg::match_kernel<%d, %s, %s, %s, %s>" % (
-                rs.W, {0: "false, false", 1: "true, false", 2: "true, true", 3: "false, true"}[s["lds_mode"]],
-                "true" if table[i][4] == 2 else "false", "true" if has_ctx else "false",
-                "true" if nb <= 190000 else "false")
-        g = groups.setdefault(name, dict(ms=0.0, bytes=0.0, sbytes=0.0, launches=0, passes=[]))
-        g["ms"] += per_pass_ms[i]
-        g["bytes"] += alg_bytes(s)
-        g["sbytes"] += survey_bytes(s)
-        g["launches"] += 1 if s["group"] == i else 0
-        g["passes"].append(i)
-    dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
-    achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-    traffic = None
+    # ---- roofline of the dominant kernel (by instantiation, as rocprofv3 names it) ----
+    launches = launch_table(st, per_pass_ms, table, index, rs.W)
+    by_kernel = {}
+    for L in launches:
+        g = by_kernel.setdefault(L["kernel"], dict(ms=0.0, sbytes=0.0, ext=0.0, launches=0, passes=[], processed=0))
+        g["ms"] += L["ms"]
+        g["sbytes"] += survey_bytes(L["processed"], L["steps"])
+        g["ext"] += L["ext"]
+        g["launches"] += 1
+        g["passes"] += L["passes"]
+        g["processed"] += L["processed"]
+    dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
+    achieved = dom["sbytes"] / max(dom["ms"], 1e-9) / 1e6
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            ent = tj.get(args.workload, {}).get(dom_name)
+            ent = tj.get(wl, {}).get(dom_name)
             if ent and ent.get("reads_per_gpu") == n_reads:
                 traffic = ent["hbm_bytes_per_launch"]
+                traffic_src = dict(file="profiles/traffic.json", collected_at=tj.get("_meta", {}).get("git_head"),
+                                   fetch_bytes_raw=ent.get("fetch_bytes_raw"),
+                                   fetch_bytes_doubled=ent.get("fetch_bytes_doubled"),
+                                   write_bytes=ent.get("write_bytes"), applies=ent.get("applies"))
         except Exception:
             traffic = None
-    roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, kernel=dom_name,
-                    launches_per_step=dom["launches"],
-                    avg_launch_ms=round(dom["ms"] / dom["launches"], 4),
-                    algorithmic_bytes_per_launch=int(dom["bytes"] / dom["launches"]),
-                    achieved_survey_8d_formula=round(dom["sbytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
-                    note="bytes = 16*reads + 64*LF steps + 8*jump-table loads + 16*candidates; "
-                         "libraries staged in LDS serve most of them on-chip, so this is an "
-                         "HBM-normalised rate, not HBM traffic (see traffic)")
+    whole_bytes = sum(survey_bytes(s["processed"], s["steps"]) for s in st)
+    roofline = dict(
+        bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src, kernel=dom_name,
+        launches_per_step=dom["launches"], passes=dom["passes"], avg_launch_ms=round(dom["ms"] / dom["launches"], 4),
+        algorithmic_bytes_per_launch=int(dom["sbytes"] / dom["launches"]),
+        formula="SURVEY.md 8d: 16 B x reads offered to each cascade pass the launch runs + 64 B x LF steps",
+        compulsory_floor_ms=round(16.0 * dom["processed"] / dom["launches"] / (HBM_ACHIEVABLE_GBS * 1e6), 4),
+        achieved_extended=round(dom["ext"] / max(dom["ms"], 1e-9) / 1e6, 1),
+        extended_formula="+ 8 B per jump-table load + 16 B per verified candidate (most of them served on chip "
+                         "or by L2: a rate, not HBM traffic)",
+        whole_step=dict(algorithmic_bytes=int(whole_bytes), achieved=round(whole_bytes / (ms_per_step * 1e6), 1),
+                        frac=round(whole_bytes / (ms_per_step * 1e6) / HBM_PEAK_GBS, 4),
+                        compulsory_floor_ms=round(sum(16.0 * s["processed"] for s in st) / (HBM_ACHIEVABLE_GBS * 1e6), 3)))
     passes_report = []
     for i, s in enumerate(st):
+        L = next((x for x in launches if i in x["passes"]), None)
         passes_report.append(dict(
-            lib=table[i][0], ms=round(float(per_pass_ms[i]), 4), processed=s["processed"],
-            aligned=s["aligned"], steps=s["steps"], candidates=s["candidates"], lookups=s["lookups"],
-            lds_bytes=s["lds_bytes"],
-            kernel="not launched" if skipped[i] else
-                   "match_kernel<%d,%s%s>" % (rs.W, ["hbm", "blocks", "blocks+text", "text", "fused"][s["lds_mode"]],
-                                             ",strata" if table[i][4] == 2 else ""),
-            group=s["group"], kbits_log2=s["kbits_log2"],
-            alg_gbs=round(alg_bytes(s) / max(per_pass_ms[i], 1e-9) / 1e6, 1)))
+            lib=table[i][0], ms=round(float(per_pass_ms[i]), 4), processed=s["processed"], aligned=s["aligned"],
+            steps=s["steps"], candidates=s["candidates"], lookups=s["lookups"], lds_bytes=s["lds_bytes"],
+            kernel="not launched" if L is None else L["kernel"].replace("mrg::", ""),
+            launch=None if L is None else L["first"], kbits_log2=s["kbits_log2"],
+            compulsory_floor_ms=round(16.0 * s["processed"] / (HBM_ACHIEVABLE_GBS * 1e6), 4)))
 
-    # ---- CPU baseline: the oracle's port on a bounded sample, all host cores ----
-    cpu = None
-    if not args.no_cpu_baseline and world == 1:  # the CPU leg is reported at N=1 only
+    # ---- parity gates + CPU baseline (rank 0, N = 1 only) ----
+    cpu, parity = None, {}
+    got = None
+    if not args.no_cpu_baseline and world == 1:
         from oracle import model
+        from mirge_amd import pack
+        got = [t.cpu().numpy() for t in out[:4]]
+        counts_gpu = fused[:ln].cpu().numpy().astype(np.uint64)
+        pd = [dict(lib=keys.index(k), min_len=a, max_len=b, seed_len=s_, max_mm_seed=ms, max_mm_total=mt,
+                   trim5=t5, trim3=t3, poly_t=pt, kbits_log2=st[i]["kbits_log2"])
+              for i, (k, a, b, s_, ms, mt, t5, t3, pt) in enumerate(table)]
+        views = [index[k].view() for k in keys]
+        wst = DEFAULT_WSTOP if args.wstop is None else args.wstop
         m = min(args.cpu_sample, n_reads)
         cores = os.cpu_count() or 1
-        pd = [dict(lib=keys.index(k), min_len=a, max_len=b, seed_len=s_, max_mm_seed=ms, max_mm_total=mt,
-                   trim5=t5, trim3=t3, poly_t=pt) for (k, a, b, s_, ms, mt, t5, t3, pt) in table]
-        views = [index[k].view() for k in keys]
-        from mirge_amd.engine import DEFAULT_WSTOP
-        wst = DEFAULT_WSTOP if args.wstop is None else args.wstop
         t1 = time.perf_counter()
-        ref = model.fm_cascade(views, pd, words[:, :m], lens[:m], None, wstop=wst, threads=cores,
-                               ftab=not args.no_ftab)
+        ref = model.fm_cascade(views, pd, words[:, :m], lens[:m], None, wstop=wst, threads=cores, ftab=not args.no_ftab)
         cnt = model.tally(ref["pass_id"], ref["ref_id"], quant[:m], M, n_pass, canon, iso)
         dt = time.perf_counter() - t1
-        # parity gate on the same sample: identical assignments before any number is reported
-        got = [t[:m].cpu().numpy() for t in out[:4]]
         for name, a in zip(("pass_id", "ref_id", "pos", "mm"), got):
-            if not np.array_equal(a, ref[name]):
+            if not np.array_equal(a[:m], ref[name]):
                 raise SystemExit("PARITY FAILURE on %s: GPU and CPU port disagree" % name)
+        if m == n_reads and not np.array_equal(cnt, counts_gpu[:ln_tally]):
+            raise SystemExit("PARITY FAILURE: the count vector differs from the CPU port's tally")
+        parity["cpu_port"] = "pass_id/ref_id/pos/mm identical on %d reads%s (oracle/fm_cpu.c, which reads the " \
+                             "product's index arrays)" % (m, "; count vector identical" if m == n_reads else "")
         cpu = dict(value=round(m / dt / 1e6, 4), unit="M reads/s", cores=cores, kind="port",
-                   sample="first %d reads of rank 0's shard, full %d-pass cascade + tally, "
-                          "oracle/fm_cpu.c with OpenMP on %d threads (%.1f s)" % (m, n_pass, cores, dt),
+                   sample="first %d reads of rank 0's shard, full %d-pass cascade + tally, oracle/fm_cpu.c with "
+                          "OpenMP on %d threads (%.1f s)" % (m, n_pass, cores, dt),
                    parity="assignments identical on the sample")
+        if wl == "a2i":
+            t1 = time.perf_counter()
+            want = model.edit_tally(index["mirna"], got[0], got[1], got[2], words, lens, quant, canon, iso)
+            if not np.array_equal(want.reshape(-1), counts_gpu[ln_tally:ln]):
+                raise SystemExit("PARITY FAILURE: the A-to-I position tally differs from the oracle's")
+            parity["edit_tally"] = "substitution counts per (miRNA, position, type, sample) identical on all %d " \
+                                   "reads (numpy restatement, %.1f s)" % (n_reads, time.perf_counter() - t1)
 
+        # -- independent of the index: exhaustive scan of the library TEXTS on a sample of distinct reads
+        if args.scan_sample > 0 and wl != "exact":
+            from oracle import cascade as ocascade
+            rng = np.random.default_rng(99)
+            pick = rng.choice(n_reads, size=min(n_reads, 4 * args.scan_sample), replace=False)
+            seqs = pack.unpack_reads(np.ascontiguousarray(words[:, pick]), lens[pick], None)
+            first = {}
+            for j, sq in zip(pick, seqs):
+                first.setdefault(sq, int(j))
+                if len(first) >= args.scan_sample:
+                    break
+            t1 = time.perf_counter()
+            olibs = {k: model.Library(*libs.libs[k]) for k in keys}
+            seq_dic = {sq: ocascade.new_seq_record(sq, 1) for sq in first}
+            log_dic = {"quantStats": [{}], "annotStats": []}
+            align = {}
+            ocascade.run_annotation_pipeline(seq_dic, olibs, log_dic, align_dic=align)
+            bad = 0
+            for sq, j in first.items():
+                a = align.get(sq)
+                mine = (int(got[0][j]), int(got[1][j]), int(got[2][j]), int(got[3][j]))
+                bad += mine != (tuple(a) if a is not None else (-1, -1, -1, 0))
+            if bad:
+                raise SystemExit("PARITY FAILURE: %d of %d sampled reads differ from the exhaustive scan" % (bad, len(first)))
+            parity["exhaustive_scan"] = "claiming pass, entry, offset and mismatches identical on %d distinct sampled " \
+                                        "reads against the full-size library texts (oracle/bowtie_model.c: no index, " \
+                                        "%.1f s on %d threads)" % (len(first), time.perf_counter() - t1, cores)
+
+        # -- a real bowtie 1, if this box has one: the reference's own command lines
+        from oracle import bowtie_probe
+        found = bowtie_probe.find_bowtie()
+        if found is None:
+            parity["bowtie"] = "no bowtie / bowtie-build on this box (PATH probed): aligner parity stays unpinned"
+        elif wl != "exact":
+            mb = min(args.bowtie_sample, n_reads)
+            all_seqs = pack.unpack_reads(np.ascontiguousarray(words[:, :mb]), lens[:mb], None)
+            where = {}
+            for j, sq in enumerate(all_seqs):
+                where.setdefault(sq, j)
+            seqs = list(where)
+            bref = bowtie_probe.reference_cascade(found[0], found[1], {k: libs.libs[k] for k in keys}, seqs, threads=cores)
+            names = {k: index[k].names for k in keys}
+            mine_pass = np.array([got[0][where[sq]] for sq in seqs], dtype=np.int8)
+            mine_name = [names[table[got[0][where[sq]]][0]][got[1][where[sq]]] if got[0][where[sq]] >= 0 else ""
+                         for sq in seqs]
+            mine_pos = np.array([got[2][where[sq]] for sq in seqs], dtype=np.int32)
+            d = bowtie_probe.compare(bref, mine_pass, mine_name, mine_pos)
+            parity["bowtie"] = "real bowtie (%s): %d distinct reads, D1 (claiming pass) disagreements %d, D2 (miRNA " \
+                               "entry, tie-break) %d, D3 (other entry/offset, tie-break) %d" % (
+                                   found[0], len(seqs), d["D1"], d["D2"], d["D3"])
+            cpu = dict(value=round(len(seqs) / bref["seconds"] / 1e6, 4), unit="M reads/s", cores=cores, kind="reference",
+                       sample="%d distinct reads through the nine bowtie command lines of runAnnotationPipeline.py:577-599 "
+                              "(--threads %d) + SAM parsing in Python (%.1f s; bowtie-build %.1f s not counted)" %
+                              (len(seqs), cores, bref["seconds"], bref["build_seconds"]),
+                       parity="D1 %d / D2 %d / D3 %d" % (d["D1"], d["D2"], d["D3"]), port=cpu)
+            if d["D1"]:
+                raise SystemExit("PARITY FAILURE vs bowtie: %d reads claimed by a different pass" % d["D1"])
+
+    # ---- extras (N = 1): end-to-end with PCIe, and the collapsed pipeline ----
+    extras = {}
+    if world == 1 and not args.no_extras:
+        try:
+            extras["e2e"] = run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, got, log)
+        except SystemExit:
+            raise
+        except Exception as e:  # the headline must not die with an optional leg
+            extras["e2e"] = dict(error=repr(e))
+        if wl == "cascade":
+            try:
+                extras["collapsed"] = run_collapsed(eng, passes, rs, out, M, n_pass, canon, iso, log)
+            except SystemExit:
+                raise
+            except Exception as e:
+                extras["collapsed"] = dict(error=repr(e))
+
+    what = {
+        "cascade": "%d M x 22 nt reads, full 9-pass cascade over 8 synthetic human-sized libraries + isomiR/count tally "
+                   "(BASELINE configs[2]%s)" % (n_total // 1_000_000,
+                                                "; sharded over %d GPUs = configs[3]" % world if world > 1 else ""),
+        "exact": "%d M x 22 nt unique reads, exact match vs miRNA library (BASELINE configs[1])" % (n_total // 1_000_000),
+        "varlen": "SECONDARY (not the headline): reads of 16..40 nt, two words per read, full 9-pass cascade incl. "
+                  "the hairpin pass (SURVEY.md 8d)",
+        "a2i": "%d M x 22 nt reads with seeded A->G edits, mouse-seeded libraries, 9-pass cascade (1-mismatch seed "
+               "search) + count tally + A-to-I position tally (BASELINE configs[4])" % (n_total // 1_000_000)}[wl]
     line = {
         "metric": "M reads/s annotated (whole node)",
         "value": round(value, 3),
@@ -280,26 +435,195 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "u64/u32 (2-bit packed bases, integer rank/popcount)",
-        "data": "synthetic (seeded libraries + %s reads, SURVEY.md 8d)" %
-                ("16..40 nt" if args.workload == "varlen" else "22 nt"),
+        "data": "synthetic (seeded libraries + %s reads, SURVEY.md 8d)" % ("16..40 nt" if wl == "varlen" else "22 nt"),
         "config": {
-            "workload": {
-                "cascade": "100 M x 22 nt reads per GPU, full 9-pass cascade over 8 synthetic human-sized "
-                           "libraries + isomiR/count tally (BASELINE configs[2]/[3])",
-                "exact": "10 M x 22 nt unique reads per GPU, exact match vs miRNA library (BASELINE configs[1])",
-                "varlen": "SECONDARY (not the headline): reads of 16..40 nt, two words per read, full 9-pass "
-                          "cascade incl. the hairpin pass (SURVEY.md 8d)"}[args.workload],
-            "reads_per_gpu": n_reads, "libraries_scale": args.scale, "samples": args.samples,
-            "parallelism": "read shards x%d, one RCCL all-reduce of the count vector" % world,
+            "workload": what, "reads_total": n_total, "reads_per_gpu": n_reads, "libraries_scale": args.scale,
+            "samples": S,
+            "parallelism": ("one read set in %d contiguous shards, libraries replicated, one RCCL all-reduce of the "
+                            "fused count vector per step" % world) if args.scaling == "strong" else
+                           ("%d independent read sets (weak scaling), one RCCL all-reduce of the count vector" % world),
         },
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "parity": parity,
         "passes": passes_report,
     }
+    line.update(extras)
     print(json.dumps(line))
+
+
+def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log, n_chunks=8, reps=3):
+    """SURVEY.md 8d "Timed region", throughput figure: H2D of packed reads + counts -> cascade ->
+    tally -> D2H of the assignment arrays and the count vector.  The host side is pinned; the read
+    set goes through in `n_chunks` chunks on three streams (copy in / compute / copy out) with two
+    device buffers, so PCIe transfers overlap the kernels."""
+    import torch
+    from mirge_amd.engine import ReadSet
+    dev = eng.device
+    W, n = words.shape
+    S = quant.shape[1]
+    t0 = time.perf_counter()
+    h_words = torch.from_numpy(words.view(np.int64)).pin_memory()
+    h_lens = torch.from_numpy(lens).pin_memory()
+    h_quant = torch.from_numpy(quant.view(np.int32)).pin_memory()
+    h_out = (torch.empty(n, dtype=torch.int8).pin_memory(), torch.empty(n, dtype=torch.int32).pin_memory(),
+             torch.empty(n, dtype=torch.int32).pin_memory(), torch.empty(n, dtype=torch.uint8).pin_memory())
+    ln = eng.counts_len(M, S, n_pass)
+    h_counts = torch.empty(ln, dtype=torch.int64).pin_memory()
+    pin_s = time.perf_counter() - t0
+    n_chunks = max(1, min(n_chunks, n // 1024 or 1))
+    bounds = [(n * c // n_chunks, n * (c + 1) // n_chunks) for c in range(n_chunks)]
+    cap = max(b - a for a, b in bounds)
+    bufs = []
+    for _ in range(2):
+        bufs.append(dict(
+            words=torch.empty((W, cap), dtype=torch.int64, device=dev), lens=torch.empty(cap, dtype=torch.uint8, device=dev),
+            quant=torch.empty((cap, S), dtype=torch.int32, device=dev),
+            out=(torch.empty(cap, dtype=torch.int8, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
+                 torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.uint8, device=dev)),
+            ev_in=torch.cuda.Event(), ev_done=torch.cuda.Event(), ev_free=torch.cuda.Event()))
+    counts = torch.zeros(ln, dtype=torch.int64, device=dev)
+    pc = torch.zeros(2 * n_pass, dtype=torch.int64, device=dev)
+    s_in, s_out, s_comp = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.current_stream(dev)
+    min_len, max_len = int(lens.min()), int(lens.max())
+
+    def one_pass():
+        counts.zero_()
+        for b in bufs:
+            b["ev_free"].record(s_comp)
+        for c, (a, e) in enumerate(bounds):
+            b = bufs[c % 2]
+            m = e - a
+            with torch.cuda.stream(s_in):
+                s_in.wait_event(b["ev_free"])
+                for w in range(W):
+                    b["words"][w, :m].copy_(h_words[w, a:e], non_blocking=True)
+                b["lens"][:m].copy_(h_lens[a:e], non_blocking=True)
+                b["quant"][:m].copy_(h_quant[a:e], non_blocking=True)
+                b["ev_in"].record(s_in)
+            s_comp.wait_event(b["ev_in"])
+            # the SoA stride of the cascade is the row length of the words array it is handed
+            wv = b["words"] if m == cap else b["words"][:, :m].contiguous()
+            rsc = ReadSet.from_device(wv, b["lens"][:m], None, b["quant"][:m], min_len, max_len)
+            o = tuple(t[:m] for t in b["out"]) + (pc,)
+            res = eng.cascade(rsc, passes, out=o)
+            eng.tally(rsc, res, M, canon, iso, counts=counts)
+            b["ev_done"].record(s_comp)
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(b["ev_done"])
+                for t_d, t_h in zip(b["out"], h_out):
+                    t_h[a:e].copy_(t_d[:m], non_blocking=True)
+                b["ev_free"].record(s_out)
+        with torch.cuda.stream(s_out):
+            s_out.wait_event(bufs[(len(bounds) - 1) % 2]["ev_done"])
+            h_counts.copy_(counts, non_blocking=True)
+        torch.cuda.synchronize()
+
+    one_pass()  # warm-up (also the run whose output is checked)
+    ok = None
+    if expect is not None:
+        ok = all(np.array_equal(h.numpy(), g) for h, g in zip(h_out, expect))
+        if not ok:
+            raise SystemExit("PARITY FAILURE: chunked end-to-end run differs from the resident run")
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one_pass()
+    ms = (time.perf_counter() - t0) * 1e3 / reps
+    # the two transfers alone, for the record
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for c, (a, e) in enumerate(bounds):
+        b = bufs[c % 2]
+        for w in range(W):
+            b["words"][w, :e - a].copy_(h_words[w, a:e], non_blocking=True)
+        b["lens"][:e - a].copy_(h_lens[a:e], non_blocking=True)
+        b["quant"][:e - a].copy_(h_quant[a:e], non_blocking=True)
+    torch.cuda.synchronize()
+    h2d_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    for c, (a, e) in enumerate(bounds):
+        b = bufs[c % 2]
+        for t_d, t_h in zip(b["out"], h_out):
+            t_h[a:e].copy_(t_d[:e - a], non_blocking=True)
+    torch.cuda.synchronize()
+    d2h_ms = (time.perf_counter() - t0) * 1e3
+    h2d_bytes = n * (8 * W + 1 + 4 * S)
+    d2h_bytes = n * 10
+    log(0, "e2e: %.2f ms per %d reads (H2D alone %.2f ms, D2H alone %.2f ms; pinning the host arrays took %.1f s)" %
+        (ms, n, h2d_ms, d2h_ms, pin_s))
+    return dict(ms_per_step=round(ms, 3), value=round(n / ms / 1e3, 3), unit="M reads/s", chunks=n_chunks,
+                h2d_ms=round(h2d_ms, 3), d2h_ms=round(d2h_ms, 3), h2d_bytes=h2d_bytes, d2h_bytes=d2h_bytes,
+                h2d_gbs=round(h2d_bytes / h2d_ms / 1e6, 1), d2h_gbs=round(d2h_bytes / d2h_ms / 1e6, 1),
+                parity=None if ok is None else "assignments identical to the resident run",
+                note="SURVEY.md 8d timed region: pinned host arrays -> H2D (packed reads + lengths + counts) -> "
+                     "cascade -> tally -> D2H (pass_id, ref_id, pos, mm, count vector); double-buffered chunks on "
+                     "three HIP streams")
+
+
+def run_collapsed(eng, passes, rs, out, M, n_pass, canon, iso, log, reps=3):
+    """The reference's own order of work (quantReads.py:3-24 before runAnnotationPipeline): the
+    resident records are treated as RAW reads, collapsed on the GPU (mrg_collapse_run) and the
+    cascade + tally run over the unique reads with their multiplicities."""
+    import torch
+    from mirge_amd.engine import CascadeResult, ReadSet
+    dev = eng.device
+    n = rs.n
+    max_len = rs.max_len
+
+    def one():
+        urs, _hist = eng.collapse(rs.words, rs.lens, None, None, 1, max_len)
+        urs.min_len = rs.min_len
+        counts = torch.zeros(eng.counts_len(M, 1, n_pass), dtype=torch.int64, device=dev)
+        res = eng.cascade(urs, passes)
+        eng.tally(urs, res, M, canon, iso, counts=counts)
+        return urs, res, counts
+
+    torch.cuda.synchronize()
+    urs, res, counts = one()
+    torch.cuda.synchronize()
+    # parity: a unique read's assignment is the one its records got in the resident run, and the
+    # multiplicity-weighted tally equals the record-level tally with every record counting once
+    ok = None
+    if rs.W == 1 and rs.min_len == rs.max_len:
+        rng = np.random.default_rng(5)
+        pick_t = torch.from_numpy(np.sort(rng.choice(n, size=min(n, 200_000), replace=False))).to(dev)
+        w_rec = rs.words[0, pick_t]
+        uw = urs.words[0]
+        where = torch.searchsorted(uw, w_rec)
+        ok = bool(torch.equal(uw[where], w_rec))
+        for a_u, a_r in zip((res.pass_id, res.ref_id, res.pos, res.mm), out[:4]):
+            ok = ok and bool(torch.equal(a_u[where], a_r[pick_t]))
+        ones = torch.ones((n, 1), dtype=torch.int32, device=dev)
+        rec = CascadeResult(out[0], out[1], out[2], out[3], None, eng, n_pass)
+        c_rec = eng.tally(ReadSet.from_device(rs.words, rs.lens, None, ones), rec, M, canon, iso)
+        k = 2 * M + n_pass + 1   # everything but trimmedUniq, which counts records there and uniques here
+        ok = ok and bool(torch.equal(c_rec[:k], counts[:k])) and int(counts[k]) == urs.n
+        if not ok:
+            raise SystemExit("PARITY FAILURE: collapsed pipeline differs from the record-level run")
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        urs2, _h = eng.collapse(rs.words, rs.lens, None, None, 1, max_len)   # synchronises (n_unique)
+        urs2.min_len = rs.min_len
+        t_c = time.perf_counter() - t0
+        counts2 = torch.zeros(eng.counts_len(M, 1, n_pass), dtype=torch.int64, device=dev)
+        res2 = eng.cascade(urs2, passes)
+        eng.tally(urs2, res2, M, canon, iso, counts=counts2)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0, t_c))
+    total, t_c = min(ts)
+    log(0, "collapsed: %d raw -> %d unique reads; collapse %.2f ms + cascade/tally %.2f ms" %
+        (n, urs.n, t_c * 1e3, (total - t_c) * 1e3))
+    return dict(raw_reads=n, unique_reads=urs.n, collapse_ms=round(t_c * 1e3, 3),
+                cascade_tally_ms=round((total - t_c) * 1e3, 3), ms_per_step=round(total * 1e3, 3),
+                value=round(n / total / 1e6, 3), unit="M raw reads/s",
+                parity=None if ok is None else "unique reads carry the assignment of their records (200 000 sampled); "
+                                               "multiplicity-weighted count vector identical to the record-level tally",
+                note="quantReads.py:3-24 then the cascade: what the reference does with 100 M raw reads")
 
 
 if __name__ == "__main__":

@@ -223,6 +223,32 @@ int mrg_tally_run(mrg_ctx *ctx, const int8_t *d_pass_id, const int32_t *d_ref_id
                   int32_t isomir_pass, uint64_t *d_counts, void *stream);
 
 /*
+ * A-to-I position tally: the per-read part of A2IEditing (utils/writeDataToCSV.py:145-229) and
+ * judgeAllign (:35-69) on the alignments the cascade already produced, for the reads claimed by
+ * the exact-miRNA pass (canon_pass) or the isomiR pass (isomir_pass, whose reported position is
+ * that of the first base after its `-5` trim: isomir_trim5).  A library entry is flank5 + mature
+ * + flank3 bases (runAnnotationPipeline.py:413: 2 and 6); a read is kept when judgeAllign keeps
+ * it -- starts at most 1 nt after the mature sequence, at most 1 mismatch and enough matches over
+ * the window that function compares -- and, if d_keep is given, d_keep[r] != 0 (the host's
+ * genome-uniqueness / RPM selection, :1251-1287, :1293-1300).  Per output bin b (= entry, or
+ * d_remap[entry] for merged miRNA names; n_bins of them) and sample s, uint64, caller zeroes:
+ *   d_counts[(b * S + s) * 3 + 0]  count_true: summed counts of the kept reads
+ *   d_counts[(b * S + s) * 3 + 1]  seq_true:   number of kept reads with a non-zero count
+ *   d_counts[(b * S + s) * 3 + 2]  canonical:  counts of kept reads that are substrings of the mature sequence
+ *   d_counts[n_bins * S * 3 + (b * 32 + i) * S + s]  counts of kept reads showing `to_base` where
+ *       the mature sequence has `from_base` at (0-based) position i < mature length - 5 (:147,:168)
+ * Bases: A=0 C=1 G=2 T=3 (A-to-I reads as A -> G: from_base 0, to_base 2).
+ */
+int mrg_edit_counts_len(uint32_t n_bins, uint32_t n_samples, uint64_t *len);
+int mrg_edit_tally_run(mrg_ctx *ctx, const uint64_t *d_reads, uint32_t words_per_read,
+                       const uint8_t *d_lens, const uint64_t *d_nmask, const int8_t *d_pass_id,
+                       const int32_t *d_ref_id, const int32_t *d_pos, const uint32_t *d_quant,
+                       const uint8_t *d_keep, const uint32_t *d_remap, uint64_t n, uint32_t n_samples,
+                       uint32_t n_bins, int32_t lib, int32_t canon_pass, int32_t isomir_pass,
+                       int32_t isomir_trim5, uint32_t flank5, uint32_t flank3, uint32_t from_base,
+                       uint32_t to_base, uint64_t *d_counts, void *stream);
+
+/*
  * Best stratum of every read against ONE library, forward strand only: d_best_mm[r] = fewest
  * mismatches of a valid alignment (255 = the read does not align), d_count[r] = number of
  * alignments reaching it (saturates at 255; also 255 when a seed is too repetitive to be

@@ -86,6 +86,11 @@ SIGNATURES = {
     "mrg_tally_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                 C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
                                 C.c_void_p, C.c_void_p]),
+    "mrg_edit_counts_len": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "mrg_edit_tally_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                     C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "mrg_count_best": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
                                  C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                  C.c_void_p]),

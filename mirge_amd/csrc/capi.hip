@@ -57,6 +57,8 @@ struct DevLib {
   uint32_t* ftab = nullptr;
   mrg::JumpTables tabs = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   uint32_t n = 0, nblk = 0, nsup = 0, primary = 0, text_words = 0, n_seg = 0, n_ref = 0;
+  uint32_t max_ref_len = 0;
+  bool simple = false;  // every entry is exactly one N-free segment: segment id == entry id, offset 0
 };
 
 template <class T>
@@ -286,6 +288,11 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
   l.n_seg = (uint32_t)ix.seg_ref.size();
   l.n_ref = (uint32_t)ix.names.size();
   l.nsup = (uint32_t)(ix.super.size() / 4);
+  // (not just "as many segments as entries": an all-N entry and one with an inner N run would
+  // also give equal counts)
+  l.simple = l.n_seg == l.n_ref;
+  for (uint32_t sg = 0; l.simple && sg < l.n_seg; ++sg) l.simple = ix.seg_ref[sg] == sg && ix.seg_off[sg] == 0;
+  for (uint32_t v : ix.ref_len) l.max_ref_len = std::max(l.max_ref_len, v);
   std::vector<uint32_t> blk(reinterpret_cast<const uint32_t*>(ix.blocks.data()),
                             reinterpret_cast<const uint32_t*>(ix.blocks.data()) + ix.blocks.size() * 4);
   int rc;
@@ -500,7 +507,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     p.nsup = l.nsup;
     p.primary = l.primary;
     p.text_words = l.text_words;
-    p.simple_segs = (l.n_seg == l.n_ref) ? 1u : 0u;
+    p.simple_segs = l.simple ? 1u : 0u;
     p.reads = d_reads;
     p.lens = d_lens;
     p.nmask = d_nmask;
@@ -654,7 +661,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
       sp.counters = stats + (size_t)i * kStatsPerPass;
       sp.n = l.n;
       sp.primary = l.primary;
-      sp.simple_segs = (l.n_seg == l.n_ref) ? 1u : 0u;
+      sp.simple_segs = l.simple ? 1u : 0u;
       sp.kb_off = kb_words;
       sp.kb_mask = lg[q] ? (1u << lg[q]) - 1u : 0u;
       if (lg[q] == 18u) {
@@ -837,6 +844,69 @@ int mrg_tally_run(mrg_ctx* ctx, const int8_t* d_pass_id, const int32_t* d_ref_id
   uint32_t per_cu = lds_hist ? (lds * 2 <= 160 * 1024 ? 2u : 1u) : 2u;
   uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)ctx->n_cu * per_cu);
   HIP_TRY(mrg::launch_tally(p, lds_hist, grid, lds_hist ? (uint32_t)lds : 0u, (hipStream_t)stream_));
+  return MRG_OK;
+}
+
+// ------------------------------------------------------------ A-to-I position tally
+int mrg_edit_counts_len(uint32_t n_bins, uint32_t n_samples, uint64_t* len) {
+  if (!len) return fail(MRG_ERR_ARG, "mrg_edit_counts_len: null argument");
+  *len = (uint64_t)n_bins * n_samples * (3ull + mrg::kEditPositions);
+  return MRG_OK;
+}
+
+int mrg_edit_tally_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_read, const uint8_t* d_lens,
+                       const uint64_t* d_nmask, const int8_t* d_pass_id, const int32_t* d_ref_id,
+                       const int32_t* d_pos, const uint32_t* d_quant, const uint8_t* d_keep,
+                       const uint32_t* d_remap, uint64_t n, uint32_t n_samples, uint32_t n_bins, int32_t lib,
+                       int32_t canon_pass, int32_t isomir_pass, int32_t isomir_trim5, uint32_t flank5,
+                       uint32_t flank3, uint32_t from_base, uint32_t to_base, uint64_t* d_counts, void* stream) {
+  if (!ctx || !d_counts) return fail(MRG_ERR_ARG, "mrg_edit_tally_run: null argument");
+  if (n && (!d_reads || !d_lens || !d_pass_id || !d_ref_id || !d_pos || !d_quant))
+    return fail(MRG_ERR_ARG, "mrg_edit_tally_run: null buffers");
+  if (lib < 0 || (size_t)lib >= ctx->libs.size()) return fail(MRG_ERR_ARG, "mrg_edit_tally_run: unknown library %d", lib);
+  if (words_per_read != 1 && words_per_read != 2 && words_per_read != 4)
+    return fail(MRG_ERR_ARG, "mrg_edit_tally_run: words_per_read must be 1, 2 or 4");
+  if (n_samples == 0 || n_bins == 0 || from_base > 3 || to_base > 3 || from_base == to_base)
+    return fail(MRG_ERR_ARG, "mrg_edit_tally_run: bad n_samples / n_bins / bases");
+  const DevLib& l = ctx->libs[lib];
+  if (l.n_seg != l.n_ref || !l.simple)
+    return fail(MRG_ERR_ARG, "mrg_edit_tally_run: the miRNA library must hold one N-free segment per entry");
+  if (!d_remap && n_bins != l.n_ref)
+    return fail(MRG_ERR_ARG, "mrg_edit_tally_run: n_bins %u != %u library entries (no remap given)", n_bins, l.n_ref);
+  if (l.max_ref_len > mrg::kEditPositions + flank5 + flank3)
+    return fail(MRG_ERR_ARG, "mrg_edit_tally_run: a library entry is longer than %u + flanks", mrg::kEditPositions);
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (n == 0) return MRG_OK;
+  mrg::EditParams p;
+  p.reads = d_reads;
+  p.lens = d_lens;
+  p.nmask = d_nmask;
+  p.words_per_read = words_per_read;
+  p.pass_id = d_pass_id;
+  p.ref_id = d_ref_id;
+  p.pos = d_pos;
+  p.quant = d_quant;
+  p.keep = d_keep;
+  p.remap = d_remap;
+  p.n = n;
+  p.n_samples = n_samples;
+  p.n_bins = n_bins;
+  p.canon_pass = canon_pass;
+  p.isomir_pass = isomir_pass;
+  p.isomir_trim5 = isomir_trim5;
+  p.flank5 = flank5;
+  p.flank3 = flank3;
+  p.from_base = from_base;
+  p.to_base = to_base;
+  p.text = l.text;
+  p.seg_start = l.seg_start;
+  p.counts = d_counts;
+  const uint64_t lds = (uint64_t)n_bins * n_samples * 3ull * 8ull;
+  const bool lds_hist = lds <= (uint64_t)ctx->lds_budget;
+  const uint64_t want = (n + mrg::kEditThreads - 1) / mrg::kEditThreads;
+  const uint32_t per_cu = lds_hist ? (lds * 2 <= 160 * 1024 ? 2u : 1u) : 2u;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)ctx->n_cu * per_cu);
+  HIP_TRY(mrg::launch_edit_tally(p, lds_hist, grid, lds_hist ? (uint32_t)lds : 0u, (hipStream_t)stream));
   return MRG_OK;
 }
 

@@ -1417,6 +1417,145 @@ __global__ void __launch_bounds__(kTallyThreads) tally_kernel(const TallyParams 
   }
 }
 
+// ---------------------------------------------------------------------------
+// edit_tally_kernel: the per-read part of the A-to-I report (writeDataToCSV.py:145-229,
+// A2IEditing + judgeAllign :35-69) on the alignments the cascade already produced.
+// For a read claimed by the exact-miRNA or the isomiR pass, entry e, entry offset o of its first
+// base (pos, minus the -5 trim of the isomiR pass): the mature sequence is entry[flank5 :
+// len - flank3] and read base j sits at mature index d + j, d = o - flank5.  judgeAllign keeps
+// the read when it starts at most 1 nt after the mature start (d <= 1) and, over the mature
+// minus its last 3 nt, shows at most 1 mismatch and at least len - 4 (d == 1: len - 5) matches.
+// Kept reads add their per-sample count to count_true (and 1 to seq_true, and the count to
+// canonical when the whole read is a substring of the mature sequence) and, for every mature
+// position i < len - 5 where the mature base is `from_base` and the read shows `to_base`, to the
+// position bin (e, i).  The three per-entry totals are privatised in LDS (every kept read hits
+// them); the position bins are rare events and go straight to L2 atomics.
+// The reference aligns read and mature with pairwise2.localms (gap penalties of -20: an ungapped
+// diagonal); the cascade's alignment is that diagonal for every read it claimed.
+// ---------------------------------------------------------------------------
+template <bool LDSH>
+__global__ void __launch_bounds__(kEditThreads) edit_tally_kernel(const EditParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  unsigned long long* hist = reinterpret_cast<unsigned long long*>(smem);
+  const uint32_t S = p.n_samples;
+  const uint32_t n_tot = p.n_bins * S * 3u;
+  unsigned long long* g = reinterpret_cast<unsigned long long*>(p.counts);
+  unsigned long long* gpos = g + n_tot;
+  if (LDSH) {
+    for (uint32_t i = threadIdx.x; i < n_tot; i += kEditThreads) hist[i] = 0ull;
+    __syncthreads();
+  }
+  unsigned long long* h = LDSH ? hist : g;
+  for (uint64_t r = (uint64_t)blockIdx.x * kEditThreads + threadIdx.x; r < p.n;
+       r += (uint64_t)gridDim.x * kEditThreads) {
+    const int32_t pass = p.pass_id[r];
+    if (pass < 0 || (pass != p.canon_pass && pass != p.isomir_pass)) continue;
+    if (p.keep && !p.keep[r]) continue;
+    const uint32_t e = (uint32_t)p.ref_id[r];
+    const int32_t L = (int32_t)p.lens[r];
+    const uint32_t e0 = p.seg_start[e], e1 = p.seg_start[e + 1];
+    const int32_t Lm_full = (int32_t)(e1 - e0) - (int32_t)(p.flank5 + p.flank3);
+    if (Lm_full <= 0 || Lm_full > (int32_t)kEditPositions) continue;  // (host rejects such libraries)
+    const int32_t Lm = Lm_full;
+    const int32_t d = p.pos[r] - (pass == p.isomir_pass ? p.isomir_trim5 : 0) - (int32_t)p.flank5;
+    if (d > 1) continue;                       // head shift (judgeAllign)
+    if (d + L <= 0) continue;                  // the read ends before the mature sequence starts
+    // 32 mature bases from the text, 2 bits each, mature index 0 in the low bits
+    uint64_t tw;
+    {
+      const uint32_t q = e0 + p.flank5, i = q >> 4, sh = (q & 15u) * 2u;
+      const uint64_t lo64 = (uint64_t)p.text[i] | ((uint64_t)p.text[i + 1] << 32);
+      tw = (lo64 >> sh) | ((((uint64_t)p.text[i + 2]) << 1) << (63 - sh));
+    }
+    // the read in mature coordinates (base j -> index d + j), and its N mask
+    const uint64_t r0 = p.reads[r], r1 = p.words_per_read > 1 ? p.reads[p.n + r] : 0ull;
+    const uint64_t m0 = p.nmask ? p.nmask[r] : 0ull, m1 = (p.nmask && p.words_per_read > 1) ? p.nmask[p.n + r] : 0ull;
+    uint64_t rw, nw;
+    if (d >= 0) {
+      rw = d ? (r0 << (2 * d)) : r0;
+      nw = d ? (m0 << (2 * d)) : m0;
+    } else {
+      const int32_t s2 = -2 * d;  // 2..62 (d >= -31 for a read that reaches the mature sequence within its first word)
+      if (s2 >= 64) {
+        const int32_t s3 = s2 - 64;
+        rw = s3 < 64 ? (r1 >> s3) : 0ull;
+        nw = s3 < 64 ? (m1 >> s3) : 0ull;
+      } else {
+        rw = (r0 >> s2) | (r1 << (64 - s2));
+        nw = (m0 >> s2) | (m1 << (64 - s2));
+      }
+    }
+    const int32_t c_lo = max(0, d), c_hi = min(Lm, d + L);  // mature indices the read covers
+    if (c_hi <= c_lo) continue;
+    const uint64_t cover = low_bits(2 * c_hi) & ~low_bits(2 * c_lo) & kOdd;
+    const uint64_t x = tw ^ rw;
+    const uint64_t diff = (((x | (x >> 1)) & kOdd) | (nw & kOdd)) & cover;
+    // judgeAllign's window, in its own arithmetic (W2C:35-69): with both sequences padded to the
+    // common frame (head_t / head_s leading dashes, frame length plen) it compares frame positions
+    // head_t .. min(end1, end2), end1 = plen - head_t - 1 - 3, end2 = last read base -- so a read
+    // that starts before the mature sequence is judged over a shorter stretch, and one that runs
+    // past its end is judged up to 3 bases before the READ's end, every base beyond the mature
+    // sequence counting as a mismatch.  hi_m = that last position in mature coordinates.
+    const int32_t head_t = max(0, -d), head_s = max(0, d);
+    const int32_t plen = max(head_t + Lm_full, head_s + L);
+    const int32_t hi_m = min(plen - head_t - 4, head_s + L - 1) - head_t;
+    const uint64_t judged = cover & low_bits(2 * max(min(hi_m + 1, Lm), 0));
+    const int32_t beyond = max(0, hi_m - max(Lm_full, c_lo) + 1);  // judged positions past the mature end
+    const int32_t mism = __popcll(diff & judged) + beyond, mat = __popcll(~diff & judged);
+    const int32_t need = (Lm_full - 4) - (d == 1 ? 1 : 0);
+    if (mism > 1 || mat < need) continue;
+    // canonical: the whole read is a substring of the mature sequence, at whatever offset (:170 `in`)
+    bool canonical = false;
+    if (L <= Lm && (m0 | m1) == 0ull) {
+      for (int32_t o = 0; o + L <= Lm; ++o) {
+        const uint64_t y = ((tw >> (2 * o)) ^ r0) & low_bits(2 * L);
+        canonical |= y == 0ull;
+      }
+    }
+    // positions i < Lm - 5 with mature == from_base and read == to_base (an N is never to_base)
+    const uint64_t f = p.from_base, t = p.to_base;
+    const uint64_t is_from = ~((tw ^ (f * kOdd)) | ((tw ^ (f * kOdd)) >> 1)) & kOdd;
+    const uint64_t is_to = ~((rw ^ (t * kOdd)) | ((rw ^ (t * kOdd)) >> 1)) & kOdd & ~(nw & kOdd);
+    uint64_t hits = is_from & is_to & cover & low_bits(2 * max(Lm - 5, 0));
+    const uint32_t bin = p.remap ? p.remap[e] : e;
+    for (uint32_t s = 0; s < S; ++s) {
+      const unsigned long long q = p.quant[r * S + s];
+      if (!q) continue;
+      unsigned long long* t3 = h + ((size_t)bin * S + s) * 3u;
+      atomicAdd(&t3[0], q);
+      atomicAdd(&t3[1], 1ull);
+      if (canonical) atomicAdd(&t3[2], q);
+      for (uint64_t hb = hits; hb; hb &= hb - 1ull) {
+        const uint32_t i = (uint32_t)(__ffsll((long long)hb) - 1) >> 1;
+        atomicAdd(&gpos[((size_t)bin * kEditPositions + i) * S + s], q);
+      }
+    }
+  }
+  if (LDSH) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_tot; i += kEditThreads) {
+      const unsigned long long v = hist[i];
+      if (v) atomicAdd(&g[i], v);
+    }
+  }
+}
+
+hipError_t launch_edit_tally(const EditParams& p, bool lds_hist, uint32_t grid, uint32_t lds_bytes,
+                             hipStream_t stream) {
+  if (lds_hist) {
+    auto kern = edit_tally_kernel<true>;
+    if (lds_bytes > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kEditThreads), lds_bytes, stream, p);
+  } else {
+    hipLaunchKernelGGL(edit_tally_kernel<false>, dim3(grid), dim3(kEditThreads), 0, stream, p);
+  }
+  return hipGetLastError();
+}
+
 __global__ void export_pass_counts_kernel(const uint64_t* stats, uint32_t n_pass,
                                           uint64_t* out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -182,6 +182,33 @@ struct TallyParams {
   uint64_t* counts;
 };
 
+// A-to-I position tally (writeDataToCSV.py:145-229 on the cascade's own alignments)
+constexpr uint32_t kEditPositions = 32u;  // mature-miRNA positions tallied per entry
+constexpr uint32_t kEditThreads = 1024u;
+struct EditParams {
+  const uint64_t* reads;
+  const uint8_t* lens;
+  const uint64_t* nmask;  // may be null
+  uint32_t words_per_read;
+  const int8_t* pass_id;
+  const int32_t* ref_id;
+  const int32_t* pos;
+  const uint32_t* quant;
+  const uint8_t* keep;    // may be null: per-read 0/1 (the genome-uniqueness / RPM selection of the host)
+  const uint32_t* remap;  // may be null: entry -> output bin (merged miRNA names)
+  uint64_t n;
+  uint32_t n_samples, n_bins;  // n_bins = output miRNA bins (entries when remap is null)
+  int32_t canon_pass, isomir_pass, isomir_trim5;
+  uint32_t flank5, flank3;     // library entry = flank5 + mature + flank3 (RAP:413: 2 and 6)
+  uint32_t from_base, to_base; // the substitution tallied per position (A -> G: 0, 2)
+  // library text
+  const uint32_t* text;
+  const uint32_t* seg_start;   // entry e = text [seg_start[e], seg_start[e + 1]) (every entry one N-free segment)
+  uint64_t* counts;            // [n_bins][S][3] then [n_bins][kEditPositions][S]
+};
+hipError_t launch_edit_tally(const EditParams& p, bool lds_hist, uint32_t grid, uint32_t lds_bytes,
+                             hipStream_t stream);
+
 // lds_mode: 0 = index in HBM/L2, 1 = occ blocks in LDS, 2 = occ blocks + text in LDS,
 //           3 = text only in LDS (occ blocks from L2)
 hipError_t launch_match(const MatchParams& p, uint32_t words_per_read, int lds_mode,

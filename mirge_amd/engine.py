@@ -65,6 +65,18 @@ class ReadSet:
                 q = q[:, None]
             self.quant = torch.from_numpy(q.view(np.int32)).to(self.device)
 
+    @classmethod
+    def from_device(cls, words, lens, nmask=None, quant=None, min_len=0, max_len=255):
+        """Wrap tensors that already live in HBM (words int64 [W, n], lens uint8 [n], nmask like
+        words or None, quant int32 [n, S] or None): nothing is copied.  min_len / max_len is the
+        caller's knowledge of the batch's length range (0 / 255 = unknown)."""
+        self = cls.__new__(cls)
+        self.W, self.n = int(words.shape[0]), int(words.shape[1])
+        self.device = words.device
+        self.words, self.lens, self.nmask, self.quant = words, lens, nmask, quant
+        self.min_len, self.max_len = int(min_len), int(max_len)
+        return self
+
     @property
     def n_samples(self):
         return 0 if self.quant is None else int(self.quant.shape[1])
@@ -218,6 +230,63 @@ class Engine:
             self._stream_ptr()))
         return counts
 
+    EDIT_POSITIONS = 32
+
+    def edit_counts_len(self, lib, n_samples, n_bins=None):
+        ln = C.c_uint64()
+        nb = self.indexes[lib].n_ref if n_bins is None else int(n_bins)
+        check(self._lib.mrg_edit_counts_len(nb, int(n_samples), C.byref(ln)))
+        return int(ln.value)
+
+    def edit_tally(self, reads, result, lib="mirna", canon_pass=CANON_PASS, isomir_pass=ISOMIR_PASS, counts=None,
+                   keep=None, remap=None, n_bins=None, from_base=0, to_base=2, isomir_trim5=1, flank5=2, flank3=6):
+        """The per-read part of A2IEditing (writeDataToCSV.py:145-229) on device: per (miRNA bin, sample)
+        count_true / seq_true / canonical and, per mature position, the counts of kept reads showing
+        `to_base` where the mature sequence has `from_base` (A -> G by default).  keep: uint8 device
+        tensor [n] or None; remap: int32 device tensor [entries] -> bin or None.  Returns the int64
+        device vector laid out as mrg_edit_tally_run documents (split with split_edit_counts)."""
+        torch = _torch()
+        S = reads.n_samples
+        nb = self.indexes[lib].n_ref if n_bins is None else int(n_bins)
+        ln = self.edit_counts_len(lib, S, nb)
+        if counts is None:
+            counts = torch.zeros(ln, dtype=torch.int64, device=self.device)
+        check(self._lib.mrg_edit_tally_run(
+            self._h, reads.words.data_ptr(), reads.W, reads.lens.data_ptr(),
+            reads.nmask.data_ptr() if reads.nmask is not None else None, result.pass_id.data_ptr(),
+            result.ref_id.data_ptr(), result.pos.data_ptr(), reads.quant.data_ptr(),
+            None if keep is None else keep.data_ptr(), None if remap is None else remap.data_ptr(), reads.n, S, nb,
+            self.libs[lib], canon_pass, isomir_pass, isomir_trim5, flank5, flank3, from_base, to_base,
+            counts.data_ptr(), self._stream_ptr()))
+        return counts
+
+    def collapse(self, words, lens, nmask=None, sample=None, n_samples=1, max_len=0):
+        """quantReads (QNT:3-24) on device tensors: raw reads (words int64 [W, n], lens uint8 [n],
+        nmask or None, sample int16 [n] or None) -> (ReadSet of the unique reads with their
+        per-sample counts, all still in HBM and ordered by (length, bases); read-length histogram
+        int64 [256, S]).  Synchronises (the number of uniques comes back to the host)."""
+        torch = _torch()
+        dev = self.device
+        W, n = int(words.shape[0]), int(words.shape[1])
+        cap = max(n, 1)
+        u_words = torch.empty((W, cap), dtype=torch.int64, device=dev)
+        u_lens = torch.empty(cap, dtype=torch.uint8, device=dev)
+        u_nmask = None if nmask is None else torch.empty((W, cap), dtype=torch.int64, device=dev)
+        quant = torch.empty((cap, n_samples), dtype=torch.int32, device=dev)
+        hist = torch.zeros((256, n_samples), dtype=torch.int64, device=dev)
+        n_unique = C.c_uint64(0)
+        check(self._lib.mrg_collapse_run(
+            self._h, words.data_ptr(), W, lens.data_ptr(), None if nmask is None else nmask.data_ptr(),
+            None if sample is None or n_samples == 1 else sample.data_ptr(), n, n_samples, int(max_len), cap,
+            u_words.data_ptr(), u_lens.data_ptr(), None if u_nmask is None else u_nmask.data_ptr(),
+            quant.data_ptr(), hist.data_ptr(), C.byref(n_unique), self._stream_ptr()))
+        U = int(n_unique.value)
+        # the SoA stride of the cascade is the array's own row length: compact views
+        rs = ReadSet.from_device(u_words[:, :U].contiguous() if U != cap else u_words, u_lens[:U],
+                                 None if u_nmask is None else (u_nmask[:, :U].contiguous() if U != cap else u_nmask),
+                                 quant[:U], 0, int(max_len) if max_len else 255)
+        return rs, hist
+
     def count_best(self, reads, lib, seed_len=28, max_mm_seed=1, max_mm_total=2):
         """Best stratum of every read of a ReadSet against one library, forward strand:
         (fewest mismatches or 255, alignments reaching it, saturating) as host uint8 arrays.
@@ -306,3 +375,11 @@ def split_counts(counts, n_mirna, n_samples, n_pass):
     cat = c[2 * M * S:2 * M * S + (n_pass + 1) * S].reshape(n_pass + 1, S)
     uniq = c[2 * M * S + (n_pass + 1) * S:2 * M * S + (n_pass + 2) * S]
     return quant, iscan, cat, uniq
+
+
+def split_edit_counts(counts, n_bins, n_samples):
+    """Views into the vector of mrg_edit_tally_run: (totals [bins, S, 3] = count_true, seq_true,
+    canonical; positions [bins, 32, S])."""
+    c = np.asarray(counts).astype(np.int64)
+    k = n_bins * n_samples * 3
+    return c[:k].reshape(n_bins, n_samples, 3), c[k:].reshape(n_bins, Engine.EDIT_POSITIONS, n_samples)

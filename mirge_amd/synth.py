@@ -29,6 +29,20 @@ FULL_SHAPES = {
 }
 
 
+# "mouse" = the same generator with another seed and other sizes; BASELINE configs[4]
+MOUSE_SEED = 10090
+MOUSE_SHAPES = {
+    "mirna": 2200,
+    "hairpin": (1500, 60, 110),
+    "mature_trna": (430, 72, 76),
+    "pre_trna": (480, 25, 60),
+    "snorna": (1100, 70, 260),
+    "rrna": [121, 157, 954, 1559, 1870, 4730, 1580, 3300],
+    "ncrna_others": (12000, 100, 1000),
+    "mrna": (40000, 500, 4500),
+}
+
+
 def codes_to_str(codes):
     return _LETTERS[codes].tobytes().decode("ascii")
 
@@ -165,6 +179,9 @@ class SynthLibraries:
 DEFAULT_MIX = dict(mirna_exact=0.55, isomir=0.15, trna=0.05, snorna=0.05, rrna_ncrna=0.05,
                    mrna=0.05, polyt=0.03, random=0.07)
 EXACT_ONLY_MIX = dict(mirna_exact=0.02, random=0.98)  # config 2: "collapsed unique" is mostly misses
+# config 5 (-ai): miRNA reads of which a part carries one A -> G substitution at a seeded position
+A2I_MIX = dict(mirna_exact=0.40, mirna_a2g=0.20, isomir=0.12, trna=0.05, snorna=0.04, rrna_ncrna=0.04,
+               mrna=0.05, polyt=0.03, random=0.07)
 
 
 def _cut_packed(codes, base, L, cache=None):
@@ -194,6 +211,12 @@ def _xor_at(words, rows, cols, delta):
 
 def _set_at(words, rows, col, value):
     sh = np.uint64(2 * col)
+    words[rows] = (words[rows] & ~(np.uint64(3) << sh)) | (value.astype(np.uint64) << sh)
+
+
+def _set_at_cols(words, rows, cols, value):
+    """Base `cols[i]` of read `rows[i]` := value[i]."""
+    sh = (2 * cols).astype(np.uint64)
     words[rows] = (words[rows] & ~(np.uint64(3) << sh)) | (value.astype(np.uint64) << sh)
 
 
@@ -248,6 +271,17 @@ def synth_reads_packed(libs, n, seed=355, L=22, mix=None, zipf_s=1.1):
             lens = np.diff(starts)[ent]
             off = np.clip(2 + rng.integers(-2, 3, m), 0, lens - L)
             blk = cut("mirna", starts[ent] + off, L)
+        elif k == "mirna_a2g":
+            # canonical-offset miRNA reads; a seeded position inside the scored part of the mature
+            # sequence is turned into G when it holds an A (about one pick in four does)
+            codes, starts, ent, _ = sample_sub("mirna", m, L, zipf=True)
+            lens = np.diff(starts)[ent]
+            off = np.clip(2 + rng.integers(0, 2, m), 0, lens - L)
+            blk = cut("mirna", starts[ent] + off, L)
+            col = rng.integers(2, L - 7, m)
+            is_a = ((blk >> (2 * col).astype(np.uint64)) & np.uint64(3)) == 0
+            rows = np.nonzero(is_a)[0]
+            _set_at_cols(blk, rows, col[rows], np.full(rows.size, 2))
         elif k == "isomir":
             codes, starts, ent, _ = sample_sub("mirna", m, L, zipf=True)
             lens = np.diff(starts)[ent]
@@ -379,3 +413,37 @@ def synth_quant(n, n_samples=1, seed=355):
         dead = q.sum(axis=1) == 0
         q[dead, 0] = 1
     return q
+
+
+GLOBAL_CHUNK = 10_000_000
+
+
+def global_read_slice(libs, n_total, lo, hi, workload="cascade", seed0=355, mix=None, n_samples=1,
+                      chunk=GLOBAL_CHUNK):
+    """Reads [lo, hi) of ONE seeded read set of n_total reads, without generating the rest: the set
+    is defined chunk by chunk (chunk c of `chunk` reads is seeded with seed0 + c), so any rank can
+    produce its own shard and the shards of every world size tile the same set (bench.py
+    --scaling strong; tests/test_bench_shards.py).
+    workload "varlen" -> reads of 16..40 nt (two words), else 22-mers from `mix`.
+    Returns (words uint64 [W, hi - lo], lens uint8 [hi - lo], quant uint32 [hi - lo, n_samples])."""
+    W = 2 if workload == "varlen" else 1
+    m_out = hi - lo
+    words = np.empty((W, m_out), dtype=np.uint64)
+    lens = np.empty(m_out, dtype=np.uint8)
+    quant = np.empty((m_out, n_samples), dtype=np.uint32)
+    for c in range(lo // chunk, (max(hi, lo + 1) - 1) // chunk + 1 if hi > lo else 0):
+        c_lo = c * chunk
+        m = min(chunk, n_total - c_lo)
+        a, b = max(lo, c_lo), min(hi, c_lo + m)
+        if b <= a:
+            continue
+        if workload == "varlen":
+            w, l = synth_reads_varlen(libs, m, seed=seed0 + 622 + c)
+        else:
+            w = synth_reads_packed(libs, m, seed=seed0 + c, mix=mix)[None, :]
+            l = np.full(m, 22, dtype=np.uint8)
+        q = synth_quant(m, n_samples, seed=seed0 + c)
+        words[:, a - lo:b - lo] = w[:, a - c_lo:b - c_lo]
+        lens[a - lo:b - lo] = l[a - c_lo:b - c_lo]
+        quant[a - lo:b - lo] = q[a - c_lo:b - c_lo]
+    return words, lens, quant

@@ -79,7 +79,7 @@ int orc_align_one(const char *lib, const uint32_t *lib_off, uint32_t n_ref, cons
 void orc_align_batch(const char *lib, const uint32_t *lib_off, uint32_t n_ref, const char *reads,
                      const uint64_t *read_off, uint64_t n_reads, int seed_len, int max_mm_seed,
                      int max_mm_total, int32_t *out_ref, int32_t *out_pos, int32_t *out_mm) {
-#pragma omp parallel for schedule(dynamic, 64)
+#pragma omp parallel for schedule(dynamic, 1)
   for (int64_t r = 0; r < (int64_t)n_reads; ++r) {
     int32_t ref = -1, pos = -1, mm = -1;
     int len = (int)(read_off[r + 1] - read_off[r]);

@@ -16,7 +16,7 @@ _lib = None
 
 def build(force=False):
     """Compile oracle/*.c -> oracle/_build/liboracle.so (gcc -O2 -fopenmp)."""
-    srcs = [os.path.join(_HERE, f) for f in ("bowtie_model.c", "fm_cpu.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("bowtie_model.c", "fm_cpu.c", "edit_tally.c", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(
         os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
@@ -257,4 +257,39 @@ def tally(pass_id, ref_id, quant, n_mirna, n_pass, canon_pass, isomir_pass):
         quant.ctypes.data_as(C.c_void_p), C.c_uint64(n), C.c_uint32(S), C.c_uint32(n_mirna),
         C.c_uint32(n_pass), C.c_int(canon_pass), C.c_int(isomir_pass),
         counts.ctypes.data_as(C.c_void_p))
+    return counts
+
+
+def edit_tally(mirna_index, pass_id, ref_id, pos, words, lens, quant, canon_pass=0, isomir_pass=8, nmask=None,
+               keep=None, remap=None, n_bins=None, from_base=0, to_base=2, isomir_trim5=1, flank5=2, flank3=6):
+    """oracle/edit_tally.c: the A-to-I position tally by dash-padded strings.  `mirna_index` is a
+    mirge_amd FmIndex (only its packed text and entry starts are read).  Returns uint64
+    [n_bins * S * 3 + n_bins * 32 * S] laid out as mrg_edit_tally_run documents."""
+    v = mirna_index.view()
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    W, n = words.shape
+    quant = np.ascontiguousarray(quant, dtype=np.uint32)
+    if quant.ndim == 1:
+        quant = quant[:, None]
+    S = quant.shape[1]
+    nb = mirna_index.n_ref if n_bins is None else int(n_bins)
+    counts = np.zeros(nb * S * 35, dtype=np.uint64)
+    text = np.ascontiguousarray(v["text"], dtype=np.uint32)
+    seg_start = np.ascontiguousarray(v["seg_start"], dtype=np.uint32)
+    lens = np.ascontiguousarray(lens, dtype=np.uint8)
+    nm = None if nmask is None else np.ascontiguousarray(nmask, dtype=np.uint64)
+    kp = None if keep is None else np.ascontiguousarray(keep, dtype=np.uint8)
+    rm = None if remap is None else np.ascontiguousarray(remap, dtype=np.uint32)
+    a_pass = np.ascontiguousarray(pass_id, dtype=np.int8)
+    a_ref = np.ascontiguousarray(ref_id, dtype=np.int32)
+    a_pos = np.ascontiguousarray(pos, dtype=np.int32)
+    f = lib().orc_edit_tally
+    f.restype = None
+    f(text.ctypes.data_as(C.c_void_p), seg_start.ctypes.data_as(C.c_void_p), words.ctypes.data_as(C.c_void_p),
+      C.c_int(W), lens.ctypes.data_as(C.c_void_p), None if nm is None else nm.ctypes.data_as(C.c_void_p),
+      a_pass.ctypes.data_as(C.c_void_p), a_ref.ctypes.data_as(C.c_void_p), a_pos.ctypes.data_as(C.c_void_p),
+      quant.ctypes.data_as(C.c_void_p), None if kp is None else kp.ctypes.data_as(C.c_void_p),
+      None if rm is None else rm.ctypes.data_as(C.c_void_p), C.c_uint64(n), C.c_uint32(S), C.c_uint32(nb),
+      C.c_int(canon_pass), C.c_int(isomir_pass), C.c_int(isomir_trim5), C.c_int(flank5), C.c_int(flank3),
+      C.c_int(from_base), C.c_int(to_base), counts.ctypes.data_as(C.c_void_p))
     return counts
