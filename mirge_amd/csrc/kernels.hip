@@ -535,23 +535,27 @@ match_kernel(const MatchParams p) {
       }
     }
   }
-  if (p.idx_out) {
-    __syncthreads();
-    if (threadIdx.x == 0) p.out_count[blockIdx.x] = ctl[0];
-  }
-
+  // Counters: summed over the wave, then over the workgroup in LDS, then ONE global atomic per
+  // counter and workgroup.  (One per wave -- 8192 waves on five addresses of one cache line --
+  // serialises in L2 at ~10 ns each: that alone was most of a 10 M-read launch.)
   const uint64_t t_processed = wave_sum(c_processed), t_aligned = wave_sum(c_aligned);
   const uint64_t t_steps = wave_sum(c_steps), t_cands = wave_sum(c_cands);
   const uint64_t t_lookups = wave_sum(c_lookups);
+  unsigned long long* wg_cnt = reinterpret_cast<unsigned long long*>(wave_slots + 4u * 16u);
+  if (threadIdx.x < 5) wg_cnt[threadIdx.x] = 0ull;
+  __syncthreads();
   if (lane == 0) {
-    if (t_processed) atomicAdd((unsigned long long*)&p.counters[0], (unsigned long long)t_processed);
-    if (t_aligned) atomicAdd((unsigned long long*)&p.counters[1], (unsigned long long)t_aligned);
-    if (t_steps) atomicAdd((unsigned long long*)&p.counters[2], (unsigned long long)t_steps);
-    if (t_cands) atomicAdd((unsigned long long*)&p.counters[3], (unsigned long long)t_cands);
-    if (t_lookups) atomicAdd((unsigned long long*)&p.counters[4], (unsigned long long)t_lookups);
+    if (t_processed) atomicAdd(&wg_cnt[0], (unsigned long long)t_processed);
+    if (t_aligned) atomicAdd(&wg_cnt[1], (unsigned long long)t_aligned);
+    if (t_steps) atomicAdd(&wg_cnt[2], (unsigned long long)t_steps);
+    if (t_cands) atomicAdd(&wg_cnt[3], (unsigned long long)t_cands);
+    if (t_lookups) atomicAdd(&wg_cnt[4], (unsigned long long)t_lookups);
   }
+  __syncthreads();
+  if (threadIdx.x < 5 && wg_cnt[threadIdx.x])
+    atomicAdd((unsigned long long*)&p.counters[threadIdx.x], wg_cnt[threadIdx.x]);
+  if (p.idx_out && threadIdx.x == 0) p.out_count[blockIdx.x] = ctl[0];
 }
-
 
 // ---------------------------------------------------------------------------
 // fused_kernel: consecutive cascade passes over ONE walk of the survivor list (see kernels.hpp).
@@ -1187,18 +1191,25 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
       }
     }
   }
-  // ---- counters: the per-lane 16-bit fields summed over the wave, one global atomic each
+  // ---- counters: the per-lane 16-bit fields summed over the wave, then over the workgroup in
+  // LDS (the result slots are free now), then one global atomic per counter and workgroup
+  __syncthreads();
+  unsigned long long* wg_cnt = reinterpret_cast<unsigned long long*>(slots);  // [n_sub][2]
+  if (threadIdx.x < 2u * kMaxFused) wg_cnt[threadIdx.x] = 0ull;
+  __syncthreads();
 #pragma unroll 1
   for (uint32_t s = 0; s < p.n_sub; ++s) {
     const uint64_t of = (acc_offered[s >> 2] >> (16u * (s & 3u))) & 0xFFFFull;
     const uint64_t al = (acc_aligned[s >> 2] >> (16u * (s & 3u))) & 0xFFFFull;
     const uint64_t t_of = wave_sum(of), t_al = wave_sum(al);
     if (lane == 0) {
-      if (t_of) atomicAdd((unsigned long long*)&p.sub[s].counters[0], (unsigned long long)t_of);
-      if (t_al) atomicAdd((unsigned long long*)&p.sub[s].counters[1], (unsigned long long)t_al);
+      if (t_of) atomicAdd(&wg_cnt[2 * s], (unsigned long long)t_of);
+      if (t_al) atomicAdd(&wg_cnt[2 * s + 1], (unsigned long long)t_al);
     }
   }
   __syncthreads();
+  if (threadIdx.x < 2u * p.n_sub && wg_cnt[threadIdx.x])
+    atomicAdd((unsigned long long*)&p.sub[threadIdx.x >> 1].counters[threadIdx.x & 1u], wg_cnt[threadIdx.x]);
   if (p.idx_out && threadIdx.x == 0) p.out_count[blockIdx.x] = ctl[0];
   for (uint32_t i = threadIdx.x; i < p.n_sub * 3u; i += BLOCK) {
     const uint32_t s = i / 3u, c = i % 3u;

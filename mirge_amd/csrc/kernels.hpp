@@ -19,7 +19,7 @@ constexpr uint32_t kKmerBitsK = 9u;
 constexpr uint32_t kKmerBitsWords = (1u << (2u * kKmerBitsK)) / 32u;
 // Survivor lists are segmented: workgroup b of the producing pass owns segment b.
 constexpr uint32_t kMaxSegments = 512u;
-constexpr uint32_t kMatchCtlBytes = (4u + 4u * 16u) * 4u;  // control words, 16 B per wave
+constexpr uint32_t kMatchCtlBytes = (4u + 4u * 16u + 10u) * 4u;  // control words, 16 B per wave, 5 counters
 
 // The jump tables of one library in ascending k (k[0] = 0: tables not used; a missing big table
 // repeats the main one), with the word offset of each inside `ftab`.
