@@ -455,7 +455,7 @@ def main():
     print(json.dumps(line))
 
 
-def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log, n_chunks=8, reps=3):
+def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log, n_chunks=16, reps=3, n_bufs=3):
     """SURVEY.md 8d "Timed region", throughput figure: H2D of packed reads + counts -> cascade ->
     tally -> D2H of the assignment arrays and the count vector.  The host side is pinned; the read
     set goes through in `n_chunks` chunks on three streams (copy in / compute / copy out) with two
@@ -478,7 +478,7 @@ def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log,
     bounds = [(n * c // n_chunks, n * (c + 1) // n_chunks) for c in range(n_chunks)]
     cap = max(b - a for a, b in bounds)
     bufs = []
-    for _ in range(2):
+    for _ in range(n_bufs):
         bufs.append(dict(
             words=torch.empty((W, cap), dtype=torch.int64, device=dev), lens=torch.empty(cap, dtype=torch.uint8, device=dev),
             quant=torch.empty((cap, S), dtype=torch.int32, device=dev),
@@ -495,7 +495,7 @@ def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log,
         for b in bufs:
             b["ev_free"].record(s_comp)
         for c, (a, e) in enumerate(bounds):
-            b = bufs[c % 2]
+            b = bufs[c % n_bufs]
             m = e - a
             with torch.cuda.stream(s_in):
                 s_in.wait_event(b["ev_free"])
@@ -518,7 +518,7 @@ def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log,
                     t_h[a:e].copy_(t_d[:m], non_blocking=True)
                 b["ev_free"].record(s_out)
         with torch.cuda.stream(s_out):
-            s_out.wait_event(bufs[(len(bounds) - 1) % 2]["ev_done"])
+            s_out.wait_event(bufs[(len(bounds) - 1) % n_bufs]["ev_done"])
             h_counts.copy_(counts, non_blocking=True)
         torch.cuda.synchronize()
 
@@ -536,7 +536,7 @@ def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log,
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for c, (a, e) in enumerate(bounds):
-        b = bufs[c % 2]
+        b = bufs[c % n_bufs]
         for w in range(W):
             b["words"][w, :e - a].copy_(h_words[w, a:e], non_blocking=True)
         b["lens"][:e - a].copy_(h_lens[a:e], non_blocking=True)
@@ -545,7 +545,7 @@ def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log,
     h2d_ms = (time.perf_counter() - t0) * 1e3
     t0 = time.perf_counter()
     for c, (a, e) in enumerate(bounds):
-        b = bufs[c % 2]
+        b = bufs[c % n_bufs]
         for t_d, t_h in zip(b["out"], h_out):
             t_h[a:e].copy_(t_d[:e - a], non_blocking=True)
     torch.cuda.synchronize()
@@ -559,8 +559,8 @@ def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log,
                 h2d_gbs=round(h2d_bytes / h2d_ms / 1e6, 1), d2h_gbs=round(d2h_bytes / d2h_ms / 1e6, 1),
                 parity=None if ok is None else "assignments identical to the resident run",
                 note="SURVEY.md 8d timed region: pinned host arrays -> H2D (packed reads + lengths + counts) -> "
-                     "cascade -> tally -> D2H (pass_id, ref_id, pos, mm, count vector); double-buffered chunks on "
-                     "three HIP streams")
+                     "cascade -> tally -> D2H (pass_id, ref_id, pos, mm, count vector); %d chunks through %d device "
+                     "buffers on three HIP streams (copy in / compute / copy out)" % (n_chunks, n_bufs))
 
 
 def run_collapsed(eng, passes, rs, out, M, n_pass, canon, iso, log, reps=3):

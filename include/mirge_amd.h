@@ -222,6 +222,25 @@ int mrg_tally_run(mrg_ctx *ctx, const int8_t *d_pass_id, const int32_t *d_ref_id
                   uint32_t n_mirna, uint32_t n_pass, int32_t canon_pass,
                   int32_t isomir_pass, uint64_t *d_counts, void *stream);
 
+/* ------------------------------------------------------------------ *
+ * Multi-GPU: one process per GPU, the globally collapsed read set cut into contiguous shards,
+ * every library replicated, and ONE collective per batch: the sum over ranks of the fused count
+ * vector [mir_quant | mir_iscan | category totals | trimmedUniq | per-pass processed, aligned]
+ * (mrg_tally_run's d_counts followed by mrg_cascade_run's d_pass_counts, all uint64).  The
+ * reference has no counterpart (it is a single process); `filter` (utils/filter.py:7-13) is
+ * non-linear and must run on the reduced vector.  RCCL over xGMI, bound at run time (dlopen): a
+ * host that already has an RCCL mapped (PyTorch) shares it.
+ *   mrg_comm_unique_id  rank 0 fills 128 bytes and hands them to the other ranks out of band
+ *                       (a file, a pipe, an environment variable)
+ *   mrg_comm_init       collective over the `world` processes, each with its own context / GPU
+ *   mrg_allreduce       in place, uint64 sum, asynchronous on `stream`; a no-op for world == 1
+ * ------------------------------------------------------------------ */
+#define MRG_COMM_ID_BYTES 128
+int mrg_comm_unique_id(void *id128);
+int mrg_comm_init(mrg_ctx *ctx, const void *id128, int32_t rank, int32_t world);
+int mrg_allreduce(mrg_ctx *ctx, uint64_t *d_buf, uint64_t n, void *stream);
+int mrg_comm_destroy(mrg_ctx *ctx);
+
 /*
  * A-to-I position tally: the per-read part of A2IEditing (utils/writeDataToCSV.py:145-229) and
  * judgeAllign (:35-69) on the alignments the cascade already produced, for the reads claimed by
@@ -310,6 +329,9 @@ typedef struct mrg_fastq_info {
   uint32_t words_per_read; /* 1, 2 or 4 */
   uint32_t max_len;
   int32_t has_n;
+  uint64_t n_long;         /* kept reads longer than 128 nt (MRG_MAX_WORDS words): not among n_kept, not
+                              packed; read them with mrg_fastq_long_read.  The reference accepts any
+                              length; the host carries these as unannotated reads */
 } mrg_fastq_info;
 /* Plain or gzip FASTQ.  qual_cutoff 10 and min_len 16 are the reference's values
  * (trim_file.py:30,33).  adapter = the `-ad` value after __main__.py:123-127: NULL or "none",
@@ -325,6 +347,8 @@ int mrg_fastq_load(const char *path, int32_t qual_cutoff, int32_t min_len, const
 int mrg_adapter_locate(const char *adapter, const char *read, double max_error_rate,
                        int32_t min_overlap, int32_t *out6);
 int mrg_fastq_get_info(const mrg_fastq *fq, mrg_fastq_info *info);
+/* i-th over-long read (upper-case ASCII, valid until mrg_fastq_free). */
+int mrg_fastq_long_read(const mrg_fastq *fq, uint64_t i, const char **seq);
 /* Copy the packed reads out, widened to words_per_read words (>= the file's own);
  * nmask may be NULL when has_n is 0. */
 int mrg_fastq_copy(const mrg_fastq *fq, uint32_t words_per_read, uint64_t *words, uint8_t *lens,
@@ -345,6 +369,23 @@ int mrg_collapse_run(mrg_ctx *ctx, const uint64_t *d_reads, uint32_t words_per_r
                      uint64_t n, uint32_t n_samples, uint32_t max_len, uint64_t cap,
                      uint64_t *d_u_reads, uint8_t *d_u_lens, uint64_t *d_u_nmask, uint32_t *d_quant,
                      uint64_t *d_len_hist, uint64_t *n_unique, void *stream);
+
+/*
+ * mapped.csv / unmapped.csv (utils/writeDataToCSV.py:582-619, :1172-1188) streamed from the
+ * columnar HOST arrays the cascade produced instead of the reference's dict of dicts:
+ *   row = uniqueSequence,annotFlag,<slot 1>,...,<slot n_slots>,<count of sample 1>,...
+ * mapped != 0: the reads with pass_id >= 0, annotFlag 1, slot pass_id + 1 = the entry's name
+ * (names[names_off[pass] + ref_id], names_off has n_slots + 1 entries); mapped == 0: the reads
+ * with pass_id < 0, annotFlag 0, all slots empty.  reads is SoA with `stride` elements between
+ * the words of a read (a slice of a larger array is fine); header (may be NULL) is written first
+ * unless append != 0.  Rows come out in array order.  *rows = rows written.
+ */
+int mrg_write_read_table(const char *path, int32_t mapped, const char *header, int32_t append,
+                         const uint64_t *reads, uint32_t words_per_read, uint64_t stride,
+                         const uint8_t *lens, const uint64_t *nmask, uint64_t n, const int8_t *pass_id,
+                         const int32_t *ref_id, const uint32_t *quant, uint32_t n_samples,
+                         uint32_t n_slots, const char *const *names, const uint64_t *names_off,
+                         uint64_t *rows);
 
 /* Packing helper used by hosts without numpy: ASCII reads -> SoA words. */
 int mrg_pack_reads(const char *const *seqs, uint64_t n, uint32_t words_per_read,

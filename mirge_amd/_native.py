@@ -44,7 +44,8 @@ class IndexInfo(C.Structure):
 
 class FastqInfo(C.Structure):
     _fields_ = [("n_total", C.c_uint64), ("n_kept", C.c_uint64), ("phred", C.c_int32),
-                ("words_per_read", C.c_uint32), ("max_len", C.c_uint32), ("has_n", C.c_int32)]
+                ("words_per_read", C.c_uint32), ("max_len", C.c_uint32), ("has_n", C.c_int32),
+                ("n_long", C.c_uint64)]
 
 
 class IndexView(C.Structure):
@@ -86,6 +87,10 @@ SIGNATURES = {
     "mrg_tally_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                 C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
                                 C.c_void_p, C.c_void_p]),
+    "mrg_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "mrg_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "mrg_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "mrg_comm_destroy": (C.c_int, [C.c_void_p]),
     "mrg_edit_counts_len": (C.c_int, [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
     "mrg_edit_tally_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -109,11 +114,16 @@ SIGNATURES = {
                                  C.POINTER(C.c_void_p)]),
     "mrg_adapter_locate": (C.c_int, [C.c_char_p, C.c_char_p, C.c_double, C.c_int32, C.POINTER(C.c_int32)]),
     "mrg_fastq_get_info": (C.c_int, [C.c_void_p, C.POINTER(FastqInfo)]),
+    "mrg_fastq_long_read": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_char_p)]),
     "mrg_fastq_copy": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mrg_fastq_free": (None, [C.c_void_p]),
     "mrg_collapse_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
+    "mrg_write_read_table": (C.c_int, [C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, C.c_void_p, C.c_uint32,
+                                       C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_char_p), C.c_void_p,
+                                       C.POINTER(C.c_uint64)]),
     "mrg_pack_reads": (C.c_int, [C.POINTER(C.c_char_p), C.c_uint64, C.c_uint32, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
 }

@@ -33,16 +33,17 @@ CATEGORY_KEYS = ["mirnaReads", "hairpinReads", "maturetrnaReads", "pretrnaReads"
                  "rrnaReads", "ncrnaOthersReads", "mrnaReads"]  # SUM:22-29, by annot slot 1..8
 
 
-def _ensure_libraries(engine, files):
+def _ensure_libraries(engine, files, cache=False):
     """files: {library key: index prefix}.  Loads/builds (concurrently: the native calls release
-    the GIL) and uploads each once."""
+    the GIL) and uploads each once.  cache: an index that had to be built from FASTA / .ebwt is
+    saved as <prefix>.mrgfm for the next run."""
     tags = engine.__dict__.setdefault("_loaded_tags", {})
     todo = [(key, prefix) for key, prefix in files.items() if tags.get(key) != "%s@%s" % (key, prefix)]
     if not todo:
         return
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=len(todo)) as pool:
-        opened = list(pool.map(lambda kp: FmIndex.open_prefix(kp[1]), todo))
+        opened = list(pool.map(lambda kp: FmIndex.open_prefix(kp[1], cache=cache), todo))
     for (key, prefix), ix in zip(todo, opened):
         engine.add_library(key, ix)
         tags[key] = "%s@%s" % (key, prefix)

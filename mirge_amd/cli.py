@@ -4,9 +4,11 @@
 Same flags, library directory layout (MAIN:108-112, :262-281) and output tables
 (`miRge.<timestamp>/annotation.report.csv`, `mapped.csv`, `unmapped.csv`, `miR.Counts.csv`,
 `miR.RPM.csv`, `-di` isomiR tables, `-gff` per-sample GFF).  Differences:
-  * `-pb` is accepted and ignored (no bowtie); `--gpu` picks the device;
-  * index files are `<prefix>.mrgfm` or `<prefix>.fa` instead of `<prefix>.*.ebwt`
-    (build with `python -m mirge_amd.build_index`);
+  * `-pb` is accepted and ignored (no bowtie); `--gpu` picks the device, `--gpus N` runs one
+    process per GPU over contiguous shards of the collapsed read set;
+  * an index prefix resolves to `<prefix>.mrgfm` (this engine's format, also written next to the
+    source on first use), `<prefix>.fa`, or the reference's own `<prefix>.1.ebwt` (read back into
+    entry names + sequences as bowtie-inspect does);
   * `-ad illumina|ion|<sequence>|+N` is applied as trim_file.py does (3' quality trimming,
     cutadapt's 3' adapter search restated, 16-nt minimum);
   * `-ai` reads the genome from `<sp>_genome.mrgfm` / `.fa` or `<sp>_genome.partNNN.mrgfm`
@@ -48,6 +50,9 @@ def build_parser():
     p.add_argument("-gff", dest="gff_output", action="store_true")
     p.add_argument("-trf", dest="trf_output", action="store_true")
     p.add_argument("--gpu", type=int, default=0, help="device index (default 0)")
+    p.add_argument("--gpus", type=int, default=1,
+                   help="annotate on N GPUs of this node: one process per GPU, the collapsed read set in N "
+                        "contiguous shards, one RCCL all-reduce of the count vector (default 1)")
     return ap
 
 
@@ -86,9 +91,39 @@ def resolve_samples(sample_args):
     sys.exit(1)
 
 
-def annotate_main(args):
-    from . import annotate, ingest, pack, report
-    from .engine import Engine
+def _launch_ranks(argv, n_gpus):
+    """`--gpus N`: one child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE in its environment),
+    started before anything in this process has touched a GPU; the exit status is the worst child's."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MIRGE_AMD_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-m", "mirge_amd"] + list(argv), env=env))
+    return max(p.wait() for p in procs)
+
+
+def annotate_main(args, engine_factory=None, materialize=False):
+    """MAIN:73-392 for `annotate`, columnar: FASTQ -> packed reads -> device collapse -> cascade +
+    tally on this rank's shard of the collapsed set -> one all-reduce of the count vector -> (rank 0)
+    merge / filter / tables.  No per-read Python object is built except for the reads the isomiR,
+    GFF, tRF and A-to-I consumers look at (those claimed by passes 0 / 8 and 2 / 3).
+    engine_factory(device_index) -> engine (default mirge_amd.engine.Engine; the multi-process CPU
+    test passes an oracle-backed stand-in).  materialize: also return the whole seqDic (tests)."""
+    from . import annotate, columnar, dist as mdist, ingest, report
+    from .engine import CANON_PASS, ISOMIR_PASS, ReadSet
+    import torch
+    if engine_factory is None:
+        from .engine import Engine as engine_factory
+    rank, local_rank, world = mdist.env_world()
+    if world > 1:
+        mdist.init_process_group(os.environ.get("MIRGE_AMD_DIST_BACKEND", "nccl"))
     db = {"mirbase": "miRBase", "mirgenedb": "MirGeneDB"}.get(args.miRNA_database.lower())
     if db is None:
         _die("The value of parameter '-d' is invalid. Please check it")
@@ -119,23 +154,34 @@ def annotate_main(args):
     if args.spikeIn:
         kinds.append("spike-in")
     prefix = {}
-    for kind in kinds:  # MAIN:262-267, with our index formats
+    for kind in kinds:  # MAIN:262-267: the reference's .1.ebwt, or this engine's own formats
         p = os.path.join(index_dir, "%s_%s" % (sp, kind))
-        if not (os.path.isfile(p + ".mrgfm") or os.path.isfile(p + ".fa")):
-            print("The index file of %s_%s (.mrgfm or .fa) is not located at %s, please check it."
+        if not any(os.path.isfile(p + ext) for ext in (".mrgfm", ".fa", ".fasta", ".1.ebwt")):
+            print("The index file of %s_%s (.1.ebwt, .mrgfm or .fa) is not located at %s, please check it."
                   % (sp, kind, index_dir))
             sys.exit(1)
         prefix[kind] = p
-    outdir = os.path.join(os.path.abspath(args.output_dir),
-                          "miRge." + time.strftime("%Y-%m-%d_%H-%M-%S", time.localtime()))
-    os.makedirs(outdir)
     raw = resolve_samples(args.sampleList)
     sample_list = [os.path.basename(s)[:-3] if s.endswith(".gz") else os.path.basename(s) for s in raw]
     S = len(sample_list)
+    outdir = None
+    if rank == 0:
+        outdir = os.path.join(os.path.abspath(args.output_dir),
+                              "miRge." + time.strftime("%Y-%m-%d_%H-%M-%S", time.localtime()))
+        os.makedirs(outdir)
 
-    engine = Engine(args.gpu)
+    engine = engine_factory(local_rank if world > 1 else args.gpu)
+    dev = engine.device
+    spike = bool(args.spikeIn)
+    files = {"mirna": prefix["mirna_" + db], "hairpin": prefix["hairpin_" + db], "mature_trna": prefix["mature_trna"],
+             "pre_trna": prefix["pre_trna"], "snorna": prefix["snorna"], "rrna": prefix["rrna"],
+             "ncrna_others": prefix["ncrna_others"], "mrna": prefix["mrna"]}
+    if spike:
+        files["spike-in"] = prefix["spike-in"]
+    t_lib = time.time()
+    annotate._ensure_libraries(engine, files, cache=(rank == 0))
     genome, removed_ai = None, []
-    if args.a_to_i:  # MAIN:136-146, :277
+    if args.a_to_i and rank == 0:  # MAIN:136-146, :277
         from . import a2i
         from .index import FmIndex
         rep = os.path.join(lib, sp, "annotation.Libs", "%s_miRNAs_in_repetitive_element_%s.csv" % (sp, db))
@@ -156,90 +202,198 @@ def annotate_main(args):
             engine.add_library("genome:%d" % k, ix)
             keys.append("genome:%d" % k)
         genome = a2i.EngineGenome(engine, keys)
+    if rank == 0:
+        print("Libraries resident on the device after %.2f sec" % (time.time() - t_lib))
+
     log_dic = {"quantStats": [], "annotStats": []}
     t0 = time.time()
-    words_all, lens_all, nmask_all, sample_all = [], [], [], []
-    any_n, W = False, 1
-    loaded = []
-    # trim_file per sample (MAIN:346-372); `-cpu` threads are shared out over the samples, which are
-    # read concurrently (one inflate/record-splitting thread each plus its trimming workers)
-    from concurrent.futures import ThreadPoolExecutor
-    n_cpu = max(1, int(args.cpu))
-    n_jobs = max(1, min(len(raw), n_cpu))
+    # ---- ingest + global collapse on rank 0 (trim_file + quantReads, MAIN:346-372) ----
+    meta, urs, hist, long_counts = None, None, None, {}
+    if rank == 0:
+        from concurrent.futures import ThreadPoolExecutor
+        n_cpu = max(1, int(args.cpu))
+        n_jobs = max(1, min(len(raw), n_cpu))
 
-    def load_one(i):
+        def load_one(i):
+            t1 = time.time()
+            fq = ingest.load_fastq(os.path.abspath(raw[i]), adapter=args.adapter, threads=max(1, n_cpu // n_jobs))
+            return fq, time.time() - t1
+
+        for name in sample_list:
+            print("Performing quantitation analysis of %s..." % name)
+        with ThreadPoolExecutor(max_workers=n_jobs) as pool:
+            loaded = list(pool.map(load_one, range(len(raw))))
+        W = max(fq["words"].shape[0] for fq, _ in loaded)
+        any_n = any(fq["nmask"] is not None for fq, _ in loaded)
+        for i, (fq, dt) in enumerate(loaded):
+            log_dic["quantStats"].append({"filename": sample_list[i], "totalReads": fq["total"],
+                                          "trimmedReads": fq["kept"], "cpuTime-trim": dt, "cpuTime-uniq": 0.0})
+            for r in fq["long_reads"]:   # beyond the packing limit: carried on the host, never aligned
+                long_counts.setdefault(r, [0] * S)[i] += 1
         t1 = time.time()
-        fq = ingest.load_fastq(os.path.abspath(raw[i]), adapter=args.adapter, threads=max(1, n_cpu // n_jobs))
-        return fq, time.time() - t1
+        n_raw = sum(fq["packed"] for fq, _ in loaded)
+        words = np.zeros((W, n_raw), dtype=np.uint64)
+        lens = np.empty(n_raw, dtype=np.uint8)
+        nmask = np.zeros((W, n_raw), dtype=np.uint64) if any_n else None
+        sample = np.empty(n_raw, dtype=np.uint16)
+        at = 0
+        for i, (fq, _) in enumerate(loaded):
+            m = fq["packed"]
+            words[:fq["words"].shape[0], at:at + m] = fq["words"]
+            lens[at:at + m] = fq["lens"]
+            if fq["nmask"] is not None:
+                nmask[:fq["nmask"].shape[0], at:at + m] = fq["nmask"]
+            sample[at:at + m] = i
+            at += m
+        max_len = max([fq["max_len"] for fq, _ in loaded] + [0])
+        del loaded
+        d_words = torch.from_numpy(words.view(np.int64)).to(dev)
+        d_lens = torch.from_numpy(lens).to(dev)
+        d_nmask = None if nmask is None else torch.from_numpy(nmask.view(np.int64)).to(dev)
+        d_sample = torch.from_numpy(sample.view(np.int16)).to(dev)
+        del words, lens, nmask, sample
+        urs, hist = engine.collapse(d_words, d_lens, d_nmask, d_sample, S, max_len)
+        del d_words, d_lens, d_nmask, d_sample
+        for q in log_dic["quantStats"]:
+            q["cpuTime-uniq"] = (time.time() - t1) / S
+        meta = dict(U=urs.n, W=urs.W, has_n=urs.nmask is not None, max_len=int(max_len))
+    # ---- every rank gets the collapsed set, takes its contiguous shard ----
+    meta = mdist.broadcast_from_rank0(meta)
+    U, W = meta["U"], meta["W"]
+    if world > 1:
+        if rank != 0:
+            urs = ReadSet.from_device(torch.empty((W, U), dtype=torch.int64, device=dev),
+                                      torch.empty(U, dtype=torch.uint8, device=dev),
+                                      torch.empty((W, U), dtype=torch.int64, device=dev) if meta["has_n"] else None,
+                                      torch.empty((U, S), dtype=torch.int32, device=dev), 0, meta["max_len"] or 255)
+        for t in (urs.words, urs.lens, urs.nmask, urs.quant):
+            if t is not None:
+                mdist.broadcast_tensor(t)
+    lo, hi = mdist.shard_bounds(U, rank, world)
+    if world > 1:
+        shard = ReadSet.from_device(urs.words[:, lo:hi].contiguous(), urs.lens[lo:hi],
+                                    None if urs.nmask is None else urs.nmask[:, lo:hi].contiguous(),
+                                    urs.quant[lo:hi], 0, meta["max_len"] or 255)
+    else:
+        shard = urs
 
-    for name in sample_list:
-        print("Performing quantitation analysis of %s..." % name)
-    with ThreadPoolExecutor(max_workers=n_jobs) as pool:
-        results = list(pool.map(load_one, range(len(raw))))
-    for i, (fq, dt) in enumerate(results):
-        loaded.append(fq)
-        W = max(W, fq["words"].shape[0])
-        any_n = any_n or fq["nmask"] is not None
-        log_dic["quantStats"].append({"filename": sample_list[i], "totalReads": fq["total"],
-                                      "trimmedReads": fq["kept"], "cpuTime-trim": dt,
-                                      "cpuTime-uniq": 0.0})
-    t1 = time.time()
-    for i, fq in enumerate(loaded):
-        w = np.zeros((W, fq["kept"]), dtype=np.uint64)
-        w[:fq["words"].shape[0]] = fq["words"]
-        words_all.append(w)
-        lens_all.append(fq["lens"])
-        nm = np.zeros((W, fq["kept"]), dtype=np.uint64)
-        if fq["nmask"] is not None:
-            nm[:fq["nmask"].shape[0]] = fq["nmask"]
-        nmask_all.append(nm)
-        sample_all.append(np.full(fq["kept"], i, dtype=np.uint16))
-    words = np.concatenate(words_all, axis=1)
-    lens = np.concatenate(lens_all)
-    nmask = np.concatenate(nmask_all, axis=1) if any_n else None
-    sample = np.concatenate(sample_all)
-    col = ingest.collapse(engine, words, lens, nmask, sample, n_samples=S,
-                          max_len=max(fq["max_len"] for fq in loaded))
-    for q in log_dic["quantStats"]:
-        q["cpuTime-uniq"] = (time.time() - t1) / S
-    seqs = pack.unpack_reads(col["words"], col["lens"], col["nmask"])
-    spike = bool(args.spikeIn)
-    width = 10 if spike else 9
-    seq_dic = {s: {"quant": q, "annot": [0] + [""] * width, "length": len(s)}
-               for s, q in zip(seqs, col["quant"].tolist())}
-    read_len_dic = col["length_hist"]
-    if args.trimmed_collapsed_fa:  # QNT:26-44
+    if rank == 0:
+        print("\nPerforming annotation for all of the collasped sequences...")
+    t2 = time.time()
+    passes = engine.mirge_passes(spike_in=spike)
+    n_pass = len(passes)
+    M = engine.indexes["mirna"].n_ref
+    try:
+        res = engine.cascade(shard, passes)
+        fused, ln = mdist.fused_buffer(engine.counts_len(M, S, n_pass), n_pass=n_pass, device=dev)
+        engine.tally(shard, res, M, CANON_PASS, ISOMIR_PASS, counts=fused[:ln])
+        fused[ln:] = res.pass_counts
+        mdist.allreduce_counts(fused)          # the one collective of the data path
+        stats = res.stats
+    except Exception as e:   # RAP:661-663: message + exit status 1
+        from ._native import MirgeAmdError
+        if not isinstance(e, MirgeAmdError):
+            raise
+        print("Alignment to library %s exited with none-zero status.\n" % getattr(e, "library", "?"))
+        print(str(e), file=sys.stderr)
+        sys.exit(1)
+    pass_id = mdist.gather_shards(res.pass_id, U)
+    ref_id = mdist.gather_shards(res.ref_id, U)
+    pos = mdist.gather_shards(res.pos, U)
+    mm = mdist.gather_shards(res.mm, U)
+    if rank != 0:
+        if world > 1:
+            torch.distributed.barrier()
+        return None
+    wall = time.time() - t2
+    print("All annotation cycles completed (%.2f sec).\n" % wall)
+
+    # ---- rank 0: the M-sized tables and the output files ----
+    print("Summarizing and tabulating results...")
+    t3 = time.time()
+    fused_h = fused.cpu().numpy()
+    gpu_ms = sum(s["ms"] for s in stats) or 1.0
+    for i, s in enumerate(stats):   # RAP:640-705 (the reference stores wall seconds per bowtie run)
+        log_dic["annotStats"].append({"cpuTime": wall * s["ms"] / gpu_ms, "readsProcessed": int(fused_h[ln + 2 * i]),
+                                      "readsAligned": int(fused_h[ln + 2 * i + 1])})
+    mir_dic, name_seq = {}, {}
+    annotate.summarize_from_counts(fused_h[:ln], engine.indexes["mirna"].names, sample_list, log_dic, mir_dic, spike)
+    for seq, q in long_counts.items():   # the unpacked reads: unique, unannotated (SUM:34-66)
+        for i in range(S):
+            if q[i]:
+                log_dic["quantStats"][i]["trimmedUniq"] += 1
+                log_dic["quantStats"][i]["remReads"] += q[i]
+    annotate.miRNAmerge(merge_file, sample_list, mir_dic, mirna_fa, name_seq)
+    annotate.filter(mir_dic, sample_list, log_dic, args.canoRatio)
+    h_words = urs.words.cpu().numpy().view(np.uint64)
+    h_lens = urs.lens.cpu().numpy()
+    h_nmask = None if urs.nmask is None else urs.nmask.cpu().numpy().view(np.uint64)
+    h_quant = urs.quant.cpu().numpy().view(np.uint32)
+    h_pass, h_ref, h_pos, h_mm = (t.cpu().numpy() for t in (pass_id, ref_id, pos, mm))
+    hist_h = hist.cpu().numpy()
+    read_len_dic = {int(L): [int(x) for x in hist_h[L]] for L in np.nonzero(hist_h.sum(axis=1))[0]}
+    for seq, q in long_counts.items():
+        row = read_len_dic.setdefault(len(seq), [0] * S)
+        for i in range(S):
+            row[i] += q[i]
+    names = list(ANNOT_NAMES) + (["spike-in"] if spike else [])
+    npp = columnar.names_by_pass(engine, spike)
+
+    if args.trimmed_collapsed_fa:  # QNT:26-44: per sample, by count then sequence, descending
+        from . import pack
         for i, name in enumerate(sample_list):
-            rows = sorted(((rec["quant"][i], s) for s, rec in seq_dic.items() if rec["quant"][i] > 0),
-                          reverse=True)
+            idx = np.nonzero(h_quant[:, i])[0]
+            seqs = pack.unpack_reads(np.ascontiguousarray(h_words[:, idx]), h_lens[idx],
+                                     None if h_nmask is None else np.ascontiguousarray(h_nmask[:, idx]))
+            rows = sorted(zip(h_quant[idx, i].tolist(), seqs), reverse=True)
+            rows += sorted(((q[i], s) for s, q in long_counts.items() if q[i]), reverse=True)
+            rows.sort(reverse=True)
             with open(os.path.join(outdir, os.path.splitext(name)[0] + ".trim.collapse.fa"), "w") as fh:
                 for k, (c, s) in enumerate(rows):
                     fh.write(">seq%d_%d\n%s\n" % (k + 1, c, s))
 
-    print("\nPerforming annotation for all of the collasped sequences...")
-    t2 = time.time()
-    names = list(ANNOT_NAMES) + (["spike-in"] if spike else [])
-    annotate.runAnnotationPipeline(
-        engine, seq_dic, args.cpu, args.phred64, names, outdir, log_dic, prefix["mirna_" + db],
-        prefix["hairpin_" + db], prefix["mature_trna"], prefix["pre_trna"], prefix["snorna"], prefix["rrna"],
-        prefix["ncrna_others"], prefix["mrna"], spike, prefix.get("spike-in"), args.gff_output, pre_name,
-        content, db, args.trf_output, trf_tables["trnaStruDic"] if trf_tables else None, trf_content, sample_list)
-    print("All annotation cycles completed (%.2f sec).\n" % (time.time() - t2))
-    print("Summarizing and tabulating results...")
-    t3 = time.time()
-    mir_dic, name_seq = {}, {}
-    annotate.summarize(seq_dic, sample_list, log_dic, mir_dic, prefix["mirna_" + db], outdir, spike, engine)
-    annotate.miRNAmerge(merge_file, sample_list, mir_dic, mirna_fa, name_seq)
-    annotate.filter(mir_dic, sample_list, log_dic, args.canoRatio)
     report.write_annotation_report_csv(os.path.join(outdir, "annotation.report.csv"), sample_list, log_dic, spike)
-    report.writeDataToCSV(outdir, names, sample_list, args.diff_isomirs, args.a_to_i, log_dic, seq_dic, mir_dic,
-                          name_seq, merged_name, spike, args.gff_output, content, db, args.trf_output,
-                          genome=genome, removedMiRNAList=removed_ai, trfContentDic=trf_content,
-                          trf_tables=trf_tables,
-                          pretrnaNameSeqDic=engine.indexes["pre_trna"].name_seq_dict() if args.trf_output else None)
+    columnar.write_read_tables(outdir, names, sample_list, h_words, h_lens, h_nmask, h_quant, h_pass, h_ref, npp,
+                               extra_unmapped=long_counts)
+    # the reads the remaining consumers look at
+    want = {CANON_PASS, ISOMIR_PASS} | ({2, 3} if args.trf_output else set())
+    sub, align = columnar.read_subset(h_words, h_lens, h_nmask, h_quant, h_pass, h_ref, h_pos, h_mm, npp, want, spike)
+    if args.gff_output:   # RAP:609-619, :653-656
+        from . import isomir
+        hairpin_seqs = engine.indexes["hairpin"].name_seq_dict()
+        mirna_seqs = engine.indexes["mirna"].name_seq_dict()
+        for pass_index in (0, 8):
+            trim = 0 if pass_index == 0 else 3  # -5 1 -3 2 shortens the aligned read
+            hits = {s: (npp[pass_index][a[1]], a[2] + 1, "%dM" % (len(s) - trim))
+                    for s, a in align.items() if a[0] == pass_index}
+            isomir.build_isomir_content(content, hits, pass_index, pre_name, hairpin_seqs, mirna_seqs, db)
+        isomir.write_isomir_gff(outdir, sample_list, content, sub, db)
+    if args.trf_output:   # RAP:629-634, :657-660, :698-701; W2C:648
+        from . import trf
+        pre_seqs = engine.indexes["pre_trna"].name_seq_dict()
+        trf.collect_trf_content(trf_content, sub, sample_list, trf_tables["trnaStruDic"], pre_seqs,
+                                trf.engine_lister(engine))
+        trf.write_trf_tables(outdir, sample_list, log_dic, trf_content, trf_tables, pre_seqs)
+    if args.diff_isomirs:
+        report.write_isomir_tables(os.path.join(outdir, "isomirs.csv"), os.path.join(outdir, "isomirs.samples.csv"),
+                                   sample_list, columnar.isomir_dic(sub, S), log_dic)
+    report.write_counts_csv(os.path.join(outdir, "miR.Counts.csv"), sample_list, mir_dic, log_dic)
+    report.write_rpm_csv(os.path.join(outdir, "miR.RPM.csv"), sample_list, mir_dic, log_dic)
+    if args.a_to_i:   # W2C:1221
+        from .a2i import a_to_i_report
+        a_to_i_report(outdir, sample_list, log_dic, sub, mir_dic, name_seq, merged_name, removed_ai, genome)
     print("Summary Complete (%.2f sec)" % (time.time() - t3))
     print("Annotation of miRge2.0 Completed (%.2f sec)" % (time.time() - t0))
-    return dict(outdir=outdir, seqDic=seq_dic, mirDic=mir_dic, logDic=log_dic, readLengthDic=read_len_dic)
+    if world > 1:
+        torch.distributed.barrier()
+    out = dict(outdir=outdir, mirDic=mir_dic, logDic=log_dic, readLengthDic=read_len_dic, n_unique=U + len(long_counts))
+    if materialize:
+        seq_dic = columnar.full_seq_dic(h_words, h_lens, h_nmask, h_quant, h_pass, h_ref, npp, spike)
+        width = 11 if spike else 10
+        for s, q in long_counts.items():
+            seq_dic[s] = {"quant": list(q), "annot": [0] + [""] * (width - 1), "length": len(s)}
+        out["seqDic"] = seq_dic
+    return out
 
 
 def main(argv=None):
@@ -248,5 +402,7 @@ def main(argv=None):
     if args.command != "annotate":
         ap.print_help()
         return 2
+    if args.gpus > 1 and os.environ.get("MIRGE_AMD_CHILD") != "1":
+        return _launch_ranks(sys.argv[1:] if argv is None else argv, args.gpus)
     annotate_main(args)
     return 0

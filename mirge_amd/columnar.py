@@ -9,17 +9,23 @@ downstream consumers actually look at are turned into the reference's shapes:
   annotate_columns     cascade + tally on packed reads; pass_id / ref_id / pos / mm + counts
   tables_from_columns  mirDic / quantStats via summarize_from_counts -> miRNAmerge -> filter
                        (SUM:12-66, MRG:3-42, FLT:3-31; M-sized)
-  mirna_read_subset    seqDic-shaped records of the reads claimed by pass 0 or 8, optionally only
-                       those the -ai grouping keeps (W2C:1223-1250: exact miRNA, or isomiR with
-                       RPM >= 1 in some sample -- at most ~10^6 reads per sample by construction)
-
-`a2i.a_to_i_report`, `report.write_isomir_tables` and the GFF writer take those records
-unchanged: they only ever read entries whose annot slot 1 or 9 is set.
+  write_read_tables    mapped.csv / unmapped.csv streamed from the arrays by the native writer
+                       (W2C:582-619, :1172-1188; mrg_write_read_table)
+  read_subset          seqDic-shaped records (+ alignments) of the reads claimed by chosen passes:
+                       passes 0 / 8 feed the isomiR tables, the GFF and the -ai report, passes 2 / 3
+                       the tRF tables -- none of them ever looks at another read
+  isomir_dic           the grouping write_mapped_csv builds on the way (W2C:588-606)
+  mirna_read_subset    the miRNA-claimed subset, optionally only what the -ai grouping keeps
+  full_seq_dic         everything as the reference's seqDic (small inputs, tests)
 """
+import ctypes as C
+import os
+
 import numpy as np
 
-from . import annotate, pack
-from .engine import CANON_PASS, ISOMIR_PASS, ReadSet
+from . import _native, annotate, pack
+from ._native import check
+from .engine import CANON_PASS, ISOMIR_PASS, MIRGE_PASS_TABLE, ReadSet
 
 
 def annotate_columns(engine, words, lens, nmask, quant, spike_in=False):
@@ -46,26 +52,116 @@ def tables_from_columns(engine, cols, sampleList, merge_file, mirna_fa, canoRati
     return mir_dic, log_dic, name_seq
 
 
+def names_by_pass(engine, spike_in=False):
+    """Entry names of the library each cascade pass aligns to (annot slot i + 1 holds names[i][ref])."""
+    return [engine.indexes[row[0]].names for row in MIRGE_PASS_TABLE[:10 if spike_in else 9]]
+
+
+def write_read_tables(outdir, annot_names, sample_list, words, lens, nmask, quant, pass_id, ref_id,
+                      names_per_pass, extra_unmapped=None):
+    """mapped.csv and unmapped.csv from the host arrays, in array order, without a Python row loop.
+    extra_unmapped: {sequence: [count per sample]} of reads that never entered the arrays (reads
+    beyond the 128-nt packing limit), appended to unmapped.csv as unannotated rows."""
+    lib = _native.load()
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    W, n = words.shape
+    lens = np.ascontiguousarray(lens, dtype=np.uint8)
+    nm = None if nmask is None else np.ascontiguousarray(nmask, dtype=np.uint64)
+    quant = np.ascontiguousarray(quant, dtype=np.uint32)
+    S = quant.shape[1] if quant.ndim == 2 else 1
+    pass_id = np.ascontiguousarray(pass_id, dtype=np.int8)
+    ref_id = np.ascontiguousarray(ref_id, dtype=np.int32)
+    n_slots = len(names_per_pass)
+    flat = [nm_.encode("ascii") for names in names_per_pass for nm_ in names]
+    arr = (C.c_char_p * max(len(flat), 1))(*flat)
+    off = np.zeros(n_slots + 1, dtype=np.uint64)
+    np.cumsum([len(x) for x in names_per_pass], out=off[1:])
+    header = ("uniqueSequence,annotFlag," + ",".join(annot_names) + "," + ",".join(sample_list) + "\n").encode()
+    rows = {}
+    for fn, mapped in (("mapped.csv", 1), ("unmapped.csv", 0)):
+        k = C.c_uint64(0)
+        check(lib.mrg_write_read_table(
+            os.fsencode(os.path.join(outdir, fn)), mapped, header, 0, words.ctypes.data, W, n, lens.ctypes.data,
+            None if nm is None else nm.ctypes.data, n, pass_id.ctypes.data, ref_id.ctypes.data, quant.ctypes.data, S,
+            n_slots, arr, off.ctypes.data, C.byref(k)))
+        rows[fn] = int(k.value)
+    if extra_unmapped:
+        with open(os.path.join(outdir, "unmapped.csv"), "a") as fh:
+            for seq, q in extra_unmapped.items():
+                fh.write(seq + ",0" + "," * n_slots + "," + ",".join(str(int(x)) for x in q) + "\n")
+                rows["unmapped.csv"] += 1
+    return rows
+
+
+def read_subset(words, lens, nmask, quant, pass_id, ref_id, pos, mm, names_per_pass, passes, spike_in=False,
+                keep=None):
+    """(records, alignments) of the reads claimed by one of `passes` (and selected by the optional
+    boolean `keep`): records[seq] = {'quant', 'annot', 'length'} as quantReads.py:13-15 +
+    updateAnnotDic (RAP:341-345) leave them; alignments[seq] = (pass, entry, 0-based offset,
+    mismatches)."""
+    sel = np.isin(pass_id, np.asarray(list(passes), dtype=pass_id.dtype))
+    if keep is not None:
+        sel &= keep
+    idx = np.nonzero(sel)[0]
+    sub_w = np.ascontiguousarray(np.asarray(words)[:, idx])
+    sub_n = None if nmask is None else np.ascontiguousarray(np.asarray(nmask)[:, idx])
+    seqs = pack.unpack_reads(sub_w, np.asarray(lens)[idx], sub_n)
+    width = 11 if spike_in else 10
+    quant = np.asarray(quant)
+    records, align = {}, {}
+    for k, i in enumerate(idx):
+        p = int(pass_id[i])
+        annot = [1] + [""] * (width - 1)
+        annot[p + 1] = names_per_pass[p][int(ref_id[i])]
+        records[seqs[k]] = {"quant": [int(x) for x in quant[i]], "annot": annot, "length": len(seqs[k])}
+        align[seqs[k]] = (p, int(ref_id[i]), int(pos[i]), int(mm[i]))
+    return records, align
+
+
+def isomir_dic(records, n_samples):
+    """The grouping write_mapped_csv builds while it writes mapped.csv (W2C:588-606): {miRNA (SNP
+    suffix stripped): {'mirnas': {seq: counts}, 'isomirs': {seq: counts}}} over the reads claimed
+    by the exact-miRNA or the isomiR pass."""
+    out = {}
+    for seq, rec in records.items():
+        annot = rec["annot"]
+        isomir, mirna = annot[9], annot[1]
+        if isomir == "" and mirna == "":
+            continue
+        key, kind = (isomir, "isomirs") if isomir != "" else (mirna, "mirnas")
+        if ".SNP" in key:
+            key = key.split(".SNP")[0]
+        slot = out.setdefault(key, {"mirnas": {}, "isomirs": {}})
+        slot[kind][seq] = [rec["quant"][i] for i in range(n_samples)]
+    return out
+
+
 def mirna_read_subset(engine, cols, words, lens, nmask, quant, log_dic=None, spike_in=False, for_a2i=False):
     """seqDic-shaped records ({'quant', 'annot', 'length'}) of the reads claimed by the miRNA passes.
     for_a2i: keep an isomiR read only if its RPM (against mirnaReadsFiltered, W2C:1240-1247) is
     >= 1 in some sample, which is all the -ai block ever groups."""
-    pass_id, ref_id = cols["pass_id"], cols["ref_id"]
-    keep = (pass_id == CANON_PASS) | (pass_id == ISOMIR_PASS)
+    pass_id = cols["pass_id"]
+    keep = None
     quant = np.asarray(quant)
     if for_a2i:
         total = np.array([q["mirnaReadsFiltered"] for q in log_dic["quantStats"]], dtype=np.float64)
         rpm_ok = (1000000.0 * quant.astype(np.float64) / total[None, :] >= 1).any(axis=1)
-        keep &= (pass_id == CANON_PASS) | rpm_ok
-    idx = np.nonzero(keep)[0]
-    sub_w = np.ascontiguousarray(np.asarray(words)[:, idx])
-    sub_n = None if nmask is None else np.ascontiguousarray(np.asarray(nmask)[:, idx])
-    seqs = pack.unpack_reads(sub_w, np.asarray(lens)[idx], sub_n)
-    names = engine.indexes["mirna"].names
+        keep = (pass_id == CANON_PASS) | rpm_ok
+    records, _ = read_subset(words, lens, nmask, quant, pass_id, cols["ref_id"], cols["pos"], cols["mm"],
+                             names_by_pass(engine, spike_in), (CANON_PASS, ISOMIR_PASS), spike_in, keep)
+    return records
+
+
+def full_seq_dic(words, lens, nmask, quant, pass_id, ref_id, names_per_pass, spike_in=False):
+    """Every read as the reference's seqDic (for small inputs and the tests; O(n) Python objects)."""
+    seqs = pack.unpack_reads(np.asarray(words), np.asarray(lens), nmask)
     width = 11 if spike_in else 10
     out = {}
-    for k, i in enumerate(idx):
-        annot = [1] + [""] * (width - 1)
-        annot[1 if pass_id[i] == CANON_PASS else 9] = names[int(ref_id[i])]
-        out[seqs[k]] = {"quant": [int(x) for x in quant[i]], "annot": annot, "length": len(seqs[k])}
+    quant = np.asarray(quant)
+    for i, s in enumerate(seqs):
+        p = int(pass_id[i])
+        annot = [1 if p >= 0 else 0] + [""] * (width - 1)
+        if p >= 0:
+            annot[p + 1] = names_per_pass[p][int(ref_id[i])]
+        out[s] = {"quant": [int(x) for x in quant[i]], "annot": annot, "length": len(s)}
     return out

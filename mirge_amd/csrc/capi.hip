@@ -3,6 +3,9 @@
 // RAP:577-599 / RAP:688, survivor lists kept on device) and the tally launch.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enums only: the library is bound at run time (see RcclApi)
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -14,6 +17,7 @@
 #include "fastq.hpp"
 #include "fm_index.hpp"
 #include "kernels.hpp"
+#include "tables.hpp"
 
 struct mrg_index {
   mrg::FmIndex ix;
@@ -76,8 +80,51 @@ constexpr uint32_t kStatsPerPass = 5;
 
 }  // namespace
 
+namespace {
+// RCCL is resolved with dlopen/dlsym at the first mrg_comm_* call: a process whose host side is
+// PyTorch has torch's own librccl loaded already (that copy is reused, one RCCL per process), a
+// torch-less host gets the system library.  Nothing links against it, so single-GPU users need no
+// RCCL at all.
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+};
+
+RcclApi* rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return &api;
+  tried = true;
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char* n : names)  // a copy that is already mapped (torch's) wins
+    if ((api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+  for (size_t i = 0; !api.handle && i < sizeof names / sizeof *names; ++i) api.handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+  if (!api.handle) {
+    api.error = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "?");
+    return &api;
+  }
+  api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
+  api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
+  api.AllReduce = (decltype(api.AllReduce))dlsym(api.handle, "ncclAllReduce");
+  api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
+  api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
+  if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) {
+    api.error = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy";
+    api.handle = nullptr;
+  }
+  return &api;
+}
+}  // namespace
+
 struct mrg_ctx {
   int device = 0;
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
   int n_cu = 0;
   uint64_t hbm_bytes = 0;
   std::string arch;
@@ -274,6 +321,7 @@ void mrg_ctx_destroy(mrg_ctx* ctx) {
   }
   if (ctx->ev_ready)
     for (auto& e : ctx->ev) (void)hipEventDestroy(e);
+  if (ctx->comm) (void)rccl_api()->CommDestroy(ctx->comm);
   delete ctx;
 }
 
@@ -847,6 +895,65 @@ int mrg_tally_run(mrg_ctx* ctx, const int8_t* d_pass_id, const int32_t* d_ref_id
   return MRG_OK;
 }
 
+// ------------------------------------------------------------ multi-GPU (RCCL over xGMI)
+#define RCCL_TRY(api, expr)                                                                         \
+  do {                                                                                              \
+    ncclResult_t r_ = (expr);                                                                       \
+    if (r_ != ncclSuccess)                                                                          \
+      return fail(MRG_ERR_HIP, "%s failed: %s", #expr, (api)->GetErrorString ? (api)->GetErrorString(r_) : "?"); \
+  } while (0)
+
+int mrg_comm_unique_id(void* id128) {
+  if (!id128) return fail(MRG_ERR_ARG, "mrg_comm_unique_id: null argument");
+  RcclApi* api = rccl_api();
+  if (!api->handle) return fail(MRG_ERR_IO, "mrg_comm_unique_id: %s", api->error.c_str());
+  ncclUniqueId id;
+  RCCL_TRY(api, api->GetUniqueId(&id));
+  static_assert(sizeof(id) == MRG_COMM_ID_BYTES, "ncclUniqueId size");
+  std::memcpy(id128, &id, sizeof id);
+  return MRG_OK;
+}
+
+int mrg_comm_init(mrg_ctx* ctx, const void* id128, int32_t rank, int32_t world) {
+  if (!ctx || !id128) return fail(MRG_ERR_ARG, "mrg_comm_init: null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(MRG_ERR_ARG, "mrg_comm_init: rank %d of %d", rank, world);
+  if (ctx->comm) return fail(MRG_ERR_ARG, "mrg_comm_init: the context already has a communicator");
+  RcclApi* api = rccl_api();
+  if (!api->handle) return fail(MRG_ERR_IO, "mrg_comm_init: %s", api->error.c_str());
+  HIP_TRY(hipSetDevice(ctx->device));
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof id);
+  RCCL_TRY(api, api->CommInitRank(&ctx->comm, world, id, rank));
+  ctx->comm_rank = rank;
+  ctx->comm_world = world;
+  return MRG_OK;
+}
+
+int mrg_allreduce(mrg_ctx* ctx, uint64_t* d_buf, uint64_t n, void* stream) {
+  if (!ctx || (n && !d_buf)) return fail(MRG_ERR_ARG, "mrg_allreduce: null argument");
+  if (!ctx->comm) {
+    if (ctx->comm_world == 1) return MRG_OK;  // one process, nothing to add
+    return fail(MRG_ERR_ARG, "mrg_allreduce: call mrg_comm_init first");
+  }
+  if (n == 0) return MRG_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  RcclApi* api = rccl_api();
+  RCCL_TRY(api, api->AllReduce(d_buf, d_buf, (size_t)n, ncclUint64, ncclSum, ctx->comm, (hipStream_t)stream));
+  return MRG_OK;
+}
+
+int mrg_comm_destroy(mrg_ctx* ctx) {
+  if (!ctx) return fail(MRG_ERR_ARG, "mrg_comm_destroy: null argument");
+  if (ctx->comm) {
+    RcclApi* api = rccl_api();
+    ncclComm_t c = ctx->comm;
+    ctx->comm = nullptr;
+    ctx->comm_world = 1;
+    RCCL_TRY(api, api->CommDestroy(c));
+  }
+  return MRG_OK;
+}
+
 // ------------------------------------------------------------ A-to-I position tally
 int mrg_edit_counts_len(uint32_t n_bins, uint32_t n_samples, uint64_t* len) {
   if (!len) return fail(MRG_ERR_ARG, "mrg_edit_counts_len: null argument");
@@ -1163,6 +1270,14 @@ int mrg_fastq_get_info(const mrg_fastq* fq, mrg_fastq_info* info) {
   info->words_per_read = fq->d.words_per_read;
   info->max_len = fq->d.max_len;
   info->has_n = fq->d.has_n ? 1 : 0;
+  info->n_long = fq->d.long_reads.size();
+  return MRG_OK;
+}
+
+int mrg_fastq_long_read(const mrg_fastq* fq, uint64_t i, const char** seq) {
+  if (!fq || !seq) return fail(MRG_ERR_ARG, "mrg_fastq_long_read: null argument");
+  if (i >= fq->d.long_reads.size()) return fail(MRG_ERR_ARG, "mrg_fastq_long_read: index out of range");
+  *seq = fq->d.long_reads[i].c_str();
   return MRG_OK;
 }
 
@@ -1214,6 +1329,27 @@ int mrg_collapse_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   if (e != hipSuccess) return fail(MRG_ERR_HIP, "mrg_collapse_run: %s", hipGetErrorString(e));
   *n_unique = nu;
   return MRG_OK;
+}
+
+// ------------------------------------------------------------- table writers
+int mrg_write_read_table(const char* path, int32_t mapped, const char* header, int32_t append, const uint64_t* reads,
+                         uint32_t words_per_read, uint64_t stride, const uint8_t* lens, const uint64_t* nmask,
+                         uint64_t n, const int8_t* pass_id, const int32_t* ref_id, const uint32_t* quant,
+                         uint32_t n_samples, uint32_t n_slots, const char* const* names, const uint64_t* names_off,
+                         uint64_t* rows) {
+  if (!path || (n && (!reads || !lens || !pass_id || !ref_id || (n_samples && !quant))))
+    return fail(MRG_ERR_ARG, "mrg_write_read_table: null argument");
+  if (mapped && (!names || !names_off)) return fail(MRG_ERR_ARG, "mrg_write_read_table: mapped rows need the entry names");
+  if (words_per_read == 0 || words_per_read > MRG_MAX_WORDS || stride < n || n_slots > MRG_MAX_PASSES)
+    return fail(MRG_ERR_ARG, "mrg_write_read_table: bad words_per_read / stride / n_slots");
+  try {
+    const uint64_t k = mrg::write_read_table(path, mapped != 0, header, append != 0, reads, words_per_read, stride, lens,
+                                             nmask, n, pass_id, ref_id, quant, n_samples, n_slots, names, names_off);
+    if (rows) *rows = k;
+    return MRG_OK;
+  } catch (const std::exception& e) {
+    return fail(MRG_ERR_IO, "mrg_write_read_table: %s", e.what());
+  }
 }
 
 // ------------------------------------------------------------- packing

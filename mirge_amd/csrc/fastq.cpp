@@ -258,6 +258,7 @@ struct Batch {
   std::vector<uint32_t> off;  // record i = [off[i], off[i+1])
   std::string kept;
   std::vector<uint8_t> kept_len;
+  std::vector<std::string> long_reads;  // trimmed reads beyond the packed limit (kept, not packed)
   uint32_t max_len = 0;
   bool has_n = false;
   std::string error;
@@ -280,8 +281,10 @@ void trim_batch(Batch& b, const TrimSpec& spec, int qual_cutoff, int base, int m
     }
     if ((int)stop < min_len) continue;
     if (stop > 32 * 4) {
-      b.error = "a trimmed read of " + std::to_string(stop) + " nt exceeds the 128-nt limit";
-      return;
+      // longer than four packed words (e.g. `-ad none` on a 151-cycle run): the reference accepts
+      // any length, so the read is kept -- counted, listed as unannotated -- but not packed
+      b.long_reads.emplace_back(sq, stop);
+      continue;
     }
     b.kept.append(sq, stop);
     b.kept_len.push_back((uint8_t)stop);
@@ -405,6 +408,7 @@ void load_fastq(const std::string& path, int qual_cutoff, int min_len, const cha
   for (size_t b = 0; b < batches.size(); ++b) {
     if (!batches[b]->error.empty()) throw std::runtime_error(path + ": " + batches[b]->error);
     first[b + 1] = first[b] + batches[b]->kept_len.size();
+    for (auto& lr : batches[b]->long_reads) out.long_reads.push_back(std::move(lr));
     out.max_len = std::max(out.max_len, batches[b]->max_len);
   }
   out.n_kept = first.back();

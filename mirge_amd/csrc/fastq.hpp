@@ -14,6 +14,9 @@ struct FastqData {
   bool has_n = false;
   std::vector<uint64_t> words, nmask;  // [W][n_kept]
   std::vector<uint8_t> lens;
+  // trimmed reads longer than 128 nt: survive trimming (they count towards "trimmedReads" on the
+  // host) but cannot be packed; the host carries them as unannotated reads
+  std::vector<std::string> long_reads;
 };
 
 // Index of the first base cut from the 3' end (cutadapt / BWA rule).

@@ -53,3 +53,42 @@ def allreduce_counts(fused):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(fused, op=dist.ReduceOp.SUM)
     return fused
+
+
+def broadcast_from_rank0(obj):
+    """A small picklable object (shapes, flags) from rank 0 to everyone."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def broadcast_tensor(t):
+    """In place, from rank 0 (no-op for one process)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(t, src=0)
+    return t
+
+
+def gather_shards(t, n_total):
+    """The per-read arrays of the contiguous shards of `shard_bounds`, put back together: every rank
+    passes its own shard (1-D tensor), every rank gets the whole array of n_total elements.  Shards
+    differ by at most one element, so they are padded to a common length for one all_gather."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return t
+    world = dist.get_world_size()
+    cap = -(-n_total // world)
+    pad = torch.zeros(cap, dtype=t.dtype, device=t.device)
+    pad[:t.numel()] = t
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    out = torch.empty(n_total, dtype=t.dtype, device=t.device)
+    for r in range(world):
+        lo, hi = shard_bounds(n_total, r, world)
+        out[lo:hi] = parts[r][:hi - lo]
+    return out

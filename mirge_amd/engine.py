@@ -230,6 +230,24 @@ class Engine:
             self._stream_ptr()))
         return counts
 
+    # ---- torch-less multi-GPU (the C-ABI's own RCCL binding; mirge_amd.dist uses torch.distributed)
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        check(_native.load().mrg_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        check(self._lib.mrg_comm_init(self._h, C.c_char_p(bytes(unique_id)), int(rank), int(world)))
+
+    def allreduce(self, counts):
+        """In-place uint64 sum of a device tensor (int64 storage) over the ranks of comm_init."""
+        check(self._lib.mrg_allreduce(self._h, counts.data_ptr(), counts.numel(), self._stream_ptr()))
+        return counts
+
+    def comm_destroy(self):
+        check(self._lib.mrg_comm_destroy(self._h))
+
     EDIT_POSITIONS = 32
 
     def edit_counts_len(self, lib, n_samples, n_bins=None):

@@ -51,17 +51,36 @@ class FmIndex:
         return cls(h.value)
 
     @classmethod
-    def open_prefix(cls, prefix):
-        """Resolve a bowtie-style index prefix as the reference passes it around
-        (MAIN:269-281): `<prefix>.mrgfm` if built, else build from `<prefix>.fa`
-        (what `bowtie-inspect <prefix>` would print)."""
-        if os.path.isfile(prefix + ".mrgfm"):
-            return cls.load(prefix + ".mrgfm")
-        for ext in (".fa", ".fasta"):
-            if os.path.isfile(prefix + ext):
-                return cls.from_fasta(prefix + ext)
-        raise FileNotFoundError(
-            "no %s.mrgfm or %s.fa: build one with `python -m mirge_amd.build_index`" % (prefix, prefix))
+    def open_prefix(cls, prefix, cache=False):
+        """Resolve a bowtie-style index prefix as the reference passes it around (MAIN:269-281):
+        `<prefix>.mrgfm` if built (and not older than its source), else build from `<prefix>.fa`
+        (what `bowtie-inspect <prefix>` would print) or from the reference's own `<prefix>.1.ebwt`
+        (mirge_amd.ebwt reads names and sequences back out of it).  cache: save what had to be
+        built as `<prefix>.mrgfm` (best effort: a read-only library directory is not an error)."""
+        src = next((prefix + e for e in (".fa", ".fasta", ".1.ebwt") if os.path.isfile(prefix + e)), None)
+        built = prefix + ".mrgfm"
+        if os.path.isfile(built) and (src is None or os.path.getmtime(built) >= os.path.getmtime(src)):
+            return cls.load(built)
+        if src is None:
+            raise FileNotFoundError(
+                "no %s.mrgfm, %s.fa or %s.1.ebwt: build one with `python -m mirge_amd.build_index`"
+                % (prefix, prefix, prefix))
+        if src.endswith(".1.ebwt"):
+            from . import ebwt
+            ix = cls.build(*ebwt.read_ebwt(prefix))
+        else:
+            ix = cls.from_fasta(src)
+        if cache:
+            tmp = "%s.%d.tmp" % (built, os.getpid())
+            try:
+                ix.save(tmp)
+                os.replace(tmp, built)
+            except Exception:
+                try:
+                    os.remove(tmp)
+                except OSError:
+                    pass
+        return ix
 
     @classmethod
     def open_prefix_parts(cls, prefix):

@@ -41,7 +41,9 @@ def adapter_locate(adapter, read, max_error_rate=0.12, min_overlap=3):
 
 def load_fastq(path, words_per_read=None, qual_cutoff=QUAL_CUTOFF, min_len=MIN_LENGTH, adapter="none",
                threads=0):
-    """Returns dict(words [W, n], lens, nmask|None, total, kept, phred, max_len)."""
+    """Returns dict(words [W, n], lens, nmask|None, total, kept, packed, phred, max_len, long_reads):
+    `kept` = reads that survive trimming (the reference's trimmedReads), `packed` = n of them in the
+    arrays, `long_reads` = the kept reads beyond 128 nt (ASCII; too long for four packed words)."""
     lib = _native.load()
     h = C.c_void_p()
     check(lib.mrg_fastq_load(os.fsencode(path), qual_cutoff, min_len, resolve_adapter(adapter).encode(),
@@ -56,8 +58,13 @@ def load_fastq(path, words_per_read=None, qual_cutoff=QUAL_CUTOFF, min_len=MIN_L
         nmask = np.zeros((W, n), dtype=np.uint64) if info.has_n else None
         check(lib.mrg_fastq_copy(h, W, words.ctypes.data, lens.ctypes.data,
                                  None if nmask is None else nmask.ctypes.data))
-        return dict(words=words, lens=lens, nmask=nmask, total=int(info.n_total), kept=n,
-                    phred=int(info.phred), max_len=int(info.max_len))
+        long_reads = []
+        ptr = C.c_char_p()
+        for i in range(int(info.n_long)):
+            check(lib.mrg_fastq_long_read(h, i, C.byref(ptr)))
+            long_reads.append(ptr.value.decode("ascii"))
+        return dict(words=words, lens=lens, nmask=nmask, total=int(info.n_total), kept=n + len(long_reads),
+                    packed=n, phred=int(info.phred), max_len=int(info.max_len), long_reads=long_reads)
     finally:
         lib.mrg_fastq_free(h)
 

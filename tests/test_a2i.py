@@ -119,7 +119,7 @@ def test_cli_ai_from_fastq_matches_reference_files(golden, native_lib, tmp_path)
                 fh.write("@r%d\n%s\n+\n%s\n" % (k, r, "I" * len(r)))
         fastqs.append(p)
     out = cli.annotate_main(cli.build_parser().parse_args(
-        ["annotate", "-s"] + fastqs + ["-lib", root, "-sp", "syn", "-o", str(tmp_path), "-ai"]))
+        ["annotate", "-s"] + fastqs + ["-lib", root, "-sp", "syn", "-o", str(tmp_path), "-ai"]), materialize=True)
     st = golden["state"]
     assert {s: r["annot"] for s, r in out["seqDic"].items()} == {s: r["annot"] for s, r in st["seqDic"].items()}
     check_files(golden, out["outdir"])

@@ -65,7 +65,7 @@ def test_cli_end_to_end_against_oracle(native_lib, oracle_lib, tmp_path, adapter
         fastqs.append(p)
     out = cli.annotate_main(cli.build_parser().parse_args(
         ["annotate", "-s"] + fastqs + ["-lib", str(tmp_path / "libs"), "-sp", "syn", "-o", str(tmp_path),
-                                       "-di", "-tcf", "-ad", adapter, "-cpu", "3"]))
+                                       "-di", "-tcf", "-ad", adapter, "-cpu", "3"]), materialize=True)
     # ---- the same run through the oracle ----
     from mirge_amd.ingest import resolve_adapter
     kept = [oingest.load_fastq(p, adapter=resolve_adapter(adapter))[0] for p in fastqs]
@@ -124,7 +124,8 @@ def test_cli_spikein_tcf_matches_reference_files(native_lib, tmp_path):
                 fh.write("@short%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % k)
         fastqs.append(p)
     out = cli.annotate_main(cli.build_parser().parse_args(
-        ["annotate", "-s"] + fastqs + ["-lib", root, "-sp", "syn", "-o", str(tmp_path), "-spikeIn", "-tcf"]))
+        ["annotate", "-s"] + fastqs + ["-lib", root, "-sp", "syn", "-o", str(tmp_path), "-spikeIn", "-tcf"]),
+        materialize=True)
     exp = golden["expected"]
     for a, b in zip(out["logDic"]["annotStats"], exp["annotStats"]):
         assert (a["readsProcessed"], a["readsAligned"]) == (b["readsProcessed"], b["readsAligned"])

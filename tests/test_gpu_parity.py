@@ -503,3 +503,23 @@ def test_long_reads_four_words(native_lib, oracle_lib):
         if ref["pass_id"][i] >= 0:
             got = (int(ref["pass_id"][i]), int(ref["ref_id"][i]), int(ref["pos"][i]), int(ref["mm"][i]))
         assert align.get(r) == got, r
+
+
+@pytest.mark.gpu
+def test_c_abi_allreduce_single_rank(native_lib):
+    """mrg_comm_unique_id / mrg_comm_init / mrg_allreduce (RCCL bound at run time): with one rank the
+    sum is the identity -- what can be exercised on a one-GPU box; more ranks need more GPUs."""
+    import torch
+    from mirge_amd.engine import Engine
+    eng = Engine(0)
+    t = torch.arange(1000, dtype=torch.int64, device=eng.device) * 3
+    want = t.clone()
+    eng.allreduce(t)                      # no communicator yet: one process, nothing to add
+    assert torch.equal(t, want)
+    uid = Engine.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    eng.comm_init(uid, 0, 1)
+    eng.allreduce(t)
+    torch.cuda.synchronize()
+    assert torch.equal(t, want)
+    eng.comm_destroy()

@@ -118,7 +118,7 @@ def test_cli_trf_from_fastq_matches_reference_files(golden, native_lib, tmp_path
                 fh.write("@r%d\n%s\n+\n%s\n" % (k, r, "I" * len(r)))
         fastqs.append(p)
     out = cli.annotate_main(cli.build_parser().parse_args(
-        ["annotate", "-s"] + fastqs + ["-lib", root, "-sp", "human", "-o", str(tmp_path), "-trf"]))
+        ["annotate", "-s"] + fastqs + ["-lib", root, "-sp", "human", "-o", str(tmp_path), "-trf"]), materialize=True)
     st = golden["state"]["seqDic"]
     assert {s: r["annot"] for s, r in out["seqDic"].items()} == {s: r["annot"] for s, r in st.items()}
     check_files(golden, out["outdir"])
