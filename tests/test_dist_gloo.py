@@ -90,3 +90,59 @@ def test_two_rank_allreduce_equals_single_process(native_lib, oracle_lib, tmp_pa
     annotate.filter(a, ["s0", "s1"], la, "0.1")
     annotate.filter(b, ["s0", "s1"], lb, "0.1")
     assert a == b and la == lb
+
+
+def _cli_worker(rank, world_size, port, argv, out_path):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world_size), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), MIRGE_AMD_DIST_BACKEND="gloo")
+    from mirge_amd import cli
+    from tests.fake_engine import OracleEngine
+    out = cli.annotate_main(cli.build_parser().parse_args(argv), engine_factory=OracleEngine)
+    assert (out is None) == (rank != 0)
+    if rank == 0:
+        with open(out_path, "w") as fh:
+            fh.write(out["outdir"])
+    torch.distributed.destroy_process_group()
+
+
+def test_cli_two_ranks_write_the_same_tables_as_one(native_lib, oracle_lib, tmp_path):
+    """`annotate --gpus 2` as its children run it (here: gloo, CPU tensors, the oracle's CPU port in
+    place of the GPU engine): rank 0 ingests and collapses, both ranks annotate their shard of the
+    collapsed set, the count vector is all-reduced, the assignments gathered, and rank 0 writes --
+    every table identical to the single-process run (filter after the reduce, trimmedUniq and the
+    per-pass counters not double-counted)."""
+    from mirge_amd import cli, synth
+    from tests.fake_engine import OracleEngine
+    from tests.golden.make_golden import SHAPES
+    from tests.test_cli import write_fastq
+    rng = np.random.default_rng(4)
+    libs = synth.SynthLibraries(seed=123, scale=1.0, n_paralogs=6, n_snp=8, shapes=SHAPES)
+    libs.write_layout(str(tmp_path / "libs"), species="syn", db="miRBase")
+    fastqs = []
+    for si in range(2):
+        reads = [synth.codes_to_str(c) for c in synth.synth_reads(libs, 1200, seed=70 + si, zipf_s=1.3)]
+        reads += ["ACGTNACGTTAGCATCGATCGA", "A" * 140]   # an N, and a read beyond the 128-nt packing limit
+        p = str(tmp_path / ("s%d.fastq" % si))
+        write_fastq(p, reads, rng)
+        fastqs.append(p)
+    base = ["annotate", "-s"] + fastqs + ["-lib", str(tmp_path / "libs"), "-sp", "syn", "-di", "-tcf"]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    one = cli.annotate_main(cli.build_parser().parse_args(base + ["-o", str(tmp_path / "one")]),
+                            engine_factory=OracleEngine)
+    marker = str(tmp_path / "outdir.txt")
+    mp.spawn(_cli_worker, args=(2, _free_port(), base + ["-o", str(tmp_path / "two")], marker), nprocs=2, join=True)
+    two_dir = open(marker).read()
+    files = sorted(os.listdir(one["outdir"]))
+    assert files == sorted(os.listdir(two_dir)) and "mapped.csv" in files and "isomirs.csv" in files
+    for fn in files:
+        a = open(os.path.join(one["outdir"], fn)).read()
+        b = open(os.path.join(two_dir, fn)).read()
+        if fn == "annotation.report.csv":
+            assert a == b, fn
+        else:
+            assert sorted(a.split("\n")) == sorted(b.split("\n")), fn
+    # the over-long read is carried as an unannotated unique read of its sample
+    assert any(line.startswith("A" * 140 + ",0,") for line in open(os.path.join(two_dir, "unmapped.csv")))
+    rep = open(os.path.join(two_dir, "annotation.report.csv")).read().split("\n")[1].split(",")
+    assert int(rep[1]) == 1202 and int(rep[2]) == one["logDic"]["quantStats"][0]["trimmedReads"]
