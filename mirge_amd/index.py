@@ -44,6 +44,19 @@ class FmIndex:
         return cls(h.value)
 
     @classmethod
+    def from_ebwt(cls, prefix):
+        """The reference's own library file `<prefix>.1.ebwt` (bowtie 1, MAIN:262-281): names and
+        sequences are read back out of the BWT (bowtie-inspect's job, SUM:6 / RAP:610-611) and
+        indexed.  Restated without a bowtie-built sample: validated by round trip only."""
+        lib = _native.load()
+        h = C.c_void_p()
+        check(lib.mrg_index_build_ebwt(os.fsencode(prefix), C.byref(h)))
+        return cls(h.value)
+
+    def write_ebwt_for_tests(self, prefix, ftab_chars=10):
+        check(self._lib.mrg_ebwt_write_for_tests(self._h, os.fsencode(prefix), int(ftab_chars)))
+
+    @classmethod
     def load(cls, path):
         lib = _native.load()
         h = C.c_void_p()
@@ -66,8 +79,7 @@ class FmIndex:
                 "no %s.mrgfm, %s.fa or %s.1.ebwt: build one with `python -m mirge_amd.build_index`"
                 % (prefix, prefix, prefix))
         if src.endswith(".1.ebwt"):
-            from . import ebwt
-            ix = cls.build(*ebwt.read_ebwt(prefix))
+            ix = cls.from_ebwt(prefix)
         else:
             ix = cls.from_fasta(src)
         if cache:

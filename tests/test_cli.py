@@ -145,3 +145,33 @@ def test_cli_spikein_tcf_matches_reference_files(native_lib, tmp_path):
                     assert abs(float(a) - float(b)) <= 1e-9 * max(1.0, abs(float(b))) and len(a) <= 14
         else:
             assert got == want, fn
+
+
+@pytest.mark.gpu
+def test_cli_runs_on_a_library_directory_that_holds_only_ebwt_files(native_lib, tmp_path):
+    """The reference's own layout: index.Libs/<sp>_*.1.ebwt and nothing else (MAIN:262-281).  The
+    `.1.ebwt` files here come from the in-tree test writer (no bowtie-build in the image), so this
+    pins the wiring -- prefix resolution, names for the histogram bins (SUM:6), sequences for the
+    cascade -- not bowtie's byte layout."""
+    import glob
+    from mirge_amd import synth
+    from mirge_amd.index import FmIndex
+    from tests.golden.make_golden import SHAPES
+    rng = np.random.default_rng(21)
+    libs = synth.SynthLibraries(seed=123, scale=1.0, n_paralogs=6, n_snp=8, shapes=SHAPES)
+    fastq = str(tmp_path / "s.fastq")
+    write_fastq(fastq, [synth.codes_to_str(c) for c in synth.synth_reads(libs, 1500, seed=5, zipf_s=1.3)], rng)
+    outs = {}
+    for kind in ("fa", "ebwt"):
+        root = str(tmp_path / ("libs_" + kind))
+        libs.write_layout(root, species="syn", db="miRBase")
+        if kind == "ebwt":
+            for fa in glob.glob(os.path.join(root, "syn", "index.Libs", "*.fa")):
+                FmIndex.from_fasta(fa).write_ebwt_for_tests(fa[:-3], ftab_chars=5)
+                os.remove(fa)
+            assert not glob.glob(os.path.join(root, "syn", "index.Libs", "*.fa"))
+        outs[kind] = cli.annotate_main(cli.build_parser().parse_args(
+            ["annotate", "-s", fastq, "-lib", root, "-sp", "syn", "-o", str(tmp_path / ("out_" + kind)), "-di"]))
+    for fn in ("mapped.csv", "unmapped.csv", "miR.Counts.csv", "miR.RPM.csv", "isomirs.csv", "annotation.report.csv"):
+        assert open(os.path.join(outs["fa"]["outdir"], fn)).read() == open(os.path.join(outs["ebwt"]["outdir"], fn)).read(), fn
+    assert glob.glob(os.path.join(str(tmp_path / "libs_ebwt"), "syn", "index.Libs", "*.mrgfm"))   # cached on first use
