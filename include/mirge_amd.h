@@ -142,8 +142,9 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * end of the piece; default 8); "ftab" = 1/0 use the k-mer jump table for the first k steps
  * of a seed search; "wide_rows" = seed intervals wider than this many rows are
  * verified cooperatively by the whole wave (default 64); "hint_min_len" / "hint_max_len" = the
- * caller's promise that every read of the coming batches has a length in that range (defaults
- * 0 / 255 = unknown): a pass whose length window excludes the whole range is not launched; "kmer_filter" = 1/0 stage a small
+ * caller's promise that every read of the NEXT mrg_cascade_run has a length in that range (defaults
+ * 0 / 255 = unknown; reset to the defaults by every run): a pass whose length window excludes the
+ * whole range is not launched, and a batch of one single length skips the length array; "kmer_filter" = 1/0 stage a small
  * library's 9-mer presence bitmap in LDS and skip the jump-table load of a seed piece whose
  * last 9 bases do not occur in the library (default 1); "ctx_wide_rows" = the same
  * threshold for libraries of >= 2^20 bases, whose cooperative path drops most rows by their
@@ -212,7 +213,10 @@ int mrg_cascade_run(mrg_ctx *ctx, const uint64_t *d_reads, uint32_t words_per_re
                     int32_t *d_ref_id, int32_t *d_pos, uint8_t *d_mm,
                     uint64_t *d_pass_counts, void *d_workspace,
                     uint64_t workspace_bytes, void *stream);
-/* Synchronises `stream` of the last run and returns its per-pass statistics. */
+/* Number of cascade runs this context has launched (a caller that reads statistics later can tell
+ * whether they are still those of its own run). */
+int mrg_cascade_run_id(const mrg_ctx *ctx, uint64_t *run_id);
+/* Synchronises `stream` of the LAST run and returns its per-pass statistics. */
 int mrg_cascade_stats(mrg_ctx *ctx, mrg_pass_stats *stats, uint32_t n_pass);
 
 /*

@@ -133,7 +133,10 @@ struct mrg_ctx {
   int64_t use_ftab = 1;
   int64_t force_lds_mode = -1;
   int64_t wide_rows = 64;
-  int64_t hint_min_len = 0, hint_max_len = 255;  // length range of the reads of the coming batches
+  int64_t hint_min_len = 0, hint_max_len = 255;  // length range of the reads of the NEXT run only
+  uint64_t run_id = 0;
+  void* scratch = nullptr;  // context-owned device scratch (grown on demand; mrg_list_best_count)
+  uint64_t scratch_bytes = 0;
   int64_t kmer_filter = 1;
   int64_t ctx_wide_rows = 32;
   int64_t prefer_two_blocks = 1;
@@ -351,6 +354,7 @@ void mrg_ctx_destroy(mrg_ctx* ctx) {
   if (ctx->ev_ready)
     for (auto& e : ctx->ev) (void)hipEventDestroy(e);
   if (ctx->comm) (void)rccl_api()->CommDestroy(ctx->comm);
+  (void)hipFree(ctx->scratch);
   delete ctx;
 }
 
@@ -359,6 +363,15 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
   HIP_TRY(hipSetDevice(ctx->device));
   const mrg::FmIndex& ix = h->ix;
   DevLib l;
+  struct Guard {  // a failed upload must not leak the arrays uploaded before it
+    DevLib* l;
+    ~Guard() {
+      if (!l) return;
+      void* ptrs[] = {l->blocks, l->super, l->text, l->sa, l->ftab, l->ctx, l->sa16, l->kbits, l->kbits_folds,
+                      l->seg_start, l->seg_ref, l->seg_off, l->chunk_seg};
+      for (void* p : ptrs) (void)hipFree(p);
+    }
+  } guard{&l};
   l.n = ix.n;
   l.nblk = (uint32_t)ix.blocks.size();
   l.primary = ix.primary;
@@ -424,6 +437,7 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
   if ((rc = upload(&l.seg_off, ix.seg_off))) return rc;
   if ((rc = upload(&l.chunk_seg, ix.chunk_seg))) return rc;
   ctx->libs.push_back(l);
+  guard.l = nullptr;
   *lib_id = (int32_t)ctx->libs.size() - 1;
   return MRG_OK;
 }
@@ -856,6 +870,16 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
   ctx->last_stream = stream;
   ctx->last_stats_dev = stats;
   ctx->last_n_pass = n_pass;
+  ++ctx->run_id;
+  // a length hint describes ONE batch: it never outlives the run it was set for
+  ctx->hint_min_len = 0;
+  ctx->hint_max_len = 255;
+  return MRG_OK;
+}
+
+int mrg_cascade_run_id(const mrg_ctx* ctx, uint64_t* run_id) {
+  if (!ctx || !run_id) return fail(MRG_ERR_ARG, "mrg_cascade_run_id: null argument");
+  *run_id = ctx->run_id;
   return MRG_OK;
 }
 
@@ -1127,8 +1151,18 @@ int mrg_list_best_count(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_pe
   if (!d_offsets || !total || (n && !d_best_mm)) return fail(MRG_ERR_ARG, "mrg_list_best_count: null buffers");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
-  uint32_t* cnt = nullptr;
-  HIP_TRY(hipMalloc((void**)&cnt, (n + 1) * sizeof(uint32_t)));
+  // per-read stratum sizes live in the context's scratch buffer (grown, never shrunk: repeated
+  // calls do not allocate)
+  const uint64_t need_bytes = (n + 1) * sizeof(uint32_t);
+  if (ctx->scratch_bytes < need_bytes) {
+    HIP_TRY(hipStreamSynchronize(st));
+    (void)hipFree(ctx->scratch);
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    HIP_TRY(hipMalloc(&ctx->scratch, need_bytes));
+    ctx->scratch_bytes = need_bytes;
+  }
+  uint32_t* cnt = (uint32_t*)ctx->scratch;
   hipError_t e = hipMemsetAsync(cnt, 0, (n + 1) * sizeof(uint32_t), st);
   if (e == hipSuccess && n) {
     p.best_mm = d_best_mm;
@@ -1139,7 +1173,6 @@ int mrg_list_best_count(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_pe
   if (e == hipSuccess) e = mrg::exclusive_sum_u32_u64(cnt, d_offsets, n + 1, st);
   if (e == hipSuccess) e = hipMemcpyAsync(total, d_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(cnt);
   HIP_TRY(e);
   return MRG_OK;
 }
@@ -1217,7 +1250,6 @@ int mrg_annotate_host(mrg_ctx* ctx, const uint64_t* reads, uint32_t words_per_re
   {
     // the lengths are on the host here: give the cascade the exact range of this batch (and put
     // the caller's own hints back afterwards)
-    const int64_t keep_min = ctx->hint_min_len, keep_max = ctx->hint_max_len;
     uint8_t lo = 255, hi = 0;
     for (uint64_t r = 0; r < n; ++r) {
       lo = std::min(lo, lens[r]);
@@ -1227,8 +1259,6 @@ int mrg_annotate_host(mrg_ctx* ctx, const uint64_t* reads, uint32_t words_per_re
     ctx->hint_max_len = n ? hi : 255;
     rc = mrg_cascade_run(ctx, d_reads, words_per_read, d_lens, d_nmask, n, passes, n_pass, d_pass, d_ref,
                          d_pos, d_mm, d_pc, d_ws, ws_bytes, nullptr);
-    ctx->hint_min_len = keep_min;
-    ctx->hint_max_len = keep_max;
   }
   if (rc) return rc;
   std::vector<mrg_pass_stats> st(n_pass);

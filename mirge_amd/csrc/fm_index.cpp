@@ -568,6 +568,18 @@ void load_index(const std::string& path, FmIndex& ix) {
       ix.super.size() != ((size_t)((ix.n + 1) >> kSuperShift) + 1) * 4 ||
       ix.text.size() < (size_t)(ix.n >> 4) + 3)
     throw std::runtime_error("index file inconsistent");
+  // the segment tables and `primary` are device indices later: a corrupt file must not become
+  // out-of-bounds reads on the GPU
+  const size_t n_seg = ix.seg_ref.size();
+  bool ok = ix.primary <= ix.n && ix.ref_len.size() == nref && ix.seg_start.size() == n_seg + 1 &&
+            ix.seg_off.size() == n_seg && ix.chunk_seg.size() == (size_t)(ix.n >> 5) + 2 &&
+            (n_seg == 0 ? ix.n == 0 : (ix.seg_start.front() == 0 && ix.seg_start.back() == ix.n));
+  for (size_t sg = 0; ok && sg < n_seg; ++sg)
+    ok = ix.seg_start[sg] <= ix.seg_start[sg + 1] && ix.seg_ref[sg] < nref &&
+         (uint64_t)ix.seg_off[sg] + (ix.seg_start[sg + 1] - ix.seg_start[sg]) <= ix.ref_len[ix.seg_ref[sg]];
+  for (size_t c = 0; ok && c < ix.chunk_seg.size(); ++c) ok = n_seg == 0 || ix.chunk_seg[c] < n_seg;
+  for (size_t i = 0; ok && i < ix.sa.size(); ++i) ok = (uint32_t)ix.sa[i] <= ix.n;
+  if (!ok) throw std::runtime_error("index file inconsistent (segment tables)");
   build_jump_tables(ix);
   build_row_context(ix);
   build_kmer_bits(ix);

@@ -1678,6 +1678,15 @@ hipError_t launch_tally(const TallyParams& p, bool lds_hist, uint32_t grid,
 
 hipError_t launch_count(const CountParams& p, uint32_t words_per_read, uint32_t grid, uint32_t lds_bytes,
                         hipStream_t stream) {
+  if (lds_bytes > 48 * 1024) {  // a genome part beyond ~200 Mbp: superblock table above the default dynamic-LDS cap
+    const void* kerns[6] = {reinterpret_cast<const void*>(count_kernel<1, true>), reinterpret_cast<const void*>(count_kernel<1, false>),
+                            reinterpret_cast<const void*>(count_kernel<2, true>), reinterpret_cast<const void*>(count_kernel<2, false>),
+                            reinterpret_cast<const void*>(count_kernel<4, true>), reinterpret_cast<const void*>(count_kernel<4, false>)};
+    for (const void* k : kerns) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) return e;
+    }
+  }
 #define MRG_COUNT(W_)                                                                                     \
   if (p.out_ref)                                                                                         \
     hipLaunchKernelGGL((count_kernel<W_, true>), dim3(grid), dim3(kCountThreads), lds_bytes, stream, p); \

@@ -89,11 +89,15 @@ class CascadeResult:
         self._engine = engine
         self.n_pass = n_pass
         self._stats = None
+        self._run_id = engine._run_id() if engine is not None and hasattr(engine, "_run_id") else None
 
     @property
     def stats(self):
         """Synchronises; list of dicts per pass."""
         if self._stats is None:
+            if self._run_id is not None and self._engine._run_id() != self._run_id:
+                raise RuntimeError("the context has run another cascade since: read `stats` of a result before "
+                                   "launching the next one (the counters and event times live in the context)")
             self._stats = self._engine._read_stats(self.n_pass)
         return self._stats
 
@@ -199,6 +203,11 @@ class Engine:
             pass_id.data_ptr(), ref_id.data_ptr(), pos.data_ptr(), mm.data_ptr(),
             pass_counts.data_ptr(), ws.data_ptr(), ws.numel(), self._stream_ptr()))
         return CascadeResult(pass_id, ref_id, pos, mm, pass_counts, self, n_pass)
+
+    def _run_id(self):
+        v = C.c_uint64()
+        check(self._lib.mrg_cascade_run_id(self._h, C.byref(v)))
+        return int(v.value)
 
     def _read_stats(self, n_pass):
         st = (PassStats * n_pass)()

@@ -1,16 +1,25 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo
-# root):  scripts/profile_round.sh r01   -> gpurun_out/<tag>_*; then
-# `python profiles/summarize_rocprof.py <tag>` and copy the bench lines into profiles/.
+# root):  scripts/profile_round.sh r02 <git head>   -> gpurun_out/<tag>_*; then
+# `python profiles/summarize_rocprof.py <tag>` here and copy the bench lines into profiles/.
 # Counters are collected in their own runs (never together with --kernel-trace/--stats).
-tag=${1:-r01}
+tag=${1:-r02}
+head=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
-B="python3 bench.py --no-cpu-baseline"
+echo "{\"git_head\": \"$head\"}" > gpurun_out/${tag}_meta.json
+B="python3 bench.py --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- $B --steps 5 --warmup 1 > gpurun_out/${tag}_stats.json 2> gpurun_out/${tag}_stats.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch -- $B --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${tag}_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_write -- $B --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${tag}_write.err
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d gpurun_out/${tag}_sq -- $B --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${tag}_sq.err
-python bench.py 2> gpurun_out/bench_final.err > gpurun_out/bench_final.json
-python bench.py --workload exact 2> gpurun_out/bench_exact.err > gpurun_out/bench_exact.json
-python bench.py --sorted --no-cpu-baseline 2> /dev/null > gpurun_out/bench_sorted.json
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD --output-format csv -d gpurun_out/${tag}_sq -- $B --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${tag}_sq.err
+rocprofv3 --pmc TCP_TOTAL_ACCESSES TCP_TCC_READ_REQ TCP_TCC_READ_REQ_LATENCY TCP_PENDING_STALL_CYCLES --output-format csv -d gpurun_out/${tag}_tcp -- $B --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${tag}_tcp.err
+rocprofv3 --pmc TCC_REQ TCC_HIT TCC_MISS --output-format csv -d gpurun_out/${tag}_tcc -- $B --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${tag}_tcc.err
+# the a2i workload's kernels (edit tally) by time
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_a2i_stats -- $B --workload a2i --steps 5 --warmup 1 > gpurun_out/${tag}_a2i_stats.json 2> gpurun_out/${tag}_a2i_stats.err
+# the bench lines proper (no profiler attached)
+python bench.py 2> gpurun_out/${tag}_bench_cascade.err > gpurun_out/${tag}_bench_cascade.json
+python bench.py --workload exact 2> gpurun_out/${tag}_bench_exact.err > gpurun_out/${tag}_bench_exact.json
+python bench.py --workload a2i 2> gpurun_out/${tag}_bench_a2i.err > gpurun_out/${tag}_bench_a2i.json
+python bench.py --workload varlen 2> gpurun_out/${tag}_bench_varlen.err > gpurun_out/${tag}_bench_varlen.json
+python bench.py --sorted --no-cpu-baseline --no-extras 2> /dev/null > gpurun_out/${tag}_bench_sorted.json
