@@ -144,6 +144,7 @@ struct mrg_ctx {
   // small (bitmap-filtered) and large libraries in separate groups; 2 = one group regardless of
   // library size; 3 = only the small-library runs are fused
   int64_t fuse = 1;
+  int64_t round_large = 0;
   int64_t wide_rows_16 = 1;  // libraries of >= 2^20 bases get 16-byte rows with 32 bases of context
   std::vector<DevLib> libs;
   // last run
@@ -470,6 +471,8 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->force_lds_mode = value;
   } else if (k == "ftab") {
     ctx->use_ftab = value != 0;
+  } else if (k == "round_large") {
+    ctx->round_large = value != 0;
   } else if (k == "wide_rows_16") {
     ctx->wide_rows_16 = value != 0;  // takes effect for libraries added afterwards
   } else if (k == "fuse") {
@@ -797,13 +800,15 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     fp.pos = d_pos;
     fp.mm = d_mm;
     fp.wstop = (uint32_t)ctx->wstop;
-    // rounds: the bitmap-filtered sub-passes of a run are looked up together (few items per read),
-    // every other library gets a round of its own (each unclaimed read has items there)
+    // rounds: the sub-passes of a run of bitmap-filtered libraries are looked up together (few
+    // items per read), with "round_large" = 1 so are those of a run of large ones (measured equal, default 0: every unclaimed
+    // read has items in each of them, but few reads are claimed in between, so little of the
+    // speculative work is wasted and the dependent jump-table -> row trips of the libraries overlap)
     fp.n_rounds = 0;
     for (uint32_t q = 0; q < n_sub;) {
       uint32_t e = q + 1;
-      if (lg[q])
-        while (e < n_sub && lg[e] && e - q < mrg::kMaxRoundSubs) ++e;
+      if (lg[q] || ctx->round_large)
+        while (e < n_sub && (lg[e] != 0) == (lg[q] != 0) && e - q < mrg::kMaxRoundSubs) ++e;
       fp.round_first[fp.n_rounds] = (uint8_t)q;
       fp.round_count[fp.n_rounds] = (uint8_t)(e - q);
       ++fp.n_rounds;
@@ -939,7 +944,8 @@ int mrg_tally_run(mrg_ctx* ctx, const int8_t* d_pass_id, const int32_t* d_ref_id
   p.counts = d_counts;
   uint64_t bins = 0;
   mrg_tally_counts_len(n_mirna, n_samples, n_pass, &bins);
-  const uint64_t lds = bins * 8;
+  // LDS histogram: the category bins are replicated (kernels.hip: tally_kernel)
+  const uint64_t lds = (bins + (uint64_t)(n_pass + 1) * n_samples * (mrg::kTallyCatReplicas - 1)) * 8;
   const bool lds_hist = lds <= (uint64_t)ctx->lds_budget;
   uint64_t want = (n + mrg::kTallyThreads - 1) / mrg::kTallyThreads;
   uint32_t per_cu = lds_hist ? (lds * 2 <= 160 * 1024 ? 2u : 1u) : 2u;
@@ -1061,12 +1067,20 @@ int mrg_edit_tally_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per
   p.text = l.text;
   p.seg_start = l.seg_start;
   p.counts = d_counts;
-  const uint64_t lds = (uint64_t)n_bins * n_samples * 3ull * 8ull;
-  const bool lds_hist = lds <= (uint64_t)ctx->lds_budget;
+  p.text_words = l.text_words;
+  p.n_entries = l.n_ref;
+  // LDS: the per-entry totals first (every kept read hits them), then -- if two workgroups per CU
+  // still fit -- the library's text and entry starts, so that a read costs no gather
+  const uint64_t hist_b = mrg::edit_hist_lds_bytes(n_bins, n_samples);
+  const uint64_t lib_b = (uint64_t)l.text_words * 4 + (((uint64_t)l.n_ref + 4) & ~3ull) * 4;
+  const uint64_t budget = (uint64_t)std::max<int64_t>(ctx->lds_budget, (int64_t)mrg::kEditHashLdsBytes) - mrg::kEditHashLdsBytes;
+  const bool lds_hist = hist_b <= budget;
+  const bool lds_lib = (lds_hist ? hist_b : 0) + lib_b + mrg::kEditHashLdsBytes <= std::min<uint64_t>(budget, 80 * 1024);
+  const uint64_t lds = (lds_hist ? hist_b : 0) + (lds_lib ? lib_b : 0) + mrg::kEditHashLdsBytes;
   const uint64_t want = (n + mrg::kEditThreads - 1) / mrg::kEditThreads;
-  const uint32_t per_cu = lds_hist ? (lds * 2 <= 160 * 1024 ? 2u : 1u) : 2u;
+  const uint32_t per_cu = lds * 2 <= 160 * 1024 ? 2u : 1u;
   const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)ctx->n_cu * per_cu);
-  HIP_TRY(mrg::launch_edit_tally(p, lds_hist, grid, lds_hist ? (uint32_t)lds : 0u, (hipStream_t)stream));
+  HIP_TRY(mrg::launch_edit_tally(p, lds_hist, lds_lib, grid, (uint32_t)lds, (hipStream_t)stream));
   return MRG_OK;
 }
 

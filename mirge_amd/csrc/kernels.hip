@@ -1388,15 +1388,21 @@ __global__ void __launch_bounds__(kTallyThreads) tally_kernel(const TallyParams 
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   unsigned long long* hist = reinterpret_cast<unsigned long long*>(smem);
   const uint32_t S = p.n_samples, M = p.n_mirna;
-  const uint32_t n_bins = 2 * M * S + (p.n_pass + 1) * S + S;
-  const uint32_t cat0 = 2 * M * S, uniq0 = cat0 + (p.n_pass + 1) * S;
+  const uint32_t n_cat = (p.n_pass + 1) * S;
+  const uint32_t n_bins = 2 * M * S + n_cat + S;
+  const uint32_t cat0 = 2 * M * S, uniq0 = cat0 + n_cat;
+  // LDS layout: [miRNA bins][category bins x kTallyCatReplicas][trimmedUniq].  The ~10 category bins
+  // are hit by EVERY lane: one copy per (lane & 31) turns a 64-way same-address LDS atomic into
+  // a 2-way one.
+  constexpr uint32_t R = kTallyCatReplicas;
+  const uint32_t l_cat0 = cat0, l_uniq0 = cat0 + n_cat * R, l_bins = l_uniq0 + S;
   unsigned long long* g = reinterpret_cast<unsigned long long*>(p.counts);
   if (LDSH) {
-    for (uint32_t i = threadIdx.x; i < n_bins; i += kTallyThreads) hist[i] = 0ull;
+    for (uint32_t i = threadIdx.x; i < l_bins; i += kTallyThreads) hist[i] = 0ull;
     __syncthreads();
   }
-  unsigned long long* h = LDSH ? hist : g;
   const uint32_t lane = threadIdx.x & 63;
+  const uint32_t rep = LDSH ? (lane & (R - 1u)) : 0u;
   const uint64_t n_round = ((p.n + kTallyThreads - 1) / kTallyThreads) * kTallyThreads;
 
   for (uint64_t r = (uint64_t)blockIdx.x * kTallyThreads + threadIdx.x; r < n_round;
@@ -1413,16 +1419,31 @@ __global__ void __launch_bounds__(kTallyThreads) tally_kernel(const TallyParams 
       const bool hit = q != 0ull;
       const uint64_t hits = __ballot(hit);
       if (!hits) continue;
-      if (lane == 0) atomicAdd(&h[uniq0 + s], (unsigned long long)__popcll(hits));
-      if (hit) atomicAdd(&h[cat0 + cat * S + s], q);
-      if (hit && (canon || iso)) atomicAdd(&h[ref * S + s], q);
-      if (hit && canon) atomicAdd(&h[M * S + ref * S + s], q);
+      if (LDSH) {
+        if (lane == 0) atomicAdd(&hist[l_uniq0 + s], (unsigned long long)__popcll(hits));
+        if (hit) atomicAdd(&hist[l_cat0 + (cat * S + s) * R + rep], q);
+        if (hit && (canon || iso)) atomicAdd(&hist[ref * S + s], q);
+        if (hit && canon) atomicAdd(&hist[M * S + ref * S + s], q);
+      } else {
+        if (lane == 0) atomicAdd(&g[uniq0 + s], (unsigned long long)__popcll(hits));
+        if (hit) atomicAdd(&g[cat0 + cat * S + s], q);
+        if (hit && (canon || iso)) atomicAdd(&g[ref * S + s], q);
+        if (hit && canon) atomicAdd(&g[M * S + ref * S + s], q);
+      }
     }
   }
   if (LDSH) {
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n_bins; i += kTallyThreads) {
-      const unsigned long long v = hist[i];
+      unsigned long long v = 0ull;
+      if (i < cat0) {
+        v = hist[i];
+      } else if (i < uniq0) {
+        const unsigned long long* src = hist + l_cat0 + (size_t)(i - cat0) * R;
+        for (uint32_t q = 0; q < R; ++q) v += src[q];
+      } else {
+        v = hist[l_uniq0 + (i - uniq0)];
+      }
       if (v) atomicAdd(&g[i], v);
     }
   }
@@ -1444,127 +1465,182 @@ __global__ void __launch_bounds__(kTallyThreads) tally_kernel(const TallyParams 
 // The reference aligns read and mature with pairwise2.localms (gap penalties of -20: an ungapped
 // diagonal); the cascade's alignment is that diagonal for every read it claimed.
 // ---------------------------------------------------------------------------
-template <bool LDSH>
+// LDSH: the three per-entry totals are privatised in LDS (count_true and canonical 64-bit,
+// seq_true 32-bit: a workgroup sees < 2^32 reads); LDSL: the library's packed text and entry
+// starts are staged in LDS too (a miRNA library is ~30 KB), so a read costs no gather at all.
+template <bool LDSH, bool LDSL>
 __global__ void __launch_bounds__(kEditThreads) edit_tally_kernel(const EditParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  unsigned long long* hist = reinterpret_cast<unsigned long long*>(smem);
   const uint32_t S = p.n_samples;
-  const uint32_t n_tot = p.n_bins * S * 3u;
+  const uint32_t n_tot = p.n_bins * S;
+  // LDS carve: [count_true u64 x n_tot][canonical u64 x n_tot][seq_true u32 x n_tot (padded)][text][seg_start]
+  unsigned long long* h_ct = reinterpret_cast<unsigned long long*>(smem);
+  unsigned long long* h_cn = h_ct + (LDSH ? n_tot : 0u);
+  uint32_t* h_st = reinterpret_cast<uint32_t*>(h_cn + (LDSH ? n_tot : 0u));
+  uint32_t* s_text = h_st + (LDSH ? ((n_tot + 3u) & ~3u) : 0u);
+  uint32_t* s_seg = s_text + (LDSL ? p.text_words : 0u);
+  // position bins: a small LDS hash (key = index into the global position array) absorbs the hot
+  // (entry, position) pairs -- one abundant miRNA with one edited site would otherwise be tens of
+  // thousands of L2 atomics on one cache line, ~10 ns each, serialised
+  uint32_t* hk = s_seg + (LDSL ? ((p.n_entries + 4u) & ~3u) : 0u);
+  unsigned long long* hv = reinterpret_cast<unsigned long long*>(hk + kEditHashSlots);
   unsigned long long* g = reinterpret_cast<unsigned long long*>(p.counts);
-  unsigned long long* gpos = g + n_tot;
-  if (LDSH) {
-    for (uint32_t i = threadIdx.x; i < n_tot; i += kEditThreads) hist[i] = 0ull;
-    __syncthreads();
+  unsigned long long* gpos = g + (size_t)n_tot * 3u;
+  for (uint32_t i = threadIdx.x; i < kEditHashSlots; i += kEditThreads) {
+    hk[i] = 0xFFFFFFFFu;
+    hv[i] = 0ull;
   }
-  unsigned long long* h = LDSH ? hist : g;
-  for (uint64_t r = (uint64_t)blockIdx.x * kEditThreads + threadIdx.x; r < p.n;
-       r += (uint64_t)gridDim.x * kEditThreads) {
-    const int32_t pass = p.pass_id[r];
-    if (pass < 0 || (pass != p.canon_pass && pass != p.isomir_pass)) continue;
-    if (p.keep && !p.keep[r]) continue;
-    const uint32_t e = (uint32_t)p.ref_id[r];
-    const int32_t L = (int32_t)p.lens[r];
-    const uint32_t e0 = p.seg_start[e], e1 = p.seg_start[e + 1];
-    const int32_t Lm_full = (int32_t)(e1 - e0) - (int32_t)(p.flank5 + p.flank3);
-    if (Lm_full <= 0 || Lm_full > (int32_t)kEditPositions) continue;  // (host rejects such libraries)
-    const int32_t Lm = Lm_full;
-    const int32_t d = p.pos[r] - (pass == p.isomir_pass ? p.isomir_trim5 : 0) - (int32_t)p.flank5;
-    if (d > 1) continue;                       // head shift (judgeAllign)
-    if (d + L <= 0) continue;                  // the read ends before the mature sequence starts
-    // 32 mature bases from the text, 2 bits each, mature index 0 in the low bits
-    uint64_t tw;
-    {
-      const uint32_t q = e0 + p.flank5, i = q >> 4, sh = (q & 15u) * 2u;
-      const uint64_t lo64 = (uint64_t)p.text[i] | ((uint64_t)p.text[i + 1] << 32);
-      tw = (lo64 >> sh) | ((((uint64_t)p.text[i + 2]) << 1) << (63 - sh));
-    }
-    // the read in mature coordinates (base j -> index d + j), and its N mask
-    const uint64_t r0 = p.reads[r], r1 = p.words_per_read > 1 ? p.reads[p.n + r] : 0ull;
-    const uint64_t m0 = p.nmask ? p.nmask[r] : 0ull, m1 = (p.nmask && p.words_per_read > 1) ? p.nmask[p.n + r] : 0ull;
-    uint64_t rw, nw;
-    if (d >= 0) {
-      rw = d ? (r0 << (2 * d)) : r0;
-      nw = d ? (m0 << (2 * d)) : m0;
-    } else {
-      const int32_t s2 = -2 * d;  // 2..62 (d >= -31 for a read that reaches the mature sequence within its first word)
-      if (s2 >= 64) {
-        const int32_t s3 = s2 - 64;
-        rw = s3 < 64 ? (r1 >> s3) : 0ull;
-        nw = s3 < 64 ? (m1 >> s3) : 0ull;
-      } else {
-        rw = (r0 >> s2) | (r1 << (64 - s2));
-        nw = (m0 >> s2) | (m1 << (64 - s2));
-      }
-    }
-    const int32_t c_lo = max(0, d), c_hi = min(Lm, d + L);  // mature indices the read covers
-    if (c_hi <= c_lo) continue;
-    const uint64_t cover = low_bits(2 * c_hi) & ~low_bits(2 * c_lo) & kOdd;
-    const uint64_t x = tw ^ rw;
-    const uint64_t diff = (((x | (x >> 1)) & kOdd) | (nw & kOdd)) & cover;
-    // judgeAllign's window, in its own arithmetic (W2C:35-69): with both sequences padded to the
-    // common frame (head_t / head_s leading dashes, frame length plen) it compares frame positions
-    // head_t .. min(end1, end2), end1 = plen - head_t - 1 - 3, end2 = last read base -- so a read
-    // that starts before the mature sequence is judged over a shorter stretch, and one that runs
-    // past its end is judged up to 3 bases before the READ's end, every base beyond the mature
-    // sequence counting as a mismatch.  hi_m = that last position in mature coordinates.
-    const int32_t head_t = max(0, -d), head_s = max(0, d);
-    const int32_t plen = max(head_t + Lm_full, head_s + L);
-    const int32_t hi_m = min(plen - head_t - 4, head_s + L - 1) - head_t;
-    const uint64_t judged = cover & low_bits(2 * max(min(hi_m + 1, Lm), 0));
-    const int32_t beyond = max(0, hi_m - max(Lm_full, c_lo) + 1);  // judged positions past the mature end
-    const int32_t mism = __popcll(diff & judged) + beyond, mat = __popcll(~diff & judged);
-    const int32_t need = (Lm_full - 4) - (d == 1 ? 1 : 0);
-    if (mism > 1 || mat < need) continue;
-    // canonical: the whole read is a substring of the mature sequence, at whatever offset (:170 `in`)
-    bool canonical = false;
-    if (L <= Lm && (m0 | m1) == 0ull) {
-      for (int32_t o = 0; o + L <= Lm; ++o) {
-        const uint64_t y = ((tw >> (2 * o)) ^ r0) & low_bits(2 * L);
-        canonical |= y == 0ull;
-      }
-    }
-    // positions i < Lm - 5 with mature == from_base and read == to_base (an N is never to_base)
-    const uint64_t f = p.from_base, t = p.to_base;
-    const uint64_t is_from = ~((tw ^ (f * kOdd)) | ((tw ^ (f * kOdd)) >> 1)) & kOdd;
-    const uint64_t is_to = ~((rw ^ (t * kOdd)) | ((rw ^ (t * kOdd)) >> 1)) & kOdd & ~(nw & kOdd);
-    uint64_t hits = is_from & is_to & cover & low_bits(2 * max(Lm - 5, 0));
-    const uint32_t bin = p.remap ? p.remap[e] : e;
-    for (uint32_t s = 0; s < S; ++s) {
-      const unsigned long long q = p.quant[r * S + s];
-      if (!q) continue;
-      unsigned long long* t3 = h + ((size_t)bin * S + s) * 3u;
-      atomicAdd(&t3[0], q);
-      atomicAdd(&t3[1], 1ull);
-      if (canonical) atomicAdd(&t3[2], q);
-      for (uint64_t hb = hits; hb; hb &= hb - 1ull) {
-        const uint32_t i = (uint32_t)(__ffsll((long long)hb) - 1) >> 1;
-        atomicAdd(&gpos[((size_t)bin * kEditPositions + i) * S + s], q);
-      }
-    }
-  }
-  if (LDSH) {
-    __syncthreads();
+  if (LDSH)
     for (uint32_t i = threadIdx.x; i < n_tot; i += kEditThreads) {
-      const unsigned long long v = hist[i];
-      if (v) atomicAdd(&g[i], v);
+      h_ct[i] = 0ull;
+      h_cn[i] = 0ull;
+      h_st[i] = 0u;
+    }
+  if (LDSL) {
+    for (uint32_t i = threadIdx.x; i < p.text_words; i += kEditThreads) s_text[i] = p.text[i];
+    for (uint32_t i = threadIdx.x; i <= p.n_entries; i += kEditThreads) s_seg[i] = p.seg_start[i];
+  }
+  __syncthreads();
+  const uint32_t* text = LDSL ? s_text : p.text;
+  const uint32_t* seg_start = LDSL ? s_seg : p.seg_start;
+  const uint64_t n_round = ((p.n + kEditThreads - 1) / kEditThreads) * kEditThreads;
+  for (uint64_t r = (uint64_t)blockIdx.x * kEditThreads + threadIdx.x; r < n_round;
+       r += (uint64_t)gridDim.x * kEditThreads) {
+    // whole waves stay in the loop (the position hits are aggregated over the wave below)
+    uint64_t hits = 0ull;
+    uint32_t bin = 0;
+    bool kept = false, canonical = false;
+    do {
+      if (r >= p.n) break;
+      const int32_t pass = p.pass_id[r];
+      if (pass < 0 || (pass != p.canon_pass && pass != p.isomir_pass)) break;
+      if (p.keep && !p.keep[r]) break;
+      const uint32_t e = (uint32_t)p.ref_id[r];
+      const int32_t L = (int32_t)p.lens[r];
+      const uint32_t e0 = seg_start[e], e1 = seg_start[e + 1];
+      const int32_t Lm = (int32_t)(e1 - e0) - (int32_t)(p.flank5 + p.flank3);
+      if (Lm <= 0 || Lm > (int32_t)kEditPositions) break;  // (the host rejects such libraries)
+      const int32_t d = p.pos[r] - (pass == p.isomir_pass ? p.isomir_trim5 : 0) - (int32_t)p.flank5;
+      if (d > 1) break;        // head shift (judgeAllign)
+      if (d + L <= 0) break;   // the read ends before the mature sequence starts
+      // 32 mature bases from the text, 2 bits each, mature index 0 in the low bits
+      uint64_t tw;
+      {
+        const uint32_t q = e0 + p.flank5, i = q >> 4, sh = (q & 15u) * 2u;
+        const uint64_t lo64 = (uint64_t)text[i] | ((uint64_t)text[i + 1] << 32);
+        tw = (lo64 >> sh) | ((((uint64_t)text[i + 2]) << 1) << (63 - sh));
+      }
+      // the read in mature coordinates (base j -> index d + j), and its N mask
+      const uint64_t r0 = p.reads[r], r1 = p.words_per_read > 1 ? p.reads[p.n + r] : 0ull;
+      const uint64_t m0 = p.nmask ? p.nmask[r] : 0ull, m1 = (p.nmask && p.words_per_read > 1) ? p.nmask[p.n + r] : 0ull;
+      uint64_t rw, nw;
+      if (d >= 0) {
+        rw = d ? (r0 << (2 * d)) : r0;
+        nw = d ? (m0 << (2 * d)) : m0;
+      } else {
+        const int32_t s2 = -2 * d;
+        if (s2 >= 64) {
+          const int32_t s3 = s2 - 64;
+          rw = s3 < 64 ? (r1 >> s3) : 0ull;
+          nw = s3 < 64 ? (m1 >> s3) : 0ull;
+        } else {
+          rw = (r0 >> s2) | (r1 << (64 - s2));
+          nw = (m0 >> s2) | (m1 << (64 - s2));
+        }
+      }
+      const int32_t c_lo = max(0, d), c_hi = min(Lm, d + L);  // mature indices the read covers
+      if (c_hi <= c_lo) break;
+      const uint64_t cover = low_bits(2 * c_hi) & ~low_bits(2 * c_lo) & kOdd;
+      const uint64_t x = tw ^ rw;
+      const uint64_t diff = (((x | (x >> 1)) & kOdd) | (nw & kOdd)) & cover;
+      // judgeAllign's window, in its own arithmetic (W2C:35-69): with both sequences padded to the
+      // common frame (head_t / head_s leading dashes, frame length plen) it compares frame positions
+      // head_t .. min(end1, end2), end1 = plen - head_t - 1 - 3, end2 = last read base -- so a read
+      // that starts before the mature sequence is judged over a shorter stretch, and one that runs
+      // past its end is judged up to 3 bases before the READ's end, every base beyond the mature
+      // sequence counting as a mismatch.  hi_m = that last position in mature coordinates.
+      const int32_t head_t = max(0, -d), head_s = max(0, d);
+      const int32_t plen = max(head_t + Lm, head_s + L);
+      const int32_t hi_m = min(plen - head_t - 4, head_s + L - 1) - head_t;
+      const uint64_t judged = cover & low_bits(2 * max(min(hi_m + 1, Lm), 0));
+      const int32_t beyond = max(0, hi_m - max(Lm, c_lo) + 1);  // judged positions past the mature end
+      const int32_t mism = __popcll(diff & judged) + beyond, mat = __popcll(~diff & judged);
+      const int32_t need = (Lm - 4) - (d == 1 ? 1 : 0);
+      if (mism > 1 || mat < need) break;
+      kept = true;
+      // canonical: the whole read is a substring of the mature sequence, at whatever offset (:170 `in`)
+      if (L <= Lm && (m0 | m1) == 0ull) {
+        for (int32_t o = 0; o + L <= Lm; ++o) {
+          const uint64_t y = ((tw >> (2 * o)) ^ r0) & low_bits(2 * L);
+          canonical |= y == 0ull;
+        }
+      }
+      // positions i < Lm - 5 with mature == from_base and read == to_base (an N is never to_base)
+      const uint64_t f = p.from_base, t = p.to_base;
+      const uint64_t is_from = ~((tw ^ (f * kOdd)) | ((tw ^ (f * kOdd)) >> 1)) & kOdd;
+      const uint64_t is_to = ~((rw ^ (t * kOdd)) | ((rw ^ (t * kOdd)) >> 1)) & kOdd & ~(nw & kOdd);
+      hits = is_from & is_to & cover & low_bits(2 * max(Lm - 5, 0));
+      bin = p.remap ? p.remap[e] : e;
+    } while (false);
+    for (uint32_t s = 0; s < S; ++s) {
+      const unsigned long long q = kept ? p.quant[r * S + s] : 0ull;
+      if (q) {
+        const size_t k = (size_t)bin * S + s;
+        if (LDSH) {
+          atomicAdd(&h_ct[k], q);
+          atomicAdd(&h_st[k], 1u);
+          if (canonical) atomicAdd(&h_cn[k], q);
+        } else {
+          atomicAdd(&g[k * 3u + 0u], q);
+          atomicAdd(&g[k * 3u + 1u], 1ull);
+          if (canonical) atomicAdd(&g[k * 3u + 2u], q);
+        }
+      }
+      for (uint64_t hb = q ? hits : 0ull; hb; hb &= hb - 1ull) {
+        const uint32_t key = (bin * kEditPositions + ((uint32_t)(__ffsll((long long)hb) - 1) >> 1)) * S + s;
+        uint32_t slot = (key * 2654435761u) >> (32u - kEditHashLog2);
+        bool done = false;
+        for (uint32_t t = 0; t < 4u && !done; ++t, slot = (slot + 1u) & (kEditHashSlots - 1u)) {
+          const uint32_t prev = atomicCAS(&hk[slot], 0xFFFFFFFFu, key);
+          if (prev == 0xFFFFFFFFu || prev == key) {
+            atomicAdd(&hv[slot], q);
+            done = true;
+          }
+        }
+        if (!done) atomicAdd(&gpos[key], q);   // four occupied slots: a rare pair goes straight to L2
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < kEditHashSlots; i += kEditThreads)
+    if (hk[i] != 0xFFFFFFFFu && hv[i]) atomicAdd(&gpos[hk[i]], hv[i]);
+  if (LDSH) {
+    for (uint32_t i = threadIdx.x; i < n_tot; i += kEditThreads) {
+      if (h_ct[i]) atomicAdd(&g[(size_t)i * 3u + 0u], h_ct[i]);
+      if (h_st[i]) atomicAdd(&g[(size_t)i * 3u + 1u], (unsigned long long)h_st[i]);
+      if (h_cn[i]) atomicAdd(&g[(size_t)i * 3u + 2u], h_cn[i]);
     }
   }
 }
 
-hipError_t launch_edit_tally(const EditParams& p, bool lds_hist, uint32_t grid, uint32_t lds_bytes,
-                             hipStream_t stream) {
-  if (lds_hist) {
-    auto kern = edit_tally_kernel<true>;
-    if (lds_bytes > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kEditThreads), lds_bytes, stream, p);
-  } else {
-    hipLaunchKernelGGL(edit_tally_kernel<false>, dim3(grid), dim3(kEditThreads), 0, stream, p);
+template <bool LDSH, bool LDSL>
+static hipError_t launch_edit_k(const EditParams& p, uint32_t grid, uint32_t lds_bytes, hipStream_t stream) {
+  auto kern = edit_tally_kernel<LDSH, LDSL>;
+  if (lds_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
   }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kEditThreads), lds_bytes, stream, p);
   return hipGetLastError();
+}
+
+hipError_t launch_edit_tally(const EditParams& p, bool lds_hist, bool lds_lib, uint32_t grid, uint32_t lds_bytes,
+                             hipStream_t stream) {
+  if (lds_hist) return lds_lib ? launch_edit_k<true, true>(p, grid, lds_bytes, stream)
+                               : launch_edit_k<true, false>(p, grid, lds_bytes, stream);
+  return lds_lib ? launch_edit_k<false, true>(p, grid, lds_bytes, stream)
+                 : launch_edit_k<false, false>(p, grid, lds_bytes, stream);
 }
 
 __global__ void export_pass_counts_kernel(const uint64_t* stats, uint32_t n_pass,

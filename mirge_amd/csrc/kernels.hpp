@@ -14,6 +14,7 @@ struct MatchBlock {
   static constexpr uint32_t kThreads = 1024u;
 };
 constexpr uint32_t kTallyThreads = 1024u;
+constexpr uint32_t kTallyCatReplicas = 32u;  // LDS copies of each category bin (one per lane & 31)
 // 9-mer presence bitmap of a small library (FmIndex::kbits): 4^9 bits
 constexpr uint32_t kKmerBitsK = 9u;
 constexpr uint32_t kKmerBitsWords = (1u << (2u * kKmerBitsK)) / 32u;
@@ -185,6 +186,7 @@ struct TallyParams {
 // A-to-I position tally (writeDataToCSV.py:145-229 on the cascade's own alignments)
 constexpr uint32_t kEditPositions = 32u;  // mature-miRNA positions tallied per entry
 constexpr uint32_t kEditThreads = 1024u;
+constexpr uint32_t kEditHashLog2 = 11u, kEditHashSlots = 1u << kEditHashLog2;  // LDS hash of position bins
 struct EditParams {
   const uint64_t* reads;
   const uint8_t* lens;
@@ -204,9 +206,13 @@ struct EditParams {
   // library text
   const uint32_t* text;
   const uint32_t* seg_start;   // entry e = text [seg_start[e], seg_start[e + 1]) (every entry one N-free segment)
+  uint32_t text_words, n_entries;
   uint64_t* counts;            // [n_bins][S][3] then [n_bins][kEditPositions][S]
 };
-hipError_t launch_edit_tally(const EditParams& p, bool lds_hist, uint32_t grid, uint32_t lds_bytes,
+// LDS bytes of the privatised totals (lds_hist) and of the staged library (lds_lib)
+constexpr uint64_t edit_hist_lds_bytes(uint64_t n_bins, uint64_t S) { return n_bins * S * 16u + ((n_bins * S + 3u) & ~3ull) * 4u; }
+constexpr uint64_t kEditHashLdsBytes = (uint64_t)kEditHashSlots * 12u;
+hipError_t launch_edit_tally(const EditParams& p, bool lds_hist, bool lds_lib, uint32_t grid, uint32_t lds_bytes,
                              hipStream_t stream);
 
 // lds_mode: 0 = index in HBM/L2, 1 = occ blocks in LDS, 2 = occ blocks + text in LDS,

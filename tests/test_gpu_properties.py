@@ -36,7 +36,13 @@ def test_permutation_invariance_and_idempotence(big):
     eng, libs, words, lens = big
     _, res = run(eng, words, lens)
     a = res.to_host()
+    st = res.stats          # the counters live in the context: read them before the next run
     _, res2 = run(eng, words, lens)
+    import copy
+    stale = copy.copy(res)
+    stale._stats = None
+    with pytest.raises(RuntimeError):       # ... a later read would silently be the next run's
+        stale.stats
     for x, y in zip(a, res2.to_host()):
         assert np.array_equal(x, y)                         # same input, same answer
     perm = np.random.default_rng(5).permutation(N)
@@ -47,7 +53,6 @@ def test_permutation_invariance_and_idempotence(big):
     _, res4 = run(eng, np.ascontiguousarray(words[:, order]), lens[order])
     for x, y in zip(a, res4.to_host()):
         assert np.array_equal(x[order], y)
-    st = res.stats
     assert sum(s["aligned"] for s in st) == int((a[0] >= 0).sum())
     assert st[0]["processed"] == N
     # every later pass is offered exactly what the earlier ones left (all reads are 22 nt)
