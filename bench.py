@@ -487,10 +487,20 @@ def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log,
             ev_in=torch.cuda.Event(), ev_done=torch.cuda.Event(), ev_free=torch.cuda.Event()))
     counts = torch.zeros(ln, dtype=torch.int64, device=dev)
     pc = torch.zeros(2 * n_pass, dtype=torch.int64, device=dev)
-    s_in, s_out, s_comp = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.current_stream(dev)
+    # HIP streams share a few hardware queues: which stream pair really overlaps H2D, D2H and the
+    # kernels differs from box to box (scripts/pcie_overlap.py), so a few assignments are tried once
+    pool = [torch.cuda.Stream(dev) for _ in range(6)]
+    cur = torch.cuda.current_stream(dev)
+    candidates = [(pool[0], pool[2], cur), (pool[0], pool[2], pool[4]), (pool[1], pool[3], pool[5]), (pool[0], pool[1], cur)]
+    s_in, s_out, s_comp = candidates[0]
     min_len, max_len = int(lens.min()), int(lens.max())
 
     def one_pass():
+        with torch.cuda.stream(s_comp):
+            _one_pass()
+        torch.cuda.synchronize()
+
+    def _one_pass():
         counts.zero_()
         for b in bufs:
             b["ev_free"].record(s_comp)
@@ -520,9 +530,16 @@ def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log,
         with torch.cuda.stream(s_out):
             s_out.wait_event(bufs[(len(bounds) - 1) % n_bufs]["ev_done"])
             h_counts.copy_(counts, non_blocking=True)
-        torch.cuda.synchronize()
 
     one_pass()  # warm-up (also the run whose output is checked)
+    trial = []
+    for cand in candidates:
+        s_in, s_out, s_comp = cand
+        one_pass()
+        t0 = time.perf_counter()
+        one_pass()
+        trial.append(time.perf_counter() - t0)
+    s_in, s_out, s_comp = candidates[int(np.argmin(trial))]
     ok = None
     if expect is not None:
         ok = all(np.array_equal(h.numpy(), g) for h, g in zip(h_out, expect))
