@@ -58,6 +58,7 @@ struct DevLib {
   // the 9-mer bitmap folded to 2^17 .. 2^13 bits (bit h = OR of the 9-mers with code & (bits - 1) == h),
   // one allocation, for fused launches whose LDS cannot hold every library's full bitmap
   uint32_t* kbits_folds = nullptr;
+  std::vector<uint32_t> kbits_host;  // host copy (32 KB): the per-round interleaved tables are built from it
   uint32_t* ftab = nullptr;
   mrg::JumpTables tabs = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   uint32_t n = 0, nblk = 0, nsup = 0, primary = 0, text_words = 0, n_seg = 0, n_ref = 0;
@@ -135,6 +136,8 @@ struct mrg_ctx {
   int64_t wide_rows = 64;
   int64_t hint_min_len = 0, hint_max_len = 255;  // length range of the reads of the NEXT run only
   uint64_t run_id = 0;
+  // interleaved 9-mer tables of fused rounds, keyed by "lib ids | log2 | bits" (built on first use)
+  std::vector<std::pair<std::string, uint32_t*>> round_tables;
   void* scratch = nullptr;  // context-owned device scratch (grown on demand; mrg_list_best_count)
   uint64_t scratch_bytes = 0;
   int64_t kmer_filter = 1;
@@ -356,6 +359,7 @@ void mrg_ctx_destroy(mrg_ctx* ctx) {
     for (auto& e : ctx->ev) (void)hipEventDestroy(e);
   if (ctx->comm) (void)rccl_api()->CommDestroy(ctx->comm);
   (void)hipFree(ctx->scratch);
+  for (auto& kv : ctx->round_tables) (void)hipFree(kv.second);
   delete ctx;
 }
 
@@ -422,6 +426,7 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
     }
   }
   if (!ix.kbits.empty() && (rc = upload(&l.kbits, ix.kbits))) return rc;
+  l.kbits_host = ix.kbits;
   if (!ix.kbits.empty()) {
     // folds of 2^17, 2^16, ... 2^13 bits back to back (word offsets: see fold_offset_words)
     std::vector<uint32_t> folds, cur = ix.kbits;
@@ -701,37 +706,31 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     mrg::FusedParams fp;
     std::memset(&fp, 0, sizeof fp);
     fp.n_sub = n_sub;
-    // bitmap sizes: start from the full 2^18 bits of every small library and halve the one with
-    // the lowest fill until the group fits the LDS of two workgroups per CU
+    // which sub-passes filter seed pieces with their library's 9-mer bitmap
     uint32_t lg[mrg::kMaxFused];
     for (uint32_t q = 0; q < n_sub; ++q) lg[q] = small_lib(members[q]) ? 18u : 0u;
     // one 1024-thread workgroup per CU (128 VGPRs per lane), so the whole LDS is its own
     const uint64_t fixed = mrg::fused_fixed_lds_bytes();
     const uint64_t lds_cap = 160 * 1024;
-    const uint64_t budget = lds_cap - fixed;
-    for (;;) {
-      uint64_t tot = 0;
-      for (uint32_t q = 0; q < n_sub; ++q) tot += lg[q] ? (1ull << lg[q]) / 8 : 0;
-      if (tot <= budget) break;
-      int pick = -1;
-      double best_fill = 0;
-      for (uint32_t q = 0; q < n_sub; ++q) {
-        if (lg[q] <= 13u) continue;
-        const double fill = (double)ctx->libs[passes[members[q]].lib].n / (double)(1ull << lg[q]);
-        if (pick < 0 || fill < best_fill) {
-          pick = (int)q;
-          best_fill = fill;
-        }
-      }
-      if (pick < 0) {  // everything at the minimum and still too large: drop the emptiest filter
-        for (uint32_t q = 0; q < n_sub; ++q)
-          if (lg[q]) pick = (int)q;
-        if (pick < 0) break;
-        lg[pick] = 0;
-        continue;
-      }
-      --lg[pick];
+    const uint64_t budget = std::min<uint64_t>((uint64_t)std::max<int64_t>(ctx->lds_budget, (int64_t)fixed), lds_cap) - fixed;
+    // rounds: the sub-passes of a run of bitmap-filtered libraries are looked up together (few
+    // items per read), with "round_large" = 1 so are those of a run of large ones (measured equal,
+    // default 0: every unclaimed read has items in each of them)
+    fp.n_rounds = 0;
+    for (uint32_t q = 0; q < n_sub;) {
+      uint32_t e = q + 1;
+      if (lg[q] || ctx->round_large)
+        while (e < n_sub && (lg[e] != 0) == (lg[q] != 0) && e - q < mrg::kMaxRoundSubs) ++e;
+      fp.round_first[fp.n_rounds] = (uint8_t)q;
+      fp.round_count[fp.n_rounds] = (uint8_t)(e - q);
+      ++fp.n_rounds;
+      q = e;
     }
+    // the 9-mer table of each bitmap round: one entry per code with a bit per sub-pass, as many
+    // codes (2^18 = every 9-mer, else folded: entry h = OR of the codes = h mod 2^log2) as the LDS
+    // left by the other rounds' tables allows
+    uint32_t n_tab_rounds = 0;
+    for (uint32_t r = 0; r < fp.n_rounds; ++r) n_tab_rounds += lg[fp.round_first[r]] ? 1u : 0u;
     uint32_t kb_words = 0;
     for (uint32_t q = 0; q < n_sub; ++q) {
       const uint32_t i = members[q];
@@ -756,17 +755,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
       sp.n = l.n;
       sp.primary = l.primary;
       sp.simple_segs = l.simple ? 1u : 0u;
-      sp.kb_off = kb_words;
-      sp.kb_mask = lg[q] ? (1u << lg[q]) - 1u : 0u;
-      if (lg[q] == 18u) {
-        sp.kbits = l.kbits;
-      } else if (lg[q]) {
-        // folds are stored 2^17 first: word offset of the 2^lg fold
-        uint32_t off = 0;
-        for (uint32_t g = 17; g > lg[q]; --g) off += (1u << g) / 32u;
-        sp.kbits = l.kbits_folds + off;
-      }
-      kb_words += lg[q] ? (1u << lg[q]) / 32u : 0u;
+      sp.kb_bit = 0xFFu;
       sp.wide_rows = l.ctx ? (uint32_t)std::min<int64_t>(ctx->wide_rows, ctx->ctx_wide_rows) : (uint32_t)ctx->wide_rows;
       sp.seed_len = c.seed_len;
       sp.max_mm_seed = c.max_mm_seed;
@@ -777,10 +766,56 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
       sp.max_len = c.max_len;
       sp.poly_t = c.poly_t;
       sp.pass_index = (int32_t)i;
-      ctx->last_lds[i] = lg[q] ? (1u << lg[q]) / 8u : 0u;
+      ctx->last_lds[i] = 0u;
       ctx->last_mode[i] = 4u;
       ctx->last_group[i] = members[0];
-      ctx->last_kbits_log2[i] = lg[q];
+      ctx->last_kbits_log2[i] = 0u;
+    }
+    for (uint32_t r = 0; r < fp.n_rounds; ++r) {
+      const uint32_t q0 = fp.round_first[r], nq = fp.round_count[r];
+      fp.round_kb_log2[r] = 0;
+      fp.round_kb_bits[r] = 0;
+      fp.round_kb_off[r] = 0;
+      fp.round_kb_src[r] = nullptr;
+      if (!lg[q0]) continue;
+      const uint32_t bits = nq <= 4 ? 4u : 8u;
+      uint32_t log2c = 18;
+      while (log2c > 13 && ((uint64_t)(1u << log2c) * bits / 8) * n_tab_rounds > budget) --log2c;
+      if (((uint64_t)(1u << log2c) * bits / 8) * n_tab_rounds > budget) {  // no room: unfiltered
+        for (uint32_t q = q0; q < q0 + nq; ++q) ctx->last_kbits_log2[members[q]] = 255u;
+        continue;
+      }
+      std::string key;
+      for (uint32_t q = q0; q < q0 + nq; ++q) key += std::to_string(passes[members[q]].lib) + ",";
+      key += "|" + std::to_string(log2c) + "|" + std::to_string(bits);
+      uint32_t* d_tab = nullptr;
+      for (auto& kv : ctx->round_tables)
+        if (kv.first == key) d_tab = kv.second;
+      if (!d_tab) {
+        std::vector<uint32_t> tab(((size_t)1 << log2c) * bits / 32, 0u);
+        for (uint32_t q = q0; q < q0 + nq; ++q) {
+          const std::vector<uint32_t>& kbh = ctx->libs[passes[members[q]].lib].kbits_host;
+          for (uint32_t c = 0; c < (1u << 18); ++c) {
+            if (!((kbh[c >> 5] >> (c & 31u)) & 1u)) continue;
+            const uint64_t bit = (uint64_t)(c & ((1u << log2c) - 1u)) * bits + (q - q0);
+            tab[bit >> 5] |= 1u << (bit & 31u);
+          }
+        }
+        HIP_TRY(hipMalloc((void**)&d_tab, tab.size() * 4));
+        HIP_TRY(hipMemcpy(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+        ctx->round_tables.emplace_back(key, d_tab);
+      }
+      fp.round_kb_src[r] = d_tab;
+      fp.round_kb_off[r] = kb_words;
+      fp.round_kb_log2[r] = (uint8_t)log2c;
+      fp.round_kb_bits[r] = (uint8_t)bits;
+      const uint32_t words = (uint32_t)(((size_t)1 << log2c) * bits / 32);
+      kb_words += words;
+      for (uint32_t q = q0; q < q0 + nq; ++q) {
+        fp.sub[q].kb_bit = q - q0;
+        ctx->last_lds[members[q]] = words * 4u / nq;
+        ctx->last_kbits_log2[members[q]] = log2c;
+      }
     }
     fp.kb_words = kb_words;
     fp.reads = d_reads;
@@ -800,20 +835,6 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     fp.pos = d_pos;
     fp.mm = d_mm;
     fp.wstop = (uint32_t)ctx->wstop;
-    // rounds: the sub-passes of a run of bitmap-filtered libraries are looked up together (few
-    // items per read), with "round_large" = 1 so are those of a run of large ones (measured equal, default 0: every unclaimed
-    // read has items in each of them, but few reads are claimed in between, so little of the
-    // speculative work is wasted and the dependent jump-table -> row trips of the libraries overlap)
-    fp.n_rounds = 0;
-    for (uint32_t q = 0; q < n_sub;) {
-      uint32_t e = q + 1;
-      if (lg[q] || ctx->round_large)
-        while (e < n_sub && (lg[e] != 0) == (lg[q] != 0) && e - q < mrg::kMaxRoundSubs) ++e;
-      fp.round_first[fp.n_rounds] = (uint8_t)q;
-      fp.round_count[fp.n_rounds] = (uint8_t)(e - q);
-      ++fp.n_rounds;
-      q = e;
-    }
     const uint32_t lds_total = kb_words * 4u + (uint32_t)fixed;
     // 128 VGPRs per lane (no spills in the pipelined walk): 16 waves = one workgroup per CU
     const uint32_t per_cu = 1u;

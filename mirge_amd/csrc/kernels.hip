@@ -728,12 +728,6 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
   uint32_t* ctl = reinterpret_cast<uint32_t*>(cnt64 + kMaxFused * 3u * kFusedCntReplicas);
   for (uint32_t s = 0; s < p.n_sub; ++s) {
     const SubPass& sp = p.sub[s];
-    if (sp.kb_mask) {
-      const uint4* src = reinterpret_cast<const uint4*>(sp.kbits);
-      uint4* dst = reinterpret_cast<uint4*>(skb + sp.kb_off);
-      const uint32_t n16 = (sp.kb_mask + 1u) / 128u;
-      for (uint32_t i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
-    }
     if (sp.text_lds_words) {
       const uint4* src = reinterpret_cast<const uint4*>(sp.text);
       uint4* dst = reinterpret_cast<uint4*>(smem + sp.text_lds_off);
@@ -768,6 +762,13 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
       t[SW_SIMPLE] = sp.simple_segs;
       t[SW_PASSIDX] = (uint32_t)sp.pass_index;
     }
+  }
+  for (uint32_t rnd = 0; rnd < p.n_rounds; ++rnd) {
+    if (!p.round_kb_log2[rnd]) continue;
+    const uint4* src = reinterpret_cast<const uint4*>(p.round_kb_src[rnd]);
+    uint4* dst = reinterpret_cast<uint4*>(skb + p.round_kb_off[rnd]);
+    const uint32_t n16 = ((1u << p.round_kb_log2[rnd]) * (uint32_t)p.round_kb_bits[rnd]) / 128u;
+    for (uint32_t i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
   }
   for (uint32_t i = threadIdx.x; i < kMaxFused * 3u * kFusedCntReplicas; i += BLOCK) cnt64[i] = 0ull;
   if (threadIdx.x == 0) {
@@ -847,15 +848,21 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
     act_c = fetch_index(chunk + 2u * gridDim.x, r_c);
 
     bool claimed = !active;  // lanes without a read never take part
-    // piece geometry of the current search region (R bases, K pieces, 5' trim), reused by every
-    // sub-pass that searches the same region: for reads of at most 28 nt all the -n 1 / -v 1
-    // passes do
-    int32_t g_R = -1, g_K = 0, g_t5 = -1;
-    uint32_t g_code[4] = {0u, 0u, 0u, 0u};  // [2k] first, [2k + 1] last 9-mer of piece k
-    uint32_t g_meta = 0;                    // piece length k at bits 8k, "piece k holds an N" at bit 16 + k
+    // What the filter phase knows about the current search region (R bases after a 5' trim of t5),
+    // computed once and reused by every sub-pass that searches the same region -- for reads of at
+    // most 28 nt that is all the -n 1 / -v 1 / -n 0 passes: per piece (the two halves, and the
+    // whole region for one-piece policies) which libraries of the round can hold it, as a bit per
+    // sub-pass (first-9 and last-9 tests in the round's interleaved table, pieces of < 9 bases
+    // pass, a piece holding an N never matches), and the same without any table.
+    int32_t g_R = -1, g_t5 = -1;
+    uint32_t g_pm = 0;   // bits 0-7 piece 0 of two, 8-15 piece 1 of two, 16-23 the whole region
+    uint32_t g_nn = 0;   // bit 0 / 8 / 16: that piece holds no N (sub-passes without a table)
 #pragma unroll 1
     for (uint32_t rnd = 0; rnd < p.n_rounds; ++rnd) {
       const uint32_t s0 = p.round_first[rnd], ns = p.round_count[rnd];
+      const uint32_t kb_log2 = p.round_kb_log2[rnd], kb_bits = p.round_kb_bits[rnd];
+      const uint32_t* kb = skb + p.round_kb_off[rnd];
+      g_R = -1;  // the library bits belong to one round's table
       // ================= phase A: which (sub-pass, piece) items does my read need? =================
       uint32_t need = 0;   // bit 2q + k: piece k of sub-pass s0 + q goes to the index
       uint32_t elig = 0;   // bit q: my read is in sub-pass s0 + q's FASTA if nothing claims it before
@@ -871,9 +878,9 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
         }
         L -= sp.trim5 + sp.trim3;
         if (el) elig |= 1u << q;
-        const int32_t R = min(L, sp.seed_len), K = sp.max_mm_seed + 1;
+        const int32_t R = min(L, sp.seed_len);
         const bool go = el && L > sp.max_mm_seed;
-        if (go && (R != g_R || K != g_K || sp.trim5 != g_t5)) {
+        if (go && (R != g_R || sp.trim5 != g_t5)) {
           uint64_t rd[W], nm[W];
 #pragma unroll
           for (int k = 0; k < W; ++k) {
@@ -885,34 +892,37 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
             if (has_nm) shift_out_5p<W>(nm, (uint32_t)sp.trim5);
           }
           g_R = R;
-          g_K = K;
           g_t5 = sp.trim5;
-          g_meta = 0;
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            if (k < K) {
-              const int32_t a = div_pieces(R * k, K), b = div_pieces(R * (k + 1), K);
-              g_meta |= (uint32_t)min(b - a, 255) << (8 * k);
-              if (has_nm && piece_has_n<W>(nm, a, b)) g_meta |= 1u << (16 + k);
-              if (b - a >= (int32_t)kKmerBitsK) {
-                g_code[2 * k] = read_bits9<W>(rd, (uint32_t)a);
-                g_code[2 * k + 1] = read_bits9<W>(rd, (uint32_t)b - kKmerBitsK);
-              }
+          const int32_t h = R >> 1;  // pieces [0, h), [h, R) and the whole [0, R)
+          const bool n0 = has_nm && piece_has_n<W>(nm, 0, h), n1 = has_nm && piece_has_n<W>(nm, h, R);
+          g_nn = (n0 ? 0u : 1u) | (n1 ? 0u : 1u << 8) | ((n0 || n1) ? 0u : 1u << 16);
+          uint32_t mF = 0xFFu, mL = 0xFFu, m0L = 0xFFu, m1F = 0xFFu;
+          if (kb_log2) {
+            const uint32_t cmask = (1u << kb_log2) - 1u, emask = (1u << kb_bits) - 1u;
+            auto libs_of = [&](uint32_t at) {
+              const uint32_t bit = (read_bits9<W>(rd, at) & cmask) * kb_bits;
+              return (kb[bit >> 5] >> (bit & 31u)) & emask;
+            };
+            if (R >= (int32_t)kKmerBitsK) {
+              mF = libs_of(0u);
+              mL = libs_of((uint32_t)R - kKmerBitsK);
             }
+            if (h >= (int32_t)kKmerBitsK) m0L = libs_of((uint32_t)h - kKmerBitsK);
+            if (R - h >= (int32_t)kKmerBitsK) m1F = libs_of((uint32_t)h);
           }
+          const int32_t k9 = (int32_t)kKmerBitsK;
+          const uint32_t P0 = h < k9 ? 0xFFu : (m0L & (h == k9 ? 0xFFu : mF));
+          const uint32_t P1 = (R - h) < k9 ? 0xFFu : (mL & ((R - h) == k9 ? 0xFFu : m1F));
+          const uint32_t Pw = R < k9 ? 0xFFu : (mL & (R == k9 ? 0xFFu : mF));
+          g_pm = (n0 ? 0u : P0) | ((n1 ? 0u : P1) << 8) | (((n0 || n1) ? 0u : Pw) << 16);
         }
-        const uint32_t* kb = skb + sp.kb_off;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const uint32_t plen = (g_meta >> (8 * k)) & 0xFFu;
-          bool pass = go && k < K && ((g_meta >> (16 + k)) & 1u) == 0u;
-          if (sp.kb_mask) {
-            const uint32_t cl = g_code[2 * k + 1] & sp.kb_mask, cf = g_code[2 * k] & sp.kb_mask;
-            const uint32_t bl = (kb[cl >> 5] >> (cl & 31u)) & 1u, bf = (kb[cf >> 5] >> (cf & 31u)) & 1u;
-            const bool filt = plen < kKmerBitsK || (bl && (plen == kKmerBitsK || bf));
-            pass = pass && filt;
-          }
-          need |= (pass ? 1u : 0u) << (2u * q + (uint32_t)k);
+        // this sub-pass's view: bit 0 / 8 / 16 = piece 0 / piece 1 / whole region goes to the index
+        const uint32_t m = sp.kb_bit != 0xFFu ? (g_pm >> sp.kb_bit) : g_nn;
+        const uint32_t gb = go ? 1u : 0u;
+        if (sp.max_mm_seed == 0) {
+          need |= (gb & (m >> 16)) << (2u * q);
+        } else {
+          need |= ((gb & m) | ((gb & (m >> 8)) << 1)) << (2u * q);
         }
       }
 

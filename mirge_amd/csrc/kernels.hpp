@@ -89,7 +89,7 @@ struct SubPass {
   const uint32_t* ctx;    // row context of a large library (null otherwise)
   const uint4* sa16;      // wide rows of a large library (null otherwise): row, 16 bases left, 16 bases from +8
   const uint32_t* ftab;
-  const uint32_t* kbits;  // folded 9-mer bitmap to stage (null = no filter)
+  const uint32_t* kbits;  // (unused by fused launches: the round's interleaved table is staged instead)
   const uint32_t* seg_start;
   const uint32_t* seg_ref;
   const uint32_t* seg_off;
@@ -100,8 +100,8 @@ struct SubPass {
   uint32_t n, primary, simple_segs;
   uint32_t text_lds_off;    // LDS word offset of the staged packed text (when text_lds_words != 0)
   uint32_t text_lds_words;  // 0 = the text is read from L2/HBM
-  uint32_t kb_off;   // word offset of the staged bitmap in LDS
-  uint32_t kb_mask;  // bits - 1 of the folded bitmap (bit index = 9-mer code & kb_mask); 0 = none
+  uint32_t kb_bit;   // this sub-pass's bit in the entries of its round's 9-mer table; 0xFF = no filter
+  uint32_t kb_pad;
   uint32_t wide_rows;
   int32_t seed_len, max_mm_seed, max_mm_total, trim5, trim3, min_len, max_len, poly_t;
   int32_t pass_index;
@@ -132,6 +132,12 @@ struct FusedParams {
   // sub-passes of the run; the owner replays the results in cascade order)
   uint32_t n_rounds;
   uint8_t round_first[kMaxFused], round_count[kMaxFused];
+  // 9-mer table of a round of bitmap-filtered sub-passes: entry c (code & (2^log2 - 1)) holds one bit
+  // per sub-pass of the round ("this library has a 9-mer with that code"), `bits` (4 or 8) bits per
+  // entry, so ONE LDS read answers a 9-mer for every library of the round.  log2 == 0: no table.
+  const uint32_t* round_kb_src[kMaxFused];
+  uint32_t round_kb_off[kMaxFused];   // LDS word offset
+  uint8_t round_kb_log2[kMaxFused], round_kb_bits[kMaxFused];
 };
 
 // LDS bytes of a fused launch besides the bitmaps: sub-pass table + one 16-byte result slot per

@@ -219,7 +219,7 @@ def fm_cascade(lib_views, passes, reads, lens, nmask=None, wstop=0, threads=None
         for k, _ in _OrcPass._fields_:
             setattr(ps[i], k, int(p.get(k, 0)))
         lg = int(p.get("kbits_log2", 0))
-        ps[i].reserved = lg if 13 <= lg < 18 else 0
+        ps[i].reserved = lg if (13 <= lg < 18 or lg == 255) else 0   # 255 = this pass ran unfiltered
     pass_id = np.empty(n, dtype=np.int8)
     ref_id = np.empty(n, dtype=np.int32)
     pos = np.empty(n, dtype=np.int32)
