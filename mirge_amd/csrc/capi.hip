@@ -148,6 +148,7 @@ struct mrg_ctx {
   // library size; 3 = only the small-library runs are fused
   int64_t fuse = 1;
   int64_t round_large = 0;
+  int64_t split_strata = 1;
   int64_t wide_rows_16 = 1;  // libraries of >= 2^20 bases get 16-byte rows with 32 bases of context
   std::vector<DevLib> libs;
   // last run
@@ -476,6 +477,8 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->force_lds_mode = value;
   } else if (k == "ftab") {
     ctx->use_ftab = value != 0;
+  } else if (k == "split_strata") {
+    ctx->split_strata = value != 0;
   } else if (k == "round_large") {
     ctx->round_large = value != 0;
   } else if (k == "wide_rows_16") {
@@ -585,7 +588,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
   auto small_lib = [&](uint32_t i) { return ctx->libs[passes[i].lib].kbits != nullptr && ctx->kmer_filter; };
 
   // the classic path: one match_kernel launch for pass i
-  auto run_single = [&](uint32_t i) -> int {
+  auto run_single = [&](uint32_t i, int32_t k_first, int32_t k_last, bool first_part, bool last_part) -> int {
     const mrg_pass_cfg& c = passes[i];
     const DevLib& l = ctx->libs[c.lib];
     mrg::MatchParams p;
@@ -616,7 +619,10 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     p.in_count = counts + cur_list * mrg::kMaxSegments;
     p.in_nseg = prev_grid;
     p.in_seg_cap = prev_seg_cap;
-    p.idx_out = (i + 1 < n_pass) ? idx[next_list] : nullptr;
+    p.idx_out = (i + 1 < n_pass || !last_part) ? idx[next_list] : nullptr;
+    p.k_first = k_first;
+    p.k_last = k_last;
+    p.count_processed = first_part ? 1u : 0u;
     p.out_count = counts + next_list * mrg::kMaxSegments;
     p.pass_id = d_pass_id;
     p.ref_id = d_ref_id;
@@ -691,7 +697,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     ctx->last_group[i] = i;
     ctx->last_kbits_log2[i] = use_kbits ? 18u : 0u;
     if (n) HIP_TRY(mrg::launch_match(p, words_per_read, lds_mode, grid, lds_total, stream));
-    HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
+    if (last_part) HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
     if (p.idx_out) {
       cur_list = next_list;
       have_list = true;
@@ -886,7 +892,15 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
         if (!runs[q]) HIP_TRY(hipEventRecord(ctx->ev[q + 1], stream));
       i = j;
     } else {
-      int rc = run_single(i);
+      const int32_t kfull = passes[i].max_mm_seed + 1;
+      int rc;
+      if (passes[i].max_mm_seed == 2 && ctx->split_strata) {
+        // strata 1..2 on the incoming reads, stratum 3 on the compacted survivors (kernels.hpp)
+        rc = run_single(i, 1, 2, true, false);
+        if (rc == MRG_OK) rc = run_single(i, 3, 3, false, true);
+      } else {
+        rc = run_single(i, 1, kfull, true, true);
+      }
       if (rc != MRG_OK) return rc;
       ++i;
     }

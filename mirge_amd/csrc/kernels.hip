@@ -346,7 +346,7 @@ match_kernel(const MatchParams p) {
     L -= p.trim5 + p.trim3;
     shift_out_5p<W>(rd, (uint32_t)p.trim5);
     if (p.nmask) shift_out_5p<W>(nm, (uint32_t)p.trim5);
-    if (eligible) ++c_processed;
+    if (eligible && p.count_processed) ++c_processed;
 
     uint64_t best = ~0ull;  // (mm << 32) | text position
     uint32_t best_seg = 0xFFFFu, best_before = 255u;
@@ -358,7 +358,7 @@ match_kernel(const MatchParams p) {
       // yields a best hit below its own bound, that hit is final and the 3-piece search -- ~15
       // candidates per 6-base piece -- is not run.  Most isomiRs are exact or 1-mismatch matches
       // of the flanked library entry.
-      for (int32_t K = (STRATA ? 1 : Kfull); K <= Kfull; ++K) {
+      for (int32_t K = (STRATA ? p.k_first : Kfull); K <= (STRATA ? p.k_last : Kfull); ++K) {
       for (int32_t k = 0; k < K; ++k) {
         const int32_t a = div_pieces(R * k, K), b = div_pieces(R * (k + 1), K);
         if (p.nmask) {
@@ -486,7 +486,9 @@ match_kernel(const MatchParams p) {
       }
     }
 
-    const bool aligned = best != ~0ull;
+    // (a launch that stops before the last stratum keeps a hit only if it is final: fewer
+    // mismatches than the strata searched so far guarantee to have found)
+    const bool aligned = best != ~0ull && (!STRATA || p.k_last > p.max_mm_seed || (int32_t)(best >> 32) < p.k_last);
     if (aligned) {
       ++c_aligned;
       const uint32_t s = (uint32_t)best;

@@ -67,6 +67,14 @@ struct MatchParams {
   int32_t pass_index;
   uint32_t wstop;
   uint32_t wide_rows;  // seed intervals wider than this are verified by the whole wave
+  // STRATA launches only: the strata [k_first, k_last] (piece counts) this launch searches.  A
+  // 2-mismatch pass is split into two launches: strata 1..2 over the incoming reads (a best hit
+  // with fewer than 2 mismatches is final, everything else survives) and stratum 3 over the
+  // COMPACTED survivors -- the three-piece search finds every alignment with <= 2 mismatches on
+  // its own, so nothing has to be carried over, and its ~45 candidates per read are verified with
+  // every lane holding a read instead of the 45 % that reach that stratum.
+  int32_t k_first, k_last;
+  uint32_t count_processed;  // 0: the launch continues a pass whose reads were counted already
 };
 
 // ---------------------------------------------------------------------------
