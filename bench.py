@@ -80,7 +80,7 @@ def launch_table(st, per_pass_ms, table, index, W):
         if s["group"] != i and launches and launches[-1]["first"] == s["group"]:
             L = launches[-1]
         else:
-            L = dict(first=i, passes=[], ms=0.0, processed=0, steps=0, ext=0.0,
+            L = dict(first=i, passes=[], ms=0.0, processed=0, steps=0, ext=0.0, n=max(1, s.get("n_launches", 1)),
                      kernel=kernel_name(W, table[i], s, index[table[i][0]].info.n_bases))
             launches.append(L)
         L["passes"].append(i)
@@ -261,7 +261,7 @@ def main():
         g["ms"] += L["ms"]
         g["sbytes"] += survey_bytes(L["processed"], L["steps"])
         g["ext"] += L["ext"]
-        g["launches"] += 1
+        g["launches"] += L["n"]
         g["passes"] += L["passes"]
         g["processed"] += L["processed"]
     dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
@@ -301,7 +301,7 @@ def main():
             lib=table[i][0], ms=round(float(per_pass_ms[i]), 4), processed=s["processed"], aligned=s["aligned"],
             steps=s["steps"], candidates=s["candidates"], lookups=s["lookups"], lds_bytes=s["lds_bytes"],
             kernel="not launched" if L is None else L["kernel"].replace("mrg::", ""),
-            launch=None if L is None else L["first"], kbits_log2=s["kbits_log2"],
+            launch=None if L is None else L["first"], n_launches=s["n_launches"], kbits_log2=s["kbits_log2"],
             compulsory_floor_ms=round(16.0 * s["processed"] / (HBM_ACHIEVABLE_GBS * 1e6), 4)))
 
     # ---- parity gates + CPU baseline (rank 0, N = 1 only) ----

@@ -184,6 +184,9 @@ typedef struct mrg_pass_stats {
                           inside a fused launch (fused_kernel<W>, only its 9-mer bitmap in LDS) */
   uint32_t group;      /* index of the first pass of the launch this pass ran in (itself when it
                           had a launch of its own) */
+  uint32_t n_launches; /* kernel launches that carried this pass: 1, or 2 for a 2-mismatch pass split
+                          into strata 1-2 and stratum 3; 0 for a pass that was not launched or rode
+                          in the fused launch of its group's first pass */
   uint32_t kbits_log2; /* log2 of the bits of the 9-mer presence bitmap the pass filtered seed
                           pieces with (18 = the library's full bitmap, 13..17 = folded for a
                           fused launch, 0 = no filter) */

@@ -158,6 +158,7 @@ struct mrg_ctx {
   uint32_t last_lds[MRG_MAX_PASSES] = {0};
   uint32_t last_mode[MRG_MAX_PASSES] = {0};
   uint32_t last_group[MRG_MAX_PASSES] = {0};
+  uint32_t last_launches[MRG_MAX_PASSES] = {0};
   uint32_t last_kbits_log2[MRG_MAX_PASSES] = {0};
   hipEvent_t ev[MRG_MAX_PASSES + 1] = {nullptr};
   bool ev_ready = false;
@@ -576,6 +577,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     ctx->last_lds[i] = 0;
     ctx->last_mode[i] = 0;
     ctx->last_group[i] = i;
+    ctx->last_launches[i] = 0;
     ctx->last_kbits_log2[i] = 0;
   }
   auto fusable = [&](uint32_t i) {
@@ -697,6 +699,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     ctx->last_group[i] = i;
     ctx->last_kbits_log2[i] = use_kbits ? 18u : 0u;
     if (n) HIP_TRY(mrg::launch_match(p, words_per_read, lds_mode, grid, lds_total, stream));
+    ctx->last_launches[i] += 1;
     if (last_part) HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
     if (p.idx_out) {
       cur_list = next_list;
@@ -849,6 +852,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     const uint32_t seg_cap = (uint32_t)(((n + 1024ull * grid - 1) / (1024ull * grid)) * 1024ull);
     fp.out_seg_cap = seg_cap;
     if (n) HIP_TRY(mrg::launch_fused(fp, words_per_read, grid, lds_total, stream));
+    ctx->last_launches[members[0]] = 1;
     for (uint32_t q = 0; q < n_sub; ++q) HIP_TRY(hipEventRecord(ctx->ev[members[q] + 1], stream));
     if (fp.idx_out) {
       cur_list = next_list;
@@ -944,6 +948,7 @@ int mrg_cascade_stats(mrg_ctx* ctx, mrg_pass_stats* out, uint32_t n_pass) {
     out[i].lds_bytes = ctx->last_lds[i];
     out[i].lds_mode = ctx->last_mode[i];
     out[i].group = ctx->last_group[i];
+    out[i].n_launches = ctx->last_launches[i];
     out[i].kbits_log2 = ctx->last_kbits_log2[i];
   }
   return MRG_OK;

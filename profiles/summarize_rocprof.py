@@ -58,8 +58,12 @@ def label_dispatches(keys, bench):
     for i, p in enumerate(bench["passes"]):
         if p.get("launch") is None:
             continue
-        launches.setdefault(p["launch"], []).append((i, p["lib"], "mrg::" + p["kernel"]))
-    plan = list(launches.values())
+        launches.setdefault(p["launch"], []).append((i, p["lib"], "mrg::" + p["kernel"], p.get("n_launches", 1)))
+    plan = []
+    for g in launches.values():   # a 2-mismatch pass split into two launches appears twice
+        n = max(1, g[0][3])
+        for part in range(n):
+            plan.append([(x[0], x[1] + (" part %d/%d" % (part + 1, n) if n > 1 else ""), x[2]) for x in g])
     out, at = {}, 0
     for k in keys:
         if "match_kernel" not in k[1] and "fused_kernel" not in k[1]:
