@@ -55,9 +55,6 @@ struct DevLib {
   uint32_t* ctx = nullptr;
   uint32_t* sa16 = nullptr;  // wide rows of a large library (fm_index.hpp: fill_wide_rows)
   uint32_t* kbits = nullptr;
-  // the 9-mer bitmap folded to 2^17 .. 2^13 bits (bit h = OR of the 9-mers with code & (bits - 1) == h),
-  // one allocation, for fused launches whose LDS cannot hold every library's full bitmap
-  uint32_t* kbits_folds = nullptr;
   std::vector<uint32_t> kbits_host;  // host copy (32 KB): the per-round interleaved tables are built from it
   uint32_t* ftab = nullptr;
   mrg::JumpTables tabs = {{0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -351,7 +348,6 @@ void mrg_ctx_destroy(mrg_ctx* ctx) {
     (void)hipFree(l.ctx);
     (void)hipFree(l.sa16);
     (void)hipFree(l.kbits);
-    (void)hipFree(l.kbits_folds);
     (void)hipFree(l.seg_start);
     (void)hipFree(l.seg_ref);
     (void)hipFree(l.seg_off);
@@ -374,7 +370,7 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
     DevLib* l;
     ~Guard() {
       if (!l) return;
-      void* ptrs[] = {l->blocks, l->super, l->text, l->sa, l->ftab, l->ctx, l->sa16, l->kbits, l->kbits_folds,
+      void* ptrs[] = {l->blocks, l->super, l->text, l->sa, l->ftab, l->ctx, l->sa16, l->kbits,
                       l->seg_start, l->seg_ref, l->seg_off, l->chunk_seg};
       for (void* p : ptrs) (void)hipFree(p);
     }
@@ -428,18 +424,7 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
     }
   }
   if (!ix.kbits.empty() && (rc = upload(&l.kbits, ix.kbits))) return rc;
-  l.kbits_host = ix.kbits;
-  if (!ix.kbits.empty()) {
-    // folds of 2^17, 2^16, ... 2^13 bits back to back (word offsets: see fold_offset_words)
-    std::vector<uint32_t> folds, cur = ix.kbits;
-    for (int lg = 17; lg >= 13; --lg) {
-      std::vector<uint32_t> half(cur.size() / 2);
-      for (size_t i = 0; i < half.size(); ++i) half[i] = cur[i] | cur[i + half.size()];
-      folds.insert(folds.end(), half.begin(), half.end());
-      cur.swap(half);
-    }
-    if ((rc = upload(&l.kbits_folds, folds))) return rc;
-  }
+  l.kbits_host = ix.kbits;  // the interleaved tables of fused rounds are built from it
   if ((rc = upload(&l.seg_start, ix.seg_start))) return rc;
   if ((rc = upload(&l.seg_ref, ix.seg_ref))) return rc;
   if ((rc = upload(&l.seg_off, ix.seg_off))) return rc;
@@ -765,7 +750,6 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
       sp.primary = l.primary;
       sp.simple_segs = l.simple ? 1u : 0u;
       sp.kb_bit = 0xFFu;
-      sp.wide_rows = l.ctx ? (uint32_t)std::min<int64_t>(ctx->wide_rows, ctx->ctx_wide_rows) : (uint32_t)ctx->wide_rows;
       sp.seed_len = c.seed_len;
       sp.max_mm_seed = c.max_mm_seed;
       sp.max_mm_total = c.max_mm_total;

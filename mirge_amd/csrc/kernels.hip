@@ -571,9 +571,10 @@ match_kernel(const MatchParams p) {
 //   reads  the walk happens once per group and is software-pipelined two chunks deep;
 //   items  a ROUND = a run of sub-passes (all the bitmap-filtered ones together, each large
 //          library on its own).  Every lane first runs the cheap part of all sub-passes of the
-//          round on its read -- length window, poly-T rule, piece geometry (cached while the
-//          search region does not change), 9-mer bitmap tests in LDS -- and ends up with a bit
-//          mask of (sub-pass, piece) WORK ITEMS that need the index.  The items of the 64 reads
+//          round on its read -- length window, poly-T rule, and per search region (computed once
+//          and reused while it does not change) which libraries can hold each piece, from four
+//          LDS reads of the round's 9-mer table -- and ends up with a bit mask of (sub-pass,
+//          piece) WORK ITEMS that need the index.  The items of the 64 reads
 //          of a wave are compacted (wave prefix sum, owner found by a six-step search over the
 //          prefix): lane i takes item i, fetches the owner's read with a shuffle and that
 //          sub-pass's library pointers from an LDS table, and does the jump-table load and the
@@ -587,8 +588,9 @@ match_kernel(const MatchParams p) {
 // ones, an exact hit of piece 0 hides piece 1 -- exactly the items the sequential search would not
 // have issued, so the per-pass processed / aligned / steps / candidates / lookups counters stay
 // those of one launch per pass although the work itself was speculative.
-// Libraries are served from L2/HBM (a small one's packed text optionally from LDS); LDS holds the
-// folded 9-mer bitmaps, the sub-pass table, the result slots and the per-pass counters.  128
+// Libraries are served from L2/HBM (a small one's packed text optionally from LDS); LDS holds per
+// round one interleaved 9-mer table ("which libraries of the round have a 9-mer with this code":
+// one read answers a 9-mer for all of them), the sub-pass table, the result slots and the counters.  128
 // VGPRs per lane (16 waves = one 1024-thread workgroup per CU): the pipelined walk and the
 // per-lane library pointers do not fit 64 without spilling, and with dense lanes 16 waves keep
 // more useful loads in flight than 32 sparse ones.

@@ -97,7 +97,6 @@ struct SubPass {
   const uint32_t* ctx;    // row context of a large library (null otherwise)
   const uint4* sa16;      // wide rows of a large library (null otherwise): row, 16 bases left, 16 bases from +8
   const uint32_t* ftab;
-  const uint32_t* kbits;  // (unused by fused launches: the round's interleaved table is staged instead)
   const uint32_t* seg_start;
   const uint32_t* seg_ref;
   const uint32_t* seg_off;
@@ -109,8 +108,6 @@ struct SubPass {
   uint32_t text_lds_off;    // LDS word offset of the staged packed text (when text_lds_words != 0)
   uint32_t text_lds_words;  // 0 = the text is read from L2/HBM
   uint32_t kb_bit;   // this sub-pass's bit in the entries of its round's 9-mer table; 0xFF = no filter
-  uint32_t kb_pad;
-  uint32_t wide_rows;
   int32_t seed_len, max_mm_seed, max_mm_total, trim5, trim3, min_len, max_len, poly_t;
   int32_t pass_index;
 };
