@@ -29,8 +29,10 @@ constexpr uint64_t kOdd = 0x5555555555555555ull;
 // suffix-array rows loaded together in the candidate loop: 4 when the text windows come from LDS,
 // 8 when they are HBM/L2 loads themselves (more of them in flight; measured: pass 6 -0.1 ms, the
 // LDS-text passes +5 % with 8)
-template <bool LDST>
+template <bool LDST, bool STRATA>
 struct RowsPerTrip {
+  // (two per trip for the non-STRATA LDS-text passes, whose searches mostly end in 0-2 rows, was
+  // measured: pass 0 1.18 -> 1.43 ms -- the second trip of a paralog tie costs a full L2 latency)
   static constexpr uint32_t value = LDST ? 4u : 8u;
 };
 
@@ -424,7 +426,7 @@ match_kernel(const MatchParams p) {
         const bool wide = width > p.wide_rows;
         if (!wide) {
           // four suffix-array rows per trip: they mostly share a cache line and their loads overlap
-          constexpr uint32_t kRowsPerTrip = RowsPerTrip<LDST>::value;
+          constexpr uint32_t kRowsPerTrip = RowsPerTrip<LDST, STRATA>::value;
           for (uint32_t i = lo; i < hi; i += kRowsPerTrip) {
             uint64_t rows[kRowsPerTrip];
 #pragma unroll
