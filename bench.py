@@ -62,6 +62,8 @@ def kernel_name(W, table_row, s, n_bases):
     """The instantiation rocprofv3 names for the launch pass `s` ran in."""
     if s["lds_mode"] == 4:
         return "mrg::fused_kernel<%d>" % W
+    if s["lds_mode"] in (5, 6):
+        return "mrg::stratum_kernel<%d>" % W
     has_ctx = n_bases >= (1 << 20) and s["lds_mode"] in (0, 1)
     return "mrg::match_kernel<%d, %s, %s, %s, %s>" % (
         W, {0: "false, false", 1: "true, false", 2: "true, true", 3: "false, true"}[s["lds_mode"]],
@@ -313,7 +315,7 @@ def main():
         got = [t.cpu().numpy() for t in out[:4]]
         counts_gpu = fused[:ln].cpu().numpy().astype(np.uint64)
         pd = [dict(lib=keys.index(k), min_len=a, max_len=b, seed_len=s_, max_mm_seed=ms, max_mm_total=mt,
-                   trim5=t5, trim3=t3, poly_t=pt, kbits_log2=st[i]["kbits_log2"])
+                   trim5=t5, trim3=t3, poly_t=pt, kbits_log2=st[i]["kbits_log2"], pair_anchor=st[i]["pair_anchor"])
               for i, (k, a, b, s_, ms, mt, t5, t3, pt) in enumerate(table)]
         views = [index[k].view() for k in keys]
         wst = DEFAULT_WSTOP if args.wstop is None else args.wstop

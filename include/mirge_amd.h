@@ -181,7 +181,8 @@ typedef struct mrg_pass_stats {
   uint32_t lds_bytes;  /* library bytes staged in LDS for this pass (0 = served from HBM/L2) */
   uint32_t lds_mode;   /* 0 nothing, 1 occ blocks, 2 occ blocks + text, 3 text only: names the
                           match_kernel<W, blocks, text> instantiation that ran; 4 = the pass ran
-                          inside a fused launch (fused_kernel<W>, only its 9-mer bitmap in LDS) */
+                          inside a fused launch (fused_kernel<W>, only its 9-mer bitmap in LDS);
+                          5 / 6 = stratum_kernel<W> with / without the packed text in LDS */
   uint32_t group;      /* index of the first pass of the launch this pass ran in (itself when it
                           had a launch of its own) */
   uint32_t n_launches; /* kernel launches that carried this pass: 1, or 2 for a 2-mismatch pass split
@@ -190,6 +191,10 @@ typedef struct mrg_pass_stats {
   uint32_t kbits_log2; /* log2 of the bits of the 9-mer presence bitmap the pass filtered seed
                           pieces with (18 = the library's full bitmap, 13..17 = folded for a
                           fused launch, 0 = no filter) */
+  uint32_t pair_anchor; /* != 0: a 2-mismatch pass whose reads of at least 4 x pair_anchor seed bases
+                          were searched through the six pairs of four anchors of that many bases
+                          (lookups = pair lookups, candidates = their rows, no LF steps); shorter
+                          reads went through the stratum-first pigeonhole pieces */
 } mrg_pass_stats;
 
 /* Bytes of device workspace mrg_cascade_run needs for n reads. */

@@ -32,7 +32,8 @@ class PassStats(C.Structure):
     _fields_ = [("processed", C.c_uint64), ("aligned", C.c_uint64), ("steps", C.c_uint64),
                 ("candidates", C.c_uint64), ("lookups", C.c_uint64), ("ms", C.c_float),
                 ("lds_bytes", C.c_uint32), ("lds_mode", C.c_uint32), ("group", C.c_uint32),
-                ("n_launches", C.c_uint32), ("kbits_log2", C.c_uint32)]
+                ("n_launches", C.c_uint32), ("kbits_log2", C.c_uint32),
+                ("pair_anchor", C.c_uint32)]
 
 
 class IndexInfo(C.Structure):

@@ -54,6 +54,11 @@ struct DevLib {
   uint64_t* sa = nullptr;
   uint32_t* ctx = nullptr;
   uint32_t* sa16 = nullptr;  // wide rows of a large library (fm_index.hpp: fill_wide_rows)
+  // pair tables of a small library (fm_index.hpp: PairTables), for 2-mismatch passes
+  uint32_t* pair_jump = nullptr;
+  uint64_t* pair_rows = nullptr;
+  uint32_t pair_row_off[3] = {0, 0, 0};
+  uint32_t pair_anchor = 0;
   uint32_t* kbits = nullptr;
   std::vector<uint32_t> kbits_host;  // host copy (32 KB): the per-round interleaved tables are built from it
   uint32_t* ftab = nullptr;
@@ -146,6 +151,8 @@ struct mrg_ctx {
   int64_t fuse = 1;
   int64_t round_large = 0;
   int64_t split_strata = 1;
+  int64_t pair_seeds = 1;    // 2-mismatch passes on small libraries search through anchor pairs (set before add_library)
+  int64_t stratum_rows = 0;  // (measured slower than match_kernel: 2.43 vs 2.28 ms) 1: the last stratum of a split 2-mismatch pass runs stratum_kernel; 2: every strata launch does
   int64_t wide_rows_16 = 1;  // libraries of >= 2^20 bases get 16-byte rows with 32 bases of context
   std::vector<DevLib> libs;
   // last run
@@ -157,6 +164,7 @@ struct mrg_ctx {
   uint32_t last_group[MRG_MAX_PASSES] = {0};
   uint32_t last_launches[MRG_MAX_PASSES] = {0};
   uint32_t last_kbits_log2[MRG_MAX_PASSES] = {0};
+  uint32_t last_pair_anchor[MRG_MAX_PASSES] = {0};
   hipEvent_t ev[MRG_MAX_PASSES + 1] = {nullptr};
   bool ev_ready = false;
 };
@@ -347,6 +355,8 @@ void mrg_ctx_destroy(mrg_ctx* ctx) {
     (void)hipFree(l.ftab);
     (void)hipFree(l.ctx);
     (void)hipFree(l.sa16);
+    (void)hipFree(l.pair_jump);
+    (void)hipFree(l.pair_rows);
     (void)hipFree(l.kbits);
     (void)hipFree(l.seg_start);
     (void)hipFree(l.seg_ref);
@@ -370,7 +380,7 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
     DevLib* l;
     ~Guard() {
       if (!l) return;
-      void* ptrs[] = {l->blocks, l->super, l->text, l->sa, l->ftab, l->ctx, l->sa16, l->kbits,
+      void* ptrs[] = {l->blocks, l->super, l->text, l->sa, l->ftab, l->ctx, l->sa16, l->kbits, l->pair_jump, l->pair_rows,
                       l->seg_start, l->seg_ref, l->seg_off, l->chunk_seg};
       for (void* p : ptrs) (void)hipFree(p);
     }
@@ -423,6 +433,18 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
       HIP_TRY(hipMemcpy(l.sa16 + lo * 4, buf.data(), (hi - lo) * 16, hipMemcpyHostToDevice));
     }
   }
+  if (ix.n <= mrg::kPairMaxBases && ix.n >= 4u * mrg::kPairAnchor && ctx->pair_seeds) {
+    mrg::PairTables pt;
+    try {
+      mrg::build_pair_tables(ix, mrg::kPairAnchor, pt);
+    } catch (const std::exception& e) {
+      return fail(MRG_ERR_ARG, "mrg_ctx_add_library: %s", e.what());
+    }
+    if ((rc = upload(&l.pair_jump, pt.jump))) return rc;
+    if ((rc = upload(&l.pair_rows, pt.rows))) return rc;
+    for (int t = 0; t < 3; ++t) l.pair_row_off[t] = pt.row_off[t];
+    l.pair_anchor = pt.anchor;
+  }
   if (!ix.kbits.empty() && (rc = upload(&l.kbits, ix.kbits))) return rc;
   l.kbits_host = ix.kbits;  // the interleaved tables of fused rounds are built from it
   if ((rc = upload(&l.seg_start, ix.seg_start))) return rc;
@@ -465,6 +487,11 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->use_ftab = value != 0;
   } else if (k == "split_strata") {
     ctx->split_strata = value != 0;
+  } else if (k == "pair_seeds") {
+    ctx->pair_seeds = value != 0;
+  } else if (k == "stratum_rows") {
+    if (value < 0 || value > 2) return fail(MRG_ERR_ARG, "stratum_rows must be in [0,2]");
+    ctx->stratum_rows = value;
   } else if (k == "round_large") {
     ctx->round_large = value != 0;
   } else if (k == "wide_rows_16") {
@@ -564,6 +591,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     ctx->last_group[i] = i;
     ctx->last_launches[i] = 0;
     ctx->last_kbits_log2[i] = 0;
+    ctx->last_pair_anchor[i] = 0;
   }
   auto fusable = [&](uint32_t i) {
     // the first launched pass streams the whole read set and keeps the classic kernel (library
@@ -575,7 +603,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
   auto small_lib = [&](uint32_t i) { return ctx->libs[passes[i].lib].kbits != nullptr && ctx->kmer_filter; };
 
   // the classic path: one match_kernel launch for pass i
-  auto run_single = [&](uint32_t i, int32_t k_first, int32_t k_last, bool first_part, bool last_part) -> int {
+  auto run_single = [&](uint32_t i, int32_t k_first, int32_t k_last, bool first_part, bool last_part, bool by_pairs = false) -> int {
     const mrg_pass_cfg& c = passes[i];
     const DevLib& l = ctx->libs[c.lib];
     mrg::MatchParams p;
@@ -610,6 +638,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     p.k_first = k_first;
     p.k_last = k_last;
     p.count_processed = first_part ? 1u : 0u;
+    p.uniform_len = (ctx->hint_min_len == ctx->hint_max_len && ctx->hint_min_len > 0) ? (uint32_t)ctx->hint_min_len : 0u;
     p.out_count = counts + next_list * mrg::kMaxSegments;
     p.pass_id = d_pass_id;
     p.ref_id = d_ref_id;
@@ -671,7 +700,25 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
         lib_bytes = need;
       }
     }
-    const uint32_t lds_total = (uint32_t)(overhead + lib_bytes);
+    // a strata launch of a 2-mismatch pass whose rows are compacted over the wave (stratum_kernel):
+    // text in LDS when it fits, occ blocks always from L2
+    const bool rows_kernel = c.max_mm_seed == 2 && ctx->force_lds_mode < 0 &&
+                             (by_pairs || ctx->stratum_rows == 2 || (ctx->stratum_rows == 1 && k_first == k_last));
+    p.pair_anchor = by_pairs ? l.pair_anchor : 0u;
+    p.pair_jump = l.pair_jump;
+    p.pair_rows = l.pair_rows;
+    for (int t = 0; t < 3; ++t) p.pair_row_off[t] = l.pair_row_off[t];
+    bool rows_lds_text = false;
+    if (rows_kernel) {
+      const uint64_t ov = (uint64_t)l.nsup * 16 + mrg::kStratumCtlBytes + (use_kbits ? kb_bytes : 0);
+      if (ov > hard)
+        return fail(MRG_ERR_ARG, "mrg_cascade_run: the superblock table of library %d does not fit LDS", c.lib);
+      rows_lds_text = txt_bytes <= budget && ov + txt_bytes <= hard;
+      lds_mode = rows_lds_text ? 3 : 0;
+      lib_bytes = rows_lds_text ? txt_bytes : 0;
+    }
+    const uint32_t lds_total = rows_kernel ? (uint32_t)((uint64_t)l.nsup * 16 + mrg::kStratumCtlBytes + (use_kbits ? kb_bytes : 0) + lib_bytes)
+                                           : (uint32_t)(overhead + lib_bytes);
     const uint32_t lds_bytes = (uint32_t)lib_bytes;
     const uint32_t per_cu = (lds_total * 2u <= 160u * 1024u) ? 2u : 1u;
     uint32_t grid = (uint32_t)ctx->n_cu * per_cu;
@@ -683,7 +730,13 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     ctx->last_mode[i] = (uint32_t)lds_mode;
     ctx->last_group[i] = i;
     ctx->last_kbits_log2[i] = use_kbits ? 18u : 0u;
-    if (n) HIP_TRY(mrg::launch_match(p, words_per_read, lds_mode, grid, lds_total, stream));
+    ctx->last_pair_anchor[i] = p.pair_anchor;
+    if (rows_kernel) ctx->last_mode[i] = rows_lds_text ? 5u : 6u;
+    if (n && rows_kernel) {
+      HIP_TRY(mrg::launch_stratum(p, words_per_read, rows_lds_text, grid, lds_total, stream));
+    } else if (n) {
+      HIP_TRY(mrg::launch_match(p, words_per_read, lds_mode, grid, lds_total, stream));
+    }
     ctx->last_launches[i] += 1;
     if (last_part) HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
     if (p.idx_out) {
@@ -882,7 +935,13 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     } else {
       const int32_t kfull = passes[i].max_mm_seed + 1;
       int rc;
-      if (passes[i].max_mm_seed == 2 && ctx->split_strata) {
+      const DevLib& l8 = ctx->libs[passes[i].lib];
+      if (passes[i].max_mm_seed == 2 && ctx->pair_seeds && l8.pair_anchor && ctx->force_lds_mode < 0 && !passes[i].poly_t &&
+          passes[i].seed_len >= (int32_t)(4u * l8.pair_anchor)) {
+        // anchor pairs for every read long enough to hold the four anchors, all strata of the
+        // pigeonhole search for the shorter ones: one launch (kernels.hip: stratum_kernel)
+        rc = run_single(i, 1, kfull, true, true, true);
+      } else if (passes[i].max_mm_seed == 2 && ctx->split_strata) {
         // strata 1..2 on the incoming reads, stratum 3 on the compacted survivors (kernels.hpp)
         rc = run_single(i, 1, 2, true, false);
         if (rc == MRG_OK) rc = run_single(i, 3, 3, false, true);
@@ -934,6 +993,7 @@ int mrg_cascade_stats(mrg_ctx* ctx, mrg_pass_stats* out, uint32_t n_pass) {
     out[i].group = ctx->last_group[i];
     out[i].n_launches = ctx->last_launches[i];
     out[i].kbits_log2 = ctx->last_kbits_log2[i];
+    out[i].pair_anchor = ctx->last_pair_anchor[i];
   }
   return MRG_OK;
 }

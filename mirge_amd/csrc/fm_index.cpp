@@ -390,6 +390,40 @@ void fill_wide_rows(const FmIndex& ix, size_t row_lo, size_t row_hi, uint32_t* o
   for (auto& th : pool) th.join();
 }
 
+void build_pair_tables(const FmIndex& ix, uint32_t anchor, PairTables& out) {
+  out = PairTables();
+  if (anchor < 2 || anchor > 6) throw std::runtime_error("pair tables: anchor length must be 2..6");
+  out.anchor = anchor;
+  const uint32_t kb = 2 * anchor;
+  const uint64_t amask = (1ull << kb) - 1ull;
+  const size_t n_codes = (size_t)1 << (2 * kb);
+  out.jump.assign(3 * (n_codes + 1), 0u);
+  const size_t n_rows = ix.sa.size();
+  // a row can only matter when both anchors lie inside its N-free segment
+  auto key_of = [&](uint64_t row, uint32_t d, uint32_t& key) -> bool {
+    const uint32_t p = (uint32_t)row, after = (uint32_t)(row >> 40) & 255u;
+    if (after < d + anchor) return false;
+    key = (uint32_t)((window64(ix, p) & amask) | ((window64(ix, (uint64_t)p + d) & amask) << kb));
+    return true;
+  };
+  std::vector<uint32_t> fill(n_codes);
+  for (uint32_t t = 0; t < 3; ++t) {
+    const uint32_t d = (t + 1) * anchor;
+    uint32_t* jump = out.jump.data() + (size_t)t * (n_codes + 1);
+    uint32_t key;
+    for (size_t i = 0; i < n_rows; ++i)
+      if (key_of(ix.sa[i], d, key)) ++jump[key + 1];
+    for (size_t c = 0; c < n_codes; ++c) jump[c + 1] += jump[c];
+    out.row_off[t] = (uint32_t)out.rows.size();
+    out.rows.resize(out.rows.size() + jump[n_codes]);
+    uint64_t* rows = out.rows.data() + out.row_off[t];
+    std::copy(jump, jump + n_codes, fill.begin());
+    for (size_t i = 0; i < n_rows; ++i)
+      if (key_of(ix.sa[i], d, key)) rows[fill[key]++] = ix.sa[i];
+  }
+  out.row_off[3] = (uint32_t)out.rows.size();
+}
+
 void build_index(const std::vector<std::string>& names,
                  const std::vector<std::string>& seqs, FmIndex& ix) {
   if (names.size() != seqs.size()) throw std::runtime_error("names/seqs size mismatch");

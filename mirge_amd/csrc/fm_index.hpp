@@ -86,6 +86,26 @@ void build_kmer_bits(FmIndex& ix);    // from text
 // piece in an 11 Mbp library) is dropped without its text-window request.  Rows [row_lo, row_hi)
 // into out[4 * (row_hi - row_lo)].
 void fill_wide_rows(const FmIndex& ix, size_t row_lo, size_t row_hi, uint32_t* out);
+// Pair tables of a small library, for policies with two seed mismatches (kernels.hip,
+// stratum_kernel).  Four disjoint anchors of `anchor` bases at read offsets 0, A, 2A, 3A: two
+// mismatches touch at most two of them, so every alignment with <= 2 seed mismatches matches
+// exactly on (at least) one of the six anchor PAIRS.  A pair (i, j) is a gapped 2A-base key with
+// gap d = (j - i) A between the starts of its halves; table t (d = A, 2A, 3A) lists, for every
+// key, the suffix-array rows (same 8-byte format as `sa`) of the text positions p whose bases
+// [p, p + A) and [p + d, p + d + A) spell it (first base in the low two bits, first half in the
+// low 2A bits) and lie inside p's N-free segment.  jump: 4^(2A) + 1 boundaries per table,
+// tables back to back; rows: the three lists back to back, row_off[t] = first row of list t.
+// Against a 2 x 6-base pigeonhole piece (84 K bases: ~20 rows per piece, 3 pieces) an 8-base pair
+// key leaves ~1.3 rows per lookup, 6 lookups.  Derived data, built at upload time.
+struct PairTables {
+  uint32_t anchor = 0;
+  std::vector<uint32_t> jump;
+  std::vector<uint64_t> rows;
+  uint32_t row_off[4] = {0, 0, 0, 0};
+};
+void build_pair_tables(const FmIndex& ix, uint32_t anchor, PairTables& out);
+constexpr uint32_t kPairMaxBases = 1u << 22;  // libraries up to this size get pair tables (3 x 8 B per base)
+constexpr uint32_t kPairAnchor = 4;
 constexpr uint32_t kWideRowMinBases = 1u << 20;
 constexpr uint32_t kWideRowRightSkip = 8;
 // largest library that gets the bitmap: its packed text (n / 4 bytes) plus the 32 KB bitmap must

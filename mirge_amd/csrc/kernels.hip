@@ -1237,6 +1237,318 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// stratum_kernel: the strata [k_first, k_last] of a stratum-first (2-mismatch) pass with the
+// suffix-array rows compacted over the wave.
+//
+// The last stratum of `-v 2` on a small library is candidate verification and nothing else: three
+// 6..7-base pieces per read, ~20 rows each.  With one read per lane (match_kernel) every row load
+// is a 64-address gather -- the launch was bound by the vector L1's tag rate (7.9e8 accesses for
+// 4.4e8 rows), not by L2 or the ALUs.  Here a wave still holds 64 reads and every lane does its own
+// jump-table load and LF steps, but the rows of the 64 intervals of one piece are dealt out as in
+// fused_kernel: lane i takes row i of the batch, whoever's interval it belongs to (consecutive
+// lanes read consecutive rows: a few cache lines per wave instruction), fetches the owner's read
+// with shuffles, verifies, and folds a valid alignment into the owner's 8-byte LDS key with a
+// 64-bit atomic min.  Pieces are swept one after the other, so the sequential search's early exits
+// (an exact hit of an earlier piece, a stratum complete below its bound) are taken by the owner
+// between sweeps and the processed / aligned / steps / candidates / lookups counters are those of
+// match_kernel<STRATA> for the same strata.
+// ---------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(1024, (W == 1 ? 8 : 4)) stratum_kernel(const MatchParams p, const uint32_t lds_text) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  constexpr uint32_t BLOCK = 1024u;
+  // ---- LDS carve: [superblocks][text][9-mer bitmap][control][one 8-byte key per lane][counters] ----
+  const uint32_t sup_words = p.nsup * 4;
+  const uint32_t txt_words = lds_text ? p.text_words : 0u;
+  uint32_t* ssuper = smem;
+  uint32_t* stext = ssuper + sup_words;
+  uint32_t* skbits = stext + txt_words;
+  uint32_t* ctl = skbits + (p.kbits ? kKmerBitsWords : 0u);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(ctl + 4);
+  unsigned long long* wg_cnt = keys + BLOCK;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(p.super);
+    uint4* dst = reinterpret_cast<uint4*>(ssuper);
+    for (uint32_t i = threadIdx.x; i < sup_words / 4; i += BLOCK) dst[i] = src[i];
+  }
+  if (lds_text) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.text);
+    uint4* dst = reinterpret_cast<uint4*>(stext);
+    for (uint32_t i = threadIdx.x; i < txt_words / 4; i += BLOCK) dst[i] = src[i];
+  }
+  if (p.kbits) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.kbits);
+    uint4* dst = reinterpret_cast<uint4*>(skbits);
+    for (uint32_t i = threadIdx.x; i < kKmerBitsWords / 4; i += BLOCK) dst[i] = src[i];
+  }
+  if (threadIdx.x == 0) {
+    ctl[0] = 0u;
+    ctl[1] = 0u;
+  }
+  if (threadIdx.x < 5) wg_cnt[threadIdx.x] = 0ull;
+  __syncthreads();
+  if (p.idx_in) {
+    uint32_t mx = 0;
+    for (uint32_t sgi = threadIdx.x; sgi < p.in_nseg; sgi += BLOCK) mx = max(mx, p.in_count[sgi]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, off, 64));
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(&ctl[1], mx);
+  }
+  __syncthreads();
+
+  Lib<false, false> fm;  // LF steps: occ blocks from L2, superblock table from LDS
+  fm.gblocks = p.blocks;
+  fm.gtext = nullptr;
+  fm.sblocks = nullptr;
+  fm.stext = nullptr;
+  fm.ssuper = ssuper;
+  fm.primary = p.primary;
+  ItemLib lib;
+  lib.gtext = p.text;
+  lib.stext = lds_text ? stext : nullptr;
+
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long* my_keys = keys + wave * 64u;
+  const bool has_nm = p.nmask != nullptr;
+  uint32_t c_processed = 0, c_aligned = 0, c_steps = 0, c_cands = 0, c_lookups = 0;
+
+  const uint32_t in_nseg = p.idx_in ? p.in_nseg : 1u;
+  const uint32_t depth_chunks = p.idx_in ? (ctl[1] + BLOCK - 1) / BLOCK : (p.n_total + BLOCK - 1) / BLOCK;
+  const uint32_t n_chunks = in_nseg * depth_chunks;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const uint32_t sgi = chunk % in_nseg, depth = chunk / in_nseg;
+    const uint32_t t = depth * BLOCK + threadIdx.x;
+    const bool active = t < (p.idx_in ? p.in_count[sgi] : p.n_total);
+    uint32_t r = 0;
+    uint64_t rd[W], nm[W];
+    uint32_t L0 = 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) rd[k] = nm[k] = 0ull;
+    if (active) {
+      r = p.idx_in ? p.idx_in[(size_t)sgi * p.in_seg_cap + t] : t;
+      L0 = p.uniform_len ? p.uniform_len : (uint32_t)p.lens[r];
+    }
+    // ---- which reads this pass's FASTA would contain (RAP:543-554, 664-686) ----
+    bool eligible = active && (int32_t)L0 >= p.min_len && (int32_t)L0 <= p.max_len;
+    if (eligible) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) {
+        rd[k] = p.reads[(size_t)k * p.n_total + r];
+        nm[k] = has_nm ? p.nmask[(size_t)k * p.n_total + r] : 0ull;
+      }
+    }
+    int32_t L = (int32_t)L0;
+    if (p.poly_t) {
+      const int32_t tail = trailing_t<W>(rd, nm, L);
+      eligible = eligible && tail >= 3 && (L - tail) >= 11;
+      L -= tail;
+    }
+    L -= p.trim5 + p.trim3;
+    shift_out_5p<W>(rd, (uint32_t)p.trim5);
+    if (has_nm) shift_out_5p<W>(nm, (uint32_t)p.trim5);
+    if (eligible && p.count_processed) ++c_processed;
+
+    // key of the best alignment so far: mm:8 | text position:32 | segment:16 | before:8
+    uint64_t best = ~0ull;
+    bool searching = eligible && L > p.max_mm_seed;
+    const int32_t R = min(L, p.seed_len);
+
+    // ---------- rows: the rows [lo, lo + rem) of `rows` of every lane, one per lane and trip;
+    // a valid alignment goes to its owner's `best` ----------
+    auto sweep = [&](const uint64_t* __restrict__ rows, uint32_t lo, uint32_t rem, uint32_t nb) {
+      const bool had_rows = rem != 0u;
+      if (!__ballot(had_rows)) return;
+      const uint32_t nb_L = nb | ((uint32_t)L << 8);
+      my_keys[lane] = ~0ull;
+      __builtin_amdgcn_wave_barrier();
+      while (__ballot(rem != 0u)) {
+        const uint32_t w = min(rem, kRowSlice);
+        const uint32_t rincl = wave_incl_scan(w, lane);
+        const uint32_t rtotal = __shfl(rincl, 63, 64);
+        for (uint32_t rb = 0; rb < rtotal; rb += 64u) {
+          const uint32_t x = rb + lane;
+          const bool has_row = x < rtotal;
+          uint32_t o = owner_of(rincl, x);
+          o = has_row ? o : lane;
+          const uint32_t o_incl = __shfl(rincl, (int)o, 64), o_w = __shfl(w, (int)o, 64);
+          const uint32_t o_lo = __shfl(lo, (int)o, 64);
+          const uint32_t o_nbL = __shfl(nb_L, (int)o, 64);
+          uint64_t o_rd[W], o_nm[W];
+#pragma unroll
+          for (int q = 0; q < W; ++q) {
+            o_rd[q] = __shfl(rd[q], (int)o, 64);
+            o_nm[q] = has_nm ? __shfl(nm[q], (int)o, 64) : 0ull;
+          }
+          if (has_row) {
+            const uint32_t need_before = o_nbL & 0xFFu;
+            const int32_t o_L = (int32_t)(o_nbL >> 8);
+            const uint64_t row = rows[o_lo + (x - (o_incl - o_w))];
+            uint64_t rbest = ~0ull;
+            uint32_t rseg = 0xFFFFu, rbefore = 255u;
+            verify_row<W>(lib, p, row, o_rd, o_nm, o_L, need_before, (uint32_t)o_L - need_before, rbest, rseg, rbefore);
+            if (rbest != ~0ull) {
+              const uint64_t key = ((rbest >> 32) << 56) | ((rbest & 0xFFFFFFFFull) << 24) |
+                                   ((uint64_t)(rseg & 0xFFFFu) << 8) | (uint64_t)(rbefore & 0xFFu);
+              atomicMin(&my_keys[o], (unsigned long long)key);
+            }
+          }
+        }
+        lo += w;
+        rem -= w;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (had_rows) best = min(best, (uint64_t)my_keys[lane]);
+    };
+
+    // ---------- reads that hold the four anchors: the six anchor pairs (fm_index.hpp) ----------
+    const uint32_t A = p.pair_anchor;
+    const bool by_pairs = searching && A != 0u && R >= (int32_t)(4u * A);
+    if (__ballot(by_pairs)) {
+      const uint32_t kb = 2u * A, amask = (1u << kb) - 1u, n_codes1 = (1u << (2u * kb)) + 1u;
+      // Stratum first, as in the piece search: an exact alignment matches EVERY pair, so pair (0,1)
+      // alone sees all of them; one mismatch leaves (0,1) or (2,3) clean, so after those two every
+      // alignment with <= 1 mismatch has been seen.  A best hit below the bound is final and the
+      // remaining pairs are not looked up.
+      bool open_pairs = by_pairs;
+#pragma unroll 1
+      for (uint32_t pr = 0; pr < 6u; ++pr) {
+        // (i, j) = (0,1) (2,3) (1,2) (0,2) (1,3) (0,3): table j - i - 1
+        const uint32_t i = (0x010120u >> (4u * pr)) & 15u, j = (0x332231u >> (4u * pr)) & 15u;
+        const uint32_t ai = (uint32_t)(rd[0] >> (i * kb)) & amask, aj = (uint32_t)(rd[0] >> (j * kb)) & amask;
+        bool go = open_pairs;
+        // an anchor holding an N is never the exact one
+        if (has_nm && ((((uint32_t)(nm[0] >> (i * kb)) | (uint32_t)(nm[0] >> (j * kb))) & amask) != 0u)) go = false;
+        uint32_t lo = 0, hi = 0;
+        const uint32_t t = j - i - 1u;
+        if (go) {
+          const uint32_t* tab = p.pair_jump + t * n_codes1 + (ai | (aj << kb));
+          lo = tab[0];
+          hi = tab[1];
+          ++c_lookups;
+        }
+        c_cands += hi - lo;
+        sweep(p.pair_rows + p.pair_row_off[t], lo, hi - lo, i * A);
+        if (pr < 2u && (uint32_t)(best >> 56) <= pr) open_pairs = false;
+        if (!__ballot(open_pairs)) break;
+      }
+      if (by_pairs) searching = false;  // every alignment with <= 2 seed mismatches has been seen
+    }
+
+    // ---------- the others: stratum-first pigeonhole pieces ----------
+    if (__ballot(searching))
+    for (int32_t K = p.k_first; K <= p.k_last; ++K) {
+      bool in_stratum = searching;
+      for (int32_t k = 0; k < K; ++k) {
+        const int32_t a = div_pieces(R * k, K), b = div_pieces(R * (k + 1), K);
+        bool go = in_stratum;
+        if (go && has_nm && piece_has_n<W>(nm, a, b)) go = false;  // a piece holding an N can never be the exact one
+        if (go && p.kbits && b - a >= (int32_t)kKmerBitsK) {
+          const uint32_t c9 = read_bits9<W>(rd, (uint32_t)b - kKmerBitsK);
+          if (((skbits[c9 >> 5] >> (c9 & 31u)) & 1u) == 0u) go = false;
+          if (go && b - a > (int32_t)kKmerBitsK) {
+            const uint32_t c0 = read_bits9<W>(rd, (uint32_t)a);
+            if (((skbits[c0 >> 5] >> (c0 & 31u)) & 1u) == 0u) go = false;
+          }
+        }
+        // ---- exact backward search of read[a,b) ----
+        uint32_t lo = 0, hi = 0;
+        int32_t j = b;
+        if (go) {
+          hi = p.n + 1;
+          uint32_t tab_off = 0;
+          const uint32_t tk = p.tabs.k[0] ? pick_table(p.tabs, b - a, tab_off) : 0u;
+          if (tk) {
+            j = b - (int32_t)tk;
+            uint64_t code = pick_word<W>(rd, (uint32_t)j >> 5) >> ((j & 31) * 2);
+            if (W > 1 && (j & 31) + (int32_t)tk > 32)
+              code |= pick_word<W>(rd, ((uint32_t)j >> 5) + 1) << (64 - (j & 31) * 2);
+            code &= (1ull << (2 * tk)) - 1ull;
+            const uint32_t* tab = p.ftab + tab_off + lex_code(code, tk);
+            lo = tab[0];
+            hi = tab[1];
+            ++c_lookups;
+          }
+          while (j > a && hi > lo && (hi - lo) > p.wstop) {
+            --j;
+            const uint32_t c = (uint32_t)(pick_word<W>(rd, (uint32_t)j >> 5) >> ((j & 31) * 2)) & 3u;
+            const uint4 vl = fm.block(lo >> 5);
+            uint4 vh = vl;
+            if ((hi >> 5) != (lo >> 5)) vh = fm.block(hi >> 5);
+            lo = fm.lf(c, lo, vl);
+            hi = fm.lf(c, hi, vh);
+            ++c_steps;
+          }
+        }
+        const uint32_t rem = hi > lo ? hi - lo : 0u;
+        c_cands += rem;
+        sweep(p.sa, lo, rem, (uint32_t)j);
+        if ((best >> 56) == 0ull) in_stratum = false;  // an exact hit is always seen by piece 0
+      }
+      if ((uint32_t)(best >> 56) < (uint32_t)K) searching = false;  // complete below K mismatches (unaligned = 255)
+    }
+
+    // (a launch that stops before the last stratum keeps a hit only if it is final)
+    const bool aligned = best != ~0ull && (by_pairs || p.k_last > p.max_mm_seed || (int32_t)(best >> 56) < p.k_last);
+    if (aligned) {
+      ++c_aligned;
+      const uint32_t s = (uint32_t)(best >> 24);
+      uint32_t sg = (uint32_t)(best >> 8) & 0xFFFFu;
+      const uint32_t before = (uint32_t)best & 0xFFu;
+      if (sg == 0xFFFFu) {  // more than 65535 segments: walk the chunk map
+        sg = p.chunk_seg[s >> 5];
+        while (p.seg_start[sg + 1] <= s) ++sg;
+      }
+      uint32_t ref = sg, pos;
+      if (p.simple_segs && before < 255u) {
+        pos = before;
+      } else {
+        uint32_t off = 0;
+        if (!p.simple_segs) {
+          ref = p.seg_ref[sg];
+          off = p.seg_off[sg];
+        }
+        pos = s - p.seg_start[sg] + off;
+      }
+      p.pass_id[r] = (int8_t)p.pass_index;
+      p.ref_id[r] = (int32_t)ref;
+      p.pos[r] = (int32_t)pos;
+      p.mm[r] = (uint8_t)(best >> 56);
+    } else if (active && !p.idx_out) {
+      p.pass_id[r] = (int8_t)-1;
+      p.ref_id[r] = -1;
+      p.pos[r] = -1;
+      p.mm[r] = 0;
+    }
+    if (p.idx_out) {
+      const bool survive = active && !aligned;
+      const uint64_t mask = __ballot(survive);
+      if (mask) {
+        uint32_t wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&ctl[0], (uint32_t)__popcll(mask));
+        wbase = __shfl(wbase, 0, 64);
+        if (survive)
+          p.idx_out[(size_t)blockIdx.x * p.out_seg_cap + wbase +
+                    (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = r;
+      }
+    }
+  }
+  const uint64_t t_processed = wave_sum(c_processed), t_aligned = wave_sum(c_aligned);
+  const uint64_t t_steps = wave_sum(c_steps), t_cands = wave_sum(c_cands);
+  const uint64_t t_lookups = wave_sum(c_lookups);
+  if (lane == 0) {
+    if (t_processed) atomicAdd(&wg_cnt[0], (unsigned long long)t_processed);
+    if (t_aligned) atomicAdd(&wg_cnt[1], (unsigned long long)t_aligned);
+    if (t_steps) atomicAdd(&wg_cnt[2], (unsigned long long)t_steps);
+    if (t_cands) atomicAdd(&wg_cnt[3], (unsigned long long)t_cands);
+    if (t_lookups) atomicAdd(&wg_cnt[4], (unsigned long long)t_lookups);
+  }
+  __syncthreads();
+  if (threadIdx.x < 5 && wg_cnt[threadIdx.x])
+    atomicAdd((unsigned long long*)&p.counters[threadIdx.x], wg_cnt[threadIdx.x]);
+  if (p.idx_out && threadIdx.x == 0) p.out_count[blockIdx.x] = ctl[0];
+}
+
+// ---------------------------------------------------------------------------
 // count_kernel: best stratum of every read against one library -- fewest mismatches of a
 // valid alignment and how many alignments reach it.  Replaces the two genome bowtie runs
 // of the -ai path (writeDataToCSV.py:1263 `-n 1 -a -3 2`, :1488 `-n 0 -a -3 2`), whose
@@ -1727,6 +2039,28 @@ hipError_t launch_match(const MatchParams& p, uint32_t words_per_read, int lds_m
     case 4: return launch_match_w<4>(p, lds_mode, grid, lds_bytes, stream);
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t launch_stratum(const MatchParams& p, uint32_t words_per_read, bool lds_text, uint32_t grid,
+                          uint32_t lds_bytes, hipStream_t stream) {
+#define MRG_STRATUM(W_)                                                                                 \
+  {                                                                                                     \
+    auto kern = stratum_kernel<W_>;                                                                     \
+    if (lds_bytes > 48 * 1024) {                                                                        \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                           \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);   \
+      if (e != hipSuccess) return e;                                                                    \
+    }                                                                                                   \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds_bytes, stream, p, lds_text ? 1u : 0u);         \
+  }
+  switch (words_per_read) {
+    case 1: MRG_STRATUM(1) break;
+    case 2: MRG_STRATUM(2) break;
+    case 4: MRG_STRATUM(4) break;
+    default: return hipErrorInvalidValue;
+  }
+#undef MRG_STRATUM
+  return hipGetLastError();
 }
 
 hipError_t launch_fused(const FusedParams& p, uint32_t words_per_read, uint32_t grid, uint32_t lds_bytes,

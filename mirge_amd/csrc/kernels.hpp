@@ -75,6 +75,14 @@ struct MatchParams {
   // every lane holding a read instead of the 45 % that reach that stratum.
   int32_t k_first, k_last;
   uint32_t count_processed;  // 0: the launch continues a pass whose reads were counted already
+  uint32_t uniform_len;      // stratum_kernel: != 0 = every read has this length (lens is not read)
+  // stratum_kernel: pair tables of the library (fm_index.hpp: PairTables); pair_anchor = 0: none.
+  // Reads whose seed region holds the four anchors (>= 4 * pair_anchor bases) are searched through
+  // the six anchor pairs, shorter ones through the pigeonhole pieces of strata [k_first, k_last].
+  const uint32_t* pair_jump;
+  const uint64_t* pair_rows;
+  uint32_t pair_row_off[3];
+  uint32_t pair_anchor;
 };
 
 // ---------------------------------------------------------------------------
@@ -230,6 +238,11 @@ hipError_t launch_edit_tally(const EditParams& p, bool lds_hist, bool lds_lib, u
 //           3 = text only in LDS (occ blocks from L2)
 hipError_t launch_match(const MatchParams& p, uint32_t words_per_read, int lds_mode,
                         uint32_t grid, uint32_t lds_bytes, hipStream_t stream);
+// stratum_kernel: strata [k_first, k_last] of a stratum-first pass, rows compacted over the wave.
+// LDS = superblocks + (lds_text ? packed text : 0) + (p.kbits ? bitmap : 0) + kStratumCtlBytes
+constexpr uint32_t kStratumCtlBytes = 16u + 1024u * 8u + 5u * 8u;
+hipError_t launch_stratum(const MatchParams& p, uint32_t words_per_read, bool lds_text, uint32_t grid,
+                          uint32_t lds_bytes, hipStream_t stream);
 hipError_t launch_tally(const TallyParams& p, bool lds_hist, uint32_t grid,
                         uint32_t lds_bytes, hipStream_t stream);
 // collapse.hip: raw reads -> unique reads + per-sample counts + length histogram

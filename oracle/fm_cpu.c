@@ -33,7 +33,17 @@ typedef struct {
 typedef struct {
   int32_t lib, seed_len, max_mm_seed, max_mm_total, trim5, trim3, min_len, max_len, poly_t,
       reserved;
+  int32_t pair_anchor; /* mrg_pass_stats.pair_anchor: != 0 = reads with >= 4 anchors of seed bases go through anchor pairs */
 } orc_pass;
+
+/* Pair tables (mirge_amd/csrc/fm_index.hpp: PairTables), rebuilt here from the suffix array and
+ * the text: table t (gap d = (t + 1) A) lists per 2A-base key the rows whose bases [p, p + A) and
+ * [p + d, p + d + A) spell it and lie inside the row's N-free segment. */
+typedef struct {
+  int anchor;
+  uint32_t *jump[3];
+  uint64_t *rows[3];
+} orc_pairs;
 
 #define ODD 0x5555555555555555ull
 
@@ -68,15 +78,99 @@ static void shift5(uint64_t *rd, int W, int t) {
   rd[W - 1] >>= sh;
 }
 
+/* one suffix-array row as a candidate of a read whose seed search stopped with j read bases left
+ * of the row's position */
+static void verify_one(const orc_lib *l, const orc_pass *p, uint64_t row, int j, const uint64_t *rd,
+                       const uint64_t *nm, int W, int L, uint64_t *best) {
+  uint32_t before = (uint32_t)(row >> 32) & 255u, after = (uint32_t)(row >> 40) & 255u;
+  if ((uint32_t)j > before || (uint32_t)(L - j) > after) return;
+  uint32_t s = (uint32_t)row - (uint32_t)j;
+  int mm_total = 0, mm_seed = 0;
+  for (int w = 0; w < W; ++w) {
+    int nb = L - 32 * w;
+    if (nb > 32) nb = 32;
+    if (nb <= 0) break;
+    uint64_t x = window(l, s + 32u * w) ^ rd[w];
+    uint64_t m = (((x | (x >> 1)) & ODD) | nm[w]) & low_bits(2 * nb);
+    mm_total += __builtin_popcountll(m);
+    int ns = p->seed_len - 32 * w;
+    if (ns > nb) ns = nb;
+    mm_seed += __builtin_popcountll(m & low_bits(2 * ns));
+  }
+  if (mm_seed > p->max_mm_seed || mm_total > p->max_mm_total) return;
+  uint64_t cand = ((uint64_t)mm_total << 32) | s;
+  if (cand < *best) *best = cand;
+}
+
+static void pairs_build(const orc_lib *l, int anchor, orc_pairs *pt) {
+  const int kb = 2 * anchor;
+  const uint64_t amask = (1ull << kb) - 1ull;
+  const size_t n_codes = (size_t)1 << (2 * kb), n_rows = (size_t)l->n + 1;
+  pt->anchor = anchor;
+  for (int t = 0; t < 3; ++t) {
+    const uint32_t d = (uint32_t)(t + 1) * (uint32_t)anchor;
+    uint32_t *jump = (uint32_t *)calloc(n_codes + 1, 4), *fill = (uint32_t *)malloc(n_codes * 4);
+    for (int sweep = 0; sweep < 2; ++sweep) {
+      if (sweep == 1) {
+        for (size_t c = 0; c < n_codes; ++c) jump[c + 1] += jump[c];
+        memcpy(fill, jump, n_codes * 4);
+        pt->rows[t] = (uint64_t *)malloc(((size_t)jump[n_codes] + 1) * 8);
+      }
+      for (size_t i = 0; i < n_rows; ++i) {
+        uint64_t row = l->sa[i];
+        uint32_t p = (uint32_t)row, after = (uint32_t)(row >> 40) & 255u;
+        if (after < d + (uint32_t)anchor) continue;
+        uint32_t key = (uint32_t)((window(l, p) & amask) | ((window(l, p + d) & amask) << kb));
+        if (sweep == 0) ++jump[key + 1];
+        else pt->rows[t][fill[key]++] = row;
+      }
+    }
+    free(fill);
+    pt->jump[t] = jump;
+  }
+}
+
+static void pairs_free(orc_pairs *pt) {
+  for (int t = 0; t < 3; ++t) {
+    free(pt->jump[t]);
+    free(pt->rows[t]);
+  }
+}
+
 /* Returns 1 if aligned; *key = (mm << 32) | text position. */
-static int match_one(const orc_lib *l, const orc_pass *p, const uint32_t *kbits, uint32_t kb_mask,
+static int match_one(const orc_lib *l, const orc_pass *p, const orc_pairs *pairs, const uint32_t *kbits, uint32_t kb_mask,
                      const uint64_t *rd, const uint64_t *nm,
-                     int W, int L, uint32_t wstop, int use_ftab, uint64_t *key, uint64_t *steps,
+                     int W, int L, uint32_t wstop, int use_ftab, uint64_t *key_out, uint64_t *steps,
                      uint64_t *cands, uint64_t *lookups) {
   uint64_t best = ~0ull;
   if (L <= p->max_mm_seed) return 0;
   int R = L < p->seed_len ? L : p->seed_len;
   int Kfull = p->max_mm_seed + 1;
+  if (pairs && R >= 4 * pairs->anchor) {
+    /* two mismatches touch at most two of the four anchors at 0, A, 2A, 3A: every alignment with
+     * <= 2 seed mismatches matches one of the six anchor pairs exactly */
+    /* stratum first: an exact alignment matches every pair, so (0,1) alone sees all of them; one
+     * mismatch leaves (0,1) or (2,3) clean; a best hit below those bounds is final */
+    static const int PI[6] = {0, 2, 1, 0, 1, 0}, PJ[6] = {1, 3, 2, 2, 3, 3};
+    const int A = pairs->anchor, kb = 2 * A;
+    const uint64_t amask = (1ull << kb) - 1ull;
+    for (int pr = 0; pr < 6; ++pr) {
+      int i = PI[pr], j = PJ[pr], t = j - i - 1;
+      if (!(((nm[0] >> (i * kb)) | (nm[0] >> (j * kb))) & amask)) {
+        uint32_t key = (uint32_t)(((rd[0] >> (i * kb)) & amask) | (((rd[0] >> (j * kb)) & amask) << kb));
+        uint32_t lo = pairs->jump[t][key], hi = pairs->jump[t][key + 1];
+        ++*lookups;
+        for (uint32_t q = lo; q < hi; ++q) {
+          ++*cands;
+          verify_one(l, p, pairs->rows[t][q], i * A, rd, nm, W, L, &best);
+        }
+      }
+      if (pr < 2 && (uint32_t)(best >> 32) <= (uint32_t)pr) break;
+    }
+    if (best == ~0ull) return 0;
+    *key_out = best;
+    return 1;
+  }
   /* stratum first for 2-mismatch policies: K pieces find every alignment with < K seed mismatches,
    * so a best hit below that bound is final and the more expensive search is skipped */
   for (int K = (Kfull == 3 ? 1 : Kfull); K <= Kfull; ++K) {
@@ -131,33 +225,15 @@ static int match_one(const orc_lib *l, const orc_pass *p, const uint32_t *kbits,
       ++*steps;
     }
     for (uint32_t i = lo; i < hi; ++i) {
-      uint64_t row = l->sa[i];
-      uint32_t before = (uint32_t)(row >> 32) & 255u, after = (uint32_t)(row >> 40) & 255u;
       ++*cands;
-      if ((uint32_t)j > before || (uint32_t)(L - j) > after) continue;
-      uint32_t s = (uint32_t)row - (uint32_t)j;
-      int mm_total = 0, mm_seed = 0;
-      for (int w = 0; w < W; ++w) {
-        int nb = L - 32 * w;
-        if (nb > 32) nb = 32;
-        if (nb <= 0) break;
-        uint64_t x = window(l, s + 32u * w) ^ rd[w];
-        uint64_t m = (((x | (x >> 1)) & ODD) | nm[w]) & low_bits(2 * nb);
-        mm_total += __builtin_popcountll(m);
-        int ns = p->seed_len - 32 * w;
-        if (ns > nb) ns = nb;
-        mm_seed += __builtin_popcountll(m & low_bits(2 * ns));
-      }
-      if (mm_seed > p->max_mm_seed || mm_total > p->max_mm_total) continue;
-      uint64_t cand = ((uint64_t)mm_total << 32) | s;
-      if (cand < best) best = cand;
+      verify_one(l, p, l->sa[i], j, rd, nm, W, L, &best);
     }
     if ((best >> 32) == 0) break;
   }
   if ((uint32_t)(best >> 32) < (uint32_t)K) break;
   }
   if (best == ~0ull) return 0;
-  *key = best;
+  *key_out = best;
   return 1;
 }
 
@@ -196,6 +272,11 @@ void orc_run_cascade(const orc_lib *libs, const orc_pass *passes, int n_pass, co
       kbits = folded;
       kb_mask = (1u << p->reserved) - 1u;
     }
+    orc_pairs pairs_store, *pairs = NULL;
+    if (p->pair_anchor > 0 && p->max_mm_seed == 2 && !p->poly_t && p->seed_len >= 4 * p->pair_anchor) {
+      pairs_build(l, p->pair_anchor, &pairs_store);
+      pairs = &pairs_store;
+    }
 #pragma omp parallel for schedule(dynamic, 4096) reduction(+ : processed, aligned, steps, cands, lookups)
     for (int64_t r = 0; r < (int64_t)n; ++r) {
       if (pass_id[r] >= 0) continue;
@@ -222,7 +303,7 @@ void orc_run_cascade(const orc_lib *libs, const orc_pass *passes, int n_pass, co
       shift5(nm, W, p->trim5);
       ++processed;
       uint64_t key = 0, st = 0, cd = 0, lk = 0;
-      int ok = L > 0 && match_one(l, p, kbits, kb_mask, rd, nm, W, L, wstop, use_ftab, &key, &st, &cd, &lk);
+      int ok = L > 0 && match_one(l, p, pairs, kbits, kb_mask, rd, nm, W, L, wstop, use_ftab, &key, &st, &cd, &lk);
       steps += st;
       cands += cd;
       lookups += lk;
@@ -239,6 +320,7 @@ void orc_run_cascade(const orc_lib *libs, const orc_pass *passes, int n_pass, co
       }
     }
     free(folded);
+    if (pairs) pairs_free(pairs);
     stats[5 * pi + 0] = processed;
     stats[5 * pi + 1] = aligned;
     stats[5 * pi + 2] = steps;

@@ -177,7 +177,7 @@ class _OrcLib(C.Structure):
 class _OrcPass(C.Structure):
     _fields_ = [(k, C.c_int32) for k in
                 ("lib", "seed_len", "max_mm_seed", "max_mm_total", "trim5", "trim3", "min_len",
-                 "max_len", "poly_t", "reserved")]
+                 "max_len", "poly_t", "reserved", "pair_anchor")]
 
 
 def fm_cascade(lib_views, passes, reads, lens, nmask=None, wstop=0, threads=None,

@@ -66,7 +66,7 @@ class OracleEngine:
         nm = None if reads.nmask is None else reads.nmask.numpy().view(np.uint64)
         ref = model.fm_cascade(views, pd, w, reads.lens.numpy(), nm, wstop=8, ftab=True)
         stats = [dict(processed=int(r[0]), aligned=int(r[1]), steps=int(r[2]), candidates=int(r[3]), lookups=int(r[4]),
-                      ms=1.0, lds_bytes=0, lds_mode=0, group=i, kbits_log2=0) for i, r in enumerate(ref["stats"])]
+                      ms=1.0, lds_bytes=0, lds_mode=0, group=i, kbits_log2=0, pair_anchor=0) for i, r in enumerate(ref["stats"])]
         pc = torch.from_numpy(ref["stats"][:, :2].astype(np.int64).reshape(-1).copy())
         return _Result(torch.from_numpy(ref["pass_id"]), torch.from_numpy(ref["ref_id"]), torch.from_numpy(ref["pos"]),
                        torch.from_numpy(ref["mm"]), pc, stats, len(passes))

@@ -29,6 +29,7 @@ def run_gpu(engine, world, quant=None, **opts):
     # the match_kernel variants are exercised one launch per pass; the fused launches have their
     # own test below (and are what every default-option test in this file runs)
     opts.setdefault("fuse", 0)
+    opts.setdefault("pair_seeds", 0)   # (the anchor-pair search of the 2-mismatch pass: test_pair_seeds_*)
     for k, v in opts.items():
         engine.set_option(k, v)
     rs = ReadSet(world.words, world.lens, world.nmask, quant, device=engine.device)
@@ -136,6 +137,47 @@ def test_cascade_matches_exhaustive_scan(engine, world):
     for i, r in zip(sub, reads):
         got = None if pass_id[i] < 0 else (int(pass_id[i]), int(ref_id[i]), int(pos[i]), int(mm[i]))
         assert align.get(r) == got, r
+
+
+def test_pair_seeds_match_port_and_exhaustive_scan(engine, world):
+    """The 2-mismatch pass through the six anchor pairs (reads whose seed region holds four 4-base
+    anchors) and through the pigeonhole pieces (shorter ones) in one stratum_kernel launch: every
+    assignment equals the piece-only search's, the five counters equal the port's, which rebuilds
+    the pair tables from the suffix array and the text, and a sample equals the exhaustive scan."""
+    base = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask,
+                            wstop=DEFAULT_WSTOP, ftab=True)
+    for fuse in (0, 1):
+        _, res = run_gpu(engine, world, pair_seeds=1, fuse=fuse, wstop=DEFAULT_WSTOP, ftab=1)
+        st = res.stats
+        assert st[8]["pair_anchor"] == 4 and st[8]["lds_mode"] in (5, 6) and st[8]["n_launches"] == 1
+        assert all(s["pair_anchor"] == 0 for s in st[:8])
+        passes = [dict(p, kbits_log2=st[i]["kbits_log2"], pair_anchor=st[i]["pair_anchor"])
+                  for i, p in enumerate(world.passes)]
+        ref = model.fm_cascade(world.views, passes, world.words, world.lens, world.nmask, wstop=DEFAULT_WSTOP,
+                               ftab=True)
+        for k in ("pass_id", "ref_id", "pos", "mm"):
+            assert np.array_equal(base[k], ref[k]), k   # the pair search never changes an assignment
+        assert_same(res, ref)
+        # both routes ran: reads of >= 19 nt (16 seed bases after -5 1 -3 2) and shorter ones
+        assert int(ref["stats"][8][2]) > 0 and int(ref["stats"][8][4]) > int(base["stats"][8][4]) // 4
+    pass_id, ref_id, pos, mm = res.to_host()
+    sub = np.random.default_rng(6).choice(len(world.reads), 3000, replace=False)
+    reads = [world.reads[i] for i in sub]
+    libs = {k: model.Library(*world.libs.libs[k]) for k in LIB_ORDER}
+    seq_dic = {r: cascade.new_seq_record(r, 1) for r in reads}
+    log_dic = {"quantStats": [{}], "annotStats": []}
+    align = {}
+    cascade.run_annotation_pipeline(seq_dic, libs, log_dic, align_dic=align)
+    for i, r in zip(sub, reads):
+        got = None if pass_id[i] < 0 else (int(pass_id[i]), int(ref_id[i]), int(pos[i]), int(mm[i]))
+        assert align.get(r) == got, r
+    # the rows-compacted kernel on the piece search alone (every strata launch / the last stratum)
+    for mode in (2, 1):
+        _, res = run_gpu(engine, world, stratum_rows=mode, wstop=DEFAULT_WSTOP, ftab=1)
+        assert_same(res, base)
+        assert res.stats[8]["lds_mode"] in (5, 6) and res.stats[8]["n_launches"] == 2
+    engine.set_option("stratum_rows", 0)
+    engine.set_option("fuse", 1)
 
 
 def test_tally_matches_oracle(engine, world):
@@ -487,7 +529,7 @@ def test_long_reads_four_words(native_lib, oracle_lib):
         eng.add_library(k, w.index[k])
     res = eng.cascade(ReadSet(words, lens, nmask, None, device=eng.device), eng.mirge_passes())
     # default options: passes 1..7 run as fused launches with folded bitmaps (stats say which)
-    ref = model.fm_cascade(w.views, [dict(p, kbits_log2=st["kbits_log2"]) for p, st in zip(pass_dicts(), res.stats)],
+    ref = model.fm_cascade(w.views, [dict(p, kbits_log2=st["kbits_log2"], pair_anchor=st["pair_anchor"]) for p, st in zip(pass_dicts(), res.stats)],
                            words, lens, nmask, wstop=DEFAULT_WSTOP, ftab=True)
     assert any(st["lds_mode"] == 4 for st in res.stats)
     assert_same(res, ref)

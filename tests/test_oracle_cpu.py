@@ -95,6 +95,22 @@ def test_fm_port_equals_exhaustive_scan(world):
     assert all(int(res["stats"][i][1]) > 0 for i in range(9))
 
 
+def test_pair_seed_port_equals_piece_search(world):
+    """The 2-mismatch pass searched through anchor pairs (mrg_pass_stats.pair_anchor = 4) claims the
+    same reads at the same place as the stratum-first pigeonhole search, without an LF step for the
+    reads long enough to hold the four anchors."""
+    base = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask, wstop=8, ftab=True)
+    passes = [dict(p, pair_anchor=4 if p["max_mm_seed"] == 2 else 0) for p in world.passes]
+    alt = model.fm_cascade(world.views, passes, world.words, world.lens, world.nmask, wstop=8, ftab=True)
+    for k in ("pass_id", "ref_id", "pos", "mm"):
+        assert np.array_equal(base[k], alt[k]), k
+    assert np.array_equal(base["stats"][:, :2], alt["stats"][:, :2])
+    assert np.array_equal(base["stats"][:8], alt["stats"][:8])
+    # (at this library size -- 2.5 K bases -- an 8-base key is no sharper than a 6-base piece; at
+    # 84 K bases the pairs leave ~8 candidate rows per read against ~50, bench.py's passes[8])
+    assert int(alt["stats"][8][2]) < int(base["stats"][8][2])
+
+
 def test_search_shortcuts_do_not_change_results(world):
     base = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask)
     for wstop, ftab in ((1, False), (4, False), (64, False), (0, True), (2, True)):
