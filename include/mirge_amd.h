@@ -193,8 +193,9 @@ typedef struct mrg_pass_stats {
                           fused launch, 0 = no filter) */
   uint32_t pair_anchor; /* != 0: a 2-mismatch pass whose reads of at least 4 x pair_anchor seed bases
                           were searched through the six pairs of four anchors of that many bases
-                          (lookups = pair lookups, candidates = their rows, no LF steps); shorter
-                          reads went through the stratum-first pigeonhole pieces */
+                          (lookups = pair lookups, candidates = their rows, no LF steps), reads
+                          of at least 4 x (pair_anchor - 1) through anchors one base shorter;
+                          still shorter reads went through the stratum-first pigeonhole pieces */
 } mrg_pass_stats;
 
 /* Bytes of device workspace mrg_cascade_run needs for n reads. */

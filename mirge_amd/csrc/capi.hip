@@ -59,6 +59,8 @@ struct DevLib {
   uint64_t* pair_rows = nullptr;
   uint32_t pair_row_off[3] = {0, 0, 0};
   uint32_t pair_anchor = 0;
+  uint32_t* pair_jump_s = nullptr;        // second set: anchors of pair_anchor - 1 bases
+  uint32_t pair_row_off_s[3] = {0, 0, 0};  // (its row lists follow the first set's in pair_rows)
   uint32_t* kbits = nullptr;
   std::vector<uint32_t> kbits_host;  // host copy (32 KB): the per-round interleaved tables are built from it
   uint32_t* ftab = nullptr;
@@ -356,6 +358,7 @@ void mrg_ctx_destroy(mrg_ctx* ctx) {
     (void)hipFree(l.ctx);
     (void)hipFree(l.sa16);
     (void)hipFree(l.pair_jump);
+    (void)hipFree(l.pair_jump_s);
     (void)hipFree(l.pair_rows);
     (void)hipFree(l.kbits);
     (void)hipFree(l.seg_start);
@@ -380,7 +383,7 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
     DevLib* l;
     ~Guard() {
       if (!l) return;
-      void* ptrs[] = {l->blocks, l->super, l->text, l->sa, l->ftab, l->ctx, l->sa16, l->kbits, l->pair_jump, l->pair_rows,
+      void* ptrs[] = {l->blocks, l->super, l->text, l->sa, l->ftab, l->ctx, l->sa16, l->kbits, l->pair_jump, l->pair_jump_s, l->pair_rows,
                       l->seg_start, l->seg_ref, l->seg_off, l->chunk_seg};
       for (void* p : ptrs) (void)hipFree(p);
     }
@@ -434,15 +437,21 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
     }
   }
   if (ix.n <= mrg::kPairMaxBases && ix.n >= 4u * mrg::kPairAnchor && ctx->pair_seeds) {
-    mrg::PairTables pt;
+    mrg::PairTables pt, pt_s;
     try {
       mrg::build_pair_tables(ix, mrg::kPairAnchor, pt);
+      mrg::build_pair_tables(ix, mrg::kPairAnchor - 1u, pt_s);
     } catch (const std::exception& e) {
       return fail(MRG_ERR_ARG, "mrg_ctx_add_library: %s", e.what());
     }
     if ((rc = upload(&l.pair_jump, pt.jump))) return rc;
+    if ((rc = upload(&l.pair_jump_s, pt_s.jump))) return rc;
+    for (int t = 0; t < 3; ++t) {
+      l.pair_row_off[t] = pt.row_off[t];
+      l.pair_row_off_s[t] = pt.row_off[3] + pt_s.row_off[t];
+    }
+    pt.rows.insert(pt.rows.end(), pt_s.rows.begin(), pt_s.rows.end());
     if ((rc = upload(&l.pair_rows, pt.rows))) return rc;
-    for (int t = 0; t < 3; ++t) l.pair_row_off[t] = pt.row_off[t];
     l.pair_anchor = pt.anchor;
   }
   if (!ix.kbits.empty() && (rc = upload(&l.kbits, ix.kbits))) return rc;
@@ -707,7 +716,11 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     p.pair_anchor = by_pairs ? l.pair_anchor : 0u;
     p.pair_jump = l.pair_jump;
     p.pair_rows = l.pair_rows;
-    for (int t = 0; t < 3; ++t) p.pair_row_off[t] = l.pair_row_off[t];
+    p.pair_jump_s = l.pair_jump_s;
+    for (int t = 0; t < 3; ++t) {
+      p.pair_row_off[t] = l.pair_row_off[t];
+      p.pair_row_off_s[t] = l.pair_row_off_s[t];
+    }
     bool rows_lds_text = false;
     if (rows_kernel) {
       const uint64_t ov = (uint64_t)l.nsup * 16 + mrg::kStratumCtlBytes + (use_kbits ? kb_bytes : 0);

@@ -1401,10 +1401,18 @@ __global__ void __launch_bounds__(1024, (W == 1 ? 8 : 4)) stratum_kernel(const M
     };
 
     // ---------- reads that hold the four anchors: the six anchor pairs (fm_index.hpp) ----------
-    const uint32_t A = p.pair_anchor;
-    const bool by_pairs = searching && A != 0u && R >= (int32_t)(4u * A);
+    // anchor length of my read: pair_anchor when the seed region holds four of them, one base less
+    // (second table set) for the next shorter reads, 0 = pigeonhole pieces
+    uint32_t A = 0u;
+    if (searching && p.pair_anchor) {
+      if (R >= (int32_t)(4u * p.pair_anchor)) A = p.pair_anchor;
+      else if (p.pair_jump_s && R >= (int32_t)(4u * (p.pair_anchor - 1u))) A = p.pair_anchor - 1u;
+    }
+    const bool by_pairs = A != 0u;
     if (__ballot(by_pairs)) {
+      const bool second = A != p.pair_anchor;
       const uint32_t kb = 2u * A, amask = (1u << kb) - 1u, n_codes1 = (1u << (2u * kb)) + 1u;
+      const uint32_t* my_jump = second ? p.pair_jump_s : p.pair_jump;
       // Stratum first, as in the piece search: an exact alignment matches EVERY pair, so pair (0,1)
       // alone sees all of them; one mismatch leaves (0,1) or (2,3) clean, so after those two every
       // alignment with <= 1 mismatch has been seen.  A best hit below the bound is final and the
@@ -1421,13 +1429,14 @@ __global__ void __launch_bounds__(1024, (W == 1 ? 8 : 4)) stratum_kernel(const M
         uint32_t lo = 0, hi = 0;
         const uint32_t t = j - i - 1u;
         if (go) {
-          const uint32_t* tab = p.pair_jump + t * n_codes1 + (ai | (aj << kb));
-          lo = tab[0];
-          hi = tab[1];
+          const uint32_t* tab = my_jump + t * n_codes1 + (ai | (aj << kb));
+          const uint32_t roff = second ? p.pair_row_off_s[t] : p.pair_row_off[t];
+          lo = tab[0] + roff;
+          hi = tab[1] + roff;
           ++c_lookups;
         }
         c_cands += hi - lo;
-        sweep(p.pair_rows + p.pair_row_off[t], lo, hi - lo, i * A);
+        sweep(p.pair_rows, lo, hi - lo, i * A);  // (row lanes index the one array both sets live in)
         if (pr < 2u && (uint32_t)(best >> 56) <= pr) open_pairs = false;
         if (!__ballot(open_pairs)) break;
       }

@@ -83,6 +83,11 @@ struct MatchParams {
   const uint64_t* pair_rows;
   uint32_t pair_row_off[3];
   uint32_t pair_anchor;
+  // a second set with anchors one base shorter, for the reads between 4 (pair_anchor - 1) and
+  // 4 pair_anchor seed bases (16..18-nt reads under -5 1 -3 2: their three 4..5-base pigeonhole
+  // pieces match ~350 rows each in 88 kbp); null = none
+  const uint32_t* pair_jump_s;
+  uint32_t pair_row_off_s[3];  // into pair_rows as well (the second set's lists follow the first's)
 };
 
 // ---------------------------------------------------------------------------

@@ -39,10 +39,11 @@ typedef struct {
 /* Pair tables (mirge_amd/csrc/fm_index.hpp: PairTables), rebuilt here from the suffix array and
  * the text: table t (gap d = (t + 1) A) lists per 2A-base key the rows whose bases [p, p + A) and
  * [p + d, p + d + A) spell it and lie inside the row's N-free segment. */
-typedef struct {
+typedef struct orc_pairs {
   int anchor;
   uint32_t *jump[3];
   uint64_t *rows[3];
+  struct orc_pairs *shorter; /* tables with anchors one base shorter, for the next shorter reads */
 } orc_pairs;
 
 #define ODD 0x5555555555555555ull
@@ -146,6 +147,7 @@ static int match_one(const orc_lib *l, const orc_pass *p, const orc_pairs *pairs
   if (L <= p->max_mm_seed) return 0;
   int R = L < p->seed_len ? L : p->seed_len;
   int Kfull = p->max_mm_seed + 1;
+  if (pairs && R < 4 * pairs->anchor) pairs = pairs->shorter; /* (never NULL: see orc_run_cascade) */
   if (pairs && R >= 4 * pairs->anchor) {
     /* two mismatches touch at most two of the four anchors at 0, A, 2A, 3A: every alignment with
      * <= 2 seed mismatches matches one of the six anchor pairs exactly */
@@ -272,9 +274,12 @@ void orc_run_cascade(const orc_lib *libs, const orc_pass *passes, int n_pass, co
       kbits = folded;
       kb_mask = (1u << p->reserved) - 1u;
     }
-    orc_pairs pairs_store, *pairs = NULL;
+    orc_pairs pairs_store, pairs_short, *pairs = NULL;
     if (p->pair_anchor > 0 && p->max_mm_seed == 2 && !p->poly_t && p->seed_len >= 4 * p->pair_anchor) {
       pairs_build(l, p->pair_anchor, &pairs_store);
+      pairs_build(l, p->pair_anchor - 1, &pairs_short);
+      pairs_store.shorter = &pairs_short;
+      pairs_short.shorter = NULL;
       pairs = &pairs_store;
     }
 #pragma omp parallel for schedule(dynamic, 4096) reduction(+ : processed, aligned, steps, cands, lookups)
@@ -320,7 +325,10 @@ void orc_run_cascade(const orc_lib *libs, const orc_pass *passes, int n_pass, co
       }
     }
     free(folded);
-    if (pairs) pairs_free(pairs);
+    if (pairs) {
+      pairs_free(pairs->shorter);
+      pairs_free(pairs);
+    }
     stats[5 * pi + 0] = processed;
     stats[5 * pi + 1] = aligned;
     stats[5 * pi + 2] = steps;

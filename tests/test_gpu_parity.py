@@ -158,8 +158,9 @@ def test_pair_seeds_match_port_and_exhaustive_scan(engine, world):
         for k in ("pass_id", "ref_id", "pos", "mm"):
             assert np.array_equal(base[k], ref[k]), k   # the pair search never changes an assignment
         assert_same(res, ref)
-        # both routes ran: reads of >= 19 nt (16 seed bases after -5 1 -3 2) and shorter ones
-        assert int(ref["stats"][8][2]) > 0 and int(ref["stats"][8][4]) > int(base["stats"][8][4]) // 4
+        # reads of >= 19 nt (16 seed bases after -5 1 -3 2) through 4-base anchors, the 16..18-nt
+        # ones through 3-base anchors: no read of this world is left to the pieces, no LF step
+        assert int(ref["stats"][8][2]) == 0 and int(ref["stats"][8][4]) > int(base["stats"][8][4]) // 4
     pass_id, ref_id, pos, mm = res.to_host()
     sub = np.random.default_rng(6).choice(len(world.reads), 3000, replace=False)
     reads = [world.reads[i] for i in sub]
@@ -171,6 +172,34 @@ def test_pair_seeds_match_port_and_exhaustive_scan(engine, world):
     for i, r in zip(sub, reads):
         got = None if pass_id[i] < 0 else (int(pass_id[i]), int(ref_id[i]), int(pos[i]), int(mm[i]))
         assert align.get(r) == got, r
+    # reads too short for any anchor set (< 15 nt) take the pigeonhole pieces inside the same launch
+    from mirge_amd import pack
+    from mirge_amd.engine import ReadSet
+    rng = np.random.default_rng(11)
+    seqs = world.libs.libs["mirna"][1]
+    tiny = []
+    for _ in range(600):
+        s = seqs[int(rng.integers(0, len(seqs)))]
+        ln = int(rng.integers(12, 24))
+        o = int(rng.integers(0, len(s) - ln + 1))
+        r = list(s[o:o + ln])
+        for _ in range(int(rng.integers(0, 3))):
+            r[int(rng.integers(0, ln))] = "ACGT"[int(rng.integers(0, 4))]
+        tiny.append("".join(r))
+    tiny = list(dict.fromkeys(tiny))
+    tw, tl, tn = pack.pack_reads(tiny)
+    only8 = [dict(world.passes[8], lib=0)]
+    eng8_passes = engine.make_passes([dict(world.passes[8], lib="mirna")])
+    engine.set_option("pair_seeds", 1)
+    res8 = engine.cascade(ReadSet(tw, tl, tn, None, device=engine.device), eng8_passes)
+    ref8 = model.fm_cascade([world.views[LIB_ORDER.index("mirna")]], [dict(only8[0], pair_anchor=res8.stats[0]["pair_anchor"])],
+                            tw, tl, tn, wstop=DEFAULT_WSTOP, ftab=True)
+    plain8 = model.fm_cascade([world.views[LIB_ORDER.index("mirna")]], only8, tw, tl, tn, wstop=DEFAULT_WSTOP, ftab=True)
+    assert res8.stats[0]["pair_anchor"] == 4
+    assert_same(res8, ref8)
+    for k in ("pass_id", "ref_id", "pos", "mm"):
+        assert np.array_equal(plain8[k], ref8[k]), k
+    assert int(ref8["stats"][0][2]) > 0 and int(ref8["stats"][0][1]) > 100   # pieces ran (LF steps), reads aligned
     # the rows-compacted kernel on the piece search alone (every strata launch / the last stratum)
     for mode in (2, 1):
         _, res = run_gpu(engine, world, stratum_rows=mode, wstop=DEFAULT_WSTOP, ftab=1)
