@@ -151,7 +151,14 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * stored text context (default 32); "fuse" = 0 one launch per pass, 1 (default)
  * consecutive passes with at most one seed mismatch after the first launched pass share one
  * fused launch per run of small (bitmap-filtered) / large libraries, 2 = one group regardless of
- * library size, 3 = only the small-library runs are fused. */
+ * library size, 3 = only the small-library runs are fused; "pair_seeds" = 1 (default) / 0: a pass
+ * with two seed mismatches on a library of at most 4 Mbp searches reads of at least 15 nt (after
+ * -5 / -3) through the six pairs of four anchors instead of three pigeonhole pieces (the pair tables
+ * are built by mrg_ctx_add_library: set 0 BEFORE adding libraries to save their memory, or at any
+ * time to run the piece search); "split_strata" = 1 (default) / 0: such a pass, when it does run the
+ * piece search, is launched as strata 1-2 and stratum 3 separately; "stratum_rows" = 0 (default) /
+ * 1 / 2: that piece search in stratum_kernel (rows compacted over the wave) for the last stratum /
+ * every strata launch; "wide_rows_16", "round_large": see DESIGN.md. */
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);
 int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,
                         char *arch, uint32_t arch_cap);

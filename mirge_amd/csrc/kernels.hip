@@ -706,13 +706,18 @@ __device__ __forceinline__ uint32_t owner_of(uint32_t incl, uint32_t x) {
   return o;
 }
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t up = __shfl_up(v, d, 64);
-    if ((int)lane >= d) v += up;
-  }
-  return v;
+// inclusive prefix sum over the wave with DPP adds (no LDS traffic): row_shr 1..3 of the input,
+// row_shr 4 / 8 inside each row of 16 lanes, then lane 15 / lane 31 broadcast into the next row(s)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t /*lane*/) {
+  const int x = (int)v;
+  int s = x + __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  s += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);         // row_shr:2
+  s += __builtin_amdgcn_update_dpp(0, x, 0x113, 0xf, 0xf, false);         // row_shr:3
+  s += __builtin_amdgcn_update_dpp(0, s, 0x114, 0xf, 0xe, false);         // row_shr:4, lanes 4-15 of a row
+  s += __builtin_amdgcn_update_dpp(0, s, 0x118, 0xf, 0xc, false);         // row_shr:8, lanes 8-15
+  s += __builtin_amdgcn_update_dpp(0, s, 0x142, 0xa, 0xf, false);         // row_bcast:15 into rows 1 and 3
+  s += __builtin_amdgcn_update_dpp(0, s, 0x143, 0xc, 0xf, false);         // row_bcast:31 into rows 2 and 3
+  return (uint32_t)s;
 }
 
 // bits 0..3 of x to bits 0, 16, 32, 48
@@ -1759,7 +1764,9 @@ __global__ void __launch_bounds__(kTallyThreads) tally_kernel(const TallyParams 
       if (LDSH) {
         if (lane == 0) atomicAdd(&hist[l_uniq0 + s], (unsigned long long)__popcll(hits));
         if (hit) atomicAdd(&hist[l_cat0 + (cat * S + s) * R + rep], q);
-        if (hit && (canon || iso)) atomicAdd(&hist[ref * S + s], q);
+        // one LDS atomic per read: a canonical read goes to the iscan bin only, quant = iscan + isomiR
+        // reads is formed at the flush
+        if (hit && iso && !canon) atomicAdd(&hist[ref * S + s], q);
         if (hit && canon) atomicAdd(&hist[M * S + ref * S + s], q);
       } else {
         if (lane == 0) atomicAdd(&g[uniq0 + s], (unsigned long long)__popcll(hits));
@@ -1775,6 +1782,7 @@ __global__ void __launch_bounds__(kTallyThreads) tally_kernel(const TallyParams 
       unsigned long long v = 0ull;
       if (i < cat0) {
         v = hist[i];
+        if (i < M * S) v += hist[M * S + i];
       } else if (i < uniq0) {
         const unsigned long long* src = hist + l_cat0 + (size_t)(i - cat0) * R;
         for (uint32_t q = 0; q < R; ++q) v += src[q];

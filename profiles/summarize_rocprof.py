@@ -25,6 +25,9 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+CASCADE_KERNELS = ("match_kernel", "fused_kernel", "stratum_kernel")   # one launch per entry of the bench line's plan
+
+
 def newest(pattern):
     files = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
     return files[-1] if files else None
@@ -66,7 +69,7 @@ def label_dispatches(keys, bench):
             plan.append([(x[0], x[1] + (" part %d/%d" % (part + 1, n) if n > 1 else ""), x[2]) for x in g])
     out, at = {}, 0
     for k in keys:
-        if "match_kernel" not in k[1] and "fused_kernel" not in k[1]:
+        if not any(name in k[1] for name in CASCADE_KERNELS):
             continue
         group = plan[at % len(plan)]
         at += 1
@@ -135,7 +138,7 @@ def main():
             wmap[k[1]].append(v.get("WRITE_SIZE", 0.0))
         seen = collections.Counter()
         for k, v in fetch.items():
-            if "match_kernel" not in k[1] and "fused_kernel" not in k[1] and "tally" not in k[1]:
+            if not any(name in k[1] for name in CASCADE_KERNELS) and "tally" not in k[1]:
                 continue
             f_kib = v.get("FETCH_SIZE", 0.0)
             wl = wmap.get(k[1], [])
