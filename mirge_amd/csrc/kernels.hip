@@ -695,7 +695,8 @@ __device__ __forceinline__ uint32_t wide_row_mismatches(const uint64_t (&rd)[W],
   return mm;
 }
 
-// first lane whose inclusive prefix exceeds x (x < total): six shuffles
+// first lane whose inclusive prefix exceeds x (x < total): six shuffles (stratum_kernel, whose 64
+// registers have no room for the owner map below)
 __device__ __forceinline__ uint32_t owner_of(uint32_t incl, uint32_t x) {
   uint32_t o = 0;
 #pragma unroll
@@ -706,8 +707,38 @@ __device__ __forceinline__ uint32_t owner_of(uint32_t incl, uint32_t x) {
   return o;
 }
 
-// inclusive prefix sum over the wave with DPP adds (no LDS traffic): row_shr 1..3 of the input,
-// row_shr 4 / 8 inside each row of 16 lanes, then lane 15 / lane 31 broadcast into the next row(s)
+// Which lane owns element x of a compaction sweep, without a search.  Per wave 128 bytes of LDS:
+// r2l[rank] = lane of the rank-th lane that has elements (written once per sweep), ends[b] = 1 when
+// some lane's LAST element is element rb + b of the current batch of 64.  The owner of element rb + b
+// is the first such lane whose elements end at or after it = the lane of rank (owners finished in
+// earlier batches) + (ends flagged strictly before b): two byte stores, two byte loads, a ballot
+// and a lane-masked bit count instead of six dependent shuffles.
+struct OwnerMap {
+  uint8_t* ends;
+  uint8_t* r2l;
+  uint32_t done;  // owners whose elements ended in earlier batches (wave-uniform)
+  __device__ __forceinline__ void begin(bool nonempty, uint32_t lane) {
+    const uint64_t m = __ballot(nonempty);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (nonempty) r2l[rank] = (uint8_t)lane;
+    done = 0u;
+  }
+  // incl = inclusive prefix of my element count, rb = first element of the batch
+  __device__ __forceinline__ uint32_t find(bool nonempty, uint32_t incl, uint32_t rb, uint32_t lane) {
+    ends[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t e = incl - 1u - rb;  // my last element, relative to the batch (wraps when before it)
+    if (nonempty && e < 64u) ends[e] = 1;
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t m = __ballot(ends[lane] != 0);
+    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    const uint32_t o = r2l[min(done + before, 63u)];
+    done += (uint32_t)__popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    return o;
+  }
+};
+
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t /*lane*/) {
   const int x = (int)v;
   int s = x + __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
@@ -737,6 +768,7 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
   uint4* slots = reinterpret_cast<uint4*>(stab + kMaxFused * kSubWords);  // 64 per wave
   unsigned long long* cnt64 = reinterpret_cast<unsigned long long*>(slots + BLOCK);
   uint32_t* ctl = reinterpret_cast<uint32_t*>(cnt64 + kMaxFused * 3u * kFusedCntReplicas);
+  uint8_t* omap_lds = reinterpret_cast<uint8_t*>(ctl + 4);  // 128 B per wave
   for (uint32_t s = 0; s < p.n_sub; ++s) {
     const SubPass& sp = p.sub[s];
     if (sp.text_lds_words) {
@@ -798,6 +830,10 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
 
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint4* my_slots = slots + wave * 64u;
+  OwnerMap omap;
+  omap.ends = omap_lds + (uint32_t)__builtin_amdgcn_readfirstlane((int)wave) * 128u;  // wave-uniform: scalar registers
+  omap.r2l = omap.ends + 64u;
+  omap.done = 0u;
   unsigned long long* my_slot_keys = reinterpret_cast<unsigned long long*>(my_slots);  // key of slot i at [2 i]
   const bool has_nm = p.nmask != nullptr;
   const uint32_t in_nseg = p.idx_in ? p.in_nseg : 1u;
@@ -949,10 +985,16 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
       uint64_t q_best = ~0ull;    // best result inside the sub-pass being replayed
       uint32_t q_cur = kNoQ;
 
+      OwnerMap imap = omap;  // (the rows sweeps below use the same LDS bytes between two item batches)
+      imap.done = 0u;
       for (uint32_t base = 0; base < total; base += 64u) {
         const uint32_t item = base + lane;
         const bool has_item = item < total;
-        uint32_t o = owner_of(incl, item);
+        // (re-register: the rows sweeps of the previous batch overwrote the rank table)
+        const uint32_t i_done = imap.done;
+        imap.begin(cnt != 0u, lane);
+        imap.done = i_done;
+        uint32_t o = imap.find(cnt != 0u, incl, base, lane);
         o = has_item ? o : lane;
         const uint32_t o_excl = __shfl(excl, (int)o, 64);
         uint32_t o_need = __shfl(need, (int)o, 64);
@@ -1039,10 +1081,11 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
           const uint32_t w = min(rem, kRowSlice);
           const uint32_t rincl = wave_incl_scan(w, lane);
           const uint32_t rtotal = __shfl(rincl, 63, 64);
+          omap.begin(w != 0u, lane);
           for (uint32_t rb = 0; rb < rtotal; rb += 64u) {
             const uint32_t x = rb + lane;
             const bool has_row = x < rtotal;
-            uint32_t t = owner_of(rincl, x);
+            uint32_t t = omap.find(w != 0u, rincl, rb, lane);
             t = has_row ? t : lane;
             const uint32_t t_incl = __shfl(rincl, (int)t, 64), t_w = __shfl(w, (int)t, 64);
             const uint32_t t_lo = __shfl(lo, (int)t, 64);

@@ -161,7 +161,7 @@ struct FusedParams {
 // LDS bytes of a fused launch besides the bitmaps: sub-pass table + one 16-byte result slot per
 // thread + counters + control words + wave slots
 constexpr uint32_t fused_fixed_lds_bytes() {
-  return kMaxFused * 40u * 4u + 1024u * 16u + kMaxFused * 3u * kFusedCntReplicas * 8u + 16u;
+  return kMaxFused * 40u * 4u + 1024u * 16u + kMaxFused * 3u * kFusedCntReplicas * 8u + 16u + 16u * 128u;  // + owner maps
 }
 // a sub-pass needs two bits of the per-lane item mask: at most this many sub-passes per round
 constexpr uint32_t kMaxRoundSubs = 8u;
