@@ -61,7 +61,7 @@ def extended_bytes(s):
 def kernel_name(W, table_row, s, n_bases):
     """The instantiation rocprofv3 names for the launch pass `s` ran in."""
     if s["lds_mode"] == 4:
-        return "mrg::fused_kernel<%d>" % W
+        return "mrg::fused_kernel<%d, false>" % W   # (launch_table switches to <W, true> when a member carries pair tables)
     if s["lds_mode"] in (5, 6):
         return "mrg::stratum_kernel<%d>" % W
     has_ctx = n_bases >= (1 << 20) and s["lds_mode"] in (0, 1)
@@ -86,6 +86,8 @@ def launch_table(st, per_pass_ms, table, index, W):
                      kernel=kernel_name(W, table[i], s, index[table[i][0]].info.n_bases))
             launches.append(L)
         L["passes"].append(i)
+        if s["lds_mode"] == 4 and s.get("pair_anchor"):
+            L["kernel"] = "mrg::fused_kernel<%d, true>" % W
         L["ms"] += float(per_pass_ms[i])
         L["processed"] += s["processed"]
         L["steps"] += s["steps"]

@@ -61,6 +61,13 @@ struct DevLib {
   uint32_t pair_anchor = 0;
   uint32_t* pair_jump_s = nullptr;        // second set: anchors of pair_anchor - 1 bases
   uint32_t pair_row_off_s[3] = {0, 0, 0};  // (its row lists follow the first set's in pair_rows)
+  // pair tables of a large library (pairs.hip), built on the device the first time a one-mismatch
+  // sub-pass of a fused launch meets reads with short seed regions: three anchors, gaps A and 2A
+  uint32_t* bpair_jump = nullptr;
+  uint64_t* bpair_rows = nullptr;
+  uint32_t bpair_row_off[3] = {0, 0, 0};
+  uint32_t bpair_anchor = 0;
+  bool bpair_failed = false;  // not enough free HBM: the pigeonhole pieces stay
   uint32_t* kbits = nullptr;
   std::vector<uint32_t> kbits_host;  // host copy (32 KB): the per-round interleaved tables are built from it
   uint32_t* ftab = nullptr;
@@ -153,6 +160,7 @@ struct mrg_ctx {
   int64_t fuse = 1;
   int64_t round_large = 0;
   int64_t split_strata = 1;
+  int64_t pair_big = 5;      // anchor length of the pair tables of large libraries (one-mismatch sub-passes of fused launches, reads with 3A..4A-1 seed bases); 0 = off
   int64_t pair_seeds = 1;    // 2-mismatch passes on small libraries search through anchor pairs (set before add_library)
   int64_t stratum_rows = 0;  // (measured slower than match_kernel: 2.43 vs 2.28 ms) 1: the last stratum of a split 2-mismatch pass runs stratum_kernel; 2: every strata launch does
   int64_t wide_rows_16 = 1;  // libraries of >= 2^20 bases get 16-byte rows with 32 bases of context
@@ -360,6 +368,8 @@ void mrg_ctx_destroy(mrg_ctx* ctx) {
     (void)hipFree(l.pair_jump);
     (void)hipFree(l.pair_jump_s);
     (void)hipFree(l.pair_rows);
+    (void)hipFree(l.bpair_jump);
+    (void)hipFree(l.bpair_rows);
     (void)hipFree(l.kbits);
     (void)hipFree(l.seg_start);
     (void)hipFree(l.seg_ref);
@@ -496,6 +506,9 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->use_ftab = value != 0;
   } else if (k == "split_strata") {
     ctx->split_strata = value != 0;
+  } else if (k == "pair_big") {
+    if (value != 0 && (value < 4 || value > 7)) return fail(MRG_ERR_ARG, "pair_big must be 0 or in [4,7]");
+    ctx->pair_big = value;
   } else if (k == "pair_seeds") {
     ctx->pair_seeds = value != 0;
   } else if (k == "stratum_rows") {
@@ -825,6 +838,50 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
       sp.max_len = c.max_len;
       sp.poly_t = c.poly_t;
       sp.pass_index = (int32_t)i;
+      sp.pair_anchor = 0u;
+      {
+        // reads whose seed region is 3A .. 4A - 1 bases: three anchor pairs instead of two pieces of
+        // less than 2A bases (tables built on the device at first use, pairs.hip)
+        const int64_t A = ctx->pair_big;
+        const int64_t r_min = std::min<int64_t>(std::max<int64_t>(ctx->hint_min_len, c.min_len) - c.trim5 - c.trim3, c.seed_len);
+        const int64_t r_max = std::min<int64_t>(std::min<int64_t>(ctx->hint_max_len, c.max_len) - c.trim5 - c.trim3, c.seed_len);
+        if (A && c.max_mm_seed == 1 && !c.poly_t && l.n >= mrg::kWideRowMinBases && !ctx->round_large && r_min < 4 * A &&
+            r_max >= 3 * A) {
+          DevLib& lm = ctx->libs[c.lib];
+          if (lm.bpair_anchor != (uint32_t)A && !lm.bpair_failed) {
+            (void)hipFree(lm.bpair_jump);
+            (void)hipFree(lm.bpair_rows);
+            lm.bpair_jump = nullptr;
+            lm.bpair_rows = nullptr;
+            lm.bpair_anchor = 0;
+            const uint64_t n_rows = (uint64_t)lm.n + 1, n_codes1 = (1ull << (4u * (uint32_t)A)) + 1ull;
+            const uint64_t need = 2 * n_codes1 * 4 + 2 * n_rows * 8 + 4 * n_rows * 4 + (256ull << 20);
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            if (free_b < need || hipMalloc((void**)&lm.bpair_jump, 2 * n_codes1 * 4) != hipSuccess ||
+                hipMalloc((void**)&lm.bpair_rows, 2 * n_rows * 8) != hipSuccess ||
+                mrg::build_pair_tables_device(lm.sa, lm.text, (uint32_t)n_rows, (uint32_t)A, 2, lm.bpair_jump, lm.bpair_rows,
+                                              lm.bpair_row_off, stream) != hipSuccess) {
+              (void)hipGetLastError();
+              (void)hipFree(lm.bpair_jump);
+              (void)hipFree(lm.bpair_rows);
+              lm.bpair_jump = nullptr;
+              lm.bpair_rows = nullptr;
+              lm.bpair_failed = true;
+            } else {
+              lm.bpair_anchor = (uint32_t)A;
+            }
+          }
+          if (lm.bpair_anchor == (uint32_t)A) {
+            sp.pair_jump = lm.bpair_jump;
+            sp.pair_rows = lm.bpair_rows;
+            sp.pair_row_off[0] = lm.bpair_row_off[0];
+            sp.pair_row_off[1] = lm.bpair_row_off[1];
+            sp.pair_anchor = (uint32_t)A;
+          }
+        }
+      }
+      ctx->last_pair_anchor[i] = sp.pair_anchor;
       ctx->last_lds[i] = 0u;
       ctx->last_mode[i] = 4u;
       ctx->last_group[i] = members[0];

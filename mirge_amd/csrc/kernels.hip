@@ -758,7 +758,9 @@ __device__ __forceinline__ uint64_t spread4(uint32_t x) {
 
 }  // namespace
 
-template <int W>
+// PAIRS: a one-mismatch sub-pass on a large library may carry pair tables (kernels.hpp: SubPass);
+// a separate instantiation so that launches without them keep the plain piece items.
+template <int W, bool PAIRS>
 __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   constexpr uint32_t BLOCK = 1024u;
@@ -904,6 +906,7 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
     int32_t g_R = -1, g_t5 = -1;
     uint32_t g_pm = 0;   // bits 0-7 piece 0 of two, 8-15 piece 1 of two, 16-23 the whole region
     uint32_t g_nn = 0;   // bit 0 / 8 / 16: that piece holds no N (sub-passes without a table)
+    uint32_t g_pa = 0;   // pair-searched sub-pass: bit pr = both anchors of pair pr hold no N
 #pragma unroll 1
     for (uint32_t rnd = 0; rnd < p.n_rounds; ++rnd) {
       const uint32_t s0 = p.round_first[rnd], ns = p.round_count[rnd];
@@ -943,6 +946,12 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
           const int32_t h = R >> 1;  // pieces [0, h), [h, R) and the whole [0, R)
           const bool n0 = has_nm && piece_has_n<W>(nm, 0, h), n1 = has_nm && piece_has_n<W>(nm, h, R);
           g_nn = (n0 ? 0u : 1u) | (n1 ? 0u : 1u << 8) | ((n0 || n1) ? 0u : 1u << 16);
+          if (PAIRS && sp.pair_anchor) {
+            const int32_t A = (int32_t)sp.pair_anchor;
+            const bool a0 = has_nm && piece_has_n<W>(nm, 0, A), a1 = has_nm && piece_has_n<W>(nm, A, 2 * A),
+                       a2 = has_nm && piece_has_n<W>(nm, 2 * A, 3 * A);
+            g_pa = ((a0 || a1) ? 0u : 1u) | ((a1 || a2) ? 0u : 2u) | ((a0 || a2) ? 0u : 4u);
+          }
           uint32_t mF = 0xFFu, mL = 0xFFu, m0L = 0xFFu, m1F = 0xFFu;
           if (kb_log2) {
             const uint32_t cmask = (1u << kb_log2) - 1u, emask = (1u << kb_bits) - 1u;
@@ -966,13 +975,17 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
         // this sub-pass's view: bit 0 / 8 / 16 = piece 0 / piece 1 / whole region goes to the index
         const uint32_t m = sp.kb_bit != 0xFFu ? (g_pm >> sp.kb_bit) : g_nn;
         const uint32_t gb = go ? 1u : 0u;
-        if (sp.max_mm_seed == 0) {
+        if (PAIRS && sp.pair_anchor && R >= 3 * (int32_t)sp.pair_anchor && R < 4 * (int32_t)sp.pair_anchor) {
+          // three anchor pairs instead of two short pieces (the sub-pass is alone in its round: bits 0-2)
+          need |= go ? g_pa : 0u;
+        } else if (sp.max_mm_seed == 0) {
           need |= (gb & (m >> 16)) << (2u * q);
         } else {
           need |= ((gb & m) | ((gb & (m >> 8)) << 1)) << (2u * q);
         }
       }
 
+      const bool pair_round = PAIRS && ns == 1u && p.sub[s0].pair_anchor != 0u;
       // ================= phase B: compact the items of the wave, one item per lane =================
       const uint32_t cnt = (uint32_t)__popc(need);
       const uint32_t incl = wave_incl_scan(cnt, lane);
@@ -1010,7 +1023,8 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
           for (uint32_t jj = item - o_excl; jj > 0; --jj) o_need &= o_need - 1u;
           combo = (uint32_t)__ffs((int)o_need) - 1u;
         }
-        const uint32_t q = combo >> 1, kpiece = combo & 1u;
+        // (a pair-searched sub-pass is alone in its round: its item bits 0-2 are the item number)
+        const uint32_t q = pair_round ? 0u : combo >> 1, kpiece = pair_round ? combo : combo & 1u;
         const uint32_t* tab = stab + (s0 + q) * kSubWords;
         const uint32_t polw = tab[SW_POLICY], trimw = tab[SW_TRIMS];
         uint32_t c_steps = 0, lo = 0, hi = 0, nb_na = 0;
@@ -1025,6 +1039,19 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
           }
           const int32_t R = min(L, (int32_t)(polw & 0xFFFFu));
           const int32_t K = (int32_t)((polw >> 16) & 0xFFu) + 1;
+          const uint32_t pA = pair_round ? p.sub[s0].pair_anchor : 0u;
+          if (PAIRS && pA && R >= 3 * (int32_t)pA && R < 4 * (int32_t)pA) {
+            // anchor pair kpiece = (0,1) (1,2) (0,2): one load of the gap's jump table
+            const uint32_t ia = kpiece == 1u ? 1u : 0u, ja = kpiece == 0u ? 1u : 2u, t = ja - ia - 1u;
+            const uint32_t kb = 2u * pA;
+            const uint32_t vi = read_bits32<W>(rd, ia * pA, pA), vj = read_bits32<W>(rd, ja * pA, pA);
+            const uint32_t* ft = p.sub[s0].pair_jump + (size_t)t * ((1ull << (2u * kb)) + 1ull) + (vi | (vj << kb));
+            const uint32_t roff = p.sub[s0].pair_row_off[t];
+            lo = ft[0] + roff;
+            hi = ft[1] + roff;
+            c_steps = 0x80000000u;
+            nb_na = (ia * pA) | ((uint32_t)(L - (int32_t)(ia * pA)) << 8) | (pA << 16) | (1u << 24);  // bit 24: rows of the pair lists
+          } else {
           const int32_t a = div_pieces(R * (int32_t)kpiece, K), b = div_pieces(R * ((int32_t)kpiece + 1), K);
           hi = tab[SW_N] + 1u;
           int32_t j = b;
@@ -1070,6 +1097,7 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
             }
           }
           nb_na = (uint32_t)j | ((uint32_t)(L - j) << 8) | ((uint32_t)min(b - j, 255) << 16);  // + exactly matched bases
+          }
         }
         uint32_t rem = (has_item && hi > lo) ? hi - lo : 0u;
         // result slot of my item: key = mm:8 | text position:32 | segment:16 | before:8 (all ones = none)
@@ -1107,12 +1135,19 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
               pol.max_mm_total = (int32_t)(tpol >> 24);
               pol.nmask = p.nmask;
               const uint32_t i = t_lo + (x - (t_incl - t_w));
-              const uint32_t need_before = t_nbna & 0xFFu, need_after = (t_nbna >> 8) & 0xFFu, exact_part = t_nbna >> 16;
+              const uint32_t need_before = t_nbna & 0xFFu, need_after = (t_nbna >> 8) & 0xFFu, exact_part = (t_nbna >> 16) & 0xFFu;
               uint64_t row = 0ull;
               uint64_t best = ~0ull;
               uint32_t best_seg = 0xFFFFu, best_before = 255u;
               const uint4* sa16 = reinterpret_cast<const uint4*>(lds_ptr(ttab, SW_SA16));
-              if (sa16) {
+              if (PAIRS && (t_nbna >> 24)) {
+                // a row of a pair list (8-byte row: the text decides)
+                row = p.sub[s0].pair_rows[i];
+                ItemLib lib;
+                lib.gtext = reinterpret_cast<const uint32_t*>(lds_ptr(ttab, SW_TEXT));
+                lib.stext = nullptr;
+                verify_row<W>(lib, pol, row, t_rd, t_nm, t_L, need_before, need_after, best, best_seg, best_before);
+              } else if (sa16) {
                 // large library: one 16-byte load = the row and 32 bases around the seed; a false
                 // candidate (nearly all of them) never asks for its text window
                 const uint4 wr = sa16[i];
@@ -1167,7 +1202,7 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
           for (uint32_t it = first; it < last; ++it) {
             const uint32_t cb = (uint32_t)__ffs((int)bits) - 1u;
             bits &= bits - 1u;
-            const uint32_t iq = cb >> 1, ik = cb & 1u;
+            const uint32_t iq = pair_round ? 0u : cb >> 1, ik = pair_round ? cb : cb & 1u;
             const uint4 sv = my_slots[it - base];
             if (iq != q_cur) {
               // the previous sub-pass is complete: did it claim the read?
@@ -1179,7 +1214,7 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
               q_best = ~0ull;
             }
             if (win_q != kNoQ) continue;                       // claimed before this sub-pass: never issued
-            if (ik == 1u && (q_best >> 56) == 0ull) continue;  // piece 0 was exact: piece 1 never issued
+            if (ik >= 1u && (q_best >> 56) == 0ull) continue;  // piece / pair 0 was exact: the others never issued
             const uint64_t key = (uint64_t)sv.x | ((uint64_t)sv.y << 32);
             q_best = min(q_best, key);
             unsigned long long* c64 =
@@ -2125,9 +2160,9 @@ hipError_t launch_stratum(const MatchParams& p, uint32_t words_per_read, bool ld
 
 hipError_t launch_fused(const FusedParams& p, uint32_t words_per_read, uint32_t grid, uint32_t lds_bytes,
                         hipStream_t stream) {
-#define MRG_FUSED(W_)                                                                                   \
+#define MRG_FUSED_K(W_, P_)                                                                             \
   {                                                                                                     \
-    auto kern = fused_kernel<W_>;                                                                       \
+    auto kern = fused_kernel<W_, P_>;                                                                   \
     if (lds_bytes > 48 * 1024) {                                                                        \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                           \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);   \
@@ -2135,12 +2170,18 @@ hipError_t launch_fused(const FusedParams& p, uint32_t words_per_read, uint32_t 
     }                                                                                                   \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds_bytes, stream, p);                             \
   }
+#define MRG_FUSED(W_)                 \
+  if (pairs) MRG_FUSED_K(W_, true)    \
+  else MRG_FUSED_K(W_, false)
+  bool pairs = false;
+  for (uint32_t q = 0; q < p.n_sub; ++q) pairs |= p.sub[q].pair_anchor != 0u;
   switch (words_per_read) {
     case 1: MRG_FUSED(1) break;
     case 2: MRG_FUSED(2) break;
     case 4: MRG_FUSED(4) break;
     default: return hipErrorInvalidValue;
   }
+#undef MRG_FUSED_K
 #undef MRG_FUSED
   return hipGetLastError();
 }

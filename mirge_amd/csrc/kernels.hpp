@@ -109,6 +109,14 @@ struct SubPass {
   const uint64_t* sa;
   const uint32_t* ctx;    // row context of a large library (null otherwise)
   const uint4* sa16;      // wide rows of a large library (null otherwise): row, 16 bases left, 16 bases from +8
+  // pair tables of a large library (pairs.hip), pair_anchor = A = 0: none.  A one-mismatch sub-pass
+  // alone in its round searches the reads whose seed region is 3A .. 4A - 1 bases (two pigeonhole
+  // pieces of less than 2A bases) through the three anchor pairs (0,1) (1,2) (0,2) instead;
+  // fused_kernel<W, true> only.
+  const uint32_t* pair_jump;
+  const uint64_t* pair_rows;
+  uint32_t pair_row_off[2];
+  uint32_t pair_anchor;
   const uint32_t* ftab;
   const uint32_t* seg_start;
   const uint32_t* seg_ref;
@@ -167,7 +175,11 @@ constexpr uint32_t fused_fixed_lds_bytes() {
 constexpr uint32_t kMaxRoundSubs = 8u;
 
 hipError_t launch_fused(const FusedParams& p, uint32_t words_per_read, uint32_t grid, uint32_t lds_bytes,
-                        hipStream_t stream);
+                        hipStream_t stream);  // (the anchor-pair instantiation when a sub-pass has pair tables)
+// pairs.hip: pair tables of a large library from its device-resident suffix array and text
+hipError_t build_pair_tables_device(const uint64_t* sa, const uint32_t* text, uint32_t n_rows, uint32_t anchor,
+                                    uint32_t n_gaps, uint32_t* jump, uint64_t* rows, uint32_t* row_off,
+                                    hipStream_t stream);
 
 constexpr uint32_t kCountThreads = 256u;
 

@@ -40,7 +40,7 @@ typedef struct {
  * the text: table t (gap d = (t + 1) A) lists per 2A-base key the rows whose bases [p, p + A) and
  * [p + d, p + d + A) spell it and lie inside the row's N-free segment. */
 typedef struct orc_pairs {
-  int anchor;
+  int anchor, n_anchors; /* four anchors: two seed mismatches; three: one (reads of 3A .. 4A - 1 seed bases only) */
   uint32_t *jump[3];
   uint64_t *rows[3];
   struct orc_pairs *shorter; /* tables with anchors one base shorter, for the next shorter reads */
@@ -103,12 +103,15 @@ static void verify_one(const orc_lib *l, const orc_pass *p, uint64_t row, int j,
   if (cand < *best) *best = cand;
 }
 
-static void pairs_build(const orc_lib *l, int anchor, orc_pairs *pt) {
+static void pairs_build(const orc_lib *l, int anchor, int n_anchors, orc_pairs *pt) {
   const int kb = 2 * anchor;
   const uint64_t amask = (1ull << kb) - 1ull;
   const size_t n_codes = (size_t)1 << (2 * kb), n_rows = (size_t)l->n + 1;
   pt->anchor = anchor;
-  for (int t = 0; t < 3; ++t) {
+  pt->n_anchors = n_anchors;
+  pt->shorter = NULL;
+  for (int t = 0; t < 3; ++t) pt->jump[t] = NULL, pt->rows[t] = NULL;
+  for (int t = 0; t + 1 < n_anchors; ++t) {
     const uint32_t d = (uint32_t)(t + 1) * (uint32_t)anchor;
     uint32_t *jump = (uint32_t *)calloc(n_codes + 1, 4), *fill = (uint32_t *)malloc(n_codes * 4);
     for (int sweep = 0; sweep < 2; ++sweep) {
@@ -132,6 +135,7 @@ static void pairs_build(const orc_lib *l, int anchor, orc_pairs *pt) {
 }
 
 static void pairs_free(orc_pairs *pt) {
+  if (!pt) return;
   for (int t = 0; t < 3; ++t) {
     free(pt->jump[t]);
     free(pt->rows[t]);
@@ -147,7 +151,40 @@ static int match_one(const orc_lib *l, const orc_pass *p, const orc_pairs *pairs
   if (L <= p->max_mm_seed) return 0;
   int R = L < p->seed_len ? L : p->seed_len;
   int Kfull = p->max_mm_seed + 1;
-  if (pairs && R < 4 * pairs->anchor) pairs = pairs->shorter; /* (never NULL: see orc_run_cascade) */
+  if (pairs && pairs->n_anchors == 3) {
+    /* one seed mismatch: reads whose two pigeonhole pieces would be shorter than 2A bases go through
+     * the three pairs of three anchors -- (0,1) first: it sees every exact alignment */
+    if (R >= 3 * pairs->anchor && R < 4 * pairs->anchor) {
+      static const int PI3[3] = {0, 1, 0}, PJ3[3] = {1, 2, 2};
+      const int A = pairs->anchor, kb = 2 * A;
+      const uint64_t amask = (1ull << kb) - 1ull;
+      for (int pr = 0; pr < 3; ++pr) {
+        int i = PI3[pr], j = PJ3[pr], t = j - i - 1, has_n = 0;
+        uint64_t key = 0;
+        for (int q = 0; q < A; ++q) {
+          int bi = i * A + q, bj = j * A + q;
+          has_n |= (int)((nm[bi >> 5] >> ((bi & 31) * 2)) & 1) | (int)((nm[bj >> 5] >> ((bj & 31) * 2)) & 1);
+          key |= ((rd[bi >> 5] >> ((bi & 31) * 2)) & 3ull) << (2 * q);
+          key |= ((rd[bj >> 5] >> ((bj & 31) * 2)) & 3ull) << (2 * q + kb);
+        }
+        (void)amask;
+        if (!has_n) {
+          uint32_t lo = pairs->jump[t][key], hi = pairs->jump[t][key + 1];
+          ++*lookups;
+          for (uint32_t q = lo; q < hi; ++q) {
+            ++*cands;
+            verify_one(l, p, pairs->rows[t][q], i * A, rd, nm, W, L, &best);
+          }
+        }
+        if (pr == 0 && (best >> 32) == 0) break;
+      }
+      if (best == ~0ull) return 0;
+      *key_out = best;
+      return 1;
+    }
+    pairs = NULL;
+  }
+  if (pairs && R < 4 * pairs->anchor) pairs = pairs->shorter;
   if (pairs && R >= 4 * pairs->anchor) {
     /* two mismatches touch at most two of the four anchors at 0, A, 2A, 3A: every alignment with
      * <= 2 seed mismatches matches one of the six anchor pairs exactly */
@@ -276,10 +313,12 @@ void orc_run_cascade(const orc_lib *libs, const orc_pass *passes, int n_pass, co
     }
     orc_pairs pairs_store, pairs_short, *pairs = NULL;
     if (p->pair_anchor > 0 && p->max_mm_seed == 2 && !p->poly_t && p->seed_len >= 4 * p->pair_anchor) {
-      pairs_build(l, p->pair_anchor, &pairs_store);
-      pairs_build(l, p->pair_anchor - 1, &pairs_short);
+      pairs_build(l, p->pair_anchor, 4, &pairs_store);
+      pairs_build(l, p->pair_anchor - 1, 4, &pairs_short);
       pairs_store.shorter = &pairs_short;
-      pairs_short.shorter = NULL;
+      pairs = &pairs_store;
+    } else if (p->pair_anchor > 0 && p->max_mm_seed == 1 && !p->poly_t) {
+      pairs_build(l, p->pair_anchor, 3, &pairs_store);
       pairs = &pairs_store;
     }
 #pragma omp parallel for schedule(dynamic, 4096) reduction(+ : processed, aligned, steps, cands, lookups)

@@ -471,17 +471,30 @@ def test_big_library_jump_tables(native_lib, oracle_lib):
     fused_passes = [dict(lib=0, seed_len=28, max_mm_seed=0, max_mm_total=2, min_len=0, max_len=20),
                     dict(lib=0, seed_len=28, max_mm_seed=1, max_mm_total=2, min_len=0, max_len=30),
                     dict(lib=0, seed_len=1024, max_mm_seed=1, max_mm_total=1, min_len=0, max_len=255)]
-    for ww, ll, nn in ((w, l, nm), (w1, l1, nm1)):
-        resf = eng.cascade(ReadSet(ww, ll, nn, None, device=eng.device),
-                           eng.make_passes([dict(p, lib="big") for p in fused_passes]))
-        reff = model.fm_cascade([ix.view()], fused_passes, ww, ll, nn, wstop=DEFAULT_WSTOP, ftab=True)
-        assert [st["lds_mode"] for st in resf.stats] == [3 if False else resf.stats[0]["lds_mode"], 4, 4]
-        for name, a in zip(("pass_id", "ref_id", "pos", "mm"), resf.to_host()):
-            assert np.array_equal(a, reff[name]), name
-        for i, st in enumerate(resf.stats):
-            assert [st[k] for k in ("processed", "aligned", "steps", "candidates", "lookups")] == \
-                [int(x) for x in reff["stats"][i]]
-        assert int((resf.to_host()[0] == 2).sum()) > 50
+    # ... and, by default, reads whose seed region is 15..19 bases (two pieces of 7..9 bases: 40..600
+    # rows each in 4.8 Mbp) go through the three pairs of three 5-base anchors instead (10-base keys,
+    # tables built on the device at first use; fused_kernel<W, true>)
+    for pair_big in (5, 0, 6):
+        eng.set_option("pair_big", pair_big)
+        for ww, ll, nn in ((w, l, nm), (w1, l1, nm1)):
+            resf = eng.cascade(ReadSet(ww, ll, nn, None, device=eng.device),
+                               eng.make_passes([dict(p, lib="big") for p in fused_passes]))
+            assert [st["pair_anchor"] for st in resf.stats] == [0, pair_big, pair_big]
+            port_passes = [dict(p, pair_anchor=st["pair_anchor"]) for p, st in zip(fused_passes, resf.stats)]
+            reff = model.fm_cascade([ix.view()], port_passes, ww, ll, nn, wstop=DEFAULT_WSTOP, ftab=True)
+            assert [st["lds_mode"] for st in resf.stats] == [resf.stats[0]["lds_mode"], 4, 4]
+            for name, a in zip(("pass_id", "ref_id", "pos", "mm"), resf.to_host()):
+                assert np.array_equal(a, reff[name]), (pair_big, name)
+            for i, st in enumerate(resf.stats):
+                assert [st[k] for k in ("processed", "aligned", "steps", "candidates", "lookups")] == \
+                    [int(x) for x in reff["stats"][i]], (pair_big, i)
+            assert int((resf.to_host()[0] == 2).sum()) > 50
+            if pair_big:   # the same assignments from far fewer candidate rows
+                plain = model.fm_cascade([ix.view()], fused_passes, ww, ll, nn, wstop=DEFAULT_WSTOP, ftab=True)
+                for name in ("pass_id", "ref_id", "pos", "mm"):
+                    assert np.array_equal(plain[name], reff[name]), name
+                assert int(reff["stats"][1][3]) < int(plain["stats"][1][3])
+    eng.set_option("pair_big", 5)
 
 
 @pytest.mark.gpu
