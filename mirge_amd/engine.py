@@ -288,19 +288,28 @@ class Engine:
             counts.data_ptr(), self._stream_ptr()))
         return counts
 
-    def collapse(self, words, lens, nmask=None, sample=None, n_samples=1, max_len=0):
+    def collapse(self, words, lens, nmask=None, sample=None, n_samples=1, max_len=0, out=None):
         """quantReads (QNT:3-24) on device tensors: raw reads (words int64 [W, n], lens uint8 [n],
         nmask or None, sample int16 [n] or None) -> (ReadSet of the unique reads with their
         per-sample counts, all still in HBM and ordered by (length, bases); read-length histogram
-        int64 [256, S]).  Synchronises (the number of uniques comes back to the host)."""
+        int64 [256, S]).  Synchronises (the number of uniques comes back to the host).
+        out = (u_words [W, n], u_lens [n], u_nmask or None, quant [n, S]): caller-owned output
+        buffers (a pipeline that collapses batch after batch keeps one set instead of asking the
+        allocator for n-sized arrays every time)."""
         torch = _torch()
         dev = self.device
         W, n = int(words.shape[0]), int(words.shape[1])
         cap = max(n, 1)
-        u_words = torch.empty((W, cap), dtype=torch.int64, device=dev)
-        u_lens = torch.empty(cap, dtype=torch.uint8, device=dev)
-        u_nmask = None if nmask is None else torch.empty((W, cap), dtype=torch.int64, device=dev)
-        quant = torch.empty((cap, n_samples), dtype=torch.int32, device=dev)
+        if out is not None:
+            u_words, u_lens, u_nmask, quant = out
+            if tuple(u_words.shape) != (W, cap) or u_lens.numel() != cap or tuple(quant.shape) != (cap, n_samples) or \
+                    (nmask is not None and u_nmask is None):
+                raise ValueError("collapse: output buffers do not match the input shape")
+        else:
+            u_words = torch.empty((W, cap), dtype=torch.int64, device=dev)
+            u_lens = torch.empty(cap, dtype=torch.uint8, device=dev)
+            u_nmask = None if nmask is None else torch.empty((W, cap), dtype=torch.int64, device=dev)
+            quant = torch.empty((cap, n_samples), dtype=torch.int32, device=dev)
         hist = torch.zeros((256, n_samples), dtype=torch.int64, device=dev)
         n_unique = C.c_uint64(0)
         check(self._lib.mrg_collapse_run(
