@@ -158,7 +158,11 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * time to run the piece search); "split_strata" = 1 (default) / 0: such a pass, when it does run the
  * piece search, is launched as strata 1-2 and stratum 3 separately; "stratum_rows" = 0 (default) /
  * 1 / 2: that piece search in stratum_kernel (rows compacted over the wave) for the last stratum /
- * every strata launch; "wide_rows_16", "round_large": see DESIGN.md. */
+ * every strata launch; "pair_big" = 5 (default) / 0 / 4..7: anchor length A of the pair tables of
+ * libraries of >= 2^20 bases -- a one-mismatch pass inside a fused launch searches reads whose seed
+ * region is 3A .. 4A - 1 bases through three anchor pairs instead of two short pigeonhole pieces
+ * (tables built on the device the first time such reads are met; mrg_pass_stats.pair_anchor reports
+ * A); "wide_rows_16", "round_large": see DESIGN.md. */
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);
 int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,
                         char *arch, uint32_t arch_cap);
@@ -198,7 +202,10 @@ typedef struct mrg_pass_stats {
   uint32_t kbits_log2; /* log2 of the bits of the 9-mer presence bitmap the pass filtered seed
                           pieces with (18 = the library's full bitmap, 13..17 = folded for a
                           fused launch, 0 = no filter) */
-  uint32_t pair_anchor; /* != 0: a 2-mismatch pass whose reads of at least 4 x pair_anchor seed bases
+  uint32_t pair_anchor; /* != 0, pass with ONE seed mismatch (fused launch, large library): reads of
+                          3 x pair_anchor .. 4 x pair_anchor - 1 seed bases were searched through the
+                          three pairs of three anchors, the others through the pigeonhole pieces.
+                          != 0, TWO seed mismatches: reads of at least 4 x pair_anchor seed bases
                           were searched through the six pairs of four anchors of that many bases
                           (lookups = pair lookups, candidates = their rows, no LF steps), reads
                           of at least 4 x (pair_anchor - 1) through anchors one base shorter;
