@@ -1096,12 +1096,13 @@ int mrg_tally_run(mrg_ctx* ctx, const int8_t* d_pass_id, const int32_t* d_ref_id
   p.canon_pass = canon_pass;
   p.isomir_pass = isomir_pass;
   p.counts = d_counts;
+  p.vec4 = (n_samples == 1 && ((uintptr_t)d_pass_id % 4 == 0) && ((uintptr_t)d_ref_id % 16 == 0) && ((uintptr_t)d_quant % 16 == 0)) ? 1u : 0u;
   uint64_t bins = 0;
   mrg_tally_counts_len(n_mirna, n_samples, n_pass, &bins);
   // LDS histogram: the category bins are replicated (kernels.hip: tally_kernel)
   const uint64_t lds = (bins + (uint64_t)(n_pass + 1) * n_samples * (mrg::kTallyCatReplicas - 1)) * 8;
   const bool lds_hist = lds <= (uint64_t)ctx->lds_budget;
-  uint64_t want = (n + mrg::kTallyThreads - 1) / mrg::kTallyThreads;
+  uint64_t want = ((p.vec4 ? (n + 3) / 4 : n) + mrg::kTallyThreads - 1) / mrg::kTallyThreads;
   uint32_t per_cu = lds_hist ? (lds * 2 <= 160 * 1024 ? 2u : 1u) : 2u;
   uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)ctx->n_cu * per_cu);
   HIP_TRY(mrg::launch_tally(p, lds_hist, grid, lds_hist ? (uint32_t)lds : 0u, (hipStream_t)stream_));

@@ -320,7 +320,7 @@ match_kernel(const MatchParams p) {
     for (int k = 0; k < W; ++k) rd[k] = nm[k] = 0ull;
     if (active) {
       r = p.idx_in ? p.idx_in[(size_t)sgi * p.in_seg_cap + t] : t;
-      L0 = p.lens[r];
+      L0 = p.uniform_len ? p.uniform_len : (uint32_t)p.lens[r];  // (a batch of one length: no 1-byte gathers)
     }
     // ---- which reads this pass's FASTA would contain (RAP:543-554, 664-686) ----
     bool eligible = active && (int32_t)L0 >= p.min_len && (int32_t)L0 <= p.max_len;
@@ -1823,36 +1823,67 @@ __global__ void __launch_bounds__(kTallyThreads) tally_kernel(const TallyParams 
   }
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t rep = LDSH ? (lane & (R - 1u)) : 0u;
-  const uint64_t n_round = ((p.n + kTallyThreads - 1) / kTallyThreads) * kTallyThreads;
 
-  for (uint64_t r = (uint64_t)blockIdx.x * kTallyThreads + threadIdx.x; r < n_round;
-       r += (uint64_t)gridDim.x * kTallyThreads) {
-    const bool active = r < p.n;  // whole waves stay in the loop: ballots below
-    const int32_t pass = active ? p.pass_id[r] : -1;
+  // one read's contribution (whole waves call it: the ballot counts the reads with a non-zero count)
+  auto add = [&](bool active, int32_t pass, uint32_t ref_raw, unsigned long long q, uint32_t s) {
     // an unclaimed read (pass -1) must not match a disabled (-1) canon/isomiR pass
     const bool canon = active && pass >= 0 && pass == p.canon_pass;
     const bool iso = active && pass >= 0 && pass == p.isomir_pass;
-    const uint32_t ref = (canon || iso) ? (uint32_t)p.ref_id[r] : 0u;
+    const uint32_t ref = (canon || iso) ? ref_raw : 0u;
     const uint32_t cat = pass < 0 ? p.n_pass : (uint32_t)pass;
-    for (uint32_t s = 0; s < S; ++s) {
-      const unsigned long long q = active ? p.quant[r * S + s] : 0ull;
-      const bool hit = q != 0ull;
-      const uint64_t hits = __ballot(hit);
-      if (!hits) continue;
-      if (LDSH) {
-        if (lane == 0) atomicAdd(&hist[l_uniq0 + s], (unsigned long long)__popcll(hits));
-        if (hit) atomicAdd(&hist[l_cat0 + (cat * S + s) * R + rep], q);
-        // one LDS atomic per read: a canonical read goes to the iscan bin only, quant = iscan + isomiR
-        // reads is formed at the flush
-        if (hit && iso && !canon) atomicAdd(&hist[ref * S + s], q);
-        if (hit && canon) atomicAdd(&hist[M * S + ref * S + s], q);
-      } else {
-        if (lane == 0) atomicAdd(&g[uniq0 + s], (unsigned long long)__popcll(hits));
-        if (hit) atomicAdd(&g[cat0 + cat * S + s], q);
-        if (hit && (canon || iso)) atomicAdd(&g[ref * S + s], q);
-        if (hit && canon) atomicAdd(&g[M * S + ref * S + s], q);
-      }
+    const bool hit = active && q != 0ull;
+    const uint64_t hits = __ballot(hit);
+    if (!hits) return;
+    if (LDSH) {
+      if (lane == 0) atomicAdd(&hist[l_uniq0 + s], (unsigned long long)__popcll(hits));
+      if (hit) atomicAdd(&hist[l_cat0 + (cat * S + s) * R + rep], q);
+      // one LDS atomic per read: a canonical read goes to the iscan bin only, quant = iscan + isomiR
+      // reads is formed at the flush
+      if (hit && iso && !canon) atomicAdd(&hist[ref * S + s], q);
+      if (hit && canon) atomicAdd(&hist[M * S + ref * S + s], q);
+    } else {
+      if (lane == 0) atomicAdd(&g[uniq0 + s], (unsigned long long)__popcll(hits));
+      if (hit) atomicAdd(&g[cat0 + cat * S + s], q);
+      if (hit && (canon || iso)) atomicAdd(&g[ref * S + s], q);
+      if (hit && canon) atomicAdd(&g[M * S + ref * S + s], q);
     }
+  };
+  uint64_t r_first = 0;  // reads before it were taken four per lane
+  if (p.vec4) {
+    // one sample, 16-byte aligned arrays: a lane takes four consecutive reads per trip -- a 4-byte,
+    // and two 16-byte loads instead of 1 + 4 + 4 bytes per lane (64-byte wave requests stream badly)
+    const uint64_t n4 = p.n >> 2;
+    const uint64_t n4_round = ((n4 + kTallyThreads - 1) / kTallyThreads) * kTallyThreads;
+    const uint32_t* pass4 = reinterpret_cast<const uint32_t*>(p.pass_id);
+    const uint4* ref4 = reinterpret_cast<const uint4*>(p.ref_id);
+    const uint4* quant4 = reinterpret_cast<const uint4*>(p.quant);
+    for (uint64_t g4 = (uint64_t)blockIdx.x * kTallyThreads + threadIdx.x; g4 < n4_round;
+         g4 += (uint64_t)gridDim.x * kTallyThreads) {
+      const bool active = g4 < n4;
+      uint32_t pw = 0xFFFFFFFFu;
+      uint4 rf = make_uint4(0u, 0u, 0u, 0u), qv = make_uint4(0u, 0u, 0u, 0u);
+      if (active) {
+        pw = pass4[g4];
+        rf = ref4[g4];
+        qv = quant4[g4];
+      }
+      add(active, (int32_t)(int8_t)(pw & 0xFFu), rf.x, qv.x, 0u);
+      add(active, (int32_t)(int8_t)((pw >> 8) & 0xFFu), rf.y, qv.y, 0u);
+      add(active, (int32_t)(int8_t)((pw >> 16) & 0xFFu), rf.z, qv.z, 0u);
+      add(active, (int32_t)(int8_t)(pw >> 24), rf.w, qv.w, 0u);
+    }
+    r_first = n4 << 2;
+  }
+  const uint64_t n_rest = p.n - r_first;
+  const uint64_t n_round = ((n_rest + kTallyThreads - 1) / kTallyThreads) * kTallyThreads;
+  for (uint64_t k = (uint64_t)blockIdx.x * kTallyThreads + threadIdx.x; k < n_round;
+       k += (uint64_t)gridDim.x * kTallyThreads) {
+    const uint64_t r = r_first + k;
+    const bool active = k < n_rest;  // whole waves stay in the loop: ballots
+    const int32_t pass = active ? p.pass_id[r] : -1;
+    const bool wants_ref = active && pass >= 0 && (pass == p.canon_pass || pass == p.isomir_pass);
+    const uint32_t ref = wants_ref ? (uint32_t)p.ref_id[r] : 0u;
+    for (uint32_t s = 0; s < S; ++s) add(active, pass, ref, active ? p.quant[r * S + s] : 0ull, s);
   }
   if (LDSH) {
     __syncthreads();

@@ -217,6 +217,7 @@ struct TallyParams {
   uint32_t n_samples, n_mirna, n_pass;
   int32_t canon_pass, isomir_pass;
   uint64_t* counts;
+  uint32_t vec4;  // one sample and 16-byte aligned arrays: four reads per lane and trip
 };
 
 // A-to-I position tally (writeDataToCSV.py:145-229 on the cascade's own alignments)
