@@ -1222,6 +1222,11 @@ int mrg_edit_tally_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per
   p.text = l.text;
   p.seg_start = l.seg_start;
   p.counts = d_counts;
+  p.vec4 = (n_samples == 1 && words_per_read == 1 && ((uintptr_t)d_reads % 16 == 0) && ((uintptr_t)d_lens % 4 == 0) &&
+            ((uintptr_t)d_pass_id % 4 == 0) && ((uintptr_t)d_ref_id % 16 == 0) && ((uintptr_t)d_pos % 16 == 0) &&
+            ((uintptr_t)d_quant % 16 == 0))
+               ? 1u
+               : 0u;
   p.text_words = l.text_words;
   p.n_entries = l.n_ref;
   // LDS: the per-entry totals first (every kept read hits them), then -- if two workgroups per CU
@@ -1232,7 +1237,7 @@ int mrg_edit_tally_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per
   const bool lds_hist = hist_b <= budget;
   const bool lds_lib = (lds_hist ? hist_b : 0) + lib_b + mrg::kEditHashLdsBytes <= std::min<uint64_t>(budget, 80 * 1024);
   const uint64_t lds = (lds_hist ? hist_b : 0) + (lds_lib ? lib_b : 0) + mrg::kEditHashLdsBytes;
-  const uint64_t want = (n + mrg::kEditThreads - 1) / mrg::kEditThreads;
+  const uint64_t want = ((p.vec4 ? (n + 3) / 4 : n) + mrg::kEditThreads - 1) / mrg::kEditThreads;
   const uint32_t per_cu = lds * 2 <= 160 * 1024 ? 2u : 1u;
   const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)ctx->n_cu * per_cu);
   HIP_TRY(mrg::launch_edit_tally(p, lds_hist, lds_lib, grid, (uint32_t)lds, (hipStream_t)stream));

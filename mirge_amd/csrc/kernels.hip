@@ -1957,24 +1957,20 @@ __global__ void __launch_bounds__(kEditThreads) edit_tally_kernel(const EditPara
   __syncthreads();
   const uint32_t* text = LDSL ? s_text : p.text;
   const uint32_t* seg_start = LDSL ? s_seg : p.seg_start;
-  const uint64_t n_round = ((p.n + kEditThreads - 1) / kEditThreads) * kEditThreads;
-  for (uint64_t r = (uint64_t)blockIdx.x * kEditThreads + threadIdx.x; r < n_round;
-       r += (uint64_t)gridDim.x * kEditThreads) {
-    // whole waves stay in the loop (the position hits are aggregated over the wave below)
+  // one read: the fields that every read has are passed in (requested before any of them is looked at)
+  auto one = [&](uint64_t r, int32_t pass, uint32_t e, int32_t L, int32_t pos_r, uint64_t r0, bool have_q,
+                 unsigned long long q_pre) {
     uint64_t hits = 0ull;
     uint32_t bin = 0;
     bool kept = false, canonical = false;
     do {
       if (r >= p.n) break;
-      const int32_t pass = p.pass_id[r];
       if (pass < 0 || (pass != p.canon_pass && pass != p.isomir_pass)) break;
       if (p.keep && !p.keep[r]) break;
-      const uint32_t e = (uint32_t)p.ref_id[r];
-      const int32_t L = (int32_t)p.lens[r];
       const uint32_t e0 = seg_start[e], e1 = seg_start[e + 1];
       const int32_t Lm = (int32_t)(e1 - e0) - (int32_t)(p.flank5 + p.flank3);
       if (Lm <= 0 || Lm > (int32_t)kEditPositions) break;  // (the host rejects such libraries)
-      const int32_t d = p.pos[r] - (pass == p.isomir_pass ? p.isomir_trim5 : 0) - (int32_t)p.flank5;
+      const int32_t d = pos_r - (pass == p.isomir_pass ? p.isomir_trim5 : 0) - (int32_t)p.flank5;
       if (d > 1) break;        // head shift (judgeAllign)
       if (d + L <= 0) break;   // the read ends before the mature sequence starts
       // 32 mature bases from the text, 2 bits each, mature index 0 in the low bits
@@ -1985,7 +1981,7 @@ __global__ void __launch_bounds__(kEditThreads) edit_tally_kernel(const EditPara
         tw = (lo64 >> sh) | ((((uint64_t)text[i + 2]) << 1) << (63 - sh));
       }
       // the read in mature coordinates (base j -> index d + j), and its N mask
-      const uint64_t r0 = p.reads[r], r1 = p.words_per_read > 1 ? p.reads[p.n + r] : 0ull;
+      const uint64_t r1 = p.words_per_read > 1 ? p.reads[p.n + r] : 0ull;
       const uint64_t m0 = p.nmask ? p.nmask[r] : 0ull, m1 = (p.nmask && p.words_per_read > 1) ? p.nmask[p.n + r] : 0ull;
       uint64_t rw, nw;
       if (d >= 0) {
@@ -2037,7 +2033,7 @@ __global__ void __launch_bounds__(kEditThreads) edit_tally_kernel(const EditPara
       bin = p.remap ? p.remap[e] : e;
     } while (false);
     for (uint32_t s = 0; s < S; ++s) {
-      const unsigned long long q = kept ? p.quant[r * S + s] : 0ull;
+      const unsigned long long q = kept ? (have_q ? q_pre : (unsigned long long)p.quant[r * S + s]) : 0ull;
       if (q) {
         const size_t k = (size_t)bin * S + s;
         if (LDSH) {
@@ -2064,7 +2060,31 @@ __global__ void __launch_bounds__(kEditThreads) edit_tally_kernel(const EditPara
         if (!done) atomicAdd(&gpos[key], q);   // four occupied slots: a rare pair goes straight to L2
       }
     }
+  };
+  uint64_t r_first = 0;
+  if (p.vec4) {
+    // one sample, one-word reads, 16-byte aligned arrays: four consecutive reads per lane and trip
+    // (4-byte loads of the pass ids and lengths, 16-byte loads of everything else)
+    const uint64_t n4 = p.n >> 2;
+    for (uint64_t g4 = (uint64_t)blockIdx.x * kEditThreads + threadIdx.x; g4 < n4; g4 += (uint64_t)gridDim.x * kEditThreads) {
+      const uint32_t pw = reinterpret_cast<const uint32_t*>(p.pass_id)[g4];
+      const uint32_t lw = reinterpret_cast<const uint32_t*>(p.lens)[g4];
+      const uint4 ev = reinterpret_cast<const uint4*>(p.ref_id)[g4], pv = reinterpret_cast<const uint4*>(p.pos)[g4];
+      const uint4 qv = reinterpret_cast<const uint4*>(p.quant)[g4];
+      const uint4 ra = reinterpret_cast<const uint4*>(p.reads)[2 * g4], rb = reinterpret_cast<const uint4*>(p.reads)[2 * g4 + 1];
+      const uint64_t r = g4 << 2;
+      one(r, (int32_t)(int8_t)(pw & 0xFFu), ev.x, (int32_t)(lw & 0xFFu), (int32_t)pv.x, (uint64_t)ra.x | ((uint64_t)ra.y << 32), true, qv.x);
+      one(r + 1, (int32_t)(int8_t)((pw >> 8) & 0xFFu), ev.y, (int32_t)((lw >> 8) & 0xFFu), (int32_t)pv.y,
+          (uint64_t)ra.z | ((uint64_t)ra.w << 32), true, qv.y);
+      one(r + 2, (int32_t)(int8_t)((pw >> 16) & 0xFFu), ev.z, (int32_t)((lw >> 16) & 0xFFu), (int32_t)pv.z,
+          (uint64_t)rb.x | ((uint64_t)rb.y << 32), true, qv.z);
+      one(r + 3, (int32_t)(int8_t)(pw >> 24), ev.w, (int32_t)(lw >> 24), (int32_t)pv.w, (uint64_t)rb.z | ((uint64_t)rb.w << 32), true,
+          qv.w);
+    }
+    r_first = n4 << 2;
   }
+  for (uint64_t r = r_first + (uint64_t)blockIdx.x * kEditThreads + threadIdx.x; r < p.n; r += (uint64_t)gridDim.x * kEditThreads)
+    one(r, (int32_t)p.pass_id[r], (uint32_t)p.ref_id[r], (int32_t)p.lens[r], p.pos[r], p.reads[r], false, 0ull);
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < kEditHashSlots; i += kEditThreads)
     if (hk[i] != 0xFFFFFFFFu && hv[i]) atomicAdd(&gpos[hk[i]], hv[i]);

@@ -245,6 +245,7 @@ struct EditParams {
   const uint32_t* seg_start;   // entry e = text [seg_start[e], seg_start[e + 1]) (every entry one N-free segment)
   uint32_t text_words, n_entries;
   uint64_t* counts;            // [n_bins][S][3] then [n_bins][kEditPositions][S]
+  uint32_t vec4;               // one sample, one-word reads, 16-byte aligned arrays: four reads per lane and trip
 };
 // LDS bytes of the privatised totals (lds_hist) and of the staged library (lds_lib)
 constexpr uint64_t edit_hist_lds_bytes(uint64_t n_bins, uint64_t S) { return n_bins * S * 16u + ((n_bins * S + 3u) & ~3ull) * 4u; }
