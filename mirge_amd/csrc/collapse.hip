@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <vector>
 
 #include "kernels.hpp"
@@ -33,14 +34,66 @@ __global__ void gather_key_kernel(const T* __restrict__ col, const uint32_t* __r
   if (i < n) key[i] = (uint64_t)col[idx[i]];
 }
 
-// fused key for reads of at most 29 nt in one word: length in the top 6 bits
+// fused key for reads of at most 29 nt in one word: the length in six bits right above the 2 max_len
+// bits of the bases (the radix sort then runs over 2 max_len + 6 bits, not 64: seven 8-bit passes
+// instead of eight for 22-nt reads)
 __global__ void gather_fused_key_kernel(const uint64_t* __restrict__ words, const uint8_t* __restrict__ lens,
                                         const uint32_t* __restrict__ idx, uint64_t* __restrict__ key,
-                                        uint32_t n) {
+                                        uint32_t n, uint32_t len_shift) {
   uint32_t i = blockIdx.x * kT + threadIdx.x;
   if (i < n) {
     const uint32_t r = idx[i];
-    key[i] = words[r] | ((uint64_t)lens[r] << 58);
+    key[i] = words[r] | ((uint64_t)lens[r] << len_shift);
+  }
+}
+
+// keys-only path (one sample, one word, no N, <= 29 nt): key of read i, in place of the index gather
+__global__ void fused_key_kernel(const uint64_t* __restrict__ words, const uint8_t* __restrict__ lens,
+                                 uint64_t* __restrict__ key, uint32_t n, uint32_t len_shift) {
+  uint32_t i = blockIdx.x * kT + threadIdx.x;
+  if (i < n) key[i] = words[i] | ((uint64_t)lens[i] << len_shift);
+}
+
+// unique key -> unique read (bases below len_shift, length above)
+__global__ void split_key_kernel(const uint64_t* __restrict__ ukey, const uint32_t* __restrict__ n_runs,
+                                 uint64_t* __restrict__ u_words, uint8_t* __restrict__ u_lens, uint32_t len_shift) {
+  uint32_t i = blockIdx.x * kT + threadIdx.x;
+  if (i < *n_runs) {
+    const uint64_t k = ukey[i];
+    u_words[i] = k & ((1ull << len_shift) - 1ull);
+    u_lens[i] = (uint8_t)(k >> len_shift);
+  }
+}
+
+// keys-only path with several samples: the sample id in the low `sb` bits of the key
+__global__ void fused_key_sample_kernel(const uint64_t* __restrict__ words, const uint8_t* __restrict__ lens,
+                                        const uint16_t* __restrict__ sample, uint64_t* __restrict__ key, uint32_t n,
+                                        uint32_t len_shift, uint32_t sb) {
+  uint32_t i = blockIdx.x * kT + threadIdx.x;
+  if (i < n) key[i] = ((words[i] | ((uint64_t)lens[i] << len_shift)) << sb) | (uint64_t)sample[i];
+}
+
+// runs of (read, sample): 1 where a new read starts
+__global__ void run_heads_kernel(const uint64_t* __restrict__ rkey, const uint32_t* __restrict__ n_runs,
+                                 uint32_t* __restrict__ flag, uint32_t n, uint32_t sb) {
+  uint32_t j = blockIdx.x * kT + threadIdx.x;
+  if (j >= n) return;
+  flag[j] = (j < *n_runs && (j == 0 || (rkey[j] >> sb) != (rkey[j - 1] >> sb))) ? 1u : 0u;
+}
+
+__global__ void emit_runs_kernel(const uint64_t* __restrict__ rkey, const uint32_t* __restrict__ rcount,
+                                 const uint32_t* __restrict__ n_runs, const uint32_t* __restrict__ uid_incl,
+                                 uint64_t* __restrict__ u_words, uint8_t* __restrict__ u_lens, uint32_t* __restrict__ quant,
+                                 uint32_t n_samples, uint32_t len_shift, uint32_t sb) {
+  uint32_t j = blockIdx.x * kT + threadIdx.x;
+  if (j >= *n_runs) return;
+  const uint64_t k = rkey[j];
+  const uint32_t u = uid_incl[j] - 1u;
+  quant[(size_t)u * n_samples + (uint32_t)(k & ((1ull << sb) - 1ull))] = rcount[j];
+  if (j == 0 || (k >> sb) != (rkey[j - 1] >> sb)) {
+    const uint64_t rk = k >> sb;
+    u_words[u] = rk & ((1ull << len_shift) - 1ull);
+    u_lens[u] = (uint8_t)(rk >> len_shift);
   }
 }
 
@@ -154,6 +207,103 @@ hipError_t collapse_reads(const uint64_t* d_reads, uint32_t W, const uint8_t* d_
   CK(hipMemsetAsync(d_len_hist, 0, (size_t)256 * n_samples * 8, stream));
   if (n == 0) return hipStreamSynchronize(stream);
   const uint32_t grid = (n + kT - 1) / kT;
+  if (W == 1 && max_len > 0 && max_len <= 29 && !d_nmask && !(d_sample && n_samples > 1) && n_samples == 1) {
+    // One sample, reads of one word without N: the packed read + its length IS the sort key and the
+    // unique read; nothing has to be carried through the sort or gathered afterwards.  Sort the
+    // keys alone over their 2 max_len + 6 bits, run-length encode them (unique keys + multiplicities
+    // = quant), split the unique keys into words and lengths.
+    const uint32_t len_shift = 2u * max_len;
+    DevBuf k0, k1, ukey, runs, tmp;
+    CK(k0.alloc((size_t)n * 8));
+    CK(k1.alloc((size_t)n * 8));
+    CK(ukey.alloc((size_t)n * 8));
+    CK(runs.alloc(4));
+    hipcub::DoubleBuffer<uint64_t> keys(k0.as<uint64_t>(), k1.as<uint64_t>());
+    size_t tb_sort = 0, tb_rle = 0;
+    CK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb_sort, keys, (int)n, 0, (int)(len_shift + 6u), stream));
+    CK(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb_rle, k0.as<uint64_t>(), ukey.as<uint64_t>(), d_quant,
+                                             runs.as<uint32_t>(), (int)n, stream));
+    const size_t tbytes = tb_sort > tb_rle ? tb_sort : tb_rle;
+    CK(tmp.alloc(tbytes));
+    hipLaunchKernelGGL(fused_key_kernel, dim3(grid), dim3(kT), 0, stream, d_reads, d_lens, keys.Current(), n, len_shift);
+    size_t tb = tbytes;
+    CK(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, keys, (int)n, 0, (int)(len_shift + 6u), stream));
+    uint32_t n_unique = 0;
+    if ((uint64_t)n <= cap) {
+      // (every run fits: multiplicities straight into quant)
+      tb = tbytes;
+      CK(hipcub::DeviceRunLengthEncode::Encode(tmp.p, tb, keys.Current(), ukey.as<uint64_t>(), d_quant, runs.as<uint32_t>(),
+                                               (int)n, stream));
+      CK(hipMemcpyAsync(&n_unique, runs.as<uint32_t>(), 4, hipMemcpyDeviceToHost, stream));
+      hipLaunchKernelGGL(split_key_kernel, dim3(grid), dim3(kT), 0, stream, ukey.as<uint64_t>(), runs.as<uint32_t>(), d_u_words,
+                         d_u_lens, len_shift);
+      const uint32_t lds = 256u * 4u;
+      hipLaunchKernelGGL(length_hist_kernel<true>, dim3(min(grid, 1024u)), dim3(kT), lds, stream, d_lens,
+                         (const uint16_t*)nullptr, n, 1u, reinterpret_cast<unsigned long long*>(d_len_hist));
+      CK(hipGetLastError());
+      CK(hipStreamSynchronize(stream));
+      *h_n_unique = n_unique;
+      return hipSuccess;
+    }
+    // (an output capacity below n: the general path below checks it)
+  }
+  uint32_t sb = 0;
+  while ((1u << sb) < n_samples) ++sb;
+  if (W == 1 && max_len > 0 && !d_nmask && d_sample && n_samples > 1 && 2u * max_len + 6u + sb <= 64u && (uint64_t)n <= cap) {
+    // Several samples: the same, with the sample id in the low bits of the key.  The runs of the
+    // sorted keys are (read, sample) pairs with their counts; a read's runs are neighbours.
+    const uint32_t len_shift = 2u * max_len;
+    DevBuf k0, k1, rkey, rcount, runs, flag, uidb, tmp;
+    CK(k0.alloc((size_t)n * 8));
+    CK(k1.alloc((size_t)n * 8));
+    CK(rkey.alloc((size_t)n * 8));
+    CK(rcount.alloc((size_t)n * 4));
+    CK(flag.alloc((size_t)n * 4));
+    CK(uidb.alloc((size_t)n * 4));
+    CK(runs.alloc(4));
+    hipcub::DoubleBuffer<uint64_t> keys(k0.as<uint64_t>(), k1.as<uint64_t>());
+    const int bits = (int)(len_shift + 6u + sb);
+    size_t tb_sort = 0, tb_rle = 0, tb_scan = 0;
+    CK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb_sort, keys, (int)n, 0, bits, stream));
+    CK(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb_rle, k0.as<uint64_t>(), rkey.as<uint64_t>(), rcount.as<uint32_t>(),
+                                             runs.as<uint32_t>(), (int)n, stream));
+    CK(hipcub::DeviceScan::InclusiveSum(nullptr, tb_scan, flag.as<uint32_t>(), uidb.as<uint32_t>(), (int)n, stream));
+    const size_t tbytes = std::max(tb_sort, std::max(tb_rle, tb_scan));
+    CK(tmp.alloc(tbytes));
+    hipLaunchKernelGGL(fused_key_sample_kernel, dim3(grid), dim3(kT), 0, stream, d_reads, d_lens, d_sample, keys.Current(), n,
+                       len_shift, sb);
+    size_t tb = tbytes;
+    CK(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, keys, (int)n, 0, bits, stream));
+    tb = tbytes;
+    CK(hipcub::DeviceRunLengthEncode::Encode(tmp.p, tb, keys.Current(), rkey.as<uint64_t>(), rcount.as<uint32_t>(),
+                                             runs.as<uint32_t>(), (int)n, stream));
+    uint32_t h_runs = 0;
+    CK(hipMemcpyAsync(&h_runs, runs.as<uint32_t>(), 4, hipMemcpyDeviceToHost, stream));
+    CK(hipStreamSynchronize(stream));
+    const uint32_t rgrid = (h_runs + kT - 1) / kT;
+    hipLaunchKernelGGL(run_heads_kernel, dim3(rgrid), dim3(kT), 0, stream, rkey.as<uint64_t>(), runs.as<uint32_t>(),
+                       flag.as<uint32_t>(), h_runs, sb);
+    tb = tbytes;
+    CK(hipcub::DeviceScan::InclusiveSum(tmp.p, tb, flag.as<uint32_t>(), uidb.as<uint32_t>(), (int)h_runs, stream));
+    uint32_t n_unique = 0;
+    CK(hipMemcpyAsync(&n_unique, uidb.as<uint32_t>() + (h_runs - 1), 4, hipMemcpyDeviceToHost, stream));
+    CK(hipStreamSynchronize(stream));
+    CK(hipMemsetAsync(d_quant, 0, (size_t)n_unique * n_samples * 4, stream));
+    hipLaunchKernelGGL(emit_runs_kernel, dim3(rgrid), dim3(kT), 0, stream, rkey.as<uint64_t>(), rcount.as<uint32_t>(),
+                       runs.as<uint32_t>(), uidb.as<uint32_t>(), d_u_words, d_u_lens, d_quant, n_samples, len_shift, sb);
+    const uint32_t lds = 256u * n_samples * 4u;
+    auto* hist = reinterpret_cast<unsigned long long*>(d_len_hist);
+    if (lds <= 48u * 1024u)
+      hipLaunchKernelGGL(length_hist_kernel<true>, dim3(min(grid, 1024u)), dim3(kT), lds, stream, d_lens, d_sample, n, n_samples,
+                         hist);
+    else
+      hipLaunchKernelGGL(length_hist_kernel<false>, dim3(min(grid, 1024u)), dim3(kT), 0, stream, d_lens, d_sample, n, n_samples,
+                         hist);
+    CK(hipGetLastError());
+    CK(hipStreamSynchronize(stream));
+    *h_n_unique = n_unique;
+    return hipSuccess;
+  }
   DevBuf idx0, idx1, key0, key1, flags_read, flags_run, uid, starts, n_runs, temp;
   CK(idx0.alloc((size_t)n * 4));
   CK(idx1.alloc((size_t)n * 4));
@@ -193,8 +343,8 @@ hipError_t collapse_reads(const uint64_t* d_reads, uint32_t W, const uint8_t* d_
   const bool fused = (W == 1 && max_len > 0 && max_len <= 29 && !d_nmask);
   if (fused) {
     hipLaunchKernelGGL(gather_fused_key_kernel, dim3(grid), dim3(kT), 0, stream, d_reads, d_lens,
-                       vals.Current(), keys.Current(), n);
-    CK(sort_pass(64));
+                       vals.Current(), keys.Current(), n, 2u * max_len);
+    CK(sort_pass((int)(2u * max_len + 6u)));
   } else {
     for (uint32_t w = 0; w < W; ++w) {
       hipLaunchKernelGGL(gather_key_kernel<uint64_t>, dim3(grid), dim3(kT), 0, stream,
