@@ -134,9 +134,14 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    torch.cuda.set_device(local_rank)
+    # MRG_BENCH_SHARE_GPU=1: a dry run of the N > 1 path on a box with fewer GPUs than ranks (ranks
+    # share devices, gloo instead of RCCL) -- exercises sharding, the all-reduce and the rank-0 line;
+    # its timings mean nothing
+    share = os.environ.get("MRG_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if share else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        mdist.init_process_group("nccl")
+        mdist.init_process_group("gloo" if share else "nccl")
 
     from mirge_amd import synth
     from mirge_amd.engine import Engine, ReadSet, MIRGE_PASS_TABLE, DEFAULT_WSTOP
@@ -189,7 +194,7 @@ def main():
     log(rank, "libraries + indexes (%s bp) ready after %.1f s" %
         (", ".join("%s %d" % (k, libs.total_bases(k)) for k in keys), time.time() - t0))
 
-    eng = Engine(local_rank)
+    eng = Engine(dev_index)
     for k in keys:
         eng.add_library(k, index[k])
     if args.wstop is not None:
