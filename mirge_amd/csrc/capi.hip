@@ -1553,9 +1553,19 @@ int mrg_collapse_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   if (d_nmask && !d_u_nmask) return fail(MRG_ERR_ARG, "mrg_collapse_run: d_u_nmask required with d_nmask");
   HIP_TRY(hipSetDevice(ctx->device));
   uint32_t nu = 0;
+  // temporaries of the keys-only path (3 x 8 B per read + the sort's own) out of the context's
+  // scratch, grown on demand and kept: per-call hipMalloc / hipFree of gigabytes costs milliseconds
+  const uint64_t want = n * 40ull + (64ull << 20);
+  if (ctx->scratch_bytes < want) {
+    (void)hipFree(ctx->scratch);
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    if (hipMalloc(&ctx->scratch, want) == hipSuccess) ctx->scratch_bytes = want;
+    else (void)hipGetLastError();  // (the collapse then allocates per call)
+  }
   hipError_t e = mrg::collapse_reads(d_reads, words_per_read, d_lens, d_nmask, d_sample, (uint32_t)n, n_samples,
                                      max_len, cap, d_u_reads, d_u_lens, d_u_nmask, d_quant, d_len_hist, &nu,
-                                     (hipStream_t)stream);
+                                     (hipStream_t)stream, ctx->scratch, ctx->scratch_bytes);
   if (e == hipErrorInvalidValue)
     return fail(MRG_ERR_ARG, "mrg_collapse_run: cap %llu is smaller than the number of unique reads",
                 (unsigned long long)cap);

@@ -178,12 +178,31 @@ __global__ void length_hist_kernel(const uint8_t* __restrict__ lens, const uint1
   }
 }
 
+// temporaries come out of the caller's arena (the context keeps one: a hipMalloc + hipFree of a
+// few GB per call is milliseconds) and fall back to hipMalloc when it is absent or full
+struct Arena {
+  char* base = nullptr;
+  size_t size = 0, used = 0;
+};
+static thread_local Arena* g_arena = nullptr;
+
 struct DevBuf {
   void* p = nullptr;
+  bool owned = false;
   ~DevBuf() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
   }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  hipError_t alloc(size_t bytes) {
+    bytes = bytes ? bytes : 16;
+    const size_t rounded = (bytes + 255) & ~(size_t)255;
+    if (g_arena && g_arena->used + rounded <= g_arena->size) {
+      p = g_arena->base + g_arena->used;
+      g_arena->used += rounded;
+      return hipSuccess;
+    }
+    owned = true;
+    return hipMalloc(&p, bytes);
+  }
   template <class T>
   T* as() {
     return reinterpret_cast<T*>(p);
@@ -202,7 +221,15 @@ hipError_t collapse_reads(const uint64_t* d_reads, uint32_t W, const uint8_t* d_
                           const uint64_t* d_nmask, const uint16_t* d_sample, uint32_t n,
                           uint32_t n_samples, uint32_t max_len, uint64_t cap, uint64_t* d_u_words,
                           uint8_t* d_u_lens, uint64_t* d_u_nmask, uint32_t* d_quant,
-                          uint64_t* d_len_hist, uint32_t* h_n_unique, hipStream_t stream) {
+                          uint64_t* d_len_hist, uint32_t* h_n_unique, hipStream_t stream, void* arena_base,
+                          uint64_t arena_bytes) {
+  Arena arena;
+  arena.base = (char*)arena_base;
+  arena.size = arena_base ? (size_t)arena_bytes : 0;
+  struct ArenaScope {
+    ArenaScope(Arena* a) { g_arena = a->base ? a : nullptr; }
+    ~ArenaScope() { g_arena = nullptr; }
+  } scope(&arena);
   *h_n_unique = 0;
   CK(hipMemsetAsync(d_len_hist, 0, (size_t)256 * n_samples * 8, stream));
   if (n == 0) return hipStreamSynchronize(stream);
