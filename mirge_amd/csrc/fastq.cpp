@@ -34,69 +34,6 @@ namespace mrg {
 
 namespace {
 
-// Records straight out of the inflate buffer: four memchr per record, no per-line copies.
-struct RecordReader {
-  gzFile f;
-  std::vector<char> buf;
-  size_t pos = 0, end = 0;
-  bool at_eof = false;
-  explicit RecordReader(const std::string& path) : buf(8u << 20) {
-    f = gzopen(path.c_str(), "rb");
-    if (!f) throw std::runtime_error("cannot open " + path);
-    gzbuffer(f, 1 << 20);
-  }
-  ~RecordReader() {
-    if (f) gzclose(f);
-  }
-  // keep the unread tail, append more input; false when nothing more arrives
-  bool refill() {
-    if (at_eof) return false;
-    if (pos > 0) {
-      std::memmove(buf.data(), buf.data() + pos, end - pos);
-      end -= pos;
-      pos = 0;
-    }
-    if (end == buf.size()) buf.resize(buf.size() * 2);  // a line longer than the buffer
-    const int got = gzread(f, buf.data() + end, (unsigned)std::min<size_t>(buf.size() - end, 1u << 30));
-    if (got < 0) throw std::runtime_error("read error (corrupt gzip?)");
-    if (got == 0) {
-      at_eof = true;
-      return false;
-    }
-    end += (size_t)got;
-    return true;
-  }
-  // One line [*s, *s + *n) without its terminator (CR stripped); false at end of input.
-  // `from` is an offset from pos so that earlier lines of the same record stay valid: callers
-  // re-derive their pointers after a refill (it may move the buffer).
-  bool line_at(size_t from, size_t* start, size_t* len, size_t* next) {
-    for (;;) {
-      const char* base = buf.data() + pos;
-      const size_t avail = end - pos;
-      if (from < avail) {
-        const char* nl = (const char*)std::memchr(base + from, '\n', avail - from);
-        if (nl) {
-          size_t n = (size_t)(nl - (base + from));
-          *next = from + n + 1;
-          if (n && base[from + n - 1] == '\r') --n;
-          *start = from;
-          *len = n;
-          return true;
-        }
-      }
-      if (!refill()) {
-        if (from >= end - pos) return false;
-        size_t n = (end - pos) - from;  // last line without a newline
-        *next = from + n;
-        if (n && buf[pos + from + n - 1] == '\r') --n;
-        *start = from;
-        *len = n;
-        return true;
-      }
-    }
-  }
-};
-
 inline int code_of(char c) {
   switch (c) {
     case 'A': case 'a': return 0;
@@ -262,6 +199,10 @@ struct Batch {
   uint32_t max_len = 0;
   bool has_n = false;
   std::string error;
+  std::vector<char> raw;      // the block's text (whole records), split by a worker
+  uint64_t n_records = 0;
+  uint64_t bad_record = 0;    // 1-based number (inside the block) of an ill-formed record
+  int bad_kind = 0;           // 1 no '@', 2 truncated, 3 sequence / quality lengths differ
 };
 
 void trim_batch(Batch& b, const TrimSpec& spec, int qual_cutoff, int base, int min_len) {
@@ -297,14 +238,101 @@ void trim_batch(Batch& b, const TrimSpec& spec, int qual_cutoff, int base, int m
 
 }  // namespace
 
-// Reader (this thread: inflate + split into records) -> workers (trim) -> parallel 2-bit packing.
+namespace {
+
+// Start of the last record header in p[0, len) that has two more line starts after it inside the
+// block (so that "the line after next starts with '+'" can be tested), or 0 when there is none.
+// A header line starts with '@' and is followed, two lines on, by the '+' line; a quality line
+// that starts with '@' is followed two lines on by a sequence or a header line, never by '+'.
+size_t last_record_start(const char* p, size_t len) {
+  std::vector<size_t> starts;  // starts of the last lines, the last (possibly partial) line first
+  size_t end = len;
+  while (starts.size() < 64) {
+    const void* nl = end ? memrchr(p, '\n', end) : nullptr;  // last newline in [0, end)
+    if (!nl) {
+      starts.push_back(0);
+      break;
+    }
+    const size_t at = (size_t)((const char*)nl - p);
+    starts.push_back(at + 1);
+    end = at;
+  }
+  for (size_t i = 2; i < starts.size(); ++i) {
+    const size_t s0 = starts[i], s2 = starts[i - 2];
+    if (s0 > 0 && s0 < len && p[s0] == '@' && s2 < len && p[s2] == '+') return s0;
+  }
+  return 0;
+}
+
+// raw text of whole records -> seq / qual / off of the batch; an ill-formed record stops the
+// block (b.bad_record = its 1-based number inside the block, b.bad_kind says what was wrong)
+void split_block(Batch& b, bool* any_hi_first1000) {
+  const char* p = b.raw.data();
+  const size_t len = b.raw.size();
+  size_t pos = 0;
+  auto line = [&](size_t from, size_t* st, size_t* ln, size_t* next) -> bool {
+    if (from >= len) return false;
+    const char* nl = (const char*)std::memchr(p + from, '\n', len - from);
+    size_t n = nl ? (size_t)(nl - (p + from)) : len - from;
+    *next = from + n + (nl ? 1 : 0);
+    if (n && p[from + n - 1] == '\r') --n;
+    *st = from;
+    *ln = n;
+    return true;
+  };
+  b.off.push_back(0);
+  b.seq.reserve(len / 3);
+  b.qual.reserve(len / 3);
+  while (pos < len) {
+    size_t st[4], ln[4], nx = 0;
+    if (!line(pos, &st[0], &ln[0], &nx)) break;
+    if (ln[0] == 0) {  // blank line between records
+      pos = nx;
+      continue;
+    }
+    bool whole = true;
+    for (int k = 1; k < 4 && whole; ++k) whole = line(nx, &st[k], &ln[k], &nx);
+    if (p[st[0]] != '@') {
+      b.bad_record = b.n_records + 1;
+      b.bad_kind = 1;
+      return;
+    }
+    if (!whole) {
+      b.bad_record = b.n_records + 1;
+      b.bad_kind = 2;
+      return;
+    }
+    if (ln[1] != ln[3]) {
+      b.bad_record = b.n_records + 1;
+      b.bad_kind = 3;
+      return;
+    }
+    if (any_hi_first1000 && b.n_records < 1000) {
+      const char* q = p + st[3];
+      for (size_t i = 0; i < ln[3]; ++i)
+        if ((unsigned char)q[i] > 74) *any_hi_first1000 = true;
+    }
+    ++b.n_records;
+    b.seq.insert(b.seq.end(), p + st[1], p + st[1] + ln[1]);
+    b.qual.insert(b.qual.end(), p + st[3], p + st[3] + ln[3]);
+    b.off.push_back((uint32_t)b.seq.size());
+    pos = nx;
+  }
+  std::vector<char>().swap(b.raw);
+}
+
+}  // namespace
+
+// Reader (this thread: inflate, cut the text at record boundaries) -> workers (split a block into
+// records, trim them) -> parallel 2-bit packing.  The per-record work is in the workers: the
+// reader only finds the last record header of each ~4 MB block.
 // The reference does the same with cutadapt worker processes (trim_file.py:24-66, `-cpu`).
 void load_fastq(const std::string& path, int qual_cutoff, int min_len, const char* adapter, int threads,
                 FastqData& out) {
   out = FastqData();
   const TrimSpec spec = parse_trim_spec(adapter);
-  if (threads <= 0) threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
-  constexpr size_t kBatchRecords = 1 << 15;
+  if (threads <= 0) threads = (int)std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
+  constexpr size_t kBlockBytes = 4u << 20;
 
   std::deque<std::unique_ptr<Batch>> batches;  // in file order; stable addresses
   std::mutex mu;
@@ -312,17 +340,21 @@ void load_fastq(const std::string& path, int qual_cutoff, int min_len, const cha
   size_t next_job = 0;
   bool eof = false;
   int base = 33;
+  bool any64 = false;  // written by the worker of block 0 only
   auto worker = [&]() {
     for (;;) {
       Batch* job = nullptr;
+      bool first_block = false;
       {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return next_job < batches.size() || eof; });
         if (next_job >= batches.size()) return;
+        first_block = next_job == 0;
         job = batches[next_job++].get();
       }
       try {
-        trim_batch(*job, spec, qual_cutoff, base, min_len);
+        split_block(*job, first_block ? &any64 : nullptr);
+        if (!job->bad_record) trim_batch(*job, spec, qual_cutoff, base, min_len);
       } catch (const std::exception& e) {
         job->error = e.what();
       }
@@ -345,56 +377,97 @@ void load_fastq(const std::string& path, int qual_cutoff, int min_len, const cha
     }
   } joiner{pool, mu, cv, eof};
 
-  RecordReader rd(path);
-  bool any64 = false;
-  std::unique_ptr<Batch> cur(new Batch());
-  cur->off.push_back(0);
-  auto flush = [&]() {
-    if (cur->off.size() == 1) return;
+  gzFile f = gzopen(path.c_str(), "rb");
+  if (!f) throw std::runtime_error("cannot open " + path);
+  struct Closer {
+    gzFile f;
+    ~Closer() { gzclose(f); }
+  } closer{f};
+  gzbuffer(f, 1 << 20);
+  std::vector<char> buf;
+  size_t have = 0;
+  bool at_eof = false, started = false;
+  auto hand_over = [&](size_t n_bytes) {
+    std::unique_ptr<Batch> bt(new Batch());
+    bt->raw.assign(buf.data(), buf.data() + n_bytes);
+    if (!started) {
+      // trim_file.py:104-106 sniffs the first 1000 records for a quality character > 'J' (74); the
+      // trimming workers are created while the first record is being read (:107-110), so only
+      // that record decides the base they trim with
+      const char* p = bt->raw.data();
+      const size_t len = bt->raw.size();
+      size_t pos = 0, lines = 0, qs = 0, qe = 0;
+      while (pos < len && lines < 4) {
+        const char* nl = (const char*)std::memchr(p + pos, '\n', len - pos);
+        const size_t e = nl ? (size_t)(nl - p) : len;
+        if (lines == 0 && e == pos) {  // blank lines before the first record
+          pos = e + 1;
+          continue;
+        }
+        if (lines == 3) {
+          qs = pos;
+          qe = e;
+        }
+        ++lines;
+        pos = e + 1;
+      }
+      bool hi = false;
+      for (size_t i = qs; i < qe; ++i) hi |= (unsigned char)p[i] > 74;
+      base = hi ? 64 : 33;
+      for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+      started = true;
+    }
     {
       std::lock_guard<std::mutex> lk(mu);
-      batches.push_back(std::move(cur));
+      batches.push_back(std::move(bt));
     }
     cv.notify_one();
-    cur.reset(new Batch());
-    cur->off.push_back(0);
+    std::memmove(buf.data(), buf.data() + n_bytes, have - n_bytes);
+    have -= n_bytes;
   };
   for (;;) {
-    size_t st[4], ln[4], nx = 0;
-    if (!rd.line_at(0, &st[0], &ln[0], &nx)) break;
-    if (ln[0] == 0) {  // blank line between records
-      rd.pos += nx;
+    // the first block must hold the 1000 records the quality sniff looks at
+    const size_t want = started ? kBlockBytes : std::max<size_t>(kBlockBytes, 1u << 20);
+    while (!at_eof && have < want) {
+      if (buf.size() < have + (1u << 20)) buf.resize(std::max<size_t>(buf.size() * 2, have + (2u << 20)));
+      const int got = gzread(f, buf.data() + have, (unsigned)std::min<size_t>(buf.size() - have, 1u << 30));
+      if (got < 0) throw std::runtime_error("read error (corrupt gzip?)");
+      if (got == 0) at_eof = true;
+      have += (size_t)got;
+    }
+    if (at_eof) {
+      if (have) hand_over(have);
+      break;
+    }
+    size_t cut = last_record_start(buf.data(), have);
+    if (!started) {
+      // (at least 1000 records in the first block: count the lines before the cut)
+      size_t lines = 0;
+      for (const char* q = buf.data(); cut && lines < 4004;) {
+        q = (const char*)std::memchr(q, '\n', buf.data() + cut - q);
+        if (!q) break;
+        ++lines;
+        ++q;
+      }
+      if (cut && lines < 4004) cut = 0;
+    }
+    if (cut == 0) {  // no boundary yet (a record longer than the block, or a short first block): read on
+      const size_t more = have + kBlockBytes;
+      while (!at_eof && have < more) {
+        if (buf.size() < have + (1u << 20)) buf.resize(std::max<size_t>(buf.size() * 2, have + (2u << 20)));
+        const int got = gzread(f, buf.data() + have, (unsigned)std::min<size_t>(buf.size() - have, 1u << 30));
+        if (got < 0) throw std::runtime_error("read error (corrupt gzip?)");
+        if (got == 0) at_eof = true;
+        have += (size_t)got;
+      }
+      if (at_eof) {
+        if (have) hand_over(have);
+        break;
+      }
       continue;
     }
-    bool whole = true;
-    for (int k = 1; k < 4 && whole; ++k) whole = rd.line_at(nx, &st[k], &ln[k], &nx);
-    const char* rec = rd.buf.data() + rd.pos;  // valid now: no refill after the last line_at
-    if (rec[st[0]] != '@') throw std::runtime_error(path + ": record " + std::to_string(out.n_total + 1) + " does not start with '@'");
-    if (!whole) throw std::runtime_error(path + ": truncated record " + std::to_string(out.n_total + 1));
-    if (ln[1] != ln[3])
-      throw std::runtime_error(path + ": sequence and quality lengths differ in record " + std::to_string(out.n_total + 1));
-    const char* seq = rec + st[1];
-    const char* qual = rec + st[3];
-    // trim_file.py:104-106 sniffs the first 1000 records for a quality character > 'J' (74);
-    // the trimming workers are created while the first record is being read (:107-110), so
-    // only that record decides the base they trim with
-    if (out.n_total < 1000) {
-      bool hi = false;
-      for (size_t i = 0; i < ln[3]; ++i) hi |= (unsigned char)qual[i] > 74;
-      if (hi) any64 = true;
-      if (out.n_total == 0) {
-        base = hi ? 64 : 33;
-        for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
-      }
-    }
-    ++out.n_total;
-    cur->seq.insert(cur->seq.end(), seq, seq + ln[1]);
-    cur->qual.insert(cur->qual.end(), qual, qual + ln[3]);
-    cur->off.push_back((uint32_t)cur->seq.size());
-    rd.pos += nx;
-    if (cur->off.size() > kBatchRecords) flush();
+    hand_over(cut);
   }
-  flush();
   {
     std::lock_guard<std::mutex> lk(mu);
     eof = true;
@@ -402,6 +475,17 @@ void load_fastq(const std::string& path, int qual_cutoff, int min_len, const cha
   cv.notify_all();
   for (auto& t : pool) t.join();
   pool.clear();
+
+  for (size_t b = 0; b < batches.size(); ++b) {
+    const Batch& bt = *batches[b];
+    if (bt.bad_record) {
+      const std::string rec = std::to_string(out.n_total + bt.bad_record);
+      if (bt.bad_kind == 1) throw std::runtime_error(path + ": record " + rec + " does not start with '@'");
+      if (bt.bad_kind == 2) throw std::runtime_error(path + ": truncated record " + rec);
+      throw std::runtime_error(path + ": sequence and quality lengths differ in record " + rec);
+    }
+    out.n_total += bt.n_records;
+  }
 
   out.phred = any64 ? 64 : 33;
   std::vector<uint64_t> first(batches.size() + 1, 0);

@@ -41,6 +41,55 @@ def test_fastq_loader_matches_oracle(native_lib, tmp_path, gz, first_hi):
     assert 0 < len(want) < total
 
 
+@pytest.mark.parametrize("crlf", [False, True])
+def test_fastq_loader_block_boundaries(native_lib, tmp_path, crlf):
+    """A file of several reader blocks (the reader cuts the text at the last record header of each
+    ~4 MB block; the workers split the blocks into records): quality lines that start with '@' or
+    '+', blank lines between records, a last record without a newline, CRLF line ends, a phred-64
+    looking record among the first 1000 but not the first -- every record arrives, in file order."""
+    rng = np.random.default_rng(17)
+    n = 120_000
+    p = str(tmp_path / "blocks.fastq")
+    nl = "\r\n" if crlf else "\n"
+    with open(p, "w", newline="") as fh:
+        for i in range(n):
+            L = int(rng.integers(16, 45))
+            seq = "".join("ACGT"[int(c)] for c in rng.integers(0, 4, L))
+            q = rng.integers(25, 41, L)
+            qs = "".join(chr(int(x) + 33) for x in q)
+            if i % 7 == 0:
+                qs = "@" + qs[1:]          # '@' = quality 31
+            if i % 11 == 0:
+                qs = "+" + qs[1:]          # '+' = quality 10
+            if i == 500:
+                qs = "h" * L               # > 'J': the file is sniffed as phred 64, the workers trim with 33
+            rec = "@read%d some text%s%s%s+%s%s" % (i, nl, seq, nl, nl, qs)
+            fh.write(rec + (nl if i + 1 < n else ""))
+    assert os.path.getsize(p) > 9_000_000
+    want, total, phred = oingest.load_fastq(p)
+    for threads in (1, 5):
+        got = ingest.load_fastq(p, threads=threads)
+        assert (got["total"], got["kept"], got["phred"]) == (total, len(want), phred) == (n, len(want), 64)
+        assert pack.unpack_reads(got["words"], got["lens"], got["nmask"]) == want
+    # blank lines between records (the oracle reads four lines at a time; the product skips them)
+    blank = str(tmp_path / "blank.fastq")
+    with open(p, newline="") as src, open(blank, "w", newline="") as dst:
+        recs = src.read().split(nl + "@read")
+        dst.write((nl + nl + "@read").join(recs[:2000]) + nl + ("@read" + (nl + "@read").join(recs[2000:])))
+    gotb = ingest.load_fastq(blank, threads=3)
+    assert (gotb["total"], gotb["kept"]) == (n, len(want))
+    assert pack.unpack_reads(gotb["words"], gotb["lens"], gotb["nmask"]) == want
+    # a broken record deep in the file is reported with its number in the file
+    from mirge_amd._native import MirgeAmdError
+    bad = str(tmp_path / "bad_deep.fastq")
+    with open(p) as src, open(bad, "w", newline="") as dst:
+        text = src.read()
+        k = text.index("@read100000 ")
+        dst.write(text[:k] + "read100000 broken" + text[k + len("@read100000 some text"):])
+    with pytest.raises(MirgeAmdError, match="record 100001"):
+        ingest.load_fastq(bad)
+
+
 def test_quality_trim_rule_known_answers():
     q = lambda s: "".join(chr(x + 33) for x in s)
     t = oingest.quality_trim_3p
