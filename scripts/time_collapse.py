@@ -41,5 +41,5 @@ for n_samples in (1, 4):
             ts.append(time.perf_counter() - t0)
         best = min(ts[1:])
         print("collapse n=%d S=%d %s: %.1f ms -> %.0f M reads/s, %d uniques" %
-              (n, n_samples, "fused 64-bit key" if max_len else "general multi-pass", best * 1e3, n / best / 1e6,
+              (n, n_samples, "keys-only (key = read + length [+ sample])" if max_len else "general (ids sorted column by column)", best * 1e3, n / best / 1e6,
                nu.value), flush=True)
