@@ -17,6 +17,9 @@ rocprofv3 --pmc TCP_TOTAL_ACCESSES TCP_TCC_READ_REQ TCP_TCC_READ_REQ_LATENCY TCP
 rocprofv3 --pmc TCC_REQ TCC_HIT TCC_MISS --output-format csv -d gpurun_out/${tag}_tcc -- $B --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${tag}_tcc.err
 # the a2i workload's kernels (edit tally) by time
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_a2i_stats -- $B --workload a2i --steps 5 --warmup 1 > gpurun_out/${tag}_a2i_stats.json 2> gpurun_out/${tag}_a2i_stats.err
+# ... and of the exact (BASELINE configs[1], the roofline configuration) and varlen workloads
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_exact_stats -- $B --workload exact --steps 20 --warmup 2 > gpurun_out/${tag}_exact_stats.json 2> gpurun_out/${tag}_exact_stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_varlen_stats -- $B --workload varlen --steps 5 --warmup 1 > gpurun_out/${tag}_varlen_stats.json 2> gpurun_out/${tag}_varlen_stats.err
 # the bench lines proper (no profiler attached)
 python bench.py 2> gpurun_out/${tag}_bench_cascade.err > gpurun_out/${tag}_bench_cascade.json
 python bench.py --workload exact 2> gpurun_out/${tag}_bench_exact.err > gpurun_out/${tag}_bench_exact.json
