@@ -64,6 +64,8 @@ def kernel_name(W, table_row, s, n_bases):
         return "mrg::fused_kernel<%d, false>" % W   # (launch_table switches to <W, true> when a member carries pair tables)
     if s["lds_mode"] in (5, 6):
         return "mrg::stratum_kernel<%d>" % W
+    if s["lds_mode"] == 7:
+        return "mrg::exact_dict_kernel"
     has_ctx = n_bases >= (1 << 20) and s["lds_mode"] in (0, 1)
     return "mrg::match_kernel<%d, %s, %s, %s, %s>" % (
         W, {0: "false, false", 1: "true, false", 2: "true, true", 3: "false, true"}[s["lds_mode"]],

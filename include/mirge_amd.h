@@ -127,6 +127,27 @@ typedef struct mrg_index_view {
 } mrg_index_view;
 int mrg_index_get_view(const mrg_index *ix, mrg_index_view *view);
 
+/* Exact-match dictionary of a library of at most 2^22 bases (read-only view, index lifetime; built on
+ * the first request for a key length and uploaded by mrg_ctx_add_library): what answers the `-n 0` /
+ * `-v 0` runs (RAP:577, :598, :688) for one-word reads in ONE 16-byte load.  Open addressing, 2^log2_slots
+ * slots of two uint64:
+ *   slots[2 i]      the 32 text bases from the slot's text position (2 bits per base, first base lowest)
+ *   slots[2 i + 1]  low 32 bits: library entry; high 32 bits: bits 0-5 bases to the end of the
+ *                   position's N-free segment (clamped to 63), bits 6-9 chain = how far behind its
+ *                   home slot a key homed at slot i may sit (15 = overflowed: ask the FM index),
+ *                   bit 10 occupied, bits 11-31 offset of the position in its entry
+ * home slot of a key = ((uint32) of its first key_bases bases * 0x9E3779B1) >> (32 - log2_slots);
+ * keys are inserted in text order, a position that an earlier one makes unreachable is left out, so
+ * the first match along home, home + 1, ... home + chain is the lowest (entry, offset). */
+typedef struct mrg_dict_view {
+  const uint64_t *slots;
+  uint32_t log2_slots;
+  uint32_t key_bases;
+  uint64_t n_keys;     /* positions stored */
+  uint64_t n_overflow; /* positions left to the FM index because their home slot's chain overflowed */
+} mrg_dict_view;
+int mrg_index_get_dict(const mrg_index *ix, uint32_t key_bases, mrg_dict_view *view);
+
 /* ------------------------------------------------------------------ *
  * Context: one per GPU.  Replaces the per-pass process spawn + .ebwt
  * load of RAP:643 / RAP:689 with libraries resident in HBM.
@@ -162,7 +183,11 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * libraries of >= 2^20 bases -- a one-mismatch pass inside a fused launch searches reads whose seed
  * region is 3A .. 4A - 1 bases through three anchor pairs instead of two short pigeonhole pieces
  * (tables built on the device the first time such reads are met; mrg_pass_stats.pair_anchor reports
- * A); "wide_rows_16", "round_large": see DESIGN.md. */
+ * A); "dict" = 1 (default) / 0: batches of one-word reads without an N mask run the dictionary
+ * kernels for the passes that can (a pass without seed mismatches on a library of at most 4 Mbp: one
+ * load of its exact-match dictionary per read, built by mrg_ctx_add_library while the option is 1);
+ * "dict_key" = 16 (default) / 8..16: key length of those dictionaries (set BEFORE adding libraries;
+ * reads shorter than the key take the FM index); "wide_rows_16", "round_large": see DESIGN.md. */
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);
 int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,
                         char *arch, uint32_t arch_cap);
@@ -193,7 +218,10 @@ typedef struct mrg_pass_stats {
   uint32_t lds_mode;   /* 0 nothing, 1 occ blocks, 2 occ blocks + text, 3 text only: names the
                           match_kernel<W, blocks, text> instantiation that ran; 4 = the pass ran
                           inside a fused launch (fused_kernel<W>, only its 9-mer bitmap in LDS);
-                          5 / 6 = stratum_kernel<W> with / without the packed text in LDS */
+                          5 / 6 = stratum_kernel<W> with / without the packed text in LDS;
+                          7 = exact_dict_kernel (one slot load of the library's exact-match
+                          dictionary per read: steps = 0, lookups = slot / table loads, candidates =
+                          slots / rows compared) */
   uint32_t group;      /* index of the first pass of the launch this pass ran in (itself when it
                           had a launch of its own) */
   uint32_t n_launches; /* kernel launches that carried this pass: 1, or 2 for a 2-mismatch pass split

@@ -56,6 +56,11 @@ class IndexView(C.Structure):
                [(k, C.POINTER(C.c_uint32)) for k in ("seg_start", "seg_ref", "seg_off", "chunk_seg", "ctx", "kbits")]
 
 
+class DictView(C.Structure):
+    _fields_ = [("slots", C.POINTER(C.c_uint64)), ("log2_slots", C.c_uint32), ("key_bases", C.c_uint32),
+                ("n_keys", C.c_uint64), ("n_overflow", C.c_uint64)]
+
+
 # name -> (restype, argtypes); every symbol include/mirge_amd.h declares
 SIGNATURES = {
     "mrg_version": (C.c_int, []),
@@ -73,6 +78,7 @@ SIGNATURES = {
     "mrg_index_seq": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32,
                                 C.POINTER(C.c_uint32)]),
     "mrg_index_get_view": (C.c_int, [C.c_void_p, C.POINTER(IndexView)]),
+    "mrg_index_get_dict": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(DictView)]),
     "mrg_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "mrg_ctx_destroy": (None, [C.c_void_p]),
     "mrg_ctx_add_library": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),

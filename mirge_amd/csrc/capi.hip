@@ -9,11 +9,14 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/mirge_amd.h"
+#include "dict_index.hpp"
 #include "fastq.hpp"
 #include "fm_index.hpp"
 #include "kernels.hpp"
@@ -21,6 +24,20 @@
 
 struct mrg_index {
   mrg::FmIndex ix;
+  // exact-match dictionaries by key length, built on first request (mrg_index_get_dict,
+  // mrg_ctx_add_library) and kept for the life of the index
+  mutable std::map<uint32_t, mrg::ExactDict> dicts;
+  mutable std::mutex dict_mutex;
+  const mrg::ExactDict& dict(uint32_t key_bases) const {
+    std::lock_guard<std::mutex> g(dict_mutex);
+    auto it = dicts.find(key_bases);
+    if (it == dicts.end()) {
+      mrg::ExactDict d;
+      mrg::build_exact_dict(ix, key_bases, d);
+      it = dicts.emplace(key_bases, std::move(d)).first;
+    }
+    return it->second;
+  }
 };
 struct mrg_fastq {
   mrg::FastqData d;
@@ -68,6 +85,9 @@ struct DevLib {
   uint32_t bpair_row_off[3] = {0, 0, 0};
   uint32_t bpair_anchor = 0;
   bool bpair_failed = false;  // not enough free HBM: the pigeonhole pieces stay
+  // exact-match dictionary (dict_index.hpp) of a library of at most kDictMaxBases bases
+  mrg::DictSlot* dict_slots = nullptr;
+  uint32_t dict_log2 = 0, dict_key = 0;
   uint32_t* kbits = nullptr;
   std::vector<uint32_t> kbits_host;  // host copy (32 KB): the per-round interleaved tables are built from it
   uint32_t* ftab = nullptr;
@@ -164,6 +184,8 @@ struct mrg_ctx {
   int64_t pair_seeds = 1;    // 2-mismatch passes on small libraries search through anchor pairs (set before add_library)
   int64_t stratum_rows = 0;  // (measured slower than match_kernel: 2.43 vs 2.28 ms) 1: the last stratum of a split 2-mismatch pass runs stratum_kernel; 2: every strata launch does
   int64_t wide_rows_16 = 1;  // libraries of >= 2^20 bases get 16-byte rows with 32 bases of context
+  int64_t dict = 1;          // one-word batches without N run the dictionary kernels (dict.hip) where a pass can
+  int64_t dict_key = 16;     // key length of the exact-match dictionaries (set before add_library)
   std::vector<DevLib> libs;
   // last run
   hipStream_t last_stream = nullptr;
@@ -326,6 +348,23 @@ int mrg_index_get_view(const mrg_index* h, mrg_index_view* v) {
   return MRG_OK;
 }
 
+int mrg_index_get_dict(const mrg_index* h, uint32_t key_bases, mrg_dict_view* v) {
+  if (!h || !v) return fail(MRG_ERR_ARG, "mrg_index_get_dict: null argument");
+  try {
+    const mrg::ExactDict& d = h->dict(key_bases);
+    v->slots = reinterpret_cast<const uint64_t*>(d.slots.data());
+    v->log2_slots = d.log2_slots;
+    v->key_bases = d.key_bases;
+    v->n_keys = d.n_keys;
+    v->n_overflow = d.n_overflow;
+    return MRG_OK;
+  } catch (const std::bad_alloc&) {
+    return fail(MRG_ERR_NOMEM, "mrg_index_get_dict: out of memory");
+  } catch (const std::exception& e) {
+    return fail(MRG_ERR_ARG, "mrg_index_get_dict: %s", e.what());
+  }
+}
+
 // --------------------------------------------------------------- context
 int mrg_ctx_create(int device, mrg_ctx** out) {
   if (!out) return fail(MRG_ERR_ARG, "mrg_ctx_create: null argument");
@@ -371,6 +410,7 @@ void mrg_ctx_destroy(mrg_ctx* ctx) {
     (void)hipFree(l.bpair_jump);
     (void)hipFree(l.bpair_rows);
     (void)hipFree(l.kbits);
+    (void)hipFree(l.dict_slots);
     (void)hipFree(l.seg_start);
     (void)hipFree(l.seg_ref);
     (void)hipFree(l.seg_off);
@@ -393,7 +433,7 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
     DevLib* l;
     ~Guard() {
       if (!l) return;
-      void* ptrs[] = {l->blocks, l->super, l->text, l->sa, l->ftab, l->ctx, l->sa16, l->kbits, l->pair_jump, l->pair_jump_s, l->pair_rows,
+      void* ptrs[] = {l->blocks, l->super, l->text, l->sa, l->ftab, l->ctx, l->sa16, l->kbits, l->pair_jump, l->pair_jump_s, l->pair_rows, l->dict_slots,
                       l->seg_start, l->seg_ref, l->seg_off, l->chunk_seg};
       for (void* p : ptrs) (void)hipFree(p);
     }
@@ -464,6 +504,19 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
     if ((rc = upload(&l.pair_rows, pt.rows))) return rc;
     l.pair_anchor = pt.anchor;
   }
+  if (ctx->dict && ix.n <= mrg::kDictMaxBases && ix.n >= (uint32_t)ctx->dict_key) {
+    const mrg::ExactDict* ed = nullptr;
+    try {
+      ed = &h->dict((uint32_t)ctx->dict_key);
+    } catch (const std::exception&) {
+      ed = nullptr;  // entries too long for the slot format: the FM kernels serve this library
+    }
+    if (ed) {
+      if ((rc = upload(&l.dict_slots, ed->slots))) return rc;
+      l.dict_log2 = ed->log2_slots;
+      l.dict_key = ed->key_bases;
+    }
+  }
   if (!ix.kbits.empty() && (rc = upload(&l.kbits, ix.kbits))) return rc;
   l.kbits_host = ix.kbits;  // the interleaved tables of fused rounds are built from it
   if ((rc = upload(&l.seg_start, ix.seg_start))) return rc;
@@ -518,6 +571,11 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->round_large = value != 0;
   } else if (k == "wide_rows_16") {
     ctx->wide_rows_16 = value != 0;  // takes effect for libraries added afterwards
+  } else if (k == "dict") {
+    ctx->dict = value != 0;  // (the dictionaries themselves are built by mrg_ctx_add_library while this is 1)
+  } else if (k == "dict_key") {
+    if (value < 8 || value > 16) return fail(MRG_ERR_ARG, "dict_key must be in [8,16]");
+    ctx->dict_key = value;
   } else if (k == "fuse") {
     if (value < 0 || value > 3) return fail(MRG_ERR_ARG, "fuse must be in [0,3]");
     ctx->fuse = value;
@@ -539,10 +597,11 @@ int mrg_ctx_device_info(const mrg_ctx* ctx, int32_t* n_cu, uint64_t* hbm_bytes, 
 }
 
 // --------------------------------------------------------------- cascade
-// workspace: [idx A][idx B]  (each n + kMaxSegments*1024 u32: segmented survivor lists)
+// workspace: [idx A][idx B]  (each n + kMaxSegments*4096 u32: segmented survivor lists; a producer
+//            workgroup's segment holds every read of its chunks, 1024 or 4096 reads each)
 //            [segment counts A, B: kMaxSegments u32 each][stats: MRG_MAX_PASSES * 5 u64]
 static uint64_t ws_idx_bytes(uint64_t n) {
-  return (((n + (uint64_t)mrg::kMaxSegments * 1024) * 4 + 255) / 256) * 256;
+  return (((n + (uint64_t)mrg::kMaxSegments * 4096) * 4 + 255) / 256) * 256;
 }
 static const uint64_t kWsCountsBytes = 2 * mrg::kMaxSegments * 4;
 static const uint64_t kWsStatsBytes = MRG_MAX_PASSES * kStatsPerPass * 8;
@@ -594,6 +653,16 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
   // "unannotated" values for whatever it does not claim)
   HIP_TRY(hipMemsetAsync(stats, 0, kWsStatsBytes, stream));
   uint32_t prev_grid = 0, prev_seg_cap = 0;
+  // Capacity of a producer workgroup's list segment: it must hold every read the workgroup may be
+  // offered -- its share of an identity list in chunks of `chunk` reads, or, reading a list, the
+  // segments whose chunks it walks (chunk c belongs to segment c % in_nseg and goes to workgroup
+  // c % grid: ceil(in_nseg / grid) whole segments at most).
+  auto segment_capacity = [&](uint32_t grid, uint64_t chunk, bool reads_list) -> uint32_t {
+    const uint64_t per_trip = chunk * grid;
+    uint64_t cap = ((n + per_trip - 1) / per_trip) * chunk;
+    if (reads_list) cap = std::max<uint64_t>(cap, (uint64_t)((prev_grid + grid - 1) / grid) * prev_seg_cap);
+    return (uint32_t)cap;
+  };
   int cur_list = 0;        // which of the two list buffers holds the newest survivor list
   bool have_list = false;  // false: the next pass that runs reads the identity list of all reads
 
@@ -623,11 +692,72 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     return ctx->fuse != 0 && passes[i].max_mm_seed <= 1 && n / (1024ull * (uint64_t)std::max(ctx->n_cu, 1)) < 60000ull;
   };
   auto small_lib = [&](uint32_t i) { return ctx->libs[passes[i].lib].kbits != nullptr && ctx->kmer_filter; };
+  // one-word reads without N: the batches the dictionary kernels (dict.hip) take
+  const bool dict_batch = ctx->dict && words_per_read == 1 && !d_nmask;
 
   // the classic path: one match_kernel launch for pass i
   auto run_single = [&](uint32_t i, int32_t k_first, int32_t k_last, bool first_part, bool last_part, bool by_pairs = false) -> int {
     const mrg_pass_cfg& c = passes[i];
     const DevLib& l = ctx->libs[c.lib];
+    if (dict_batch && c.max_mm_seed == 0 && l.dict_slots && ctx->force_lds_mode < 0) {
+      // no seed mismatch, one-word reads, a library with an exact-match dictionary: dict.hip
+      mrg::ExactParams e;
+      e.slots = reinterpret_cast<const uint4*>(l.dict_slots);
+      e.log2_slots = l.dict_log2;
+      e.key_bases = l.dict_key;
+      e.kbits = ctx->kmer_filter ? l.kbits : nullptr;
+      e.ftab = l.ftab;
+      e.tabs = l.tabs;
+      e.sa = l.sa;
+      e.text = l.text;
+      e.n = l.n;
+      e.seg_start = l.seg_start;
+      e.seg_ref = l.seg_ref;
+      e.seg_off = l.seg_off;
+      e.chunk_seg = l.chunk_seg;
+      e.simple_segs = l.simple ? 1u : 0u;
+      e.reads = d_reads;
+      e.lens = d_lens;
+      e.n_total = (uint32_t)n;
+      const int next_list = have_list ? (cur_list ^ 1) : 0;
+      e.idx_in = have_list ? idx[cur_list] : nullptr;
+      e.in_count = counts + cur_list * mrg::kMaxSegments;
+      e.in_nseg = prev_grid;
+      e.in_seg_cap = prev_seg_cap;
+      e.idx_out = (i + 1 < n_pass) ? idx[next_list] : nullptr;
+      e.out_count = counts + next_list * mrg::kMaxSegments;
+      e.pass_id = d_pass_id;
+      e.ref_id = d_ref_id;
+      e.pos = d_pos;
+      e.mm = d_mm;
+      e.counters = stats + (size_t)i * kStatsPerPass;
+      e.seed_len = c.seed_len;
+      e.max_mm_total = c.max_mm_total;
+      e.trim5 = c.trim5;
+      e.trim3 = c.trim3;
+      e.min_len = c.min_len;
+      e.max_len = c.max_len;
+      e.poly_t = c.poly_t;
+      e.pass_index = (int32_t)i;
+      uint32_t grid = (uint32_t)ctx->n_cu * 2u;
+      if (grid > mrg::kMaxSegments) grid = mrg::kMaxSegments;
+      // (a workgroup takes chunks of 4096 reads: four per lane)
+      const uint32_t seg_cap = segment_capacity(grid, mrg::kExactChunk, have_list);
+      e.out_seg_cap = seg_cap;
+      ctx->last_lds[i] = 0u;
+      ctx->last_mode[i] = 7u;
+      ctx->last_group[i] = i;
+      if (n) HIP_TRY(mrg::launch_exact_dict(e, grid, stream));
+      ctx->last_launches[i] += 1;
+      HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
+      if (e.idx_out) {
+        cur_list = next_list;
+        have_list = true;
+        prev_grid = grid;
+        prev_seg_cap = seg_cap;
+      }
+      return MRG_OK;
+    }
     mrg::MatchParams p;
     p.blocks = l.blocks;
     p.super = l.super;
@@ -750,7 +880,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     uint32_t grid = (uint32_t)ctx->n_cu * per_cu;
     if (grid > mrg::kMaxSegments) grid = mrg::kMaxSegments;
     // a workgroup's segment must hold every read it may be offered
-    const uint32_t seg_cap = (uint32_t)(((n + 1024ull * grid - 1) / (1024ull * grid)) * 1024ull);
+    const uint32_t seg_cap = segment_capacity(grid, 1024, have_list);
     p.out_seg_cap = seg_cap;
     ctx->last_lds[i] = lds_bytes;
     ctx->last_mode[i] = (uint32_t)lds_mode;
@@ -956,7 +1086,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     const uint32_t per_cu = 1u;
     uint32_t grid = (uint32_t)ctx->n_cu * per_cu;
     if (grid > mrg::kMaxSegments) grid = mrg::kMaxSegments;
-    const uint32_t seg_cap = (uint32_t)(((n + 1024ull * grid - 1) / (1024ull * grid)) * 1024ull);
+    const uint32_t seg_cap = segment_capacity(grid, 1024, have_list);
     fp.out_seg_cap = seg_cap;
     if (n) HIP_TRY(mrg::launch_fused(fp, words_per_read, grid, lds_total, stream));
     ctx->last_launches[members[0]] = 1;

@@ -1,0 +1,111 @@
+// Device helpers shared by the dictionary kernels (dict.hip).  gfx950, wave64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+namespace mrg {
+namespace dev {
+
+constexpr uint64_t kOddBits = 0x5555555555555555ull;
+
+__device__ __forceinline__ uint64_t low_bits(uint32_t nbits) {  // nbits in [0,64]
+  return nbits >= 64 ? ~0ull : ((1ull << nbits) - 1ull);
+}
+
+__device__ __forceinline__ uint32_t mbcnt(uint64_t m) {  // set bits of m below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+__device__ __forceinline__ uint64_t wave_sum(uint64_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// k bases packed first-base-lowest -> their lexicographic number (first base most significant)
+__device__ __forceinline__ uint32_t lex_code(uint64_t code, uint32_t k) {
+  const uint64_t r = __brevll(code) >> (64u - 2u * k);  // groups reversed, bits inside a group swapped
+  return (uint32_t)(((r >> 1) & kOddBits) | ((r & kOddBits) << 1));
+}
+
+// The largest jump table with k <= plen (tables in ascending k; k[0] == 0: none usable): its k
+// (0 = none) and its word offset inside `ftab`.
+__device__ __forceinline__ uint32_t pick_table(const JumpTables& t, int32_t plen, uint32_t& word_off) {
+  uint32_t k = plen >= (int32_t)t.k[0] ? t.k[0] : 0u;
+  word_off = t.off[0];
+#pragma unroll
+  for (int i = 1; i < 4; ++i) {
+    const bool take = plen >= (int32_t)t.k[i];
+    k = take ? t.k[i] : k;
+    word_off = take ? t.off[i] : word_off;
+  }
+  return k;
+}
+
+// 32 text bases from position p (2-bit packed text in global memory, 3 dword loads)
+__device__ __forceinline__ uint64_t text_window(const uint32_t* __restrict__ text, uint32_t p) {
+  const uint32_t i = p >> 4, sh = (p & 15) * 2;
+  const uint32_t w0 = text[i], w1 = text[i + 1], w2 = text[i + 2];
+  const uint64_t lo64 = (uint64_t)w0 | ((uint64_t)w1 << 32);
+  return (lo64 >> sh) | ((((uint64_t)w2) << 1) << (63 - sh));
+}
+
+// mismatch mask (one bit per differing base, in the even bit positions) of two packed sequences
+__device__ __forceinline__ uint64_t mismatch_bits(uint64_t a, uint64_t b) {
+  const uint64_t x = a ^ b;
+  return (x | (x >> 1)) & kOddBits;
+}
+
+// number of trailing T (code 3) of a one-word read of L bases (runAnnotationPipeline.py:664-676)
+__device__ __forceinline__ int32_t trailing_t(uint64_t rd, int32_t L) {
+  const uint64_t x = ~rd & low_bits(2 * (uint32_t)L);  // non-zero 2-bit group = not T
+  const int32_t hb = x ? ((63 - __clzll((long long)x)) >> 1) : -1;
+  return L - 1 - hb;
+}
+
+// inclusive prefix sum over the wave (seven DPP adds)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  const int x = (int)v;
+  int s = x + __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  s += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);         // row_shr:2
+  s += __builtin_amdgcn_update_dpp(0, x, 0x113, 0xf, 0xf, false);         // row_shr:3
+  s += __builtin_amdgcn_update_dpp(0, s, 0x114, 0xf, 0xe, false);         // row_shr:4, lanes 4-15 of a row
+  s += __builtin_amdgcn_update_dpp(0, s, 0x118, 0xf, 0xc, false);         // row_shr:8, lanes 8-15
+  s += __builtin_amdgcn_update_dpp(0, s, 0x142, 0xa, 0xf, false);         // row_bcast:15 into rows 1 and 3
+  s += __builtin_amdgcn_update_dpp(0, s, 0x143, 0xc, 0xf, false);         // row_bcast:31 into rows 2 and 3
+  return (uint32_t)s;
+}
+
+// entry (ref, pos) of text position s whose suffix-array row said (seg16, before): the epilogue of
+// every match kernel
+struct SegTables {
+  const uint32_t* seg_start;
+  const uint32_t* seg_ref;
+  const uint32_t* seg_off;
+  const uint32_t* chunk_seg;
+  uint32_t simple_segs;
+};
+__device__ __forceinline__ void locate_entry(const SegTables& t, uint32_t s, uint32_t seg16, uint32_t before,
+                                             uint32_t& ref, uint32_t& pos) {
+  uint32_t sg = seg16;
+  if (sg == 0xFFFFu) {  // more than 65535 segments: walk the chunk map
+    sg = t.chunk_seg[s >> 5];
+    while (t.seg_start[sg + 1] <= s) ++sg;
+  }
+  ref = sg;
+  if (t.simple_segs && before < 255u) {
+    pos = before;
+  } else {
+    uint32_t off = 0;
+    if (!t.simple_segs) {
+      ref = t.seg_ref[sg];
+      off = t.seg_off[sg];
+    }
+    pos = s - t.seg_start[sg] + off;
+  }
+}
+
+}  // namespace dev
+}  // namespace mrg

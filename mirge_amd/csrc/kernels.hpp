@@ -181,6 +181,50 @@ hipError_t build_pair_tables_device(const uint64_t* sa, const uint32_t* text, ui
                                     uint32_t n_gaps, uint32_t* jump, uint64_t* rows, uint32_t* row_off,
                                     hipStream_t stream);
 
+// ---------------------------------------------------------------------------
+// dict.hip: the dictionary kernels for batches of one-word reads without N.  Same survivor-list
+// format, outputs and counter slots as match_kernel / fused_kernel, so every launch of the plan can
+// be either.
+// ---------------------------------------------------------------------------
+// exact_dict_kernel: a pass with no seed mismatch on a library that has an exact-match dictionary
+// (dict_index.hpp): one 16-byte slot load per read; reads shorter than the dictionary's key, and
+// keys whose chain overflowed, take the FM index (prefix interval of the largest jump table that
+// fits the read, every row verified against the text).
+struct ExactParams {
+  const uint4* slots;
+  uint32_t log2_slots, key_bases;
+  const uint32_t* kbits;  // the library's 9-mer presence bitmap (null = none): staged in LDS as a reject filter
+  // FM index of the same library, for the fallback
+  const uint32_t* ftab;
+  JumpTables tabs;
+  const uint64_t* sa;
+  const uint32_t* text;
+  uint32_t n;
+  const uint32_t* seg_start;
+  const uint32_t* seg_ref;
+  const uint32_t* seg_off;
+  const uint32_t* chunk_seg;
+  uint32_t simple_segs;
+  // reads (one word each, no N mask)
+  const uint64_t* reads;
+  const uint8_t* lens;
+  uint32_t n_total;
+  const uint32_t* idx_in;    // null = identity list of n_total reads
+  const uint32_t* in_count;
+  uint32_t in_nseg, in_seg_cap;
+  uint32_t* idx_out;         // null on the last pass
+  uint32_t* out_count;
+  uint32_t out_seg_cap;
+  int8_t* pass_id;
+  int32_t* ref_id;
+  int32_t* pos;
+  uint8_t* mm;
+  uint64_t* counters;  // processed, aligned, steps (0), candidates (slots / rows compared), lookups (slot + table loads)
+  int32_t seed_len, max_mm_total, trim5, trim3, min_len, max_len, poly_t, pass_index;
+};
+constexpr uint32_t kExactChunk = 4096u;  // reads a workgroup takes per trip (four per lane)
+hipError_t launch_exact_dict(const ExactParams& p, uint32_t grid, hipStream_t stream);
+
 constexpr uint32_t kCountThreads = 256u;
 
 struct CountParams {

@@ -167,3 +167,12 @@ class FmIndex:
             kbits=arr(v.kbits, (1 << 18) // 32) if v.kbits else None,
             n=int(inf.n_bases), primary=int(inf.primary), C=[int(c) for c in inf.C],
             _owner=self)
+
+    def exact_dict(self, key_bases=16):
+        """The library's exact-match dictionary (mrg_index_get_dict): dict(slots uint64 [2^log2, 2],
+        log2_slots, key_bases, n_keys, n_overflow); built on first use, valid while the index lives."""
+        v = _native.DictView()
+        check(self._lib.mrg_index_get_dict(self._h, int(key_bases), C.byref(v)))
+        n = 1 << v.log2_slots
+        return dict(slots=np.ctypeslib.as_array(v.slots, shape=(n, 2)), log2_slots=int(v.log2_slots),
+                    key_bases=int(v.key_bases), n_keys=int(v.n_keys), n_overflow=int(v.n_overflow), _owner=self)

@@ -1,0 +1,112 @@
+"""GPU parity (-m gpu) of the dictionary kernels (csrc/dict.hip): batches of one-word reads without N.
+Assignments and the per-pass processed / aligned counters (bowtie's log lines, RAP:9-18) must equal
+the oracle's CPU port and the exhaustive scan; the FM kernels (option dict = 0) are a third,
+independently implemented witness on the same device."""
+import numpy as np
+import pytest
+
+from oracle import cascade, model
+from tests.util import LIB_ORDER, World
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world(native_lib, oracle_lib):
+    # 22-mers of the standard mixture + 16..32-nt reads cut from the libraries (0-2 edits, some with a
+    # poly-T tail), no N: one word per read
+    w = World(scale=0.05, n_fixed=20000, n_var=6000, with_n=False, max_var_len=32)
+    assert w.words.shape[0] == 1 and w.nmask is None
+    return w
+
+
+@pytest.fixture(scope="module")
+def engine(world):
+    from mirge_amd.engine import Engine
+    eng = Engine(0)
+    for k in LIB_ORDER:
+        eng.add_library(k, world.index[k])
+    return eng
+
+
+def run(engine, world, passes=None, **opts):
+    from mirge_amd.engine import ReadSet
+    for k, v in opts.items():
+        engine.set_option(k, v)
+    rs = ReadSet(world.words, world.lens, None, None, device=engine.device)
+    res = engine.cascade(rs, engine.mirge_passes() if passes is None else engine.make_passes(passes))
+    return res
+
+
+def same_assignments(res, ref):
+    for name, a in zip(("pass_id", "ref_id", "pos", "mm"), res.to_host()):
+        assert np.array_equal(a, ref[name]), name
+    for i, st in enumerate(res.stats):
+        assert st["processed"] == int(ref["stats"][i][0]), i
+        assert st["aligned"] == int(ref["stats"][i][1]), i
+
+
+def test_dict_cascade_equals_port_and_fm_kernels(engine, world):
+    ref = model.fm_cascade(world.views, world.passes, world.words, world.lens, None)
+    for fuse in (1, 0):
+        res = run(engine, world, dict=1, fuse=fuse)
+        same_assignments(res, ref)
+        st = res.stats
+        assert st[0]["lds_mode"] == 7 and st[0]["steps"] == 0   # the first pass ran exact_dict_kernel
+        assert st[0]["aligned"] <= st[0]["lookups"] <= st[0]["processed"]   # at most one home-slot load per offered read
+        if fuse == 0:
+            assert st[3]["lds_mode"] == 7 and st[7]["lds_mode"] != 7  # pre-tRNA has a dictionary, mRNA is too large
+        fm = run(engine, world, dict=0, fuse=fuse)
+        for a, b in zip(res.to_host(), fm.to_host()):
+            assert np.array_equal(a, b)
+    engine.set_option("fuse", 1)
+    engine.set_option("dict", 1)
+
+
+def test_dict_cascade_equals_exhaustive_scan(engine, world):
+    res = run(engine, world, dict=1)
+    pass_id, ref_id, pos, mm = res.to_host()
+    sub = np.random.default_rng(7).choice(len(world.reads), 4000, replace=False)
+    reads = [world.reads[i] for i in sub]
+    libs = {k: model.Library(*world.libs.libs[k]) for k in LIB_ORDER}
+    seq_dic = {r: cascade.new_seq_record(r, 1) for r in reads}
+    log_dic = {"quantStats": [{}], "annotStats": []}
+    align = {}
+    cascade.run_annotation_pipeline(seq_dic, libs, log_dic, align_dic=align)
+    for i, r in zip(sub, reads):
+        got = None if pass_id[i] < 0 else (int(pass_id[i]), int(ref_id[i]), int(pos[i]), int(mm[i]))
+        assert align.get(r) == got, r
+
+
+def test_exact_policies_on_every_dictionary_library(engine, world):
+    """Single-pass cascades (the pass is first AND last: identity list in, 'unannotated' written for
+    the rest) with `-n 0`, `-v 0`, trims and the poly-T rule, against the port: reads longer than the
+    seed (29..32 nt: mismatches allowed behind base 28), reads shorter than the 16-base key after
+    trimming (FM fallback)."""
+    for lib in ("mirna", "hairpin", "pre_trna", "snorna"):
+        li = LIB_ORDER.index(lib)
+        for pol in (dict(seed_len=28, max_mm_seed=0, max_mm_total=2), dict(seed_len=1024, max_mm_seed=0, max_mm_total=0),
+                    dict(seed_len=20, max_mm_seed=0, max_mm_total=3, trim5=1, trim3=2),
+                    dict(seed_len=1024, max_mm_seed=0, max_mm_total=0, poly_t=1),
+                    dict(seed_len=28, max_mm_seed=0, max_mm_total=2, min_len=18, max_len=25, trim3=4)):
+            p = dict(lib=li, min_len=0, max_len=255, trim5=0, trim3=0, poly_t=0)
+            p.update(pol)
+            ref = model.fm_cascade(world.views, [p], world.words, world.lens, None)
+            res = run(engine, world, passes=[dict(p, lib=lib)], dict=1)
+            same_assignments(res, ref)
+            assert res.stats[0]["lds_mode"] == 7
+            assert 0 < res.stats[0]["aligned"] < res.stats[0]["processed"]
+
+
+def test_short_dictionary_keys(world):
+    """dict_key = 12: nothing takes the fallback; dict_key = 16 is the default tested above."""
+    from mirge_amd.engine import Engine
+    eng = Engine(0)
+    eng.set_option("dict_key", 12)
+    for k in LIB_ORDER:
+        eng.add_library(k, world.index[k])
+    ref = model.fm_cascade(world.views, world.passes, world.words, world.lens, None)
+    res = run(eng, world)
+    same_assignments(res, ref)
+    assert res.stats[0]["lds_mode"] == 7
+    eng.close()

@@ -30,6 +30,7 @@ def run_gpu(engine, world, quant=None, **opts):
     # own test below (and are what every default-option test in this file runs)
     opts.setdefault("fuse", 0)
     opts.setdefault("pair_seeds", 0)   # (the anchor-pair search of the 2-mismatch pass: test_pair_seeds_*)
+    opts.setdefault("dict", 0)         # (the dictionary kernels of one-word batches: tests/test_gpu_dict.py)
     for k, v in opts.items():
         engine.set_option(k, v)
     rs = ReadSet(world.words, world.lens, world.nmask, quant, device=engine.device)

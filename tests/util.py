@@ -16,7 +16,7 @@ def pass_dicts(spike_in=False, order=LIB_ORDER):
             for (k, a, b, s, ms, mt, t5, t3, pt) in rows]
 
 
-def mixed_reads(libs, n_fixed=3000, n_var=500, seed=1, with_n=True):
+def mixed_reads(libs, n_fixed=3000, n_var=500, seed=1, with_n=True, max_var_len=44):
     """22-mers from the standard mixture plus variable-length (16..44 nt) reads cut
     from hairpin / miRNA / ncRNA entries with 0-2 edits (some of them N)."""
     reads = [synth.codes_to_str(c) for c in synth.synth_reads(libs, n_fixed, seed=seed + 354)]
@@ -26,7 +26,7 @@ def mixed_reads(libs, n_fixed=3000, n_var=500, seed=1, with_n=True):
         key = ["hairpin", "mirna", "ncrna_others", "pre_trna"][int(rng.integers(0, 4))]
         seqs = libs.libs[key][1]
         s = seqs[int(rng.integers(0, len(seqs)))]
-        ln = int(rng.integers(16, 45))
+        ln = int(rng.integers(16, max_var_len + 1))
         if len(s) < ln:
             continue
         o = int(rng.integers(0, len(s) - ln + 1))
@@ -35,16 +35,16 @@ def mixed_reads(libs, n_fixed=3000, n_var=500, seed=1, with_n=True):
             r[int(rng.integers(0, ln))] = alphabet[int(rng.integers(0, len(alphabet)))]
         if rng.random() < 0.2:
             r += list("T" * int(rng.integers(3, 7)))
-        reads.append("".join(r)[:60])
+        reads.append("".join(r)[:60 if max_var_len > 32 else 32])
     return list(dict.fromkeys(reads))
 
 
 class World:
-    def __init__(self, scale=0.03, seed=20181, n_fixed=3000, n_var=500, with_n=True):
+    def __init__(self, scale=0.03, seed=20181, n_fixed=3000, n_var=500, with_n=True, max_var_len=44):
         self.libs = synth.SynthLibraries(seed=seed, scale=scale)
         self.index = {k: FmIndex.build(*self.libs.libs[k]) for k in LIB_ORDER}
         self.views = [self.index[k].view() for k in LIB_ORDER]
-        self.reads = mixed_reads(self.libs, n_fixed, n_var, with_n=with_n)
+        self.reads = mixed_reads(self.libs, n_fixed, n_var, with_n=with_n, max_var_len=max_var_len)
         self.words, self.lens, self.nmask = pack.pack_reads(self.reads)
         self.passes = pass_dicts()
         self.n_mirna = self.index["mirna"].n_ref
