@@ -66,6 +66,8 @@ def kernel_name(W, table_row, s, n_bases):
         return "mrg::stratum_kernel<%d>" % W
     if s["lds_mode"] == 7:
         return "mrg::exact_dict_kernel"
+    if s["lds_mode"] == 8:
+        return "mrg::seed_kernel"
     has_ctx = n_bases >= (1 << 20) and s["lds_mode"] in (0, 1)
     return "mrg::match_kernel<%d, %s, %s, %s, %s>" % (
         W, {0: "false, false", 1: "true, false", 2: "true, true", 3: "false, true"}[s["lds_mode"]],
@@ -78,7 +80,7 @@ def launch_table(st, per_pass_ms, table, index, W):
     launches = []
     for i, s in enumerate(st):
         skipped = s["processed"] == 0 and s["lds_bytes"] == 0 and per_pass_ms[i] < 0.05 and i + 1 < len(st) \
-            and s["lds_mode"] != 4
+            and s["lds_mode"] not in (4, 8)
         if skipped:
             continue
         if s["group"] != i and launches and launches[-1]["first"] == s["group"]:

@@ -187,7 +187,10 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * kernels for the passes that can (a pass without seed mismatches on a library of at most 4 Mbp: one
  * load of its exact-match dictionary per read, built by mrg_ctx_add_library while the option is 1);
  * "dict_key" = 16 (default) / 8..16: key length of those dictionaries (set BEFORE adding libraries;
- * reads shorter than the key take the FM index); "wide_rows_16", "round_large": see DESIGN.md. */
+ * reads shorter than the key take the FM index); "seed_units" = 1 (default) / 0: in such batches the runs
+ * of passes with at most one seed mismatch after the first launch go through seed_kernel (libraries of at
+ * most 4 Mbp searched with one policy as ONE index of their concatenation, built when a cascade first
+ * plans it); "wide_rows_16", "round_large": see DESIGN.md. */
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);
 int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,
                         char *arch, uint32_t arch_cap);
@@ -221,7 +224,10 @@ typedef struct mrg_pass_stats {
                           5 / 6 = stratum_kernel<W> with / without the packed text in LDS;
                           7 = exact_dict_kernel (one slot load of the library's exact-match
                           dictionary per read: steps = 0, lookups = slot / table loads, candidates =
-                          slots / rows compared) */
+                          slots / rows compared); 8 = seed_kernel (the pass rode, as a unit or a member
+                          of a unit, in the seed launch of its group's first pass: steps = 0, lookups =
+                          jump-table / slot loads and candidates = rows of the unit, reported with the
+                          unit's first pass) */
   uint32_t group;      /* index of the first pass of the launch this pass ran in (itself when it
                           had a launch of its own) */
   uint32_t n_launches; /* kernel launches that carried this pass: 1, or 2 for a 2-mismatch pass split

@@ -90,6 +90,7 @@ struct DevLib {
   uint32_t dict_log2 = 0, dict_key = 0;
   uint32_t* kbits = nullptr;
   std::vector<uint32_t> kbits_host;  // host copy (32 KB): the per-round interleaved tables are built from it
+  std::vector<std::string> host_seqs;  // entries of a library of at most kDictMaxBases bases (for seed units over several libraries)
   uint32_t* ftab = nullptr;
   mrg::JumpTables tabs = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   uint32_t n = 0, nblk = 0, nsup = 0, primary = 0, text_words = 0, n_seg = 0, n_ref = 0;
@@ -109,6 +110,20 @@ int upload(T** dst, const std::vector<T>& v, size_t pad_to_multiple = 1) {
 }
 
 constexpr uint32_t kStatsPerPass = 5;
+
+void free_dev_lib(DevLib& l);
+
+// What a seed_kernel unit searches: one library, or several small ones searched with the same
+// policy as ONE index of their concatenation (entries of member j start at entry_lo[j]).  Built
+// the first time a cascade plans such a unit, kept for the life of the context.
+struct SeedLib {
+  std::string key;     // member library ids, e.g. "2,4,5"
+  DevLib lib;          // FM arrays (with 16-byte rows)
+  bool owned = false;  // false: `lib` is a copy of the pointers of a library of the context
+  std::vector<uint32_t> entry_lo;
+  uint32_t* kbits = nullptr;  // presence bitmaps of the 8-, 9-, 10- and 11-mers (owned units of small libraries)
+  uint32_t kbits_off[4] = {0, 0, 0, 0};
+};
 
 }  // namespace
 
@@ -186,7 +201,9 @@ struct mrg_ctx {
   int64_t wide_rows_16 = 1;  // libraries of >= 2^20 bases get 16-byte rows with 32 bases of context
   int64_t dict = 1;          // one-word batches without N run the dictionary kernels (dict.hip) where a pass can
   int64_t dict_key = 16;     // key length of the exact-match dictionaries (set before add_library)
+  int64_t seed_units = 1;    // ... and their runs of passes with at most one seed mismatch go through seed_kernel
   std::vector<DevLib> libs;
+  std::vector<std::unique_ptr<SeedLib>> seed_libs;
   // last run
   hipStream_t last_stream = nullptr;
   uint64_t* last_stats_dev = nullptr;
@@ -396,25 +413,10 @@ int mrg_ctx_create(int device, mrg_ctx** out) {
 void mrg_ctx_destroy(mrg_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  for (DevLib& l : ctx->libs) {
-    (void)hipFree(l.blocks);
-    (void)hipFree(l.super);
-    (void)hipFree(l.text);
-    (void)hipFree(l.sa);
-    (void)hipFree(l.ftab);
-    (void)hipFree(l.ctx);
-    (void)hipFree(l.sa16);
-    (void)hipFree(l.pair_jump);
-    (void)hipFree(l.pair_jump_s);
-    (void)hipFree(l.pair_rows);
-    (void)hipFree(l.bpair_jump);
-    (void)hipFree(l.bpair_rows);
-    (void)hipFree(l.kbits);
-    (void)hipFree(l.dict_slots);
-    (void)hipFree(l.seg_start);
-    (void)hipFree(l.seg_ref);
-    (void)hipFree(l.seg_off);
-    (void)hipFree(l.chunk_seg);
+  for (DevLib& l : ctx->libs) free_dev_lib(l);
+  for (auto& sl : ctx->seed_libs) {
+    if (sl->owned) free_dev_lib(sl->lib);
+    (void)hipFree(sl->kbits);
   }
   if (ctx->ev_ready)
     for (auto& e : ctx->ev) (void)hipEventDestroy(e);
@@ -424,20 +426,17 @@ void mrg_ctx_destroy(mrg_ctx* ctx) {
   delete ctx;
 }
 
-int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
-  if (!ctx || !h || !lib_id) return fail(MRG_ERR_ARG, "mrg_ctx_add_library: null argument");
-  HIP_TRY(hipSetDevice(ctx->device));
-  const mrg::FmIndex& ix = h->ix;
-  DevLib l;
-  struct Guard {  // a failed upload must not leak the arrays uploaded before it
-    DevLib* l;
-    ~Guard() {
-      if (!l) return;
-      void* ptrs[] = {l->blocks, l->super, l->text, l->sa, l->ftab, l->ctx, l->sa16, l->kbits, l->pair_jump, l->pair_jump_s, l->pair_rows, l->dict_slots,
-                      l->seg_start, l->seg_ref, l->seg_off, l->chunk_seg};
-      for (void* p : ptrs) (void)hipFree(p);
-    }
-  } guard{&l};
+namespace {
+void free_dev_lib(DevLib& l) {
+  void* ptrs[] = {l.blocks, l.super, l.text, l.sa, l.ftab, l.ctx, l.sa16, l.kbits, l.pair_jump, l.pair_jump_s, l.pair_rows, l.dict_slots,
+                  l.bpair_jump, l.bpair_rows, l.seg_start, l.seg_ref, l.seg_off, l.chunk_seg};
+  for (void* p : ptrs) (void)hipFree(p);
+}
+
+// The FM arrays of one index into HBM.  wide_rows: also the 16-byte rows; pair_tables: also the
+// anchor-pair tables of 2-mismatch passes.
+int upload_index(mrg_ctx* ctx, const mrg::FmIndex& ix, DevLib& l, bool wide_rows, bool pair_tables) {
+  int rc;
   l.n = ix.n;
   l.nblk = (uint32_t)ix.blocks.size();
   l.primary = ix.primary;
@@ -451,7 +450,6 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
   for (uint32_t v : ix.ref_len) l.max_ref_len = std::max(l.max_ref_len, v);
   std::vector<uint32_t> blk(reinterpret_cast<const uint32_t*>(ix.blocks.data()),
                             reinterpret_cast<const uint32_t*>(ix.blocks.data()) + ix.blocks.size() * 4);
-  int rc;
   if ((rc = upload(&l.blocks, blk, 4))) return rc;
   if ((rc = upload(&l.super, ix.super, 4))) return rc;
   // text is staged into LDS 16 B at a time: round its word count up to 4
@@ -474,7 +472,7 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
   }
   if ((rc = upload(&l.ftab, ix.ftab))) return rc;
   if (!ix.ctx.empty() && (rc = upload(&l.ctx, ix.ctx))) return rc;
-  if (ix.n >= mrg::kWideRowMinBases && ctx->wide_rows_16) {
+  if (wide_rows) {
     // 16-byte rows for the fused launches: filled on the host in chunks, never kept there
     const size_t n_rows = ix.sa.size(), chunk = 1u << 24;
     HIP_TRY(hipMalloc((void**)&l.sa16, n_rows * 16));
@@ -486,7 +484,7 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
       HIP_TRY(hipMemcpy(l.sa16 + lo * 4, buf.data(), (hi - lo) * 16, hipMemcpyHostToDevice));
     }
   }
-  if (ix.n <= mrg::kPairMaxBases && ix.n >= 4u * mrg::kPairAnchor && ctx->pair_seeds) {
+  if (pair_tables && ix.n <= mrg::kPairMaxBases && ix.n >= 4u * mrg::kPairAnchor) {
     mrg::PairTables pt, pt_s;
     try {
       mrg::build_pair_tables(ix, mrg::kPairAnchor, pt);
@@ -504,6 +502,29 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
     if ((rc = upload(&l.pair_rows, pt.rows))) return rc;
     l.pair_anchor = pt.anchor;
   }
+  if (!ix.kbits.empty() && (rc = upload(&l.kbits, ix.kbits))) return rc;
+  l.kbits_host = ix.kbits;  // the interleaved tables of fused rounds are built from it
+  if ((rc = upload(&l.seg_start, ix.seg_start))) return rc;
+  if ((rc = upload(&l.seg_ref, ix.seg_ref))) return rc;
+  if ((rc = upload(&l.seg_off, ix.seg_off))) return rc;
+  if ((rc = upload(&l.chunk_seg, ix.chunk_seg))) return rc;
+  return MRG_OK;
+}
+}  // namespace
+
+int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
+  if (!ctx || !h || !lib_id) return fail(MRG_ERR_ARG, "mrg_ctx_add_library: null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const mrg::FmIndex& ix = h->ix;
+  DevLib l;
+  struct Guard {  // a failed upload must not leak the arrays uploaded before it
+    DevLib* l;
+    ~Guard() {
+      if (l) free_dev_lib(*l);
+    }
+  } guard{&l};
+  int rc = upload_index(ctx, ix, l, ix.n >= mrg::kWideRowMinBases && ctx->wide_rows_16, ctx->pair_seeds != 0);
+  if (rc) return rc;
   if (ctx->dict && ix.n <= mrg::kDictMaxBases && ix.n >= (uint32_t)ctx->dict_key) {
     const mrg::ExactDict* ed = nullptr;
     try {
@@ -517,12 +538,12 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
       l.dict_key = ed->key_bases;
     }
   }
-  if (!ix.kbits.empty() && (rc = upload(&l.kbits, ix.kbits))) return rc;
-  l.kbits_host = ix.kbits;  // the interleaved tables of fused rounds are built from it
-  if ((rc = upload(&l.seg_start, ix.seg_start))) return rc;
-  if ((rc = upload(&l.seg_ref, ix.seg_ref))) return rc;
-  if ((rc = upload(&l.seg_off, ix.seg_off))) return rc;
-  if ((rc = upload(&l.chunk_seg, ix.chunk_seg))) return rc;
+  // small libraries keep their entries on the host: passes that search several of them with one
+  // policy get one index of their concatenation (seed_kernel units), built when a cascade first asks
+  if (ctx->dict && ix.n <= mrg::kDictMaxBases) {
+    l.host_seqs.resize(ix.names.size());
+    for (uint32_t i = 0; i < l.host_seqs.size(); ++i) l.host_seqs[i] = mrg::entry_sequence(ix, i);
+  }
   ctx->libs.push_back(l);
   guard.l = nullptr;
   *lib_id = (int32_t)ctx->libs.size() - 1;
@@ -573,6 +594,8 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->wide_rows_16 = value != 0;  // takes effect for libraries added afterwards
   } else if (k == "dict") {
     ctx->dict = value != 0;  // (the dictionaries themselves are built by mrg_ctx_add_library while this is 1)
+  } else if (k == "seed_units") {
+    ctx->seed_units = value != 0;
   } else if (k == "dict_key") {
     if (value < 8 || value > 16) return fail(MRG_ERR_ARG, "dict_key must be in [8,16]");
     ctx->dict_key = value;
@@ -611,6 +634,84 @@ int mrg_cascade_workspace_bytes(uint64_t n, uint64_t* bytes) {
   *bytes = 2 * ws_idx_bytes(n) + kWsCountsBytes + kWsStatsBytes;
   return MRG_OK;
 }
+
+namespace {
+// The index a seed unit searches (SeedLib): cached by member list.
+int get_seed_lib(mrg_ctx* ctx, const std::vector<int32_t>& lib_ids, SeedLib** out) {
+  std::string key;
+  for (int32_t id : lib_ids) key += std::to_string(id) + ",";
+  for (auto& sl : ctx->seed_libs)
+    if (sl->key == key) {
+      *out = sl.get();
+      return MRG_OK;
+    }
+  auto sl = std::make_unique<SeedLib>();
+  sl->key = key;
+  const DevLib& first = ctx->libs[lib_ids[0]];
+  if (lib_ids.size() == 1 && first.host_seqs.empty()) {
+    // a large library: its own arrays (the caller made sure it has 16-byte rows)
+    sl->lib = first;
+    sl->lib.host_seqs.clear();
+    sl->lib.kbits_host.clear();
+    sl->owned = false;
+    sl->entry_lo.assign(1, 0u);
+  } else {
+    std::vector<std::string> names, seqs;
+    for (int32_t id : lib_ids) {
+      const DevLib& l = ctx->libs[id];
+      sl->entry_lo.push_back((uint32_t)seqs.size());
+      for (size_t i = 0; i < l.host_seqs.size(); ++i) {
+        names.push_back("u" + std::to_string(id) + "_" + std::to_string(i));
+        seqs.push_back(l.host_seqs[i]);
+      }
+    }
+    mrg::FmIndex ix;
+    try {
+      mrg::build_index(names, seqs, ix);
+    } catch (const std::bad_alloc&) {
+      return fail(MRG_ERR_NOMEM, "mrg_cascade_run: out of memory indexing libraries %s", key.c_str());
+    } catch (const std::exception& e) {
+      return fail(MRG_ERR_FORMAT, "mrg_cascade_run: indexing libraries %s: %s", key.c_str(), e.what());
+    }
+    sl->owned = true;
+    struct Guard {
+      SeedLib* s;
+      ~Guard() {
+        if (!s) return;
+        free_dev_lib(s->lib);
+        (void)hipFree(s->kbits);
+      }
+    } guard{sl.get()};
+    int rc = upload_index(ctx, ix, sl->lib, true, false);
+    if (rc) return rc;
+    // presence bitmaps of the k-mers, k = 8..11: bit c = some text position starts the k-mer with
+    // code c (first base in the low two bits)
+    uint32_t words = 0;
+    for (uint32_t k = 8; k <= 11; ++k) {
+      sl->kbits_off[k - 8] = words;
+      words += (1u << (2 * k)) / 32u;
+    }
+    std::vector<uint32_t> bits(words, 0u);
+    for (size_t sg = 0; sg + 1 < ix.seg_start.size(); ++sg) {
+      const uint32_t s0 = ix.seg_start[sg], s1 = ix.seg_start[sg + 1];
+      for (uint32_t p = s0; p < s1; ++p) {
+        const uint32_t w = p >> 4, sh = (p & 15u) * 2u;
+        const uint64_t lo64 = (uint64_t)ix.text[w] | ((uint64_t)ix.text[w + 1] << 32);
+        const uint32_t win = (uint32_t)(lo64 >> sh);  // 16 bases from p
+        for (uint32_t k = 8; k <= 11 && p + k <= s1; ++k) {
+          const uint32_t c = win & ((1u << (2 * k)) - 1u);
+          bits[sl->kbits_off[k - 8] + (c >> 5)] |= 1u << (c & 31u);
+        }
+      }
+    }
+    if ((rc = upload(&sl->kbits, bits))) return rc;
+    guard.s = nullptr;
+  }
+  *out = sl.get();
+  ctx->seed_libs.push_back(std::move(sl));
+  return MRG_OK;
+}
+}  // namespace
 
 int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_read,
                     const uint8_t* d_lens, const uint64_t* d_nmask, uint64_t n,
@@ -1100,11 +1201,155 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     return MRG_OK;
   };
 
+  // one seed_kernel launch (dict.hip) for the passes of `plan`: each entry = one unit = (kind, member passes)
+  struct UnitPlan {
+    uint32_t kind;
+    std::vector<uint32_t> members;
+  };
+  auto run_seed = [&](const std::vector<UnitPlan>& plan, uint32_t first, uint32_t end, bool ends_cascade, bool small) -> int {
+    mrg::SeedParams sp;
+    std::memset(&sp, 0, sizeof sp);
+    sp.n_units = (uint32_t)plan.size();
+    for (uint32_t u = 0; u < sp.n_units; ++u) {
+      mrg::SeedUnit& un = sp.unit[u];
+      const mrg_pass_cfg& c0 = passes[plan[u].members[0]];
+      un.kind = plan[u].kind;
+      const DevLib* fm = &ctx->libs[c0.lib];
+      SeedLib* sl = nullptr;
+      if (un.kind == 0u) {
+        std::vector<int32_t> ids;
+        for (uint32_t i : plan[u].members) ids.push_back(passes[i].lib);
+        int rc = get_seed_lib(ctx, ids, &sl);
+        if (rc != MRG_OK) return rc;
+        fm = &sl->lib;
+        un.kbits = sl->kbits;
+        for (int t = 0; t < 4; ++t) un.kbits_off[t] = sl->kbits_off[t];
+      } else {
+        un.slots = reinterpret_cast<const uint4*>(fm->dict_slots);
+        un.log2_slots = fm->dict_log2;
+        un.key_bases = fm->dict_key;
+      }
+      un.ftab = fm->ftab;
+      un.tabs = fm->tabs;
+      un.sa16 = reinterpret_cast<const uint4*>(fm->sa16);
+      un.sa = fm->sa;
+      un.text = fm->text;
+      un.n = fm->n;
+      un.seg_start = fm->seg_start;
+      un.seg_ref = fm->seg_ref;
+      un.seg_off = fm->seg_off;
+      un.chunk_seg = fm->chunk_seg;
+      un.simple_segs = fm->simple ? 1u : 0u;
+      un.max_mm_seed = c0.max_mm_seed;
+      un.trim5 = c0.trim5;
+      un.trim3 = c0.trim3;
+      un.min_len = c0.min_len;
+      un.max_len = c0.max_len;
+      un.poly_t = c0.poly_t;
+      un.n_members = (uint32_t)plan[u].members.size();
+      un.min_seed_len = 0x7FFFFFFF;
+      un.max_total = 0;
+      for (uint32_t mi = 0; mi < un.n_members; ++mi) {
+        const uint32_t i = plan[u].members[mi];
+        const mrg_pass_cfg& c = passes[i];
+        un.m[mi].pass_index = (int32_t)i;
+        un.m[mi].seed_len = c.seed_len;
+        un.m[mi].max_mm_total = c.max_mm_total;
+        un.m[mi].entry_lo = sl ? sl->entry_lo[mi] : 0u;
+        un.min_seed_len = std::min(un.min_seed_len, c.seed_len);
+        un.max_total = std::max(un.max_total, c.max_mm_total);
+        ctx->last_lds[i] = 0u;
+        ctx->last_mode[i] = 8u;
+        ctx->last_group[i] = first;
+        ctx->last_kbits_log2[i] = un.kbits ? 22u : 0u;
+      }
+    }
+    sp.reads_per_lane = 1u;
+    sp.item_cap = mrg::kSeedThreads * sp.reads_per_lane * 2u;
+    sp.row_cap = small ? 2048u : 4096u;
+    sp.stats = stats;
+    sp.reads = d_reads;
+    sp.lens = d_lens;
+    sp.n_total = (uint32_t)n;
+    const int next_list = have_list ? (cur_list ^ 1) : 0;
+    sp.idx_in = have_list ? idx[cur_list] : nullptr;
+    sp.in_count = counts + cur_list * mrg::kMaxSegments;
+    sp.in_nseg = prev_grid;
+    sp.in_seg_cap = prev_seg_cap;
+    sp.idx_out = ends_cascade ? nullptr : idx[next_list];
+    sp.out_count = counts + next_list * mrg::kMaxSegments;
+    sp.pass_id = d_pass_id;
+    sp.ref_id = d_ref_id;
+    sp.pos = d_pos;
+    sp.mm = d_mm;
+    const uint32_t lds = mrg::seed_lds_bytes(sp);
+    uint32_t grid = (uint32_t)ctx->n_cu * (lds * 2u <= 160u * 1024u ? 2u : 1u);
+    if (grid > mrg::kMaxSegments) grid = mrg::kMaxSegments;
+    const uint32_t seg_cap = segment_capacity(grid, (uint64_t)mrg::kSeedThreads * sp.reads_per_lane, have_list);
+    sp.out_seg_cap = seg_cap;
+    if (n) HIP_TRY(mrg::launch_seed(sp, grid, stream));
+    ctx->last_launches[first] = 1;
+    for (uint32_t q = first; q < end; ++q) HIP_TRY(hipEventRecord(ctx->ev[q + 1], stream));
+    if (sp.idx_out) {
+      cur_list = next_list;
+      have_list = true;
+      prev_grid = grid;
+      prev_seg_cap = seg_cap;
+    }
+    return MRG_OK;
+  };
+  // a pass seed_kernel can take as (part of) a unit, and the size class of its library
+  auto seedable = [&](uint32_t i) {
+    if (!dict_batch || !ctx->seed_units || ctx->force_lds_mode >= 0 || !fusable(i)) return false;
+    const mrg_pass_cfg& c = passes[i];
+    const DevLib& l = ctx->libs[c.lib];
+    if (c.max_mm_seed == 0 && l.dict_slots) return true;
+    return !l.host_seqs.empty() || l.sa16 != nullptr;
+  };
+  auto small_class = [&](uint32_t i) { return !ctx->libs[passes[i].lib].host_seqs.empty(); };
+
   bool launched_any = false;
   for (uint32_t i = 0; i < n_pass;) {
     if (!runs[i]) {
       HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
       ++i;
+      continue;
+    }
+    if (launched_any && seedable(i)) {
+      std::vector<UnitPlan> plan;
+      const bool cls = small_class(i);
+      uint32_t j = i;
+      while (j < n_pass) {
+        if (!runs[j]) {
+          ++j;
+          continue;
+        }
+        if (!seedable(j) || small_class(j) != cls) break;
+        const mrg_pass_cfg& c = passes[j];
+        const bool k1 = c.max_mm_seed == 0 && ctx->libs[c.lib].dict_slots != nullptr;
+        int join = -1;
+        if (!k1 && cls)  // small libraries searched with one policy: one unit over their concatenation
+          for (size_t u = 0; u < plan.size(); ++u) {
+            if (plan[u].kind != 0u || plan[u].members.size() >= mrg::kSeedMaxMembers) continue;
+            const mrg_pass_cfg& d = passes[plan[u].members[0]];
+            if (d.max_mm_seed == c.max_mm_seed && d.trim5 == c.trim5 && d.trim3 == c.trim3 && d.min_len == c.min_len &&
+                d.max_len == c.max_len && d.poly_t == c.poly_t) {
+              join = (int)u;
+              break;
+            }
+          }
+        if (join >= 0) {
+          plan[join].members.push_back(j);
+        } else {
+          if (plan.size() == mrg::kSeedMaxUnits) break;
+          plan.push_back(UnitPlan{k1 ? 1u : 0u, {j}});
+        }
+        ++j;
+      }
+      // (passes skipped by the length hint at the end of the run stay with it: never the last pass)
+      int rc = run_seed(plan, i, j, j == n_pass, cls);
+      if (rc != MRG_OK) return rc;
+      i = j;
       continue;
     }
     uint32_t members[mrg::kMaxFused];

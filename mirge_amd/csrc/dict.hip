@@ -330,6 +330,477 @@ __global__ void __launch_bounds__(kBlock, 8) exact_dict_kernel(const ExactParams
   if (p.idx_out && threadIdx.x == 0) p.out_count[blockIdx.x] = ctl[0];
 }
 
+// ---------------------------------------------------------------------------
+// seed_kernel (kernels.hpp): units of seed searches / dictionary probes over tiles of reads.
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr uint32_t kUnitWords = 24u;  // LDS table entry of a unit (what a row's verification needs)
+enum UnitWord : uint32_t { UW_SA16 = 0, UW_TEXT = 2, UW_SEGSTART = 4, UW_SEGREF = 6, UW_SEGOFF = 8, UW_CHUNKSEG = 10, UW_FLAGS = 12,
+                           UW_LIMITS = 13, UW_MEMBERS = 14 };
+constexpr uint32_t kSeedCtlWords = 16u;
+constexpr uint32_t kSeedCntSlots = 16u * 2u + kSeedMaxUnits * 2u;  // per pass processed / aligned, per unit candidates / lookups
+
+struct SeedLds {
+  unsigned long long* srd;   // [tile] packed read
+  unsigned long long* best;  // [tile] best key
+  uint2* rows;               // [row_cap] (row index, slot | unit << 11 | offset << 13 | k' << 19)
+  uint4* wide;               // [kSeedWideCap] (lo, hi, slot | unit | offset | k', -)
+  uint32_t* sidx;            // [tile] read index
+  uint32_t* items;           // [n_units][item_cap] slot | seed << 11
+  uint32_t* utab;            // [kSeedMaxUnits][kUnitWords]
+  uint32_t* ctl;             // [0] survivors, [1] longest input segment, [2] rows, [3] wide, [4 + u] items of unit u
+  unsigned long long* cnt;   // [kSeedCntSlots]
+  uint8_t* sL0;              // [tile] read length, 255 = no read
+};
+
+__device__ __forceinline__ SeedLds carve_seed_lds(uint32_t* smem, uint32_t tile, uint32_t row_cap, uint32_t item_cap, uint32_t n_units) {
+  SeedLds l;
+  l.srd = reinterpret_cast<unsigned long long*>(smem);
+  l.best = l.srd + tile;
+  l.rows = reinterpret_cast<uint2*>(l.best + tile);
+  l.wide = reinterpret_cast<uint4*>(l.rows + row_cap);
+  l.sidx = reinterpret_cast<uint32_t*>(l.wide + kSeedWideCap);
+  l.items = l.sidx + tile;
+  l.utab = l.items + n_units * item_cap;
+  l.ctl = l.utab + kSeedMaxUnits * kUnitWords;
+  l.cnt = reinterpret_cast<unsigned long long*>(l.ctl + kSeedCtlWords);
+  l.sL0 = reinterpret_cast<uint8_t*>(l.cnt + kSeedCntSlots);
+  return l;
+}
+
+// the read as one unit's bowtie run sees it: length window, poly-T rule, trims
+__device__ __forceinline__ bool unit_view(int32_t min_len, int32_t max_len, int32_t poly_t, int32_t trim5, int32_t trim3, uint64_t rd,
+                                          uint32_t L0, uint64_t& q, int32_t& L) {
+  bool el = (int32_t)L0 >= min_len && (int32_t)L0 <= max_len;
+  L = (int32_t)L0;
+  if (poly_t) {
+    const int32_t tail = trailing_t(rd, L);
+    el = el && tail >= 3 && (L - tail) >= 11;
+    L -= tail;
+  }
+  L -= trim5 + trim3;
+  q = rd >> (2 * trim5);
+  return el;
+}
+
+// seed length of a read of L bases in a unit: K = V + 1 seeds of floor(R / K) bases
+__device__ __forceinline__ int32_t seed_bases(int32_t L, int32_t min_seed_len, int32_t V) {
+  const int32_t R = min(L, min_seed_len);
+  return V ? (R >> 1) : R;
+}
+
+__device__ __forceinline__ const void* lds_pointer(const uint32_t* t, uint32_t w) {
+  return reinterpret_cast<const void*>((uint64_t)t[w] | ((uint64_t)t[w + 1] << 32));
+}
+
+// One candidate row of a seed whose k' first bases matched at text position wr.x, `off` read
+// bases left of it: fold a valid alignment into the read's slot.
+__device__ __forceinline__ void verify_seed_row(const uint32_t* ut, const uint4 wr, uint64_t q, int32_t L, uint32_t off, uint32_t kprime,
+                                                unsigned long long* best_slot) {
+  const uint32_t before = wr.y & 255u, after = (wr.y >> 8) & 255u, seg16 = wr.y >> 16;
+  const uint32_t need_after = (uint32_t)L - off;
+  if ((off > before) | (need_after > after)) return;
+  const uint32_t limits = ut[UW_LIMITS], flags = ut[UW_FLAGS];
+  const int32_t min_seed_len = (int32_t)(limits & 0xFFFFu), max_total = (int32_t)(limits >> 16);
+  const int32_t V = (int32_t)((flags >> 21) & 3u);
+  // mismatches the stored context shows: the <= 16 bases left of the position, the bases 8..23 right of it
+  uint32_t mm = 0;
+  {
+    const uint32_t c = min(off, 16u);
+    if (c) {
+      const uint32_t want = (uint32_t)(q >> (2u * (off - c))) & (uint32_t)low_bits(2u * c);
+      const uint32_t x = (wr.z >> (32u - 2u * c)) ^ want;
+      mm += (uint32_t)__popc((x | (x >> 1)) & 0x55555555u & (uint32_t)low_bits(2u * c));
+    }
+    if (need_after > 8u) {
+      const uint32_t c2 = min(need_after, 24u) - 8u;
+      const uint32_t want = (uint32_t)(q >> (2u * (off + 8u))) & (uint32_t)low_bits(2u * c2);
+      const uint32_t x = (wr.w ^ want) & (uint32_t)low_bits(2u * c2);
+      mm += (uint32_t)__popc((x | (x >> 1)) & 0x55555555u);
+    }
+  }
+  if ((int32_t)mm > max_total) return;  // a lower bound of the alignment's mismatches: final
+  const uint32_t s = wr.x - off;
+  uint64_t mbits = 0;
+  const bool covered = off <= 16u && need_after <= 24u && kprime >= 8u && L <= min_seed_len;
+  if (!covered) {
+    const uint32_t* text = reinterpret_cast<const uint32_t*>(lds_pointer(ut, UW_TEXT));
+    mbits = mismatch_bits(text_window(text, s), q) & low_bits(2u * (uint32_t)L);
+    mm = (uint32_t)__popcll(mbits);
+    if ((int32_t)mm > max_total) return;
+  }
+  // which member (pass) the entry belongs to, and that pass's policy
+  const uint32_t n_members = (flags >> 18) & 7u;
+  uint32_t mi = 0;
+  if (n_members > 1u) {
+    uint32_t sg = seg16;
+    if (sg == 0xFFFFu) {
+      const uint32_t* chunk_seg = reinterpret_cast<const uint32_t*>(lds_pointer(ut, UW_CHUNKSEG));
+      const uint32_t* seg_start = reinterpret_cast<const uint32_t*>(lds_pointer(ut, UW_SEGSTART));
+      sg = chunk_seg[s >> 5];
+      while (seg_start[sg + 1] <= s) ++sg;
+    }
+    const uint32_t ref = ((flags >> 17) & 1u) ? sg : reinterpret_cast<const uint32_t*>(lds_pointer(ut, UW_SEGREF))[sg];
+    for (uint32_t j = 1; j < n_members; ++j) mi += ref >= ut[UW_MEMBERS + 2u * j + 1u] ? 1u : 0u;
+  }
+  const uint32_t mw = ut[UW_MEMBERS + 2u * mi];
+  const int32_t pass_index = (int32_t)(mw & 0xFFu), seed_len = (int32_t)((mw >> 8) & 0xFFFFu), m_total = (int32_t)(mw >> 24);
+  uint32_t mm_seed = mm;
+  if (L > seed_len) mm_seed = (uint32_t)__popcll(mbits & low_bits(2u * (uint32_t)seed_len));  // (then never `covered`)
+  if ((int32_t)mm_seed > V || (int32_t)mm > m_total) return;
+  const unsigned long long key = ((unsigned long long)pass_index << 56) | ((unsigned long long)mm << 48) | ((unsigned long long)s << 16) | seg16;
+  atomicMin(best_slot, key);
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(kSeedThreads, 8) seed_kernel(const SeedParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t T = p.reads_per_lane, tile = kSeedThreads * T;
+  const SeedLds l = carve_seed_lds(smem, tile, p.row_cap, p.item_cap, p.n_units);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  // ---- unit table, counters, control ----
+  if (tid < p.n_units) {
+    const SeedUnit& un = p.unit[tid];
+    uint32_t* t = l.utab + tid * kUnitWords;
+    auto put = [&](uint32_t w, const void* ptr) {
+      t[w] = (uint32_t)(uint64_t)ptr;
+      t[w + 1] = (uint32_t)((uint64_t)ptr >> 32);
+    };
+    put(UW_SA16, un.sa16);
+    put(UW_TEXT, un.text);
+    put(UW_SEGSTART, un.seg_start);
+    put(UW_SEGREF, un.seg_ref);
+    put(UW_SEGOFF, un.seg_off);
+    put(UW_CHUNKSEG, un.chunk_seg);
+    t[UW_FLAGS] = (uint32_t)un.trim5 | ((uint32_t)un.trim3 << 8) | (un.poly_t ? 1u << 16 : 0u) | (un.simple_segs ? 1u << 17 : 0u) |
+                  (un.n_members << 18) | ((uint32_t)un.max_mm_seed << 21);
+    t[UW_LIMITS] = (uint32_t)min(un.min_seed_len, 0xFFFF) | ((uint32_t)min(un.max_total, 0xFFFF) << 16);
+    for (uint32_t j = 0; j < kSeedMaxMembers; ++j) {
+      t[UW_MEMBERS + 2u * j] = (uint32_t)un.m[j].pass_index | ((uint32_t)min(un.m[j].seed_len, 0xFFFF) << 8) | ((uint32_t)min(un.m[j].max_mm_total, 255) << 24);
+      t[UW_MEMBERS + 2u * j + 1u] = un.m[j].entry_lo;
+    }
+  }
+  for (uint32_t i = tid; i < kSeedCntSlots; i += kSeedThreads) l.cnt[i] = 0ull;
+  if (tid < kSeedCtlWords) l.ctl[tid] = 0u;
+  __syncthreads();
+  if (p.idx_in) longest_segment(p.in_count, p.in_nseg, &l.ctl[1]);
+  __syncthreads();
+
+  const uint32_t in_nseg = p.idx_in ? p.in_nseg : 1u;
+  const uint32_t depth_chunks = p.idx_in ? (l.ctl[1] + tile - 1) / tile : (p.n_total + tile - 1) / tile;
+  const uint32_t n_chunks = in_nseg * depth_chunks;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const uint32_t sgi = chunk % in_nseg, depth = chunk / in_nseg;
+    const uint32_t count = p.idx_in ? p.in_count[sgi] : p.n_total;
+    // ================= phase 1: reads of the tile, and their items =================
+    for (uint32_t u = 0; u < T; ++u) {
+      const uint32_t slot = tid * T + u;
+      const uint32_t t = depth * tile + slot;
+      const bool active = t < count;
+      uint32_t r = 0, L0 = 255u;
+      uint64_t rd = 0;
+      if (active) {
+        r = p.idx_in ? p.idx_in[(size_t)sgi * p.in_seg_cap + t] : t;
+        L0 = p.lens[r];
+        rd = p.reads[r];
+      }
+      l.srd[slot] = rd;
+      l.sidx[slot] = r;
+      l.sL0[slot] = (uint8_t)L0;
+      l.best[slot] = ~0ull;
+      for (uint32_t ui = 0; ui < p.n_units; ++ui) {
+        const SeedUnit& un = p.unit[ui];
+        uint64_t q = 0;
+        int32_t L = 0;
+        const bool el = active && unit_view(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, rd, L0, q, L);
+        const int32_t V = un.max_mm_seed;
+        const bool search = el && L > V;
+        const uint32_t n_seeds = un.kind == 1u ? 1u : (uint32_t)V + 1u;
+        const int32_t k = seed_bases(L, un.min_seed_len, V);
+        for (uint32_t j = 0; j < n_seeds; ++j) {
+          bool need = search;
+          if (un.kind == 0u && un.kbits && need && k >= 8) {
+            const uint32_t kb = (uint32_t)min(k, 11);
+            const uint32_t code = (uint32_t)(q >> (2u * j * (uint32_t)k)) & ((1u << (2u * kb)) - 1u);
+            need = ((un.kbits[un.kbits_off[kb - 8u] + (code >> 5)] >> (code & 31u)) & 1u) != 0u;
+          }
+          const uint64_t mask = __ballot(need);
+          if (mask) {
+            uint32_t base = 0;
+            if (lane == (uint32_t)__ffsll((long long)mask) - 1u) base = atomicAdd(&l.ctl[4u + ui], (uint32_t)__popcll(mask));
+            base = __shfl(base, __ffsll((long long)mask) - 1, 64);
+            if (need) l.items[ui * p.item_cap + base + mbcnt(mask)] = slot | (j << 11);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ================= phase 2a: items -> dictionary answers / suffix-array rows =================
+    for (uint32_t ui = 0; ui < p.n_units; ++ui) {
+      const SeedUnit& un = p.unit[ui];
+      const uint32_t n_items = l.ctl[4u + ui];
+      uint32_t c_lookups = 0, c_cands = 0;
+      for (uint32_t it0 = 0; it0 < n_items; it0 += kSeedThreads) {
+        const uint32_t it = it0 + tid;
+        const bool has = it < n_items;
+        uint32_t slot = 0, j = 0;
+        uint64_t q = 0;
+        int32_t L = 0;
+        if (has) {
+          const uint32_t e = l.items[ui * p.item_cap + it];
+          slot = e & 2047u;
+          j = e >> 11;
+          unit_view(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, l.srd[slot], l.sL0[slot], q, L);
+        }
+        if (un.kind == 1u) {
+          // ---- exact-match dictionary (see exact_dict_kernel) ----
+          if (has) {
+            const int32_t pass_index = un.m[0].pass_index, seed_len = un.m[0].seed_len, max_total = un.m[0].max_mm_total;
+            const uint32_t smask = (1u << un.log2_slots) - 1u;
+            const uint32_t kmask = un.key_bases >= 16u ? 0xFFFFFFFFu : ((1u << (2u * un.key_bases)) - 1u);
+            bool fallback = (uint32_t)L < un.key_bases;
+            unsigned long long key = ~0ull;
+            if (!fallback) {
+              const uint64_t lmask = low_bits(2u * (uint32_t)L), seedmask = low_bits(2u * (uint32_t)min(L, seed_len));
+              const uint32_t home = (((uint32_t)q & kmask) * kDictHashMul) >> (32u - un.log2_slots);
+              uint4 sl = un.slots[home];
+              ++c_lookups;
+              const uint32_t chain = (sl.w >> kDictChainShift) & kDictChainMask;
+              if (chain == kDictChainOverflow) {
+                fallback = true;
+              } else {
+                uint32_t bestj = ~0u;
+                for (uint32_t jj = 0;; ++jj) {
+                  const uint64_t win = (uint64_t)sl.x | ((uint64_t)sl.y << 32);
+                  ++c_cands;
+                  const uint64_t m = mismatch_bits(win, q) & lmask;
+                  const uint32_t mmt = (uint32_t)__popcll(m);
+                  if ((sl.w & kDictOccBit) && (m & seedmask) == 0ull && (int32_t)mmt <= max_total && (uint32_t)L <= (sl.w & kDictAfterMask) &&
+                      ((mmt << 8) | jj) < bestj) {
+                    bestj = (mmt << 8) | jj;
+                    key = ((unsigned long long)pass_index << 56) | ((unsigned long long)mmt << 48) | ((unsigned long long)sl.z << 21) |
+                          (sl.w >> kDictOffShift);
+                  }
+                  if (jj >= chain || (bestj >> 8) == 0u) break;
+                  sl = un.slots[(home + jj + 1u) & smask];
+                }
+              }
+            }
+            if (fallback) {
+              // the FM index: rows of the longest prefix a jump table knows, each against the text
+              const int32_t R = min(L, seed_len);
+              uint32_t tab_off = 0;
+              const uint32_t kp = un.tabs.k[0] ? pick_table(un.tabs, R, tab_off) : 0u;
+              uint32_t lo = 0, hi = un.n + 1u;
+              if (kp) {
+                const uint32_t* tab = un.ftab + tab_off + lex_code(q & low_bits(2u * kp), kp);
+                lo = tab[0];
+                hi = tab[1];
+              }
+              ++c_lookups;
+              const uint64_t lmask = low_bits(2u * (uint32_t)L), seedmask = low_bits(2u * (uint32_t)R);
+              uint64_t bestk = ~0ull;
+              uint32_t bseg = 0xFFFFu, bbefore = 255u;
+              for (uint32_t i = lo; i < hi; ++i) {
+                const uint64_t row = un.sa[i];
+                ++c_cands;
+                if ((uint32_t)L > ((uint32_t)(row >> 40) & 255u)) continue;
+                const uint64_t m = mismatch_bits(text_window(un.text, (uint32_t)row), q) & lmask;
+                const uint32_t mmt = (uint32_t)__popcll(m);
+                if ((m & seedmask) != 0ull || (int32_t)mmt > max_total) continue;
+                const uint64_t kk = ((uint64_t)mmt << 32) | (uint32_t)row;
+                if (kk < bestk) {
+                  bestk = kk;
+                  bseg = (uint32_t)(row >> 48);
+                  bbefore = (uint32_t)(row >> 32) & 255u;
+                }
+              }
+              if (bestk != ~0ull) {
+                uint32_t ref, pos;
+                SegTables segs{un.seg_start, un.seg_ref, un.seg_off, un.chunk_seg, un.simple_segs};
+                locate_entry(segs, (uint32_t)bestk, bseg, bbefore, ref, pos);
+                key = ((unsigned long long)pass_index << 56) | ((unsigned long long)(bestk >> 32) << 48) | ((unsigned long long)ref << 21) | pos;
+              }
+            }
+            if (key != ~0ull) atomicMin(&l.best[slot], key);
+          }
+          continue;
+        }
+        // ---- a seed: jump-table load, then its rows into the row queue ----
+        uint32_t lo = 0, n_rows = 0, tag = 0;
+        if (has) {
+          const int32_t k = seed_bases(L, un.min_seed_len, un.max_mm_seed);
+          const uint32_t off = j * (uint32_t)k;
+          uint32_t tab_off = 0;
+          const uint32_t kp = un.tabs.k[0] ? pick_table(un.tabs, k, tab_off) : 0u;
+          uint32_t hi = un.n + 1u;
+          if (kp) {
+            const uint32_t* tab = un.ftab + tab_off + lex_code((q >> (2u * off)) & low_bits(2u * kp), kp);
+            lo = tab[0];
+            hi = tab[1];
+          }
+          ++c_lookups;
+          n_rows = hi > lo ? hi - lo : 0u;
+          c_cands += n_rows;
+          tag = slot | (ui << 11) | (off << 13) | (kp << 19);
+        }
+        const bool is_wide = n_rows > kSeedRowsPerItem;
+        const uint32_t mine = is_wide ? 0u : n_rows;
+        const uint32_t incl = wave_incl_scan(mine);
+        const uint32_t total = __shfl(incl, 63, 64);
+        uint32_t base = 0;
+        if (total) {
+          if (lane == 0) base = atomicAdd(&l.ctl[2], total);
+          base = __shfl(base, 0, 64);
+        }
+        if (mine) {
+          // (entries past the queue's capacity -- other tiles' share of a crowded tile -- are verified here)
+          const uint32_t first = base + (incl - mine);
+          const uint32_t* ut = l.utab + ui * kUnitWords;
+          for (uint32_t i = 0; i < mine; ++i) {
+            if (first + i < p.row_cap) l.rows[first + i] = make_uint2(lo + i, tag);
+            else verify_seed_row(ut, un.sa16[lo + i], q, L, (tag >> 13) & 63u, tag >> 19, &l.best[slot]);
+          }
+        }
+        if (is_wide) {
+          const uint32_t w = atomicAdd(&l.ctl[3], 1u);
+          if (w < kSeedWideCap) {
+            l.wide[w] = make_uint4(lo, lo + n_rows, tag, 0u);
+          } else {
+            const uint32_t* ut = l.utab + ui * kUnitWords;
+            for (uint32_t i = 0; i < n_rows; ++i) verify_seed_row(ut, un.sa16[lo + i], q, L, (tag >> 13) & 63u, tag >> 19, &l.best[slot]);
+          }
+        }
+      }
+      // diagnostics of the unit: one LDS atomic per wave
+      const uint64_t t_l = wave_sum(c_lookups), t_c = wave_sum(c_cands);
+      if (lane == 0) {
+        if (t_c) atomicAdd(&l.cnt[32u + 2u * ui], (unsigned long long)t_c);
+        if (t_l) atomicAdd(&l.cnt[32u + 2u * ui + 1u], (unsigned long long)t_l);
+      }
+    }
+    __syncthreads();
+    // ================= phase 2b: one row per lane =================
+    {
+      const uint32_t n_rows = min(l.ctl[2], p.row_cap);
+      for (uint32_t x = tid; x < n_rows; x += kSeedThreads) {
+        const uint2 e = l.rows[x];
+        const uint32_t slot = e.y & 2047u, ui = (e.y >> 11) & 3u, off = (e.y >> 13) & 63u, kp = e.y >> 19;
+        const uint32_t* ut = l.utab + ui * kUnitWords;
+        const uint32_t flags = ut[UW_FLAGS];
+        uint64_t q;
+        int32_t L;
+        unit_view(0, 255, (int32_t)((flags >> 16) & 1u), (int32_t)(flags & 255u), (int32_t)((flags >> 8) & 255u), l.srd[slot], l.sL0[slot], q, L);
+        const uint4 wr = reinterpret_cast<const uint4*>(lds_pointer(ut, UW_SA16))[e.x];
+        verify_seed_row(ut, wr, q, L, off, kp, &l.best[slot]);
+      }
+      const uint32_t n_wide = min(l.ctl[3], kSeedWideCap);
+      for (uint32_t w = 0; w < n_wide; ++w) {
+        const uint4 e = l.wide[w];
+        const uint32_t slot = e.z & 2047u, ui = (e.z >> 11) & 3u, off = (e.z >> 13) & 63u, kp = e.z >> 19;
+        const uint32_t* ut = l.utab + ui * kUnitWords;
+        const uint32_t flags = ut[UW_FLAGS];
+        uint64_t q;
+        int32_t L;
+        unit_view(0, 255, (int32_t)((flags >> 16) & 1u), (int32_t)(flags & 255u), (int32_t)((flags >> 8) & 255u), l.srd[slot], l.sL0[slot], q, L);
+        const uint4* sa16 = reinterpret_cast<const uint4*>(lds_pointer(ut, UW_SA16));
+        for (uint32_t i = e.x + tid; i < e.y; i += kSeedThreads) verify_seed_row(ut, sa16[i], q, L, off, kp, &l.best[slot]);
+      }
+    }
+    __syncthreads();
+    // ================= phase 3: the claim, outputs, survivors, counters =================
+    for (uint32_t u = 0; u < T; ++u) {
+      const uint32_t slot = tid * T + u;
+      const uint32_t L0 = l.sL0[slot];
+      const bool active = L0 != 255u;
+      const uint64_t rd = l.srd[slot];
+      const uint32_t r = l.sidx[slot];
+      const unsigned long long key = l.best[slot];
+      const bool claimed = key != ~0ull;
+      const int32_t cp = claimed ? (int32_t)(key >> 56) : 255;
+      uint32_t o_ref = 0, o_pos = 0;
+      for (uint32_t ui = 0; ui < p.n_units; ++ui) {
+        const SeedUnit& un = p.unit[ui];
+        uint64_t q;
+        int32_t L;
+        const bool el = active && unit_view(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, rd, L0, q, L);
+        for (uint32_t mi = 0; mi < un.n_members; ++mi) {
+          const int32_t pi = un.m[mi].pass_index;
+          const uint64_t m_proc = __ballot(el && cp >= pi), m_alig = __ballot(cp == pi);
+          if (lane == 0) {
+            if (m_proc) atomicAdd(&l.cnt[2 * pi], (unsigned long long)__popcll(m_proc));
+            if (m_alig) atomicAdd(&l.cnt[2 * pi + 1], (unsigned long long)__popcll(m_alig));
+          }
+          if (cp == pi) {
+            if (un.kind == 1u) {
+              o_ref = (uint32_t)(key >> 21) & 0x7FFFFFFu;
+              o_pos = (uint32_t)key & 0x1FFFFFu;
+            } else {
+              SegTables segs{un.seg_start, un.seg_ref, un.seg_off, un.chunk_seg, un.simple_segs};
+              uint32_t ref;
+              locate_entry(segs, (uint32_t)(key >> 16), (uint32_t)key & 0xFFFFu, 255u, ref, o_pos);
+              o_ref = ref - un.m[mi].entry_lo;
+            }
+          }
+        }
+      }
+      if (claimed) {
+        p.pass_id[r] = (int8_t)cp;
+        p.ref_id[r] = (int32_t)o_ref;
+        p.pos[r] = (int32_t)o_pos;
+        p.mm[r] = (uint8_t)((key >> 48) & 255u);
+      } else if (active && !p.idx_out) {
+        p.pass_id[r] = (int8_t)-1;
+        p.ref_id[r] = -1;
+        p.pos[r] = -1;
+        p.mm[r] = 0;
+      }
+      if (p.idx_out) {
+        const bool survive = active && !claimed;
+        const uint64_t mask = __ballot(survive);
+        if (mask) {
+          uint32_t wbase = 0;
+          if (lane == 0) wbase = atomicAdd(&l.ctl[0], (uint32_t)__popcll(mask));
+          wbase = __shfl(wbase, 0, 64);
+          if (survive) p.idx_out[(size_t)blockIdx.x * p.out_seg_cap + wbase + mbcnt(mask)] = r;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid >= 2u && tid < 4u + p.n_units) l.ctl[tid] = 0u;  // rows, wide, items: empty for the next tile
+    __syncthreads();
+  }
+  // ---- counters: one global atomic per non-zero counter and workgroup ----
+  __syncthreads();
+  if (tid < 32u) {
+    const unsigned long long v = l.cnt[tid];
+    if (v) atomicAdd((unsigned long long*)&p.stats[(tid >> 1) * 5u + (tid & 1u)], v);
+  } else if (tid < 32u + 2u * p.n_units) {
+    const uint32_t ui = (tid - 32u) >> 1, what = (tid - 32u) & 1u;  // 0 candidates, 1 lookups
+    const unsigned long long v = l.cnt[tid];
+    if (v) atomicAdd((unsigned long long*)&p.stats[(uint32_t)p.unit[ui].m[0].pass_index * 5u + 3u + what], v);
+  }
+  if (p.idx_out && tid == 0) p.out_count[blockIdx.x] = l.ctl[0];
+}
+
+uint32_t seed_lds_bytes(const SeedParams& p) {
+  const uint32_t tile = kSeedThreads * p.reads_per_lane;
+  return tile * 8u + tile * 8u + p.row_cap * 8u + kSeedWideCap * 16u + tile * 4u + p.n_units * p.item_cap * 4u +
+         kSeedMaxUnits * kUnitWords * 4u + kSeedCtlWords * 4u + kSeedCntSlots * 8u + tile;
+}
+
+hipError_t launch_seed(const SeedParams& p, uint32_t grid, hipStream_t stream) {
+  const uint32_t lds = seed_lds_bytes(p);
+  if (lds > 48u * 1024u) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(seed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(seed_kernel, dim3(grid), dim3(kSeedThreads), lds, stream, p);
+  return hipGetLastError();
+}
+
 hipError_t launch_exact_dict(const ExactParams& p, uint32_t grid, hipStream_t stream) {
   // the streaming instantiation needs the identity list and arrays it can address 16 bytes at a time
   const bool first = !p.idx_in && ((uintptr_t)p.reads % 16 == 0) && ((uintptr_t)p.lens % 4 == 0) && ((uintptr_t)p.pass_id % 4 == 0) &&

@@ -225,6 +225,74 @@ struct ExactParams {
 constexpr uint32_t kExactChunk = 4096u;  // reads a workgroup takes per trip (four per lane)
 hipError_t launch_exact_dict(const ExactParams& p, uint32_t grid, hipStream_t stream);
 
+// seed_kernel: one launch = a run of consecutive passes with at most one seed mismatch, as UNITS:
+//   kind 0  V + 1 disjoint seeds of k = floor(R / (V + 1)) bases at the front of the seed region
+//           (R = min(read, shortest -l of the members)): at most V mismatches there leave one seed
+//           clean.  A seed's first k' bases (k' = the largest jump table <= k) name an interval of
+//           suffix-array rows = text positions; every row is a candidate start, verified from its
+//           16-byte wide row (position, segment room and 32 bases of context) or, when the context
+//           does not cover the read, from the text.  Several libraries searched with the same policy
+//           (tRNA `-v 1`, snoRNA and rRNA `-n 1`: RAP:579,581,582) are ONE unit over the index of
+//           their concatenation: members[] tells which pass an entry belongs to.  Small units filter
+//           seeds through presence bitmaps of the library's 8..11-mers (L2-resident) first.
+//   kind 1  a pass without seed mismatches on a library with an exact-match dictionary.
+// A workgroup works through tiles of 1024 T reads in three phases with dense lanes in each: per
+// read, which (unit, seed) ITEMS need the index -> per item, the jump-table load and its ROWS ->
+// per row, verification and a 64-bit atomic min into the read's LDS slot -> per read, the claim in
+// cascade order (the key starts with the pass index), outputs, survivors and counters.
+constexpr uint32_t kSeedMaxUnits = 3u, kSeedMaxMembers = 4u, kSeedThreads = 1024u;
+constexpr uint32_t kSeedRowsPerItem = 24u;  // wider intervals are verified by the whole workgroup
+constexpr uint32_t kSeedWideCap = 256u;
+struct SeedMember {
+  int32_t pass_index, seed_len, max_mm_total;
+  uint32_t entry_lo;  // first entry of this member in the unit's (union) library
+};
+struct SeedUnit {
+  uint32_t kind;
+  const uint32_t* ftab;
+  JumpTables tabs;
+  const uint4* sa16;
+  const uint64_t* sa;
+  const uint32_t* text;
+  uint32_t n;
+  const uint32_t* seg_start;
+  const uint32_t* seg_ref;
+  const uint32_t* seg_off;
+  const uint32_t* chunk_seg;
+  uint32_t simple_segs;
+  const uint4* slots;  // kind 1
+  uint32_t log2_slots, key_bases;
+  const uint32_t* kbits;  // presence bitmaps of the k-mers, k = 8..11, at word offsets kbits_off[k - 8]; null = none
+  uint32_t kbits_off[4];
+  int32_t max_mm_seed, trim5, trim3, min_len, max_len, poly_t;
+  int32_t min_seed_len, max_total;  // over the members
+  uint32_t n_members;
+  SeedMember m[kSeedMaxMembers];
+};
+struct SeedParams {
+  SeedUnit unit[kSeedMaxUnits];
+  uint32_t n_units;
+  uint32_t reads_per_lane;  // T: 1 or 2
+  uint32_t item_cap;        // per unit: 1024 T x seeds
+  uint32_t row_cap;
+  uint64_t* stats;          // counter slots [pass][5]: processed, aligned, steps, candidates, lookups
+  const uint64_t* reads;
+  const uint8_t* lens;
+  uint32_t n_total;
+  const uint32_t* idx_in;
+  const uint32_t* in_count;
+  uint32_t in_nseg, in_seg_cap;
+  uint32_t* idx_out;  // null: the launch ends the cascade
+  uint32_t* out_count;
+  uint32_t out_seg_cap;
+  int8_t* pass_id;
+  int32_t* ref_id;
+  int32_t* pos;
+  uint8_t* mm;
+};
+uint32_t seed_lds_bytes(const SeedParams& p);
+hipError_t launch_seed(const SeedParams& p, uint32_t grid, hipStream_t stream);
+
 constexpr uint32_t kCountThreads = 256u;
 
 struct CountParams {

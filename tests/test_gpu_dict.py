@@ -48,19 +48,27 @@ def same_assignments(res, ref):
 
 def test_dict_cascade_equals_port_and_fm_kernels(engine, world):
     ref = model.fm_cascade(world.views, world.passes, world.words, world.lens, None)
-    for fuse in (1, 0):
-        res = run(engine, world, dict=1, fuse=fuse)
+    for fuse, seed_units in ((1, 1), (1, 0), (0, 0)):
+        res = run(engine, world, dict=1, fuse=fuse, seed_units=seed_units)
         same_assignments(res, ref)
         st = res.stats
         assert st[0]["lds_mode"] == 7 and st[0]["steps"] == 0   # the first pass ran exact_dict_kernel
         assert st[0]["aligned"] <= st[0]["lookups"] <= st[0]["processed"]   # at most one home-slot load per offered read
-        if fuse == 0:
+        if seed_units:
+            # hairpin .. ncRNA-others (small libraries) share one seed_kernel launch: hairpin alone (its own
+            # length window), tRNA + snoRNA + rRNA + ncRNA-others as ONE unit over their concatenation,
+            # pre-tRNA through its dictionary; mRNA (large) has a launch of its own
+            assert [s["lds_mode"] for s in st[1:8]] == [8] * 7
+            assert [s["group"] for s in st[1:8]] == [1] * 6 + [7]
+            assert all(s["steps"] == 0 for s in st[1:8])
+        elif fuse == 0:
             assert st[3]["lds_mode"] == 7 and st[7]["lds_mode"] != 7  # pre-tRNA has a dictionary, mRNA is too large
         fm = run(engine, world, dict=0, fuse=fuse)
         for a, b in zip(res.to_host(), fm.to_host()):
             assert np.array_equal(a, b)
     engine.set_option("fuse", 1)
     engine.set_option("dict", 1)
+    engine.set_option("seed_units", 1)
 
 
 def test_dict_cascade_equals_exhaustive_scan(engine, world):
