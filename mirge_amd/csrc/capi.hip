@@ -71,6 +71,8 @@ struct DevLib {
   uint64_t* sa = nullptr;
   uint32_t* ctx = nullptr;
   uint32_t* sa16 = nullptr;  // wide rows of a large library (fm_index.hpp: fill_wide_rows)
+  uint32_t* buckets = nullptr;  // seed buckets (fm_index.hpp: fill_seed_buckets), 128 B per k-mer of bucket_k bases
+  uint32_t bucket_k = 0;
   // pair tables of a small library (fm_index.hpp: PairTables), for 2-mismatch passes
   uint32_t* pair_jump = nullptr;
   uint64_t* pair_rows = nullptr;
@@ -201,6 +203,8 @@ struct mrg_ctx {
   int64_t wide_rows_16 = 1;  // libraries of >= 2^20 bases get 16-byte rows with 32 bases of context
   int64_t dict = 1;          // one-word batches without N run the dictionary kernels (dict.hip) where a pass can
   int64_t dict_key = 16;     // key length of the exact-match dictionaries (set before add_library)
+  int64_t seed_buckets = 1;  // large libraries get seed buckets where they pay (set before add_library); 0 at run time: not used
+  int64_t seed_wgs = 0;      // seed_kernel workgroups (256 threads) per CU; 0 = what the launch's instantiation keeps resident
   int64_t seed_units = 1;    // ... and their runs of passes with at most one seed mismatch go through seed_kernel
   std::vector<DevLib> libs;
   std::vector<std::unique_ptr<SeedLib>> seed_libs;
@@ -428,7 +432,7 @@ void mrg_ctx_destroy(mrg_ctx* ctx) {
 
 namespace {
 void free_dev_lib(DevLib& l) {
-  void* ptrs[] = {l.blocks, l.super, l.text, l.sa, l.ftab, l.ctx, l.sa16, l.kbits, l.pair_jump, l.pair_jump_s, l.pair_rows, l.dict_slots,
+  void* ptrs[] = {l.blocks, l.super, l.text, l.sa, l.ftab, l.ctx, l.sa16, l.buckets, l.kbits, l.pair_jump, l.pair_jump_s, l.pair_rows, l.dict_slots,
                   l.bpair_jump, l.bpair_rows, l.seg_start, l.seg_ref, l.seg_off, l.chunk_seg};
   for (void* p : ptrs) (void)hipFree(p);
 }
@@ -538,6 +542,27 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
       l.dict_key = ed->key_bases;
     }
   }
+  if (ctx->dict && ctx->seed_buckets && l.sa16) {
+    // large library where a seed of 11 bases has a few rows: those rows in one line per seed
+    const uint32_t bk = mrg::seed_bucket_k(ix);
+    if (bk) {
+      const uint64_t n_codes = 1ull << (2 * bk), chunk = 1ull << 18;
+      size_t free_b = 0, total_b = 0;
+      HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+      if (free_b > n_codes * 128ull + (4ull << 30) && hipMalloc((void**)&l.buckets, n_codes * 128ull) == hipSuccess) {
+        std::vector<uint32_t> buf(chunk * 32);
+        for (uint64_t lo = 0; lo < n_codes; lo += chunk) {
+          const uint64_t hi = std::min(n_codes, lo + chunk);
+          mrg::fill_seed_buckets(ix, bk, lo, hi, buf.data());
+          HIP_TRY(hipMemcpy(l.buckets + lo * 32, buf.data(), (hi - lo) * 128, hipMemcpyHostToDevice));
+        }
+        l.bucket_k = bk;
+      } else {
+        (void)hipGetLastError();
+        l.buckets = nullptr;
+      }
+    }
+  }
   // small libraries keep their entries on the host: passes that search several of them with one
   // policy get one index of their concatenation (seed_kernel units), built when a cascade first asks
   if (ctx->dict && ix.n <= mrg::kDictMaxBases) {
@@ -594,6 +619,10 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->wide_rows_16 = value != 0;  // takes effect for libraries added afterwards
   } else if (k == "dict") {
     ctx->dict = value != 0;  // (the dictionaries themselves are built by mrg_ctx_add_library while this is 1)
+  } else if (k == "seed_buckets") {
+    ctx->seed_buckets = value != 0;
+  } else if (k == "seed_wgs") {
+    ctx->seed_wgs = value;
   } else if (k == "seed_units") {
     ctx->seed_units = value != 0;
   } else if (k == "dict_key") {
@@ -620,11 +649,11 @@ int mrg_ctx_device_info(const mrg_ctx* ctx, int32_t* n_cu, uint64_t* hbm_bytes, 
 }
 
 // --------------------------------------------------------------- cascade
-// workspace: [idx A][idx B]  (each n + kMaxSegments*4096 u32: segmented survivor lists; a producer
-//            workgroup's segment holds every read of its chunks, 1024 or 4096 reads each)
+// workspace: [idx A][idx B]  (each n + kListSlack u32: segmented survivor lists; a producer
+//            workgroup's segment holds every read of its chunks, 256, 1024 or 4096 reads each)
 //            [segment counts A, B: kMaxSegments u32 each][stats: MRG_MAX_PASSES * 5 u64]
 static uint64_t ws_idx_bytes(uint64_t n) {
-  return (((n + (uint64_t)mrg::kMaxSegments * 4096) * 4 + 255) / 256) * 256;
+  return (((n + mrg::kListSlack) * 4 + 255) / 256) * 256;
 }
 static const uint64_t kWsCountsBytes = 2 * mrg::kMaxSegments * 4;
 static const uint64_t kWsStatsBytes = MRG_MAX_PASSES * kStatsPerPass * 8;
@@ -756,12 +785,20 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
   uint32_t prev_grid = 0, prev_seg_cap = 0;
   // Capacity of a producer workgroup's list segment: it must hold every read the workgroup may be
   // offered -- its share of an identity list in chunks of `chunk` reads, or, reading a list, the
-  // segments whose chunks it walks (chunk c belongs to segment c % in_nseg and goes to workgroup
-  // c % grid: ceil(in_nseg / grid) whole segments at most).
+  // chunks it walks (chunk c belongs to segment c % in_nseg and goes to workgroup c % grid: of
+  // in_nseg x depth chunks every grid-th one).
+  // (0 = the segments would not fit the workspace: every launch adds at most grid x chunk entries of
+  // rounding, kListSlack covers sixteen launches)
   auto segment_capacity = [&](uint32_t grid, uint64_t chunk, bool reads_list) -> uint32_t {
-    const uint64_t per_trip = chunk * grid;
-    uint64_t cap = ((n + per_trip - 1) / per_trip) * chunk;
-    if (reads_list) cap = std::max<uint64_t>(cap, (uint64_t)((prev_grid + grid - 1) / grid) * prev_seg_cap);
+    uint64_t cap;
+    if (!reads_list) {
+      const uint64_t per_trip = chunk * grid;
+      cap = ((n + per_trip - 1) / per_trip) * chunk;
+    } else {
+      const uint64_t depth = ((uint64_t)prev_seg_cap + chunk - 1) / chunk;  // chunks of the longest input segment
+      cap = (((uint64_t)prev_grid * depth + grid - 1) / grid) * chunk;
+    }
+    if (cap * grid > n + mrg::kListSlack) return 0u;
     return (uint32_t)cap;
   };
   int cur_list = 0;        // which of the two list buffers holds the newest survivor list
@@ -841,9 +878,10 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
       e.poly_t = c.poly_t;
       e.pass_index = (int32_t)i;
       uint32_t grid = (uint32_t)ctx->n_cu * 2u;
-      if (grid > mrg::kMaxSegments) grid = mrg::kMaxSegments;
+      if (grid > 512u) grid = 512u;
       // (a workgroup takes chunks of 4096 reads: four per lane)
       const uint32_t seg_cap = segment_capacity(grid, mrg::kExactChunk, have_list);
+      if (!seg_cap && n) return fail(MRG_ERR_ARG, "mrg_cascade_run: survivor lists outgrew the workspace");
       e.out_seg_cap = seg_cap;
       ctx->last_lds[i] = 0u;
       ctx->last_mode[i] = 7u;
@@ -982,6 +1020,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     if (grid > mrg::kMaxSegments) grid = mrg::kMaxSegments;
     // a workgroup's segment must hold every read it may be offered
     const uint32_t seg_cap = segment_capacity(grid, 1024, have_list);
+    if (!seg_cap && n) return fail(MRG_ERR_ARG, "mrg_cascade_run: survivor lists outgrew the workspace");
     p.out_seg_cap = seg_cap;
     ctx->last_lds[i] = lds_bytes;
     ctx->last_mode[i] = (uint32_t)lds_mode;
@@ -1188,6 +1227,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     uint32_t grid = (uint32_t)ctx->n_cu * per_cu;
     if (grid > mrg::kMaxSegments) grid = mrg::kMaxSegments;
     const uint32_t seg_cap = segment_capacity(grid, 1024, have_list);
+    if (!seg_cap && n) return fail(MRG_ERR_ARG, "mrg_cascade_run: survivor lists outgrew the workspace");
     fp.out_seg_cap = seg_cap;
     if (n) HIP_TRY(mrg::launch_fused(fp, words_per_read, grid, lds_total, stream));
     ctx->last_launches[members[0]] = 1;
@@ -1232,6 +1272,8 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
       un.ftab = fm->ftab;
       un.tabs = fm->tabs;
       un.sa16 = reinterpret_cast<const uint4*>(fm->sa16);
+      un.buckets = ctx->seed_buckets ? reinterpret_cast<const uint4*>(fm->buckets) : nullptr;
+      un.bucket_k = fm->bucket_k;
       un.sa = fm->sa;
       un.text = fm->text;
       un.n = fm->n;
@@ -1266,7 +1308,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     }
     sp.reads_per_lane = 1u;
     sp.item_cap = mrg::kSeedThreads * sp.reads_per_lane * 2u;
-    sp.row_cap = small ? 2048u : 4096u;
+    sp.row_cap = small ? 1024u : 2048u;
     sp.stats = stats;
     sp.reads = d_reads;
     sp.lens = d_lens;
@@ -1283,9 +1325,11 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     sp.pos = d_pos;
     sp.mm = d_mm;
     const uint32_t lds = mrg::seed_lds_bytes(sp);
-    uint32_t grid = (uint32_t)ctx->n_cu * (lds * 2u <= 160u * 1024u ? 2u : 1u);
+    (void)lds;
+    uint32_t grid = (uint32_t)ctx->n_cu * (ctx->seed_wgs > 0 ? (uint32_t)ctx->seed_wgs : mrg::seed_wgs_per_cu(sp));
     if (grid > mrg::kMaxSegments) grid = mrg::kMaxSegments;
     const uint32_t seg_cap = segment_capacity(grid, (uint64_t)mrg::kSeedThreads * sp.reads_per_lane, have_list);
+    if (!seg_cap && n) return fail(MRG_ERR_ARG, "mrg_cascade_run: survivor lists outgrew the workspace");
     sp.out_seg_cap = seg_cap;
     if (n) HIP_TRY(mrg::launch_seed(sp, grid, stream));
     ctx->last_launches[first] = 1;

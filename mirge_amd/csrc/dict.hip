@@ -335,9 +335,10 @@ __global__ void __launch_bounds__(kBlock, 8) exact_dict_kernel(const ExactParams
 // ---------------------------------------------------------------------------
 namespace {
 
-constexpr uint32_t kUnitWords = 24u;  // LDS table entry of a unit (what a row's verification needs)
+constexpr uint32_t kUnitWords = 26u;  // LDS table entry of a unit (what a row's verification needs)
 enum UnitWord : uint32_t { UW_SA16 = 0, UW_TEXT = 2, UW_SEGSTART = 4, UW_SEGREF = 6, UW_SEGOFF = 8, UW_CHUNKSEG = 10, UW_FLAGS = 12,
-                           UW_LIMITS = 13, UW_MEMBERS = 14 };
+                           UW_LIMITS = 13, UW_MEMBERS = 14, UW_BUCKETS = 22, UW_SA = 24 };
+constexpr uint32_t kRowFromBucket = 1u << 23;  // tag bit of a row-queue entry: x indexes the unit's buckets, not its wide rows
 constexpr uint32_t kSeedCtlWords = 16u;
 constexpr uint32_t kSeedCntSlots = 16u * 2u + kSeedMaxUnits * 2u;  // per pass processed / aligned, per unit candidates / lookups
 
@@ -346,7 +347,6 @@ struct SeedLds {
   unsigned long long* best;  // [tile] best key
   uint2* rows;               // [row_cap] (row index, slot | unit << 11 | offset << 13 | k' << 19)
   uint4* wide;               // [kSeedWideCap] (lo, hi, slot | unit | offset | k', -)
-  uint32_t* sidx;            // [tile] read index
   uint32_t* items;           // [n_units][item_cap] slot | seed << 11
   uint32_t* utab;            // [kSeedMaxUnits][kUnitWords]
   uint32_t* ctl;             // [0] survivors, [1] longest input segment, [2] rows, [3] wide, [4 + u] items of unit u
@@ -360,8 +360,7 @@ __device__ __forceinline__ SeedLds carve_seed_lds(uint32_t* smem, uint32_t tile,
   l.best = l.srd + tile;
   l.rows = reinterpret_cast<uint2*>(l.best + tile);
   l.wide = reinterpret_cast<uint4*>(l.rows + row_cap);
-  l.sidx = reinterpret_cast<uint32_t*>(l.wide + kSeedWideCap);
-  l.items = l.sidx + tile;
+  l.items = reinterpret_cast<uint32_t*>(l.wide + kSeedWideCap);
   l.utab = l.items + n_units * item_cap;
   l.ctl = l.utab + kSeedMaxUnits * kUnitWords;
   l.cnt = reinterpret_cast<unsigned long long*>(l.ctl + kSeedCtlWords);
@@ -395,18 +394,24 @@ __device__ __forceinline__ const void* lds_pointer(const uint32_t* t, uint32_t w
 }
 
 // One candidate row of a seed whose k' first bases matched at text position wr.x, `off` read
-// bases left of it: fold a valid alignment into the read's slot.
-__device__ __forceinline__ void verify_seed_row(const uint32_t* ut, const uint4 wr, uint64_t q, int32_t L, uint32_t off, uint32_t kprime,
-                                                unsigned long long* best_slot) {
-  const uint32_t before = wr.y & 255u, after = (wr.y >> 8) & 255u, seg16 = wr.y >> 16;
+// bases left of it: the key of a valid alignment (pass : 8 | mismatches : 8 | start : 32 | segment : 16), ~0 = none.
+// (bucket rows keep their segment room in six bits each: fm_index.hpp)
+__device__ __forceinline__ unsigned long long seed_row_key(const uint32_t* ut, const uint4 wr, uint64_t q, int32_t L, uint32_t off,
+                                                           uint32_t kprime, bool bucket_row) {
+  constexpr unsigned long long kNone = ~0ull;
+  const uint32_t before = bucket_row ? (wr.y & 63u) : (wr.y & 255u), after = bucket_row ? ((wr.y >> 6) & 63u) : ((wr.y >> 8) & 255u);
+  const uint32_t seg16 = wr.y >> 16;
+  if (bucket_row && wr.x == 0xFFFFFFFFu) return kNone;
   const uint32_t need_after = (uint32_t)L - off;
-  if ((off > before) | (need_after > after)) return;
+  if ((off > before) | (need_after > after)) return kNone;
   const uint32_t limits = ut[UW_LIMITS], flags = ut[UW_FLAGS];
   const int32_t min_seed_len = (int32_t)(limits & 0xFFFFu), max_total = (int32_t)(limits >> 16);
   const int32_t V = (int32_t)((flags >> 21) & 3u);
   // mismatches the stored context shows: the <= 16 bases left of the position, the bases 8..23 right of it
+  // (a unit without wide rows -- small libraries: 8-byte rows and a text that stay in L2 -- passes
+  // kprime = 0 and zero context words: the text decides)
   uint32_t mm = 0;
-  {
+  if (kprime) {
     const uint32_t c = min(off, 16u);
     if (c) {
       const uint32_t want = (uint32_t)(q >> (2u * (off - c))) & (uint32_t)low_bits(2u * c);
@@ -420,15 +425,15 @@ __device__ __forceinline__ void verify_seed_row(const uint32_t* ut, const uint4 
       mm += (uint32_t)__popc((x | (x >> 1)) & 0x55555555u);
     }
   }
-  if ((int32_t)mm > max_total) return;  // a lower bound of the alignment's mismatches: final
+  if ((int32_t)mm > max_total) return kNone;  // a lower bound of the alignment's mismatches: final
   const uint32_t s = wr.x - off;
   uint64_t mbits = 0;
-  const bool covered = off <= 16u && need_after <= 24u && kprime >= 8u && L <= min_seed_len;
+  const bool covered = kprime != 0u && off <= 16u && need_after <= 24u && kprime >= 8u && L <= min_seed_len;
   if (!covered) {
     const uint32_t* text = reinterpret_cast<const uint32_t*>(lds_pointer(ut, UW_TEXT));
     mbits = mismatch_bits(text_window(text, s), q) & low_bits(2u * (uint32_t)L);
     mm = (uint32_t)__popcll(mbits);
-    if ((int32_t)mm > max_total) return;
+    if ((int32_t)mm > max_total) return kNone;
   }
   // which member (pass) the entry belongs to, and that pass's policy
   const uint32_t n_members = (flags >> 18) & 7u;
@@ -448,14 +453,22 @@ __device__ __forceinline__ void verify_seed_row(const uint32_t* ut, const uint4 
   const int32_t pass_index = (int32_t)(mw & 0xFFu), seed_len = (int32_t)((mw >> 8) & 0xFFFFu), m_total = (int32_t)(mw >> 24);
   uint32_t mm_seed = mm;
   if (L > seed_len) mm_seed = (uint32_t)__popcll(mbits & low_bits(2u * (uint32_t)seed_len));  // (then never `covered`)
-  if ((int32_t)mm_seed > V || (int32_t)mm > m_total) return;
-  const unsigned long long key = ((unsigned long long)pass_index << 56) | ((unsigned long long)mm << 48) | ((unsigned long long)s << 16) | seg16;
-  atomicMin(best_slot, key);
+  if ((int32_t)mm_seed > V || (int32_t)mm > m_total) return kNone;
+  return ((unsigned long long)pass_index << 56) | ((unsigned long long)mm << 48) | ((unsigned long long)s << 16) | seg16;
+}
+
+__device__ __forceinline__ void verify_seed_row(const uint32_t* ut, const uint4 wr, uint64_t q, int32_t L, uint32_t off, uint32_t kprime,
+                                                unsigned long long* best_slot, bool bucket_row = false) {
+  const unsigned long long key = seed_row_key(ut, wr, q, L, off, kprime, bucket_row);
+  if (key != ~0ull) atomicMin(best_slot, key);
 }
 
 }  // namespace
 
-__global__ void __launch_bounds__(kSeedThreads, 8) seed_kernel(const SeedParams p) {
+// BUCKETS: some unit has seed buckets (the instantiation without them needs fewer registers: WAVES = 8
+// workgroups per CU instead of 6)
+template <bool BUCKETS, int WAVES>
+__global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t T = p.reads_per_lane, tile = kSeedThreads * T;
   const SeedLds l = carve_seed_lds(smem, tile, p.row_cap, p.item_cap, p.n_units);
@@ -474,6 +487,8 @@ __global__ void __launch_bounds__(kSeedThreads, 8) seed_kernel(const SeedParams 
     put(UW_SEGREF, un.seg_ref);
     put(UW_SEGOFF, un.seg_off);
     put(UW_CHUNKSEG, un.chunk_seg);
+    put(UW_BUCKETS, un.buckets);
+    put(UW_SA, un.sa);
     t[UW_FLAGS] = (uint32_t)un.trim5 | ((uint32_t)un.trim3 << 8) | (un.poly_t ? 1u << 16 : 0u) | (un.simple_segs ? 1u << 17 : 0u) |
                   (un.n_members << 18) | ((uint32_t)un.max_mm_seed << 21);
     t[UW_LIMITS] = (uint32_t)min(un.min_seed_len, 0xFFFF) | ((uint32_t)min(un.max_total, 0xFFFF) << 16);
@@ -491,36 +506,114 @@ __global__ void __launch_bounds__(kSeedThreads, 8) seed_kernel(const SeedParams 
   const uint32_t in_nseg = p.idx_in ? p.in_nseg : 1u;
   const uint32_t depth_chunks = p.idx_in ? (l.ctl[1] + tile - 1) / tile : (p.n_total + tile - 1) / tile;
   const uint32_t n_chunks = in_nseg * depth_chunks;
-  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  // ---- the walk, software-pipelined: the read of tile + grid and the list entry of tile + 2 grid are
+  // in flight while a tile is worked on ----
+  auto fetch_index = [&](uint32_t chunk, uint32_t& r_out) -> bool {
+    if (chunk >= n_chunks) return false;
     const uint32_t sgi = chunk % in_nseg, depth = chunk / in_nseg;
-    const uint32_t count = p.idx_in ? p.in_count[sgi] : p.n_total;
-    // ================= phase 1: reads of the tile, and their items =================
-    for (uint32_t u = 0; u < T; ++u) {
-      const uint32_t slot = tid * T + u;
-      const uint32_t t = depth * tile + slot;
-      const bool active = t < count;
-      uint32_t r = 0, L0 = 255u;
-      uint64_t rd = 0;
-      if (active) {
-        r = p.idx_in ? p.idx_in[(size_t)sgi * p.in_seg_cap + t] : t;
-        L0 = p.lens[r];
-        rd = p.reads[r];
-      }
+    const uint32_t t = depth * tile + tid;
+    const bool act = t < (p.idx_in ? p.in_count[sgi] : p.n_total);
+    r_out = 0;
+    if (act) r_out = p.idx_in ? p.idx_in[(size_t)sgi * p.in_seg_cap + t] : t;
+    return act;
+  };
+  uint32_t r_b = 0, r_c = 0, L_b = 255u;
+  uint64_t rd_b = 0;
+  uint32_t c_inl_lookups = 0, c_inl_cands = 0, inl_unit = 0;  // bucket lookups answered in phase 1 (diagnostics, per lane)
+  uint32_t el_mask = 0;  // bit u: the lane's read is offered to unit u (set in phase 1, read in phase 3)
+  // reads offered to / claimed by each member pass: wave-level sums of ballots (scalar registers)
+  uint32_t acc_proc[kSeedMaxUnits][kSeedMaxMembers], acc_alig[kSeedMaxUnits][kSeedMaxMembers];
+#pragma unroll
+  for (uint32_t a = 0; a < kSeedMaxUnits; ++a)
+#pragma unroll
+    for (uint32_t b = 0; b < kSeedMaxMembers; ++b) acc_proc[a][b] = acc_alig[a][b] = 0u;
+  bool act_b = fetch_index(blockIdx.x, r_b);
+  bool act_c = fetch_index(blockIdx.x + gridDim.x, r_c);
+  if (act_b) {
+    L_b = p.lens[r_b];
+    rd_b = p.reads[r_b];
+  }
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const bool active = act_b;
+    const uint32_t r = r_b, L0 = active ? L_b : 255u, slot = tid;
+    const uint64_t rd = rd_b;
+    act_b = act_c;
+    r_b = r_c;
+    L_b = 255u;
+    rd_b = 0;
+    if (act_b) {
+      L_b = p.lens[r_b];
+      rd_b = p.reads[r_b];
+    }
+    act_c = fetch_index(chunk + 2u * gridDim.x, r_c);
+    // ================= phase 1: the tile's reads into LDS, and their items =================
+    // A seed of exactly bucket_k bases in a unit with seed buckets is answered right here: the first four
+    // rows of both seeds' buckets are requested together (one 128-byte line per seed, eight loads in
+    // flight per lane) and verified into a lane-local best; a fuller or overflowing bucket, any other
+    // seed length and every unit without buckets go through the item queue.
+    {
+      unsigned long long my_best = ~0ull;
+      el_mask = 0u;
       l.srd[slot] = rd;
-      l.sidx[slot] = r;
       l.sL0[slot] = (uint8_t)L0;
-      l.best[slot] = ~0ull;
       for (uint32_t ui = 0; ui < p.n_units; ++ui) {
         const SeedUnit& un = p.unit[ui];
         uint64_t q = 0;
         int32_t L = 0;
         const bool el = active && unit_view(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, rd, L0, q, L);
+        el_mask |= el ? 1u << ui : 0u;
         const int32_t V = un.max_mm_seed;
         const bool search = el && L > V;
         const uint32_t n_seeds = un.kind == 1u ? 1u : (uint32_t)V + 1u;
         const int32_t k = seed_bases(L, un.min_seed_len, V);
+        uint32_t queued = search ? (1u << n_seeds) - 1u : 0u;  // seeds that need the item queue
+        if (BUCKETS && un.kind == 0u && un.buckets) {
+          const bool inl = search && (uint32_t)k == un.bucket_k;
+          if (__any(inl)) {
+            const uint32_t* ut = l.utab + ui * kUnitWords;
+            const uint32_t cmask = (1u << (2u * un.bucket_k)) - 1u;
+            const uint32_t base0 = ((uint32_t)q & cmask) * kSeedBucketRows;
+            const uint32_t base1 = ((uint32_t)(q >> (2u * un.bucket_k)) & cmask) * kSeedBucketRows;
+            const bool two = V >= 1;
+            uint4 ra[4], rb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              ra[i] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+              rb[i] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+            }
+            if (inl) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) ra[i] = un.buckets[base0 + i];
+              if (two) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rb[i] = un.buckets[base1 + i];
+              }
+            }
+            if (inl) {
+              const uint32_t cnt0 = (ra[0].y >> 12) & 15u, cnt1 = two ? ((rb[0].y >> 12) & 15u) : 0u;
+              c_inl_lookups += two ? 2u : 1u;
+              queued = 0u;
+              if (cnt0 <= 4u) {
+                c_inl_cands += cnt0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) my_best = min(my_best, seed_row_key(ut, ra[i], q, L, 0u, un.bucket_k, true));
+              } else {
+                queued |= 1u;
+              }
+              if (two) {
+                if (cnt1 <= 4u) {
+                  c_inl_cands += cnt1;
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) my_best = min(my_best, seed_row_key(ut, rb[i], q, L, un.bucket_k, un.bucket_k, true));
+                } else {
+                  queued |= 2u;
+                }
+              }
+            }
+          }
+        }
         for (uint32_t j = 0; j < n_seeds; ++j) {
-          bool need = search;
+          bool need = ((queued >> j) & 1u) != 0u;
           if (un.kind == 0u && un.kbits && need && k >= 8) {
             const uint32_t kb = (uint32_t)min(k, 11);
             const uint32_t code = (uint32_t)(q >> (2u * j * (uint32_t)k)) & ((1u << (2u * kb)) - 1u);
@@ -534,9 +627,14 @@ __global__ void __launch_bounds__(kSeedThreads, 8) seed_kernel(const SeedParams 
             if (need) l.items[ui * p.item_cap + base + mbcnt(mask)] = slot | (j << 11);
           }
         }
+        if (un.kind == 0u && un.buckets) inl_unit = ui;
       }
+      l.best[slot] = my_best;
     }
     __syncthreads();
+    uint32_t any_items = 0;
+    for (uint32_t ui = 0; ui < p.n_units; ++ui) any_items |= l.ctl[4u + ui];
+    if (any_items) {  // (workgroup-uniform)
     // ================= phase 2a: items -> dictionary answers / suffix-array rows =================
     for (uint32_t ui = 0; ui < p.n_units; ++ui) {
       const SeedUnit& un = p.unit[ui];
@@ -633,18 +731,32 @@ __global__ void __launch_bounds__(kSeedThreads, 8) seed_kernel(const SeedParams 
         if (has) {
           const int32_t k = seed_bases(L, un.min_seed_len, un.max_mm_seed);
           const uint32_t off = j * (uint32_t)k;
-          uint32_t tab_off = 0;
-          const uint32_t kp = un.tabs.k[0] ? pick_table(un.tabs, k, tab_off) : 0u;
-          uint32_t hi = un.n + 1u;
-          if (kp) {
-            const uint32_t* tab = un.ftab + tab_off + lex_code((q >> (2u * off)) & low_bits(2u * kp), kp);
-            lo = tab[0];
-            hi = tab[1];
+          uint32_t kp = 0, cnt = kSeedBucketOverflow;
+          if (BUCKETS && un.buckets && (uint32_t)k == un.bucket_k) {
+            // the seed's rows sit in one 128-byte line addressed by the seed itself
+            kp = un.bucket_k;
+            lo = ((uint32_t)(q >> (2u * off)) & ((1u << (2u * kp)) - 1u)) * kSeedBucketRows;
+            cnt = (un.buckets[lo].y >> 12) & 15u;
+            ++c_lookups;
           }
-          ++c_lookups;
-          n_rows = hi > lo ? hi - lo : 0u;
+          if (cnt != kSeedBucketOverflow) {
+            n_rows = cnt;
+            tag = slot | (ui << 11) | (off << 13) | (kp << 19) | kRowFromBucket;
+          } else {
+            uint32_t tab_off = 0;
+            kp = un.tabs.k[0] ? pick_table(un.tabs, k, tab_off) : 0u;
+            uint32_t hi = un.n + 1u;
+            lo = 0;
+            if (kp) {
+              const uint32_t* tab = un.ftab + tab_off + lex_code((q >> (2u * off)) & low_bits(2u * kp), kp);
+              lo = tab[0];
+              hi = tab[1];
+            }
+            ++c_lookups;
+            n_rows = hi > lo ? hi - lo : 0u;
+            tag = slot | (ui << 11) | (off << 13) | (kp << 19);
+          }
           c_cands += n_rows;
-          tag = slot | (ui << 11) | (off << 13) | (kp << 19);
         }
         const bool is_wide = n_rows > kSeedRowsPerItem;
         const uint32_t mine = is_wide ? 0u : n_rows;
@@ -661,7 +773,13 @@ __global__ void __launch_bounds__(kSeedThreads, 8) seed_kernel(const SeedParams 
           const uint32_t* ut = l.utab + ui * kUnitWords;
           for (uint32_t i = 0; i < mine; ++i) {
             if (first + i < p.row_cap) l.rows[first + i] = make_uint2(lo + i, tag);
-            else verify_seed_row(ut, un.sa16[lo + i], q, L, (tag >> 13) & 63u, tag >> 19, &l.best[slot]);
+            else if ((tag & kRowFromBucket) || un.sa16)
+              verify_seed_row(ut, (tag & kRowFromBucket) ? un.buckets[lo + i] : un.sa16[lo + i], q, L, (tag >> 13) & 63u, (tag >> 19) & 15u,
+                              &l.best[slot], (tag & kRowFromBucket) != 0u);
+            else {
+              const uint64_t row = un.sa[lo + i];
+              verify_seed_row(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), q, L, (tag >> 13) & 63u, 0u, &l.best[slot]);
+            }
           }
         }
         if (is_wide) {
@@ -670,7 +788,14 @@ __global__ void __launch_bounds__(kSeedThreads, 8) seed_kernel(const SeedParams 
             l.wide[w] = make_uint4(lo, lo + n_rows, tag, 0u);
           } else {
             const uint32_t* ut = l.utab + ui * kUnitWords;
-            for (uint32_t i = 0; i < n_rows; ++i) verify_seed_row(ut, un.sa16[lo + i], q, L, (tag >> 13) & 63u, tag >> 19, &l.best[slot]);
+            for (uint32_t i = 0; i < n_rows; ++i) {
+              if (un.sa16) {
+                verify_seed_row(ut, un.sa16[lo + i], q, L, (tag >> 13) & 63u, (tag >> 19) & 15u, &l.best[slot]);
+              } else {
+                const uint64_t row = un.sa[lo + i];
+                verify_seed_row(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), q, L, (tag >> 13) & 63u, 0u, &l.best[slot]);
+              }
+            }
           }
         }
       }
@@ -682,57 +807,73 @@ __global__ void __launch_bounds__(kSeedThreads, 8) seed_kernel(const SeedParams 
       }
     }
     __syncthreads();
+    if (tid < p.n_units) l.ctl[4u + tid] = 0u;  // the item queues are read: empty for the next tile
     // ================= phase 2b: one row per lane =================
     {
       const uint32_t n_rows = min(l.ctl[2], p.row_cap);
       for (uint32_t x = tid; x < n_rows; x += kSeedThreads) {
         const uint2 e = l.rows[x];
-        const uint32_t slot = e.y & 2047u, ui = (e.y >> 11) & 3u, off = (e.y >> 13) & 63u, kp = e.y >> 19;
+        const uint32_t slot = e.y & 2047u, ui = (e.y >> 11) & 3u, off = (e.y >> 13) & 63u, kp = (e.y >> 19) & 15u;
+        const bool from_bucket = (e.y & kRowFromBucket) != 0u;
         const uint32_t* ut = l.utab + ui * kUnitWords;
         const uint32_t flags = ut[UW_FLAGS];
         uint64_t q;
         int32_t L;
         unit_view(0, 255, (int32_t)((flags >> 16) & 1u), (int32_t)(flags & 255u), (int32_t)((flags >> 8) & 255u), l.srd[slot], l.sL0[slot], q, L);
-        const uint4 wr = reinterpret_cast<const uint4*>(lds_pointer(ut, UW_SA16))[e.x];
-        verify_seed_row(ut, wr, q, L, off, kp, &l.best[slot]);
+        const uint4* wide = reinterpret_cast<const uint4*>(lds_pointer(ut, from_bucket ? UW_BUCKETS : UW_SA16));
+        if (wide) {
+          verify_seed_row(ut, wide[e.x], q, L, off, kp, &l.best[slot], from_bucket);
+        } else {
+          const uint64_t row = reinterpret_cast<const uint64_t*>(lds_pointer(ut, UW_SA))[e.x];
+          verify_seed_row(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), q, L, off, 0u, &l.best[slot]);
+        }
       }
       const uint32_t n_wide = min(l.ctl[3], kSeedWideCap);
       for (uint32_t w = 0; w < n_wide; ++w) {
         const uint4 e = l.wide[w];
-        const uint32_t slot = e.z & 2047u, ui = (e.z >> 11) & 3u, off = (e.z >> 13) & 63u, kp = e.z >> 19;
+        const uint32_t slot = e.z & 2047u, ui = (e.z >> 11) & 3u, off = (e.z >> 13) & 63u, kp = (e.z >> 19) & 15u;
         const uint32_t* ut = l.utab + ui * kUnitWords;
         const uint32_t flags = ut[UW_FLAGS];
         uint64_t q;
         int32_t L;
         unit_view(0, 255, (int32_t)((flags >> 16) & 1u), (int32_t)(flags & 255u), (int32_t)((flags >> 8) & 255u), l.srd[slot], l.sL0[slot], q, L);
         const uint4* sa16 = reinterpret_cast<const uint4*>(lds_pointer(ut, UW_SA16));
-        for (uint32_t i = e.x + tid; i < e.y; i += kSeedThreads) verify_seed_row(ut, sa16[i], q, L, off, kp, &l.best[slot]);
+        const uint64_t* sa8 = reinterpret_cast<const uint64_t*>(lds_pointer(ut, UW_SA));
+        for (uint32_t i = e.x + tid; i < e.y; i += kSeedThreads) {
+          if (sa16) {
+            verify_seed_row(ut, sa16[i], q, L, off, kp, &l.best[slot]);
+          } else {
+            const uint64_t row = sa8[i];
+            verify_seed_row(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), q, L, off, 0u, &l.best[slot]);
+          }
+        }
       }
     }
     __syncthreads();
+    }
     // ================= phase 3: the claim, outputs, survivors, counters =================
-    for (uint32_t u = 0; u < T; ++u) {
-      const uint32_t slot = tid * T + u;
-      const uint32_t L0 = l.sL0[slot];
-      const bool active = L0 != 255u;
-      const uint64_t rd = l.srd[slot];
-      const uint32_t r = l.sidx[slot];
+    // (no barrier between this and the next tile's phase 1: both touch the lane's own slot only; the
+    // row queue, read before the barrier above, is emptied here, ahead of the next tile's barrier)
+    if (tid == 0) {
+      l.ctl[2] = 0u;
+      l.ctl[3] = 0u;
+    }
+    {
       const unsigned long long key = l.best[slot];
       const bool claimed = key != ~0ull;
       const int32_t cp = claimed ? (int32_t)(key >> 56) : 255;
       uint32_t o_ref = 0, o_pos = 0;
-      for (uint32_t ui = 0; ui < p.n_units; ++ui) {
+#pragma unroll
+      for (uint32_t ui = 0; ui < kSeedMaxUnits; ++ui) {
+        if (ui >= p.n_units) break;
         const SeedUnit& un = p.unit[ui];
-        uint64_t q;
-        int32_t L;
-        const bool el = active && unit_view(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, rd, L0, q, L);
-        for (uint32_t mi = 0; mi < un.n_members; ++mi) {
+        const bool el = ((el_mask >> ui) & 1u) != 0u;
+#pragma unroll
+        for (uint32_t mi = 0; mi < kSeedMaxMembers; ++mi) {
+          if (mi >= un.n_members) break;
           const int32_t pi = un.m[mi].pass_index;
-          const uint64_t m_proc = __ballot(el && cp >= pi), m_alig = __ballot(cp == pi);
-          if (lane == 0) {
-            if (m_proc) atomicAdd(&l.cnt[2 * pi], (unsigned long long)__popcll(m_proc));
-            if (m_alig) atomicAdd(&l.cnt[2 * pi + 1], (unsigned long long)__popcll(m_alig));
-          }
+          acc_proc[ui][mi] += (uint32_t)__popcll(__ballot(el && cp >= pi));
+          acc_alig[ui][mi] += (uint32_t)__popcll(__ballot(cp == pi));
           if (cp == pi) {
             if (un.kind == 1u) {
               o_ref = (uint32_t)(key >> 21) & 0x7FFFFFFu;
@@ -768,11 +909,26 @@ __global__ void __launch_bounds__(kSeedThreads, 8) seed_kernel(const SeedParams 
         }
       }
     }
-    __syncthreads();
-    if (tid >= 2u && tid < 4u + p.n_units) l.ctl[tid] = 0u;  // rows, wide, items: empty for the next tile
-    __syncthreads();
   }
   // ---- counters: one global atomic per non-zero counter and workgroup ----
+  {
+    const uint64_t t_l = wave_sum(c_inl_lookups), t_c = wave_sum(c_inl_cands);
+    if (lane == 0) {
+      if (t_c) atomicAdd(&l.cnt[32u + 2u * inl_unit], (unsigned long long)t_c);
+      if (t_l) atomicAdd(&l.cnt[32u + 2u * inl_unit + 1u], (unsigned long long)t_l);
+#pragma unroll
+      for (uint32_t ui = 0; ui < kSeedMaxUnits; ++ui) {
+        if (ui >= p.n_units) break;
+#pragma unroll
+        for (uint32_t mi = 0; mi < kSeedMaxMembers; ++mi) {
+          if (mi >= p.unit[ui].n_members) break;
+          const int32_t pi = p.unit[ui].m[mi].pass_index;
+          if (acc_proc[ui][mi]) atomicAdd(&l.cnt[2 * pi], (unsigned long long)acc_proc[ui][mi]);
+          if (acc_alig[ui][mi]) atomicAdd(&l.cnt[2 * pi + 1], (unsigned long long)acc_alig[ui][mi]);
+        }
+      }
+    }
+  }
   __syncthreads();
   if (tid < 32u) {
     const unsigned long long v = l.cnt[tid];
@@ -787,17 +943,28 @@ __global__ void __launch_bounds__(kSeedThreads, 8) seed_kernel(const SeedParams 
 
 uint32_t seed_lds_bytes(const SeedParams& p) {
   const uint32_t tile = kSeedThreads * p.reads_per_lane;
-  return tile * 8u + tile * 8u + p.row_cap * 8u + kSeedWideCap * 16u + tile * 4u + p.n_units * p.item_cap * 4u +
+  return tile * 8u + tile * 8u + p.row_cap * 8u + kSeedWideCap * 16u + p.n_units * p.item_cap * 4u +
          kSeedMaxUnits * kUnitWords * 4u + kSeedCtlWords * 4u + kSeedCntSlots * 8u + tile;
+}
+
+uint32_t seed_wgs_per_cu(const SeedParams& p) {
+  bool buckets = false;
+  for (uint32_t u = 0; u < p.n_units; ++u) buckets |= p.unit[u].kind == 0u && p.unit[u].buckets != nullptr;
+  const uint32_t by_regs = buckets ? 6u : 8u, by_lds = (160u * 1024u) / seed_lds_bytes(p);
+  return by_regs < by_lds ? by_regs : (by_lds ? by_lds : 1u);
 }
 
 hipError_t launch_seed(const SeedParams& p, uint32_t grid, hipStream_t stream) {
   const uint32_t lds = seed_lds_bytes(p);
+  bool buckets = false;
+  for (uint32_t u = 0; u < p.n_units; ++u) buckets |= p.unit[u].kind == 0u && p.unit[u].buckets != nullptr;
+  const void* kern = buckets ? reinterpret_cast<const void*>(seed_kernel<true, 6>) : reinterpret_cast<const void*>(seed_kernel<false, 8>);
   if (lds > 48u * 1024u) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(seed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(seed_kernel, dim3(grid), dim3(kSeedThreads), lds, stream, p);
+  if (buckets) hipLaunchKernelGGL((seed_kernel<true, 6>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+  else hipLaunchKernelGGL((seed_kernel<false, 8>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
   return hipGetLastError();
 }
 

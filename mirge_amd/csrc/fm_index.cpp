@@ -359,32 +359,82 @@ void build_row_context(FmIndex& ix) {
   for (auto& th : pool) th.join();
 }
 
+namespace {
+// one wide row (fm_index.hpp: fill_wide_rows): the 8-byte row, the 16 bases left of its position, the 16 bases from + 8
+inline void wide_row_of(const FmIndex& ix, uint64_t row, uint32_t* o) {
+  const uint32_t p = (uint32_t)row;
+  // left: text[p-16 .. p), text[p-1] in the top two bits (bases before the text read as A)
+  uint32_t left;
+  if (p >= 16) {
+    left = (uint32_t)window64(ix, (uint64_t)p - 16);
+  } else {
+    left = p ? ((uint32_t)window64(ix, 0) & (uint32_t)((1ull << (2 * p)) - 1ull)) << (32 - 2 * p) : 0u;
+  }
+  // right: text[p+8 .. p+24), text[p+8] in the low two bits (bases past the end read as A)
+  uint32_t right = (uint32_t)window64(ix, (uint64_t)p + kWideRowRightSkip);
+  const uint64_t start = (uint64_t)p + kWideRowRightSkip;
+  if (start >= ix.n) right = 0;
+  else if (start + 16 > ix.n) right &= (uint32_t)((1ull << (2 * (ix.n - start))) - 1ull);
+  o[0] = (uint32_t)row;
+  o[1] = (uint32_t)(row >> 32);
+  o[2] = left;
+  o[3] = right;
+}
+}  // namespace
+
 void fill_wide_rows(const FmIndex& ix, size_t row_lo, size_t row_hi, uint32_t* out) {
   const unsigned n_threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   std::vector<std::thread> pool;
   const size_t n = row_hi - row_lo;
   for (unsigned t = 0; t < n_threads; ++t)
     pool.emplace_back([&ix, row_lo, n, n_threads, t, out] {
-      for (size_t k = n * t / n_threads; k < n * (t + 1) / n_threads; ++k) {
-        const uint64_t row = ix.sa[row_lo + k];
-        const uint32_t p = (uint32_t)row;
-        // left: text[p-16 .. p), text[p-1] in the top two bits (bases before the text read as A)
-        uint32_t left;
-        if (p >= 16) {
-          left = (uint32_t)window64(ix, (uint64_t)p - 16);
-        } else {
-          left = p ? ((uint32_t)window64(ix, 0) & (uint32_t)((1ull << (2 * p)) - 1ull)) << (32 - 2 * p) : 0u;
+      for (size_t k = n * t / n_threads; k < n * (t + 1) / n_threads; ++k) wide_row_of(ix, ix.sa[row_lo + k], out + 4 * k);
+    });
+  for (auto& th : pool) th.join();
+}
+
+uint32_t seed_bucket_k(const FmIndex& ix) {
+  // a bucket holds kSeedBucketRows rows: worth it when a k-mer has a few rows on average, and the
+  // index must have the jump table of that k (overflowing buckets fall back to it)
+  const uint32_t k = kSeedBucketK;
+  const double fill = (double)ix.n / (double)(1ull << (2 * k));
+  bool has = false;
+  for (int t = 0; t < 4; ++t) has |= ix.ftab_ks[t] == k;
+  return (has && fill >= 0.25 && fill <= 4.0) ? k : 0u;
+}
+
+void fill_seed_buckets(const FmIndex& ix, uint32_t k, uint64_t code_lo, uint64_t code_hi, uint32_t* out) {
+  size_t tab_base = 0;
+  bool found = false;
+  for (int t = 0; t < 4 && !found; ++t) {
+    if (ix.ftab_ks[t] == k) found = true;
+    else if (ix.ftab_ks[t]) tab_base += ((size_t)1 << (2 * ix.ftab_ks[t])) + 1;
+  }
+  if (!found) throw std::runtime_error("seed buckets: the index has no jump table of that k");
+  const uint32_t* tab = ix.ftab.data() + tab_base;
+  const unsigned n_threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  std::vector<std::thread> pool;
+  const uint64_t n = code_hi - code_lo;
+  for (unsigned t = 0; t < n_threads; ++t)
+    pool.emplace_back([&ix, tab, k, code_lo, n, n_threads, t, out] {
+      for (uint64_t q = n * t / n_threads; q < n * (t + 1) / n_threads; ++q) {
+        const uint64_t code = code_lo + q;                  // first base in the low two bits
+        const uint64_t lex = reverse_pairs(code, k);        // the jump table's numbering
+        const uint32_t lo = tab[lex], hi = tab[lex + 1];
+        uint32_t* b = out + q * (4u * kSeedBucketRows);
+        const uint32_t cnt = hi - lo;
+        for (uint32_t i = 0; i < kSeedBucketRows; ++i) {
+          uint32_t* o = b + 4 * i;
+          if (cnt <= kSeedBucketRows && i < cnt) {
+            wide_row_of(ix, ix.sa[lo + i], o);
+            const uint32_t before = std::min<uint32_t>(63u, o[1] & 255u), after = std::min<uint32_t>(63u, (o[1] >> 8) & 255u);
+            o[1] = before | (after << 6) | (o[1] & 0xFFFF0000u);
+          } else {
+            o[0] = 0xFFFFFFFFu;
+            o[1] = o[2] = o[3] = 0u;
+          }
         }
-        // right: text[p+8 .. p+24), text[p+8] in the low two bits (bases past the end read as A)
-        uint32_t right = (uint32_t)window64(ix, (uint64_t)p + kWideRowRightSkip);
-        const uint64_t start = (uint64_t)p + kWideRowRightSkip;
-        if (start >= ix.n) right = 0;
-        else if (start + 16 > ix.n) right &= (uint32_t)((1ull << (2 * (ix.n - start))) - 1ull);
-        uint32_t* o = out + 4 * k;
-        o[0] = (uint32_t)row;
-        o[1] = (uint32_t)(row >> 32);
-        o[2] = left;
-        o[3] = right;
+        b[1] |= (cnt <= kSeedBucketRows ? cnt : kSeedBucketOverflow) << 12;
       }
     });
   for (auto& th : pool) th.join();

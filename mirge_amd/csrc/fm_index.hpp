@@ -86,6 +86,19 @@ void build_kmer_bits(FmIndex& ix);    // from text
 // piece in an 11 Mbp library) is dropped without its text-window request.  Rows [row_lo, row_hi)
 // into out[4 * (row_hi - row_lo)].
 void fill_wide_rows(const FmIndex& ix, size_t row_lo, size_t row_hi, uint32_t* out);
+// Seed buckets of a large library (seed_kernel, kernels.hpp): for every k-mer, k = kSeedBucketK = 11 --
+// a seed of a 22..23-nt read under a one-mismatch policy -- the wide rows of the text positions that
+// start with it, side by side in ONE 128-byte line addressed by the k-mer itself (first base in the
+// low two bits): a seed lookup is one memory trip instead of a jump-table load and then its rows.
+// Bucket = kSeedBucketRows rows of 16 bytes like fill_wide_rows', except for word 1: bits 0-5
+// bases back to the segment start (clamped to 63), 6-11 bases to its end (clamped to 63), 12-15 in
+// row 0 only the number of rows of the k-mer (kSeedBucketOverflow = more than a bucket holds: the
+// jump table serves that k-mer), 16-31 segment id; unused rows have position 0xFFFFFFFF.
+// seed_bucket_k: the k a library gets buckets for (0 = none: only libraries where a k-mer has
+// 0.25..4 rows on average).  Buckets [code_lo, code_hi) into out[32 * (code_hi - code_lo)].
+constexpr uint32_t kSeedBucketK = 11, kSeedBucketRows = 8, kSeedBucketOverflow = 15;
+uint32_t seed_bucket_k(const FmIndex& ix);
+void fill_seed_buckets(const FmIndex& ix, uint32_t k, uint64_t code_lo, uint64_t code_hi, uint32_t* out);
 // Pair tables of a small library, for policies with two seed mismatches (kernels.hip,
 // stratum_kernel).  Four disjoint anchors of `anchor` bases at read offsets 0, A, 2A, 3A: two
 // mismatches touch at most two of them, so every alignment with <= 2 seed mismatches matches

@@ -19,7 +19,9 @@ constexpr uint32_t kTallyCatReplicas = 32u;  // LDS copies of each category bin 
 constexpr uint32_t kKmerBitsK = 9u;
 constexpr uint32_t kKmerBitsWords = (1u << (2u * kKmerBitsK)) / 32u;
 // Survivor lists are segmented: workgroup b of the producing pass owns segment b.
-constexpr uint32_t kMaxSegments = 512u;
+constexpr uint32_t kMaxSegments = 2048u;
+// entries a survivor list can hold beyond one per read: every launch rounds its workgroups' segments up to its chunk size
+constexpr uint64_t kListSlack = 1ull << 23;
 constexpr uint32_t kMatchCtlBytes = (4u + 4u * 16u + 10u) * 4u;  // control words, 16 B per wave, 5 counters
 
 // The jump tables of one library in ascending k (k[0] = 0: tables not used; a missing big table
@@ -236,13 +238,14 @@ hipError_t launch_exact_dict(const ExactParams& p, uint32_t grid, hipStream_t st
 //           their concatenation: members[] tells which pass an entry belongs to.  Small units filter
 //           seeds through presence bitmaps of the library's 8..11-mers (L2-resident) first.
 //   kind 1  a pass without seed mismatches on a library with an exact-match dictionary.
-// A workgroup works through tiles of 1024 T reads in three phases with dense lanes in each: per
+// A workgroup (four waves; six of them per CU hide each other's memory trips) works through tiles
+// of 256 reads in three phases with dense lanes in each: per
 // read, which (unit, seed) ITEMS need the index -> per item, the jump-table load and its ROWS ->
 // per row, verification and a 64-bit atomic min into the read's LDS slot -> per read, the claim in
 // cascade order (the key starts with the pass index), outputs, survivors and counters.
-constexpr uint32_t kSeedMaxUnits = 3u, kSeedMaxMembers = 4u, kSeedThreads = 1024u;
+constexpr uint32_t kSeedMaxUnits = 3u, kSeedMaxMembers = 4u, kSeedThreads = 256u;
 constexpr uint32_t kSeedRowsPerItem = 24u;  // wider intervals are verified by the whole workgroup
-constexpr uint32_t kSeedWideCap = 256u;
+constexpr uint32_t kSeedWideCap = 64u;
 struct SeedMember {
   int32_t pass_index, seed_len, max_mm_total;
   uint32_t entry_lo;  // first entry of this member in the unit's (union) library
@@ -252,6 +255,8 @@ struct SeedUnit {
   const uint32_t* ftab;
   JumpTables tabs;
   const uint4* sa16;
+  const uint4* buckets;  // seed buckets of the library (fm_index.hpp), null = none: a seed of exactly bucket_k
+  uint32_t bucket_k;     // bases finds its rows in ONE 128-byte line instead of jump table + rows
   const uint64_t* sa;
   const uint32_t* text;
   uint32_t n;
@@ -291,6 +296,8 @@ struct SeedParams {
   uint8_t* mm;
 };
 uint32_t seed_lds_bytes(const SeedParams& p);
+// workgroups per CU the instantiation a launch gets can keep resident (registers; LDS permitting)
+uint32_t seed_wgs_per_cu(const SeedParams& p);
 hipError_t launch_seed(const SeedParams& p, uint32_t grid, hipStream_t stream);
 
 constexpr uint32_t kCountThreads = 256u;

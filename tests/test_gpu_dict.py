@@ -106,6 +106,25 @@ def test_exact_policies_on_every_dictionary_library(engine, world):
             assert 0 < res.stats[0]["aligned"] < res.stats[0]["processed"]
 
 
+def test_seed_buckets_and_jump_tables_on_a_large_library(engine, world):
+    """One-mismatch passes on the 6.8 Mbp mRNA library of this world (a seed of 11 bases has 1.6 rows
+    on average: it gets seed buckets): 22..23-nt reads find their rows in the bucket of the seed,
+    other lengths and overflowing buckets through the jump table; `seed_buckets` = 0 sends everything
+    through the jump table.  Same assignments as the port either way, and as the FM kernels."""
+    mi, li = LIB_ORDER.index("mirna"), LIB_ORDER.index("mrna")
+    for pol in (dict(seed_len=28, max_mm_seed=1, max_mm_total=2), dict(seed_len=1024, max_mm_seed=1, max_mm_total=1),
+                dict(seed_len=28, max_mm_seed=1, max_mm_total=2, trim5=1, trim3=2)):
+        passes = [dict(lib=mi, min_len=0, max_len=25, seed_len=28, max_mm_seed=0, max_mm_total=2, trim5=0, trim3=0, poly_t=0),
+                  dict(dict(lib=li, min_len=0, max_len=255, trim5=0, trim3=0, poly_t=0), **pol)]
+        ref = model.fm_cascade(world.views, passes, world.words, world.lens, None)
+        names = [dict(p, lib=LIB_ORDER[p["lib"]]) for p in passes]
+        for sb in (1, 0):
+            res = run(engine, world, passes=names, seed_buckets=sb)
+            same_assignments(res, ref)
+            assert res.stats[1]["lds_mode"] == 8 and res.stats[1]["aligned"] > 300
+    engine.set_option("seed_buckets", 1)
+
+
 def test_short_dictionary_keys(world):
     """dict_key = 12: nothing takes the fallback; dict_key = 16 is the default tested above."""
     from mirge_amd.engine import Engine
