@@ -15,8 +15,12 @@ configs[2]; with N GPUs configs[3]) cut into contiguous shards with mirge_amd.di
 every rank generating only its own shard; `weak` = every rank annotates --reads reads of its own.
 
 Besides the contract keys the JSON line carries
-  roofline      dominant kernel by time; achieved = SURVEY.md 8d bytes (16 B per read offered to a
-                pass + 64 B per LF step) / HIP-event time; peak 8 TB/s
+  roofline      dominant kernel by time; achieved / frac = the STRICT SURVEY.md 8d reading: 16 B per
+                read a launch walks (each read once per launch, however many passes the launch runs)
+                + 64 B per LF step, / HIP-event time; peak 8 TB/s.  The round-2 reading (16 B per
+                read offered to each pass of the launch) rides along as `per_pass_offered`
+  legs          (N = 1, default workload) the `exact` (BASELINE configs[1]) and `a2i` (configs[4],
+                1-GPU form) workloads, each a run of this script with its own roofline and parity
   cpu_baseline  the oracle's CPU port on a bounded sample (kind "port"), or the reference-shaped
                 bowtie cascade when a real bowtie 1 is on the box (kind "reference")
   parity        what was compared with what before any number was printed
@@ -47,6 +51,17 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def kernels_sha16():
+    """Hash of the device sources: tells whether profiles/traffic.json was collected on this tree's kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mirge_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def survey_bytes(processed, steps):
     """16 B of streaming I/O per read offered to a pass (8 B packed read + 4 B count
     in + 4 B assignment out) + 64 B per LF step (two rank queries on the canonical 32-byte block)."""
@@ -75,10 +90,14 @@ def kernel_name(W, table_row, s, n_bases):
         "true" if n_bases <= 190000 else "false")
 
 
-def launch_table(st, per_pass_ms, table, index, W):
-    """One entry per kernel launch of the last step (a fused launch covers several passes)."""
+def launch_table(st, per_pass_ms, table, index, W, n_reads=0):
+    """One entry per kernel launch of the last step (a fused launch covers several passes).
+    `walked` = reads on the launch's input list = the batch minus what earlier passes claimed."""
     launches = []
+    claimed_before = 0
     for i, s in enumerate(st):
+        claimed_here = claimed_before
+        claimed_before += s["aligned"]
         skipped = s["processed"] == 0 and s["lds_bytes"] == 0 and per_pass_ms[i] < 0.05 and i + 1 < len(st) \
             and s["lds_mode"] not in (4, 8)
         if skipped:
@@ -87,6 +106,7 @@ def launch_table(st, per_pass_ms, table, index, W):
             L = launches[-1]
         else:
             L = dict(first=i, passes=[], ms=0.0, processed=0, steps=0, ext=0.0, n=max(1, s.get("n_launches", 1)),
+                     walked=max(0, n_reads - claimed_here),
                      kernel=kernel_name(W, table[i], s, index[table[i][0]].info.n_bases))
             launches.append(L)
         L["passes"].append(i)
@@ -115,11 +135,14 @@ def main():
     ap.add_argument("--samples", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=100_000_000,
                     help="reads of rank 0's shard the CPU port re-annotates (baseline + parity gate)")
-    ap.add_argument("--scan-sample", type=int, default=2000,
-                    help="distinct reads re-annotated by exhaustive scan of the library texts (no index at all)")
+    ap.add_argument("--scan-sample", type=int, default=4000,
+                    help="distinct reads re-annotated by exhaustive scan of the library texts (no index at all), "
+                         "split evenly over the claiming passes and the unclaimed reads")
     ap.add_argument("--bowtie-sample", type=int, default=100_000, help="reads for the bowtie probe, if bowtie exists")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the e2e and collapsed legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the e2e and collapsed legs (and the workload legs)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the exact / a2i child runs of the default workload")
+    ap.add_argument("--legs-reads", type=int, default=None, help="reads of each leg (default: the workloads' own sizes)")
     ap.add_argument("--wstop", type=int, default=None)
     ap.add_argument("--no-ftab", action="store_true")
     ap.add_argument("--sorted", action="store_true",
@@ -267,18 +290,21 @@ def main():
         return
 
     # ---- roofline of the dominant kernel (by instantiation, as rocprofv3 names it) ----
-    launches = launch_table(st, per_pass_ms, table, index, rs.W)
+    launches = launch_table(st, per_pass_ms, table, index, rs.W, n_reads)
     by_kernel = {}
     for L in launches:
-        g = by_kernel.setdefault(L["kernel"], dict(ms=0.0, sbytes=0.0, ext=0.0, launches=0, passes=[], processed=0))
+        g = by_kernel.setdefault(L["kernel"], dict(ms=0.0, sbytes=0.0, strict=0.0, ext=0.0, launches=0, passes=[], processed=0, walked=0))
         g["ms"] += L["ms"]
         g["sbytes"] += survey_bytes(L["processed"], L["steps"])
+        g["strict"] += survey_bytes(L["walked"], L["steps"])
         g["ext"] += L["ext"]
         g["launches"] += L["n"]
         g["passes"] += L["passes"]
         g["processed"] += L["processed"]
+        g["walked"] += L["walked"]
     dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
-    achieved = dom["sbytes"] / max(dom["ms"], 1e-9) / 1e6
+    achieved = dom["strict"] / max(dom["ms"], 1e-9) / 1e6
+    achieved_offered = dom["sbytes"] / max(dom["ms"], 1e-9) / 1e6
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -287,26 +313,40 @@ def main():
             ent = tj.get(wl, {}).get(dom_name)
             if ent and ent.get("reads_per_gpu") == n_reads:
                 traffic = ent["hbm_bytes_per_launch"]
-                traffic_src = dict(file="profiles/traffic.json", collected_at=tj.get("_meta", {}).get("git_head"),
+                meta = tj.get("_meta", {})
+                traffic_src = dict(file="profiles/traffic.json", collected_at=meta.get("git_head"),
+                                   kernels_sha16=meta.get("kernels_sha16"), tree_kernels_sha16=kernels_sha16(),
+                                   stale=meta.get("kernels_sha16") != kernels_sha16(),
                                    fetch_bytes_raw=ent.get("fetch_bytes_raw"),
                                    fetch_bytes_doubled=ent.get("fetch_bytes_doubled"),
                                    write_bytes=ent.get("write_bytes"), applies=ent.get("applies"))
         except Exception:
             traffic = None
-    whole_bytes = sum(survey_bytes(s["processed"], s["steps"]) for s in st)
+    whole_strict = 16.0 * n_reads + 64.0 * sum(s["steps"] for s in st)
+    whole_offered = sum(survey_bytes(s["processed"], s["steps"]) for s in st)
     roofline = dict(
         bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src, kernel=dom_name,
         launches_per_step=dom["launches"], passes=dom["passes"], avg_launch_ms=round(dom["ms"] / dom["launches"], 4),
-        algorithmic_bytes_per_launch=int(dom["sbytes"] / dom["launches"]),
-        formula="SURVEY.md 8d: 16 B x reads offered to each cascade pass the launch runs + 64 B x LF steps",
-        compulsory_floor_ms=round(16.0 * dom["processed"] / dom["launches"] / (HBM_ACHIEVABLE_GBS * 1e6), 4),
+        algorithmic_bytes_per_launch=int(dom["strict"] / dom["launches"]),
+        accounting="per_read_strict",
+        formula="SURVEY.md 8d, strict: 16 B x reads a launch walks (each read once per launch) + 64 B x LF steps",
+        per_pass_offered=dict(
+            achieved=round(achieved_offered, 1), frac=round(achieved_offered / HBM_PEAK_GBS, 4),
+            algorithmic_bytes_per_launch=int(dom["sbytes"] / dom["launches"]),
+            formula="round 2's reading: 16 B x reads offered to EACH cascade pass the launch runs + 64 B x LF steps"),
+        compulsory_floor_ms=round(16.0 * dom["walked"] / dom["launches"] / (HBM_ACHIEVABLE_GBS * 1e6), 4),
         achieved_extended=round(dom["ext"] / max(dom["ms"], 1e-9) / 1e6, 1),
-        extended_formula="+ 8 B per jump-table load + 16 B per verified candidate (most of them served on chip "
-                         "or by L2: a rate, not HBM traffic)",
-        whole_step=dict(algorithmic_bytes=int(whole_bytes), achieved=round(whole_bytes / (ms_per_step * 1e6), 1),
-                        frac=round(whole_bytes / (ms_per_step * 1e6) / HBM_PEAK_GBS, 4),
-                        compulsory_floor_ms=round(sum(16.0 * s["processed"] for s in st) / (HBM_ACHIEVABLE_GBS * 1e6), 3)))
+        extended_formula="per_pass_offered + 8 B per jump-table / slot load + 16 B per verified candidate (most of them "
+                         "served on chip or by L2: a rate, not HBM traffic)",
+        whole_step=dict(algorithmic_bytes=int(whole_strict), achieved=round(whole_strict / (ms_per_step * 1e6), 1),
+                        frac=round(whole_strict / (ms_per_step * 1e6) / HBM_PEAK_GBS, 4),
+                        frac_per_pass_offered=round(whole_offered / (ms_per_step * 1e6) / HBM_PEAK_GBS, 4),
+                        compulsory_floor_ms=round(16.0 * n_reads / (HBM_ACHIEVABLE_GBS * 1e6), 3)),
+        per_launch=[dict(kernel=L["kernel"].replace("mrg::", ""), passes=L["passes"], ms=round(L["ms"], 4), reads_walked=L["walked"],
+                         frac_strict=round(survey_bytes(L["walked"], L["steps"]) / max(L["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
+                         frac_per_pass_offered=round(survey_bytes(L["processed"], L["steps"]) / max(L["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4))
+                    for L in launches])
     passes_report = []
     for i, s in enumerate(st):
         L = next((x for x in launches if i in x["passes"]), None)
@@ -355,23 +395,35 @@ def main():
             parity["edit_tally"] = "substitution counts per (miRNA, position, type, sample) identical on all %d " \
                                    "reads (numpy restatement, %.1f s)" % (n_reads, time.perf_counter() - t1)
 
-        # -- independent of the index: exhaustive scan of the library TEXTS on a sample of distinct reads
-        if args.scan_sample > 0 and wl != "exact":
+        # -- independent of the index: exhaustive scan of the library TEXTS on distinct reads sampled PER
+        # CLAIMING PASS (and among the unclaimed), so that every library -- also the HBM-served ones that
+        # claim a few percent of the reads -- gets hundreds of positive checks at full size
+        if args.scan_sample > 0:
             from oracle import cascade as ocascade
             rng = np.random.default_rng(99)
-            pick = rng.choice(n_reads, size=min(n_reads, 4 * args.scan_sample), replace=False)
-            seqs = pack.unpack_reads(np.ascontiguousarray(words[:, pick]), lens[pick], None)
-            first = {}
-            for j, sq in zip(pick, seqs):
-                first.setdefault(sq, int(j))
-                if len(first) >= args.scan_sample:
-                    break
+            strata = [-1] + list(range(n_pass))
+            per = max(1, args.scan_sample // len(strata))
+            first, by_stratum = {}, {}
+            for v in strata:
+                cand = np.nonzero(got[0] == v)[0]
+                if cand.size == 0:
+                    continue
+                pick = rng.choice(cand, size=min(cand.size, 4 * per), replace=False)
+                seqs = pack.unpack_reads(np.ascontiguousarray(words[:, pick]), lens[pick], None)
+                k = 0
+                for j, sq in zip(pick, seqs):
+                    if sq not in first:
+                        first[sq] = int(j)
+                        k += 1
+                        if k >= per:
+                            break
+                by_stratum[v] = k
             t1 = time.perf_counter()
             olibs = {k: model.Library(*libs.libs[k]) for k in keys}
             seq_dic = {sq: ocascade.new_seq_record(sq, 1) for sq in first}
             log_dic = {"quantStats": [{}], "annotStats": []}
             align = {}
-            ocascade.run_annotation_pipeline(seq_dic, olibs, log_dic, align_dic=align)
+            ocascade.run_annotation_pipeline(seq_dic, olibs, log_dic, align_dic=align, n_passes=n_pass)
             bad = 0
             for sq, j in first.items():
                 a = align.get(sq)
@@ -379,9 +431,11 @@ def main():
                 bad += mine != (tuple(a) if a is not None else (-1, -1, -1, 0))
             if bad:
                 raise SystemExit("PARITY FAILURE: %d of %d sampled reads differ from the exhaustive scan" % (bad, len(first)))
-            parity["exhaustive_scan"] = "claiming pass, entry, offset and mismatches identical on %d distinct sampled " \
-                                        "reads against the full-size library texts (oracle/bowtie_model.c: no index, " \
-                                        "%.1f s on %d threads)" % (len(first), time.perf_counter() - t1, cores)
+            parity["exhaustive_scan"] = "claiming pass, entry, offset and mismatches identical on %d distinct reads sampled per " \
+                                        "claiming pass (%s; -1 = unclaimed) against the full-size library texts " \
+                                        "(oracle/bowtie_model.c: no index, %.1f s on %d threads)" % (
+                                            len(first), ", ".join("%d: %d" % kv for kv in sorted(by_stratum.items())),
+                                            time.perf_counter() - t1, cores)
 
         # -- a real bowtie 1, if this box has one: the reference's own command lines
         from oracle import bowtie_probe
@@ -430,6 +484,40 @@ def main():
             except Exception as e:
                 extras["collapsed"] = dict(error=repr(e))
 
+    # ---- legs (N = 1, headline workload): the other single-GPU configurations of BASELINE.json, each a
+    # child run of this script with its own parity gates, roofline and CPU baseline ----
+    legs = {}
+    if wl == "cascade" and world == 1 and not args.no_extras and not args.no_legs:
+        import subprocess
+        del rs
+        torch.cuda.empty_cache()
+        for leg, leg_args in (("exact", ["--steps", "20", "--warmup", "2"]), ("a2i", ["--steps", "5", "--warmup", "1"])):
+            t1 = time.perf_counter()
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", leg, "--no-extras", "--no-legs",
+                   "--scale", str(args.scale)] + leg_args
+            for kv in args.opt:
+                cmd += ["--opt", kv]
+            if args.legs_reads:
+                cmd += ["--reads", str(args.legs_reads), "--cpu-sample", str(args.legs_reads), "--scan-sample", str(args.scan_sample)]
+            try:
+                cp = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+            except subprocess.TimeoutExpired:
+                legs[leg] = dict(error="timed out")
+                continue
+            if cp.returncode != 0:
+                tail = (cp.stderr or "").strip().splitlines()[-1:] or ["?"]
+                if "PARITY FAILURE" in (cp.stderr or ""):
+                    raise SystemExit("leg %s: %s" % (leg, tail[0]))
+                legs[leg] = dict(error=tail[0])
+                continue
+            d = json.loads(cp.stdout.strip().splitlines()[-1])
+            legs[leg] = {k: d[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "cpu_baseline", "parity")}
+            legs[leg]["passes"] = [dict(lib=p_["lib"], ms=p_["ms"], kernel=p_["kernel"], processed=p_["processed"], aligned=p_["aligned"])
+                                   for p_ in d["passes"]]
+            legs[leg]["wall_s"] = round(time.perf_counter() - t1, 1)
+            log(rank, "leg %s: %.3f ms per step, roofline.frac %.4f (%.0f s)" % (leg, d["ms_per_step"], d["roofline"]["frac"],
+                                                                               time.perf_counter() - t1))
+
     what = {
         "cascade": "%d M x 22 nt reads, full 9-pass cascade over 8 synthetic human-sized libraries + isomiR/count tally "
                    "(BASELINE configs[2]%s)" % (n_total // 1_000_000,
@@ -465,6 +553,8 @@ def main():
         "passes": passes_report,
     }
     line.update(extras)
+    if legs:
+        line["legs"] = legs
     print(json.dumps(line))
 
 

@@ -94,12 +94,13 @@ def _bowtie(library, reads, seed_len, mm_seed, mm_total, trim5, trim3):
     return hits, len(reads), int((ref >= 0).sum())
 
 
-def run_annotation_pipeline(seq_dic, libraries, log_dic, spike_in=False, align_dic=None):
+def run_annotation_pipeline(seq_dic, libraries, log_dic, spike_in=False, align_dic=None, n_passes=None):
     """runAnnotationPipeline.py:566-707 without -gff / -trf side products.
 
     libraries: {key: oracle.model.Library} for the keys of PASS_TABLE.
-    align_dic (optional dict) receives seq -> (pass index, ref idx, pos0, mm)."""
-    n_pass = 10 if spike_in else 9
+    align_dic (optional dict) receives seq -> (pass index, ref idx, pos0, mm).
+    n_passes: only the first so many iterations of the loop (a truncated cascade)."""
+    n_pass = (10 if spike_in else 9) if n_passes is None else int(n_passes)
     for i in range(n_pass):
         key, length_filter, seed_len, mm_seed, mm_total, t5, t3 = PASS_TABLE[i]
         lib = libraries[key]

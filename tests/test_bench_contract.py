@@ -23,7 +23,7 @@ def run_bench(*extra):
 
 
 def test_headline_line_has_the_contract_keys():
-    d = run_bench()
+    d = run_bench("--no-legs")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -33,12 +33,24 @@ def test_headline_line_has_the_contract_keys():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["kernel"].startswith("mrg::")
-    # achieved follows SURVEY.md 8d and can be recomputed from the per-pass counters of the line
+    # achieved follows SURVEY.md 8d, strict reading (each read once per launch), and can be recomputed from
+    # the per-pass counters of the line; the per-pass-offered reading rides along
+    mine = [L for L in r["per_launch"] if "mrg::" + L["kernel"] == r["kernel"]]
+    assert sum(len(L["passes"]) for L in mine) == len(r["passes"])
+    strict = 0
+    for L in mine:
+        walked = 300000 - sum(p["aligned"] for p in d["passes"][:L["passes"][0]])
+        assert L["reads_walked"] == walked
+        strict += 16 * walked + 64 * sum(d["passes"][i]["steps"] for i in L["passes"])
+    assert abs(r["algorithmic_bytes_per_launch"] * r["launches_per_step"] - strict) <= r["launches_per_step"]
+    assert abs(r["achieved"] - strict / (r["avg_launch_ms"] * r["launches_per_step"]) / 1e6) < 0.02 * r["achieved"] + 1
     dom = [p for i, p in enumerate(d["passes"]) if i in r["passes"]]
     alg = sum(16 * p["processed"] + 64 * p["steps"] for p in dom)
-    assert abs(r["algorithmic_bytes_per_launch"] * r["launches_per_step"] - alg) <= r["launches_per_step"]
-    assert abs(r["achieved"] - alg / (r["avg_launch_ms"] * r["launches_per_step"]) / 1e6) < 0.02 * r["achieved"] + 1
-    assert r["compulsory_floor_ms"] > 0 and r["whole_step"]["algorithmic_bytes"] >= alg
+    po = r["per_pass_offered"]
+    assert abs(po["algorithmic_bytes_per_launch"] * r["launches_per_step"] - alg) <= r["launches_per_step"]
+    assert po["frac"] >= r["frac"] and r["accounting"] == "per_read_strict"
+    assert r["compulsory_floor_ms"] > 0 and r["whole_step"]["algorithmic_bytes"] == 16 * 300000 + 64 * sum(p["steps"] for p in d["passes"])
+    assert r["whole_step"]["frac_per_pass_offered"] >= r["whole_step"]["frac"]
     assert "identical" in d["parity"]["cpu_port"] and "identical" in d["parity"]["exhaustive_scan"]
     assert "bowtie" in d["parity"]
     assert "identical" in d["e2e"]["parity"] and d["e2e"]["value"] > 0 and d["e2e"]["h2d_ms"] > 0
@@ -46,6 +58,19 @@ def test_headline_line_has_the_contract_keys():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "identical" in c["parity"]
     assert len(d["passes"]) == 9 and d["passes"][0]["processed"] == 300000
+
+
+def test_default_run_carries_the_exact_and_a2i_legs():
+    """The default workload also runs BASELINE configs[1] and configs[4] (1-GPU form) as child runs
+    with their own roofline and parity gates."""
+    d = run_bench("--legs-reads", "200000", "--scan-sample", "300")
+    assert set(d["legs"]) == {"exact", "a2i"}
+    for leg in ("exact", "a2i"):
+        L = d["legs"][leg]
+        assert "error" not in L, L
+        assert L["value"] > 0 and L["roofline"]["frac"] > 0 and "identical" in L["parity"]["cpu_port"]
+        assert "identical" in L["parity"]["exhaustive_scan"] and L["config"]["reads_per_gpu"] == 200000
+    assert "identical" in d["legs"]["a2i"]["parity"]["edit_tally"]
 
 
 def test_secondary_workloads_run_and_agree_with_the_port():

@@ -475,6 +475,7 @@ def test_big_library_jump_tables(native_lib, oracle_lib):
     # ... and, by default, reads whose seed region is 15..19 bases (two pieces of 7..9 bases: 40..600
     # rows each in 4.8 Mbp) go through the three pairs of three 5-base anchors instead (10-base keys,
     # tables built on the device at first use; fused_kernel<W, true>)
+    eng.set_option("dict", 0)   # (the fused FM launches; the dictionary kernels of the one-word batch follow below)
     for pair_big in (5, 0, 6):
         eng.set_option("pair_big", pair_big)
         for ww, ll, nn in ((w, l, nm), (w1, l1, nm1)):
@@ -496,6 +497,17 @@ def test_big_library_jump_tables(native_lib, oracle_lib):
                     assert np.array_equal(plain[name], reff[name]), name
                 assert int(reff["stats"][1][3]) < int(plain["stats"][1][3])
     eng.set_option("pair_big", 5)
+    # the one-word batch through seed_kernel (dict = 1, the default): seed buckets for the 22..23-nt
+    # reads of this 4.8 Mbp library, the jump tables for the other lengths; boundary reads included
+    eng.set_option("dict", 1)
+    assert nm1 is None
+    resd = eng.cascade(ReadSet(w1, l1, None, None, device=eng.device), eng.make_passes([dict(p, lib="big") for p in fused_passes]))
+    plain = model.fm_cascade([ix.view()], fused_passes, w1, l1, None, wstop=DEFAULT_WSTOP, ftab=True)
+    assert [st["lds_mode"] for st in resd.stats][1:] == [8, 8]
+    for name, a in zip(("pass_id", "ref_id", "pos", "mm"), resd.to_host()):
+        assert np.array_equal(a, plain[name]), name
+    for i, st in enumerate(resd.stats):
+        assert (st["processed"], st["aligned"]) == (int(plain["stats"][i][0]), int(plain["stats"][i][1]))
 
 
 @pytest.mark.gpu
