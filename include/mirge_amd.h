@@ -194,6 +194,11 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);
 int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,
                         char *arch, uint32_t arch_cap);
+/* A context is used by one host thread at a time (calls on it are serialised by the caller).  It keeps
+ * one device scratch arena, grown on demand by mrg_collapse_run (40 B per raw read + 64 MB) and
+ * mrg_list_best_count and reused by later calls; this frees it (after synchronising the device), e.g.
+ * once the one collapse of a run is done. */
+int mrg_ctx_release_scratch(mrg_ctx *ctx);
 
 /* One alignment pass = one bowtie command line of RAP:577-599 / RAP:688. */
 typedef struct mrg_pass_cfg {
@@ -431,7 +436,9 @@ void mrg_fastq_free(mrg_fastq *fq);
  *   d_u_reads [words_per_read][cap], d_u_lens [cap], d_u_nmask ([..][cap] or NULL),
  *   d_quant [n_unique][n_samples] (uint32), d_len_hist [256][n_samples] (uint64, the
  *   reference's readLengthDic), *n_unique on the host.  cap >= n is always enough.
- * max_len is a hint (0 = unknown) that lets reads of <= 29 nt sort in one pass.
+ * max_len (0 = unknown) lets reads of <= 29 nt sort in one pass over fused keys; the call checks it
+ * against the batch (one pass over the lengths): a longer read sends the batch down the general
+ * path, a sample id >= n_samples is MRG_ERR_ARG.
  * Uniques come out ordered by (length, bases); the call synchronises `stream`.
  */
 int mrg_collapse_run(mrg_ctx *ctx, const uint64_t *d_reads, uint32_t words_per_read,

@@ -93,7 +93,10 @@ def resolve_samples(sample_args):
 
 def _launch_ranks(argv, n_gpus):
     """`--gpus N`: one child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE in its environment),
-    started before anything in this process has touched a GPU; the exit status is the worst child's."""
+    started before anything in this process has touched a GPU.  The children are polled: the first
+    one that fails (non-zero status, or killed by a signal) takes its siblings down with it -- they
+    would otherwise sit in a collective until the RCCL watchdog fires -- and the launcher returns
+    non-zero (128 + signal for a killed child)."""
     import socket
     import subprocess
     sock = socket.socket()
@@ -106,7 +109,29 @@ def _launch_ranks(argv, n_gpus):
                    MASTER_PORT=str(port), MIRGE_AMD_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, "-m", "mirge_amd"] + list(argv), env=env))
-    return max(p.wait() for p in procs)
+    status = 0
+    live = list(procs)
+    while live and status == 0:
+        time.sleep(0.2)
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0:
+                status = 128 - rc if rc < 0 else rc
+                break
+    if status != 0:
+        for p in live:
+            p.terminate()
+        deadline = time.time() + 10.0
+        for p in live:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    return status
 
 
 def annotate_main(args, engine_factory=None, materialize=False):
@@ -121,9 +146,12 @@ def annotate_main(args, engine_factory=None, materialize=False):
     import torch
     if engine_factory is None:
         from .engine import Engine as engine_factory
-    rank, local_rank, world = mdist.env_world()
+    # (RANK / WORLD_SIZE of a foreign launcher's environment do not make this a multi-rank run:
+    # only the children of `--gpus N` -- or a test that says so -- take part in a process group)
+    multi = os.environ.get("MIRGE_AMD_CHILD") == "1" or os.environ.get("MIRGE_AMD_DIST_BACKEND") is not None
+    rank, local_rank, world = mdist.env_world() if multi else (0, 0, 1)
     if world > 1:
-        mdist.init_process_group(os.environ.get("MIRGE_AMD_DIST_BACKEND", "nccl"))
+        mdist.init_process_group(os.environ.get("MIRGE_AMD_DIST_BACKEND", "nccl"), timeout_s=600)
     db = {"mirbase": "miRBase", "mirgenedb": "MirGeneDB"}.get(args.miRNA_database.lower())
     if db is None:
         _die("The value of parameter '-d' is invalid. Please check it")
@@ -207,75 +235,91 @@ def annotate_main(args, engine_factory=None, materialize=False):
 
     log_dic = {"quantStats": [], "annotStats": []}
     t0 = time.time()
-    # ---- ingest + global collapse on rank 0 (trim_file + quantReads, MAIN:346-372) ----
-    meta, urs, hist, long_counts = None, None, None, {}
+    # ---- ingest (trim_file, MAIN:346-369): every rank its own files (file i -> rank i mod world) ----
+    from concurrent.futures import ThreadPoolExecutor
+    mine = [i for i in range(len(raw)) if i % world == rank]
+    n_cpu = max(1, int(args.cpu))
+    n_jobs = max(1, min(len(mine), n_cpu))
+
+    def load_one(i):
+        t1 = time.time()
+        fq = ingest.load_fastq(os.path.abspath(raw[i]), adapter=args.adapter, threads=max(1, n_cpu // n_jobs))
+        return fq, time.time() - t1
+
     if rank == 0:
-        from concurrent.futures import ThreadPoolExecutor
-        n_cpu = max(1, int(args.cpu))
-        n_jobs = max(1, min(len(raw), n_cpu))
-
-        def load_one(i):
-            t1 = time.time()
-            fq = ingest.load_fastq(os.path.abspath(raw[i]), adapter=args.adapter, threads=max(1, n_cpu // n_jobs))
-            return fq, time.time() - t1
-
         for name in sample_list:
             print("Performing quantitation analysis of %s..." % name)
+    loaded = []
+    if mine:
         with ThreadPoolExecutor(max_workers=n_jobs) as pool:
-            loaded = list(pool.map(load_one, range(len(raw))))
-        W = max(fq["words"].shape[0] for fq, _ in loaded)
-        any_n = any(fq["nmask"] is not None for fq, _ in loaded)
-        for i, (fq, dt) in enumerate(loaded):
-            log_dic["quantStats"].append({"filename": sample_list[i], "totalReads": fq["total"],
-                                          "trimmedReads": fq["kept"], "cpuTime-trim": dt, "cpuTime-uniq": 0.0})
-            for r in fq["long_reads"]:   # beyond the packing limit: carried on the host, never aligned
-                long_counts.setdefault(r, [0] * S)[i] += 1
-        t1 = time.time()
-        n_raw = sum(fq["packed"] for fq, _ in loaded)
-        words = np.zeros((W, n_raw), dtype=np.uint64)
-        lens = np.empty(n_raw, dtype=np.uint8)
-        nmask = np.zeros((W, n_raw), dtype=np.uint64) if any_n else None
-        sample = np.empty(n_raw, dtype=np.uint16)
-        at = 0
-        for i, (fq, _) in enumerate(loaded):
-            m = fq["packed"]
-            words[:fq["words"].shape[0], at:at + m] = fq["words"]
-            lens[at:at + m] = fq["lens"]
-            if fq["nmask"] is not None:
-                nmask[:fq["nmask"].shape[0], at:at + m] = fq["nmask"]
-            sample[at:at + m] = i
-            at += m
-        max_len = max([fq["max_len"] for fq, _ in loaded] + [0])
-        del loaded
-        d_words = torch.from_numpy(words.view(np.int64)).to(dev)
-        d_lens = torch.from_numpy(lens).to(dev)
-        d_nmask = None if nmask is None else torch.from_numpy(nmask.view(np.int64)).to(dev)
-        d_sample = torch.from_numpy(sample.view(np.int16)).to(dev)
-        del words, lens, nmask, sample
+            loaded = list(pool.map(load_one, mine))
+    quant_stats, long_counts = {}, {}
+    for i, (fq, dt) in zip(mine, loaded):
+        quant_stats[i] = {"filename": sample_list[i], "totalReads": fq["total"], "trimmedReads": fq["kept"],
+                          "cpuTime-trim": dt, "cpuTime-uniq": 0.0}
+        for r in fq["long_reads"]:   # beyond the packing limit: carried on the host, never aligned
+            long_counts.setdefault(r, [0] * S)[i] += 1
+    t1 = time.time()
+    # the batch's shape must be the same on every rank: words per read, N mask or not, longest read
+    W, any_n, max_len = mdist.allreduce_max([max([fq["words"].shape[0] for fq, _ in loaded] + [1]),
+                                             int(any(fq["nmask"] is not None for fq, _ in loaded)),
+                                             max([fq["max_len"] for fq, _ in loaded] + [0])])
+    n_raw = sum(fq["packed"] for fq, _ in loaded)
+    words = np.zeros((W, n_raw), dtype=np.uint64)
+    lens = np.empty(n_raw, dtype=np.uint8)
+    nmask = np.zeros((W, n_raw), dtype=np.uint64) if any_n else None
+    sample = np.empty(n_raw, dtype=np.uint16)
+    at = 0
+    for i, (fq, _) in zip(mine, loaded):
+        m = fq["packed"]
+        words[:fq["words"].shape[0], at:at + m] = fq["words"]
+        lens[at:at + m] = fq["lens"]
+        if fq["nmask"] is not None:
+            nmask[:fq["nmask"].shape[0], at:at + m] = fq["nmask"]
+        sample[at:at + m] = i
+        at += m
+    del loaded
+    d_words = torch.from_numpy(words.view(np.int64)).to(dev)
+    d_lens = torch.from_numpy(lens).to(dev)
+    d_nmask = None if nmask is None else torch.from_numpy(nmask.view(np.int64)).to(dev)
+    d_sample = torch.from_numpy(sample.view(np.int16)).to(dev)
+    del words, lens, nmask, sample
+    if world > 1:
+        # ---- partition by sequence: one all-to-all puts every copy of a sequence on one
+        # rank, so the per-rank collapses below are disjoint and nothing is collapsed globally ----
+        dest = mdist.sequence_destination(d_words, d_lens, world)
+        got = mdist.exchange_by_destination(dest, [d_words.t().contiguous(), d_lens,
+                                                   None if d_nmask is None else d_nmask.t().contiguous(), d_sample])
+        d_words, d_lens, d_sample = got[0].t().contiguous(), got[1], got[3]
+        d_nmask = None if got[2] is None else got[2].t().contiguous()
+        del dest, got
+    # ---- quantReads (QNT:3-24) on this rank's sequences ----
+    if d_lens.numel():
         urs, hist = engine.collapse(d_words, d_lens, d_nmask, d_sample, S, max_len)
-        del d_words, d_lens, d_nmask, d_sample
-        for q in log_dic["quantStats"]:
-            q["cpuTime-uniq"] = (time.time() - t1) / S
-        meta = dict(U=urs.n, W=urs.W, has_n=urs.nmask is not None, max_len=int(max_len))
-    # ---- every rank gets the collapsed set, takes its contiguous shard ----
-    meta = mdist.broadcast_from_rank0(meta)
-    U, W = meta["U"], meta["W"]
-    if world > 1:
-        if rank != 0:
-            urs = ReadSet.from_device(torch.empty((W, U), dtype=torch.int64, device=dev),
-                                      torch.empty(U, dtype=torch.uint8, device=dev),
-                                      torch.empty((W, U), dtype=torch.int64, device=dev) if meta["has_n"] else None,
-                                      torch.empty((U, S), dtype=torch.int32, device=dev), 0, meta["max_len"] or 255)
-        for t in (urs.words, urs.lens, urs.nmask, urs.quant):
-            if t is not None:
-                mdist.broadcast_tensor(t)
-    lo, hi = mdist.shard_bounds(U, rank, world)
-    if world > 1:
-        shard = ReadSet.from_device(urs.words[:, lo:hi].contiguous(), urs.lens[lo:hi],
-                                    None if urs.nmask is None else urs.nmask[:, lo:hi].contiguous(),
-                                    urs.quant[lo:hi], 0, meta["max_len"] or 255)
     else:
-        shard = urs
+        urs = ReadSet.from_device(torch.empty((W, 0), dtype=torch.int64, device=dev), torch.empty(0, dtype=torch.uint8, device=dev),
+                                  torch.empty((W, 0), dtype=torch.int64, device=dev) if any_n else None,
+                                  torch.empty((0, S), dtype=torch.int32, device=dev), 0, max_len or 255)
+        hist = torch.zeros((256, S), dtype=torch.int64, device=dev)
+    del d_words, d_lens, d_nmask, d_sample
+    if hasattr(engine, "release_scratch"):
+        engine.release_scratch()   # the collapse arena (40 B per raw read) is not needed again
+    for q in quant_stats.values():
+        q["cpuTime-uniq"] = (time.time() - t1) / max(1, len(mine))
+    if world > 1:
+        torch.distributed.all_reduce(hist)   # readLengthDic is a sum over reads
+        boxes = mdist.gather_objects_to_rank0((quant_stats, long_counts))
+        if rank == 0:
+            quant_stats, long_counts = {}, {}
+            for qs, lc in boxes:
+                quant_stats.update(qs)
+                for seq, q in lc.items():
+                    row = long_counts.setdefault(seq, [0] * S)
+                    for i in range(S):
+                        row[i] += q[i]
+    if rank == 0:
+        log_dic["quantStats"] = [quant_stats[i] for i in range(len(raw))]
+    shard = urs
 
     if rank == 0:
         print("\nPerforming annotation for all of the collasped sequences...")
@@ -297,14 +341,31 @@ def annotate_main(args, engine_factory=None, materialize=False):
         print("Alignment to library %s exited with none-zero status.\n" % getattr(e, "library", "?"))
         print(str(e), file=sys.stderr)
         sys.exit(1)
-    pass_id = mdist.gather_shards(res.pass_id, U)
-    ref_id = mdist.gather_shards(res.ref_id, U)
-    pos = mdist.gather_shards(res.pos, U)
-    mm = mdist.gather_shards(res.mm, U)
+    # per-read arrays go to the rank that writes the tables, nowhere else
+    pass_id = mdist.gather_to_rank0(res.pass_id)
+    ref_id = mdist.gather_to_rank0(res.ref_id)
+    pos = mdist.gather_to_rank0(res.pos)
+    mm = mdist.gather_to_rank0(res.mm)
+    if world > 1:   # ... and so do the unique reads themselves (read-major for the transfer)
+        g_words = mdist.gather_to_rank0(urs.words.t().contiguous())
+        g_lens = mdist.gather_to_rank0(urs.lens)
+        g_nmask = None if urs.nmask is None else mdist.gather_to_rank0(urs.nmask.t().contiguous())
+        g_quant = mdist.gather_to_rank0(urs.quant)
     if rank != 0:
-        if world > 1:
-            torch.distributed.barrier()
+        mdist.barrier()
         return None
+    if world > 1:
+        h_words = np.ascontiguousarray(g_words.cpu().numpy().view(np.uint64).T)
+        h_lens = g_lens.cpu().numpy()
+        h_nmask = None if g_nmask is None else np.ascontiguousarray(g_nmask.cpu().numpy().view(np.uint64).T)
+        h_quant = g_quant.cpu().numpy().view(np.uint32)
+        del g_words, g_lens, g_nmask, g_quant
+    else:
+        h_words = urs.words.cpu().numpy().view(np.uint64)
+        h_lens = urs.lens.cpu().numpy()
+        h_nmask = None if urs.nmask is None else urs.nmask.cpu().numpy().view(np.uint64)
+        h_quant = urs.quant.cpu().numpy().view(np.uint32)
+    U = int(h_lens.size)
     wall = time.time() - t2
     print("All annotation cycles completed (%.2f sec).\n" % wall)
 
@@ -325,10 +386,6 @@ def annotate_main(args, engine_factory=None, materialize=False):
                 log_dic["quantStats"][i]["remReads"] += q[i]
     annotate.miRNAmerge(merge_file, sample_list, mir_dic, mirna_fa, name_seq)
     annotate.filter(mir_dic, sample_list, log_dic, args.canoRatio)
-    h_words = urs.words.cpu().numpy().view(np.uint64)
-    h_lens = urs.lens.cpu().numpy()
-    h_nmask = None if urs.nmask is None else urs.nmask.cpu().numpy().view(np.uint64)
-    h_quant = urs.quant.cpu().numpy().view(np.uint32)
     h_pass, h_ref, h_pos, h_mm = (t.cpu().numpy() for t in (pass_id, ref_id, pos, mm))
     hist_h = hist.cpu().numpy()
     read_len_dic = {int(L): [int(x) for x in hist_h[L]] for L in np.nonzero(hist_h.sum(axis=1))[0]}
@@ -384,8 +441,7 @@ def annotate_main(args, engine_factory=None, materialize=False):
         a_to_i_report(outdir, sample_list, log_dic, sub, mir_dic, name_seq, merged_name, removed_ai, genome)
     print("Summary Complete (%.2f sec)" % (time.time() - t3))
     print("Annotation of miRge2.0 Completed (%.2f sec)" % (time.time() - t0))
-    if world > 1:
-        torch.distributed.barrier()
+    mdist.barrier()
     out = dict(outdir=outdir, mirDic=mir_dic, logDic=log_dic, readLengthDic=read_len_dic, n_unique=U + len(long_counts))
     if materialize:
         seq_dic = columnar.full_seq_dic(h_words, h_lens, h_nmask, h_quant, h_pass, h_ref, npp, spike)

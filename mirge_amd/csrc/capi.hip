@@ -648,6 +648,16 @@ int mrg_ctx_device_info(const mrg_ctx* ctx, int32_t* n_cu, uint64_t* hbm_bytes, 
   return MRG_OK;
 }
 
+int mrg_ctx_release_scratch(mrg_ctx* ctx) {
+  if (!ctx) return fail(MRG_ERR_ARG, "mrg_ctx_release_scratch: null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  if (ctx->scratch) HIP_TRY(hipFree(ctx->scratch));
+  ctx->scratch = nullptr;
+  ctx->scratch_bytes = 0;
+  return MRG_OK;
+}
+
 // --------------------------------------------------------------- cascade
 // workspace: [idx A][idx B]  (each n + kListSlack u32: segmented survivor lists; a producer
 //            workgroup's segment holds every read of its chunks, 256, 1024 or 4096 reads each)
@@ -1976,6 +1986,7 @@ int mrg_collapse_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   // scratch, grown on demand and kept: per-call hipMalloc / hipFree of gigabytes costs milliseconds
   const uint64_t want = n * 40ull + (64ull << 20);
   if (ctx->scratch_bytes < want) {
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // (nothing queued may still use the old arena)
     (void)hipFree(ctx->scratch);
     ctx->scratch = nullptr;
     ctx->scratch_bytes = 0;
@@ -1988,6 +1999,8 @@ int mrg_collapse_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   if (e == hipErrorInvalidValue)
     return fail(MRG_ERR_ARG, "mrg_collapse_run: cap %llu is smaller than the number of unique reads",
                 (unsigned long long)cap);
+  if (e == hipErrorInvalidDevicePointer)
+    return fail(MRG_ERR_ARG, "mrg_collapse_run: a sample id is not below n_samples (%u)", n_samples);
   if (e != hipSuccess) return fail(MRG_ERR_HIP, "mrg_collapse_run: %s", hipGetErrorString(e));
   *n_unique = nu;
   return MRG_OK;

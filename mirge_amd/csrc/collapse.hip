@@ -215,6 +215,26 @@ struct DevBuf {
     if (e_ != hipSuccess) return e_;   \
   } while (0)
 
+// longest read and largest sample id of the batch: the fused sort keys put the length right above
+// 2 max_len base bits and the sample id below them, so both bounds must HOLD, not be hoped for
+__global__ void __launch_bounds__(256) bounds_kernel(const uint8_t* __restrict__ lens, const uint16_t* __restrict__ sample, uint32_t n,
+                                                     uint32_t* __restrict__ out) {
+  uint32_t ml = 0, ms = 0;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    ml = max(ml, (uint32_t)lens[i]);
+    if (sample) ms = max(ms, (uint32_t)sample[i]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    ml = max(ml, (uint32_t)__shfl_down(ml, off, 64));
+    ms = max(ms, (uint32_t)__shfl_down(ms, off, 64));
+  }
+  if ((threadIdx.x & 63u) == 0u) {
+    atomicMax(&out[0], ml);
+    atomicMax(&out[1], ms);
+  }
+}
+
 }  // namespace
 
 hipError_t collapse_reads(const uint64_t* d_reads, uint32_t W, const uint8_t* d_lens,
@@ -234,6 +254,20 @@ hipError_t collapse_reads(const uint64_t* d_reads, uint32_t W, const uint8_t* d_
   CK(hipMemsetAsync(d_len_hist, 0, (size_t)256 * n_samples * 8, stream));
   if (n == 0) return hipStreamSynchronize(stream);
   const uint32_t grid = (n + kT - 1) / kT;
+  {
+    // the caller's max_len is only a hint: a read longer than it would overlap the length bits of a
+    // fused key and merge or split sequences silently.  One pass over the lengths (and sample ids):
+    // an out-of-range sample id is an error, an exceeded max_len sends the batch down the general path.
+    DevBuf b;
+    CK(b.alloc(8));
+    CK(hipMemsetAsync(b.p, 0, 8, stream));
+    hipLaunchKernelGGL(bounds_kernel, dim3(min(grid, 2048u)), dim3(256), 0, stream, d_lens, n_samples > 1 ? d_sample : nullptr, n, b.as<uint32_t>());
+    uint32_t h[2] = {0, 0};
+    CK(hipMemcpyAsync(h, b.p, 8, hipMemcpyDeviceToHost, stream));
+    CK(hipStreamSynchronize(stream));
+    if (n_samples > 1 && h[1] >= n_samples) return hipErrorInvalidDevicePointer;  // (mapped to MRG_ERR_ARG by the C-ABI)
+    if (max_len && h[0] > max_len) max_len = 0;
+  }
   if (W == 1 && max_len > 0 && max_len <= 29 && !d_nmask && !(d_sample && n_samples > 1) && n_samples == 1) {
     // One sample, reads of one word without N: the packed read + its length IS the sort key and the
     // unique read; nothing has to be carried through the sort or gathered afterwards.  Sort the

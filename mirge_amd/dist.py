@@ -1,8 +1,14 @@
-"""Multi-GPU: shard the globally collapsed read set, replicate the libraries,
-all-reduce ONE fused count vector.
+"""Multi-GPU: partition the reads by SEQUENCE, replicate the libraries, all-reduce ONE fused count
+vector.
 
-The cascade outcome of a read depends only on that read, so ranks never
-exchange reads.  The only collective is a sum over
+The cascade outcome of a read depends only on that read.  Two ways to give every rank its own
+reads: contiguous shards of a globally collapsed set (`shard_bounds`: bench.py, whose synthetic
+read set exists on every rank), or -- the command line, whose reads start in FASTQ files -- every
+rank ingests its own files and the raw reads are hash-partitioned by sequence with one all-to-all
+(`sequence_destination`, `exchange_by_destination`): all copies of a sequence land on one rank, the
+per-rank collapses are disjoint, so trimmedUniq (summarize.py:37) and readsProcessed / readsAligned
+(runAnnotationPipeline.py:648-650) add up without a global collapse and no rank ever holds the whole
+read set.  After that the only collective of the data path is a sum over
 [mir_quant | mir_iscan | category totals | trimmedUniq | per-pass processed,aligned]
 (int64, a few tens of KB): latency-bound on xGMI, so it is one all-reduce, not
 one per table.  `filter` (filter.py:7-13) is non-linear and must run on the
@@ -16,16 +22,40 @@ def env_world():
         int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init_process_group(backend=None):
-    """One process per GPU; `nccl` is RCCL on ROCm, `gloo` for the CPU tests."""
+def init_process_group(backend=None, timeout_s=None):
+    """One process per GPU; `nccl` is RCCL on ROCm, `gloo` for the CPU tests.  With nccl the rank's
+    GPU (LOCAL_RANK) is made torch's current device first and bound to the process group, so that
+    no collective can ever pick device 0 on every rank."""
     import torch.distributed as dist
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        # the caller has already made LOCAL_RANK its current device (barrier() uses it)
-        dist.init_process_group(backend=backend or "nccl", rank=rank, world_size=world)
+        backend = backend or "nccl"
+        kw = {}
+        if timeout_s:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
+        if backend == "nccl":
+            import torch
+            n_dev = torch.cuda.device_count()
+            dev = local_rank % max(n_dev, 1) if os.environ.get("MRG_BENCH_SHARE_GPU") == "1" else local_rank
+            torch.cuda.set_device(dev)
+            kw["device_id"] = torch.device("cuda", dev)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
+
+
+def barrier():
+    """Barrier on the rank's own device (no-op for one process)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    if dist.get_backend() == "nccl":
+        import torch
+        dist.barrier(device_ids=[torch.cuda.current_device()])
+    else:
+        dist.barrier()
 
 
 def shard_bounds(n, rank, world):
@@ -92,3 +122,109 @@ def gather_shards(t, n_total):
         lo, hi = shard_bounds(n_total, r, world)
         out[lo:hi] = parts[r][:hi - lo]
     return out
+
+
+# ---------------------------------------------------------------------------
+# partition by sequence (the command line's multi-GPU data path)
+# ---------------------------------------------------------------------------
+def _active():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def sequence_destination(words, lens, world):
+    """Rank that owns each read: a hash of (length, packed bases) modulo the world size, computed
+    where the reads live (words int64 [W, n], lens uint8 [n]).  Identical sequences -- whichever
+    rank ingested them -- get the same destination; an N mask need not enter the hash."""
+    import torch
+    h = lens.to(torch.int64) * -7046029254386353131           # 0x9E3779B97F4A7C15 as int64
+    for w in range(words.shape[0]):
+        x = words[w]
+        x = (x ^ (x >> 31)) * (-4658895280553007687 + 2 * w)   # odd multipliers, wrap-around arithmetic
+        h = (h ^ x) * -7046029254386353131
+        h = h ^ (h >> 29)
+    return ((h >> 17) & 0x7FFFFFFF) % int(world)
+
+
+def exchange_by_destination(dest, tensors):
+    """One all-to-all per tensor: row i of every tensor (first dimension = reads) goes to rank
+    dest[i].  Returns the rows this rank received, grouped by sending rank (rows of one sender keep
+    their order).  No-op for one process."""
+    import torch
+    import torch.distributed as dist
+    if not _active():
+        return list(tensors)
+    world = dist.get_world_size()
+    order = torch.argsort(dest, stable=True)
+    send_counts = torch.bincount(dest, minlength=world).to(torch.int64)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts)
+    sc, rc = [int(x) for x in send_counts.cpu()], [int(x) for x in recv_counts.cpu()]
+    out = []
+    for t in tensors:
+        if t is None:
+            out.append(None)
+            continue
+        # (as bytes: neither RCCL nor gloo moves every integer width -- int16 sample ids, for one)
+        k = t.element_size()
+        for d in t.shape[1:]:
+            k *= int(d)
+        src = t[order].contiguous().reshape(-1).view(torch.uint8)
+        dst = torch.empty(sum(rc) * k, dtype=torch.uint8, device=t.device)
+        dist.all_to_all_single(dst, src, [c * k for c in rc], [c * k for c in sc])
+        out.append(dst.view(t.dtype).reshape((sum(rc),) + tuple(t.shape[1:])))
+    return out
+
+
+def gather_to_rank0(t):
+    """Per-read arrays for the table writers: rank 0 gets the concatenation (in rank order) of every
+    rank's tensor along the first dimension, the other ranks get None.  Point-to-point sends into
+    place: nothing is replicated on ranks that do not write (no all_gather)."""
+    import torch
+    import torch.distributed as dist
+    if not _active():
+        return t
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n_local = torch.tensor([int(t.shape[0])], dtype=torch.int64, device=t.device)
+    sizes = [torch.empty_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local)
+    sizes = [int(x.item()) for x in sizes]
+    if rank != 0:
+        if sizes[rank]:
+            dist.send(t.contiguous().reshape(-1).view(torch.uint8), dst=0)   # (bytes: see exchange_by_destination)
+        return None
+    out = torch.empty((sum(sizes),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    out[:sizes[0]] = t
+    at = sizes[0]
+    row_bytes = t.element_size()
+    for d in t.shape[1:]:
+        row_bytes *= int(d)
+    for r in range(1, world):
+        if sizes[r]:
+            buf = torch.empty(sizes[r] * row_bytes, dtype=torch.uint8, device=t.device)
+            dist.recv(buf, src=r)
+            out[at:at + sizes[r]] = buf.view(t.dtype).reshape((sizes[r],) + tuple(t.shape[1:]))
+        at += sizes[r]
+    return out
+
+
+def gather_objects_to_rank0(obj):
+    """Small picklable per-rank objects (ingest statistics, over-long reads): list on rank 0, None elsewhere."""
+    import torch.distributed as dist
+    if not _active():
+        return [obj]
+    box = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
+    dist.gather_object(obj, box, dst=0)
+    return box
+
+
+def allreduce_max(values):
+    """Element-wise maximum of a short list of ints over all ranks."""
+    import torch
+    import torch.distributed as dist
+    if not _active():
+        return list(values)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor(list(values), dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [int(x) for x in t.cpu()]

@@ -105,12 +105,53 @@ def _cli_worker(rank, world_size, port, argv, out_path):
     torch.distributed.destroy_process_group()
 
 
-def test_cli_two_ranks_write_the_same_tables_as_one(native_lib, oracle_lib, tmp_path):
-    """`annotate --gpus 2` as its children run it (here: gloo, CPU tensors, the oracle's CPU port in
-    place of the GPU engine): rank 0 ingests and collapses, both ranks annotate their shard of the
-    collapsed set, the count vector is all-reduced, the assignments gathered, and rank 0 writes --
-    every table identical to the single-process run (filter after the reduce, trimmedUniq and the
-    per-pass counters not double-counted)."""
+def _exchange_worker(rank, world_size, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world_size),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from mirge_amd import dist as mdist
+    mdist.init_process_group("gloo")
+    rng = np.random.default_rng(100 + rank)
+    n = 500 + 37 * rank
+    # a pool of 300 sequences shared by all ranks: every rank holds copies of most of them
+    pool = np.random.default_rng(1).integers(0, 2 ** 40, (2, 300), dtype=np.int64)
+    pick = rng.integers(0, 300, n)
+    words = torch.from_numpy(np.ascontiguousarray(pool[:, pick]))
+    lens = torch.from_numpy((20 + pick % 5).astype(np.uint8))
+    tag = torch.from_numpy((rank * 10000 + np.arange(n)).astype(np.int32))
+    dest = mdist.sequence_destination(words, lens, world_size)
+    got_w, got_l, got_none, got_tag = mdist.exchange_by_destination(dest, [words.t().contiguous(), lens, None, tag])
+    assert got_none is None and got_w.shape[0] == got_l.shape[0] == got_tag.shape[0]
+    # everything this rank received is its own by the same rule, wherever it came from
+    assert bool((mdist.sequence_destination(got_w.t().contiguous(), got_l, world_size) == rank).all())
+    whole = mdist.gather_to_rank0(got_tag)
+    assert (whole is None) == (rank != 0)
+    objs = mdist.gather_objects_to_rank0({"rank": rank, "n": n})
+    assert mdist.allreduce_max([rank, 7 - rank]) == [world_size - 1, 7]
+    if rank == 0:
+        assert sorted(o["rank"] for o in objs) == list(range(world_size))
+        np.save(os.path.join(out_dir, "tags.npy"), whole.numpy())
+        np.save(os.path.join(out_dir, "n.npy"), np.array([o["n"] for o in objs]))
+    torch.distributed.destroy_process_group()
+
+
+def test_partition_by_sequence_moves_every_read_exactly_once(tmp_path):
+    """sequence_destination + exchange_by_destination + gather_to_rank0 on three gloo ranks: no read
+    lost or duplicated, copies of one sequence end on one rank (asserted inside the workers)."""
+    mp.spawn(_exchange_worker, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    tags, ns = np.load(str(tmp_path / "tags.npy")), np.load(str(tmp_path / "n.npy"))
+    want = np.concatenate([r * 10000 + np.arange(n) for r, n in enumerate(ns)])
+    assert np.array_equal(np.sort(tags), np.sort(want))
+
+
+@pytest.mark.parametrize("world_size", [2, 3])
+def test_cli_ranks_write_the_same_tables_as_one(native_lib, oracle_lib, tmp_path, world_size):
+    """`annotate --gpus N` as its children run it (here: gloo, CPU tensors, the oracle's CPU port in
+    place of the GPU engine): every rank ingests its own files (with three ranks and two files one
+    rank ingests nothing), the raw reads are partitioned by sequence with one all-to-all -- the same
+    sequences occur in both files -- every rank collapses and annotates its own sequences, the count
+    vector is all-reduced, the per-read arrays go to rank 0 only, and rank 0 writes: every table
+    identical to the single-process run (filter after the reduce, trimmedUniq and the per-pass
+    counters not double-counted)."""
     from mirge_amd import cli, synth
     from tests.fake_engine import OracleEngine
     from tests.golden.make_golden import SHAPES
@@ -131,7 +172,8 @@ def test_cli_two_ranks_write_the_same_tables_as_one(native_lib, oracle_lib, tmp_
     one = cli.annotate_main(cli.build_parser().parse_args(base + ["-o", str(tmp_path / "one")]),
                             engine_factory=OracleEngine)
     marker = str(tmp_path / "outdir.txt")
-    mp.spawn(_cli_worker, args=(2, _free_port(), base + ["-o", str(tmp_path / "two")], marker), nprocs=2, join=True)
+    mp.spawn(_cli_worker, args=(world_size, _free_port(), base + ["-o", str(tmp_path / "two")], marker), nprocs=world_size,
+             join=True)
     two_dir = open(marker).read()
     files = sorted(os.listdir(one["outdir"]))
     assert files == sorted(os.listdir(two_dir)) and "mapped.csv" in files and "isomirs.csv" in files
