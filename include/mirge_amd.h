@@ -73,12 +73,11 @@ int mrg_index_build_fasta(const char *fasta_path, mrg_index **out);
 /* Build from the reference's own library file: `<prefix>.1.ebwt` (bowtie 1), the only form in which
  * miRge.Libs ships its libraries (MAIN:262-281).  Entry names and sequences are recovered from
  * the BWT as `bowtie-inspect` does (SUM:6, RAP:610-611,630, W2C:649) and indexed like a FASTA
- * file.  The format is restated from bowtie 1.1.x without a bowtie-built sample at hand:
- * validated by round trip with mrg_ebwt_write_for_tests only. */
+ * file.  EXPERIMENTAL: the format is restated from bowtie 1.1.x without a bowtie-built sample at
+ * hand and validated by round trip with an independent test writer only (tests/helpers/); the
+ * reader therefore re-derives every redundant field of the file (side occurrence counts, fchr,
+ * ftab order, fragment table) from the BWT it decoded and fails with MRG_ERR_IO on any mismatch. */
 int mrg_index_build_ebwt(const char *prefix, mrg_index **out);
-/* TEST SUPPORT: writes `<prefix>.1.ebwt` holding the index's entries so that the reader above can
- * be round-tripped; occurrence counts and ftab are zero-filled (a real bowtie cannot search it). */
-int mrg_ebwt_write_for_tests(const mrg_index *ix, const char *prefix, int32_t ftab_chars);
 int mrg_index_save(const mrg_index *ix, const char *path);
 int mrg_index_load(const char *path, mrg_index **out);
 void mrg_index_free(mrg_index *ix);

@@ -69,7 +69,6 @@ SIGNATURES = {
                                   C.POINTER(C.c_void_p)]),
     "mrg_index_build_fasta": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "mrg_index_build_ebwt": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
-    "mrg_ebwt_write_for_tests": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     "mrg_index_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "mrg_index_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "mrg_index_free": (None, [C.c_void_p]),

@@ -280,19 +280,6 @@ int mrg_index_build_ebwt(const char* prefix, mrg_index** out) {
   }
 }
 
-int mrg_ebwt_write_for_tests(const mrg_index* ix, const char* prefix, int32_t ftab_chars) {
-  if (!ix || !prefix) return fail(MRG_ERR_ARG, "mrg_ebwt_write_for_tests: null argument");
-  if (ftab_chars < 1 || ftab_chars > 12) return fail(MRG_ERR_ARG, "mrg_ebwt_write_for_tests: ftab_chars out of range");
-  try {
-    std::vector<std::string> sv(ix->ix.names.size());
-    for (uint32_t i = 0; i < sv.size(); ++i) sv[i] = mrg::entry_sequence(ix->ix, i);
-    mrg::write_ebwt(prefix, ix->ix.names, sv, ftab_chars);
-    return MRG_OK;
-  } catch (const std::exception& e) {
-    return fail(MRG_ERR_IO, "mrg_ebwt_write_for_tests: %s", e.what());
-  }
-}
-
 int mrg_index_save(const mrg_index* ix, const char* path) {
   if (!ix || !path) return fail(MRG_ERR_ARG, "mrg_index_save: null argument");
   try {

@@ -1,4 +1,4 @@
-// Reader (and a test-only writer) for bowtie 1 `.1.ebwt` index files.
+// Reader for bowtie 1 `.1.ebwt` index files.
 //
 // Role in the reference: miRge.Libs/<species>/index.Libs ships ONLY bowtie 1 indexes
 // (MAIN:262-281 checks for `<prefix>.1.ebwt`); entry names and sequences are recovered from them
@@ -10,14 +10,22 @@
 // Format, restated from bowtie 1.1.x (ebwt.h: Ebwt::readIntoMemory / buildToDisk / restore /
 // joinedToTextOff; bowtie_inspect.cpp: print_index_sequences); bowtie's source is NOT in
 // /root/reference and the image has neither bowtie nor a sample index, so this restatement is
-// VALIDATED BY ROUND TRIP ONLY (write_ebwt below -> read_ebwt) until a bowtie-built fixture exists:
+// VALIDATED BY ROUND TRIP ONLY (tests/helpers/ebwt_writer.cpp, an independent restatement of
+// bowtie-build's layout -> read_ebwt) until a bowtie-built fixture exists.  Because of that the
+// reader trusts nothing it can recompute: every redundant field of the file -- the occurrence
+// counts inside the sides, fchr, the order of ftab, the fragment table against len and plen -- is
+// checked against the BWT it decoded, so a file laid out differently from this restatement
+// FAILS LOUDLY on first contact instead of yielding wrong sequences:
 //   int32  1                      endianness hint
 //   uint32 len                    joined text length (unambiguous bases of all references)
 //   int32  lineRate, linesPerSide, offRate, ftabChars, flags (negated flag bits; colour = 2)
 //   uint32 nPat,  uint32 plen[nPat]          reference lengths, ambiguous bases included
 //   uint32 nFrag, uint32 rstarts[3 * nFrag]  per unambiguous stretch: joined offset, reference, offset in it
-//   uint8  ebwt[numSides << lineRate]        the BWT in "sides" of (1 << lineRate) bytes: the last 8
-//                                            bytes of a side hold two occurrence counts, the rest
+//   uint8  ebwt[numSides * sideSz]           the BWT in "sides" of sideSz = (1 << lineRate) * linesPerSide
+//                                            bytes: the last 8 bytes of a side hold two occurrence
+//                                            counts (rows before the backward/forward boundary of
+//                                            the side pair, '$' excluded: A and C in the backward
+//                                            side, G and T in the forward one), the rest
 //                                            four 2-bit characters per byte; even sides are
 //                                            "backward" (row k of the side at byte sideBwtSz-1-k/4,
 //                                            bit pair 3-(k&3)), odd sides "forward" (byte k/4, pair k&3)
@@ -46,14 +54,11 @@ T get(std::ifstream& in) {
   if (!in) throw std::runtime_error("truncated .ebwt file");
   return v;
 }
-template <class T>
-void put(std::ofstream& out, T v) {
-  out.write(reinterpret_cast<const char*>(&v), sizeof v);
-}
 
 struct Sides {
   uint32_t side_sz, side_bwt_sz, side_bwt_len;
-  explicit Sides(int line_rate) : side_sz(1u << line_rate), side_bwt_sz(side_sz - 8), side_bwt_len(side_bwt_sz * 4) {}
+  Sides(int line_rate, int lines_per_side)
+      : side_sz((1u << line_rate) * (uint32_t)lines_per_side), side_bwt_sz(side_sz - 8), side_bwt_len(side_bwt_sz * 4) {}
   uint64_t total(uint64_t bwt_len) const {
     const uint64_t pairs = (bwt_len + 2ull * side_bwt_len - 1) / (2ull * side_bwt_len);
     return pairs * 2 * side_sz;
@@ -81,34 +86,42 @@ void read_ebwt(const std::string& prefix, std::vector<std::string>& names, std::
   if (get<int32_t>(in) != 1) throw std::runtime_error(path + ": not a little-endian bowtie 1 index");
   const uint32_t len = get<uint32_t>(in);
   const int32_t line_rate = get<int32_t>(in);
-  (void)get<int32_t>(in);  // linesPerSide
+  const int32_t lines_per_side = get<int32_t>(in);
   (void)get<int32_t>(in);  // offRate
   const int32_t ftab_chars = get<int32_t>(in);
   const int32_t flags = get<int32_t>(in);
-  if (line_rate < 4 || line_rate > 16 || ftab_chars < 1 || ftab_chars > 14)
-    throw std::runtime_error(path + ": implausible header (lineRate / ftabChars)");
+  if (line_rate < 4 || line_rate > 16 || lines_per_side < 1 || lines_per_side > 64 || ftab_chars < 1 || ftab_chars > 14)
+    throw std::runtime_error(path + ": implausible header (lineRate / linesPerSide / ftabChars)");
   if (flags < 0 && ((-flags) & 2)) throw std::runtime_error(path + ": colourspace indexes are not supported");
   const uint32_t n_pat = get<uint32_t>(in);
+  in.seekg(0, std::ios::end);
+  const uint64_t file_size = (uint64_t)in.tellg();
+  in.seekg(7 * 4 + 4, std::ios::beg);
+  if ((uint64_t)n_pat * 4 > file_size) throw std::runtime_error(path + ": implausible reference count");
   std::vector<uint32_t> plen(n_pat);
   in.read(reinterpret_cast<char*>(plen.data()), (std::streamsize)n_pat * 4);
+  if (!in) throw std::runtime_error(path + ": truncated (plen)");
   const uint32_t n_frag = get<uint32_t>(in);
+  if ((uint64_t)n_frag * 12 > file_size) throw std::runtime_error(path + ": implausible fragment count");
   std::vector<uint32_t> rstarts((size_t)n_frag * 3);
   in.read(reinterpret_cast<char*>(rstarts.data()), (std::streamsize)rstarts.size() * 4);
-  const Sides sd(line_rate);
+  if (!in) throw std::runtime_error(path + ": truncated (rstarts)");
+  const Sides sd(line_rate, lines_per_side);
   const uint64_t bwt_len = (uint64_t)len + 1;
+  if (sd.total(bwt_len) > file_size) throw std::runtime_error(path + ": truncated (the header promises a longer BWT)");
   std::vector<uint8_t> ebwt(sd.total(bwt_len));
   in.read(reinterpret_cast<char*>(ebwt.data()), (std::streamsize)ebwt.size());
   if (!in) throw std::runtime_error(path + ": truncated (BWT)");
   const uint32_t z_off = get<uint32_t>(in);
   if (z_off > len) throw std::runtime_error(path + ": zOff out of range");
-  {
-    const std::streamoff here = in.tellg();
-    const std::streamoff skip = (std::streamoff)(5 + ((1ull << (2 * ftab_chars)) + 1) + 2ull * ftab_chars) * 4;
-    in.seekg(0, std::ios::end);
-    const std::streamoff size = in.tellg();
-    if (here < 0 || here + skip > size) throw std::runtime_error(path + ": truncated (fchr / ftab)");
-    in.seekg(here + skip, std::ios::beg);
-  }
+  uint32_t file_fchr[5];
+  in.read(reinterpret_cast<char*>(file_fchr), sizeof file_fchr);
+  if (!in) throw std::runtime_error(path + ": truncated (fchr)");
+  std::vector<uint32_t> ftab(((size_t)1 << (2 * ftab_chars)) + 1), eftab(2 * (size_t)ftab_chars);
+  in.read(reinterpret_cast<char*>(ftab.data()), (std::streamsize)ftab.size() * 4);
+  if (!in) throw std::runtime_error(path + ": truncated (ftab)");
+  in.read(reinterpret_cast<char*>(eftab.data()), (std::streamsize)eftab.size() * 4);
+  if (!in) throw std::runtime_error(path + ": truncated (eftab)");
   names.clear();
   {
     std::string cur;
@@ -132,6 +145,23 @@ void read_ebwt(const std::string& prefix, std::vector<std::string>& names, std::
     sd.locate(i, byte, shift);
     bwt[i] = (ebwt[byte] >> shift) & 3;
   }
+  {
+    // the occurrence counts stored in the sides against a recount of the decoded rows
+    uint32_t occ[4] = {0, 0, 0, 0};
+    const uint64_t n_pairs = ebwt.size() / (2ull * sd.side_sz);
+    uint64_t row = 0;
+    for (uint64_t pr = 0; pr < n_pairs; ++pr) {
+      const uint64_t boundary = std::min<uint64_t>((2 * pr + 1) * sd.side_bwt_len, bwt_len);
+      for (; row < boundary; ++row)
+        if (row != z_off) ++occ[bwt[row]];
+      uint32_t ac[2], gt[2];
+      std::memcpy(ac, &ebwt[(2 * pr) * sd.side_sz + sd.side_bwt_sz], 8);
+      std::memcpy(gt, &ebwt[(2 * pr + 1) * sd.side_sz + sd.side_bwt_sz], 8);
+      if (ac[0] != occ[0] || ac[1] != occ[1] || gt[0] != occ[2] || gt[1] != occ[3])
+        throw std::runtime_error(path + ": the occurrence counts of side pair " + std::to_string(pr) +
+                                 " disagree with the BWT (not the bowtie 1 layout this reader restates)");
+    }
+  }
   std::vector<uint8_t>().swap(ebwt);
   const uint64_t n_chk = bwt_len / 64 + 1;
   std::vector<uint32_t> chk(n_chk * 4);
@@ -143,6 +173,18 @@ void read_ebwt(const std::string& prefix, std::vector<std::string>& names, std::
   if ((bwt_len & 63) == 0) std::memcpy(&chk[(bwt_len >> 6) * 4], run, sizeof run);
   uint32_t fchr[5] = {0, run[0], run[0] + run[1], run[0] + run[1] + run[2], len};
   if ((uint64_t)run[0] + run[1] + run[2] + run[3] != len) throw std::runtime_error(path + ": BWT length mismatch");
+  for (int c = 0; c < 5; ++c)
+    if (file_fchr[c] != fchr[c]) throw std::runtime_error(path + ": fchr disagrees with the BWT's character counts");
+  {
+    // ftab: row boundaries per ftabChars-mer, ascending; an entry with the top bit set points into
+    // eftab (a range split by a '$' suffix) and is skipped
+    uint32_t prev = 0;
+    for (uint32_t v : ftab) {
+      if (v & 0x80000000u) continue;
+      if (v < prev || v > len + 1) throw std::runtime_error(path + ": ftab is not an ascending list of BWT rows");
+      prev = v;
+    }
+  }
   std::vector<uint8_t> text(len);
   uint64_t i = len, jumps = 0;
   while (i != z_off) {
@@ -159,11 +201,15 @@ void read_ebwt(const std::string& prefix, std::vector<std::string>& names, std::
   static const char L[4] = {'A', 'C', 'G', 'T'};
   seqs.assign(n_pat, std::string());
   for (uint32_t t = 0; t < n_pat; ++t) seqs[t].assign(plen[t], 'N');
+  if (n_frag ? rstarts[0] != 0 : len != 0) throw std::runtime_error(path + ": the fragment table does not start at the text's first base");
   for (uint32_t f = 0; f < n_frag; ++f) {
     const uint64_t a = rstarts[3 * f], b = f + 1 < n_frag ? rstarts[3 * (f + 1)] : len;
     const uint32_t t = rstarts[3 * f + 1], off = rstarts[3 * f + 2];
     if (t >= n_pat || a > b || b > len || (uint64_t)off + (b - a) > plen[t])
       throw std::runtime_error(path + ": fragment table out of range");
+    if (f && (rstarts[3 * (f - 1) + 1] > t ||
+              (rstarts[3 * (f - 1) + 1] == t && (uint64_t)rstarts[3 * (f - 1) + 2] + (a - rstarts[3 * (f - 1)]) > off)))
+      throw std::runtime_error(path + ": fragments out of order or overlapping");
     for (uint64_t k = a; k < b; ++k) seqs[t][off + (k - a)] = L[text[k]];
   }
   if (names.size() < n_pat)
@@ -175,89 +221,6 @@ void read_ebwt(const std::string& prefix, std::vector<std::string>& names, std::
     const size_t ws = nm.find_first_of(" \t");
     if (ws != std::string::npos) nm.resize(ws);
   }
-}
-
-// TEST-ONLY writer: enough of bowtie-build to round-trip the reader (the occurrence counts inside
-// the sides and the ftab / eftab tables are filled with zeros: a real bowtie could not search this
-// file, and nothing here reads them).
-void write_ebwt(const std::string& prefix, const std::vector<std::string>& names, const std::vector<std::string>& seqs,
-                int ftab_chars) {
-  std::vector<uint8_t> joined;
-  std::vector<uint32_t> plen, rstarts;
-  for (size_t t = 0; t < seqs.size(); ++t) {
-    const std::string& s = seqs[t];
-    plen.push_back((uint32_t)s.size());
-    size_t i = 0;
-    while (i < s.size()) {
-      auto code = [](char c) -> int {
-        switch (c) {
-          case 'A': case 'a': return 0;
-          case 'C': case 'c': return 1;
-          case 'G': case 'g': return 2;
-          case 'T': case 't': return 3;
-          default: return -1;
-        }
-      };
-      while (i < s.size() && code(s[i]) < 0) ++i;
-      if (i >= s.size()) break;
-      rstarts.push_back((uint32_t)joined.size());
-      rstarts.push_back((uint32_t)t);
-      rstarts.push_back((uint32_t)i);
-      while (i < s.size() && code(s[i]) >= 0) joined.push_back((uint8_t)code(s[i++]));
-    }
-  }
-  const uint32_t len = (uint32_t)joined.size();
-  // suffix order with '$' after every base: symbols 1..4 = ACGT, 5 = bowtie's '$', 0 = SA-IS sentinel
-  std::vector<int32_t> s(len + 2), sa(len + 2);
-  for (uint32_t i = 0; i < len; ++i) s[i] = joined[i] + 1;
-  s[len] = 5;
-  s[len + 1] = 0;
-  suffix_array(s.data(), sa.data(), (int32_t)len + 2, 6);
-  const int line_rate = 6;
-  const Sides sd(line_rate);
-  const uint64_t bwt_len = (uint64_t)len + 1;
-  std::vector<uint8_t> ebwt(sd.total(bwt_len), 0);
-  uint32_t z_off = 0, counts[4] = {0, 0, 0, 0};
-  for (uint64_t row = 0; row < bwt_len; ++row) {
-    const int32_t p = sa[row + 1];  // sa[0] is the SA-IS sentinel
-    uint8_t c = 0;
-    if (p == 0) {
-      z_off = (uint32_t)row;
-    } else {
-      c = joined[p - 1];
-      ++counts[c];
-    }
-    uint64_t byte;
-    uint32_t shift;
-    sd.locate(row, byte, shift);
-    ebwt[byte] |= (uint8_t)(c << shift);
-  }
-  const std::string path = prefix + ".1.ebwt";
-  std::ofstream out(path, std::ios::binary);
-  if (!out) throw std::runtime_error("cannot write " + path);
-  put<int32_t>(out, 1);
-  put<uint32_t>(out, len);
-  put<int32_t>(out, line_rate);
-  put<int32_t>(out, 1);
-  put<int32_t>(out, 5);
-  put<int32_t>(out, ftab_chars);
-  put<int32_t>(out, -4);  // EBWT_ENTIRE_REV, what bowtie-build 1.x sets
-  put<uint32_t>(out, (uint32_t)plen.size());
-  out.write(reinterpret_cast<const char*>(plen.data()), (std::streamsize)plen.size() * 4);
-  put<uint32_t>(out, (uint32_t)(rstarts.size() / 3));
-  out.write(reinterpret_cast<const char*>(rstarts.data()), (std::streamsize)rstarts.size() * 4);
-  out.write(reinterpret_cast<const char*>(ebwt.data()), (std::streamsize)ebwt.size());
-  put<uint32_t>(out, z_off);
-  put<uint32_t>(out, 0);
-  put<uint32_t>(out, counts[0]);
-  put<uint32_t>(out, counts[0] + counts[1]);
-  put<uint32_t>(out, counts[0] + counts[1] + counts[2]);
-  put<uint32_t>(out, len);
-  std::vector<uint32_t> zeros(((size_t)1 << (2 * ftab_chars)) + 1 + 2 * (size_t)ftab_chars, 0);
-  out.write(reinterpret_cast<const char*>(zeros.data()), (std::streamsize)zeros.size() * 4);
-  for (const auto& n : names) out << n << '\n';
-  out << '\0' << '\n';
-  if (!out) throw std::runtime_error("short write to " + path);
 }
 
 }  // namespace mrg

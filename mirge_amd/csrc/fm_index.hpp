@@ -132,9 +132,6 @@ std::string entry_sequence(const FmIndex& ix, uint32_t i);
 
 // bowtie 1 `.1.ebwt` -> entry names + sequences (what bowtie-inspect prints); ebwt.cpp
 void read_ebwt(const std::string& prefix, std::vector<std::string>& names, std::vector<std::string>& seqs);
-// test-only writer used to round-trip read_ebwt (not searchable by a real bowtie)
-void write_ebwt(const std::string& prefix, const std::vector<std::string>& names, const std::vector<std::string>& seqs,
-                int ftab_chars);
 
 // Suffix array of s[0..n) over alphabet [0,K); s[n-1] must be the unique
 // smallest symbol.  Induced sorting (SA-IS).

@@ -53,9 +53,6 @@ class FmIndex:
         check(lib.mrg_index_build_ebwt(os.fsencode(prefix), C.byref(h)))
         return cls(h.value)
 
-    def write_ebwt_for_tests(self, prefix, ftab_chars=10):
-        check(self._lib.mrg_ebwt_write_for_tests(self._h, os.fsencode(prefix), int(ftab_chars)))
-
     @classmethod
     def load(cls, path):
         lib = _native.load()
@@ -82,7 +79,9 @@ class FmIndex:
             ix = cls.from_ebwt(prefix)
         else:
             ix = cls.from_fasta(src)
-        if cache:
+        # (an index read back from a `.1.ebwt` is not cached: that reader is validated by round trip
+        # only, and a wrong guess must not outlive the run next to the library)
+        if cache and not src.endswith(".1.ebwt"):
             tmp = "%s.%d.tmp" % (built, os.getpid())
             try:
                 ix.save(tmp)
