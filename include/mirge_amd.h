@@ -274,6 +274,21 @@ int mrg_cascade_run(mrg_ctx *ctx, const uint64_t *d_reads, uint32_t words_per_re
                     int32_t *d_ref_id, int32_t *d_pos, uint8_t *d_mm,
                     uint64_t *d_pass_counts, void *d_workspace,
                     uint64_t workspace_bytes, void *stream);
+/*
+ * The four assignment arrays of mrg_cascade_run as ONE 32-bit word per read ("4 B packed
+ * assignment out"), for callers that move assignments over PCIe: 4 bytes per read instead of 10.
+ *   bits 28-31  claiming pass + 1 (0 = unannotated)
+ *   bits 26-27  mismatches, saturating at 3
+ *   bits  8-25  library entry, saturating at MRG_PACKED_REF_SAT (2^18 - 1)
+ *   bits  0-7   offset of the alignment in the entry, saturating at MRG_PACKED_POS_SAT (255)
+ * Every miRNA / hairpin / tRNA alignment fits (what the isomiR, A-to-I, GFF and tRF consumers read);
+ * a saturated field says "ask the full arrays" (an mRNA entry past the 262143rd, an offset deep inside
+ * a transcript).  n_pass must be at most 15.  Asynchronous on `stream`.
+ */
+#define MRG_PACKED_REF_SAT 0x3FFFFu
+#define MRG_PACKED_POS_SAT 0xFFu
+int mrg_pack_assignments(mrg_ctx *ctx, const int8_t *d_pass_id, const int32_t *d_ref_id, const int32_t *d_pos,
+                         const uint8_t *d_mm, uint64_t n, uint32_t *d_packed, void *stream);
 /* Number of cascade runs this context has launched (a caller that reads statistics later can tell
  * whether they are still those of its own run). */
 int mrg_cascade_run_id(const mrg_ctx *ctx, uint64_t *run_id);

@@ -1450,6 +1450,15 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
   return MRG_OK;
 }
 
+int mrg_pack_assignments(mrg_ctx* ctx, const int8_t* d_pass_id, const int32_t* d_ref_id, const int32_t* d_pos, const uint8_t* d_mm,
+                         uint64_t n, uint32_t* d_packed, void* stream) {
+  if (!ctx) return fail(MRG_ERR_ARG, "mrg_pack_assignments: null argument");
+  if (n && (!d_pass_id || !d_ref_id || !d_pos || !d_mm || !d_packed)) return fail(MRG_ERR_ARG, "mrg_pack_assignments: null buffers");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(mrg::launch_pack_assignments(d_pass_id, d_ref_id, d_pos, d_mm, n, d_packed, (hipStream_t)stream));
+  return MRG_OK;
+}
+
 int mrg_cascade_run_id(const mrg_ctx* ctx, uint64_t* run_id) {
   if (!ctx || !run_id) return fail(MRG_ERR_ARG, "mrg_cascade_run_id: null argument");
   *run_id = ctx->run_id;

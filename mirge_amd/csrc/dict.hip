@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "device_util.hpp"
 #include "dict_index.hpp"
 #include "kernels.hpp"
@@ -939,6 +941,39 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
     if (v) atomicAdd((unsigned long long*)&p.stats[(uint32_t)p.unit[ui].m[0].pass_index * 5u + 3u + what], v);
   }
   if (p.idx_out && tid == 0) p.out_count[blockIdx.x] = l.ctl[0];
+}
+
+// mrg_pack_assignments: the four output arrays as one word per read (include/mirge_amd.h); four reads per lane
+__global__ void __launch_bounds__(256) pack_assignments_kernel(const int8_t* __restrict__ pass_id, const int32_t* __restrict__ ref_id,
+                                                               const int32_t* __restrict__ pos, const uint8_t* __restrict__ mm, uint64_t n,
+                                                               uint32_t* __restrict__ packed, uint32_t vec) {
+  auto pack = [](int32_t pi, int32_t ref, int32_t ps, uint32_t m) -> uint32_t {
+    if (pi < 0) return 0u;
+    return ((uint32_t)(pi + 1) << 28) | (min(m, 3u) << 26) | (min((uint32_t)ref, 0x3FFFFu) << 8) | min((uint32_t)ps, 0xFFu);
+  };
+  const uint64_t quads = n / 4;
+  for (uint64_t q = (uint64_t)blockIdx.x * 256u + threadIdx.x; vec && q < quads; q += (uint64_t)gridDim.x * 256u) {
+    const uint32_t p4 = reinterpret_cast<const uint32_t*>(pass_id)[q], m4 = reinterpret_cast<const uint32_t*>(mm)[q];
+    const int4_t r4 = reinterpret_cast<const int4_t*>(ref_id)[q], o4 = reinterpret_cast<const int4_t*>(pos)[q];
+    typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+    u4_t out;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) out[u] = pack((int32_t)(int8_t)((p4 >> (8 * u)) & 255u), r4[u], o4[u], (m4 >> (8 * u)) & 255u);
+    reinterpret_cast<u4_t*>(packed)[q] = out;
+  }
+  for (uint64_t i = (vec ? quads * 4 : 0) + (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u)
+    packed[i] = pack((int32_t)pass_id[i], ref_id[i], pos[i], mm[i]);
+}
+
+hipError_t launch_pack_assignments(const int8_t* pass_id, const int32_t* ref_id, const int32_t* pos, const uint8_t* mm, uint64_t n,
+                                   uint32_t* packed, hipStream_t stream) {
+  if (!n) return hipSuccess;
+  const bool vec = ((uintptr_t)pass_id % 4 == 0) && ((uintptr_t)mm % 4 == 0) && ((uintptr_t)ref_id % 16 == 0) && ((uintptr_t)pos % 16 == 0) &&
+                   ((uintptr_t)packed % 16 == 0);
+  const uint64_t want = (n / 4 + 255) / 256;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), 256ull * 16);
+  hipLaunchKernelGGL(pack_assignments_kernel, dim3(grid), dim3(256), 0, stream, pass_id, ref_id, pos, mm, n, packed, vec ? 1u : 0u);
+  return hipGetLastError();
 }
 
 uint32_t seed_lds_bytes(const SeedParams& p) {

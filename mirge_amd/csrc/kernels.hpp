@@ -300,6 +300,9 @@ uint32_t seed_lds_bytes(const SeedParams& p);
 uint32_t seed_wgs_per_cu(const SeedParams& p);
 hipError_t launch_seed(const SeedParams& p, uint32_t grid, hipStream_t stream);
 
+hipError_t launch_pack_assignments(const int8_t* pass_id, const int32_t* ref_id, const int32_t* pos, const uint8_t* mm, uint64_t n,
+                                   uint32_t* packed, hipStream_t stream);
+
 constexpr uint32_t kCountThreads = 256u;
 
 struct CountParams {

@@ -137,3 +137,25 @@ def test_short_dictionary_keys(world):
     same_assignments(res, ref)
     assert res.stats[0]["lds_mode"] == 7
     eng.close()
+
+
+def test_packed_assignments_round_trip(engine, world):
+    """mrg_pack_assignments: one word per read carries pass, mismatches, entry and offset (the last
+    three saturating); unpacked on the host it equals the four arrays."""
+    from mirge_amd.engine import unpack_assignments, PACKED_POS_SAT, PACKED_REF_SAT
+    res = run(engine, world)
+    packed = engine.pack_assignments(res).cpu().numpy()
+    pass_id, ref_id, pos, mm = res.to_host()
+    u_pass, u_ref, u_pos, u_mm = unpack_assignments(packed)
+    assert np.array_equal(u_pass, pass_id)
+    assert np.array_equal(u_ref, np.where(ref_id >= 0, np.minimum(ref_id, PACKED_REF_SAT), -1))
+    assert np.array_equal(u_pos, np.where(pos >= 0, np.minimum(pos, PACKED_POS_SAT), -1))
+    assert np.array_equal(u_mm, np.minimum(mm, 3))
+    assert int((pos > PACKED_POS_SAT).sum()) > 0 and int((pass_id < 0).sum()) > 0   # both edges are exercised
+    # an odd, unaligned slice takes the scalar path
+    import torch
+    from mirge_amd.engine import CascadeResult
+    n = len(pass_id) - 3
+    sub = CascadeResult(res.pass_id[1:1 + n], res.ref_id[1:1 + n], res.pos[1:1 + n], res.mm[1:1 + n], None, engine, 9)
+    got = engine.pack_assignments(sub, out=torch.empty(n, dtype=torch.int32, device=engine.device)).cpu().numpy()
+    assert np.array_equal(got, packed[1:1 + n])
