@@ -80,9 +80,10 @@ def kernel_name(W, table_row, s, n_bases):
     if s["lds_mode"] in (5, 6):
         return "mrg::stratum_kernel<%d>" % W
     if s["lds_mode"] == 7:
-        return "mrg::exact_dict_kernel"
-    if s["lds_mode"] == 8:
-        return "mrg::seed_kernel"
+        # (FIRST = the pass streams the whole read set; KBITS = its library has the 9-mer bitmap)
+        return "mrg::exact_dict_kernel<%s, %s>" % ("true" if s.get("first_pass") else "false", "true" if n_bases <= 190000 else "false")
+    if s["lds_mode"] in (8, 9):
+        return "mrg::seed_kernel<false, 8>" if s["lds_mode"] == 8 else "mrg::seed_kernel<true, 6>"
     has_ctx = n_bases >= (1 << 20) and s["lds_mode"] in (0, 1)
     return "mrg::match_kernel<%d, %s, %s, %s, %s>" % (
         W, {0: "false, false", 1: "true, false", 2: "true, true", 3: "false, true"}[s["lds_mode"]],
@@ -91,6 +92,9 @@ def kernel_name(W, table_row, s, n_bases):
 
 
 def launch_table(st, per_pass_ms, table, index, W, n_reads=0):
+    first_launched = next((i for i, s in enumerate(st) if s.get("n_launches", 0)), 0)
+    for i, s in enumerate(st):
+        s["first_pass"] = i == first_launched
     """One entry per kernel launch of the last step (a fused launch covers several passes).
     `walked` = reads on the launch's input list = the batch minus what earlier passes claimed."""
     launches = []
@@ -99,7 +103,7 @@ def launch_table(st, per_pass_ms, table, index, W, n_reads=0):
         claimed_here = claimed_before
         claimed_before += s["aligned"]
         skipped = s["processed"] == 0 and s["lds_bytes"] == 0 and per_pass_ms[i] < 0.05 and i + 1 < len(st) \
-            and s["lds_mode"] not in (4, 8)
+            and s["lds_mode"] not in (4, 8, 9)
         if skipped:
             continue
         if s["group"] != i and launches and launches[-1]["first"] == s["group"]:
@@ -267,6 +271,9 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # whatever the launch plan derives lazily (concatenated small libraries, anchor-pair tables) is built
+    # here, not inside a step
+    eng.prepare(passes, rs.W, rs.min_len, rs.max_len)
     for _ in range(args.warmup):
         step()
     fence()

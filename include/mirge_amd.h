@@ -228,10 +228,11 @@ typedef struct mrg_pass_stats {
                           5 / 6 = stratum_kernel<W> with / without the packed text in LDS;
                           7 = exact_dict_kernel (one slot load of the library's exact-match
                           dictionary per read: steps = 0, lookups = slot / table loads, candidates =
-                          slots / rows compared); 8 = seed_kernel (the pass rode, as a unit or a member
-                          of a unit, in the seed launch of its group's first pass: steps = 0, lookups =
-                          jump-table / slot loads and candidates = rows of the unit, reported with the
-                          unit's first pass) */
+                          slots / rows compared); 8 / 9 = seed_kernel<false, 8> / seed_kernel<true, 6>
+                          (the pass rode, as a unit or a member of a unit, in the seed launch of its
+                          group's first pass -- 9: a launch with a library that has seed buckets; steps = 0,
+                          lookups = jump-table / bucket / slot loads and candidates = rows of the unit,
+                          reported with the unit's first pass) */
   uint32_t group;      /* index of the first pass of the launch this pass ran in (itself when it
                           had a launch of its own) */
   uint32_t n_launches; /* kernel launches that carried this pass: 1, or 2 for a 2-mismatch pass split

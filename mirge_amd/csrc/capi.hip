@@ -1321,6 +1321,14 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     sp.ref_id = d_ref_id;
     sp.pos = d_pos;
     sp.mm = d_mm;
+    {
+      // which instantiation the launch gets: mrg_pass_stats.lds_mode 8 = seed_kernel<false, 8>, 9 = <true, 6>
+      bool with_buckets = false;
+      for (uint32_t u = 0; u < sp.n_units; ++u) with_buckets |= sp.unit[u].kind == 0u && sp.unit[u].buckets != nullptr;
+      if (with_buckets)
+        for (uint32_t q = first; q < end; ++q)
+          if (ctx->last_mode[q] == 8u) ctx->last_mode[q] = 9u;
+    }
     const uint32_t lds = mrg::seed_lds_bytes(sp);
     (void)lds;
     uint32_t grid = (uint32_t)ctx->n_cu * (ctx->seed_wgs > 0 ? (uint32_t)ctx->seed_wgs : mrg::seed_wgs_per_cu(sp));

@@ -220,6 +220,20 @@ class Engine:
                                              result.mm.data_ptr(), n, out.data_ptr(), self._stream_ptr()))
         return out
 
+    def prepare(self, passes, words_per_read=1, min_len=0, max_len=255, has_n=False):
+        """Build, ahead of the first timed run, whatever a cascade with these passes on batches of this
+        shape derives lazily (the index over several small libraries searched with one policy, the
+        anchor-pair tables of a large library for reads with short seed regions): a cascade over zero
+        reads with the same length hints plans exactly the same launches."""
+        torch = _torch()
+        W = int(words_per_read)
+        rs = ReadSet.from_device(torch.empty((W, 0), dtype=torch.int64, device=self.device),
+                                 torch.empty(0, dtype=torch.uint8, device=self.device),
+                                 torch.empty((W, 0), dtype=torch.int64, device=self.device) if has_n else None, None,
+                                 int(min_len), int(max_len))
+        self.cascade(rs, passes)
+        torch.cuda.synchronize(self.device)
+
     def _run_id(self):
         v = C.c_uint64()
         check(self._lib.mrg_cascade_run_id(self._h, C.byref(v)))

@@ -25,7 +25,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-CASCADE_KERNELS = ("match_kernel", "fused_kernel", "stratum_kernel")   # one launch per entry of the bench line's plan
+CASCADE_KERNELS = ("match_kernel", "fused_kernel", "stratum_kernel", "exact_dict_kernel", "seed_kernel")   # one launch per entry of the bench line's plan
 
 
 def newest(pattern):
@@ -101,8 +101,11 @@ def main():
     except Exception:
         head = "?"
     meta_f = os.path.join(ROOT, "gpurun_out", a.tag + "_meta.json")
+    kernels_sha = None
     if os.path.exists(meta_f):
-        head = json.load(open(meta_f)).get("git_head", head)
+        mj = json.load(open(meta_f))
+        head = mj.get("git_head", head)
+        kernels_sha = mj.get("kernels_sha16")   # bench.kernels_sha16() of the profiled tree
     lines = ["# rocprofv3 summary `%s` (%s workload, %s reads per GPU, tree %s)\n" % (a.tag, a.workload, reads, head)]
 
     stats = newest(os.path.join(ROOT, "gpurun_out", a.tag + "_stats", "**", "*_kernel_stats.csv"))
@@ -184,7 +187,7 @@ def main():
         tp = os.path.join(out, "traffic.json")
         tj = json.load(open(tp)) if os.path.exists(tp) else {}
         tj[a.workload] = traffic
-        tj["_meta"] = dict(git_head=head, tag=a.tag,
+        tj["_meta"] = dict(git_head=head, tag=a.tag, kernels_sha16=kernels_sha,
                            note="collected by scripts/profile_round.sh (separate --pmc passes); see <tag>_summary.md")
         json.dump(tj, open(tp, "w"), indent=1, sort_keys=True)
     print("\n".join(lines))

@@ -7,19 +7,20 @@ tag=${1:-r02}
 head=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
-echo "{\"git_head\": \"$head\"}" > gpurun_out/${tag}_meta.json
+sha=$(python3 -c "import bench; print(bench.kernels_sha16())")
+echo "{\"git_head\": \"$head\", \"kernels_sha16\": \"$sha\"}" > gpurun_out/${tag}_meta.json
 B="python3 bench.py --no-cpu-baseline --no-extras"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- $B --steps 5 --warmup 1 > gpurun_out/${tag}_stats.json 2> gpurun_out/${tag}_stats.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch -- $B --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${tag}_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_write -- $B --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${tag}_write.err
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD --output-format csv -d gpurun_out/${tag}_sq -- $B --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${tag}_sq.err
-rocprofv3 --pmc TCP_TOTAL_ACCESSES TCP_TCC_READ_REQ TCP_TCC_READ_REQ_LATENCY TCP_PENDING_STALL_CYCLES --output-format csv -d gpurun_out/${tag}_tcp -- $B --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${tag}_tcp.err
-rocprofv3 --pmc TCC_REQ TCC_HIT TCC_MISS --output-format csv -d gpurun_out/${tag}_tcc -- $B --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${tag}_tcc.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- $B --steps 5 --warmup 1 > gpurun_out/${tag}_stats.json 2> gpurun_out/${tag}_stats.err
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch -- $B --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${tag}_fetch.err
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_write -- $B --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${tag}_write.err
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD --output-format csv -d gpurun_out/${tag}_sq -- $B --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${tag}_sq.err
+timeout 600 rocprofv3 --pmc TCP_TOTAL_ACCESSES TCP_TCC_READ_REQ TCP_TCC_READ_REQ_LATENCY TCP_PENDING_STALL_CYCLES --output-format csv -d gpurun_out/${tag}_tcp -- $B --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${tag}_tcp.err
+timeout 600 rocprofv3 --pmc TCC_REQ TCC_HIT TCC_MISS --output-format csv -d gpurun_out/${tag}_tcc -- $B --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${tag}_tcc.err
 # the a2i workload's kernels (edit tally) by time
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_a2i_stats -- $B --workload a2i --steps 5 --warmup 1 > gpurun_out/${tag}_a2i_stats.json 2> gpurun_out/${tag}_a2i_stats.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_a2i_stats -- $B --workload a2i --steps 5 --warmup 1 > gpurun_out/${tag}_a2i_stats.json 2> gpurun_out/${tag}_a2i_stats.err
 # ... and of the exact (BASELINE configs[1], the roofline configuration) and varlen workloads
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_exact_stats -- $B --workload exact --steps 20 --warmup 2 > gpurun_out/${tag}_exact_stats.json 2> gpurun_out/${tag}_exact_stats.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_varlen_stats -- $B --workload varlen --steps 5 --warmup 1 > gpurun_out/${tag}_varlen_stats.json 2> gpurun_out/${tag}_varlen_stats.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_exact_stats -- $B --workload exact --steps 20 --warmup 2 > gpurun_out/${tag}_exact_stats.json 2> gpurun_out/${tag}_exact_stats.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_varlen_stats -- $B --workload varlen --steps 5 --warmup 1 > gpurun_out/${tag}_varlen_stats.json 2> gpurun_out/${tag}_varlen_stats.err
 # the bench lines proper (no profiler attached)
 python bench.py 2> gpurun_out/${tag}_bench_cascade.err > gpurun_out/${tag}_bench_cascade.json
 python bench.py --workload exact 2> gpurun_out/${tag}_bench_exact.err > gpurun_out/${tag}_bench_exact.json

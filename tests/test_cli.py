@@ -177,3 +177,36 @@ def test_cli_runs_on_a_library_directory_that_holds_only_ebwt_files(native_lib, 
         assert open(os.path.join(outs["fa"]["outdir"], fn)).read() == open(os.path.join(outs["ebwt"]["outdir"], fn)).read(), fn
     # (what was read back from a `.1.ebwt` is never cached next to the library: the reader is unpinned)
     assert not glob.glob(os.path.join(str(tmp_path / "libs_ebwt"), "syn", "index.Libs", "*.mrgfm"))
+
+
+@pytest.mark.gpu
+def test_cli_two_gpus_over_rccl(native_lib, tmp_path):
+    """`annotate --gpus 2` for real: two child processes, one GPU each, RCCL all-to-all / all-reduce /
+    send-recv (skipped on a one-GPU box; the gloo tests of tests/test_dist_gloo.py cover the logic)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from mirge_amd import synth
+    from tests.golden.make_golden import SHAPES
+    rng = np.random.default_rng(8)
+    libs = synth.SynthLibraries(seed=123, scale=1.0, n_paralogs=6, n_snp=8, shapes=SHAPES)
+    root = str(tmp_path / "libs")
+    libs.write_layout(root, species="syn", db="miRBase")
+    fastqs = []
+    for si in range(3):
+        p = str(tmp_path / ("s%d.fastq" % si))
+        write_fastq(p, [synth.codes_to_str(c) for c in synth.synth_reads(libs, 2000, seed=40 + si, zipf_s=1.3)], rng)
+        fastqs.append(p)
+    base = [sys.executable, "-m", "mirge_amd", "annotate", "-s"] + fastqs + ["-lib", root, "-sp", "syn", "-di"]
+    outs = {}
+    for n_gpu in (1, 2):
+        o = str(tmp_path / ("out%d" % n_gpu))
+        cp = subprocess.run(base + ["-o", o, "--gpus", str(n_gpu)], capture_output=True, text=True, timeout=900)
+        assert cp.returncode == 0, cp.stderr[-2000:]
+        outs[n_gpu] = os.path.join(o, os.listdir(o)[0])
+    for fn in ("mapped.csv", "unmapped.csv", "miR.Counts.csv", "miR.RPM.csv", "isomirs.csv", "annotation.report.csv"):
+        a = open(os.path.join(outs[1], fn)).read()
+        b = open(os.path.join(outs[2], fn)).read()
+        assert sorted(a.split("\n")) == sorted(b.split("\n")), fn

@@ -58,7 +58,7 @@ def test_dict_cascade_equals_port_and_fm_kernels(engine, world):
             # hairpin .. ncRNA-others (small libraries) share one seed_kernel launch: hairpin alone (its own
             # length window), tRNA + snoRNA + rRNA + ncRNA-others as ONE unit over their concatenation,
             # pre-tRNA through its dictionary; mRNA (large) has a launch of its own
-            assert [s["lds_mode"] for s in st[1:8]] == [8] * 7
+            assert [s["lds_mode"] for s in st[1:8]] == [8] * 6 + [9]   # (9: the mRNA library of this world has seed buckets)
             assert [s["group"] for s in st[1:8]] == [1] * 6 + [7]
             assert all(s["steps"] == 0 for s in st[1:8])
         elif fuse == 0:
@@ -121,7 +121,7 @@ def test_seed_buckets_and_jump_tables_on_a_large_library(engine, world):
         for sb in (1, 0):
             res = run(engine, world, passes=names, seed_buckets=sb)
             same_assignments(res, ref)
-            assert res.stats[1]["lds_mode"] == 8 and res.stats[1]["aligned"] > 300
+            assert res.stats[1]["lds_mode"] in (8, 9) and res.stats[1]["aligned"] > 300
     engine.set_option("seed_buckets", 1)
 
 

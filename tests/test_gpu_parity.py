@@ -503,7 +503,7 @@ def test_big_library_jump_tables(native_lib, oracle_lib):
     assert nm1 is None
     resd = eng.cascade(ReadSet(w1, l1, None, None, device=eng.device), eng.make_passes([dict(p, lib="big") for p in fused_passes]))
     plain = model.fm_cascade([ix.view()], fused_passes, w1, l1, None, wstop=DEFAULT_WSTOP, ftab=True)
-    assert [st["lds_mode"] for st in resd.stats][1:] == [8, 8]
+    assert [st["lds_mode"] for st in resd.stats][1:] == [9, 9]
     for name, a in zip(("pass_id", "ref_id", "pos", "mm"), resd.to_host()):
         assert np.array_equal(a, plain[name]), name
     for i, st in enumerate(resd.stats):
