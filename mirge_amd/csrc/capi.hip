@@ -203,6 +203,7 @@ struct mrg_ctx {
   int64_t wide_rows_16 = 1;  // libraries of >= 2^20 bases get 16-byte rows with 32 bases of context
   int64_t dict = 1;          // one-word batches without N run the dictionary kernels (dict.hip) where a pass can
   int64_t dict_key = 16;     // key length of the exact-match dictionaries (set before add_library)
+  int64_t stratum0_unit = 0;  // (measured slower, default off) the exact stratum of a 2-mismatch pass behind a seed launch rides in that launch
   int64_t seed_buckets = 1;  // large libraries get seed buckets where they pay (set before add_library); 0 at run time: not used
   int64_t seed_wgs = 0;      // seed_kernel workgroups (256 threads) per CU; 0 = what the launch's instantiation keeps resident
   int64_t seed_units = 1;    // ... and their runs of passes with at most one seed mismatch go through seed_kernel
@@ -606,6 +607,8 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->wide_rows_16 = value != 0;  // takes effect for libraries added afterwards
   } else if (k == "dict") {
     ctx->dict = value != 0;  // (the dictionaries themselves are built by mrg_ctx_add_library while this is 1)
+  } else if (k == "stratum0_unit") {
+    ctx->stratum0_unit = value != 0;
   } else if (k == "seed_buckets") {
     ctx->seed_buckets = value != 0;
   } else if (k == "seed_wgs") {
@@ -808,6 +811,12 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
   // pass, len > 25, on 22-nt reads) would only copy its input list: it is not launched; its
   // counters stay zero and the next pass reads the same list.  (Never the last pass: that one
   // writes the "unannotated" values.)
+  // A 2-mismatch `--best` pass on a library with an exact-match dictionary, right behind a seed
+  // launch: its exact stratum -- what most isomiRs are after the -5 / -3 trims -- rides in that launch
+  // as a dictionary unit (a 0-mismatch hit is final: nothing beats it, the lowest (entry, offset) wins
+  // ties as always); the pass's own launch then searches the reads that are left and does not count
+  // "processed" again.
+  bool stratum0_done[MRG_MAX_PASSES] = {false};
   bool runs[MRG_MAX_PASSES];
   for (uint32_t i = 0; i < n_pass; ++i) {
     const mrg_pass_cfg& c = passes[i];
@@ -1242,6 +1251,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
   struct UnitPlan {
     uint32_t kind;
     std::vector<uint32_t> members;
+    bool stratum0 = false;  // the exact stratum of a LATER 2-mismatch pass (see stratum0_done)
   };
   auto run_seed = [&](const std::vector<UnitPlan>& plan, uint32_t first, uint32_t end, bool ends_cascade, bool small) -> int {
     mrg::SeedParams sp;
@@ -1279,7 +1289,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
       un.seg_off = fm->seg_off;
       un.chunk_seg = fm->chunk_seg;
       un.simple_segs = fm->simple ? 1u : 0u;
-      un.max_mm_seed = c0.max_mm_seed;
+      un.max_mm_seed = plan[u].stratum0 ? 0 : c0.max_mm_seed;
       un.trim5 = c0.trim5;
       un.trim3 = c0.trim3;
       un.min_len = c0.min_len;
@@ -1297,6 +1307,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
         un.m[mi].entry_lo = sl ? sl->entry_lo[mi] : 0u;
         un.min_seed_len = std::min(un.min_seed_len, c.seed_len);
         un.max_total = std::max(un.max_total, c.max_mm_total);
+        if (plan[u].stratum0) continue;  // (that pass has its own launch afterwards and reports that one)
         ctx->last_lds[i] = 0u;
         ctx->last_mode[i] = 8u;
         ctx->last_group[i] = first;
@@ -1396,6 +1407,13 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
         ++j;
       }
       // (passes skipped by the length hint at the end of the run stay with it: never the last pass)
+      if (ctx->stratum0_unit && j < n_pass && runs[j] && passes[j].max_mm_seed == 2 && !passes[j].poly_t &&
+          ctx->libs[passes[j].lib].dict_slots && plan.size() < mrg::kSeedMaxUnits && ctx->pair_seeds && ctx->force_lds_mode < 0) {
+        UnitPlan s0{1u, {j}};
+        s0.stratum0 = true;
+        plan.push_back(s0);
+        stratum0_done[j] = true;
+      }
       int rc = run_seed(plan, i, j, j == n_pass, cls);
       if (rc != MRG_OK) return rc;
       i = j;
@@ -1434,13 +1452,13 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
           passes[i].seed_len >= (int32_t)(4u * l8.pair_anchor)) {
         // anchor pairs for every read long enough to hold the four anchors, all strata of the
         // pigeonhole search for the shorter ones: one launch (kernels.hip: stratum_kernel)
-        rc = run_single(i, 1, kfull, true, true, true);
+        rc = run_single(i, 1, kfull, !stratum0_done[i], true, true);
       } else if (passes[i].max_mm_seed == 2 && ctx->split_strata) {
         // strata 1..2 on the incoming reads, stratum 3 on the compacted survivors (kernels.hpp)
-        rc = run_single(i, 1, 2, true, false);
+        rc = run_single(i, 1, 2, !stratum0_done[i], false);
         if (rc == MRG_OK) rc = run_single(i, 3, 3, false, true);
       } else {
-        rc = run_single(i, 1, kfull, true, true);
+        rc = run_single(i, 1, kfull, !stratum0_done[i], true);
       }
       if (rc != MRG_OK) return rc;
       ++i;

@@ -71,6 +71,17 @@ def test_dict_cascade_equals_port_and_fm_kernels(engine, world):
     engine.set_option("seed_units", 1)
 
 
+def test_exact_stratum_of_the_two_mismatch_pass_as_a_dictionary_unit(engine, world):
+    """stratum0_unit = 1: the 0-mismatch stratum of pass 8 (`-v 2 --best` on the miRNA library) rides in
+    the preceding seed launch as a dictionary unit, the pass's own launch searches what is left and
+    does not count `processed` twice.  Same assignments and counters (measured slower on the headline
+    workload, hence off by default)."""
+    ref = model.fm_cascade(world.views, world.passes, world.words, world.lens, None)
+    res = run(engine, world, stratum0_unit=1)
+    same_assignments(res, ref)
+    engine.set_option("stratum0_unit", 0)
+
+
 def test_dict_cascade_equals_exhaustive_scan(engine, world):
     res = run(engine, world, dict=1)
     pass_id, ref_id, pos, mm = res.to_host()
