@@ -604,12 +604,8 @@ def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log,
     candidates = [(pool[0], pool[2], cur), (pool[0], pool[2], pool[4]), (pool[1], pool[3], pool[5]), (pool[0], pool[1], cur)]
     s_in, s_out, s_comp = candidates[0]
     min_len, max_len = int(lens.min()), int(lens.max())
-    # a batch of one single length needs no length array (the hint says so and the kernels do not
-    # read it): the device buffers hold the constant, nothing is sent
-    send_lens = min_len != max_len
-    if not send_lens:
-        for b in bufs:
-            b["lens"].fill_(min_len)
+    # the length array always travels (13 B per read up): the kernels read it whatever the hints say
+    send_lens = True
 
     def one_pass():
         with torch.cuda.stream(s_comp):

@@ -164,7 +164,7 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * verified cooperatively by the whole wave (default 64); "hint_min_len" / "hint_max_len" = the
  * caller's promise that every read of the NEXT mrg_cascade_run has a length in that range (defaults
  * 0 / 255 = unknown; reset to the defaults by every run): a pass whose length window excludes the
- * whole range is not launched, and a batch of one single length skips the length array; "kmer_filter" = 1/0 stage a small
+ * whole range is not launched (the hints decide nothing else: every kernel reads d_lens); "kmer_filter" = 1/0 stage a small
  * library's 9-mer presence bitmap in LDS and skip the jump-table load of a seed piece whose
  * last 9 bases do not occur in the library (default 1); "ctx_wide_rows" = the same
  * threshold for libraries of >= 2^20 bases, whose cooperative path drops most rows by their

@@ -935,7 +935,10 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     p.k_first = k_first;
     p.k_last = k_last;
     p.count_processed = first_part ? 1u : 0u;
-    p.uniform_len = (ctx->hint_min_len == ctx->hint_max_len && ctx->hint_min_len > 0) ? (uint32_t)ctx->hint_min_len : 0u;
+    // (the length hints only decide which passes are launched: every kernel reads the length array --
+    // a caller whose equal hints do not describe the batch gets a skipped pass at worst, never a read
+    // aligned with somebody else's length)
+    p.uniform_len = 0u;
     p.out_count = counts + next_list * mrg::kMaxSegments;
     p.pass_id = d_pass_id;
     p.ref_id = d_ref_id;
@@ -1214,7 +1217,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     fp.lens = d_lens;
     fp.nmask = d_nmask;
     fp.n_total = (uint32_t)n;
-    fp.uniform_len = (ctx->hint_min_len == ctx->hint_max_len && ctx->hint_min_len > 0) ? (uint32_t)ctx->hint_min_len : 0u;
+    fp.uniform_len = 0u;  // (see run_single)
     const int next_list = have_list ? (cur_list ^ 1) : 0;
     fp.idx_in = have_list ? idx[cur_list] : nullptr;
     fp.in_count = counts + cur_list * mrg::kMaxSegments;
