@@ -152,6 +152,9 @@ def main():
     ap.add_argument("--sorted", action="store_true",
                     help="feed the reads in the order the GPU collapse emits uniques (sorted by packed key)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
+    ap.add_argument("--outputs", choices=["packed", "arrays"], default="packed",
+                    help="per-read output of the timed steps: one 4-byte packed word per read (mrg_cascade_run_packed, "
+                         "SURVEY.md 8d's unit) or the four arrays pass_id / ref_id / pos / mm (10 B per read)")
     ap.add_argument("--mix", action="append", default=[],
                     help="override a fraction of the read mixture, e.g. polyt=0 (experiments; not the headline workload)")
     args = ap.parse_args()
@@ -256,9 +259,14 @@ def main():
            torch.empty(n_reads, dtype=torch.uint8, device=eng.device),
            fused[ln:])
 
+    packed_out = torch.empty(n_reads, dtype=torch.int32, device=eng.device) if args.outputs == "packed" else None
+
     def step():
         fused.zero_()
-        res = eng.cascade(rs, passes, out=out)
+        if packed_out is not None:
+            res = eng.cascade_packed(rs, passes, out=(packed_out, fused[ln:]))
+        else:
+            res = eng.cascade(rs, passes, out=out)
         eng.tally(rs, res, M, canon, iso, counts=fused[:ln_tally])
         if wl == "a2i":
             eng.edit_tally(rs, res, "mirna", canon, iso, counts=fused[ln_tally:ln])
@@ -367,11 +375,32 @@ def main():
     # ---- parity gates + CPU baseline (rank 0, N = 1 only) ----
     cpu, parity = None, {}
     got = None
+    if world == 1 and not (args.no_cpu_baseline and args.no_extras):
+        if packed_out is not None:
+            # the timed steps wrote packed words only: one more (untimed) run with the four full arrays for the
+            # gates below, and the packed words must be exactly what packing those arrays gives
+            from mirge_amd.engine import PACKED_POS_SAT, PACKED_REF_SAT, unpack_assignments
+            fused_chk = torch.zeros_like(fused)
+            res_a = eng.cascade(rs, passes, out=out[:4] + (fused_chk[ln:],))
+            eng.tally(rs, res_a, M, canon, iso, counts=fused_chk[:ln_tally])
+            if wl == "a2i":
+                eng.edit_tally(rs, res_a, "mirna", canon, iso, counts=fused_chk[ln_tally:ln])
+            torch.cuda.synchronize()
+            e_pass, e_ref, e_pos, e_mm = [t.cpu().numpy() for t in out[:4]]
+            u_pass, u_ref, u_pos, u_mm = unpack_assignments(packed_out.cpu().numpy())
+            same = np.array_equal(u_pass, e_pass) and np.array_equal(u_ref, np.where(e_ref >= 0, np.minimum(e_ref, PACKED_REF_SAT), -1)) \
+                and np.array_equal(u_pos, np.where(e_pos >= 0, np.minimum(e_pos, PACKED_POS_SAT), -1)) \
+                and np.array_equal(u_mm, np.minimum(e_mm, 3)) and bool(torch.equal(fused_chk[:ln], fused[:ln]))
+            if not same:
+                raise SystemExit("PARITY FAILURE: the packed-output run differs from the four-array run")
+            parity["packed_outputs"] = "the timed steps' packed words = the four-array run's assignments packed (entries / offsets " \
+                                       "saturating at %d / %d), count vectors identical" % (PACKED_REF_SAT, PACKED_POS_SAT)
+
     if not args.no_cpu_baseline and world == 1:
         from oracle import model
         from mirge_amd import pack
-        got = [t.cpu().numpy() for t in out[:4]]
         counts_gpu = fused[:ln].cpu().numpy().astype(np.uint64)
+        got = [t.cpu().numpy() for t in out[:4]]
         pd = [dict(lib=keys.index(k), min_len=a, max_len=b, seed_len=s_, max_mm_seed=ms, max_mm_total=mt,
                    trim5=t5, trim3=t3, poly_t=pt, kbits_log2=st[i]["kbits_log2"], pair_anchor=st[i]["pair_anchor"])
               for i, (k, a, b, s_, ms, mt, t5, t3, pt) in enumerate(table)]
@@ -550,6 +579,8 @@ def main():
         "config": {
             "workload": what, "reads_total": n_total, "reads_per_gpu": n_reads, "libraries_scale": args.scale,
             "samples": S,
+            "outputs": ("one 4-byte packed assignment per read (mrg_cascade_run_packed)" if args.outputs == "packed" else
+                        "pass_id, ref_id, pos, mm arrays (10 B per read)"),
             "parallelism": ("one read set in %d contiguous shards, libraries replicated, one RCCL all-reduce of the "
                             "fused count vector per step" % world) if args.scaling == "strong" else
                            ("%d independent read sets (weak scaling), one RCCL all-reduce of the count vector" % world),
@@ -632,9 +663,8 @@ def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log,
             wv = b["words"] if m == cap else b["words"][:, :m].contiguous()
             rsc = ReadSet.from_device(wv, b["lens"][:m], None, b["quant"][:m], min_len, max_len)
             o = tuple(t[:m] for t in b["out"]) + (pc,)
-            res = eng.cascade(rsc, passes, out=o)
+            res = eng.cascade_packed(rsc, passes, out=(b["packed"][:m], pc))
             eng.tally(rsc, res, M, canon, iso, counts=counts)
-            eng.pack_assignments(res, out=b["packed"][:m])
             b["ev_done"].record(s_comp)
             with torch.cuda.stream(s_out):
                 s_out.wait_event(b["ev_done"])
@@ -695,7 +725,7 @@ def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log,
                 parity=None if ok is None else "packed assignments (pass, mismatches, entry, offset; the last two saturating at "
                                                "262143 / 255) identical to the resident run's",
                 note="SURVEY.md 8d timed region: pinned host arrays -> H2D (packed reads + counts%s) -> "
-                     "cascade -> tally -> 4-byte packed assignment per read (mrg_pack_assignments) -> D2H (packed words, count "
+                     "cascade (mrg_cascade_run_packed: 4-byte packed assignment per read) -> tally -> D2H (packed words, count "
                      "vector); %d chunks through %d device buffers on three HIP streams (copy in / compute / copy out); "
                      "H2D-bound: 12-13 B per read up, 4 B down"
                      % (" + lengths" if send_lens else "; one read length: no length array", n_chunks, n_bufs))

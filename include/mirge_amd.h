@@ -290,6 +290,23 @@ int mrg_cascade_run(mrg_ctx *ctx, const uint64_t *d_reads, uint32_t words_per_re
 #define MRG_PACKED_POS_SAT 0xFFu
 int mrg_pack_assignments(mrg_ctx *ctx, const int8_t *d_pass_id, const int32_t *d_ref_id, const int32_t *d_pos,
                          const uint8_t *d_mm, uint64_t n, uint32_t *d_packed, void *stream);
+/* The cascade with the packed word as its ONLY per-read output (every kernel writes d_packed[r]
+ * instead of the four arrays: 4 bytes out per read, what SURVEY.md 8d's byte accounting assumes), and
+ * the two tallies reading it.  Same semantics otherwise; the saturation rules above apply (the count
+ * tally needs entries of the miRNA library only, the edit tally their offsets too: always exact). */
+int mrg_cascade_run_packed(mrg_ctx *ctx, const uint64_t *d_reads, uint32_t words_per_read, const uint8_t *d_lens,
+                           const uint64_t *d_nmask, uint64_t n, const mrg_pass_cfg *passes, uint32_t n_pass,
+                           uint32_t *d_packed, uint64_t *d_pass_counts, void *d_workspace, uint64_t workspace_bytes,
+                           void *stream);
+int mrg_tally_run_packed(mrg_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_quant, uint64_t n, uint32_t n_samples,
+                         uint32_t n_mirna, uint32_t n_pass, int32_t canon_pass, int32_t isomir_pass, uint64_t *d_counts,
+                         void *stream);
+int mrg_edit_tally_run_packed(mrg_ctx *ctx, const uint64_t *d_reads, uint32_t words_per_read, const uint8_t *d_lens,
+                              const uint64_t *d_nmask, const uint32_t *d_packed, const uint32_t *d_quant,
+                              const uint8_t *d_keep, const uint32_t *d_remap, uint64_t n, uint32_t n_samples,
+                              uint32_t n_bins, int32_t lib, int32_t canon_pass, int32_t isomir_pass, int32_t isomir_trim5,
+                              uint32_t flank5, uint32_t flank3, uint32_t from_base, uint32_t to_base, uint64_t *d_counts,
+                              void *stream);
 /* Number of cascade runs this context has launched (a caller that reads statistics later can tell
  * whether they are still those of its own run). */
 int mrg_cascade_run_id(const mrg_ctx *ctx, uint64_t *run_id);

@@ -92,6 +92,14 @@ SIGNATURES = {
                                   C.c_uint64, C.c_void_p]),
     "mrg_pack_assignments": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
                                        C.c_void_p]),
+    "mrg_cascade_run_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(PassCfg),
+                                         C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "mrg_tally_run_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                       C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mrg_edit_tally_run_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
+                                            C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                            C.c_void_p]),
     "mrg_cascade_run_id": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "mrg_cascade_stats": (C.c_int, [C.c_void_p, C.POINTER(PassStats), C.c_uint32]),
     "mrg_tally_counts_len": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32,

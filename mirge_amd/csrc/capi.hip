@@ -742,14 +742,19 @@ int get_seed_lib(mrg_ctx* ctx, const std::vector<int32_t>& lib_ids, SeedLib** ou
 }
 }  // namespace
 
-int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_read,
+}  // extern "C"
+
+namespace {
+// mrg_cascade_run / mrg_cascade_run_packed: d_packed != null = the one-array output form
+int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_read,
                     const uint8_t* d_lens, const uint64_t* d_nmask, uint64_t n,
                     const mrg_pass_cfg* passes, uint32_t n_pass, int8_t* d_pass_id,
-                    int32_t* d_ref_id, int32_t* d_pos, uint8_t* d_mm, uint64_t* d_pass_counts,
+                    int32_t* d_ref_id, int32_t* d_pos, uint8_t* d_mm, uint32_t* d_packed, uint64_t* d_pass_counts,
                     void* d_workspace, uint64_t workspace_bytes, void* stream_) {
   if (!ctx || !passes || !d_workspace) return fail(MRG_ERR_ARG, "mrg_cascade_run: null argument");
-  if (n && (!d_reads || !d_lens || !d_pass_id || !d_ref_id || !d_pos || !d_mm))
+  if (n && (!d_reads || !d_lens || (!d_packed && (!d_pass_id || !d_ref_id || !d_pos || !d_mm))))
     return fail(MRG_ERR_ARG, "mrg_cascade_run: null read/output buffers");
+  if (d_packed && n_pass > 15) return fail(MRG_ERR_ARG, "mrg_cascade_run_packed: at most 15 passes fit the packed word");
   if (n_pass == 0 || n_pass > MRG_MAX_PASSES)
     return fail(MRG_ERR_ARG, "mrg_cascade_run: n_pass %u not in [1,%d]", n_pass, MRG_MAX_PASSES);
   if (words_per_read != 1 && words_per_read != 2 && words_per_read != 4)
@@ -874,6 +879,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
       e.ref_id = d_ref_id;
       e.pos = d_pos;
       e.mm = d_mm;
+      e.packed = d_packed;
       e.counters = stats + (size_t)i * kStatsPerPass;
       e.seed_len = c.seed_len;
       e.max_mm_total = c.max_mm_total;
@@ -944,6 +950,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     p.ref_id = d_ref_id;
     p.pos = d_pos;
     p.mm = d_mm;
+    p.packed = d_packed;
     p.counters = stats + (size_t)i * kStatsPerPass;
     p.seed_len = c.seed_len;
     p.max_mm_seed = c.max_mm_seed;
@@ -1229,6 +1236,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     fp.ref_id = d_ref_id;
     fp.pos = d_pos;
     fp.mm = d_mm;
+    fp.packed = d_packed;
     fp.wstop = (uint32_t)ctx->wstop;
     const uint32_t lds_total = kb_words * 4u + (uint32_t)fixed;
     // 128 VGPRs per lane (no spills in the pipelined walk): 16 waves = one workgroup per CU
@@ -1335,6 +1343,7 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
     sp.ref_id = d_ref_id;
     sp.pos = d_pos;
     sp.mm = d_mm;
+    sp.packed = d_packed;
     {
       // which instantiation the launch gets: mrg_pass_stats.lds_mode 8 = seed_kernel<false, 8>, 9 = <true, 6>
       bool with_buckets = false;
@@ -1478,6 +1487,24 @@ int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
   ctx->hint_max_len = 255;
   return MRG_OK;
 }
+}  // namespace
+
+extern "C" {
+
+int mrg_cascade_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_read, const uint8_t* d_lens, const uint64_t* d_nmask,
+                    uint64_t n, const mrg_pass_cfg* passes, uint32_t n_pass, int8_t* d_pass_id, int32_t* d_ref_id, int32_t* d_pos,
+                    uint8_t* d_mm, uint64_t* d_pass_counts, void* d_workspace, uint64_t workspace_bytes, void* stream) {
+  return cascade_run_impl(ctx, d_reads, words_per_read, d_lens, d_nmask, n, passes, n_pass, d_pass_id, d_ref_id, d_pos, d_mm, nullptr,
+                          d_pass_counts, d_workspace, workspace_bytes, stream);
+}
+
+int mrg_cascade_run_packed(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_read, const uint8_t* d_lens,
+                           const uint64_t* d_nmask, uint64_t n, const mrg_pass_cfg* passes, uint32_t n_pass, uint32_t* d_packed,
+                           uint64_t* d_pass_counts, void* d_workspace, uint64_t workspace_bytes, void* stream) {
+  if (n && !d_packed) return fail(MRG_ERR_ARG, "mrg_cascade_run_packed: null output buffer");
+  return cascade_run_impl(ctx, d_reads, words_per_read, d_lens, d_nmask, n, passes, n_pass, nullptr, nullptr, nullptr, nullptr,
+                          d_packed, d_pass_counts, d_workspace, workspace_bytes, stream);
+}
 
 int mrg_pack_assignments(mrg_ctx* ctx, const int8_t* d_pass_id, const int32_t* d_ref_id, const int32_t* d_pos, const uint8_t* d_mm,
                          uint64_t n, uint32_t* d_packed, void* stream) {
@@ -1529,17 +1556,21 @@ int mrg_tally_counts_len(uint32_t n_mirna, uint32_t n_samples, uint32_t n_pass, 
   return MRG_OK;
 }
 
-int mrg_tally_run(mrg_ctx* ctx, const int8_t* d_pass_id, const int32_t* d_ref_id,
+}  // extern "C"
+
+namespace {
+int tally_run_impl(mrg_ctx* ctx, const int8_t* d_pass_id, const int32_t* d_ref_id, const uint32_t* d_packed,
                   const uint32_t* d_quant, uint64_t n, uint32_t n_samples, uint32_t n_mirna,
                   uint32_t n_pass, int32_t canon_pass, int32_t isomir_pass, uint64_t* d_counts,
                   void* stream_) {
   if (!ctx || !d_counts) return fail(MRG_ERR_ARG, "mrg_tally_run: null argument");
-  if (n && (!d_pass_id || !d_ref_id || !d_quant)) return fail(MRG_ERR_ARG, "mrg_tally_run: null buffers");
+  if (n && ((!d_packed && (!d_pass_id || !d_ref_id)) || !d_quant)) return fail(MRG_ERR_ARG, "mrg_tally_run: null buffers");
   if (n_samples == 0 || n_pass == 0 || n_pass > MRG_MAX_PASSES)
     return fail(MRG_ERR_ARG, "mrg_tally_run: bad n_samples/n_pass");
   HIP_TRY(hipSetDevice(ctx->device));
   if (n == 0) return MRG_OK;
   mrg::TallyParams p;
+  p.packed = d_packed;
   p.pass_id = d_pass_id;
   p.ref_id = d_ref_id;
   p.quant = d_quant;
@@ -1550,7 +1581,8 @@ int mrg_tally_run(mrg_ctx* ctx, const int8_t* d_pass_id, const int32_t* d_ref_id
   p.canon_pass = canon_pass;
   p.isomir_pass = isomir_pass;
   p.counts = d_counts;
-  p.vec4 = (n_samples == 1 && ((uintptr_t)d_pass_id % 4 == 0) && ((uintptr_t)d_ref_id % 16 == 0) && ((uintptr_t)d_quant % 16 == 0)) ? 1u : 0u;
+  const bool in_ok = d_packed ? ((uintptr_t)d_packed % 16 == 0) : (((uintptr_t)d_pass_id % 4 == 0) && ((uintptr_t)d_ref_id % 16 == 0));
+  p.vec4 = (n_samples == 1 && in_ok && ((uintptr_t)d_quant % 16 == 0)) ? 1u : 0u;
   uint64_t bins = 0;
   mrg_tally_counts_len(n_mirna, n_samples, n_pass, &bins);
   // LDS histogram: the category bins are replicated (kernels.hip: tally_kernel)
@@ -1561,6 +1593,21 @@ int mrg_tally_run(mrg_ctx* ctx, const int8_t* d_pass_id, const int32_t* d_ref_id
   uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)ctx->n_cu * per_cu);
   HIP_TRY(mrg::launch_tally(p, lds_hist, grid, lds_hist ? (uint32_t)lds : 0u, (hipStream_t)stream_));
   return MRG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mrg_tally_run(mrg_ctx* ctx, const int8_t* d_pass_id, const int32_t* d_ref_id, const uint32_t* d_quant, uint64_t n,
+                  uint32_t n_samples, uint32_t n_mirna, uint32_t n_pass, int32_t canon_pass, int32_t isomir_pass, uint64_t* d_counts,
+                  void* stream) {
+  return tally_run_impl(ctx, d_pass_id, d_ref_id, nullptr, d_quant, n, n_samples, n_mirna, n_pass, canon_pass, isomir_pass, d_counts, stream);
+}
+
+int mrg_tally_run_packed(mrg_ctx* ctx, const uint32_t* d_packed, const uint32_t* d_quant, uint64_t n, uint32_t n_samples,
+                         uint32_t n_mirna, uint32_t n_pass, int32_t canon_pass, int32_t isomir_pass, uint64_t* d_counts, void* stream) {
+  if (n && !d_packed) return fail(MRG_ERR_ARG, "mrg_tally_run_packed: null buffers");
+  return tally_run_impl(ctx, nullptr, nullptr, d_packed, d_quant, n, n_samples, n_mirna, n_pass, canon_pass, isomir_pass, d_counts, stream);
 }
 
 // ------------------------------------------------------------ multi-GPU (RCCL over xGMI)
@@ -1629,14 +1676,17 @@ int mrg_edit_counts_len(uint32_t n_bins, uint32_t n_samples, uint64_t* len) {
   return MRG_OK;
 }
 
-int mrg_edit_tally_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_read, const uint8_t* d_lens,
+}  // extern "C"
+
+namespace {
+int edit_tally_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_read, const uint8_t* d_lens,
                        const uint64_t* d_nmask, const int8_t* d_pass_id, const int32_t* d_ref_id,
-                       const int32_t* d_pos, const uint32_t* d_quant, const uint8_t* d_keep,
+                       const int32_t* d_pos, const uint32_t* d_packed, const uint32_t* d_quant, const uint8_t* d_keep,
                        const uint32_t* d_remap, uint64_t n, uint32_t n_samples, uint32_t n_bins, int32_t lib,
                        int32_t canon_pass, int32_t isomir_pass, int32_t isomir_trim5, uint32_t flank5,
                        uint32_t flank3, uint32_t from_base, uint32_t to_base, uint64_t* d_counts, void* stream) {
   if (!ctx || !d_counts) return fail(MRG_ERR_ARG, "mrg_edit_tally_run: null argument");
-  if (n && (!d_reads || !d_lens || !d_pass_id || !d_ref_id || !d_pos || !d_quant))
+  if (n && (!d_reads || !d_lens || (!d_packed && (!d_pass_id || !d_ref_id || !d_pos)) || !d_quant))
     return fail(MRG_ERR_ARG, "mrg_edit_tally_run: null buffers");
   if (lib < 0 || (size_t)lib >= ctx->libs.size()) return fail(MRG_ERR_ARG, "mrg_edit_tally_run: unknown library %d", lib);
   if (words_per_read != 1 && words_per_read != 2 && words_per_read != 4)
@@ -1657,6 +1707,7 @@ int mrg_edit_tally_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per
   p.lens = d_lens;
   p.nmask = d_nmask;
   p.words_per_read = words_per_read;
+  p.packed = d_packed;
   p.pass_id = d_pass_id;
   p.ref_id = d_ref_id;
   p.pos = d_pos;
@@ -1676,8 +1727,9 @@ int mrg_edit_tally_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per
   p.text = l.text;
   p.seg_start = l.seg_start;
   p.counts = d_counts;
-  p.vec4 = (n_samples == 1 && words_per_read == 1 && ((uintptr_t)d_reads % 16 == 0) && ((uintptr_t)d_lens % 4 == 0) &&
-            ((uintptr_t)d_pass_id % 4 == 0) && ((uintptr_t)d_ref_id % 16 == 0) && ((uintptr_t)d_pos % 16 == 0) &&
+  const bool in_ok = d_packed ? ((uintptr_t)d_packed % 16 == 0)
+                              : (((uintptr_t)d_pass_id % 4 == 0) && ((uintptr_t)d_ref_id % 16 == 0) && ((uintptr_t)d_pos % 16 == 0));
+  p.vec4 = (n_samples == 1 && words_per_read == 1 && ((uintptr_t)d_reads % 16 == 0) && ((uintptr_t)d_lens % 4 == 0) && in_ok &&
             ((uintptr_t)d_quant % 16 == 0))
                ? 1u
                : 0u;
@@ -1696,6 +1748,30 @@ int mrg_edit_tally_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per
   const uint32_t grid = (uint32_t)std::min<uint64_t>(want, (uint64_t)ctx->n_cu * per_cu);
   HIP_TRY(mrg::launch_edit_tally(p, lds_hist, lds_lib, grid, (uint32_t)lds, (hipStream_t)stream));
   return MRG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mrg_edit_tally_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_read, const uint8_t* d_lens, const uint64_t* d_nmask,
+                       const int8_t* d_pass_id, const int32_t* d_ref_id, const int32_t* d_pos, const uint32_t* d_quant,
+                       const uint8_t* d_keep, const uint32_t* d_remap, uint64_t n, uint32_t n_samples, uint32_t n_bins, int32_t lib,
+                       int32_t canon_pass, int32_t isomir_pass, int32_t isomir_trim5, uint32_t flank5, uint32_t flank3,
+                       uint32_t from_base, uint32_t to_base, uint64_t* d_counts, void* stream) {
+  return edit_tally_impl(ctx, d_reads, words_per_read, d_lens, d_nmask, d_pass_id, d_ref_id, d_pos, nullptr, d_quant, d_keep, d_remap, n,
+                         n_samples, n_bins, lib, canon_pass, isomir_pass, isomir_trim5, flank5, flank3, from_base, to_base, d_counts,
+                         stream);
+}
+
+int mrg_edit_tally_run_packed(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_read, const uint8_t* d_lens,
+                              const uint64_t* d_nmask, const uint32_t* d_packed, const uint32_t* d_quant, const uint8_t* d_keep,
+                              const uint32_t* d_remap, uint64_t n, uint32_t n_samples, uint32_t n_bins, int32_t lib, int32_t canon_pass,
+                              int32_t isomir_pass, int32_t isomir_trim5, uint32_t flank5, uint32_t flank3, uint32_t from_base,
+                              uint32_t to_base, uint64_t* d_counts, void* stream) {
+  if (n && !d_packed) return fail(MRG_ERR_ARG, "mrg_edit_tally_run_packed: null buffers");
+  return edit_tally_impl(ctx, d_reads, words_per_read, d_lens, d_nmask, nullptr, nullptr, nullptr, d_packed, d_quant, d_keep, d_remap, n,
+                         n_samples, n_bins, lib, canon_pass, isomir_pass, isomir_trim5, flank5, flank3, from_base, to_base, d_counts,
+                         stream);
 }
 
 // ------------------------------------------------------------ count best

@@ -271,7 +271,22 @@ __global__ void __launch_bounds__(kBlock, 8) exact_dict_kernel(const ExactParams
       c_aligned += aligned[u] ? 1u : 0u;
       n_surv += (active[u] && !aligned[u]) ? 1u : 0u;
     }
-    if (FIRST && full) {
+    if (p.packed) {
+      // the one output array: 16 bytes per quartet instead of 40
+      if (FIRST && full) {
+        typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+        u4_t w;
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = aligned[u] ? pack_assignment(p.pass_index, o_ref[u], o_pos[u], o_mm[u]) : 0u;
+        *reinterpret_cast<u4_t*>(p.packed + t0) = w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (aligned[u]) p.packed[r[u]] = pack_assignment(p.pass_index, o_ref[u], o_pos[u], o_mm[u]);
+          else if (active[u] && (FIRST || !p.idx_out)) p.packed[r[u]] = 0u;
+        }
+      }
+    } else if (FIRST && full) {
       uint32_t pid = 0, mmv = 0;
       int4_t refs, poss;
 #pragma unroll
@@ -889,7 +904,10 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
           }
         }
       }
-      if (claimed) {
+      if (p.packed) {
+        if (claimed) p.packed[r] = pack_assignment(cp, o_ref, o_pos, (uint32_t)((key >> 48) & 255u));
+        else if (active && !p.idx_out) p.packed[r] = 0u;
+      } else if (claimed) {
         p.pass_id[r] = (int8_t)cp;
         p.ref_id[r] = (int32_t)o_ref;
         p.pos[r] = (int32_t)o_pos;
@@ -948,8 +966,7 @@ __global__ void __launch_bounds__(256) pack_assignments_kernel(const int8_t* __r
                                                                const int32_t* __restrict__ pos, const uint8_t* __restrict__ mm, uint64_t n,
                                                                uint32_t* __restrict__ packed, uint32_t vec) {
   auto pack = [](int32_t pi, int32_t ref, int32_t ps, uint32_t m) -> uint32_t {
-    if (pi < 0) return 0u;
-    return ((uint32_t)(pi + 1) << 28) | (min(m, 3u) << 26) | (min((uint32_t)ref, 0x3FFFFu) << 8) | min((uint32_t)ps, 0xFFu);
+    return pi < 0 ? 0u : pack_assignment(pi, (uint32_t)ref, (uint32_t)ps, m);
   };
   const uint64_t quads = n / 4;
   for (uint64_t q = (uint64_t)blockIdx.x * 256u + threadIdx.x; vec && q < quads; q += (uint64_t)gridDim.x * 256u) {
@@ -1005,8 +1022,10 @@ hipError_t launch_seed(const SeedParams& p, uint32_t grid, hipStream_t stream) {
 
 hipError_t launch_exact_dict(const ExactParams& p, uint32_t grid, hipStream_t stream) {
   // the streaming instantiation needs the identity list and arrays it can address 16 bytes at a time
-  const bool first = !p.idx_in && ((uintptr_t)p.reads % 16 == 0) && ((uintptr_t)p.lens % 4 == 0) && ((uintptr_t)p.pass_id % 4 == 0) &&
-                     ((uintptr_t)p.mm % 4 == 0) && ((uintptr_t)p.ref_id % 16 == 0) && ((uintptr_t)p.pos % 16 == 0);
+  const bool out_ok = p.packed ? ((uintptr_t)p.packed % 16 == 0)
+                               : (((uintptr_t)p.pass_id % 4 == 0) && ((uintptr_t)p.mm % 4 == 0) && ((uintptr_t)p.ref_id % 16 == 0) &&
+                                  ((uintptr_t)p.pos % 16 == 0));
+  const bool first = !p.idx_in && ((uintptr_t)p.reads % 16 == 0) && ((uintptr_t)p.lens % 4 == 0) && out_ok;
   const bool kb = p.kbits != nullptr && p.key_bases >= kKmerBitsK;
   if (first && kb) hipLaunchKernelGGL((exact_dict_kernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, p);
   else if (first) hipLaunchKernelGGL((exact_dict_kernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, p);

@@ -510,16 +510,24 @@ match_kernel(const MatchParams p) {
         }
         pos = s - p.seg_start[sg] + off;
       }
-      p.pass_id[r] = (int8_t)p.pass_index;
-      p.ref_id[r] = (int32_t)ref;
-      p.pos[r] = (int32_t)pos;
-      p.mm[r] = (uint8_t)(best >> 32);
+      if (p.packed) {
+        p.packed[r] = pack_assignment(p.pass_index, ref, pos, (uint32_t)(best >> 32));
+      } else {
+        p.pass_id[r] = (int8_t)p.pass_index;
+        p.ref_id[r] = (int32_t)ref;
+        p.pos[r] = (int32_t)pos;
+        p.mm[r] = (uint8_t)(best >> 32);
+      }
     } else if (active && !p.idx_out) {
       // last pass: whatever is still unclaimed stays unannotated (no memset needed)
-      p.pass_id[r] = (int8_t)-1;
-      p.ref_id[r] = -1;
-      p.pos[r] = -1;
-      p.mm[r] = 0;
+      if (p.packed) {
+        p.packed[r] = 0u;
+      } else {
+        p.pass_id[r] = (int8_t)-1;
+        p.ref_id[r] = -1;
+        p.pos[r] = -1;
+        p.mm[r] = 0;
+      }
     }
 
     // ---- survivors of this pass feed the next one ----
@@ -1262,20 +1270,28 @@ __global__ void __launch_bounds__(1024, 4) fused_kernel(const FusedParams p) {
           }
           pos = st - seg_start[sg] + off;
         }
-        p.pass_id[r] = (int8_t)tab[SW_PASSIDX];
-        p.ref_id[r] = (int32_t)ref;
-        p.pos[r] = (int32_t)pos;
-        p.mm[r] = (uint8_t)(win_key >> 56);
+        if (p.packed) {
+          p.packed[r] = pack_assignment((int32_t)tab[SW_PASSIDX], ref, pos, (uint32_t)(win_key >> 56));
+        } else {
+          p.pass_id[r] = (int8_t)tab[SW_PASSIDX];
+          p.ref_id[r] = (int32_t)ref;
+          p.pos[r] = (int32_t)pos;
+          p.mm[r] = (uint8_t)(win_key >> 56);
+        }
         claimed = true;
       }
     }
 
     if (active && !claimed && !p.idx_out) {
       // the group ends the cascade: whatever is still unclaimed stays unannotated
-      p.pass_id[r] = (int8_t)-1;
-      p.ref_id[r] = -1;
-      p.pos[r] = -1;
-      p.mm[r] = 0;
+      if (p.packed) {
+        p.packed[r] = 0u;
+      } else {
+        p.pass_id[r] = (int8_t)-1;
+        p.ref_id[r] = -1;
+        p.pos[r] = -1;
+        p.mm[r] = 0;
+      }
     }
     if (p.idx_out) {
       const bool survive = active && !claimed;
@@ -1601,15 +1617,23 @@ __global__ void __launch_bounds__(1024, (W == 1 ? 8 : 4)) stratum_kernel(const M
         }
         pos = s - p.seg_start[sg] + off;
       }
-      p.pass_id[r] = (int8_t)p.pass_index;
-      p.ref_id[r] = (int32_t)ref;
-      p.pos[r] = (int32_t)pos;
-      p.mm[r] = (uint8_t)(best >> 56);
+      if (p.packed) {
+        p.packed[r] = pack_assignment(p.pass_index, ref, pos, (uint32_t)(best >> 56));
+      } else {
+        p.pass_id[r] = (int8_t)p.pass_index;
+        p.ref_id[r] = (int32_t)ref;
+        p.pos[r] = (int32_t)pos;
+        p.mm[r] = (uint8_t)(best >> 56);
+      }
     } else if (active && !p.idx_out) {
-      p.pass_id[r] = (int8_t)-1;
-      p.ref_id[r] = -1;
-      p.pos[r] = -1;
-      p.mm[r] = 0;
+      if (p.packed) {
+        p.packed[r] = 0u;
+      } else {
+        p.pass_id[r] = (int8_t)-1;
+        p.ref_id[r] = -1;
+        p.pos[r] = -1;
+        p.mm[r] = 0;
+      }
     }
     if (p.idx_out) {
       const bool survive = active && !aligned;
@@ -1856,6 +1880,7 @@ __global__ void __launch_bounds__(kTallyThreads) tally_kernel(const TallyParams 
     const uint64_t n4_round = ((n4 + kTallyThreads - 1) / kTallyThreads) * kTallyThreads;
     const uint32_t* pass4 = reinterpret_cast<const uint32_t*>(p.pass_id);
     const uint4* ref4 = reinterpret_cast<const uint4*>(p.ref_id);
+    const uint4* packed4 = reinterpret_cast<const uint4*>(p.packed);
     const uint4* quant4 = reinterpret_cast<const uint4*>(p.quant);
     for (uint64_t g4 = (uint64_t)blockIdx.x * kTallyThreads + threadIdx.x; g4 < n4_round;
          g4 += (uint64_t)gridDim.x * kTallyThreads) {
@@ -1863,8 +1888,16 @@ __global__ void __launch_bounds__(kTallyThreads) tally_kernel(const TallyParams 
       uint32_t pw = 0xFFFFFFFFu;
       uint4 rf = make_uint4(0u, 0u, 0u, 0u), qv = make_uint4(0u, 0u, 0u, 0u);
       if (active) {
-        pw = pass4[g4];
-        rf = ref4[g4];
+        if (p.packed) {
+          // one 16-byte load of packed words instead of 4 + 16 bytes of pass ids and entries
+          const uint4 k = packed4[g4];
+          pw = (((k.x >> 28) - 1u) & 0xFFu) | ((((k.y >> 28) - 1u) & 0xFFu) << 8) | ((((k.z >> 28) - 1u) & 0xFFu) << 16) |
+               ((((k.w >> 28) - 1u) & 0xFFu) << 24);
+          rf = make_uint4((k.x >> 8) & 0x3FFFFu, (k.y >> 8) & 0x3FFFFu, (k.z >> 8) & 0x3FFFFu, (k.w >> 8) & 0x3FFFFu);
+        } else {
+          pw = pass4[g4];
+          rf = ref4[g4];
+        }
         qv = quant4[g4];
       }
       add(active, (int32_t)(int8_t)(pw & 0xFFu), rf.x, qv.x, 0u);
@@ -1880,9 +1913,10 @@ __global__ void __launch_bounds__(kTallyThreads) tally_kernel(const TallyParams 
        k += (uint64_t)gridDim.x * kTallyThreads) {
     const uint64_t r = r_first + k;
     const bool active = k < n_rest;  // whole waves stay in the loop: ballots
-    const int32_t pass = active ? p.pass_id[r] : -1;
+    const uint32_t pk = (active && p.packed) ? p.packed[r] : 0u;
+    const int32_t pass = !active ? -1 : (p.packed ? (int32_t)(pk >> 28) - 1 : (int32_t)p.pass_id[r]);
     const bool wants_ref = active && pass >= 0 && (pass == p.canon_pass || pass == p.isomir_pass);
-    const uint32_t ref = wants_ref ? (uint32_t)p.ref_id[r] : 0u;
+    const uint32_t ref = wants_ref ? (p.packed ? (pk >> 8) & 0x3FFFFu : (uint32_t)p.ref_id[r]) : 0u;
     for (uint32_t s = 0; s < S; ++s) add(active, pass, ref, active ? p.quant[r * S + s] : 0ull, s);
   }
   if (LDSH) {
@@ -2067,9 +2101,20 @@ __global__ void __launch_bounds__(kEditThreads) edit_tally_kernel(const EditPara
     // (4-byte loads of the pass ids and lengths, 16-byte loads of everything else)
     const uint64_t n4 = p.n >> 2;
     for (uint64_t g4 = (uint64_t)blockIdx.x * kEditThreads + threadIdx.x; g4 < n4; g4 += (uint64_t)gridDim.x * kEditThreads) {
-      const uint32_t pw = reinterpret_cast<const uint32_t*>(p.pass_id)[g4];
+      uint32_t pw;
+      uint4 ev, pv;
+      if (p.packed) {
+        const uint4 k = reinterpret_cast<const uint4*>(p.packed)[g4];
+        pw = (((k.x >> 28) - 1u) & 0xFFu) | ((((k.y >> 28) - 1u) & 0xFFu) << 8) | ((((k.z >> 28) - 1u) & 0xFFu) << 16) |
+             ((((k.w >> 28) - 1u) & 0xFFu) << 24);
+        ev = make_uint4((k.x >> 8) & 0x3FFFFu, (k.y >> 8) & 0x3FFFFu, (k.z >> 8) & 0x3FFFFu, (k.w >> 8) & 0x3FFFFu);
+        pv = make_uint4(k.x & 0xFFu, k.y & 0xFFu, k.z & 0xFFu, k.w & 0xFFu);
+      } else {
+        pw = reinterpret_cast<const uint32_t*>(p.pass_id)[g4];
+        ev = reinterpret_cast<const uint4*>(p.ref_id)[g4];
+        pv = reinterpret_cast<const uint4*>(p.pos)[g4];
+      }
       const uint32_t lw = reinterpret_cast<const uint32_t*>(p.lens)[g4];
-      const uint4 ev = reinterpret_cast<const uint4*>(p.ref_id)[g4], pv = reinterpret_cast<const uint4*>(p.pos)[g4];
       const uint4 qv = reinterpret_cast<const uint4*>(p.quant)[g4];
       const uint4 ra = reinterpret_cast<const uint4*>(p.reads)[2 * g4], rb = reinterpret_cast<const uint4*>(p.reads)[2 * g4 + 1];
       const uint64_t r = g4 << 2;
@@ -2083,8 +2128,14 @@ __global__ void __launch_bounds__(kEditThreads) edit_tally_kernel(const EditPara
     }
     r_first = n4 << 2;
   }
-  for (uint64_t r = r_first + (uint64_t)blockIdx.x * kEditThreads + threadIdx.x; r < p.n; r += (uint64_t)gridDim.x * kEditThreads)
-    one(r, (int32_t)p.pass_id[r], (uint32_t)p.ref_id[r], (int32_t)p.lens[r], p.pos[r], p.reads[r], false, 0ull);
+  for (uint64_t r = r_first + (uint64_t)blockIdx.x * kEditThreads + threadIdx.x; r < p.n; r += (uint64_t)gridDim.x * kEditThreads) {
+    if (p.packed) {
+      const uint32_t k = p.packed[r];
+      one(r, (int32_t)(k >> 28) - 1, (k >> 8) & 0x3FFFFu, (int32_t)p.lens[r], (int32_t)(k & 0xFFu), p.reads[r], false, 0ull);
+    } else {
+      one(r, (int32_t)p.pass_id[r], (uint32_t)p.ref_id[r], (int32_t)p.lens[r], p.pos[r], p.reads[r], false, 0ull);
+    }
+  }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < kEditHashSlots; i += kEditThreads)
     if (hk[i] != 0xFFFFFFFFu && hv[i]) atomicAdd(&gpos[hk[i]], hv[i]);

@@ -24,6 +24,12 @@ constexpr uint32_t kMaxSegments = 2048u;
 constexpr uint64_t kListSlack = 1ull << 23;
 constexpr uint32_t kMatchCtlBytes = (4u + 4u * 16u + 10u) * 4u;  // control words, 16 B per wave, 5 counters
 
+// Packed assignment (include/mirge_amd.h: mrg_pack_assignments / mrg_cascade_run_packed): one word per read.
+// Kernels that are handed a `packed` array write it INSTEAD of pass_id / ref_id / pos / mm.
+__host__ __device__ inline uint32_t pack_assignment(int32_t pass, uint32_t ref, uint32_t pos, uint32_t mm) {
+  return ((uint32_t)(pass + 1) << 28) | ((mm < 3u ? mm : 3u) << 26) | ((ref < 0x3FFFFu ? ref : 0x3FFFFu) << 8) | (pos < 0xFFu ? pos : 0xFFu);
+}
+
 // The jump tables of one library in ascending k (k[0] = 0: tables not used; a missing big table
 // repeats the main one), with the word offset of each inside `ftab`.
 struct JumpTables {
@@ -63,6 +69,7 @@ struct MatchParams {
   int32_t* ref_id;
   int32_t* pos;
   uint8_t* mm;
+  uint32_t* packed;    // non-null: the one output array (the four above are not touched)
   uint64_t* counters;  // processed, aligned, steps, candidates, lookups of this pass
   // policy
   int32_t seed_len, max_mm_seed, max_mm_total, trim5, trim3, min_len, max_len, poly_t;
@@ -155,6 +162,7 @@ struct FusedParams {
   int32_t* ref_id;
   int32_t* pos;
   uint8_t* mm;
+  uint32_t* packed;  // non-null: the one output array
   uint32_t wstop;
   // rounds: runs of sub-passes whose seed pieces are looked up together (speculatively across the
   // sub-passes of the run; the owner replays the results in cascade order)
@@ -221,6 +229,7 @@ struct ExactParams {
   int32_t* ref_id;
   int32_t* pos;
   uint8_t* mm;
+  uint32_t* packed;    // non-null: the one output array
   uint64_t* counters;  // processed, aligned, steps (0), candidates (slots / rows compared), lookups (slot + table loads)
   int32_t seed_len, max_mm_total, trim5, trim3, min_len, max_len, poly_t, pass_index;
 };
@@ -294,6 +303,7 @@ struct SeedParams {
   int32_t* ref_id;
   int32_t* pos;
   uint8_t* mm;
+  uint32_t* packed;  // non-null: the one output array
 };
 uint32_t seed_lds_bytes(const SeedParams& p);
 // workgroups per CU the instantiation a launch gets can keep resident (registers; LDS permitting)
@@ -332,6 +342,7 @@ struct CountParams {
 };
 
 struct TallyParams {
+  const uint32_t* packed;  // non-null: pass and entry come from the packed words (pass_id / ref_id unused)
   const int8_t* pass_id;
   const int32_t* ref_id;
   const uint32_t* quant;
@@ -351,6 +362,7 @@ struct EditParams {
   const uint8_t* lens;
   const uint64_t* nmask;  // may be null
   uint32_t words_per_read;
+  const uint32_t* packed;  // non-null: pass, entry and offset come from the packed words
   const int8_t* pass_id;
   const int32_t* ref_id;
   const int32_t* pos;

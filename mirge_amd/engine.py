@@ -83,8 +83,9 @@ class ReadSet:
 
 
 class CascadeResult:
-    def __init__(self, pass_id, ref_id, pos, mm, pass_counts, engine, n_pass):
+    def __init__(self, pass_id, ref_id, pos, mm, pass_counts, engine, n_pass, packed=None):
         self.pass_id, self.ref_id, self.pos, self.mm = pass_id, ref_id, pos, mm
+        self.packed = packed            # device int32 [n] (Engine.cascade_packed): then the four arrays are None
         self.pass_counts = pass_counts  # device int64 [2*n_pass]: processed, aligned
         self._engine = engine
         self.n_pass = n_pass
@@ -102,6 +103,8 @@ class CascadeResult:
         return self._stats
 
     def to_host(self):
+        if self.packed is not None:   # (entries and offsets saturate: unpack_assignments)
+            return unpack_assignments(self.packed.cpu().numpy())
         return (self.pass_id.cpu().numpy(), self.ref_id.cpu().numpy(), self.pos.cpu().numpy(),
                 self.mm.cpu().numpy())
 
@@ -234,6 +237,24 @@ class Engine:
         self.cascade(rs, passes)
         torch.cuda.synchronize(self.device)
 
+    def cascade_packed(self, reads, passes, out=None):
+        """The cascade with ONE 4-byte word per read as its per-read output (mrg_cascade_run_packed: every
+        kernel writes the packed assignment instead of pass_id / ref_id / pos / mm; SURVEY.md 8d's "4 B
+        packed assignment out").  out = (packed int32 [n], pass_counts int64 [2 n_pass])."""
+        torch = _torch()
+        n, n_pass = reads.n, len(passes)
+        if out is None:
+            out = (torch.empty(n, dtype=torch.int32, device=self.device), torch.zeros(2 * n_pass, dtype=torch.int64, device=self.device))
+        packed, pass_counts = out
+        ws = self._workspace(n)
+        self.set_option("hint_min_len", reads.min_len)
+        self.set_option("hint_max_len", reads.max_len)
+        check(self._lib.mrg_cascade_run_packed(
+            self._h, reads.words.data_ptr(), reads.W, reads.lens.data_ptr(),
+            reads.nmask.data_ptr() if reads.nmask is not None else None, n, passes, n_pass, packed.data_ptr(),
+            pass_counts.data_ptr(), ws.data_ptr(), ws.numel(), self._stream_ptr()))
+        return CascadeResult(None, None, None, None, pass_counts, self, n_pass, packed=packed)
+
     def _run_id(self):
         v = C.c_uint64()
         check(self._lib.mrg_cascade_run_id(self._h, C.byref(v)))
@@ -264,6 +285,11 @@ class Engine:
         ln = self.counts_len(n_mirna, S, result.n_pass)
         if counts is None:
             counts = torch.zeros(ln, dtype=torch.int64, device=self.device)
+        if getattr(result, "packed", None) is not None:
+            check(self._lib.mrg_tally_run_packed(
+                self._h, result.packed.data_ptr(), reads.quant.data_ptr(), reads.n, S, n_mirna, result.n_pass, canon_pass,
+                isomir_pass, counts.data_ptr(), self._stream_ptr()))
+            return counts
         check(self._lib.mrg_tally_run(
             self._h, result.pass_id.data_ptr(), result.ref_id.data_ptr(), reads.quant.data_ptr(),
             reads.n, S, n_mirna, result.n_pass, canon_pass, isomir_pass, counts.data_ptr(),
@@ -309,6 +335,14 @@ class Engine:
         ln = self.edit_counts_len(lib, S, nb)
         if counts is None:
             counts = torch.zeros(ln, dtype=torch.int64, device=self.device)
+        if getattr(result, "packed", None) is not None:
+            check(self._lib.mrg_edit_tally_run_packed(
+                self._h, reads.words.data_ptr(), reads.W, reads.lens.data_ptr(),
+                reads.nmask.data_ptr() if reads.nmask is not None else None, result.packed.data_ptr(), reads.quant.data_ptr(),
+                None if keep is None else keep.data_ptr(), None if remap is None else remap.data_ptr(), reads.n, S, nb,
+                self.libs[lib], canon_pass, isomir_pass, isomir_trim5, flank5, flank3, from_base, to_base,
+                counts.data_ptr(), self._stream_ptr()))
+            return counts
         check(self._lib.mrg_edit_tally_run(
             self._h, reads.words.data_ptr(), reads.W, reads.lens.data_ptr(),
             reads.nmask.data_ptr() if reads.nmask is not None else None, result.pass_id.data_ptr(),

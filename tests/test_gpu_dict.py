@@ -170,3 +170,42 @@ def test_packed_assignments_round_trip(engine, world):
     sub = CascadeResult(res.pass_id[1:1 + n], res.ref_id[1:1 + n], res.pos[1:1 + n], res.mm[1:1 + n], None, engine, 9)
     got = engine.pack_assignments(sub, out=torch.empty(n, dtype=torch.int32, device=engine.device)).cpu().numpy()
     assert np.array_equal(got, packed[1:1 + n])
+
+
+def test_packed_cascade_and_tallies_equal_the_four_array_form(engine, world, native_lib, oracle_lib):
+    """mrg_cascade_run_packed / mrg_tally_run_packed / mrg_edit_tally_run_packed: every kernel writes the
+    packed word instead of the four arrays, the tallies read it.  Equal to packing the four-array run, for
+    the dictionary kernels (this world), the FM kernels (`dict` = 0) and a batch with N and two-word reads."""
+    from mirge_amd import synth
+    from mirge_amd.engine import Engine, ReadSet, unpack_assignments, PACKED_POS_SAT, PACKED_REF_SAT
+
+    def check(eng, w):
+        quant = synth.synth_quant(len(w.lens), n_samples=1)
+        rs = ReadSet(w.words, w.lens, w.nmask, quant, device=eng.device)
+        passes = eng.mirge_passes()
+        full = eng.cascade(rs, passes)
+        c_full = eng.tally(rs, full, w.n_mirna).cpu().numpy()
+        e_full = eng.edit_tally(rs, full).cpu().numpy()
+        pk = eng.cascade_packed(rs, passes)
+        c_pk = eng.tally(rs, pk, w.n_mirna).cpu().numpy()
+        e_pk = eng.edit_tally(rs, pk).cpu().numpy()
+        assert np.array_equal(pk.packed.cpu().numpy(), eng.pack_assignments(full).cpu().numpy())
+        assert np.array_equal(c_pk, c_full) and np.array_equal(e_pk, e_full)
+        assert np.array_equal(pk.pass_counts.cpu().numpy(), full.pass_counts.cpu().numpy())
+        e_pass, e_ref, e_pos, e_mm = full.to_host()
+        u_pass, u_ref, u_pos, u_mm = pk.to_host()
+        assert np.array_equal(u_pass, e_pass) and np.array_equal(u_mm, np.minimum(e_mm, 3))
+        assert np.array_equal(u_ref, np.where(e_ref >= 0, np.minimum(e_ref, PACKED_REF_SAT), -1))
+        assert np.array_equal(u_pos, np.where(e_pos >= 0, np.minimum(e_pos, PACKED_POS_SAT), -1))
+
+    for dict_on in (1, 0):
+        engine.set_option("dict", dict_on)
+        check(engine, world)
+    engine.set_option("dict", 1)
+    w2 = World(scale=0.05, n_fixed=6000, n_var=2000)   # reads with N, up to 44 nt: the FM kernels, two words per read
+    assert w2.words.shape[0] == 2 and w2.nmask is not None
+    eng2 = Engine(0)
+    for k in LIB_ORDER:
+        eng2.add_library(k, w2.index[k])
+    check(eng2, w2)
+    eng2.close()
