@@ -463,6 +463,39 @@ int mrg_fastq_copy(const mrg_fastq *fq, uint32_t words_per_read, uint64_t *words
 void mrg_fastq_free(mrg_fastq *fq);
 
 /*
+ * The same ingest ON THE DEVICE for raw text (round 3): the host reads the file, cuts it into blocks
+ * of whole records (mrg_fastq_block_cut gives the offset of the last record boundary of a buffer:
+ * buf[0, cut) is a block, the rest is carried over; at_eof != 0 takes everything) and uploads them;
+ * mrg_fastq_parse_device splits the records, applies the 3' quality rule (phred = 33 or 64, as the
+ * first record's qualities decide: trim_file.py:104-110), the `-ad +N` cutter (cut > 0 drops the
+ * first `cut` bases, cut < 0 the last -cut; 0 = `-ad none`), the minimum length and the 2-bit packing
+ * -- the packed reads never exist on the host.  Kept reads come out in file order:
+ * d_words[w * cap + i], d_lens[i], d_nmask[w * cap + i] (may be NULL; info.has_n then says whether
+ * one was needed).  Strict four-line records only ('\n' or "\r\n", final newline optional):
+ * info.status != 0 (1-3: record info.bad_record, 1-based, is ill-formed -- not a '@' header or a
+ * blank line, no '+' line, sequence and quality of different length; 4: the line count is not a
+ * multiple of four; 5: more kept reads than `cap`) means nothing was packed: use mrg_fastq_load,
+ * which also accepts blank lines between records and words the errors as the reference's loader
+ * does.  info.n_long = kept reads longer than 32 * words_per_read bases (not packed: call again with
+ * more words).  An adapter SEQUENCE (`-ad illumina`, cutadapt's alignment) is host-only.
+ * Synchronises `stream`; at most 2^31 - 2 bytes per call.
+ */
+typedef struct mrg_fastq_device_info {
+  uint64_t n_records;  /* records in the block ("totalReads") */
+  uint64_t n_kept;     /* reads packed */
+  uint64_t n_long;     /* kept by the rules but longer than the words offered */
+  uint64_t bad_record;
+  uint32_t max_len;    /* longest packed read */
+  int32_t has_n;
+  int32_t status;
+  int32_t reserved;
+} mrg_fastq_device_info;
+int mrg_fastq_block_cut(const char *buf, uint64_t len, int32_t at_eof, uint64_t *cut);
+int mrg_fastq_parse_device(mrg_ctx *ctx, const char *d_text, uint64_t n_bytes, int32_t phred, int32_t qual_cutoff,
+                           int32_t min_len, int32_t cut, uint32_t words_per_read, uint64_t cap, uint64_t *d_words,
+                           uint8_t *d_lens, uint64_t *d_nmask, mrg_fastq_device_info *info, void *stream);
+
+/*
  * Collapse n raw reads (device arrays, layout as for mrg_cascade_run; d_sample gives the
  * sample of each read or is NULL for one sample) into unique reads:
  *   d_u_reads [words_per_read][cap], d_u_lens [cap], d_u_nmask ([..][cap] or NULL),

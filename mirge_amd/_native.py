@@ -49,6 +49,11 @@ class FastqInfo(C.Structure):
                 ("n_long", C.c_uint64)]
 
 
+class FastqDeviceInfo(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("n_kept", C.c_uint64), ("n_long", C.c_uint64), ("bad_record", C.c_uint64),
+                ("max_len", C.c_uint32), ("has_n", C.c_int32), ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
 class IndexView(C.Structure):
     _fields_ = [("blocks", C.POINTER(C.c_uint32)), ("super", C.POINTER(C.c_uint32)),
                 ("text", C.POINTER(C.c_uint32)), ("sa", C.POINTER(C.c_uint64)),
@@ -137,6 +142,9 @@ SIGNATURES = {
     "mrg_fastq_long_read": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_char_p)]),
     "mrg_fastq_copy": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mrg_fastq_free": (None, [C.c_void_p]),
+    "mrg_fastq_block_cut": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(C.c_uint64)]),
+    "mrg_fastq_parse_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
+                                         C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FastqDeviceInfo), C.c_void_p]),
     "mrg_collapse_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),

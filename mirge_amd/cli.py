@@ -50,6 +50,9 @@ def build_parser():
     p.add_argument("-gff", dest="gff_output", action="store_true")
     p.add_argument("-trf", dest="trf_output", action="store_true")
     p.add_argument("--gpu", type=int, default=0, help="device index (default 0)")
+    p.add_argument("--device-ingest", action="store_true",
+                   help="split, trim and pack the FASTQ records on the GPU (raw text blocks are uploaded; `-ad none` / `-ad +N` "
+                        "and plain four-line records only: anything else falls back to the host parser per file)")
     p.add_argument("--gpus", type=int, default=1,
                    help="annotate on N GPUs of this node: one process per GPU, the collapsed read set in N "
                         "contiguous shards, one RCCL all-reduce of the count vector (default 1)")
@@ -241,16 +244,27 @@ def annotate_main(args, engine_factory=None, materialize=False):
     n_cpu = max(1, int(args.cpu))
     n_jobs = max(1, min(len(mine), n_cpu))
 
+    device_ingest = bool(getattr(args, "device_ingest", False)) and hasattr(engine, "_lib")
+
     def load_one(i):
         t1 = time.time()
-        fq = ingest.load_fastq(os.path.abspath(raw[i]), adapter=args.adapter, threads=max(1, n_cpu // n_jobs))
+        fq = None
+        if device_ingest:
+            try:
+                fq = ingest.load_fastq_device(engine, os.path.abspath(raw[i]), adapter=args.adapter)
+            except ingest.DeviceIngestUnsupported:
+                fq = None   # the host parser takes it (and words whatever is wrong with the file)
+        if fq is None:
+            fq = ingest.load_fastq(os.path.abspath(raw[i]), adapter=args.adapter, threads=max(1, n_cpu // n_jobs))
         return fq, time.time() - t1
 
     if rank == 0:
         for name in sample_list:
             print("Performing quantitation analysis of %s..." % name)
     loaded = []
-    if mine:
+    if mine and device_ingest:
+        loaded = [load_one(i) for i in mine]   # (one file at a time: each already fills the PCIe link)
+    elif mine:
         with ThreadPoolExecutor(max_workers=n_jobs) as pool:
             loaded = list(pool.map(load_one, mine))
     quant_stats, long_counts = {}, {}
@@ -265,25 +279,23 @@ def annotate_main(args, engine_factory=None, materialize=False):
                                              int(any(fq["nmask"] is not None for fq, _ in loaded)),
                                              max([fq["max_len"] for fq, _ in loaded] + [0])])
     n_raw = sum(fq["packed"] for fq, _ in loaded)
-    words = np.zeros((W, n_raw), dtype=np.uint64)
-    lens = np.empty(n_raw, dtype=np.uint8)
-    nmask = np.zeros((W, n_raw), dtype=np.uint64) if any_n else None
-    sample = np.empty(n_raw, dtype=np.uint16)
+    d_words = torch.zeros((W, n_raw), dtype=torch.int64, device=dev)
+    d_lens = torch.empty(n_raw, dtype=torch.uint8, device=dev)
+    d_nmask = torch.zeros((W, n_raw), dtype=torch.int64, device=dev) if any_n else None
+    d_sample = torch.empty(n_raw, dtype=torch.int16, device=dev)
     at = 0
     for i, (fq, _) in zip(mine, loaded):
         m = fq["packed"]
-        words[:fq["words"].shape[0], at:at + m] = fq["words"]
-        lens[at:at + m] = fq["lens"]
+
+        def on_dev(a, dt):   # a file's arrays: numpy from the host parser, device tensors from the device parser
+            return a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)
+        d_words[:fq["words"].shape[0], at:at + m] = on_dev(fq["words"], np.int64)
+        d_lens[at:at + m] = on_dev(fq["lens"], np.uint8)
         if fq["nmask"] is not None:
-            nmask[:fq["nmask"].shape[0], at:at + m] = fq["nmask"]
-        sample[at:at + m] = i
+            d_nmask[:fq["nmask"].shape[0], at:at + m] = on_dev(fq["nmask"], np.int64)
+        d_sample[at:at + m] = i
         at += m
     del loaded
-    d_words = torch.from_numpy(words.view(np.int64)).to(dev)
-    d_lens = torch.from_numpy(lens).to(dev)
-    d_nmask = None if nmask is None else torch.from_numpy(nmask.view(np.int64)).to(dev)
-    d_sample = torch.from_numpy(sample.view(np.int16)).to(dev)
-    del words, lens, nmask, sample
     if world > 1:
         # ---- partition by sequence: one all-to-all puts every copy of a sequence on one
         # rank, so the per-rank collapses below are disjoint and nothing is collapsed globally ----

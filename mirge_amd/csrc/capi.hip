@@ -2067,6 +2067,35 @@ int mrg_fastq_copy(const mrg_fastq* fq, uint32_t words_per_read, uint64_t* words
 
 void mrg_fastq_free(mrg_fastq* fq) { delete fq; }
 
+int mrg_fastq_block_cut(const char* buf, uint64_t len, int32_t at_eof, uint64_t* cut) {
+  if (!buf || !cut) return fail(MRG_ERR_ARG, "mrg_fastq_block_cut: null argument");
+  *cut = mrg::fastq_block_cut(buf, (size_t)len, at_eof != 0);
+  return MRG_OK;
+}
+
+int mrg_fastq_parse_device(mrg_ctx* ctx, const char* d_text, uint64_t n_bytes, int32_t phred, int32_t qual_cutoff, int32_t min_len,
+                           int32_t cut, uint32_t words_per_read, uint64_t cap, uint64_t* d_words, uint8_t* d_lens, uint64_t* d_nmask,
+                           mrg_fastq_device_info* info, void* stream) {
+  if (!ctx || !info) return fail(MRG_ERR_ARG, "mrg_fastq_parse_device: null argument");
+  if (n_bytes && (!d_text || !d_words || !d_lens)) return fail(MRG_ERR_ARG, "mrg_fastq_parse_device: null buffers");
+  if (words_per_read != 1 && words_per_read != 2 && words_per_read != 4)
+    return fail(MRG_ERR_ARG, "mrg_fastq_parse_device: words_per_read must be 1, 2 or 4");
+  if (phred != 33 && phred != 64) return fail(MRG_ERR_ARG, "mrg_fastq_parse_device: phred must be 33 or 64");
+  if (n_bytes >= 0x7fffffffull) return fail(MRG_ERR_ARG, "mrg_fastq_parse_device: at most 2^31 - 2 bytes of text per call");
+  HIP_TRY(hipSetDevice(ctx->device));
+  uint64_t h[7];
+  HIP_TRY(mrg::fastq_parse_device(d_text, n_bytes, phred, qual_cutoff, min_len, cut, words_per_read, cap, d_words, d_lens, d_nmask, h,
+                                  (hipStream_t)stream));
+  info->n_records = h[0];
+  info->n_kept = h[1];
+  info->n_long = h[2];
+  info->max_len = (uint32_t)h[3];
+  info->has_n = (int32_t)h[4];
+  info->status = (int32_t)h[5];
+  info->bad_record = h[6];
+  return MRG_OK;
+}
+
 int mrg_collapse_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_read, const uint8_t* d_lens,
                      const uint64_t* d_nmask, const uint16_t* d_sample, uint64_t n, uint32_t n_samples,
                      uint32_t max_len, uint64_t cap, uint64_t* d_u_reads, uint8_t* d_u_lens,

@@ -323,6 +323,11 @@ void split_block(Batch& b, bool* any_hi_first1000) {
 
 }  // namespace
 
+size_t fastq_block_cut(const char* buf, size_t len, bool at_eof) {
+  if (at_eof) return len;
+  return last_record_start(buf, len);
+}
+
 // Reader (this thread: inflate, cut the text at record boundaries) -> workers (split a block into
 // records, trim them) -> parallel 2-bit packing.  The per-record work is in the workers: the
 // reader only finds the last record header of each ~4 MB block.

@@ -39,6 +39,11 @@ struct TrimSpec {
 TrimSpec parse_trim_spec(const char* adapter);
 size_t apply_trim_spec(const TrimSpec& spec, std::string& read);  // returns the new length
 
+// Offset of the last record boundary in a buffer of FASTQ text: buf[0, cut) holds whole records (what a
+// caller that feeds text blocks to the device parser uploads), the rest is carried into the next block.
+// at_eof: the buffer ends the file (everything is taken).  0 = no complete record in the buffer yet.
+size_t fastq_block_cut(const char* buf, size_t len, bool at_eof);
+
 // threads <= 0: one per hardware thread, at most 32
 void load_fastq(const std::string& path, int qual_cutoff, int min_len, const char* adapter, int threads,
                 FastqData& out);

@@ -1,0 +1,237 @@
+// FASTQ text -> packed reads ON THE DEVICE: record splitting, 3' quality trimming, the `-ad +N` cutter,
+// the minimum length and the 2-bit packing of trim_file (utils/trim_file.py:24-66, 89-134) and of the
+// FASTQ loop of quantReads (utils/quantReads.py:4-24), for raw text blocks that the host only reads,
+// cuts at a record boundary and uploads.
+//
+// Why: csrc/fastq.cpp does this on the host at 85 M reads/s on the GPU box's 256 cores
+// (profiles/r03_ingest_scale.json) -- 1.2 s for what the cascade annotates in 6 ms.  Here a block of text
+// is one upload and three kernels; the packed reads never exist on the host.
+// Scope: strict four-line records ('\n' or "\r\n", last newline optional), `-ad none` and `-ad +N`;
+// anything else (blank lines between records, an adapter SEQUENCE: cutadapt's alignment) is reported
+// (status != 0) or not offered here, and the caller takes the host parser, which also words the errors.
+// Rules restated exactly as csrc/fastq.cpp / oracle/ingest.py state them:
+//   quality  walk from the 3' end accumulating (cutoff - q), stop when the sum turns negative, cut at the
+//            position of the maximum (cutadapt's / BWA's rule);
+//   +N       N > 0 removes the first N bases, N < 0 the last -N, after the quality trim;
+//   keep     trimmed length >= min_len; bases other than ACGT (any case) are N (code 0 + mask bit).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+
+#include "kernels.hpp"
+
+namespace mrg {
+
+namespace {
+
+struct IsNewline {
+  const char* text;
+  __host__ __device__ bool operator()(uint32_t i) const { return text[i] == '\n'; }
+};
+
+constexpr uint32_t kIngestThreads = 256;
+
+// per record: where its trimmed read starts in the text and how long it is (0 = dropped)
+__global__ void __launch_bounds__(kIngestThreads) ingest_trim_kernel(const char* __restrict__ text, uint64_t n_bytes,
+                                                                      const uint32_t* __restrict__ nl, uint32_t n_nl, uint32_t n_records,
+                                                                      int32_t phred, int32_t cutoff, int32_t min_len, int32_t cut,
+                                                                      uint32_t max_packed, uint32_t* __restrict__ rec_start,
+                                                                      uint32_t* __restrict__ rec_len, uint32_t* __restrict__ keep,
+                                                                      uint32_t* __restrict__ info /* status, bad record, n_long, max_len */) {
+  const uint32_t r = blockIdx.x * kIngestThreads + threadIdx.x;
+  if (r >= n_records) return;
+  auto line_end = [&](uint32_t i) -> uint32_t { return i < n_nl ? nl[i] : (uint32_t)n_bytes; };
+  const uint32_t s0 = r ? nl[4 * r - 1] + 1 : 0u;
+  const uint32_t e0 = line_end(4 * r), e1 = line_end(4 * r + 1), e2 = line_end(4 * r + 2);
+  uint32_t e3 = line_end(4 * r + 3);
+  const uint32_t s1 = e0 + 1, s2 = e1 + 1, s3 = e2 + 1;
+  uint32_t q1 = e1;
+  if (q1 > s1 && text[q1 - 1] == '\r') --q1;
+  if (e3 > s3 && text[e3 - 1] == '\r') --e3;
+  uint32_t len = 0, start = s1;
+  uint32_t bad = 0;
+  if (e0 <= s0 || text[s0] != '@') bad = 1;                      // not a header line (or a blank line)
+  else if (s2 >= (uint32_t)n_bytes || text[s2] != '+') bad = 2;  // the third line is not the '+' line
+  else if (q1 - s1 != e3 - s3) bad = 3;                          // sequence and quality lengths differ
+  if (bad) {
+    atomicCAS(&info[0], 0u, bad);
+    atomicMin(&info[1], r);
+  } else {
+    const uint32_t L = q1 - s1;
+    // 3' quality trim
+    int32_t s = 0, best = 0;
+    uint32_t stop = L;
+    for (uint32_t i = L; i-- > 0;) {
+      s += cutoff - ((int32_t)(uint8_t)text[s3 + i] - phred);
+      if (s < 0) break;
+      if (s > best) {
+        best = s;
+        stop = i;
+      }
+    }
+    uint32_t a = 0, b = stop;
+    if (cut > 0) a = min((uint32_t)cut, b);
+    else if (cut < 0) b = b > (uint32_t)(-cut) ? b - (uint32_t)(-cut) : 0u;
+    len = b - a;
+    start = s1 + a;
+  }
+  uint32_t k = (!bad && (int32_t)len >= min_len) ? 1u : 0u;
+  if (k && len > max_packed) {  // kept by the rules, too long for the words the caller offers
+    atomicAdd(&info[2], 1u);
+    k = 0u;
+  }
+  if (k) atomicMax(&info[3], len);
+  rec_start[r] = start;
+  rec_len[r] = k ? len : 0u;
+  keep[r] = k;
+}
+
+__global__ void __launch_bounds__(kIngestThreads) ingest_pack_kernel(const char* __restrict__ text, const uint32_t* __restrict__ rec_start,
+                                                                      const uint32_t* __restrict__ rec_len, const uint32_t* __restrict__ out_idx,
+                                                                      uint32_t n_records, uint32_t W, uint64_t cap, uint64_t* __restrict__ words,
+                                                                      uint8_t* __restrict__ lens, uint64_t* __restrict__ nmask,
+                                                                      uint32_t* __restrict__ info /* [4] has_n */) {
+  const uint32_t r = blockIdx.x * kIngestThreads + threadIdx.x;
+  if (r >= n_records) return;
+  const uint32_t len = rec_len[r];
+  if (!len) return;
+  const uint64_t o = out_idx[r];
+  const char* p = text + rec_start[r];
+  bool any_n = false;
+  for (uint32_t w = 0; w < W; ++w) {
+    uint64_t bits = 0, nm = 0;
+    const uint32_t nb = len > 32u * w ? min(32u, len - 32u * w) : 0u;
+    for (uint32_t i = 0; i < nb; ++i) {
+      const char c = p[32u * w + i];
+      uint64_t code = 0;
+      bool is_n = false;
+      switch (c) {
+        case 'A': case 'a': code = 0; break;
+        case 'C': case 'c': code = 1; break;
+        case 'G': case 'g': code = 2; break;
+        case 'T': case 't': code = 3; break;
+        default: is_n = true; break;
+      }
+      bits |= code << (2u * i);
+      if (is_n) nm |= 1ull << (2u * i);
+    }
+    words[(uint64_t)w * cap + o] = bits;
+    if (nmask) nmask[(uint64_t)w * cap + o] = nm;
+    any_n |= nm != 0ull;
+  }
+  lens[o] = (uint8_t)len;
+  if (any_n) atomicOr(&info[4], 1u);
+}
+
+#define CK(expr)                     \
+  do {                               \
+    hipError_t e_ = (expr);          \
+    if (e_ != hipSuccess) return e_; \
+  } while (0)
+
+struct Scratch {
+  void* p = nullptr;
+  ~Scratch() { (void)hipFree(p); }
+};
+
+}  // namespace
+
+hipError_t fastq_parse_device(const char* d_text, uint64_t n_bytes, int32_t phred, int32_t cutoff, int32_t min_len, int32_t cut,
+                              uint32_t W, uint64_t cap, uint64_t* d_words, uint8_t* d_lens, uint64_t* d_nmask, uint64_t* h_info,
+                              hipStream_t stream) {
+  // h_info: records, kept (packed), too long, max_len, has_n, status (0 ok; 1-3 ill-formed record, 4 line count not a
+  // multiple of four, 5 more kept reads than `cap`), first bad record
+  for (int i = 0; i < 7; ++i) h_info[i] = 0;
+  if (n_bytes == 0) return hipSuccess;
+  if (n_bytes >= 0x7fffffffull) return hipErrorInvalidValue;
+  const uint32_t n = (uint32_t)n_bytes;
+  // ---- positions of the newlines ----
+  Scratch s_nl, s_cnt, s_tmp, s_rec, s_info;
+  CK(hipMalloc(&s_nl.p, (size_t)(n / 2 + 16) * 4));  // (a line has at least one byte besides its '\n'... blank lines are errors anyway)
+  CK(hipMalloc(&s_cnt.p, 8));
+  hipcub::CountingInputIterator<uint32_t> idx(0u);
+  hipcub::TransformInputIterator<bool, IsNewline, hipcub::CountingInputIterator<uint32_t>> flags(idx, IsNewline{d_text});
+  size_t tmp_bytes = 0;
+  // (a text of nothing but newlines would overflow s_nl: bound the selection by counting first)
+  CK(hipcub::DeviceSelect::Flagged(nullptr, tmp_bytes, idx, flags, (uint32_t*)s_nl.p, (uint32_t*)s_cnt.p, (int)n, stream));
+  CK(hipMalloc(&s_tmp.p, tmp_bytes ? tmp_bytes : 16));
+  {
+    // count pass (reduce over the flags) so that the position array is known to fit
+    size_t rb = 0;
+    CK(hipcub::DeviceReduce::Sum(nullptr, rb, flags, (uint32_t*)s_cnt.p, (int)n, stream));
+    Scratch s_r;
+    CK(hipMalloc(&s_r.p, rb ? rb : 16));
+    CK(hipcub::DeviceReduce::Sum(s_r.p, rb, flags, (uint32_t*)s_cnt.p, (int)n, stream));
+    uint32_t cnt = 0;
+    CK(hipMemcpyAsync(&cnt, s_cnt.p, 4, hipMemcpyDeviceToHost, stream));
+    CK(hipStreamSynchronize(stream));
+    if ((uint64_t)cnt > (uint64_t)n / 2 + 8) {
+      h_info[5] = 1;  // blank lines: not four-line records
+      return hipSuccess;
+    }
+  }
+  CK(hipcub::DeviceSelect::Flagged(s_tmp.p, tmp_bytes, idx, flags, (uint32_t*)s_nl.p, (uint32_t*)s_cnt.p, (int)n, stream));
+  uint32_t n_nl = 0;
+  char last = 0;
+  CK(hipMemcpyAsync(&n_nl, s_cnt.p, 4, hipMemcpyDeviceToHost, stream));
+  CK(hipMemcpyAsync(&last, d_text + n_bytes - 1, 1, hipMemcpyDeviceToHost, stream));
+  CK(hipStreamSynchronize(stream));
+  const uint32_t n_lines = n_nl + (last != '\n' ? 1u : 0u);
+  if (n_lines % 4u) {
+    h_info[5] = 4;
+    return hipSuccess;
+  }
+  const uint32_t n_records = n_lines / 4u;
+  h_info[0] = n_records;
+  if (!n_records) return hipSuccess;
+  // ---- per record: trimmed extent, keep flag ----
+  CK(hipMalloc(&s_rec.p, (size_t)n_records * 16));
+  uint32_t* rec_start = (uint32_t*)s_rec.p;
+  uint32_t* rec_len = rec_start + n_records;
+  uint32_t* keep = rec_len + n_records;
+  uint32_t* out_idx = keep + n_records;
+  CK(hipMalloc(&s_info.p, 32));
+  {
+    const uint32_t init[8] = {0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u};
+    CK(hipMemcpyAsync(s_info.p, init, 32, hipMemcpyHostToDevice, stream));
+  }
+  const uint32_t grid = (n_records + kIngestThreads - 1) / kIngestThreads;
+  hipLaunchKernelGGL(ingest_trim_kernel, dim3(grid), dim3(kIngestThreads), 0, stream, d_text, n_bytes, (const uint32_t*)s_nl.p, n_nl,
+                     n_records, phred, cutoff, min_len, cut, 32u * W, rec_start, rec_len, keep, (uint32_t*)s_info.p);
+  CK(hipGetLastError());
+  // ---- output positions: exclusive prefix of the keep flags ----
+  size_t scan_bytes = 0;
+  CK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, keep, out_idx, (int)n_records, stream));
+  Scratch s_scan;
+  CK(hipMalloc(&s_scan.p, scan_bytes ? scan_bytes : 16));
+  CK(hipcub::DeviceScan::ExclusiveSum(s_scan.p, scan_bytes, keep, out_idx, (int)n_records, stream));
+  uint32_t last_idx = 0, last_keep = 0, info[8];
+  CK(hipMemcpyAsync(&last_idx, out_idx + n_records - 1, 4, hipMemcpyDeviceToHost, stream));
+  CK(hipMemcpyAsync(&last_keep, keep + n_records - 1, 4, hipMemcpyDeviceToHost, stream));
+  CK(hipMemcpyAsync(info, s_info.p, 32, hipMemcpyDeviceToHost, stream));
+  CK(hipStreamSynchronize(stream));
+  const uint64_t n_kept = (uint64_t)last_idx + last_keep;
+  h_info[2] = info[2];
+  h_info[3] = info[3];
+  if (info[0]) {
+    h_info[5] = info[0];
+    h_info[6] = (uint64_t)info[1] + 1;  // 1-based record number inside the block
+    return hipSuccess;
+  }
+  if (n_kept > cap) {
+    h_info[5] = 5;
+    return hipSuccess;
+  }
+  h_info[1] = n_kept;
+  if (n_kept) {
+    hipLaunchKernelGGL(ingest_pack_kernel, dim3(grid), dim3(kIngestThreads), 0, stream, d_text, rec_start, rec_len, out_idx, n_records, W, cap,
+                       d_words, d_lens, d_nmask, (uint32_t*)s_info.p);
+    CK(hipGetLastError());
+    CK(hipMemcpyAsync(info, s_info.p, 32, hipMemcpyDeviceToHost, stream));
+    CK(hipStreamSynchronize(stream));
+    h_info[4] = info[4];
+  }
+  return hipSuccess;
+}
+
+}  // namespace mrg

@@ -310,6 +310,11 @@ uint32_t seed_lds_bytes(const SeedParams& p);
 uint32_t seed_wgs_per_cu(const SeedParams& p);
 hipError_t launch_seed(const SeedParams& p, uint32_t grid, hipStream_t stream);
 
+// ingest.hip: FASTQ text (whole four-line records) on the device -> packed reads.  h_info[7]: records, kept
+// (packed), kept but longer than 32 W bases, longest packed read, has N, status (0 ok), first bad record.
+hipError_t fastq_parse_device(const char* d_text, uint64_t n_bytes, int32_t phred, int32_t cutoff, int32_t min_len, int32_t cut,
+                              uint32_t W, uint64_t cap, uint64_t* d_words, uint8_t* d_lens, uint64_t* d_nmask, uint64_t* h_info,
+                              hipStream_t stream);
 hipError_t launch_pack_assignments(const int8_t* pass_id, const int32_t* ref_id, const int32_t* pos, const uint8_t* mm, uint64_t n,
                                    uint32_t* packed, hipStream_t stream);
 

@@ -69,6 +69,157 @@ def load_fastq(path, words_per_read=None, qual_cutoff=QUAL_CUTOFF, min_len=MIN_L
         lib.mrg_fastq_free(h)
 
 
+class DeviceIngestUnsupported(Exception):
+    """The device parser does not take this input (adapter sequence, ill-formed or blank-line-separated
+    records, reads beyond 128 nt): the caller uses load_fastq, which does and which words the errors."""
+
+
+def load_fastq_device(engine, path, adapter="none", qual_cutoff=QUAL_CUTOFF, min_len=MIN_LENGTH, block_bytes=256 << 20,
+                      read_threads=8):
+    """load_fastq with the record splitting, trimming and packing ON THE DEVICE (mrg_fastq_parse_device):
+    the host reads the file into a pinned buffer (plain text: `read_threads` parallel preads; gzip: one
+    inflate stream), cuts it at record boundaries (mrg_fastq_block_cut) and uploads text blocks.  `-ad none`
+    and `-ad +N` only.  Returns dict(words int64 [W, n], lens uint8 [n], nmask int64 [W, n] | None -- DEVICE
+    tensors, reads in file order --, total, kept, packed, phred, max_len, long_reads=[])."""
+    import gzip
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    ad = resolve_adapter(adapter)
+    if ad in (None, "", "none"):
+        cut = 0
+    elif ad.startswith("+"):
+        cut = int(ad)
+    else:
+        raise DeviceIngestUnsupported("adapter sequences are trimmed on the host (cutadapt's alignment)")
+    lib = engine._lib
+    dev = engine.device
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    is_gz = path.endswith(".gz")
+    # two pinned buffers, used in turn: the tail behind a block's last record boundary is copied to the head
+    # of the other one.  (Reading block i + 1 in a background thread while the device parses block i was
+    # measured SLOWER: 130-230 M reads/s against 230-266 -- the parallel preads and the upload compete.)
+    pins = [torch.empty(block_bytes + (1 << 20), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    pin_nps = [t.numpy() for t in pins]
+    pin_mvs = [memoryview(a) for a in pin_nps]
+    d_text = torch.empty(block_bytes + (1 << 20), dtype=torch.uint8, device=dev)
+    outs, total, kept, max_len, any64, base = [], 0, 0, 0, False, None
+    fh = gzip.open(path, "rb") if is_gz else open(path, "rb", buffering=0)
+    pool = None if is_gz else ThreadPoolExecutor(max_workers=max(1, int(read_threads)))
+    state = dict(offset=0, eof=False)
+    size = None if is_gz else os.fstat(fh.fileno()).st_size
+
+    def fill(which, have):
+        """Read up to block_bytes - have bytes behind the `have` carried-over bytes of buffer `which`;
+        returns the bytes now in the buffer."""
+        mv = pin_mvs[which]
+        room = block_bytes - have
+        got = 0
+        if is_gz:
+            while got < room:
+                k = fh.readinto(mv[have + got:have + room])
+                if not k:
+                    state["eof"] = True
+                    break
+                got += k
+        else:
+            got = max(0, min(room, size - state["offset"]))
+            if got:
+                n_parts = max(1, min(int(read_threads), got >> 22))
+                step = (got + n_parts - 1) // n_parts
+                fd, off0 = fh.fileno(), state["offset"]
+
+                def part(i):
+                    a, b = i * step, min(got, (i + 1) * step)
+                    done = a
+                    while done < b:
+                        k = os.preadv(fd, [mv[have + done:have + b]], off0 + done)
+                        if k <= 0:
+                            raise IOError("short read from %s" % path)
+                        done += k
+                list(pool.map(part, range(n_parts)))
+            state["offset"] += got
+            state["eof"] = state["offset"] >= size
+        return have + got
+
+    try:
+        cur = 0
+        n_buf = fill(cur, 0)
+        while n_buf:
+            eof = state["eof"]
+            pin, pin_np = pins[cur], pin_nps[cur]
+            cut_at = C.c_uint64(0)
+            check(lib.mrg_fastq_block_cut(pin.data_ptr(), n_buf, 1 if eof else 0, C.byref(cut_at)))
+            n_blk = int(cut_at.value)
+            if n_blk == 0:
+                if eof:
+                    break
+                raise DeviceIngestUnsupported("no record boundary inside %d bytes of text" % n_buf)
+            # the tail behind the last record boundary starts the next block, whose read begins now
+            have = n_buf - n_blk
+            nxt = cur ^ 1
+            if have:
+                pin_nps[nxt][:have] = pin_np[n_blk:n_buf]
+            if base is None:
+                # trim_file.py:104-110: the first record's qualities decide the base the workers trim with,
+                # the first 1000 records what the report says
+                head = bytes(pin_np[:min(n_blk, 1 << 20)]).split(b"\n")
+                quals = [head[i].rstrip(b"\r") for i in range(3, min(len(head), 4000), 4)]
+                base = 64 if quals and any(c > 74 for c in quals[0]) else 33
+                any64 = any(c > 74 for q in quals[:1000] for c in q)
+            d_text[:n_blk].copy_(pin[:n_blk], non_blocking=True)
+            cap = n_blk // (2 * max(int(min_len), 1) + 6) + 1
+            info = _native.FastqDeviceInfo()
+            W = 1
+            while True:
+                words = torch.empty((W, cap), dtype=torch.int64, device=dev)
+                lens = torch.empty(cap, dtype=torch.uint8, device=dev)
+                nmask = torch.empty((W, cap), dtype=torch.int64, device=dev)
+                check(lib.mrg_fastq_parse_device(engine._h, d_text.data_ptr(), n_blk, base, int(qual_cutoff), int(min_len), cut, W, cap,
+                                                 words.data_ptr(), lens.data_ptr(), nmask.data_ptr(), C.byref(info), stream))
+                if info.status:
+                    raise DeviceIngestUnsupported("record %d of a block is not a plain four-line record (status %d)"
+                                                  % (info.bad_record, info.status))
+                if info.n_long == 0:
+                    break
+                if W == 4:
+                    raise DeviceIngestUnsupported("reads beyond 128 nt")
+                W *= 2
+            k = int(info.n_kept)
+            total += int(info.n_records)
+            kept += k
+            max_len = max(max_len, int(info.max_len))
+            outs.append((words[:, :k].clone(), lens[:k].clone(), nmask[:, :k].clone() if info.has_n else None))
+            del words, lens, nmask
+            torch.cuda.current_stream(dev).synchronize()
+            if eof:
+                break
+            n_buf = fill(nxt, have)
+            cur = nxt
+    finally:
+        fh.close()
+        if pool is not None:
+            pool.shutdown()
+    W = max([o[0].shape[0] for o in outs] + [1])
+    any_n = any(o[2] is not None for o in outs)
+
+    def widen(t, k):
+        if t is None:
+            t = torch.zeros((W, k), dtype=torch.int64, device=dev)
+        elif t.shape[0] < W:
+            t = torch.cat([t, torch.zeros((W - t.shape[0], k), dtype=torch.int64, device=dev)], dim=0)
+        return t
+    if outs:
+        words = torch.cat([widen(o[0], o[0].shape[1]) for o in outs], dim=1)
+        lens = torch.cat([o[1] for o in outs])
+        nmask = torch.cat([widen(o[2], o[0].shape[1]) for o in outs], dim=1) if any_n else None
+    else:
+        words = torch.empty((1, 0), dtype=torch.int64, device=dev)
+        lens = torch.empty(0, dtype=torch.uint8, device=dev)
+        nmask = None
+    return dict(words=words, lens=lens, nmask=nmask, total=total, kept=kept, packed=kept, phred=64 if any64 else 33,
+                max_len=max_len, long_reads=[])
+
+
 def collapse(engine, words, lens, nmask=None, sample=None, n_samples=1, max_len=0):
     """Collapse raw packed reads on the engine's GPU.
 

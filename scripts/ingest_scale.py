@@ -70,6 +70,31 @@ def main():
                 del fq
             out["runs"].append(dict(input=name, threads=th, seconds=round(best, 3), m_reads_per_s=round(n / best / 1e6, 2)))
             print("[ingest] %s threads=%d: %.2f M reads/s" % (name, th, n / best / 1e6), file=sys.stderr, flush=True)
+    # the device parser (csrc/ingest.hip): raw text blocks uploaded, records split / trimmed / packed on the GPU
+    try:
+        import torch
+        if torch.cuda.is_available():
+            from mirge_amd.engine import Engine
+            eng = Engine(0)
+            for name, path in (("plain", plain), ("gzip", gz)):
+                for th in (4, 16, 32):
+                    best = None
+                    for _ in range(2):
+                        t1 = time.perf_counter()
+                        fq = ingest.load_fastq_device(eng, path, adapter="none", read_threads=th)
+                        torch.cuda.synchronize()
+                        dt = time.perf_counter() - t1
+                        assert fq["kept"] == n, (name, fq["kept"])
+                        best = dt if best is None else min(best, dt)
+                        del fq
+                    out["runs"].append(dict(input=name + " (device parser)", threads=th, seconds=round(best, 3),
+                                            m_reads_per_s=round(n / best / 1e6, 2)))
+                    print("[ingest] %s, device parser, %d read threads: %.2f M reads/s" % (name, th, n / best / 1e6), file=sys.stderr,
+                          flush=True)
+                    if name == "gzip":
+                        break
+    except Exception as e:
+        out["device_error"] = repr(e)
     for f in (plain, trimmed, gz):
         os.remove(f)
     print(json.dumps(out))

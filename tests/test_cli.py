@@ -210,3 +210,37 @@ def test_cli_two_gpus_over_rccl(native_lib, tmp_path):
         a = open(os.path.join(outs[1], fn)).read()
         b = open(os.path.join(outs[2], fn)).read()
         assert sorted(a.split("\n")) == sorted(b.split("\n")), fn
+
+
+@pytest.mark.gpu
+def test_cli_device_ingest_writes_the_same_tables(native_lib, tmp_path):
+    """`--device-ingest`: the FASTQ records are split, trimmed and packed on the GPU (one plain file, one
+    gzip file; a third with blank lines between records falls back to the host parser on its own):
+    every table equals the default run's."""
+    from mirge_amd import synth
+    from tests.golden.make_golden import SHAPES
+    rng = np.random.default_rng(9)
+    libs = synth.SynthLibraries(seed=123, scale=1.0, n_paralogs=6, n_snp=8, shapes=SHAPES)
+    root = str(tmp_path / "libs")
+    libs.write_layout(root, species="syn", db="miRBase")
+    fastqs = []
+    for si in range(3):
+        p = str(tmp_path / ("s%d.fastq" % si))
+        write_fastq(p, [synth.codes_to_str(c) for c in synth.synth_reads(libs, 1500, seed=60 + si, zipf_s=1.3)], rng)
+        fastqs.append(p)
+    import gzip
+    with open(fastqs[1], "rb") as fi, gzip.open(fastqs[1] + ".gz", "wb") as fo:
+        fo.write(fi.read())
+    os.remove(fastqs[1])
+    fastqs[1] += ".gz"
+    text = open(fastqs[2]).read().split("\n@")
+    open(fastqs[2], "w").write(text[0] + "\n\n@" + "\n@".join(text[1:]))
+    outs = {}
+    for mode in ("host", "device"):
+        argv = ["annotate", "-s"] + fastqs + ["-lib", root, "-sp", "syn", "-o", str(tmp_path / mode), "-di", "-ad", "+1"]
+        outs[mode] = cli.annotate_main(cli.build_parser().parse_args(argv + (["--device-ingest"] if mode == "device" else [])))
+    for fn in ("mapped.csv", "unmapped.csv", "miR.Counts.csv", "miR.RPM.csv", "isomirs.csv", "annotation.report.csv"):
+        a = open(os.path.join(outs["host"]["outdir"], fn)).read()
+        b = open(os.path.join(outs["device"]["outdir"], fn)).read()
+        assert a == b, fn
+    assert outs["host"]["logDic"]["quantStats"][0]["trimmedReads"] == outs["device"]["logDic"]["quantStats"][0]["trimmedReads"] > 1000

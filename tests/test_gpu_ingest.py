@@ -1,0 +1,124 @@
+"""GPU parity (-m gpu) of the device-side FASTQ ingest (csrc/ingest.hip, mrg_fastq_parse_device): record
+splitting, the 3' quality rule, the `-ad +N` cutter, the 16-nt minimum and the 2-bit packing of
+trim_file.py:24-66,89-134 / quantReads.py:4-24 on raw text blocks.  Checked against the oracle's Python
+restatement (oracle/ingest.py) and, array for array, against the host parser (csrc/fastq.cpp)."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from mirge_amd import ingest, pack
+from oracle import ingest as oingest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine(native_lib):
+    from mirge_amd.engine import Engine
+    return Engine(0)
+
+
+def make_fastq(path, rng, n=6000, max_len=50, phred=33, crlf=False, final_newline=True, long_reads=0):
+    eol = "\r\n" if crlf else "\n"
+    recs = []
+    for i in range(n):
+        L = int(rng.integers(14, max_len + 1))
+        seq = "".join("ACGTN"[c] for c in rng.choice(5, L, p=[0.245, 0.245, 0.245, 0.245, 0.02]))
+        if rng.random() < 0.1:
+            seq = seq.lower()
+        q = rng.integers(20, 41, L)
+        if rng.random() < 0.5:   # a low-quality 3' tail (sometimes the whole read)
+            t = int(rng.integers(0, L + 1))
+            q[t:] = rng.integers(0, 12, L - t)
+        qual = "".join(chr(int(v) + phred) for v in q)
+        if i == 0 and phred == 64:
+            qual = "h" * L   # (the first record decides the base: make it unmistakably phred 64)
+        recs.append("@r%d some text%s%s%s+%s%s" % (i, eol, seq, eol, eol, qual))
+    for i in range(long_reads):
+        L = 150
+        recs.append("@long%d%s%s%s+%s%s" % (i, eol, "ACGT" * 37 + "AC", eol, eol, "I" * L))
+    text = eol.join(recs) + (eol if final_newline else "")
+    if path.endswith(".gz"):
+        with gzip.open(path, "wt", newline="") as fh:
+            fh.write(text)
+    else:
+        with open(path, "w", newline="") as fh:
+            fh.write(text)
+
+
+def same_as_host_and_oracle(engine, path, adapter, **kw):
+    dev = ingest.load_fastq_device(engine, path, adapter=adapter, **kw)
+    host = ingest.load_fastq(path, adapter=adapter)
+    want, total, phred = oingest.load_fastq(path, adapter=ingest.resolve_adapter(adapter))
+    assert (dev["total"], dev["kept"], dev["phred"]) == (total, len(want), phred) == (host["total"], host["kept"], host["phred"])
+    w = dev["words"].cpu().numpy().view(np.uint64)
+    l = dev["lens"].cpu().numpy()
+    nm = None if dev["nmask"] is None else dev["nmask"].cpu().numpy().view(np.uint64)
+    assert pack.unpack_reads(w, l, nm) == [s.upper() for s in want]          # same reads, same order
+    W = max(w.shape[0], host["words"].shape[0])
+
+    def pad(a):
+        return a if a.shape[0] == W else np.concatenate([a, np.zeros((W - a.shape[0], a.shape[1]), dtype=np.uint64)])
+    assert np.array_equal(pad(w), pad(host["words"])) and np.array_equal(l, host["lens"])
+    assert (nm is None) == (host["nmask"] is None) and (nm is None or np.array_equal(pad(nm), pad(host["nmask"])))
+    assert dev["max_len"] == host["max_len"]
+    return dev
+
+
+def test_device_ingest_equals_host_and_oracle(engine, tmp_path):
+    rng = np.random.default_rng(31)
+    for name, kw, adapter in (("plain.fastq", {}, "none"), ("crlf.fastq", dict(crlf=True), "none"),
+                              ("nofinal.fastq", dict(final_newline=False), "+3"), ("p64.fastq", dict(phred=64), "none"),
+                              ("short.fastq", dict(max_len=30), "+2"), ("z.fastq.gz", {}, "none")):
+        p = str(tmp_path / name)
+        make_fastq(p, rng, **kw)
+        dev = same_as_host_and_oracle(engine, p, adapter)
+        assert 500 < dev["kept"] < dev["total"]
+    # many small blocks: the tail behind the last record boundary is carried into the next block
+    p = str(tmp_path / "plain.fastq")
+    a = same_as_host_and_oracle(engine, p, "none", block_bytes=64 << 10, read_threads=3)
+    b = ingest.load_fastq_device(engine, p, adapter="none")
+    assert bool((a["words"] == b["words"]).all()) and bool((a["lens"] == b["lens"]).all())
+
+
+def test_what_the_device_parser_refuses(engine, tmp_path):
+    """An adapter sequence, blank lines between records, a missing '+' line, reads beyond 128 nt: the
+    device parser says so (the caller then takes the host parser)."""
+    rng = np.random.default_rng(32)
+    p = str(tmp_path / "ok.fastq")
+    make_fastq(p, rng, n=200)
+    with pytest.raises(ingest.DeviceIngestUnsupported):
+        ingest.load_fastq_device(engine, p, adapter="illumina")
+    text = open(p).read()
+    blank = str(tmp_path / "blank.fastq")
+    recs = text.split("\n@r")
+    open(blank, "w").write(recs[0] + "\n\n@r" + "\n@r".join(recs[1:]))
+    with pytest.raises(ingest.DeviceIngestUnsupported):
+        ingest.load_fastq_device(engine, blank)
+    assert ingest.load_fastq(blank)["total"] == 200            # (the host parser accepts blank lines)
+    noplus = str(tmp_path / "noplus.fastq")
+    lines = text.split("\n")
+    lines[4 * 7 + 2] = "x"
+    open(noplus, "w").write("\n".join(lines))
+    with pytest.raises(ingest.DeviceIngestUnsupported):
+        ingest.load_fastq_device(engine, noplus)
+    longp = str(tmp_path / "long.fastq")
+    make_fastq(longp, rng, n=100, long_reads=2)
+    with pytest.raises(ingest.DeviceIngestUnsupported):
+        ingest.load_fastq_device(engine, longp)
+    assert len(ingest.load_fastq(longp)["long_reads"]) == 2
+
+
+def test_block_cut_on_the_host(native_lib):
+    """mrg_fastq_block_cut: the offset of the last record header that can be told from a quality line
+    starting with '@' (the line after next starts with '+')."""
+    import ctypes as C
+    rec = lambda i, q: "@r%d\nACGTACGTACGTACGTAC\n+\n%s\n" % (i, q)
+    text = (rec(0, "I" * 18) + rec(1, "@" + "I" * 17) + rec(2, "I" * 18) + "@r3\nACGT").encode()
+    cut = C.c_uint64(0)
+    assert native_lib.mrg_fastq_block_cut(text, len(text), 0, C.byref(cut)) == 0
+    assert text[cut.value:cut.value + 3] == b"@r2" or text[cut.value:cut.value + 3] == b"@r3"
+    assert text[:cut.value].count(b"\n") % 4 == 0
+    assert native_lib.mrg_fastq_block_cut(text, len(text), 1, C.byref(cut)) == 0 and cut.value == len(text)
