@@ -164,7 +164,8 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * verified cooperatively by the whole wave (default 64); "hint_min_len" / "hint_max_len" = the
  * caller's promise that every read of the NEXT mrg_cascade_run has a length in that range (defaults
  * 0 / 255 = unknown; reset to the defaults by every run): a pass whose length window excludes the
- * whole range is not launched (the hints decide nothing else: every kernel reads d_lens); "kmer_filter" = 1/0 stage a small
+ * whole range is not launched, and a one-word batch that may hold reads under "split_min_len" is split
+ * (below); the hints decide no result: every kernel reads d_lens; "kmer_filter" = 1/0 stage a small
  * library's 9-mer presence bitmap in LDS and skip the jump-table load of a seed piece whose
  * last 9 bases do not occur in the library (default 1); "ctx_wide_rows" = the same
  * threshold for libraries of >= 2^20 bases, whose cooperative path drops most rows by their
@@ -189,7 +190,13 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * reads shorter than the key take the FM index); "seed_units" = 1 (default) / 0: in such batches the runs
  * of passes with at most one seed mismatch after the first launch go through seed_kernel (libraries of at
  * most 4 Mbp searched with one policy as ONE index of their concatenation, built when a cascade first
- * plans it); "wide_rows_16", "round_large": see DESIGN.md. */
+ * plans it); "split_mixed" = 1 (default) / 0 and "split_min_len" = 20 (default) / 0..32: a batch with more
+ * than one word per read, an N mask, or (by the length hint) reads under split_min_len nt is split on the
+ * device into the reads of split_min_len .. 32 nt without N, which run the cascade through the dictionary
+ * kernels as the one-word batch they are, and the rest, which runs it through the FM kernels first -- two
+ * cascades over disjoint lists adding to the same counters (mrg_pass_stats then names the kernels of the
+ * second one, n_launches counts both, and the first pass's ms includes the whole first cascade);
+ * "wide_rows_16", "round_large": see DESIGN.md. */
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);
 int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,
                         char *arch, uint32_t arch_cap);
@@ -237,7 +244,8 @@ typedef struct mrg_pass_stats {
                           had a launch of its own) */
   uint32_t n_launches; /* kernel launches that carried this pass: 1, or 2 for a 2-mismatch pass split
                           into strata 1-2 and stratum 3; 0 for a pass that was not launched or rode
-                          in the fused launch of its group's first pass */
+                          in the fused launch of its group's first pass; a split batch ("split_mixed")
+                          counts the launches of both of its cascades */
   uint32_t kbits_log2; /* log2 of the bits of the 9-mer presence bitmap the pass filtered seed
                           pieces with (18 = the library's full bitmap, 13..17 = folded for a
                           fused launch, 0 = no filter) */
@@ -251,7 +259,8 @@ typedef struct mrg_pass_stats {
                           still shorter reads went through the stratum-first pigeonhole pieces */
 } mrg_pass_stats;
 
-/* Bytes of device workspace mrg_cascade_run needs for n reads. */
+/* Bytes of device workspace mrg_cascade_run needs for n reads (three index lists of n + 2^23 entries,
+ * segment counts, counters: 12 B per read + 96 MB). */
 int mrg_cascade_workspace_bytes(uint64_t n, uint64_t *bytes);
 
 /*

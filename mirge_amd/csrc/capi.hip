@@ -203,6 +203,8 @@ struct mrg_ctx {
   int64_t wide_rows_16 = 1;  // libraries of >= 2^20 bases get 16-byte rows with 32 bases of context
   int64_t dict = 1;          // one-word batches without N run the dictionary kernels (dict.hip) where a pass can
   int64_t dict_key = 16;     // key length of the exact-match dictionaries (set before add_library)
+  int64_t split_mixed = 1;    // a batch with long reads / reads with N: its one-word N-free reads take the dictionary kernels
+  int64_t split_min_len = 20;  // ... and so do not reads shorter than this: their seeds (half a read in a 1-mismatch pass) name hundreds of rows of a large library
   int64_t stratum0_unit = 0;  // (measured slower, default off) the exact stratum of a 2-mismatch pass behind a seed launch rides in that launch
   int64_t seed_buckets = 1;  // large libraries get seed buckets where they pay (set before add_library); 0 at run time: not used
   int64_t seed_wgs = 0;      // seed_kernel workgroups (256 threads) per CU; 0 = what the launch's instantiation keeps resident
@@ -217,6 +219,7 @@ struct mrg_ctx {
   uint32_t last_mode[MRG_MAX_PASSES] = {0};
   uint32_t last_group[MRG_MAX_PASSES] = {0};
   uint32_t last_launches[MRG_MAX_PASSES] = {0};
+  uint32_t last_split = 0;  // the last run split its batch into one-word reads and the rest
   uint32_t last_kbits_log2[MRG_MAX_PASSES] = {0};
   uint32_t last_pair_anchor[MRG_MAX_PASSES] = {0};
   hipEvent_t ev[MRG_MAX_PASSES + 1] = {nullptr};
@@ -607,6 +610,11 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->wide_rows_16 = value != 0;  // takes effect for libraries added afterwards
   } else if (k == "dict") {
     ctx->dict = value != 0;  // (the dictionaries themselves are built by mrg_ctx_add_library while this is 1)
+  } else if (k == "split_mixed") {
+    ctx->split_mixed = value != 0;
+  } else if (k == "split_min_len") {
+    if (value < 0 || value > 32) return fail(MRG_ERR_ARG, "mrg_ctx_set_option: split_min_len must be in [0,32]");
+    ctx->split_min_len = value;
   } else if (k == "stratum0_unit") {
     ctx->stratum0_unit = value != 0;
   } else if (k == "seed_buckets") {
@@ -649,18 +657,19 @@ int mrg_ctx_release_scratch(mrg_ctx* ctx) {
 }
 
 // --------------------------------------------------------------- cascade
-// workspace: [idx A][idx B]  (each n + kListSlack u32: segmented survivor lists; a producer
-//            workgroup's segment holds every read of its chunks, 256, 1024 or 4096 reads each)
-//            [segment counts A, B: kMaxSegments u32 each][stats: MRG_MAX_PASSES * 5 u64]
+// workspace: [idx A][idx B][idx C]  (each n + kListSlack u32: segmented survivor lists; a producer
+//            workgroup's segment holds every read of its chunks, 256, 1024 or 4096 reads each; C parks
+//            the one-word reads of a split batch while the other reads run their cascade)
+//            [segment counts A, B, C: kMaxSegments u32 each][stats: MRG_MAX_PASSES * 5 u64]
 static uint64_t ws_idx_bytes(uint64_t n) {
   return (((n + mrg::kListSlack) * 4 + 255) / 256) * 256;
 }
-static const uint64_t kWsCountsBytes = 2 * mrg::kMaxSegments * 4;
+static const uint64_t kWsCountsBytes = 3 * mrg::kMaxSegments * 4;
 static const uint64_t kWsStatsBytes = MRG_MAX_PASSES * kStatsPerPass * 8;
 
 int mrg_cascade_workspace_bytes(uint64_t n, uint64_t* bytes) {
   if (!bytes) return fail(MRG_ERR_ARG, "mrg_cascade_workspace_bytes: null argument");
-  *bytes = 2 * ws_idx_bytes(n) + kWsCountsBytes + kWsStatsBytes;
+  *bytes = 3 * ws_idx_bytes(n) + kWsCountsBytes + kWsStatsBytes;
   return MRG_OK;
 }
 
@@ -781,9 +790,9 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   }
 
   char* ws = (char*)d_workspace;
-  uint32_t* idx[2] = {(uint32_t*)ws, (uint32_t*)(ws + ws_idx_bytes(n))};
-  uint32_t* counts = (uint32_t*)(ws + 2 * ws_idx_bytes(n));
-  uint64_t* stats = (uint64_t*)(ws + 2 * ws_idx_bytes(n) + kWsCountsBytes);
+  uint32_t* idx[3] = {(uint32_t*)ws, (uint32_t*)(ws + ws_idx_bytes(n)), (uint32_t*)(ws + 2 * ws_idx_bytes(n))};
+  uint32_t* counts = (uint32_t*)(ws + 3 * ws_idx_bytes(n));
+  uint64_t* stats = (uint64_t*)(ws + 3 * ws_idx_bytes(n) + kWsCountsBytes);
   // per-pass counters only; the outputs need no memset (the last pass writes the
   // "unannotated" values for whatever it does not claim)
   HIP_TRY(hipMemsetAsync(stats, 0, kWsStatsBytes, stream));
@@ -806,8 +815,10 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     if (cap * grid > n + mrg::kListSlack) return 0u;
     return (uint32_t)cap;
   };
-  int cur_list = 0;        // which of the two list buffers holds the newest survivor list
+  int cur_list = 0;        // which list buffer holds the newest survivor list
   bool have_list = false;  // false: the next pass that runs reads the identity list of all reads
+  int pair0 = 0, pair1 = 1;  // the two buffers the running cascade alternates between
+  auto other_list = [&](int cur) { return cur == pair0 ? pair1 : pair0; };
 
   HIP_TRY(hipEventRecord(ctx->ev[0], stream));
 
@@ -841,8 +852,18 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     return ctx->fuse != 0 && passes[i].max_mm_seed <= 1 && n / (1024ull * (uint64_t)std::max(ctx->n_cu, 1)) < 60000ull;
   };
   auto small_lib = [&](uint32_t i) { return ctx->libs[passes[i].lib].kbits != nullptr && ctx->kmer_filter; };
-  // one-word reads without N: the batches the dictionary kernels (dict.hip) take
-  const bool dict_batch = ctx->dict && words_per_read == 1 && !d_nmask;
+  // one-word reads without N: the batches the dictionary kernels (dict.hip) take.  A batch with
+  // longer reads, reads with N or very short reads is SPLIT: the reads of split_min_len .. 32 nt
+  // without N -- most of any small-RNA read set -- go through the cascade as the one-word batch they
+  // are (the kernels read word 0 of the plane-major array), the rest through the FM kernels (whose
+  // backtracking search does not mind a 16-nt read's 8-base seeds); two cascades over disjoint lists,
+  // one after the other, adding to the same counters.  (The length hint only says whether a one-word
+  // batch may hold such short reads: a wrong hint costs time, never a result.)
+  bool dict_batch = ctx->dict && words_per_read == 1 && !d_nmask;
+  uint32_t words_eff = words_per_read;
+  const uint64_t* nmask_eff = d_nmask;
+  const bool split = ctx->dict && ctx->split_mixed && n > 0 && ctx->force_lds_mode < 0 &&
+                     (!dict_batch || ctx->hint_min_len < ctx->split_min_len);
 
   // the classic path: one match_kernel launch for pass i
   auto run_single = [&](uint32_t i, int32_t k_first, int32_t k_last, bool first_part, bool last_part, bool by_pairs = false) -> int {
@@ -868,7 +889,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       e.reads = d_reads;
       e.lens = d_lens;
       e.n_total = (uint32_t)n;
-      const int next_list = have_list ? (cur_list ^ 1) : 0;
+      const int next_list = have_list ? other_list(cur_list) : pair0;
       e.idx_in = have_list ? idx[cur_list] : nullptr;
       e.in_count = counts + cur_list * mrg::kMaxSegments;
       e.in_nseg = prev_grid;
@@ -930,9 +951,9 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     p.simple_segs = l.simple ? 1u : 0u;
     p.reads = d_reads;
     p.lens = d_lens;
-    p.nmask = d_nmask;
+    p.nmask = nmask_eff;
     p.n_total = (uint32_t)n;
-    const int next_list = have_list ? (cur_list ^ 1) : 0;
+    const int next_list = have_list ? other_list(cur_list) : pair0;
     p.idx_in = have_list ? idx[cur_list] : nullptr;
     p.in_count = counts + cur_list * mrg::kMaxSegments;
     p.in_nseg = prev_grid;
@@ -1045,9 +1066,9 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     ctx->last_pair_anchor[i] = p.pair_anchor;
     if (rows_kernel) ctx->last_mode[i] = rows_lds_text ? 5u : 6u;
     if (n && rows_kernel) {
-      HIP_TRY(mrg::launch_stratum(p, words_per_read, rows_lds_text, grid, lds_total, stream));
+      HIP_TRY(mrg::launch_stratum(p, words_eff, rows_lds_text, grid, lds_total, stream));
     } else if (n) {
-      HIP_TRY(mrg::launch_match(p, words_per_read, lds_mode, grid, lds_total, stream));
+      HIP_TRY(mrg::launch_match(p, words_eff, lds_mode, grid, lds_total, stream));
     }
     ctx->last_launches[i] += 1;
     if (last_part) HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
@@ -1109,7 +1130,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       sp.seg_ref = l.seg_ref;
       sp.seg_off = l.seg_off;
       sp.chunk_seg = l.chunk_seg;
-      sp.nmask = d_nmask;
+      sp.nmask = nmask_eff;
       sp.counters = stats + (size_t)i * kStatsPerPass;
       sp.n = l.n;
       sp.primary = l.primary;
@@ -1222,10 +1243,10 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     fp.kb_words = kb_words;
     fp.reads = d_reads;
     fp.lens = d_lens;
-    fp.nmask = d_nmask;
+    fp.nmask = nmask_eff;
     fp.n_total = (uint32_t)n;
     fp.uniform_len = 0u;  // (see run_single)
-    const int next_list = have_list ? (cur_list ^ 1) : 0;
+    const int next_list = have_list ? other_list(cur_list) : pair0;
     fp.idx_in = have_list ? idx[cur_list] : nullptr;
     fp.in_count = counts + cur_list * mrg::kMaxSegments;
     fp.in_nseg = prev_grid;
@@ -1246,7 +1267,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     const uint32_t seg_cap = segment_capacity(grid, 1024, have_list);
     if (!seg_cap && n) return fail(MRG_ERR_ARG, "mrg_cascade_run: survivor lists outgrew the workspace");
     fp.out_seg_cap = seg_cap;
-    if (n) HIP_TRY(mrg::launch_fused(fp, words_per_read, grid, lds_total, stream));
+    if (n) HIP_TRY(mrg::launch_fused(fp, words_eff, grid, lds_total, stream));
     ctx->last_launches[members[0]] = 1;
     for (uint32_t q = 0; q < n_sub; ++q) HIP_TRY(hipEventRecord(ctx->ev[members[q] + 1], stream));
     if (fp.idx_out) {
@@ -1332,7 +1353,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     sp.reads = d_reads;
     sp.lens = d_lens;
     sp.n_total = (uint32_t)n;
-    const int next_list = have_list ? (cur_list ^ 1) : 0;
+    const int next_list = have_list ? other_list(cur_list) : pair0;
     sp.idx_in = have_list ? idx[cur_list] : nullptr;
     sp.in_count = counts + cur_list * mrg::kMaxSegments;
     sp.in_nseg = prev_grid;
@@ -1380,6 +1401,42 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   };
   auto small_class = [&](uint32_t i) { return !ctx->libs[passes[i].lib].host_seqs.empty(); };
 
+  uint32_t split_grid = 0, split_cap = 0;
+  if (split) {
+    mrg::SplitParams sp;
+    sp.lens = d_lens;
+    sp.nmask = d_nmask;
+    sp.n_total = (uint32_t)n;
+    sp.min_len = (uint32_t)ctx->split_min_len;
+    split_grid = std::min<uint32_t>((uint32_t)ctx->n_cu * 2u, mrg::kMaxSegments);
+    split_cap = segment_capacity(split_grid, 1024, false);
+    if (!split_cap) return fail(MRG_ERR_ARG, "mrg_cascade_run: survivor lists outgrew the workspace");
+    sp.seg_cap = split_cap;
+    sp.idx_rest = idx[0];
+    sp.cnt_rest = counts;
+    sp.idx_short = idx[2];
+    sp.cnt_short = counts + 2 * mrg::kMaxSegments;
+    HIP_TRY(mrg::launch_split(sp, split_grid, stream));
+  }
+  ctx->last_split = split ? 1u : 0u;
+  // (a split batch: the per-pass events are recorded by both cascades, the later record stands -- the
+  // first pass's time then includes the whole cascade of the long reads)
+  for (int chain = 0; chain < (split ? 2 : 1); ++chain) {
+  if (split) {
+    have_list = true;
+    prev_grid = split_grid;
+    prev_seg_cap = split_cap;
+    for (auto& b : stratum0_done) b = false;
+    if (chain == 0) {  // long reads and reads with N: lists in buffers 0 / 1
+      pair0 = 0, pair1 = 1, cur_list = 0;
+      dict_batch = false;
+    } else {  // the one-word reads: parked in buffer 2, alternating with buffer 1
+      pair0 = 2, pair1 = 1, cur_list = 2;
+      dict_batch = true;
+      words_eff = 1u;
+      nmask_eff = nullptr;
+    }
+  }
   bool launched_any = false;
   for (uint32_t i = 0; i < n_pass;) {
     if (!runs[i]) {
@@ -1476,6 +1533,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       ++i;
     }
     launched_any = true;
+  }
   }
   if (d_pass_counts) HIP_TRY(mrg::launch_export_pass_counts(stats, n_pass, d_pass_counts, stream));
   ctx->last_stream = stream;

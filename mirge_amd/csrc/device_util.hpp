@@ -44,6 +44,27 @@ __device__ __forceinline__ uint32_t pick_table(const JumpTables& t, int32_t plen
   return k;
 }
 
+// The jump table a seed of k bases is looked up in without LF steps: the smallest table with K >= k --
+// the seed's rows are those of the 4^(K - k) K-mers it is a prefix of, the interval between two
+// entries of that table 4^(K - k) apart (`shift` = 2 (K - k); all k bases are then known to match) --
+// else the largest table with K <= k (shift = 0, the first K bases match).  Returns K (0 = none).
+__device__ __forceinline__ uint32_t pick_seed_table(const JumpTables& t, int32_t k, uint32_t& word_off, uint32_t& shift) {
+  uint32_t K = 0;
+  word_off = 0;
+  shift = 0;
+#pragma unroll
+  for (int i = 3; i >= 0; --i) {  // descending: the last table taken is the smallest one that holds the seed
+    const bool take = t.k[i] != 0u && (int32_t)t.k[i] >= k;
+    K = take ? t.k[i] : K;
+    word_off = take ? t.off[i] : word_off;
+  }
+  if (K) {
+    shift = 2u * (K - (uint32_t)k);
+    return K;
+  }
+  return pick_table(t, k, word_off);
+}
+
 // 32 text bases from position p (2-bit packed text in global memory, 3 dword loads)
 __device__ __forceinline__ uint64_t text_window(const uint32_t* __restrict__ text, uint32_t p) {
   const uint32_t i = p >> 4, sh = (p & 15) * 2;

@@ -760,14 +760,17 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
             n_rows = cnt;
             tag = slot | (ui << 11) | (off << 13) | (kp << 19) | kRowFromBucket;
           } else {
-            uint32_t tab_off = 0;
-            kp = un.tabs.k[0] ? pick_table(un.tabs, k, tab_off) : 0u;
+            uint32_t tab_off = 0, shift = 0;
+            const uint32_t K = un.tabs.k[0] ? pick_seed_table(un.tabs, k, tab_off, shift) : 0u;
             uint32_t hi = un.n + 1u;
             lo = 0;
-            if (kp) {
-              const uint32_t* tab = un.ftab + tab_off + lex_code((q >> (2u * off)) & low_bits(2u * kp), kp);
+            kp = 0;
+            if (K) {
+              // (a seed shorter than the table's K: the rows of every K-mer it starts)
+              kp = min(K, (uint32_t)k);
+              const uint32_t* tab = un.ftab + tab_off + (lex_code((q >> (2u * off)) & low_bits(2u * kp), kp) << shift);
               lo = tab[0];
-              hi = tab[1];
+              hi = tab[1u << shift];
             }
             ++c_lookups;
             n_rows = hi > lo ? hi - lo : 0u;

@@ -2177,6 +2177,42 @@ __global__ void export_pass_counts_kernel(const uint64_t* stats, uint32_t n_pass
   }
 }
 
+// One-word N-free reads to one list, the rest to the other (SplitParams).  A wave appends its
+// members with one LDS atomic per list; the order inside a segment is whatever the waves' turns
+// make it -- no consumer depends on it.
+__global__ __launch_bounds__(1024) void split_kernel(SplitParams p) {
+  __shared__ uint32_t fill[2];
+  if (threadIdx.x < 2) fill[threadIdx.x] = 0u;
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * p.seg_cap;
+  for (uint64_t c0 = (uint64_t)blockIdx.x * 1024u; c0 < p.n_total; c0 += (uint64_t)gridDim.x * 1024u) {
+    const uint64_t r = c0 + threadIdx.x;
+    const bool live = r < p.n_total;
+    bool is_short = false;
+    if (live) {
+      const uint32_t len = p.lens[r];
+      is_short = len >= p.min_len && len <= 32u && (!p.nmask || p.nmask[r] == 0ull);
+    }
+    const uint64_t m_short = __ballot(live && is_short), m_rest = __ballot(live && !is_short);
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t o_short = 0, o_rest = 0;
+    if (lane == 0) {
+      if (m_short) o_short = atomicAdd(&fill[0], (uint32_t)__popcll(m_short));
+      if (m_rest) o_rest = atomicAdd(&fill[1], (uint32_t)__popcll(m_rest));
+    }
+    o_short = __shfl(o_short, 0);
+    o_rest = __shfl(o_rest, 0);
+    const uint64_t below = (1ull << lane) - 1ull;
+    if (live && is_short) p.idx_short[base + o_short + __popcll(m_short & below)] = (uint32_t)r;
+    if (live && !is_short) p.idx_rest[base + o_rest + __popcll(m_rest & below)] = (uint32_t)r;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    p.cnt_short[blockIdx.x] = fill[0];
+    p.cnt_rest[blockIdx.x] = fill[1];
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Launch helpers (host)
 // ---------------------------------------------------------------------------
@@ -2328,6 +2364,11 @@ hipError_t launch_count(const CountParams& p, uint32_t words_per_read, uint32_t 
     default: return hipErrorInvalidValue;
   }
 #undef MRG_COUNT
+  return hipGetLastError();
+}
+
+hipError_t launch_split(const SplitParams& p, uint32_t grid, hipStream_t stream) {
+  hipLaunchKernelGGL(split_kernel, dim3(grid), dim3(1024), 0, stream, p);
   return hipGetLastError();
 }
 

@@ -415,5 +415,20 @@ hipError_t launch_count(const CountParams& p, uint32_t words_per_read, uint32_t 
 hipError_t exclusive_sum_u32_u64(const uint32_t* in, uint64_t* out, uint64_t n_plus_1, hipStream_t stream);
 hipError_t launch_export_pass_counts(const uint64_t* stats, uint32_t n_pass, uint64_t* out,
                                      hipStream_t stream);
+// A batch split into two segmented lists: the reads the dictionary kernels take (min_len <= length
+// <= 32, no N: they read word 0 only) and the rest.  Workgroup b owns segment b of both lists (seg_cap entries each, chunks of 1024
+// reads).
+struct SplitParams {
+  const uint8_t* lens;
+  const uint64_t* nmask;  // null = no read has an N
+  uint32_t n_total;
+  uint32_t min_len;
+  uint32_t seg_cap;
+  uint32_t* idx_short;
+  uint32_t* cnt_short;
+  uint32_t* idx_rest;
+  uint32_t* cnt_rest;
+};
+hipError_t launch_split(const SplitParams& p, uint32_t grid, hipStream_t stream);
 
 }  // namespace mrg

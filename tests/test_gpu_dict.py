@@ -26,6 +26,9 @@ def engine(world):
     eng = Engine(0)
     for k in LIB_ORDER:
         eng.add_library(k, world.index[k])
+    # this module's subject is the dictionary kernels: every read of the batch goes to them (by default
+    # reads under 20 nt take the FM kernels: tests/test_gpu_split.py)
+    eng.set_option("split_min_len", 0)
     return eng
 
 

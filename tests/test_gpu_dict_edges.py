@@ -41,6 +41,7 @@ def test_low_complexity_library_through_the_dictionary_kernels(native_lib, oracl
     w, l, nm = pack.pack_reads(reads)
     assert w.shape[0] == 1 and nm is None
     eng = Engine(0)
+    eng.set_option("split_min_len", 0)     # the short reads too go to the dictionary kernels
     eng.add_library("rep", ix)
     eng.add_library("decoy", FmIndex.build(["decoy"], ["GATTACAGATTACAGGCCTTAAGGCCTTAACGCGCGTATATA" * 3]))
     lib = model.Library(names, seqs)
@@ -89,12 +90,15 @@ def test_reads_shorter_than_keys_and_seed_tables(native_lib, oracle_lib):
     for k in LIB_ORDER:
         eng.add_library(k, w0.index[k])
     ref = model.fm_cascade(w0.views, w0.passes, w, l, None, wstop=DEFAULT_WSTOP, ftab=True)
-    res = eng.cascade(ReadSet(w, l, None, None, device=eng.device), eng.mirge_passes())
-    for name, a in zip(("pass_id", "ref_id", "pos", "mm"), res.to_host()):
-        assert np.array_equal(a, ref[name]), name
-    for i, st in enumerate(res.stats):
-        assert (st["processed"], st["aligned"]) == (int(ref["stats"][i][0]), int(ref["stats"][i][1])), i
-    assert res.stats[0]["lds_mode"] == 7 and res.stats[2]["lds_mode"] in (8, 9)
+    for split_min_len in (0, 20):          # all reads through the dictionary kernels / the short ones through the FM kernels
+        eng.set_option("split_min_len", split_min_len)
+        res = eng.cascade(ReadSet(w, l, None, None, device=eng.device), eng.mirge_passes())
+        for name, a in zip(("pass_id", "ref_id", "pos", "mm"), res.to_host()):
+            assert np.array_equal(a, ref[name]), (split_min_len, name)
+        for i, st in enumerate(res.stats):
+            assert (st["processed"], st["aligned"]) == (int(ref["stats"][i][0]), int(ref["stats"][i][1])), (split_min_len, i)
+        assert res.stats[0]["lds_mode"] == 7 and res.stats[2]["lds_mode"] in (8, 9)
+        assert res.stats[0]["n_launches"] == (2 if split_min_len else 1)
     eng.close()
 
 

@@ -1,0 +1,87 @@
+"""GPU parity (-m gpu) of split batches: a batch with reads longer than 32 nt or reads with N (two words
+per read and / or an N mask -- what a real trimmed FASTQ gives) runs as two cascades over disjoint
+lists, its one-word N-free reads through the dictionary kernels and the rest through the FM kernels
+(capi.hip: cascade_run_impl).  Assignments, the per-pass processed / aligned counters, the packed form
+and the tally must equal the CPU port's and the unsplit FM run's."""
+import numpy as np
+import pytest
+
+from oracle import model
+from mirge_amd.engine import DEFAULT_WSTOP
+from tests.util import LIB_ORDER, World
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world(native_lib, oracle_lib):
+    w = World(scale=0.05, n_fixed=12000, n_var=5000, with_n=True, max_var_len=60)
+    assert w.words.shape[0] == 2 and w.nmask is not None
+    assert int((w.lens <= 32).sum()) > 5000 and int((w.lens > 32).sum()) > 300 and int((w.lens < 20).sum()) > 100
+    return w
+
+
+@pytest.fixture(scope="module")
+def engine(world):
+    from mirge_amd.engine import Engine
+    eng = Engine(0)
+    for k in LIB_ORDER:
+        eng.add_library(k, world.index[k])
+    yield eng
+    eng.close()
+
+
+def same(res, ref):
+    for name, a in zip(("pass_id", "ref_id", "pos", "mm"), res.to_host()):
+        assert np.array_equal(a, ref[name]), name
+    for i, st in enumerate(res.stats):
+        assert (st["processed"], st["aligned"]) == (int(ref["stats"][i][0]), int(ref["stats"][i][1])), i
+
+
+def test_split_batch_equals_port_and_unsplit_run(engine, world):
+    from mirge_amd import synth
+    from mirge_amd.engine import ReadSet
+    ref = model.fm_cascade(world.views, world.passes, world.words, world.lens, world.nmask, wstop=DEFAULT_WSTOP, ftab=True)
+    quant = synth.synth_quant(world.words.shape[1], n_samples=3)
+    rs = ReadSet(world.words, world.lens, world.nmask, quant, device=engine.device)
+    passes = engine.mirge_passes()
+    res = engine.cascade(rs, passes)
+    same(res, ref)
+    st = res.stats
+    # the one-word reads' cascade ran last: its kernels are the ones reported, both cascades launched pass 0
+    assert st[0]["lds_mode"] == 7 and st[0]["n_launches"] == 2
+    assert st[2]["lds_mode"] in (8, 9)
+    engine.set_option("split_mixed", 0)
+    whole = engine.cascade(rs, passes)
+    engine.set_option("split_mixed", 1)
+    same(whole, ref)
+    assert whole.stats[0]["lds_mode"] != 7 and whole.stats[0]["n_launches"] == 1
+    # packed outputs and the tally on top of them
+    pk = engine.cascade_packed(rs, passes)
+    assert np.array_equal(pk.packed.cpu().numpy(), engine.pack_assignments(res).cpu().numpy())   # (res equals the port's arrays)
+    counts = engine.tally(rs, pk, world.n_mirna).cpu().numpy()
+    assert np.array_equal(counts.astype(np.uint64), model.tally(ref["pass_id"], ref["ref_id"], quant, world.n_mirna, 9, 0, 8))
+
+
+@pytest.mark.parametrize("keep", ["short", "long", "n_only"])
+def test_split_batch_with_an_empty_side(engine, world, keep):
+    """Two-word batches whose reads are all short (an N mask of zeros / a W = 2 array the caller padded),
+    all long, or short but every one with an N: one of the two lists is empty."""
+    from mirge_amd.engine import ReadSet
+    if keep == "short":
+        sel = np.flatnonzero((world.lens <= 32) & (world.lens >= 20) & (world.nmask[0] == 0))[:4000]
+    elif keep == "long":
+        sel = np.flatnonzero(world.lens > 32)
+    else:
+        sel = np.flatnonzero((world.lens <= 32) & (world.nmask[0] != 0))
+    assert len(sel) > 50
+    words = np.ascontiguousarray(world.words[:, sel])
+    lens = np.ascontiguousarray(world.lens[sel])
+    nmask = np.ascontiguousarray(world.nmask[:, sel])
+    ref = model.fm_cascade(world.views, world.passes, words, lens, nmask, wstop=DEFAULT_WSTOP, ftab=True)
+    res = engine.cascade(ReadSet(words, lens, nmask, None, device=engine.device), engine.mirge_passes())
+    same(res, ref)
+    # one word per read but an N mask: still a split batch
+    if keep == "n_only":
+        res1 = engine.cascade(ReadSet(words[:1].copy(), lens, nmask[:1].copy(), None, device=engine.device), engine.mirge_passes())
+        same(res1, ref)
