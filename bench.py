@@ -151,6 +151,12 @@ def main():
     ap.add_argument("--no-ftab", action="store_true")
     ap.add_argument("--sorted", action="store_true",
                     help="feed the reads in the order the GPU collapse emits uniques (sorted by packed key)")
+    ap.add_argument("--e2e-wire", choices=["compact", "arrays"], default="compact",
+                    help="upload form of the e2e leg: the compact wire form (6.5 B per 22-nt read; one-word reads) or the arrays (13 B)")
+    ap.add_argument("--e2e-chunks", default="8,12,16", help="chunks of the e2e leg (a comma list: each is run, the best is reported)")
+    ap.add_argument("--sort-key", choices=["word", "seed0", "seed1"], default="word",
+                    help="--sorted by the packed word (the collapse's order) or by the first / second 11 bases (what a "
+                         "partition by seed would give the large-library launch: an experiment)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
     ap.add_argument("--outputs", choices=["packed", "arrays"], default="packed",
                     help="per-read output of the timed steps: one 4-byte packed word per read (mrg_cascade_run_packed, "
@@ -219,7 +225,8 @@ def main():
         libs, n_job, lo, hi, workload=("varlen" if wl == "varlen" else "cascade"),
         seed0=seed0 + (4000 if wl == "a2i" else 0), mix=mix, n_samples=args.samples)
     if args.sorted:
-        order = np.argsort(words[0], kind="stable")
+        key = words[0] if args.sort_key == "word" else (words[0] >> np.uint64(22 * int(args.sort_key[-1]))) & np.uint64((1 << 22) - 1)
+        order = np.argsort(key, kind="stable")
         words, lens, quant = np.ascontiguousarray(words[:, order]), lens[order], quant[order]
     log(rank, "reads: %d of %d (%s, %s scaling) generated+packed in %.1f s" %
         (n_reads, n_total, "16..40 nt" if wl == "varlen" else "22 nt", args.scaling, time.time() - t0))
@@ -507,7 +514,11 @@ def main():
     extras = {}
     if world == 1 and not args.no_extras:
         try:
-            extras["e2e"] = run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, got, log)
+            runs_ = [run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, got, log, wire=args.e2e_wire, n_chunks=int(k))
+                     for k in args.e2e_chunks.split(",")]
+            extras["e2e"] = min(runs_, key=lambda r: r["ms_per_step"])
+            if len(runs_) > 1:
+                extras["e2e"]["chunk_sweep"] = {str(r["chunks"]): r["ms_per_step"] for r in runs_}
         except SystemExit:
             raise
         except Exception as e:  # the headline must not die with an optional leg
@@ -596,17 +607,29 @@ def main():
     print(json.dumps(line))
 
 
-def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log, n_chunks=16, reps=3, n_bufs=3):
+def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log, n_chunks=16, reps=3, n_bufs=3, wire="compact"):
     """SURVEY.md 8d "Timed region", throughput figure: H2D of packed reads + counts -> cascade ->
     tally -> D2H of the assignment arrays and the count vector.  The host side is pinned; the read
     set goes through in `n_chunks` chunks on three streams (copy in / compute / copy out) with two
-    device buffers, so PCIe transfers overlap the kernels."""
+    device buffers, so PCIe transfers overlap the kernels.
+    wire = "compact": the host-resident collapsed set travels in the compact wire form (mrg_expand_compact:
+    reads grouped by length as a bit stream of 2 L bits each, one-byte counts + escapes: 6.5 B per 22-nt read
+    instead of 13) when its reads allow (one word, no N); the grouping and bit packing are the host
+    collapse's output format, prepared before the timed region like the arrays are."""
     import torch
+    from mirge_amd import pack
     from mirge_amd.engine import ReadSet
     dev = eng.device
     W, n = words.shape
     S = quant.shape[1]
     t0 = time.perf_counter()
+    compact = wire == "compact" and W == 1 and n > 0 and int(lens.max()) <= 32
+    if compact:
+        order = None if not np.any(lens[1:] < lens[:-1]) else np.argsort(lens, kind="stable")
+        if order is not None:
+            words, lens, quant = np.ascontiguousarray(words[:, order]), lens[order], quant[order]
+            if expect is not None:
+                expect = tuple(a[order] for a in expect)
     h_words = torch.from_numpy(words.view(np.int64)).pin_memory()
     h_lens = torch.from_numpy(lens).pin_memory()
     h_quant = torch.from_numpy(quant.view(np.int32)).pin_memory()
@@ -615,8 +638,25 @@ def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log,
     h_counts = torch.empty(ln, dtype=torch.int64).pin_memory()
     pin_s = time.perf_counter() - t0
     n_chunks = max(1, min(n_chunks, n // 1024 or 1))
-    bounds = [(n * c // n_chunks, n * (c + 1) // n_chunks) for c in range(n_chunks)]
+    cuts = [(n * c // n_chunks) & ~3 for c in range(n_chunks)] + [n]
+    bounds = [(cuts[c], cuts[c + 1]) for c in range(n_chunks)]
     cap = max(b - a for a, b in bounds)
+    if compact:
+        # one bit stream per chunk (already grouped by length: no permutation), back to back in one pinned buffer
+        streams = [pack.compact_read_set(words[:, a:e], lens[a:e])["bits"] for a, e in bounds]
+        s_off = np.concatenate(([0], np.cumsum([len(x) for x in streams]))).astype(np.int64)
+        h_bits = torch.from_numpy(np.concatenate(streams).view(np.int64)).pin_memory()
+        bits_cap = max(len(x) for x in streams)
+        del streams
+        q8, _ = pack.compact_counts(quant)
+        h_q8 = torch.from_numpy(q8).pin_memory()
+        c_runs = [pack.compact_runs(lens[a:e]) for a, e in bounds]
+        c_esc = []
+        for a, e in bounds:
+            _, esc = pack.compact_counts(quant[a:e])
+            c_esc.append(torch.from_numpy(esc.view(np.int32)).pin_memory())
+        esc_cap = max(1, max(int(t.shape[0]) for t in c_esc))
+        esc_total = sum(int(t.shape[0]) for t in c_esc)
     bufs = []
     for _ in range(n_bufs):
         bufs.append(dict(
@@ -625,6 +665,9 @@ def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log,
             out=(torch.empty(cap, dtype=torch.int8, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
                  torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.uint8, device=dev)),
             packed=torch.empty(cap, dtype=torch.int32, device=dev),
+            bits=torch.empty(bits_cap, dtype=torch.int64, device=dev) if compact else None,
+            q8=torch.empty((cap, S), dtype=torch.uint8, device=dev) if compact else None,
+            esc=torch.empty((esc_cap, 2), dtype=torch.int32, device=dev) if compact else None,
             ev_in=torch.cuda.Event(), ev_done=torch.cuda.Event(), ev_free=torch.cuda.Event()))
     counts = torch.zeros(ln, dtype=torch.int64, device=dev)
     pc = torch.zeros(2 * n_pass, dtype=torch.int64, device=dev)
@@ -643,33 +686,55 @@ def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log,
             _one_pass()
         torch.cuda.synchronize()
 
+    host_s = dict(copy=0.0, expand=0.0, cascade=0.0, tally=0.0, out=0.0)
+
     def _one_pass():
+        tp = time.perf_counter
         counts.zero_()
         for b in bufs:
             b["ev_free"].record(s_comp)
         for c, (a, e) in enumerate(bounds):
             b = bufs[c % n_bufs]
             m = e - a
+            t_a = tp()
             with torch.cuda.stream(s_in):
                 s_in.wait_event(b["ev_free"])
-                for w in range(W):
-                    b["words"][w, :m].copy_(h_words[w, a:e], non_blocking=True)
-                if send_lens:
-                    b["lens"][:m].copy_(h_lens[a:e], non_blocking=True)
-                b["quant"][:m].copy_(h_quant[a:e], non_blocking=True)
+                if compact:
+                    nw = int(s_off[c + 1] - s_off[c])
+                    b["bits"][:nw].copy_(h_bits[s_off[c]:s_off[c + 1]], non_blocking=True)
+                    b["q8"][:m].copy_(h_q8[a:e], non_blocking=True)
+                    k = int(c_esc[c].shape[0])
+                    if k:
+                        b["esc"][:k].copy_(c_esc[c], non_blocking=True)
+                else:
+                    for w in range(W):
+                        b["words"][w, :m].copy_(h_words[w, a:e], non_blocking=True)
+                    if send_lens:
+                        b["lens"][:m].copy_(h_lens[a:e], non_blocking=True)
+                    b["quant"][:m].copy_(h_quant[a:e], non_blocking=True)
                 b["ev_in"].record(s_in)
             s_comp.wait_event(b["ev_in"])
-            # the SoA stride of the cascade is the row length of the words array it is handed
-            wv = b["words"] if m == cap else b["words"][:, :m].contiguous()
-            rsc = ReadSet.from_device(wv, b["lens"][:m], None, b["quant"][:m], min_len, max_len)
-            o = tuple(t[:m] for t in b["out"]) + (pc,)
+            t_b = tp()
+            if compact:
+                rsc = eng.expand_compact(b["bits"][:int(s_off[c + 1] - s_off[c])], c_runs[c], b["q8"][:m], b["esc"][:int(c_esc[c].shape[0])], n_samples=S,
+                                         out=(b["words"][:, :m], b["lens"][:m], b["quant"][:m]))
+            else:
+                # the SoA stride of the cascade is the row length of the words array it is handed
+                wv = b["words"] if m == cap else b["words"][:, :m].contiguous()
+                rsc = ReadSet.from_device(wv, b["lens"][:m], None, b["quant"][:m], min_len, max_len)
+            t_c = tp()
             res = eng.cascade_packed(rsc, passes, out=(b["packed"][:m], pc))
+            t_d = tp()
             eng.tally(rsc, res, M, canon, iso, counts=counts)
             b["ev_done"].record(s_comp)
+            t_e = tp()
             with torch.cuda.stream(s_out):
                 s_out.wait_event(b["ev_done"])
                 h_packed[a:e].copy_(b["packed"][:m], non_blocking=True)
                 b["ev_free"].record(s_out)
+            t_f = tp()
+            for key, dt in (("copy", t_b - t_a), ("expand", t_c - t_b), ("cascade", t_d - t_c), ("tally", t_e - t_d), ("out", t_f - t_e)):
+                host_s[key] += dt
         with torch.cuda.stream(s_out):
             s_out.wait_event(bufs[(len(bounds) - 1) % n_bufs]["ev_done"])
             h_counts.copy_(counts, non_blocking=True)
@@ -697,11 +762,21 @@ def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log,
     for _ in range(reps):
         one_pass()
     ms = (time.perf_counter() - t0) * 1e3 / reps
+    for key in host_s:
+        host_s[key] = 0.0
+    one_pass()
+    log(0, "e2e: host time issuing one pass of %d chunks: %s ms" % (n_chunks, ", ".join("%s %.2f" % (k, v * 1e3) for k, v in host_s.items())))
     # the two transfers alone, for the record
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for c, (a, e) in enumerate(bounds):
         b = bufs[c % n_bufs]
+        if compact:
+            b["bits"][:int(s_off[c + 1] - s_off[c])].copy_(h_bits[s_off[c]:s_off[c + 1]], non_blocking=True)
+            b["q8"][:e - a].copy_(h_q8[a:e], non_blocking=True)
+            if int(c_esc[c].shape[0]):
+                b["esc"][:int(c_esc[c].shape[0])].copy_(c_esc[c], non_blocking=True)
+            continue
         for w in range(W):
             b["words"][w, :e - a].copy_(h_words[w, a:e], non_blocking=True)
         if send_lens:
@@ -716,6 +791,8 @@ def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log,
     torch.cuda.synchronize()
     d2h_ms = (time.perf_counter() - t0) * 1e3
     h2d_bytes = n * (8 * W + (1 if send_lens else 0) + 4 * S)
+    if compact:
+        h2d_bytes = 8 * int(s_off[-1]) + n * S + 8 * esc_total
     d2h_bytes = n * 4
     log(0, "e2e: %.2f ms per %d reads (H2D alone %.2f ms, D2H alone %.2f ms; pinning the host arrays took %.1f s)" %
         (ms, n, h2d_ms, d2h_ms, pin_s))
@@ -727,8 +804,11 @@ def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log,
                 note="SURVEY.md 8d timed region: pinned host arrays -> H2D (packed reads + counts%s) -> "
                      "cascade (mrg_cascade_run_packed: 4-byte packed assignment per read) -> tally -> D2H (packed words, count "
                      "vector); %d chunks through %d device buffers on three HIP streams (copy in / compute / copy out); "
-                     "H2D-bound: 12-13 B per read up, 4 B down"
-                     % (" + lengths" if send_lens else "; one read length: no length array", n_chunks, n_bufs))
+                     "H2D-bound: %s, 4 B down"
+                     % (" + lengths" if send_lens else "; one read length: no length array", n_chunks, n_bufs,
+                        ("compact wire form (mrg_expand_compact: reads in length groups as a bit stream of 2 L bits each, one-byte counts + %d escapes), "
+                         "%.2f B per read up" % (esc_total, h2d_bytes / max(n, 1))) if compact else "13 B per read up"),
+                wire="compact" if compact else "arrays")
 
 
 def run_collapsed(eng, passes, rs, out, M, n_pass, canon, iso, log, reps=3):

@@ -505,6 +505,28 @@ int mrg_fastq_parse_device(mrg_ctx *ctx, const char *d_text, uint64_t n_bytes, i
                            uint8_t *d_lens, uint64_t *d_nmask, mrg_fastq_device_info *info, void *stream);
 
 /*
+ * The compact wire form of a collapsed read set, for callers whose unique reads live on the HOST (the
+ * reference's seqDic after quantReads.py:3-24): 6.5 bytes per 22-nt read over PCIe instead of the 13 of
+ * the arrays (8-byte word + length + 32-bit count) -- what bounds a host-resident pipeline is the upload.
+ *   runs       HOST array of n_runs (length, count) uint32 pairs: the reads come grouped by length
+ *              (groups in any order, at most 64 of them; N-free reads of at most 32 nt) -- this replaces
+ *              the length array
+ *   d_bits     the reads as a bit stream of 64-bit words: read j of a run of L-base reads is the 2 L bits
+ *              from bit 2 L j of the run's words (little-endian bit order: bit b of the run = bit b % 64 of
+ *              word b / 64; base k of a read in its bits 2k, 2k+1 as in the packed word); every run starts
+ *              a new word.  n_words = the words given: the runs' words + at least one of padding
+ *   d_quant8   n x n_samples bytes, the per-sample counts; 255 = the count is in the escape list
+ *              (NULL: no counts are expanded, d_quant is not written)
+ *   d_esc      n_esc pairs of uint32: (flat index into the n x n_samples counts, count)
+ * widened on the device into the arrays mrg_cascade_run / mrg_tally_run take: d_reads [1][n], d_lens [n],
+ * d_quant [n][n_samples] (16-byte aligned).  Asynchronous on `stream`; the runs are read before the
+ * call returns.
+ */
+int mrg_expand_compact(mrg_ctx *ctx, const uint64_t *d_bits, uint64_t n_words, const uint32_t *runs, uint32_t n_runs,
+                       const uint8_t *d_quant8, const uint32_t *d_esc, uint64_t n_esc, uint64_t n,
+                       uint32_t n_samples, uint64_t *d_reads, uint8_t *d_lens, uint32_t *d_quant, void *stream);
+
+/*
  * Collapse n raw reads (device arrays, layout as for mrg_cascade_run; d_sample gives the
  * sample of each read or is NULL for one sample) into unique reads:
  *   d_u_reads [words_per_read][cap], d_u_lens [cap], d_u_nmask ([..][cap] or NULL),

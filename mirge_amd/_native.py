@@ -145,6 +145,8 @@ SIGNATURES = {
     "mrg_fastq_block_cut": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(C.c_uint64)]),
     "mrg_fastq_parse_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
                                          C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FastqDeviceInfo), C.c_void_p]),
+    "mrg_expand_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
+                                     C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mrg_collapse_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),

@@ -2154,6 +2154,42 @@ int mrg_fastq_parse_device(mrg_ctx* ctx, const char* d_text, uint64_t n_bytes, i
   return MRG_OK;
 }
 
+int mrg_expand_compact(mrg_ctx* ctx, const uint64_t* d_bits, uint64_t n_words, const uint32_t* runs, uint32_t n_runs,
+                       const uint8_t* d_quant8, const uint32_t* d_esc, uint64_t n_esc, uint64_t n, uint32_t n_samples, uint64_t* d_reads,
+                       uint8_t* d_lens, uint32_t* d_quant, void* stream) {
+  if (!ctx) return fail(MRG_ERR_ARG, "mrg_expand_compact: null argument");
+  if (n && (!d_bits || !runs || !d_reads || !d_lens)) return fail(MRG_ERR_ARG, "mrg_expand_compact: null buffers");
+  if (d_quant8 && (!d_quant || !n_samples || (n_esc && !d_esc))) return fail(MRG_ERR_ARG, "mrg_expand_compact: null count buffers");
+  if (n >= 0xfffffff0ull || n * (uint64_t)(n_samples ? n_samples : 1u) >= 0xfffffff0ull)
+    return fail(MRG_ERR_ARG, "mrg_expand_compact: at most 2^32-16 reads (and counts) per call");
+  if (n_runs > mrg::kCompactMaxRuns || (n && !n_runs))
+    return fail(MRG_ERR_ARG, "mrg_expand_compact: 1..%u length runs (got %u)", mrg::kCompactMaxRuns, n_runs);
+  if (((uintptr_t)d_bits % 8) || ((uintptr_t)d_quant8 % 4) || ((uintptr_t)d_quant % 16))
+    return fail(MRG_ERR_ARG, "mrg_expand_compact: buffers must be aligned (bits 8, quant8 4, quant 16 bytes)");
+  mrg::CompactRuns cr;
+  std::memset(&cr, 0, sizeof cr);
+  cr.n = n_runs;
+  uint64_t end = 0, base = 0;
+  for (uint32_t r = 0; r < n_runs; ++r) {
+    const uint32_t len = runs[2 * r], count = runs[2 * r + 1];
+    if (len > 32u) return fail(MRG_ERR_ARG, "mrg_expand_compact: run %u has reads of %u nt (one-word reads only)", r, len);
+    end += count;
+    if (end > n) break;
+    cr.end[r] = (uint32_t)end;
+    cr.base[r] = (uint32_t)base;
+    cr.len[r] = (uint8_t)len;
+    base += ((uint64_t)count * 2u * len + 63u) / 64u;  // every run starts a word
+  }
+  if (end != n) return fail(MRG_ERR_ARG, "mrg_expand_compact: the runs count %llu reads, n is %llu", (unsigned long long)end, (unsigned long long)n);
+  // (the kernel may read one word past a run's last read)
+  if (base + 1 > n_words || base >= 0xffffffffull)
+    return fail(MRG_ERR_ARG, "mrg_expand_compact: the runs need %llu + 1 words of bit stream, %llu were given", (unsigned long long)base,
+                (unsigned long long)n_words);
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(mrg::expand_compact(d_bits, cr, d_quant8, d_esc, n_esc, n, n_samples, d_reads, d_lens, d_quant, (hipStream_t)stream));
+  return MRG_OK;
+}
+
 int mrg_collapse_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_read, const uint8_t* d_lens,
                      const uint64_t* d_nmask, const uint16_t* d_sample, uint64_t n, uint32_t n_samples,
                      uint32_t max_len, uint64_t cap, uint64_t* d_u_reads, uint8_t* d_u_lens,

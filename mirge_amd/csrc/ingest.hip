@@ -234,4 +234,87 @@ hipError_t fastq_parse_device(const char* d_text, uint64_t n_bytes, int32_t phre
   return hipSuccess;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The compact wire form of a collapsed read set that lives on the HOST (include/mirge_amd.h:
+// mrg_expand_compact): reads grouped by length as a bit stream of 2 L bits each, one-byte counts with an
+// escape list -- 6.5 bytes per 22-nt read over PCIe instead of 13 -- widened here into the arrays the
+// cascade and the tally take.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr uint32_t kExpandThreads = 256;
+
+// One read per thread: read j of a run of L-base reads sits at bit 2 L j of the run's words.
+__global__ void __launch_bounds__(kExpandThreads) expand_bits_kernel(const uint64_t* __restrict__ in, CompactRuns runs, uint32_t n,
+                                                                      uint64_t* __restrict__ words, uint8_t* __restrict__ lens) {
+  __shared__ uint32_t s_end[kCompactMaxRuns];
+  __shared__ uint32_t s_len[kCompactMaxRuns];
+  __shared__ uint32_t s_base[kCompactMaxRuns];
+  if (threadIdx.x < kCompactMaxRuns) {
+    s_end[threadIdx.x] = threadIdx.x < runs.n ? runs.end[threadIdx.x] : 0xFFFFFFFFu;
+    s_len[threadIdx.x] = threadIdx.x < runs.n ? runs.len[threadIdx.x] : 0u;
+    s_base[threadIdx.x] = threadIdx.x < runs.n ? runs.base[threadIdx.x] : 0u;
+  }
+  __syncthreads();
+  const uint32_t i = blockIdx.x * kExpandThreads + threadIdx.x;
+  if (i >= n) return;
+  // the run of read i: the first one that ends behind it
+  uint32_t lo = 0, hi = runs.n - 1u;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (s_end[mid] > i) hi = mid;
+    else lo = mid + 1u;
+  }
+  const uint32_t L = s_len[lo], start = lo ? s_end[lo - 1u] : 0u;
+  const uint64_t bit = (uint64_t)(i - start) * (2u * L);
+  const uint64_t* src = in + s_base[lo] + (bit >> 6);
+  const uint32_t sh = (uint32_t)(bit & 63u);
+  uint64_t w = src[0] >> sh;
+  if (sh + 2u * L > 64u) w |= src[1] << (64u - sh);
+  words[i] = L >= 32u ? w : (w & ((1ull << (2u * L)) - 1ull));
+  lens[i] = (uint8_t)L;
+}
+
+// one-byte counts -> 32-bit counts, four per thread (255 = escaped: overwritten by apply_escapes_kernel)
+__global__ void __launch_bounds__(kExpandThreads) widen_counts_kernel(const uint8_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ out) {
+  const uint64_t i0 = ((uint64_t)blockIdx.x * kExpandThreads + threadIdx.x) * 4ull;
+  if (i0 >= n) return;
+  if (i0 + 4ull <= n) {
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(in + i0);
+    *reinterpret_cast<uint4*>(out + i0) = make_uint4(v & 255u, (v >> 8) & 255u, (v >> 16) & 255u, v >> 24);
+  } else {
+    for (uint64_t i = i0; i < n; ++i) out[i] = in[i];
+  }
+}
+
+__global__ void __launch_bounds__(kExpandThreads) apply_escapes_kernel(const uint32_t* __restrict__ esc, uint64_t n_esc, uint64_t n,
+                                                                        uint32_t* __restrict__ out) {
+  const uint64_t k = (uint64_t)blockIdx.x * kExpandThreads + threadIdx.x;
+  if (k >= n_esc) return;
+  const uint32_t i = esc[2 * k];
+  if (i < n) out[i] = esc[2 * k + 1];
+}
+
+}  // namespace
+
+hipError_t expand_compact(const uint64_t* d_bits, const CompactRuns& runs, const uint8_t* d_quant8, const uint32_t* d_esc, uint64_t n_esc,
+                          uint64_t n, uint32_t n_samples, uint64_t* d_reads, uint8_t* d_lens, uint32_t* d_quant, hipStream_t stream) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(expand_bits_kernel, dim3((uint32_t)((n + kExpandThreads - 1) / kExpandThreads)), dim3(kExpandThreads), 0, stream, d_bits,
+                     runs, (uint32_t)n, d_reads, d_lens);
+  CK(hipGetLastError());
+  if (d_quant8) {
+    const uint64_t m = n * n_samples, mq = (m + 3) / 4;
+    hipLaunchKernelGGL(widen_counts_kernel, dim3((uint32_t)((mq + kExpandThreads - 1) / kExpandThreads)), dim3(kExpandThreads), 0, stream,
+                       d_quant8, m, d_quant);
+    CK(hipGetLastError());
+    if (n_esc) {
+      hipLaunchKernelGGL(apply_escapes_kernel, dim3((uint32_t)((n_esc + kExpandThreads - 1) / kExpandThreads)), dim3(kExpandThreads), 0,
+                         stream, d_esc, n_esc, m, d_quant);
+      CK(hipGetLastError());
+    }
+  }
+  return hipSuccess;
+}
+
 }  // namespace mrg

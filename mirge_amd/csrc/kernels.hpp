@@ -315,6 +315,18 @@ hipError_t launch_seed(const SeedParams& p, uint32_t grid, hipStream_t stream);
 hipError_t fastq_parse_device(const char* d_text, uint64_t n_bytes, int32_t phred, int32_t cutoff, int32_t min_len, int32_t cut,
                               uint32_t W, uint64_t cap, uint64_t* d_words, uint8_t* d_lens, uint64_t* d_nmask, uint64_t* h_info,
                               hipStream_t stream);
+// ingest.hip: the compact wire form of a host-resident collapsed read set (mrg_expand_compact) -> the
+// arrays of the cascade and the tally.  Run r: reads [end[r-1], end[r]) have len[r] bases, 2 len[r] bits each
+// from word base[r] of the bit stream.
+constexpr uint32_t kCompactMaxRuns = 64;
+struct CompactRuns {
+  uint32_t n;
+  uint32_t end[kCompactMaxRuns];
+  uint32_t base[kCompactMaxRuns];
+  uint8_t len[kCompactMaxRuns];
+};
+hipError_t expand_compact(const uint64_t* d_bits, const CompactRuns& runs, const uint8_t* d_quant8, const uint32_t* d_esc, uint64_t n_esc,
+                          uint64_t n, uint32_t n_samples, uint64_t* d_reads, uint8_t* d_lens, uint32_t* d_quant, hipStream_t stream);
 hipError_t launch_pack_assignments(const int8_t* pass_id, const int32_t* ref_id, const int32_t* pos, const uint8_t* mm, uint64_t n,
                                    uint32_t* packed, hipStream_t stream);
 

@@ -388,6 +388,29 @@ class Engine:
                                  quant[:U], 0, int(max_len) if max_len else 255)
         return rs, hist
 
+    def expand_compact(self, bits, runs, quant8=None, esc=None, n_samples=1, out=None):
+        """mrg_expand_compact: the compact wire form of a host-resident collapsed read set
+        (pack.compact_read_set; bits int64 [n_words] and quant8 uint8 [n, S] / esc int32 [k, 2] already on
+        the device, runs a host array of (length, count)) -> ReadSet in HBM.  Asynchronous.
+        out = (words int64 [1, n], lens uint8 [n], quant int32 [n, S] or None): caller-owned buffers."""
+        torch = _torch()
+        dev = self.device
+        runs = np.ascontiguousarray(np.asarray(runs, dtype=np.uint32).reshape(-1, 2))
+        n = int(runs[:, 1].sum())
+        if out is not None:
+            words, lens, quant = out
+        else:
+            words = torch.empty((1, max(n, 1)), dtype=torch.int64, device=dev)[:, :n]
+            lens = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)[:n]
+            quant = None if quant8 is None else torch.empty((max(n, 1), n_samples), dtype=torch.int32, device=dev)[:n]
+        check(self._lib.mrg_expand_compact(
+            self._h, bits.data_ptr(), int(bits.numel()), runs.ctypes.data, runs.shape[0], None if quant8 is None else quant8.data_ptr(),
+            None if esc is None or esc.shape[0] == 0 else esc.data_ptr(), 0 if esc is None else int(esc.shape[0]), n, n_samples,
+            words.data_ptr(), lens.data_ptr(), None if quant8 is None else quant.data_ptr(), self._stream_ptr()))
+        live = runs[:, 0][runs[:, 1] > 0]
+        return ReadSet.from_device(words, lens, None, None if quant8 is None else quant, int(live.min()) if n else 0,
+                                   int(live.max()) if n else 255)
+
     def count_best(self, reads, lib, seed_len=28, max_mm_seed=1, max_mm_total=2):
         """Best stratum of every read of a ReadSet against one library, forward strand:
         (fewest mismatches or 255, alignments reaching it, saturating) as host uint8 arrays.

@@ -98,3 +98,90 @@ def unpack_reads(words, lens, nmask=None):
         chars[:, 32 * w:32 * w + nb] = grid
     blob = chars.tobytes()
     return [blob[r * width:r * width + L].decode("ascii") for r, L in enumerate(lens.tolist())]
+
+
+COMPACT_ESCAPE = 255      # one-byte count meaning "look in the escape list"
+COMPACT_MAX_RUNS = 64
+
+
+def pack_bits(w, L):
+    """Reads of L bases (uint64 packed words) as a bit stream of 2 L bits each, little-endian bit order:
+    uint64 [ceil(len(w) * 2 L / 64)]."""
+    w = np.ascontiguousarray(w, dtype=np.uint64)
+    m, bits = w.shape[0], 2 * int(L)
+    if m == 0 or bits == 0:
+        return np.zeros(0, dtype=np.uint64)
+    if bits == 64:
+        return w.copy()
+    g = int(np.gcd(bits, 64))
+    period, wpb = 64 // g, bits // g          # reads and words of one block of the stream
+    n_blk = -(-m // period)
+    v = np.zeros(n_blk * period, dtype=np.uint64)
+    v[:m] = w & np.uint64((1 << bits) - 1)
+    v = v.reshape(n_blk, period)
+    out = np.zeros((n_blk, wpb), dtype=np.uint64)
+    for j in range(period):
+        off = bits * j
+        k, sh = off >> 6, off & 63
+        out[:, k] |= v[:, j] << np.uint64(sh)
+        if sh + bits > 64:
+            out[:, k + 1] |= v[:, j] >> np.uint64(64 - sh)
+    return np.ascontiguousarray(out.reshape(-1)[:-(-(m * bits) // 64)])
+
+
+def compact_read_set(words, lens, quant=None):
+    """The compact wire form of a host-resident collapsed read set (include/mirge_amd.h:
+    mrg_expand_compact): one-word N-free reads grouped by length, 2 L bits each.
+    -> dict(order (the reads' permutation into length groups, None = unchanged), bits uint64 [n_words]
+            (every run starts a word; one word of padding at the end), runs uint32 [n_runs, 2] (length, count),
+            quant8 uint8 [n, S] or None, esc uint32 [k, 2] (flat index, count) or None)."""
+    words = np.asarray(words)
+    lens = np.asarray(lens, dtype=np.uint8)
+    if words.ndim != 2 or words.shape[0] != 1:
+        raise ValueError("compact_read_set: one word per read")
+    n = lens.shape[0]
+    if n and int(lens.max()) > 32:
+        raise ValueError("compact_read_set: reads of more than 32 nt")
+    order = None
+    if n and np.any(lens[1:] < lens[:-1]):
+        order = np.argsort(lens, kind="stable")
+        lens = lens[order]
+    w = words[0] if order is None else words[0][order]
+    runs = compact_runs(lens)
+    parts, a = [], 0
+    for L, count in runs:
+        parts.append(pack_bits(w[a:a + int(count)], int(L)))
+        a += int(count)
+    bits = np.concatenate(parts + [np.zeros(1, dtype=np.uint64)])
+    quant8 = esc = None
+    if quant is not None:
+        q = np.asarray(quant)
+        q = q.reshape(n, q.shape[1] if q.ndim == 2 else 1)
+        if order is not None:
+            q = q[order]
+        quant8, esc = compact_counts(q)
+    return dict(order=order, bits=bits, runs=runs, quant8=quant8, esc=esc)
+
+
+def compact_runs(lens):
+    """(length, count) runs of a length array grouped by length: uint32 [n_runs, 2]."""
+    lens = np.asarray(lens)
+    if lens.shape[0] == 0:
+        return np.zeros((0, 2), dtype=np.uint32)
+    cut = np.flatnonzero(lens[1:] != lens[:-1]) + 1
+    starts = np.concatenate(([0], cut))
+    ends = np.concatenate((cut, [lens.shape[0]]))
+    runs = np.stack([lens[starts].astype(np.uint32), (ends - starts).astype(np.uint32)], axis=1)
+    if runs.shape[0] > COMPACT_MAX_RUNS:
+        raise ValueError("compact_runs: %d length runs (at most %d): group the reads by length" % (runs.shape[0], COMPACT_MAX_RUNS))
+    return np.ascontiguousarray(runs)
+
+
+def compact_counts(quant):
+    """uint32 counts [n, S] -> (uint8 [n, S] with 255 = escaped, uint32 [k, 2] (flat index, count))."""
+    q = np.ascontiguousarray(np.asarray(quant)).astype(np.uint32, copy=False)
+    big = q >= COMPACT_ESCAPE
+    q8 = np.where(big, COMPACT_ESCAPE, q).astype(np.uint8)
+    idx = np.flatnonzero(big.reshape(-1))
+    esc = np.stack([idx.astype(np.uint32), q.reshape(-1)[idx]], axis=1) if idx.size else np.zeros((0, 2), dtype=np.uint32)
+    return q8, np.ascontiguousarray(esc)

@@ -122,3 +122,49 @@ def test_block_cut_on_the_host(native_lib):
     assert text[cut.value:cut.value + 3] == b"@r2" or text[cut.value:cut.value + 3] == b"@r3"
     assert text[:cut.value].count(b"\n") % 4 == 0
     assert native_lib.mrg_fastq_block_cut(text, len(text), 1, C.byref(cut)) == 0 and cut.value == len(text)
+
+
+@pytest.mark.parametrize("n,S", [(0, 1), (1, 1), (3, 2), (4, 1), (4099, 1), (20001, 3)])
+def test_compact_wire_form_expands_to_the_arrays(engine, n, S):
+    """mrg_expand_compact: reads grouped by length as a bit stream of 2 L bits each + one-byte counts with
+    an escape list, widened on the device, must equal the arrays they were made from (every tail size,
+    several samples, counts around the escape value, a single length and all of 1..32)."""
+    import torch
+    rng = np.random.default_rng(n + S)
+    lens = rng.integers(1, 33, n).astype(np.uint8)
+    if n == 4:
+        lens[:] = 22
+    words = rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64)
+    words = np.where(lens < 32, words & ((np.uint64(1) << (2 * np.minimum(lens, 31).astype(np.uint64))) - np.uint64(1)), words)
+    quant = rng.choice([0, 1, 2, 7, 254, 255, 256, 70000, 2**32 - 1], (n, S)).astype(np.uint32)
+    c = pack.compact_read_set(words[None, :], lens, quant)
+    order = np.arange(n) if c["order"] is None else c["order"]
+    dev = engine.device
+    bits = torch.from_numpy(c["bits"].view(np.int64)).to(dev)
+    q8 = torch.from_numpy(c["quant8"]).to(dev)
+    esc = torch.from_numpy(c["esc"].view(np.int32)).to(dev)
+    rs = engine.expand_compact(bits, c["runs"], q8, esc, n_samples=S)
+    torch.cuda.synchronize()
+    assert rs.n == n and rs.W == 1
+    assert np.array_equal(rs.words.cpu().numpy().view(np.uint64)[0], words[order])
+    assert np.array_equal(rs.lens.cpu().numpy(), lens[order])
+    assert np.array_equal(rs.quant.cpu().numpy().view(np.uint32), quant[order])
+    if n:
+        assert (rs.min_len, rs.max_len) == (int(lens.min()), int(lens.max()))
+    # reads only
+    rs2 = engine.expand_compact(bits, c["runs"])
+    torch.cuda.synchronize()
+    assert rs2.quant is None and np.array_equal(rs2.words.cpu().numpy().view(np.uint64)[0], words[order])
+
+
+def test_compact_wire_form_refuses_what_it_cannot_hold(engine):
+    import torch
+    from mirge_amd._native import MirgeAmdError
+    with pytest.raises(ValueError):
+        pack.compact_read_set(np.zeros((1, 2), dtype=np.uint64), np.array([22, 33], dtype=np.uint8))
+    bits = torch.zeros(7, dtype=torch.int64, device=engine.device)      # 8 x 22 nt = 352 bits = 6 words + padding
+    engine.expand_compact(bits, np.array([[22, 8]], dtype=np.uint32))
+    with pytest.raises(MirgeAmdError):
+        engine.expand_compact(bits[:6], np.array([[22, 8]], dtype=np.uint32))      # no padding word
+    with pytest.raises(MirgeAmdError):
+        engine.expand_compact(bits, np.array([[33, 1]], dtype=np.uint32))          # one-word reads only

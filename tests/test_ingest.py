@@ -249,3 +249,38 @@ def test_gpu_collapse_fused_and_general_paths(native_lib):
     # empty input
     out = ingest.collapse(eng, np.zeros((1, 0), np.uint64), np.zeros(0, np.uint8))
     assert out["words"].shape == (1, 0) and out["quant"].shape[0] == 0
+
+
+def test_compact_read_set_groups_by_length_and_escapes_large_counts():
+    """pack.compact_read_set (the host side of mrg_expand_compact): a bit stream of 2 L bits per read in
+    length groups, one-byte counts, escapes for counts >= 255 -- and back, bit by bit."""
+    from mirge_amd import pack
+    rng = np.random.default_rng(3)
+    n = 1000
+    lens = rng.integers(1, 33, n).astype(np.uint8)
+    words = rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64)
+    words = np.where(lens < 32, words & ((np.uint64(1) << (2 * np.minimum(lens, 31).astype(np.uint64))) - np.uint64(1)), words)
+    quant = rng.choice([0, 1, 5, 254, 255, 300, 10**6], (n, 2)).astype(np.uint32)
+    c = pack.compact_read_set(words[None, :], lens, quant)
+    order = c["order"]
+    assert sorted(order.tolist()) == list(range(n)) and np.all(np.diff(lens[order].astype(int)) >= 0)
+    assert c["runs"][:, 1].sum() == n and list(c["runs"][:, 0]) == sorted(set(lens.tolist()))
+    # decode the stream with Python integers
+    stream = [int(x) for x in c["bits"]]
+    base, i = 0, 0
+    for L, count in c["runs"].tolist():
+        big = sum(x << (64 * k) for k, x in enumerate(stream[base:base + (count * 2 * L + 63) // 64 + 1]))
+        for j in range(count):
+            assert (big >> (2 * L * j)) & ((1 << (2 * L)) - 1) == int(words[order][i]), (L, j)
+            i += 1
+        base += (count * 2 * L + 63) // 64
+    assert base + 1 == len(stream)
+    q = c["quant8"].astype(np.uint32).reshape(-1)
+    assert np.all((q == 255) == (quant[order].reshape(-1) >= 255))
+    q[c["esc"][:, 0]] = c["esc"][:, 1]
+    assert np.array_equal(q.reshape(n, 2), quant[order])
+    same = pack.compact_read_set(words[None, :] & np.uint64((1 << 44) - 1), np.full(n, 22, dtype=np.uint8))
+    assert same["order"] is None and same["runs"].tolist() == [[22, n]] and same["quant8"] is None
+    assert same["bits"].shape[0] == (n * 44 + 63) // 64 + 1
+    with pytest.raises(ValueError):
+        pack.compact_read_set(words[None, :2], np.array([22, 33], dtype=np.uint8))
