@@ -357,6 +357,7 @@ enum UnitWord : uint32_t { UW_SA16 = 0, UW_TEXT = 2, UW_SEGSTART = 4, UW_SEGREF 
                            UW_LIMITS = 13, UW_MEMBERS = 14, UW_BUCKETS = 22, UW_SA = 24 };
 constexpr uint32_t kRowFromBucket = 1u << 23;  // tag bit of a row-queue entry: x indexes the unit's buckets, not its wide rows
 constexpr uint32_t kSeedCtlWords = 16u;
+static_assert(2u * kSeedMaxUnits * kSeedMaxMembers <= 64u && kSeedMaxMembers <= 4u, "seed_kernel: one lane per member counter");
 constexpr uint32_t kSeedCntSlots = 16u * 2u + kSeedMaxUnits * 2u;  // per pass processed / aligned, per unit candidates / lookups
 
 struct SeedLds {
@@ -507,7 +508,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
     put(UW_BUCKETS, un.buckets);
     put(UW_SA, un.sa);
     t[UW_FLAGS] = (uint32_t)un.trim5 | ((uint32_t)un.trim3 << 8) | (un.poly_t ? 1u << 16 : 0u) | (un.simple_segs ? 1u << 17 : 0u) |
-                  (un.n_members << 18) | ((uint32_t)un.max_mm_seed << 21);
+                  (un.n_members << 18) | ((uint32_t)un.max_mm_seed << 21) | (un.kind == 1u ? 1u << 23 : 0u);
     t[UW_LIMITS] = (uint32_t)min(un.min_seed_len, 0xFFFF) | ((uint32_t)min(un.max_total, 0xFFFF) << 16);
     for (uint32_t j = 0; j < kSeedMaxMembers; ++j) {
       t[UW_MEMBERS + 2u * j] = (uint32_t)un.m[j].pass_index | ((uint32_t)min(un.m[j].seed_len, 0xFFFF) << 8) | ((uint32_t)min(un.m[j].max_mm_total, 255) << 24);
@@ -525,27 +526,37 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
   const uint32_t n_chunks = in_nseg * depth_chunks;
   // ---- the walk, software-pipelined: the read of tile + grid and the list entry of tile + 2 grid are
   // in flight while a tile is worked on ----
-  auto fetch_index = [&](uint32_t chunk, uint32_t& r_out) -> bool {
-    if (chunk >= n_chunks) return false;
-    const uint32_t sgi = chunk % in_nseg, depth = chunk / in_nseg;
-    const uint32_t t = depth * tile + tid;
-    const bool act = t < (p.idx_in ? p.in_count[sgi] : p.n_total);
+  // (the list cursor: chunk c is chunk c / in_nseg of segment c % in_nseg; it advances by the grid size,
+  // so the division is done once)
+  uint32_t f_chunk = blockIdx.x, f_sgi = blockIdx.x % in_nseg, f_depth = blockIdx.x / in_nseg;
+  const uint32_t f_dsgi = gridDim.x % in_nseg, f_ddepth = gridDim.x / in_nseg;
+  auto fetch_next = [&](uint32_t& r_out) -> bool {
+    bool act = false;
     r_out = 0;
-    if (act) r_out = p.idx_in ? p.idx_in[(size_t)sgi * p.in_seg_cap + t] : t;
+    if (f_chunk < n_chunks) {
+      const uint32_t t = f_depth * tile + tid;
+      act = t < (p.idx_in ? p.in_count[f_sgi] : p.n_total);
+      if (act) r_out = p.idx_in ? p.idx_in[(size_t)f_sgi * p.in_seg_cap + t] : t;
+    }
+    f_chunk += gridDim.x;
+    f_sgi += f_dsgi;
+    f_depth += f_ddepth;
+    if (f_sgi >= in_nseg) {
+      f_sgi -= in_nseg;
+      ++f_depth;
+    }
     return act;
   };
   uint32_t r_b = 0, r_c = 0, L_b = 255u;
   uint64_t rd_b = 0;
   uint32_t c_inl_lookups = 0, c_inl_cands = 0, inl_unit = 0;  // bucket lookups answered in phase 1 (diagnostics, per lane)
   uint32_t el_mask = 0;  // bit u: the lane's read is offered to unit u (set in phase 1, read in phase 3)
-  // reads offered to / claimed by each member pass: wave-level sums of ballots (scalar registers)
-  uint32_t acc_proc[kSeedMaxUnits][kSeedMaxMembers], acc_alig[kSeedMaxUnits][kSeedMaxMembers];
-#pragma unroll
-  for (uint32_t a = 0; a < kSeedMaxUnits; ++a)
-#pragma unroll
-    for (uint32_t b = 0; b < kSeedMaxMembers; ++b) acc_proc[a][b] = acc_alig[a][b] = 0u;
-  bool act_b = fetch_index(blockIdx.x, r_b);
-  bool act_c = fetch_index(blockIdx.x + gridDim.x, r_c);
+  // reads offered to / claimed by each member pass, summed over the wave's tiles: ONE vector register,
+  // lane 2c / 2c + 1 = the two counters of member c (units in order, members in order) -- two dozen
+  // scalar accumulators live across the loop would be spilled
+  uint32_t acc_v = 0;
+  bool act_b = fetch_next(r_b);
+  bool act_c = fetch_next(r_c);
   if (act_b) {
     L_b = p.lens[r_b];
     rd_b = p.reads[r_b];
@@ -562,7 +573,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
       L_b = p.lens[r_b];
       rd_b = p.reads[r_b];
     }
-    act_c = fetch_index(chunk + 2u * gridDim.x, r_c);
+    act_c = fetch_next(r_c);
     // ================= phase 1: the tile's reads into LDS, and their items =================
     // A seed of exactly bucket_k bases in a unit with seed buckets is answered right here: the first four
     // rows of both seeds' buckets are requested together (one 128-byte line per seed, eight loads in
@@ -883,28 +894,33 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
       const bool claimed = key != ~0ull;
       const int32_t cp = claimed ? (int32_t)(key >> 56) : 255;
       uint32_t o_ref = 0, o_pos = 0;
-#pragma unroll
-      for (uint32_t ui = 0; ui < kSeedMaxUnits; ++ui) {
-        if (ui >= p.n_units) break;
+      uint32_t tile_cnt = 0, c = 0, sel = 0;  // sel: unit << 2 | member of the claiming pass
+      for (uint32_t ui = 0; ui < p.n_units; ++ui) {
         const SeedUnit& un = p.unit[ui];
         const bool el = ((el_mask >> ui) & 1u) != 0u;
-#pragma unroll
-        for (uint32_t mi = 0; mi < kSeedMaxMembers; ++mi) {
-          if (mi >= un.n_members) break;
+        for (uint32_t mi = 0; mi < un.n_members; ++mi, ++c) {
           const int32_t pi = un.m[mi].pass_index;
-          acc_proc[ui][mi] += (uint32_t)__popcll(__ballot(el && cp >= pi));
-          acc_alig[ui][mi] += (uint32_t)__popcll(__ballot(cp == pi));
-          if (cp == pi) {
-            if (un.kind == 1u) {
-              o_ref = (uint32_t)(key >> 21) & 0x7FFFFFFu;
-              o_pos = (uint32_t)key & 0x1FFFFFu;
-            } else {
-              SegTables segs{un.seg_start, un.seg_ref, un.seg_off, un.chunk_seg, un.simple_segs};
-              uint32_t ref;
-              locate_entry(segs, (uint32_t)(key >> 16), (uint32_t)key & 0xFFFFu, 255u, ref, o_pos);
-              o_ref = ref - un.m[mi].entry_lo;
-            }
-          }
+          const uint32_t n_off = (uint32_t)__popcll(__ballot(el && cp >= pi)), n_al = (uint32_t)__popcll(__ballot(cp == pi));
+          tile_cnt = lane == 2u * c ? n_off : tile_cnt;
+          tile_cnt = lane == 2u * c + 1u ? n_al : tile_cnt;
+          sel = cp == pi ? (ui << 2) | mi : sel;
+        }
+      }
+      acc_v += tile_cnt;
+      if (claimed) {
+        // one decode, with the claiming unit's tables from the LDS unit table
+        const uint32_t* ut = l.utab + (sel >> 2) * kUnitWords;
+        const uint32_t flags = ut[UW_FLAGS];
+        if (flags & (1u << 23)) {
+          o_ref = (uint32_t)(key >> 21) & 0x7FFFFFFu;
+          o_pos = (uint32_t)key & 0x1FFFFFu;
+        } else {
+          SegTables segs{reinterpret_cast<const uint32_t*>(lds_pointer(ut, UW_SEGSTART)), reinterpret_cast<const uint32_t*>(lds_pointer(ut, UW_SEGREF)),
+                         reinterpret_cast<const uint32_t*>(lds_pointer(ut, UW_SEGOFF)), reinterpret_cast<const uint32_t*>(lds_pointer(ut, UW_CHUNKSEG)),
+                         (flags >> 17) & 1u};
+          uint32_t ref;
+          locate_entry(segs, (uint32_t)(key >> 16), (uint32_t)key & 0xFFFFu, 255u, ref, o_pos);
+          o_ref = ref - ut[UW_MEMBERS + 2u * (sel & 3u) + 1u];
         }
       }
       if (p.packed) {
@@ -939,18 +955,15 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
     if (lane == 0) {
       if (t_c) atomicAdd(&l.cnt[32u + 2u * inl_unit], (unsigned long long)t_c);
       if (t_l) atomicAdd(&l.cnt[32u + 2u * inl_unit + 1u], (unsigned long long)t_l);
-#pragma unroll
-      for (uint32_t ui = 0; ui < kSeedMaxUnits; ++ui) {
-        if (ui >= p.n_units) break;
-#pragma unroll
-        for (uint32_t mi = 0; mi < kSeedMaxMembers; ++mi) {
-          if (mi >= p.unit[ui].n_members) break;
-          const int32_t pi = p.unit[ui].m[mi].pass_index;
-          if (acc_proc[ui][mi]) atomicAdd(&l.cnt[2 * pi], (unsigned long long)acc_proc[ui][mi]);
-          if (acc_alig[ui][mi]) atomicAdd(&l.cnt[2 * pi + 1], (unsigned long long)acc_alig[ui][mi]);
-        }
-      }
     }
+    // lane 2c / 2c + 1 holds the wave's counts of member c
+    uint32_t c = 0, cslot = 0;
+    for (uint32_t ui = 0; ui < p.n_units; ++ui)
+      for (uint32_t mi = 0; mi < p.unit[ui].n_members; ++mi, ++c) {
+        const uint32_t pi = (uint32_t)p.unit[ui].m[mi].pass_index;
+        cslot = (lane >> 1) == c ? 2u * pi + (lane & 1u) : cslot;
+      }
+    if (lane < 2u * c && acc_v) atomicAdd(&l.cnt[cslot], (unsigned long long)acc_v);
   }
   __syncthreads();
   if (tid < 32u) {
