@@ -378,6 +378,10 @@ def main():
             kernel="not launched" if L is None else L["kernel"].replace("mrg::", ""),
             launch=None if L is None else L["first"], n_launches=s["n_launches"], kbits_log2=s["kbits_log2"],
             compulsory_floor_ms=round(16.0 * s["processed"] / (HBM_ACHIEVABLE_GBS * 1e6), 4)))
+        if s.get("ms_rest", 0.0) > 0.0:
+            # a split batch (long reads / reads with N / very short reads ran their own cascade through the FM
+            # kernels first): `ms`, `kernel` and the roofline describe the cascade of the one-word reads
+            passes_report[-1]["ms_rest"] = round(float(s["ms_rest"]), 4)
 
     # ---- parity gates + CPU baseline (rank 0, N = 1 only) ----
     cpu, parity = None, {}
@@ -600,6 +604,11 @@ def main():
         "cpu_baseline": cpu,
         "parity": parity,
         "passes": passes_report,
+        "split_batch": None if not any("ms_rest" in p_ for p_ in passes_report) else dict(
+            rest_ms=round(sum(p_.get("ms_rest", 0.0) for p_ in passes_report), 4),
+            one_word_ms=round(sum(p_["ms"] for p_ in passes_report), 4),
+            note="the batch was split on the device: reads of 20..32 nt without N ran the cascade through the dictionary kernels "
+                 "(passes[].ms, kernel, roofline), the rest through the FM kernels first (passes[].ms_rest); counters are the sums"),
     }
     line.update(extras)
     if legs:

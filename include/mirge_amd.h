@@ -194,8 +194,8 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * than one word per read, an N mask, or (by the length hint) reads under split_min_len nt is split on the
  * device into the reads of split_min_len .. 32 nt without N, which run the cascade through the dictionary
  * kernels as the one-word batch they are, and the rest, which runs it through the FM kernels first -- two
- * cascades over disjoint lists adding to the same counters (mrg_pass_stats then names the kernels of the
- * second one, n_launches counts both, and the first pass's ms includes the whole first cascade);
+ * cascades over disjoint lists adding to the same counters (mrg_pass_stats then names the kernels and times
+ * of the second one, ms_rest the times of the first, n_launches counts both);
  * "wide_rows_16", "round_large": see DESIGN.md. */
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);
 int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,
@@ -257,6 +257,9 @@ typedef struct mrg_pass_stats {
                           (lookups = pair lookups, candidates = their rows, no LF steps), reads
                           of at least 4 x (pair_anchor - 1) through anchors one base shorter;
                           still shorter reads went through the stratum-first pigeonhole pieces */
+  float ms_rest;       /* a split batch ("split_mixed"): device time of this pass in the FIRST cascade (the
+                          long reads, reads with N, very short reads: FM kernels); ms and the kernel fields
+                          above describe the second one (the one-word reads); 0 when the batch was not split */
 } mrg_pass_stats;
 
 /* Bytes of device workspace mrg_cascade_run needs for n reads (three index lists of n + 2^23 entries,

@@ -33,7 +33,7 @@ class PassStats(C.Structure):
                 ("candidates", C.c_uint64), ("lookups", C.c_uint64), ("ms", C.c_float),
                 ("lds_bytes", C.c_uint32), ("lds_mode", C.c_uint32), ("group", C.c_uint32),
                 ("n_launches", C.c_uint32), ("kbits_log2", C.c_uint32),
-                ("pair_anchor", C.c_uint32)]
+                ("pair_anchor", C.c_uint32), ("ms_rest", C.c_float)]
 
 
 class IndexInfo(C.Structure):

@@ -223,6 +223,7 @@ struct mrg_ctx {
   uint32_t last_kbits_log2[MRG_MAX_PASSES] = {0};
   uint32_t last_pair_anchor[MRG_MAX_PASSES] = {0};
   hipEvent_t ev[MRG_MAX_PASSES + 1] = {nullptr};
+  hipEvent_t ev0[MRG_MAX_PASSES + 1] = {nullptr};  // the first cascade of a split batch
   bool ev_ready = false;
 };
 
@@ -414,7 +415,10 @@ void mrg_ctx_destroy(mrg_ctx* ctx) {
     (void)hipFree(sl->kbits);
   }
   if (ctx->ev_ready)
+  {
     for (auto& e : ctx->ev) (void)hipEventDestroy(e);
+    for (auto& e : ctx->ev0) (void)hipEventDestroy(e);
+  }
   if (ctx->comm) (void)rccl_api()->CommDestroy(ctx->comm);
   (void)hipFree(ctx->scratch);
   for (auto& kv : ctx->round_tables) (void)hipFree(kv.second);
@@ -786,6 +790,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   hipStream_t stream = (hipStream_t)stream_;
   if (!ctx->ev_ready) {
     for (auto& e : ctx->ev) HIP_TRY(hipEventCreate(&e));
+    for (auto& e : ctx->ev0) HIP_TRY(hipEventCreate(&e));
     ctx->ev_ready = true;
   }
 
@@ -820,7 +825,8 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   int pair0 = 0, pair1 = 1;  // the two buffers the running cascade alternates between
   auto other_list = [&](int cur) { return cur == pair0 ? pair1 : pair0; };
 
-  HIP_TRY(hipEventRecord(ctx->ev[0], stream));
+  hipEvent_t* evs = ctx->ev;  // the per-pass events of the cascade that is being issued
+  HIP_TRY(hipEventRecord(evs[0], stream));
 
   // ---- launch plan: which passes run, and which consecutive ones share a (fused) launch ----
   // A pass whose length window excludes every read of the batch (caller's hint: e.g. the hairpin
@@ -921,7 +927,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       ctx->last_group[i] = i;
       if (n) HIP_TRY(mrg::launch_exact_dict(e, grid, stream));
       ctx->last_launches[i] += 1;
-      HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
+      HIP_TRY(hipEventRecord(evs[i + 1], stream));
       if (e.idx_out) {
         cur_list = next_list;
         have_list = true;
@@ -1071,7 +1077,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       HIP_TRY(mrg::launch_match(p, words_eff, lds_mode, grid, lds_total, stream));
     }
     ctx->last_launches[i] += 1;
-    if (last_part) HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
+    if (last_part) HIP_TRY(hipEventRecord(evs[i + 1], stream));
     if (p.idx_out) {
       cur_list = next_list;
       have_list = true;
@@ -1269,7 +1275,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     fp.out_seg_cap = seg_cap;
     if (n) HIP_TRY(mrg::launch_fused(fp, words_eff, grid, lds_total, stream));
     ctx->last_launches[members[0]] = 1;
-    for (uint32_t q = 0; q < n_sub; ++q) HIP_TRY(hipEventRecord(ctx->ev[members[q] + 1], stream));
+    for (uint32_t q = 0; q < n_sub; ++q) HIP_TRY(hipEventRecord(evs[members[q] + 1], stream));
     if (fp.idx_out) {
       cur_list = next_list;
       have_list = true;
@@ -1382,7 +1388,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     sp.out_seg_cap = seg_cap;
     if (n) HIP_TRY(mrg::launch_seed(sp, grid, stream));
     ctx->last_launches[first] = 1;
-    for (uint32_t q = first; q < end; ++q) HIP_TRY(hipEventRecord(ctx->ev[q + 1], stream));
+    for (uint32_t q = first; q < end; ++q) HIP_TRY(hipEventRecord(evs[q + 1], stream));
     if (sp.idx_out) {
       cur_list = next_list;
       have_list = true;
@@ -1419,8 +1425,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     HIP_TRY(mrg::launch_split(sp, split_grid, stream));
   }
   ctx->last_split = split ? 1u : 0u;
-  // (a split batch: the per-pass events are recorded by both cascades, the later record stands -- the
-  // first pass's time then includes the whole cascade of the long reads)
+  // (a split batch: each cascade records its own per-pass events: mrg_pass_stats.ms / .ms_rest)
   for (int chain = 0; chain < (split ? 2 : 1); ++chain) {
   if (split) {
     have_list = true;
@@ -1430,7 +1435,13 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     if (chain == 0) {  // long reads and reads with N: lists in buffers 0 / 1
       pair0 = 0, pair1 = 1, cur_list = 0;
       dict_batch = false;
-    } else {  // the one-word reads: parked in buffer 2, alternating with buffer 1
+      evs = ctx->ev0;
+      HIP_TRY(hipEventRecord(evs[0], stream));
+    } else {
+      evs = ctx->ev;
+      HIP_TRY(hipEventRecord(evs[0], stream));
+    }
+    if (chain == 1) {  // the one-word reads: parked in buffer 2, alternating with buffer 1
       pair0 = 2, pair1 = 1, cur_list = 2;
       dict_batch = true;
       words_eff = 1u;
@@ -1440,7 +1451,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   bool launched_any = false;
   for (uint32_t i = 0; i < n_pass;) {
     if (!runs[i]) {
-      HIP_TRY(hipEventRecord(ctx->ev[i + 1], stream));
+      HIP_TRY(hipEventRecord(evs[i + 1], stream));
       ++i;
       continue;
     }
@@ -1511,7 +1522,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       int rc = run_fused(members, n_sub, ends);
       if (rc != MRG_OK) return rc;
       for (uint32_t q = i; q < j; ++q)
-        if (!runs[q]) HIP_TRY(hipEventRecord(ctx->ev[q + 1], stream));
+        if (!runs[q]) HIP_TRY(hipEventRecord(evs[q + 1], stream));
       i = j;
     } else {
       const int32_t kfull = passes[i].max_mm_seed + 1;
@@ -1597,6 +1608,8 @@ int mrg_cascade_stats(mrg_ctx* ctx, mrg_pass_stats* out, uint32_t n_pass) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
     out[i].ms = ms;
+    out[i].ms_rest = 0.f;
+    if (ctx->last_split) HIP_TRY(hipEventElapsedTime(&out[i].ms_rest, ctx->ev0[i], ctx->ev0[i + 1]));
     out[i].lds_bytes = ctx->last_lds[i];
     out[i].lds_mode = ctx->last_mode[i];
     out[i].group = ctx->last_group[i];

@@ -51,11 +51,12 @@ def test_split_batch_equals_port_and_unsplit_run(engine, world):
     # the one-word reads' cascade ran last: its kernels are the ones reported, both cascades launched pass 0
     assert st[0]["lds_mode"] == 7 and st[0]["n_launches"] == 2
     assert st[2]["lds_mode"] in (8, 9)
+    assert st[0]["ms_rest"] > 0 and st[0]["ms"] > 0     # each cascade has its own per-pass times
     engine.set_option("split_mixed", 0)
     whole = engine.cascade(rs, passes)
     engine.set_option("split_mixed", 1)
     same(whole, ref)
-    assert whole.stats[0]["lds_mode"] != 7 and whole.stats[0]["n_launches"] == 1
+    assert whole.stats[0]["lds_mode"] != 7 and whole.stats[0]["n_launches"] == 1 and whole.stats[0]["ms_rest"] == 0
     # packed outputs and the tally on top of them
     pk = engine.cascade_packed(rs, passes)
     assert np.array_equal(pk.packed.cpu().numpy(), engine.pack_assignments(res).cpu().numpy())   # (res equals the port's arrays)
