@@ -191,7 +191,8 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * of passes with at most one seed mismatch after the first launch go through seed_kernel (libraries of at
  * most 4 Mbp searched with one policy as ONE index of their concatenation, built when a cascade first
  * plans it); "split_mixed" = 1 (default) / 0 and "split_min_len" = 20 (default) / 0..32: a batch with more
- * than one word per read, an N mask, or (by the length hint) reads under split_min_len nt is split on the
+ * than one word per read, an N mask, or (by the length hint) reads under split_min_len nt -- unless the hint
+ * puts every read on one side: all longer than 32 nt, or all under split_min_len -- is split on the
  * device into the reads of split_min_len .. 32 nt without N, which run the cascade through the dictionary
  * kernels as the one-word batch they are, and the rest, which runs it through the FM kernels first -- two
  * cascades over disjoint lists adding to the same counters (mrg_pass_stats then names the kernels and times

@@ -869,7 +869,8 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   uint32_t words_eff = words_per_read;
   const uint64_t* nmask_eff = d_nmask;
   const bool split = ctx->dict && ctx->split_mixed && n > 0 && ctx->force_lds_mode < 0 &&
-                     (!dict_batch || ctx->hint_min_len < ctx->split_min_len);
+                     (!dict_batch || ctx->hint_min_len < ctx->split_min_len) &&
+                     ctx->hint_min_len <= 32 && ctx->hint_max_len >= ctx->split_min_len;  // (some read may be on either side)
 
   // the classic path: one match_kernel launch for pass i
   auto run_single = [&](uint32_t i, int32_t k_first, int32_t k_last, bool first_part, bool last_part, bool by_pairs = false) -> int {

@@ -451,12 +451,22 @@ def test_big_library_jump_tables(native_lib, oracle_lib):
     assert w.shape[0] == 2
     ref = model.fm_cascade([ix.view()], BIG_PASSES, w, l, nm, wstop=DEFAULT_WSTOP, ftab=True)
     rs = ReadSet(w, l, nm, None, device=eng.device)
+    # the FM kernels on the whole batch (their search counters equal the port's) ...
+    eng.set_option("split_mixed", 0)
     res = eng.cascade(rs, eng.make_passes([dict(p, lib="big") for p in BIG_PASSES]))
     for name, a in zip(("pass_id", "ref_id", "pos", "mm"), res.to_host()):
         assert np.array_equal(a, ref[name]), name
     for i, st in enumerate(res.stats):
         assert [st[k] for k in ("processed", "aligned", "steps", "candidates", "lookups")] == \
             [int(x) for x in ref["stats"][i]]
+    # ... and the default: the batch split, its 20..32-nt reads through the dictionary kernels
+    eng.set_option("split_mixed", 1)
+    res = eng.cascade(rs, eng.make_passes([dict(p, lib="big") for p in BIG_PASSES]))
+    for name, a in zip(("pass_id", "ref_id", "pos", "mm"), res.to_host()):
+        assert np.array_equal(a, ref[name]), name
+    for i, st in enumerate(res.stats):
+        assert [st[k] for k in ("processed", "aligned")] == [int(x) for x in ref["stats"][i][:2]]
+    assert any(st["ms_rest"] > 0 for st in res.stats)
     short = [r for r in reads if len(r) <= 32]
     w1, l1, nm1 = pack.pack_reads(short)
     assert w1.shape[0] == 1
