@@ -168,3 +168,36 @@ def test_compact_wire_form_refuses_what_it_cannot_hold(engine):
         engine.expand_compact(bits[:6], np.array([[22, 8]], dtype=np.uint32))      # no padding word
     with pytest.raises(MirgeAmdError):
         engine.expand_compact(bits, np.array([[33, 1]], dtype=np.uint32))          # one-word reads only
+
+
+def test_cascade_over_a_compact_upload_equals_the_arrays(engine, native_lib, oracle_lib):
+    """The whole host-resident path: a collapsed set of 16..32-nt reads -> pack.compact_read_set -> upload ->
+    mrg_expand_compact -> packed cascade + tally, against the same reads sent as arrays (the compact form
+    regroups the reads by length: `order` maps back)."""
+    import torch
+    from mirge_amd import synth
+    from mirge_amd.engine import Engine, ReadSet
+    from tests.util import LIB_ORDER, World
+    w0 = World(scale=0.03, n_fixed=6000, n_var=3000, with_n=False, max_var_len=32)
+    eng = Engine(0)
+    for k in LIB_ORDER:
+        eng.add_library(k, w0.index[k])
+    n = w0.words.shape[1]
+    quant = synth.synth_quant(n, n_samples=2)
+    quant[::97, 0] = 1000 + np.arange(len(quant[::97]))        # some counts beyond one byte
+    rs = ReadSet(w0.words, w0.lens, None, quant, device=eng.device)
+    passes = eng.mirge_passes()
+    want = eng.cascade_packed(rs, passes)
+    want_stats = want.stats                      # (read before the next cascade: the counters live in the context)
+    want_counts = eng.tally(rs, want, w0.n_mirna).cpu().numpy()
+    c = pack.compact_read_set(w0.words, w0.lens, quant)
+    assert c["order"] is not None and len(c["runs"]) > 10 and len(c["esc"]) > 0
+    dev = eng.device
+    rs2 = eng.expand_compact(torch.from_numpy(c["bits"].view(np.int64)).to(dev), c["runs"], torch.from_numpy(c["quant8"]).to(dev),
+                             torch.from_numpy(c["esc"].view(np.int32)).to(dev), n_samples=2)
+    got = eng.cascade_packed(rs2, passes)
+    assert np.array_equal(got.packed.cpu().numpy(), want.packed.cpu().numpy()[c["order"]])
+    assert np.array_equal(eng.tally(rs2, got, w0.n_mirna).cpu().numpy(), want_counts)
+    for a, b in zip(got.stats, want_stats):
+        assert (a["processed"], a["aligned"]) == (b["processed"], b["aligned"])
+    eng.close()
