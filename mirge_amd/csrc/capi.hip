@@ -124,7 +124,6 @@ struct SeedLib {
   bool owned = false;  // false: `lib` is a copy of the pointers of a library of the context
   std::vector<uint32_t> entry_lo;
   uint32_t* kbits = nullptr;  // presence bitmaps of the 8-, 9-, 10- and 11-mers (owned units of small libraries)
-  uint32_t kbits_off[4] = {0, 0, 0, 0};
 };
 
 }  // namespace
@@ -728,12 +727,7 @@ int get_seed_lib(mrg_ctx* ctx, const std::vector<int32_t>& lib_ids, SeedLib** ou
     if (rc) return rc;
     // presence bitmaps of the k-mers, k = 8..11: bit c = some text position starts the k-mer with
     // code c (first base in the low two bits)
-    uint32_t words = 0;
-    for (uint32_t k = 8; k <= 11; ++k) {
-      sl->kbits_off[k - 8] = words;
-      words += (1u << (2 * k)) / 32u;
-    }
-    std::vector<uint32_t> bits(words, 0u);
+    std::vector<uint32_t> bits(mrg::kSeedKbitsWords, 0u);
     for (size_t sg = 0; sg + 1 < ix.seg_start.size(); ++sg) {
       const uint32_t s0 = ix.seg_start[sg], s1 = ix.seg_start[sg + 1];
       for (uint32_t p = s0; p < s1; ++p) {
@@ -742,7 +736,7 @@ int get_seed_lib(mrg_ctx* ctx, const std::vector<int32_t>& lib_ids, SeedLib** ou
         const uint32_t win = (uint32_t)(lo64 >> sh);  // 16 bases from p
         for (uint32_t k = 8; k <= 11 && p + k <= s1; ++k) {
           const uint32_t c = win & ((1u << (2 * k)) - 1u);
-          bits[sl->kbits_off[k - 8] + (c >> 5)] |= 1u << (c & 31u);
+          bits[mrg::seed_kbits_word_off(k) + (c >> 5)] |= 1u << (c & 31u);
         }
       }
     }
@@ -1309,7 +1303,6 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
         if (rc != MRG_OK) return rc;
         fm = &sl->lib;
         un.kbits = sl->kbits;
-        for (int t = 0; t < 4; ++t) un.kbits_off[t] = sl->kbits_off[t];
       } else {
         un.slots = reinterpret_cast<const uint4*>(fm->dict_slots);
         un.log2_slots = fm->dict_log2;

@@ -30,6 +30,18 @@ __device__ __forceinline__ uint32_t lex_code(uint64_t code, uint32_t k) {
   return (uint32_t)(((r >> 1) & kOddBits) | ((r & kOddBits) << 1));
 }
 
+// The kernel's (single, by-value) parameter block where it sits, in the kernel-argument segment, through
+// a pointer laundered by an empty asm: fields read through it are scalar loads issued HERE, every time --
+// for values a loop needs once per trip but that, kept in registers across it, are spilled (to VGPR
+// lanes, or worse to scratch, whose reloads wait with vmcnt(0) and drain the loads in flight).
+template <typename Params>
+__device__ __forceinline__ const __attribute__((address_space(4))) Params* kernel_args_here() {
+  typedef const __attribute__((address_space(4))) Params* kernarg_ptr_t;
+  kernarg_ptr_t k = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(k));
+  return k;
+}
+
 // The largest jump table with k <= plen (tables in ascending k; k[0] == 0: none usable): its k
 // (0 = none) and its word offset inside `ftab`.
 __device__ __forceinline__ uint32_t pick_table(const JumpTables& t, int32_t plen, uint32_t& word_off) {

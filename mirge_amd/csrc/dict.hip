@@ -534,9 +534,21 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
     bool act = false;
     r_out = 0;
     if (f_chunk < n_chunks) {
-      const uint32_t t = f_depth * tile + tid;
-      act = t < (p.idx_in ? p.in_count[f_sgi] : p.n_total);
-      if (act) r_out = p.idx_in ? p.idx_in[(size_t)f_sgi * p.in_seg_cap + t] : t;
+      // (segment and depth are the workgroup's: scalar registers, so that the segment's count is a scalar
+      // load -- a vector load here would be waited for with vmcnt(0) and drain the reads just requested)
+      const uint32_t sgi = __builtin_amdgcn_readfirstlane(f_sgi), t_base = __builtin_amdgcn_readfirstlane(f_depth * tile);
+      const uint32_t t = t_base + tid;
+      const auto* kp = kernel_args_here<SeedParams>();  // (the list's pointers: scalar loads per trip, not spilled registers)
+      const uint32_t* idx_in = kp->idx_in;
+      if (idx_in) {
+        typedef const __attribute__((address_space(4))) uint32_t* const_u32_t;  // (written by the launch before this one)
+        act = t < ((const_u32_t)(uintptr_t)kp->in_count)[sgi];
+        const uint32_t* seg = idx_in + (size_t)sgi * kp->in_seg_cap + t_base;
+        if (act) r_out = seg[tid];
+      } else {
+        act = t < kp->n_total;
+        r_out = act ? t : 0u;
+      }
     }
     f_chunk += gridDim.x;
     f_sgi += f_dsgi;
@@ -640,13 +652,18 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
             }
           }
         }
+        // the unit's presence bitmaps: both seeds' words are requested before either is looked at
+        if (un.kind == 0u && un.kbits && k >= 8) {
+          const uint32_t kb = (uint32_t)min(k, 11), woff = seed_kbits_word_off(kb), cmask = (1u << (2u * kb)) - 1u;
+          const uint32_t code0 = (uint32_t)q & cmask, code1 = (uint32_t)(q >> (2u * (uint32_t)k)) & cmask;
+          uint32_t w0 = ~0u, w1 = ~0u;
+          if (queued & 1u) w0 = un.kbits[woff + (code0 >> 5)];
+          if (queued & 2u) w1 = un.kbits[woff + (code1 >> 5)];
+          if (!((w0 >> (code0 & 31u)) & 1u)) queued &= ~1u;
+          if (!((w1 >> (code1 & 31u)) & 1u)) queued &= ~2u;
+        }
         for (uint32_t j = 0; j < n_seeds; ++j) {
-          bool need = ((queued >> j) & 1u) != 0u;
-          if (un.kind == 0u && un.kbits && need && k >= 8) {
-            const uint32_t kb = (uint32_t)min(k, 11);
-            const uint32_t code = (uint32_t)(q >> (2u * j * (uint32_t)k)) & ((1u << (2u * kb)) - 1u);
-            need = ((un.kbits[un.kbits_off[kb - 8u] + (code >> 5)] >> (code & 31u)) & 1u) != 0u;
-          }
+          const bool need = ((queued >> j) & 1u) != 0u;
           const uint64_t mask = __ballot(need);
           if (mask) {
             uint32_t base = 0;

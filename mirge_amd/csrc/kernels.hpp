@@ -255,6 +255,13 @@ hipError_t launch_exact_dict(const ExactParams& p, uint32_t grid, hipStream_t st
 constexpr uint32_t kSeedMaxUnits = 3u, kSeedMaxMembers = 4u, kSeedThreads = 256u;
 constexpr uint32_t kSeedRowsPerItem = 24u;  // wider intervals are verified by the whole workgroup
 constexpr uint32_t kSeedWideCap = 64u;
+// Word offset of the k-mer presence bitmap (k = 8..11, 4^k bits each, back to back) inside a seed
+// library's `kbits` array: arithmetic, so that a lane with its own k needs no table load.
+__host__ __device__ constexpr uint32_t seed_kbits_word_off(uint32_t k) {
+  return k <= 8u ? 0u : k == 9u ? 2048u : k == 10u ? 2048u + 8192u : 2048u + 8192u + 32768u;
+}
+constexpr uint32_t kSeedKbitsWords = 2048u + 8192u + 32768u + 131072u;
+
 struct SeedMember {
   int32_t pass_index, seed_len, max_mm_total;
   uint32_t entry_lo;  // first entry of this member in the unit's (union) library
@@ -276,8 +283,7 @@ struct SeedUnit {
   uint32_t simple_segs;
   const uint4* slots;  // kind 1
   uint32_t log2_slots, key_bases;
-  const uint32_t* kbits;  // presence bitmaps of the k-mers, k = 8..11, at word offsets kbits_off[k - 8]; null = none
-  uint32_t kbits_off[4];
+  const uint32_t* kbits;  // presence bitmaps of the k-mers, k = 8..11, at word offsets seed_kbits_word_off(k); null = none
   int32_t max_mm_seed, trim5, trim3, min_len, max_len, poly_t;
   int32_t min_seed_len, max_total;  // over the members
   uint32_t n_members;
