@@ -192,13 +192,14 @@ __global__ void __launch_bounds__(kBlock, 8) exact_dict_kernel(const ExactParams
       }
       home[u] = (((uint32_t)rd[u] & kmask) * kDictHashMul) >> hshift;
       s[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (search[u]) {
-        s[u] = p.slots[home[u]];
-        ++c_lookups;
-      }
+      // (nothing but the load here: a counter bumped between the four slot loads was a spilled register
+      // whose scratch reload waited with vmcnt(0) -- for the slot load just issued, one after the other)
+      if (search[u]) s[u] = p.slots[home[u]];
     }
     bool aligned[U];
     uint32_t o_ref[U], o_pos[U], o_mm[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) c_lookups += search[u] ? 1u : 0u;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       aligned[u] = false;
