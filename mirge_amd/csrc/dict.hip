@@ -163,6 +163,8 @@ __global__ void __launch_bounds__(kBlock, 8) exact_dict_kernel(const ExactParams
           rd[u] = p.reads[r[u]];
         }
     }
+    // (the streaming instantiation's read indices are arithmetic: no registers held, or spilled, for them)
+    auto rid = [&](int u) -> uint32_t { return FIRST ? t0 + (uint32_t)u : r[u]; };
     // ---- which reads this pass's FASTA would contain (RAP:543-554, 664-686), and their slots ----
     int32_t L[U];
     bool eligible[U], search[U], fallback[U];
@@ -283,8 +285,8 @@ __global__ void __launch_bounds__(kBlock, 8) exact_dict_kernel(const ExactParams
       } else {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          if (aligned[u]) p.packed[r[u]] = pack_assignment(p.pass_index, o_ref[u], o_pos[u], o_mm[u]);
-          else if (active[u] && (FIRST || !p.idx_out)) p.packed[r[u]] = 0u;
+          if (aligned[u]) p.packed[rid(u)] = pack_assignment(p.pass_index, o_ref[u], o_pos[u], o_mm[u]);
+          else if (active[u] && (FIRST || !p.idx_out)) p.packed[rid(u)] = 0u;
         }
       }
     } else if (FIRST && full) {
@@ -305,16 +307,16 @@ __global__ void __launch_bounds__(kBlock, 8) exact_dict_kernel(const ExactParams
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (aligned[u]) {
-          p.pass_id[r[u]] = (int8_t)p.pass_index;
-          p.ref_id[r[u]] = (int32_t)o_ref[u];
-          p.pos[r[u]] = (int32_t)o_pos[u];
-          p.mm[r[u]] = (uint8_t)o_mm[u];
+          p.pass_id[rid(u)] = (int8_t)p.pass_index;
+          p.ref_id[rid(u)] = (int32_t)o_ref[u];
+          p.pos[rid(u)] = (int32_t)o_pos[u];
+          p.mm[rid(u)] = (uint8_t)o_mm[u];
         } else if (active[u] && (FIRST || !p.idx_out)) {
           // first pass: every output is written; last pass: whatever is still unclaimed stays unannotated
-          p.pass_id[r[u]] = (int8_t)-1;
-          p.ref_id[r[u]] = -1;
-          p.pos[r[u]] = -1;
-          p.mm[r[u]] = 0;
+          p.pass_id[rid(u)] = (int8_t)-1;
+          p.ref_id[rid(u)] = -1;
+          p.pos[rid(u)] = -1;
+          p.mm[rid(u)] = 0;
         }
       }
     }
@@ -330,7 +332,7 @@ __global__ void __launch_bounds__(kBlock, 8) exact_dict_kernel(const ExactParams
         uint32_t* dst = p.idx_out + (size_t)blockIdx.x * p.out_seg_cap + wbase + (incl - n_surv);
 #pragma unroll
         for (int u = 0; u < U; ++u)
-          if (active[u] && !aligned[u]) *dst++ = r[u];
+          if (active[u] && !aligned[u]) *dst++ = rid(u);
       }
     }
   }
