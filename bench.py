@@ -62,6 +62,25 @@ def kernels_sha16():
     return h.hexdigest()[:16]
 
 
+def git_head():
+    """Commit the tree was built from: `git rev-parse` where .git exists (this container), else what
+    __graft_entry__.build() recorded next to the library (the GPU box gets a snapshot without .git)."""
+    import subprocess
+    try:
+        out = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True, timeout=10)
+        if out.returncode == 0 and out.stdout.strip():
+            dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], capture_output=True,
+                                   text=True, timeout=20).stdout.strip() != ""
+            return out.stdout.strip()[:12] + ("+dirty" if dirty else "")
+    except Exception:
+        pass
+    try:
+        info = json.load(open(os.path.join(ROOT, "mirge_amd", "lib", "build_info.json")))
+        return info.get("git_head", "unknown") + ("" if info.get("kernels_sha16") == kernels_sha16() else "+changed")
+    except Exception:
+        return "unknown"
+
+
 def survey_bytes(processed, steps):
     """16 B of streaming I/O per read offered to a pass (8 B packed read + 4 B count
     in + 4 B assignment out) + 64 B per LF step (two rank queries on the canonical 32-byte block)."""
@@ -158,6 +177,8 @@ def main():
                     help="--sorted by the packed word (the collapse's order) or by the first / second 11 bases (what a "
                          "partition by seed would give the large-library launch: an experiment)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (repeatable)")
+    ap.add_argument("--big-dict", type=int, default=1,
+                    help="0: no exact-match dictionary for the large libraries searched without seed mismatch (mRNA): A/B knob")
     ap.add_argument("--outputs", choices=["packed", "arrays"], default="packed",
                     help="per-read output of the timed steps: one 4-byte packed word per read (mrg_cascade_run_packed, "
                          "SURVEY.md 8d's unit) or the four arrays pass_id / ref_id / pos / mm (10 B per read)")
@@ -237,7 +258,7 @@ def main():
 
     eng = Engine(dev_index)
     for k in keys:
-        eng.add_library(k, index[k])
+        eng.add_library(k, index[k], exact_dict=None if args.big_dict else False)
     if args.wstop is not None:
         eng.set_option("wstop", args.wstop)
     if args.no_ftab:
@@ -611,6 +632,8 @@ def main():
                  "(passes[].ms, kernel, roofline), the rest through the FM kernels first (passes[].ms_rest); counters are the sums"),
     }
     line.update(extras)
+    line["git_head"] = git_head()
+    line["kernels_sha16"] = kernels_sha16()
     if legs:
         line["legs"] = legs
     print(json.dumps(line))

@@ -38,6 +38,10 @@ struct mrg_index {
     }
     return it->second;
   }
+  void drop_dict(uint32_t key_bases) const {  // (a large library's slot array is gigabytes: not kept on the host once uploaded)
+    std::lock_guard<std::mutex> g(dict_mutex);
+    dicts.erase(key_bases);
+  }
 };
 struct mrg_fastq {
   mrg::FastqData d;
@@ -87,12 +91,12 @@ struct DevLib {
   uint32_t bpair_row_off[3] = {0, 0, 0};
   uint32_t bpair_anchor = 0;
   bool bpair_failed = false;  // not enough free HBM: the pigeonhole pieces stay
-  // exact-match dictionary (dict_index.hpp) of a library of at most kDictMaxBases bases
+  // exact-match dictionary (dict_index.hpp) of a library of at most dict_max_bases bases
   mrg::DictSlot* dict_slots = nullptr;
   uint32_t dict_log2 = 0, dict_key = 0;
   uint32_t* kbits = nullptr;
   std::vector<uint32_t> kbits_host;  // host copy (32 KB): the per-round interleaved tables are built from it
-  std::vector<std::string> host_seqs;  // entries of a library of at most kDictMaxBases bases (for seed units over several libraries)
+  std::vector<std::string> host_seqs;  // entries of a library of at most kDictSmallBases bases (for seed units over several libraries)
   uint32_t* ftab = nullptr;
   mrg::JumpTables tabs = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   uint32_t n = 0, nblk = 0, nsup = 0, primary = 0, text_words = 0, n_seg = 0, n_ref = 0;
@@ -202,6 +206,10 @@ struct mrg_ctx {
   int64_t wide_rows_16 = 1;  // libraries of >= 2^20 bases get 16-byte rows with 32 bases of context
   int64_t dict = 1;          // one-word batches without N run the dictionary kernels (dict.hip) where a pass can
   int64_t dict_key = 16;     // key length of the exact-match dictionaries (set before add_library)
+  // libraries up to this size get an exact-match dictionary (set before add_library).  The default covers the
+  // small libraries; a host that will run passes WITHOUT seed mismatch on a large one (mRNA `-n 0`) raises it
+  // for that library (16 B x 2..4 slots per base of HBM), as mirge_amd/engine.py does
+  int64_t dict_max_bases = (int64_t)mrg::kDictSmallBases;
   int64_t split_mixed = 1;    // a batch with long reads / reads with N: its one-word N-free reads take the dictionary kernels
   int64_t split_min_len = 20;  // ... and so do not reads shorter than this: their seeds (half a read in a 1-mismatch pass) name hundreds of rows of a large library
   int64_t stratum0_unit = 0;  // (measured slower, default off) the exact stratum of a 2-mismatch pass behind a seed launch rides in that launch
@@ -523,7 +531,18 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
   } guard{&l};
   int rc = upload_index(ctx, ix, l, ix.n >= mrg::kWideRowMinBases && ctx->wide_rows_16, ctx->pair_seeds != 0);
   if (rc) return rc;
-  if (ctx->dict && ix.n <= mrg::kDictMaxBases && ix.n >= (uint32_t)ctx->dict_key) {
+  // Exact-match dictionary: every library of at most dict_max_bases bases whose slot array (16 B x 2..4
+  // slots per base: 8.6 GB for the 137 Mbp mRNA library) leaves 8 GB of this GPU's HBM free.  A pass
+  // without seed mismatch on it -- mRNA `-n 0`, RAP:584/598 -- is then ONE 16-byte gather per read
+  // instead of a jump-table line and a wide-row line.
+  bool want_dict = ctx->dict && ix.n <= (uint64_t)ctx->dict_max_bases && ix.n <= mrg::kDictMaxBases && ix.n >= (uint32_t)ctx->dict_key;
+  if (want_dict && ix.n > mrg::kDictSmallBases) {
+    const uint64_t need = mrg::exact_dict_bytes(ix, (uint32_t)ctx->dict_key);
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    want_dict = need != 0 && free_b > need + (8ull << 30);
+  }
+  if (want_dict) {
     const mrg::ExactDict* ed = nullptr;
     try {
       ed = &h->dict((uint32_t)ctx->dict_key);
@@ -534,6 +553,7 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
       if ((rc = upload(&l.dict_slots, ed->slots))) return rc;
       l.dict_log2 = ed->log2_slots;
       l.dict_key = ed->key_bases;
+      if (ix.n > mrg::kDictSmallBases) h->drop_dict((uint32_t)ctx->dict_key);
     }
   }
   if (ctx->dict && ctx->seed_buckets && l.sa16) {
@@ -559,7 +579,7 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
   }
   // small libraries keep their entries on the host: passes that search several of them with one
   // policy get one index of their concatenation (seed_kernel units), built when a cascade first asks
-  if (ctx->dict && ix.n <= mrg::kDictMaxBases) {
+  if (ctx->dict && ix.n <= mrg::kDictSmallBases) {
     l.host_seqs.resize(ix.names.size());
     for (uint32_t i = 0; i < l.host_seqs.size(); ++i) l.host_seqs[i] = mrg::entry_sequence(ix, i);
   }
@@ -626,6 +646,9 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->seed_wgs = value;
   } else if (k == "seed_units") {
     ctx->seed_units = value != 0;
+  } else if (k == "dict_max_bases") {
+    if (value < 0) return fail(MRG_ERR_ARG, "dict_max_bases must be >= 0");
+    ctx->dict_max_bases = value;  // takes effect for libraries added afterwards
   } else if (k == "dict_key") {
     if (value < 8 || value > 16) return fail(MRG_ERR_ARG, "dict_key must be in [8,16]");
     ctx->dict_key = value;
@@ -870,13 +893,14 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   auto run_single = [&](uint32_t i, int32_t k_first, int32_t k_last, bool first_part, bool last_part, bool by_pairs = false) -> int {
     const mrg_pass_cfg& c = passes[i];
     const DevLib& l = ctx->libs[c.lib];
-    if (dict_batch && c.max_mm_seed == 0 && l.dict_slots && ctx->force_lds_mode < 0) {
+    // (the dictionary's key is matched letter for letter: only a pass whose seed covers it may take it)
+    if (dict_batch && c.max_mm_seed == 0 && l.dict_slots && c.seed_len >= (int32_t)l.dict_key && ctx->force_lds_mode < 0) {
       // no seed mismatch, one-word reads, a library with an exact-match dictionary: dict.hip
       mrg::ExactParams e;
       e.slots = reinterpret_cast<const uint4*>(l.dict_slots);
       e.log2_slots = l.dict_log2;
       e.key_bases = l.dict_key;
-      e.kbits = ctx->kmer_filter ? l.kbits : nullptr;
+      e.kbits = (ctx->kmer_filter && c.seed_len >= (int32_t)mrg::kKmerBitsK) ? l.kbits : nullptr;
       e.ftab = l.ftab;
       e.tabs = l.tabs;
       e.sa = l.sa;
@@ -1396,7 +1420,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     if (!dict_batch || !ctx->seed_units || ctx->force_lds_mode >= 0 || !fusable(i)) return false;
     const mrg_pass_cfg& c = passes[i];
     const DevLib& l = ctx->libs[c.lib];
-    if (c.max_mm_seed == 0 && l.dict_slots) return true;
+    if (c.max_mm_seed == 0 && l.dict_slots && c.seed_len >= (int32_t)l.dict_key) return true;
     return !l.host_seqs.empty() || l.sa16 != nullptr;
   };
   auto small_class = [&](uint32_t i) { return !ctx->libs[passes[i].lib].host_seqs.empty(); };
@@ -1460,7 +1484,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
         }
         if (!seedable(j) || small_class(j) != cls) break;
         const mrg_pass_cfg& c = passes[j];
-        const bool k1 = c.max_mm_seed == 0 && ctx->libs[c.lib].dict_slots != nullptr;
+        const bool k1 = c.max_mm_seed == 0 && ctx->libs[c.lib].dict_slots != nullptr && c.seed_len >= (int32_t)ctx->libs[c.lib].dict_key;
         int join = -1;
         if (!k1 && cls)  // small libraries searched with one policy: one unit over their concatenation
           for (size_t u = 0; u < plan.size(); ++u) {
@@ -1482,7 +1506,8 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       }
       // (passes skipped by the length hint at the end of the run stay with it: never the last pass)
       if (ctx->stratum0_unit && j < n_pass && runs[j] && passes[j].max_mm_seed == 2 && !passes[j].poly_t &&
-          ctx->libs[passes[j].lib].dict_slots && plan.size() < mrg::kSeedMaxUnits && ctx->pair_seeds && ctx->force_lds_mode < 0) {
+          ctx->libs[passes[j].lib].dict_slots && passes[j].seed_len >= (int32_t)ctx->libs[passes[j].lib].dict_key &&
+          plan.size() < mrg::kSeedMaxUnits && ctx->pair_seeds && ctx->force_lds_mode < 0) {
         UnitPlan s0{1u, {j}};
         s0.stratum0 = true;
         plan.push_back(s0);
@@ -1672,6 +1697,9 @@ int mrg_tally_run(mrg_ctx* ctx, const int8_t* d_pass_id, const int32_t* d_ref_id
 int mrg_tally_run_packed(mrg_ctx* ctx, const uint32_t* d_packed, const uint32_t* d_quant, uint64_t n, uint32_t n_samples,
                          uint32_t n_mirna, uint32_t n_pass, int32_t canon_pass, int32_t isomir_pass, uint64_t* d_counts, void* stream) {
   if (n && !d_packed) return fail(MRG_ERR_ARG, "mrg_tally_run_packed: null buffers");
+  // (the packed word's entry field saturates at 0x3FFFF: a larger library would be tallied into the wrong bin)
+  if (n_mirna > 0x3FFFFu)
+    return fail(MRG_ERR_ARG, "mrg_tally_run_packed: %u miRNA entries do not fit the packed word's 18-bit entry field (use mrg_tally_run)", n_mirna);
   return tally_run_impl(ctx, nullptr, nullptr, d_packed, d_quant, n, n_samples, n_mirna, n_pass, canon_pass, isomir_pass, d_counts, stream);
 }
 
@@ -1834,6 +1862,10 @@ int mrg_edit_tally_run_packed(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t wo
                               int32_t isomir_pass, int32_t isomir_trim5, uint32_t flank5, uint32_t flank3, uint32_t from_base,
                               uint32_t to_base, uint64_t* d_counts, void* stream) {
   if (n && !d_packed) return fail(MRG_ERR_ARG, "mrg_edit_tally_run_packed: null buffers");
+  // (entry and offset fields of the packed word saturate at 0x3FFFF / 0xFF)
+  if (ctx && lib >= 0 && (size_t)lib < ctx->libs.size() && (ctx->libs[lib].n_ref > 0x3FFFFu || ctx->libs[lib].max_ref_len >= 0xFFu))
+    return fail(MRG_ERR_ARG, "mrg_edit_tally_run_packed: the library (%u entries, longest %u) does not fit the packed word (use mrg_edit_tally_run)",
+                ctx->libs[lib].n_ref, ctx->libs[lib].max_ref_len);
   return edit_tally_impl(ctx, d_reads, words_per_read, d_lens, d_nmask, nullptr, nullptr, nullptr, d_packed, d_quant, d_keep, d_remap, n,
                          n_samples, n_bins, lib, canon_pass, isomir_pass, isomir_trim5, flank5, flank3, from_base, to_base, d_counts,
                          stream);

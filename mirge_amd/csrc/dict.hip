@@ -360,6 +360,7 @@ enum UnitWord : uint32_t { UW_SA16 = 0, UW_TEXT = 2, UW_SEGSTART = 4, UW_SEGREF 
                            UW_LIMITS = 13, UW_MEMBERS = 14, UW_BUCKETS = 22, UW_SA = 24 };
 constexpr uint32_t kRowFromBucket = 1u << 23;  // tag bit of a row-queue entry: x indexes the unit's buckets, not its wide rows
 constexpr uint32_t kSeedCtlWords = 16u;
+static_assert(4u + 2u * kSeedMaxUnits <= kSeedCtlWords, "seed_kernel: two sets of item counters");
 static_assert(2u * kSeedMaxUnits * kSeedMaxMembers <= 64u && kSeedMaxMembers <= 4u, "seed_kernel: one lane per member counter");
 constexpr uint32_t kSeedCntSlots = 16u * 2u + kSeedMaxUnits * 2u;  // per pass processed / aligned, per unit candidates / lookups
 
@@ -370,7 +371,7 @@ struct SeedLds {
   uint4* wide;               // [kSeedWideCap] (lo, hi, slot | unit | offset | k', -)
   uint32_t* items;           // [n_units][item_cap] slot | seed << 11
   uint32_t* utab;            // [kSeedMaxUnits][kUnitWords]
-  uint32_t* ctl;             // [0] survivors, [1] longest input segment, [2] rows, [3] wide, [4 + u] items of unit u
+  uint32_t* ctl;             // [0] survivors, [1] longest input segment, [2] rows, [3] wide, [4 + 3 parity + u] items of unit u (by tile parity)
   unsigned long long* cnt;   // [kSeedCntSlots]
   uint8_t* sL0;              // [tile] read length, 255 = no read
 };
@@ -576,7 +577,12 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
     L_b = p.lens[r_b];
     rd_b = p.reads[r_b];
   }
-  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  // The item counters are double-buffered by tile parity: a tile without items has no barrier behind
+  // the one that closes phase 1, so a fast wave may already be pushing the NEXT tile's items while a
+  // slow one still reads this tile's counters (it cannot get two tiles ahead: the next tile's barrier
+  // waits for the slow wave).
+  uint32_t ctl_items = 4u;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x, ctl_items ^= (4u ^ (4u + kSeedMaxUnits))) {
     const bool active = act_b;
     const uint32_t r = r_b, L0 = active ? L_b : 255u, slot = tid;
     const uint64_t rd = rd_b;
@@ -670,7 +676,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
           const uint64_t mask = __ballot(need);
           if (mask) {
             uint32_t base = 0;
-            if (lane == (uint32_t)__ffsll((long long)mask) - 1u) base = atomicAdd(&l.ctl[4u + ui], (uint32_t)__popcll(mask));
+            if (lane == (uint32_t)__ffsll((long long)mask) - 1u) base = atomicAdd(&l.ctl[ctl_items + ui], (uint32_t)__popcll(mask));
             base = __shfl(base, __ffsll((long long)mask) - 1, 64);
             if (need) l.items[ui * p.item_cap + base + mbcnt(mask)] = slot | (j << 11);
           }
@@ -681,12 +687,12 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
     }
     __syncthreads();
     uint32_t any_items = 0;
-    for (uint32_t ui = 0; ui < p.n_units; ++ui) any_items |= l.ctl[4u + ui];
+    for (uint32_t ui = 0; ui < p.n_units; ++ui) any_items |= l.ctl[ctl_items + ui];
     if (any_items) {  // (workgroup-uniform)
     // ================= phase 2a: items -> dictionary answers / suffix-array rows =================
     for (uint32_t ui = 0; ui < p.n_units; ++ui) {
       const SeedUnit& un = p.unit[ui];
-      const uint32_t n_items = l.ctl[4u + ui];
+      const uint32_t n_items = l.ctl[ctl_items + ui];
       uint32_t c_lookups = 0, c_cands = 0;
       for (uint32_t it0 = 0; it0 < n_items; it0 += kSeedThreads) {
         const uint32_t it = it0 + tid;
@@ -858,7 +864,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
       }
     }
     __syncthreads();
-    if (tid < p.n_units) l.ctl[4u + tid] = 0u;  // the item queues are read: empty for the next tile
+    if (tid < p.n_units) l.ctl[ctl_items + tid] = 0u;  // the item queues are read: empty for the tile after next
     // ================= phase 2b: one row per lane =================
     {
       const uint32_t n_rows = min(l.ctl[2], p.row_cap);
@@ -1043,6 +1049,7 @@ uint32_t seed_wgs_per_cu(const SeedParams& p) {
 }
 
 hipError_t launch_seed(const SeedParams& p, uint32_t grid, hipStream_t stream) {
+  if (p.reads_per_lane != 1u) return hipErrorInvalidValue;  // (a lane works on slot = tid of a tile of kSeedThreads reads)
   const uint32_t lds = seed_lds_bytes(p);
   bool buckets = false;
   for (uint32_t u = 0; u < p.n_units; ++u) buckets |= p.unit[u].kind == 0u && p.unit[u].buckets != nullptr;

@@ -36,7 +36,8 @@ static_assert(sizeof(DictSlot) == 16, "dictionary slot must be 16 bytes");
 
 constexpr uint32_t kDictAfterMask = 63u, kDictChainShift = 6u, kDictChainMask = 15u, kDictOccBit = 1u << 10, kDictOffShift = 11u;
 constexpr uint32_t kDictChainOverflow = 15u;
-constexpr uint32_t kDictMaxBases = 1u << 22;    // libraries up to this size get a dictionary
+constexpr uint32_t kDictSmallBases = 1u << 22;  // "small" libraries (serial build; their entries are also kept for seed units)
+constexpr uint32_t kDictMaxBases = 1u << 30;    // libraries up to this size can have a dictionary (16 B x 2..4 slots per base of HBM)
 constexpr uint32_t kDictMaxOffset = 1u << 21;   // entry offsets must fit 21 bits
 constexpr uint32_t kDictHashMul = 0x9E3779B1u;  // slot = (key * mul) >> (32 - log2_slots)
 
@@ -49,6 +50,10 @@ struct ExactDict {
 };
 
 // Throws std::runtime_error when the library cannot have one (too large, entry offsets too wide).
-void build_exact_dict(const FmIndex& ix, uint32_t key_bases, ExactDict& out);
+// Libraries beyond kDictSmallBases are filled by `threads` workers (0 = one per hardware thread), each
+// owning a range of home slots; the layout then depends on the worker count, what a lookup finds does not.
+void build_exact_dict(const FmIndex& ix, uint32_t key_bases, ExactDict& out, uint32_t threads = 0);
+// Bytes of the slot array build_exact_dict would start with (before any doubling), 0 = no dictionary possible.
+uint64_t exact_dict_bytes(const FmIndex& ix, uint32_t key_bases);
 
 }  // namespace mrg

@@ -32,6 +32,10 @@ MIRGE_PASS_TABLE = [
     ("mirna", 0, 255, V_MODE_SEED, 2, 2, 1, 2, 0),          # -5 1 -3 2 -v 2 --best
     ("spike-in", 0, 255, 28, 0, 2, 0, 0, 0),                # -n 0 (only with -spikeIn)
 ]
+# libraries a pass searches WITHOUT seed mismatch: a large one of them gets an exact-match dictionary too
+EXACT_LIBS = frozenset(row[0] for row in MIRGE_PASS_TABLE if row[4] == 0)
+DICT_SMALL_BASES = 1 << 22   # csrc/dict_index.hpp: kDictSmallBases / kDictMaxBases
+DICT_MAX_BASES = 1 << 30
 CANON_PASS = 0   # annot slot 1 "exact miRNA"
 ISOMIR_PASS = 8  # annot slot 9 "isomiR miRNA"
 
@@ -144,7 +148,15 @@ class Engine:
         """Free the context's scratch arena (the collapse keeps 40 B per raw read otherwise)."""
         check(self._lib.mrg_ctx_release_scratch(self._h))
 
-    def add_library(self, key, index):
+    def add_library(self, key, index, exact_dict=None):
+        """Make a library resident.  exact_dict: give a LARGE library (> 4 Mbp) an exact-match dictionary
+        too (16 B x 2..4 slots per base of HBM) -- by default the libraries the reference cascade searches
+        without a seed mismatch (mRNA `-n 0`, runAnnotationPipeline.py:584/598; spike-in, :586): one 16-byte
+        gather per read instead of a jump-table line and a suffix-array row line.  Small libraries always
+        get theirs."""
+        if exact_dict is None:
+            exact_dict = key in EXACT_LIBS
+        self.set_option("dict_max_bases", DICT_MAX_BASES if exact_dict else DICT_SMALL_BASES)
         lid = C.c_int32(-1)
         check(self._lib.mrg_ctx_add_library(self._h, index._h, C.byref(lid)))
         self.libs[key] = lid.value

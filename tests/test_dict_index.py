@@ -140,3 +140,42 @@ def test_too_large_or_bad_key_is_an_error(native_lib):
         ix.exact_dict(17)
     with pytest.raises(MirgeAmdError):
         ix.exact_dict(7)
+
+
+def test_large_library_is_filled_in_parallel(native_lib):
+    """A library beyond 4 Mbp (the size class of the mRNA library, runAnnotationPipeline.py:584/598) is
+    filled by several workers, each owning a range of home slots; a lookup still finds the first entry
+    that holds the read at its lowest offset -- including repeats that sit in different workers' ranges
+    or next to a range boundary -- and never claims a wrong 'absent'."""
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = [acgt[rng.integers(0, 4, 150_000)].tobytes().decode() for _ in range(30)]   # 4.5 Mbp
+    # repeats: the same 40-mer in several entries (first occurrence wins), at various offsets
+    rep = [acgt[rng.integers(0, 4, 40)].tobytes().decode() for _ in range(50)]
+    for i, r in enumerate(rep):
+        for e in (3 + i % 5, 11 + i % 7, 25):
+            o = 1000 * (i + 1) + e
+            seqs[e] = seqs[e][:o] + r + seqs[e][o + 40:]
+    ix = FmIndex.build(["big%d" % i for i in range(len(seqs))], seqs)
+    d = ix.exact_dict(16)
+    assert d["log2_slots"] >= 24 and d["n_keys"] > 4_000_000
+    joined = "\x00".join(seqs)
+    starts = np.cumsum([0] + [len(s) + 1 for s in seqs])
+
+    def first_hit(read):
+        o = joined.find(read)
+        if o < 0:
+            return None
+        e = int(np.searchsorted(starts, o, side="right")) - 1
+        return (e, o - int(starts[e]))
+
+    n_hit = 0
+    reads = sample_reads(seqs, rng, 1500) + [r[:L] for r in rep for L in (16, 22, 32)] + [r[5:27] for r in rep]
+    for r in reads:
+        got = lookup(d, r)
+        if got == "fallback":
+            continue
+        want = first_hit(r)
+        assert got == want, (r, got, want)
+        n_hit += want is not None
+    assert n_hit > 700

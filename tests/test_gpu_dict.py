@@ -60,12 +60,12 @@ def test_dict_cascade_equals_port_and_fm_kernels(engine, world):
         if seed_units:
             # hairpin .. ncRNA-others (small libraries) share one seed_kernel launch: hairpin alone (its own
             # length window), tRNA + snoRNA + rRNA + ncRNA-others as ONE unit over their concatenation,
-            # pre-tRNA through its dictionary; mRNA (large) has a launch of its own
-            assert [s["lds_mode"] for s in st[1:8]] == [8] * 6 + [9]   # (9: the mRNA library of this world has seed buckets)
+            # pre-tRNA through its dictionary; mRNA (large; `-n 0`: a dictionary unit, no buckets) has a launch of its own
+            assert [s["lds_mode"] for s in st[1:8]] == [8] * 7
             assert [s["group"] for s in st[1:8]] == [1] * 6 + [7]
             assert all(s["steps"] == 0 for s in st[1:8])
         elif fuse == 0:
-            assert st[3]["lds_mode"] == 7 and st[7]["lds_mode"] != 7  # pre-tRNA has a dictionary, mRNA is too large
+            assert st[3]["lds_mode"] == 7 and st[7]["lds_mode"] == 7  # pre-tRNA and the 6.8 Mbp mRNA library have dictionaries
         fm = run(engine, world, dict=0, fuse=fuse)
         for a, b in zip(res.to_host(), fm.to_host()):
             assert np.array_equal(a, b)
