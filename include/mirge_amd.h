@@ -509,6 +509,22 @@ int mrg_fastq_parse_device(mrg_ctx *ctx, const char *d_text, uint64_t n_bytes, i
                            uint8_t *d_lens, uint64_t *d_nmask, mrg_fastq_device_info *info, void *stream);
 
 /*
+ * Parallel inflate of a `.fastq.gz` sample (round 4): the reference reads gzip samples through ONE
+ * inflate stream (parseArgument.py:32, __main__.py:289-314, trim_file.py:89-134).  mrg_gz_open maps the
+ * file and inflates it with `threads` workers (block starts found by trial, the 32 KB window in front of
+ * a chunk kept symbolic until the chunk in front is done: csrc/pgzip.cpp); mrg_gz_read returns the next
+ * bytes of the text in order, exactly what gzread returns (*got == 0: end of file), checking every
+ * member's CRC-32 and length.  threads <= 1, plain files and files too small to cut take zlib's own
+ * reader.  mrg_fastq_load uses the same reader.  One reader per handle; not thread-safe.
+ */
+typedef struct mrg_gz mrg_gz;
+int mrg_gz_open(const char *path, int32_t threads, mrg_gz **out);
+int mrg_gz_read(mrg_gz *gz, void *buf, uint64_t len, uint64_t *got);
+/* parallel != NULL: 1 when the parallel reader serves the file; merged != NULL: chunk starts dropped so far */
+int mrg_gz_info(const mrg_gz *gz, int32_t *parallel, uint64_t *merged);
+void mrg_gz_close(mrg_gz *gz);
+
+/*
  * The compact wire form of a collapsed read set, for callers whose unique reads live on the HOST (the
  * reference's seqDic after quantReads.py:3-24): 6.5 bytes per 22-nt read over PCIe instead of the 13 of
  * the arrays (8-byte word + length + 32-bit count) -- what bounds a host-resident pipeline is the upload.

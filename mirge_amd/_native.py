@@ -143,6 +143,10 @@ SIGNATURES = {
     "mrg_fastq_copy": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mrg_fastq_free": (None, [C.c_void_p]),
     "mrg_fastq_block_cut": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(C.c_uint64)]),
+    "mrg_gz_open": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "mrg_gz_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "mrg_gz_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
+    "mrg_gz_close": (None, [C.c_void_p]),
     "mrg_fastq_parse_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
                                          C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FastqDeviceInfo), C.c_void_p]),
     "mrg_expand_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,

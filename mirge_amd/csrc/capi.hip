@@ -17,6 +17,7 @@
 
 #include "../../include/mirge_amd.h"
 #include "dict_index.hpp"
+#include "pgzip.hpp"
 #include "fastq.hpp"
 #include "fm_index.hpp"
 #include "kernels.hpp"
@@ -45,6 +46,9 @@ struct mrg_index {
 };
 struct mrg_fastq {
   mrg::FastqData d;
+};
+struct mrg_gz {
+  std::unique_ptr<mrg::GzipReader> rd;
 };
 
 namespace {
@@ -216,6 +220,7 @@ struct mrg_ctx {
   int64_t seed_buckets = 1;  // large libraries get seed buckets where they pay (set before add_library); 0 at run time: not used
   int64_t seed_wgs = 0;      // seed_kernel workgroups (256 threads) per CU; 0 = what the launch's instantiation keeps resident
   int64_t seed_units = 1;    // ... and their runs of passes with at most one seed mismatch go through seed_kernel
+  int64_t seed_impl = 1;   // 1 = wave_seed_kernel (every wave on its own), 0 = seed_kernel (tiles, barriers)
   std::vector<DevLib> libs;
   std::vector<std::unique_ptr<SeedLib>> seed_libs;
   // last run
@@ -644,6 +649,9 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->seed_buckets = value != 0;
   } else if (k == "seed_wgs") {
     ctx->seed_wgs = value;
+  } else if (k == "seed_impl") {
+    if (value < 0 || value > 4) return fail(MRG_ERR_ARG, "seed_impl must be in [0,4]");
+    ctx->seed_impl = value;
   } else if (k == "seed_units") {
     ctx->seed_units = value != 0;
   } else if (k == "dict_max_bases") {
@@ -1370,9 +1378,11 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
         ctx->last_kbits_log2[i] = un.kbits ? 22u : 0u;
       }
     }
+    sp.impl = ctx->seed_impl ? 1u : 0u;
+    sp.wave_regs = ctx->seed_impl >= 2 ? (uint32_t)(ctx->seed_impl - 1) : 0u;  // 2: more registers, 3: the same in lockstep, 4: lockstep only
     sp.reads_per_lane = 1u;
     sp.item_cap = mrg::kSeedThreads * sp.reads_per_lane * 2u;
-    sp.row_cap = small ? 1024u : 2048u;
+    sp.row_cap = sp.impl ? 192u : (small ? 1024u : 2048u);
     sp.stats = stats;
     sp.reads = d_reads;
     sp.lens = d_lens;
@@ -2163,6 +2173,41 @@ int mrg_fastq_copy(const mrg_fastq* fq, uint32_t words_per_read, uint64_t* words
 }
 
 void mrg_fastq_free(mrg_fastq* fq) { delete fq; }
+
+int mrg_gz_open(const char* path, int32_t threads, mrg_gz** out) {
+  if (!path || !out) return fail(MRG_ERR_ARG, "mrg_gz_open: null argument");
+  try {
+    std::unique_ptr<mrg_gz> h(new mrg_gz());
+    h->rd.reset(new mrg::GzipReader(path, threads));
+    *out = h.release();
+  } catch (const std::bad_alloc&) {
+    return fail(MRG_ERR_NOMEM, "mrg_gz_open: out of memory");
+  } catch (const std::exception& e) {
+    return fail(MRG_ERR_IO, "mrg_gz_open: %s", e.what());
+  }
+  return MRG_OK;
+}
+
+int mrg_gz_read(mrg_gz* gz, void* buf, uint64_t len, uint64_t* got) {
+  if (!gz || !got || (len && !buf)) return fail(MRG_ERR_ARG, "mrg_gz_read: null argument");
+  try {
+    *got = gz->rd->read(static_cast<char*>(buf), (size_t)len);
+  } catch (const std::bad_alloc&) {
+    return fail(MRG_ERR_NOMEM, "mrg_gz_read: out of memory");
+  } catch (const std::exception& e) {
+    return fail(MRG_ERR_IO, "mrg_gz_read: %s", e.what());
+  }
+  return MRG_OK;
+}
+
+int mrg_gz_info(const mrg_gz* gz, int32_t* parallel, uint64_t* merged) {
+  if (!gz) return fail(MRG_ERR_ARG, "mrg_gz_info: null argument");
+  if (parallel) *parallel = gz->rd->parallel() ? 1 : 0;
+  if (merged) *merged = gz->rd->chunks_merged();
+  return MRG_OK;
+}
+
+void mrg_gz_close(mrg_gz* gz) { delete gz; }
 
 int mrg_fastq_block_cut(const char* buf, uint64_t len, int32_t at_eof, uint64_t* cut) {
   if (!buf || !cut) return fail(MRG_ERR_ARG, "mrg_fastq_block_cut: null argument");

@@ -44,7 +44,8 @@ __device__ __forceinline__ const __attribute__((address_space(4))) Params* kerne
 
 // The largest jump table with k <= plen (tables in ascending k; k[0] == 0: none usable): its k
 // (0 = none) and its word offset inside `ftab`.
-__device__ __forceinline__ uint32_t pick_table(const JumpTables& t, int32_t plen, uint32_t& word_off) {
+template <class Tabs>  // (JumpTables in any address space)
+__device__ __forceinline__ uint32_t pick_table(const Tabs& t, int32_t plen, uint32_t& word_off) {
   uint32_t k = plen >= (int32_t)t.k[0] ? t.k[0] : 0u;
   word_off = t.off[0];
 #pragma unroll
@@ -60,7 +61,8 @@ __device__ __forceinline__ uint32_t pick_table(const JumpTables& t, int32_t plen
 // the seed's rows are those of the 4^(K - k) K-mers it is a prefix of, the interval between two
 // entries of that table 4^(K - k) apart (`shift` = 2 (K - k); all k bases are then known to match) --
 // else the largest table with K <= k (shift = 0, the first K bases match).  Returns K (0 = none).
-__device__ __forceinline__ uint32_t pick_seed_table(const JumpTables& t, int32_t k, uint32_t& word_off, uint32_t& shift) {
+template <class Tabs>
+__device__ __forceinline__ uint32_t pick_seed_table(const Tabs& t, int32_t k, uint32_t& word_off, uint32_t& shift) {
   uint32_t K = 0;
   word_off = 0;
   shift = 0;

@@ -1003,6 +1003,638 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
   if (p.idx_out && tid == 0) p.out_count[blockIdx.x] = l.ctl[0];
 }
 
+// ---------------------------------------------------------------------------
+// wave_seed_kernel: the same units as seed_kernel, but every WAVE works on its own -- no barrier between
+// the setup and the final counter flush.  What the tile kernel's counters said: three
+// quarters of the reads a seed launch walks have no item in any unit (their seeds fail the presence
+// bitmaps, their buckets are answered in one trip) and still paid the tile protocol: LDS staging, three
+// barriers, the claim over a tile with holes.  Here a lane
+//   streams its read: eligibility per unit, bitmap probes, the inline answers (a bucket seed's rows, a
+//   dictionary's home slot) -- and FINISHES it on the spot when nothing is left to look up: claim,
+//   output, survivor list, counters;
+//   parks it as a CANDIDATE in the wave's own LDS region otherwise.  As soon as 64 candidates are parked
+//   the wave works them off with dense lanes: their items unit by unit (jump-table / bucket-count /
+//   slot loads), the rows of those items through a row queue (64 rows verified per trip, whoever's
+//   they are, 64-bit atomic min into the candidate's slot), then the claim of the 64 candidates.
+// Waves of a workgroup share the unit table, the counter slots and the cursor of the workgroup's
+// survivor segment, nothing else; a slow wave (a poly-A seed with 10^5 rows) delays nobody.
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr uint32_t kWaveCand = 128u;   // candidate slots of a wave (fewer than 64 parked + the 64 of one trip)
+constexpr uint32_t kWaveItems = 128u;  // item list of a wave (fewer than 64 pending + one plane of 64)
+constexpr uint32_t kWaveRowsMin = 128u;  // smallest row queue: fewer than 64 pending + one item's kSeedRowsPerItem rows must fit
+
+struct WaveLds {
+  unsigned long long* rd;    // [kWaveCand] packed read
+  unsigned long long* best;  // [kWaveCand] best key
+  uint32_t* r;               // [kWaveCand] read index
+  uint32_t* meta;            // [kWaveCand] length | eligibility mask << 8 | queued seeds << 16
+  uint2* rows;               // [row_cap] (row index, candidate | offset << 13 | k' << 19 | bucket flag)
+  uint16_t* items;           // [kWaveItems] candidate lane | seed << 6
+};
+
+__host__ __device__ constexpr uint32_t wave_lds_bytes(uint32_t row_cap) {
+  return kWaveCand * (8u + 8u + 4u + 4u) + row_cap * 8u + kWaveItems * 2u;
+}
+__host__ __device__ constexpr uint32_t wave_shared_words() { return kSeedMaxUnits * kUnitWords + kSeedCtlWords + 2u * kSeedCntSlots; }
+
+// LDS written by some lanes of the wave, read by others: program order is enough in hardware (one wave's
+// LDS operations execute in order); this keeps the compiler from moving them across
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// A dictionary unit's answer for one read (exact_dict_kernel's probe): the best key, ~0 = none.
+// `first`: the home slot when the caller has loaded it already (first.w's occupied bit may be clear).
+template <class Unit>
+__device__ __forceinline__ unsigned long long dict_unit_probe(const Unit& un, uint64_t q, int32_t L, bool have_first, uint4 first,
+                                                              uint32_t& c_lookups, uint32_t& c_cands) {
+  const int32_t pass_index = un.m[0].pass_index, seed_len = un.m[0].seed_len, max_total = un.m[0].max_mm_total;
+  const uint32_t smask = (1u << un.log2_slots) - 1u;
+  const uint32_t kmask = un.key_bases >= 16u ? 0xFFFFFFFFu : ((1u << (2u * un.key_bases)) - 1u);
+  bool fallback = (uint32_t)L < un.key_bases;
+  unsigned long long key = ~0ull;
+  if (!fallback) {
+    const uint64_t lmask = low_bits(2u * (uint32_t)L), seedmask = low_bits(2u * (uint32_t)min(L, seed_len));
+    const uint32_t home = (((uint32_t)q & kmask) * kDictHashMul) >> (32u - un.log2_slots);
+    uint4 sl = first;
+    if (!have_first) {
+      sl = un.slots[home];
+      ++c_lookups;
+    }
+    const uint32_t chain = (sl.w >> kDictChainShift) & kDictChainMask;
+    if (chain == kDictChainOverflow) {
+      fallback = true;
+    } else {
+      uint32_t bestj = ~0u;
+      for (uint32_t jj = 0;; ++jj) {
+        const uint64_t win = (uint64_t)sl.x | ((uint64_t)sl.y << 32);
+        ++c_cands;
+        const uint64_t m = mismatch_bits(win, q) & lmask;
+        const uint32_t mmt = (uint32_t)__popcll(m);
+        if ((sl.w & kDictOccBit) && (m & seedmask) == 0ull && (int32_t)mmt <= max_total && (uint32_t)L <= (sl.w & kDictAfterMask) &&
+            ((mmt << 8) | jj) < bestj) {
+          bestj = (mmt << 8) | jj;
+          key = ((unsigned long long)pass_index << 56) | ((unsigned long long)mmt << 48) | ((unsigned long long)sl.z << 21) |
+                (sl.w >> kDictOffShift);
+        }
+        if (jj >= chain || (bestj >> 8) == 0u) break;
+        sl = un.slots[(home + jj + 1u) & smask];
+      }
+    }
+  }
+  if (fallback) {
+    // the FM index: rows of the longest prefix a jump table knows, each against the text
+    const int32_t R = min(L, seed_len);
+    uint32_t tab_off = 0;
+    const uint32_t kp = un.tabs.k[0] ? pick_table(un.tabs, R, tab_off) : 0u;
+    uint32_t lo = 0, hi = un.n + 1u;
+    if (kp) {
+      const uint32_t* tab = un.ftab + tab_off + lex_code(q & low_bits(2u * kp), kp);
+      lo = tab[0];
+      hi = tab[1];
+    }
+    ++c_lookups;
+    const uint64_t lmask = low_bits(2u * (uint32_t)L), seedmask = low_bits(2u * (uint32_t)R);
+    uint64_t bestk = ~0ull;
+    uint32_t bseg = 0xFFFFu, bbefore = 255u;
+    for (uint32_t i = lo; i < hi; ++i) {
+      const uint64_t row = un.sa[i];
+      ++c_cands;
+      if ((uint32_t)L > ((uint32_t)(row >> 40) & 255u)) continue;
+      const uint64_t m = mismatch_bits(text_window(un.text, (uint32_t)row), q) & lmask;
+      const uint32_t mmt = (uint32_t)__popcll(m);
+      if ((m & seedmask) != 0ull || (int32_t)mmt > max_total) continue;
+      const uint64_t kk = ((uint64_t)mmt << 32) | (uint32_t)row;
+      if (kk < bestk) {
+        bestk = kk;
+        bseg = (uint32_t)(row >> 48);
+        bbefore = (uint32_t)(row >> 32) & 255u;
+      }
+    }
+    if (bestk != ~0ull) {
+      uint32_t ref, pos;
+      SegTables segs{un.seg_start, un.seg_ref, un.seg_off, un.chunk_seg, un.simple_segs};
+      locate_entry(segs, (uint32_t)bestk, bseg, bbefore, ref, pos);
+      key = ((unsigned long long)pass_index << 56) | ((unsigned long long)(bestk >> 32) << 48) | ((unsigned long long)ref << 21) | pos;
+    }
+  }
+  return key;
+}
+
+}  // namespace
+
+template <bool BUCKETS, int WAVES>
+__global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const SeedParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  // (the units are read where they sit, in the kernel-argument segment: scalar loads; a by-value copy whose
+  // address reaches the nested lambdas is moved to scratch as a whole -- 1 KB per lane)
+  typedef const __attribute__((address_space(4))) SeedUnit KUnit;
+  const auto* const kargs = kernel_args_here<SeedParams>();
+  uint32_t* const utab = smem;
+  uint32_t* const ctl = utab + kSeedMaxUnits * kUnitWords;  // [0] survivors of the workgroup, [1] longest input segment
+  unsigned long long* const cnt = reinterpret_cast<unsigned long long*>(ctl + kSeedCtlWords);
+  WaveLds w;
+  {
+    uint8_t* base = reinterpret_cast<uint8_t*>(smem + wave_shared_words()) + (size_t)wv * wave_lds_bytes(p.row_cap);
+    w.rd = reinterpret_cast<unsigned long long*>(base);
+    w.best = w.rd + kWaveCand;
+    w.rows = reinterpret_cast<uint2*>(w.best + kWaveCand);
+    w.r = reinterpret_cast<uint32_t*>(w.rows + p.row_cap);
+    w.meta = w.r + kWaveCand;
+    w.items = reinterpret_cast<uint16_t*>(w.meta + kWaveCand);
+  }
+  const uint32_t row_cap = p.row_cap;
+  // ---- unit table, counters, control (as seed_kernel) ----
+  if (tid < p.n_units) {
+    const KUnit& un = kargs->unit[tid];
+    uint32_t* t = utab + tid * kUnitWords;
+    auto put = [&](uint32_t wd, const void* ptr) __attribute__((always_inline)) {
+      t[wd] = (uint32_t)(uint64_t)ptr;
+      t[wd + 1] = (uint32_t)((uint64_t)ptr >> 32);
+    };
+    put(UW_SA16, un.sa16);
+    put(UW_TEXT, un.text);
+    put(UW_SEGSTART, un.seg_start);
+    put(UW_SEGREF, un.seg_ref);
+    put(UW_SEGOFF, un.seg_off);
+    put(UW_CHUNKSEG, un.chunk_seg);
+    put(UW_BUCKETS, un.buckets);
+    put(UW_SA, un.sa);
+    t[UW_FLAGS] = (uint32_t)un.trim5 | ((uint32_t)un.trim3 << 8) | (un.poly_t ? 1u << 16 : 0u) | (un.simple_segs ? 1u << 17 : 0u) |
+                  (un.n_members << 18) | ((uint32_t)un.max_mm_seed << 21) | (un.kind == 1u ? 1u << 23 : 0u);
+    t[UW_LIMITS] = (uint32_t)min(un.min_seed_len, 0xFFFF) | ((uint32_t)min(un.max_total, 0xFFFF) << 16);
+    for (uint32_t j = 0; j < kSeedMaxMembers; ++j) {
+      t[UW_MEMBERS + 2u * j] = (uint32_t)un.m[j].pass_index | ((uint32_t)min(un.m[j].seed_len, 0xFFFF) << 8) | ((uint32_t)min(un.m[j].max_mm_total, 255) << 24);
+      t[UW_MEMBERS + 2u * j + 1u] = un.m[j].entry_lo;
+    }
+  }
+  for (uint32_t i = tid; i < kSeedCntSlots; i += kSeedThreads) cnt[i] = 0ull;
+  if (tid < kSeedCtlWords) ctl[tid] = 0u;
+  __syncthreads();
+  if (p.idx_in) longest_segment(p.in_count, p.in_nseg, &ctl[1]);
+  __syncthreads();
+
+  const uint32_t tile = kSeedThreads;
+  const uint32_t in_nseg = p.idx_in ? p.in_nseg : 1u;
+  const uint32_t depth_chunks = p.idx_in ? (ctl[1] + tile - 1) / tile : (p.n_total + tile - 1) / tile;
+  const uint32_t n_chunks = in_nseg * depth_chunks;
+  // ---- the walk (seed_kernel's): a workgroup's chunk of 256 list entries, 64 per wave; the read of chunk
+  // + grid and the list entry of chunk + 2 grid are in flight while a chunk is worked on ----
+  uint32_t f_chunk = blockIdx.x, f_sgi = blockIdx.x % in_nseg, f_depth = blockIdx.x / in_nseg;
+  const uint32_t f_dsgi = gridDim.x % in_nseg, f_ddepth = gridDim.x / in_nseg;
+  auto fetch_next = [&](uint32_t& r_out) __attribute__((always_inline)) -> bool {
+    bool act = false;
+    r_out = 0;
+    if (f_chunk < n_chunks) {
+      const uint32_t sgi = __builtin_amdgcn_readfirstlane(f_sgi), t_base = __builtin_amdgcn_readfirstlane(f_depth * tile);
+      const uint32_t t = t_base + tid;
+      const auto* kp = kernel_args_here<SeedParams>();
+      const uint32_t* idx_in = kp->idx_in;
+      if (idx_in) {
+        typedef const __attribute__((address_space(4))) uint32_t* const_u32_t;
+        act = t < ((const_u32_t)(uintptr_t)kp->in_count)[sgi];
+        const uint32_t* seg = idx_in + (size_t)sgi * kp->in_seg_cap + t_base;
+        if (act) r_out = seg[tid];
+      } else {
+        act = t < kp->n_total;
+        r_out = act ? t : 0u;
+      }
+    }
+    f_chunk += gridDim.x;
+    f_sgi += f_dsgi;
+    f_depth += f_ddepth;
+    if (f_sgi >= in_nseg) {
+      f_sgi -= in_nseg;
+      ++f_depth;
+    }
+    return act;
+  };
+
+  uint32_t acc_v = 0;  // lane 2c / 2c + 1: reads offered to / claimed by member pass c (units in order, members in order)
+  // diagnostics, per lane: of the unit being worked off (flushed per unit), and of the answers given inline in
+  // the stream by bucket units / dictionary units (flushed once, to the first unit of that kind)
+  uint32_t c_lookups = 0, c_cands = 0, c_bl = 0, c_bc = 0, c_dl = 0, c_dc = 0;
+  // ---- a read is finished: the claim in cascade order, ONE entry decode, output, survivor list, counters ----
+  auto finalize = [&](bool valid, uint32_t r, uint32_t el_mask, unsigned long long key) __attribute__((always_inline)) {
+    const bool claimed = valid && key != ~0ull;
+    const int32_t cp = claimed ? (int32_t)(key >> 56) : 255;
+    uint32_t o_ref = 0, o_pos = 0;
+    uint32_t tile_cnt = 0, c = 0, sel = 0;  // sel: unit << 2 | member of the claiming pass
+    for (uint32_t ui = 0; ui < p.n_units; ++ui) {
+      const KUnit& un = kargs->unit[ui];
+      const bool el = valid && ((el_mask >> ui) & 1u) != 0u;
+      for (uint32_t mi = 0; mi < un.n_members; ++mi, ++c) {
+        const int32_t pi = un.m[mi].pass_index;
+        const uint32_t n_off = (uint32_t)__popcll(__ballot(el && cp >= pi)), n_al = (uint32_t)__popcll(__ballot(cp == pi));
+        tile_cnt = lane == 2u * c ? n_off : tile_cnt;
+        tile_cnt = lane == 2u * c + 1u ? n_al : tile_cnt;
+        sel = cp == pi ? (ui << 2) | mi : sel;
+      }
+    }
+    acc_v += tile_cnt;
+    if (claimed) {
+      const uint32_t* ut = utab + (sel >> 2) * kUnitWords;
+      const uint32_t flags = ut[UW_FLAGS];
+      if (flags & (1u << 23)) {
+        o_ref = (uint32_t)(key >> 21) & 0x7FFFFFFu;
+        o_pos = (uint32_t)key & 0x1FFFFFu;
+      } else {
+        SegTables segs{reinterpret_cast<const uint32_t*>(lds_pointer(ut, UW_SEGSTART)), reinterpret_cast<const uint32_t*>(lds_pointer(ut, UW_SEGREF)),
+                       reinterpret_cast<const uint32_t*>(lds_pointer(ut, UW_SEGOFF)), reinterpret_cast<const uint32_t*>(lds_pointer(ut, UW_CHUNKSEG)),
+                       (flags >> 17) & 1u};
+        uint32_t ref;
+        locate_entry(segs, (uint32_t)(key >> 16), (uint32_t)key & 0xFFFFu, 255u, ref, o_pos);
+        o_ref = ref - ut[UW_MEMBERS + 2u * (sel & 3u) + 1u];
+      }
+    }
+    if (p.packed) {
+      if (claimed) p.packed[r] = pack_assignment(cp, o_ref, o_pos, (uint32_t)((key >> 48) & 255u));
+      else if (valid && !p.idx_out) p.packed[r] = 0u;
+    } else if (claimed) {
+      p.pass_id[r] = (int8_t)cp;
+      p.ref_id[r] = (int32_t)o_ref;
+      p.pos[r] = (int32_t)o_pos;
+      p.mm[r] = (uint8_t)((key >> 48) & 255u);
+    } else if (valid && !p.idx_out) {
+      p.pass_id[r] = (int8_t)-1;
+      p.ref_id[r] = -1;
+      p.pos[r] = -1;
+      p.mm[r] = 0;
+    }
+    if (p.idx_out) {
+      const bool survive = valid && !claimed;
+      const uint64_t mask = __ballot(survive);
+      if (mask) {
+        uint32_t wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&ctl[0], (uint32_t)__popcll(mask));
+        wbase = __shfl(wbase, 0, 64);
+        if (survive) p.idx_out[(size_t)blockIdx.x * p.out_seg_cap + wbase + mbcnt(mask)] = r;
+      }
+    }
+  };
+  auto flush_diag = [&](uint32_t ui) __attribute__((always_inline)) {
+    const uint64_t t_l = wave_sum(c_lookups), t_c = wave_sum(c_cands);
+    if (lane == 0) {
+      if (t_c) atomicAdd(&cnt[32u + 2u * ui], (unsigned long long)t_c);
+      if (t_l) atomicAdd(&cnt[32u + 2u * ui + 1u], (unsigned long long)t_l);
+    }
+    c_lookups = 0;
+    c_cands = 0;
+  };
+
+  // ---- the wave's row queue: rows of items, verified 64 at a time, whoever's they are ----
+  uint32_t rpend = 0;  // rows waiting (wave-uniform, < 64 between pushes)
+  auto verify_rows = [&](uint32_t from, uint32_t n, uint32_t cbase) __attribute__((always_inline)) {  // rows [from, from + n), n <= 64
+    wave_lds_sync();
+    if (lane < n) {
+      const uint2 e = w.rows[from + lane];
+      const uint32_t c = cbase + (e.y & 63u), ui = (e.y >> 11) & 3u, off = (e.y >> 13) & 63u, kp = (e.y >> 19) & 15u;
+      const bool from_bucket = (e.y & kRowFromBucket) != 0u;
+      const uint32_t* ut = utab + ui * kUnitWords;
+      const uint32_t flags = ut[UW_FLAGS];
+      uint64_t q;
+      int32_t L;
+      unit_view(0, 255, (int32_t)((flags >> 16) & 1u), (int32_t)(flags & 255u), (int32_t)((flags >> 8) & 255u), w.rd[c], w.meta[c] & 255u, q, L);
+      const uint4* wide = reinterpret_cast<const uint4*>(lds_pointer(ut, from_bucket ? UW_BUCKETS : UW_SA16));
+      if (wide) {
+        verify_seed_row(ut, wide[e.x], q, L, off, kp, &w.best[c], from_bucket);
+      } else {
+        const uint64_t row = reinterpret_cast<const uint64_t*>(lds_pointer(ut, UW_SA))[e.x];
+        verify_seed_row(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), q, L, off, 0u, &w.best[c]);
+      }
+    }
+  };
+  // (tag: candidate lane | unit << 11 | offset << 13 | k' << 19 | bucket flag; n_rows <= kSeedRowsPerItem)
+  auto push_rows = [&](uint32_t lo, uint32_t n_rows, uint32_t tag, uint32_t cbase) __attribute__((always_inline)) {
+    uint32_t left = n_rows;
+    while (__any(left != 0u)) {
+      const uint32_t incl = wave_incl_scan(left);
+      const uint32_t room = row_cap - rpend;
+      const bool fits = left != 0u && incl <= room;
+      const uint64_t fm = __ballot(fits);
+      // (the lanes that fit are a prefix of the lanes with rows; after a drain rpend < 64, so the first one always fits)
+      const uint32_t total = fm ? __shfl(incl, 63 - __clzll((long long)fm), 64) : 0u;
+      if (fits) {
+        const uint32_t first = rpend + incl - left;
+        for (uint32_t i = 0; i < left; ++i) w.rows[first + i] = make_uint2(lo + i, tag);
+        left = 0u;
+      }
+      rpend += total;
+      while (rpend >= 64u) {
+        rpend -= 64u;
+        verify_rows(rpend, 64u, cbase);
+      }
+    }
+  };
+
+  // ---- 64 parked candidates (or what is left at the end): items unit by unit, rows, the claim ----
+  auto work_off = [&](uint32_t cbase, uint32_t n_cand) __attribute__((always_inline)) {
+    wave_lds_sync();
+    const bool valid = lane < n_cand;
+    const uint32_t my_meta = valid ? w.meta[cbase + lane] : 0u;
+    for (uint32_t ui = 0; ui < p.n_units; ++ui) {
+      const KUnit& un = kargs->unit[ui];
+      const uint32_t n_seeds = un.kind == 1u ? 1u : (uint32_t)un.max_mm_seed + 1u;
+      uint32_t n_it = 0;  // items of this unit waiting in the list (wave-uniform)
+      // lane < m: item (candidate lane, seed) from the list
+      auto run_items = [&](uint32_t from, uint32_t m) __attribute__((always_inline)) {
+        wave_lds_sync();
+        const bool has = lane < m;
+        uint32_t cl = 0, j = 0;
+        uint64_t q = 0;
+        int32_t L = 0;
+        if (has) {
+          const uint32_t e = w.items[from + lane];
+          cl = e & 63u;
+          j = e >> 6;
+          unit_view(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, w.rd[cbase + cl], w.meta[cbase + cl] & 255u, q, L);
+        }
+        if (un.kind == 1u) {
+          if (has) {
+            const unsigned long long key = dict_unit_probe(un, q, L, false, make_uint4(0u, 0u, 0u, 0u), c_lookups, c_cands);
+            if (key != ~0ull) atomicMin(&w.best[cbase + cl], key);
+          }
+          return;
+        }
+        // ---- a seed: bucket count or jump-table load, then its rows into the row queue ----
+        uint32_t lo = 0, n_rows = 0, tag = 0;
+        if (has) {
+          const int32_t k = seed_bases(L, un.min_seed_len, un.max_mm_seed);
+          const uint32_t off = j * (uint32_t)k;
+          uint32_t kp = 0, bcnt = kSeedBucketOverflow;
+          if (BUCKETS && un.buckets && (uint32_t)k == un.bucket_k) {
+            kp = un.bucket_k;
+            lo = ((uint32_t)(q >> (2u * off)) & ((1u << (2u * kp)) - 1u)) * kSeedBucketRows;
+            bcnt = (un.buckets[lo].y >> 12) & 15u;
+            ++c_lookups;
+          }
+          if (bcnt != kSeedBucketOverflow) {
+            n_rows = bcnt;
+            tag = cl | (ui << 11) | (off << 13) | (kp << 19) | kRowFromBucket;
+          } else {
+            uint32_t tab_off = 0, shift = 0;
+            const uint32_t K = un.tabs.k[0] ? pick_seed_table(un.tabs, k, tab_off, shift) : 0u;
+            uint32_t hi = un.n + 1u;
+            lo = 0;
+            kp = 0;
+            if (K) {
+              kp = min(K, (uint32_t)k);
+              const uint32_t* tab = un.ftab + tab_off + (lex_code((q >> (2u * off)) & low_bits(2u * kp), kp) << shift);
+              lo = tab[0];
+              hi = tab[1u << shift];
+            }
+            ++c_lookups;
+            n_rows = hi > lo ? hi - lo : 0u;
+            tag = cl | (ui << 11) | (off << 13) | (kp << 19);
+          }
+          c_cands += n_rows;
+        }
+        // wide intervals (a poly-A seed matches 10^5 rows): the whole wave verifies one after the other
+        uint64_t wide_m = __ballot(n_rows > kSeedRowsPerItem);
+        while (wide_m) {
+          const int src = __ffsll((long long)wide_m) - 1;
+          wide_m &= wide_m - 1ull;
+          const uint32_t w_lo = __shfl(lo, src, 64), w_n = __shfl(n_rows, src, 64), w_tag = __shfl(tag, src, 64);
+          const uint64_t w_q = __shfl((unsigned long long)q, src, 64);
+          const int32_t w_L = __shfl(L, src, 64);
+          const uint32_t* ut = utab + ui * kUnitWords;
+          unsigned long long* slot = &w.best[cbase + (w_tag & 63u)];
+          for (uint32_t i = lane; i < w_n; i += 64u) {
+            if (un.sa16) {
+              verify_seed_row(ut, un.sa16[w_lo + i], w_q, w_L, (w_tag >> 13) & 63u, (w_tag >> 19) & 15u, slot);
+            } else {
+              const uint64_t row = un.sa[w_lo + i];
+              verify_seed_row(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), w_q, w_L, (w_tag >> 13) & 63u, 0u, slot);
+            }
+          }
+        }
+        push_rows(lo, n_rows > kSeedRowsPerItem ? 0u : n_rows, tag, cbase);
+      };
+      for (uint32_t j = 0; j <= n_seeds; ++j) {  // (the last trip only works off what is left in the list)
+        if (j < n_seeds) {
+          const bool need = ((my_meta >> (16u + 2u * ui + j)) & 1u) != 0u;
+          const uint64_t mask = __ballot(need);
+          if (need) w.items[n_it + mbcnt(mask)] = (uint16_t)(lane | (j << 6));
+          n_it += (uint32_t)__popcll(mask);
+        }
+        if (n_it >= 64u || (j == n_seeds && n_it)) {
+          const uint32_t m = min(n_it, 64u);
+          n_it -= m;
+          run_items(n_it, m);
+        }
+      }
+      flush_diag(ui);
+    }
+    if (rpend) {
+      verify_rows(0u, rpend, cbase);
+      rpend = 0u;
+    }
+    wave_lds_sync();
+    finalize(valid, valid ? w.r[cbase + lane] : 0u, (my_meta >> 8) & 255u, valid ? w.best[cbase + lane] : ~0ull);
+  };
+
+  uint32_t r_b = 0, r_c = 0, L_b = 255u;
+  uint64_t rd_b = 0;
+  uint32_t pend = 0;  // candidates parked (wave-uniform, < 64 between chunks)
+  uint32_t pre_ui = kSeedMaxUnits;  // the first dictionary unit (none: kSeedMaxUnits)
+  for (uint32_t ui = p.n_units; ui-- > 0u;)
+    if (kargs->unit[ui].kind == 1u) pre_ui = ui;
+  bool act_b = fetch_next(r_b);
+  bool act_c = fetch_next(r_c);
+  if (act_b) {
+    L_b = p.lens[r_b];
+    rd_b = p.reads[r_b];
+  }
+  // (one trip more than there are chunks: the last one has no reads and works off what is still parked)
+  for (uint32_t chunk = blockIdx.x;; chunk += gridDim.x) {
+    const bool last_trip = chunk >= n_chunks;
+    if (p.wave_regs & 2u) __syncthreads();  // (experiment: the workgroup's waves kept on the same chunk)
+    const bool active = act_b;
+    const uint32_t r = r_b, L0 = active ? L_b : 255u;
+    const uint64_t rd = rd_b;
+    act_b = act_c;
+    r_b = r_c;
+    L_b = 255u;
+    rd_b = 0;
+    if (act_b) {
+      L_b = p.lens[r_b];
+      rd_b = p.reads[r_b];
+    }
+    act_c = fetch_next(r_c);
+    // ================= the stream: eligibility, filters, inline answers =================
+    unsigned long long my_best = ~0ull;
+    uint32_t el_mask = 0u, queued_all = 0u;
+    // the home slot of the first dictionary unit is requested before anything else, so that its trip runs
+    // beside the bucket / bitmap trips of the units in front of it (when enough lanes ask: see below)
+    uint4 pre_sl = make_uint4(0u, 0u, 0u, 0u);
+    bool pre_direct = false;
+    if (pre_ui < p.n_units) {
+      const KUnit& un = kargs->unit[pre_ui];
+      uint64_t q = 0;
+      int32_t L = 0;
+      const bool el = active && unit_view(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, rd, L0, q, L);
+      const bool search = el && L > 0;
+      if ((uint32_t)__popcll(__ballot(search)) >= 16u) {
+        const uint32_t kmask = un.key_bases >= 16u ? 0xFFFFFFFFu : ((1u << (2u * un.key_bases)) - 1u);
+        pre_direct = search && (uint32_t)L >= un.key_bases;
+        if (pre_direct) {
+          // (one 16-byte load: left to itself the compiler loads the meta half, tests the chain, then loads the window)
+          const uint4* sp = un.slots + ((((uint32_t)q & kmask) * kDictHashMul) >> (32u - un.log2_slots));
+          typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+          const u4v v = *reinterpret_cast<const volatile u4v*>(sp);
+          pre_sl = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    for (uint32_t ui = 0; ui < p.n_units; ++ui) {
+      const KUnit& un = kargs->unit[ui];
+      uint64_t q = 0;
+      int32_t L = 0;
+      const bool el = active && unit_view(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, rd, L0, q, L);
+      el_mask |= el ? 1u << ui : 0u;
+      const int32_t V = un.max_mm_seed;
+      const bool search = el && L > V;
+      uint32_t queued = 0u;
+      if (un.kind == 1u) {
+        // a dictionary unit: when enough lanes ask, the home slot was requested at the top of the trip (one
+        // load for the wave) and a chain of one slot is answered here; longer chains, overflowed homes and
+        // reads shorter than the key are parked.  A unit few reads are offered to (pre-tRNA: the poly-T
+        // rule) parks them all: their slot loads then run with dense lanes.  (Only the first dictionary
+        // unit of a launch is answered inline.)
+        queued = search ? 1u : 0u;
+        if (ui == pre_ui && pre_direct) {
+          ++c_dl;
+          const uint32_t chain = (pre_sl.w >> kDictChainShift) & kDictChainMask;
+          if (chain == 0u) {
+            uint32_t dl = 0;  // (the slot is in hand: the probe neither loads nor counts it again)
+            my_best = min(my_best, dict_unit_probe(un, q, L, true, pre_sl, dl, c_dc));
+            queued = 0u;
+          }
+        }
+      } else {
+        const uint32_t n_seeds = (uint32_t)V + 1u;
+        const int32_t k = seed_bases(L, un.min_seed_len, V);
+        queued = search ? (1u << n_seeds) - 1u : 0u;  // seeds that need the index
+        if (BUCKETS && un.buckets) {
+          // a seed of exactly bucket_k bases: the first four rows of both seeds' buckets are requested together
+          // (one 64-byte half line per seed) and verified here; a fuller or overflowing bucket is parked
+          const bool inl = search && (uint32_t)k == un.bucket_k;
+          if (__any(inl)) {
+            const uint32_t* ut = utab + ui * kUnitWords;
+            const uint32_t cmask = (1u << (2u * un.bucket_k)) - 1u;
+            const uint32_t base0 = ((uint32_t)q & cmask) * kSeedBucketRows;
+            const uint32_t base1 = ((uint32_t)(q >> (2u * un.bucket_k)) & cmask) * kSeedBucketRows;
+            const bool two = V >= 1;
+            uint4 ra[4], rb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              ra[i] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+              rb[i] = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+            }
+            if (inl) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) ra[i] = un.buckets[base0 + i];
+              if (two) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rb[i] = un.buckets[base1 + i];
+              }
+            }
+            if (inl) {
+              const uint32_t cnt0 = (ra[0].y >> 12) & 15u, cnt1 = two ? ((rb[0].y >> 12) & 15u) : 0u;
+              c_bl += two ? 2u : 1u;
+              queued = 0u;
+              if (cnt0 <= 4u) {
+                c_bc += cnt0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) my_best = min(my_best, seed_row_key(ut, ra[i], q, L, 0u, un.bucket_k, true));
+              } else {
+                queued |= 1u;
+              }
+              if (two) {
+                if (cnt1 <= 4u) {
+                  c_bc += cnt1;
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) my_best = min(my_best, seed_row_key(ut, rb[i], q, L, un.bucket_k, un.bucket_k, true));
+                } else {
+                  queued |= 2u;
+                }
+              }
+            }
+          }
+        }
+        // the unit's presence bitmaps: both seeds' words are requested before either is looked at
+        if (un.kbits && k >= 8) {
+          const uint32_t kb = (uint32_t)min(k, 11), woff = seed_kbits_word_off(kb), cmask = (1u << (2u * kb)) - 1u;
+          const uint32_t code0 = (uint32_t)q & cmask, code1 = (uint32_t)(q >> (2u * (uint32_t)k)) & cmask;
+          uint32_t w0 = ~0u, w1 = ~0u;
+          if (queued & 1u) w0 = un.kbits[woff + (code0 >> 5)];
+          if (queued & 2u) w1 = un.kbits[woff + (code1 >> 5)];
+          if (!((w0 >> (code0 & 31u)) & 1u)) queued &= ~1u;
+          if (!((w1 >> (code1 & 31u)) & 1u)) queued &= ~2u;
+        }
+      }
+      queued_all |= queued << (2u * ui);
+    }
+    // ================= finished on the spot, or parked =================
+    const bool park = queued_all != 0u;
+    finalize(active && !park, r, el_mask, my_best);
+    const uint64_t pm = __ballot(park);
+    if (pm) {
+      const uint32_t c = pend + mbcnt(pm);
+      if (park) {
+        w.rd[c] = rd;
+        w.best[c] = my_best;
+        w.r[c] = r;
+        w.meta[c] = L0 | (el_mask << 8) | (queued_all << 16);
+      }
+      pend += (uint32_t)__popcll(pm);
+    }
+    if (pend >= 64u || (last_trip && pend)) {
+      const uint32_t m = min(pend, 64u);
+      pend -= m;
+      work_off(pend, m);
+    }
+    if (last_trip) break;
+  }
+  // ---- counters: one global atomic per non-zero counter and workgroup ----
+  {
+    // (the inline answers' lookups / candidates: to the first bucket unit / the first dictionary unit)
+    uint32_t b_unit = 0, d_unit = 0;
+    for (uint32_t ui = p.n_units; ui-- > 0u;) {
+      if (kargs->unit[ui].kind == 0u && kargs->unit[ui].buckets) b_unit = ui;
+      if (kargs->unit[ui].kind == 1u) d_unit = ui;
+    }
+    c_lookups = c_bl;
+    c_cands = c_bc;
+    flush_diag(b_unit);
+    c_lookups = c_dl;
+    c_cands = c_dc;
+    flush_diag(d_unit);
+    uint32_t c = 0, cslot = 0;
+    for (uint32_t ui = 0; ui < p.n_units; ++ui)
+      for (uint32_t mi = 0; mi < kargs->unit[ui].n_members; ++mi, ++c) {
+        const uint32_t pi = (uint32_t)kargs->unit[ui].m[mi].pass_index;
+        cslot = (lane >> 1) == c ? 2u * pi + (lane & 1u) : cslot;
+      }
+    if (lane < 2u * c && acc_v) atomicAdd(&cnt[cslot], (unsigned long long)acc_v);
+  }
+  __syncthreads();
+  if (tid < 32u) {
+    const unsigned long long v = cnt[tid];
+    if (v) atomicAdd((unsigned long long*)&p.stats[(tid >> 1) * 5u + (tid & 1u)], v);
+  } else if (tid < 32u + 2u * p.n_units) {
+    const uint32_t ui = (tid - 32u) >> 1, what = (tid - 32u) & 1u;  // 0 candidates, 1 lookups
+    const unsigned long long v = cnt[tid];
+    if (v) atomicAdd((unsigned long long*)&p.stats[(uint32_t)kargs->unit[ui].m[0].pass_index * 5u + 3u + what], v);
+  }
+  if (p.idx_out && tid == 0) p.out_count[blockIdx.x] = ctl[0];
+}
+
 // mrg_pack_assignments: the four output arrays as one word per read (include/mirge_amd.h); four reads per lane
 __global__ void __launch_bounds__(256) pack_assignments_kernel(const int8_t* __restrict__ pass_id, const int32_t* __restrict__ ref_id,
                                                                const int32_t* __restrict__ pos, const uint8_t* __restrict__ mm, uint64_t n,
@@ -1036,6 +1668,7 @@ hipError_t launch_pack_assignments(const int8_t* pass_id, const int32_t* ref_id,
 }
 
 uint32_t seed_lds_bytes(const SeedParams& p) {
+  if (p.impl == 1u) return wave_shared_words() * 4u + (kSeedThreads / 64u) * wave_lds_bytes(p.row_cap);
   const uint32_t tile = kSeedThreads * p.reads_per_lane;
   return tile * 8u + tile * 8u + p.row_cap * 8u + kSeedWideCap * 16u + p.n_units * p.item_cap * 4u +
          kSeedMaxUnits * kUnitWords * 4u + kSeedCtlWords * 4u + kSeedCntSlots * 8u + tile;
@@ -1044,7 +1677,7 @@ uint32_t seed_lds_bytes(const SeedParams& p) {
 uint32_t seed_wgs_per_cu(const SeedParams& p) {
   bool buckets = false;
   for (uint32_t u = 0; u < p.n_units; ++u) buckets |= p.unit[u].kind == 0u && p.unit[u].buckets != nullptr;
-  const uint32_t by_regs = buckets ? 6u : 8u, by_lds = (160u * 1024u) / seed_lds_bytes(p);
+  const uint32_t by_regs = (p.impl == 1u && (p.wave_regs & 1u)) ? (buckets ? 5u : 6u) : (buckets ? 6u : 8u), by_lds = (160u * 1024u) / seed_lds_bytes(p);
   return by_regs < by_lds ? by_regs : (by_lds ? by_lds : 1u);
 }
 
@@ -1053,6 +1686,22 @@ hipError_t launch_seed(const SeedParams& p, uint32_t grid, hipStream_t stream) {
   const uint32_t lds = seed_lds_bytes(p);
   bool buckets = false;
   for (uint32_t u = 0; u < p.n_units; ++u) buckets |= p.unit[u].kind == 0u && p.unit[u].buckets != nullptr;
+  if (p.impl == 1u) {
+    if (p.row_cap < kWaveRowsMin) return hipErrorInvalidValue;
+    // (p.wave_regs: the instantiation with more registers and fewer resident workgroups -- an A/B knob)
+    const bool more_regs = (p.wave_regs & 1u) != 0u;
+    const void* wk = buckets ? (more_regs ? reinterpret_cast<const void*>(wave_seed_kernel<true, 5>) : reinterpret_cast<const void*>(wave_seed_kernel<true, 6>))
+                             : (more_regs ? reinterpret_cast<const void*>(wave_seed_kernel<false, 6>) : reinterpret_cast<const void*>(wave_seed_kernel<false, 8>));
+    if (lds > 48u * 1024u) {
+      hipError_t e = hipFuncSetAttribute(wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    if (buckets && more_regs) hipLaunchKernelGGL((wave_seed_kernel<true, 5>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+    else if (buckets) hipLaunchKernelGGL((wave_seed_kernel<true, 6>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+    else if (more_regs) hipLaunchKernelGGL((wave_seed_kernel<false, 6>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+    else hipLaunchKernelGGL((wave_seed_kernel<false, 8>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+    return hipGetLastError();
+  }
   const void* kern = buckets ? reinterpret_cast<const void*>(seed_kernel<true, 6>) : reinterpret_cast<const void*>(seed_kernel<false, 8>);
   if (lds > 48u * 1024u) {
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

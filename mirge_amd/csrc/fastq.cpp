@@ -15,6 +15,7 @@
 //     one with most matches, then fewest errors, first found wins); the read is cut where the
 //     adapter starts.  With several comma-separated adapters the one with most matches wins.
 #include "fastq.hpp"
+#include "pgzip.hpp"
 
 #include <zlib.h>
 
@@ -382,13 +383,8 @@ void load_fastq(const std::string& path, int qual_cutoff, int min_len, const cha
     }
   } joiner{pool, mu, cv, eof};
 
-  gzFile f = gzopen(path.c_str(), "rb");
-  if (!f) throw std::runtime_error("cannot open " + path);
-  struct Closer {
-    gzFile f;
-    ~Closer() { gzclose(f); }
-  } closer{f};
-  gzbuffer(f, 1 << 20);
+  // (gzip samples: inflated by `threads` workers, pgzip.cpp; plain text and threads = 1: zlib's reader)
+  GzipReader f(path, threads);
   std::vector<char> buf;
   size_t have = 0;
   bool at_eof = false, started = false;
@@ -435,8 +431,7 @@ void load_fastq(const std::string& path, int qual_cutoff, int min_len, const cha
     const size_t want = started ? kBlockBytes : std::max<size_t>(kBlockBytes, 1u << 20);
     while (!at_eof && have < want) {
       if (buf.size() < have + (1u << 20)) buf.resize(std::max<size_t>(buf.size() * 2, have + (2u << 20)));
-      const int got = gzread(f, buf.data() + have, (unsigned)std::min<size_t>(buf.size() - have, 1u << 30));
-      if (got < 0) throw std::runtime_error("read error (corrupt gzip?)");
+      const size_t got = f.read(buf.data() + have, std::min<size_t>(buf.size() - have, 1u << 30));
       if (got == 0) at_eof = true;
       have += (size_t)got;
     }
@@ -460,8 +455,7 @@ void load_fastq(const std::string& path, int qual_cutoff, int min_len, const cha
       const size_t more = have + kBlockBytes;
       while (!at_eof && have < more) {
         if (buf.size() < have + (1u << 20)) buf.resize(std::max<size_t>(buf.size() * 2, have + (2u << 20)));
-        const int got = gzread(f, buf.data() + have, (unsigned)std::min<size_t>(buf.size() - have, 1u << 30));
-        if (got < 0) throw std::runtime_error("read error (corrupt gzip?)");
+        const size_t got = f.read(buf.data() + have, std::min<size_t>(buf.size() - have, 1u << 30));
         if (got == 0) at_eof = true;
         have += (size_t)got;
       }

@@ -292,9 +292,11 @@ struct SeedUnit {
 struct SeedParams {
   SeedUnit unit[kSeedMaxUnits];
   uint32_t n_units;
-  uint32_t reads_per_lane;  // T: 1 or 2
-  uint32_t item_cap;        // per unit: 1024 T x seeds
-  uint32_t row_cap;
+  uint32_t impl;            // 0 = seed_kernel (tiles of 256 reads, three barriers per tile), 1 = wave_seed_kernel (every wave on its own)
+  uint32_t wave_regs;       // wave_seed_kernel: 1 = the instantiation with more registers, fewer resident workgroups
+  uint32_t reads_per_lane;  // seed_kernel: 1
+  uint32_t item_cap;        // seed_kernel, per unit: 256 x seeds
+  uint32_t row_cap;         // rows a tile (seed_kernel) / a wave (wave_seed_kernel) can queue
   uint64_t* stats;          // counter slots [pass][5]: processed, aligned, steps, candidates, lookups
   const uint64_t* reads;
   const uint8_t* lens;

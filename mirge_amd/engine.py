@@ -129,6 +129,12 @@ class Engine:
         arch = C.create_string_buffer(64)
         check(self._lib.mrg_ctx_device_info(self._h, C.byref(n_cu), C.byref(hbm), arch, 64))
         self.n_cu, self.hbm_bytes, self.arch = n_cu.value, hbm.value, arch.value.decode()
+        # development aid: MIRGE_AMD_OPTS="key=value,key=value" sets context options on every new engine (A/B runs
+        # of the whole test suite under another kernel variant)
+        import os
+        for kv in filter(None, os.environ.get("MIRGE_AMD_OPTS", "").split(",")):
+            k, v = kv.split("=")
+            self.set_option(k.strip(), int(v))
 
     def close(self):
         if getattr(self, "_h", None):

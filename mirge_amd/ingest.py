@@ -75,13 +75,12 @@ class DeviceIngestUnsupported(Exception):
 
 
 def load_fastq_device(engine, path, adapter="none", qual_cutoff=QUAL_CUTOFF, min_len=MIN_LENGTH, block_bytes=256 << 20,
-                      read_threads=8):
+                      read_threads=8, inflate_threads=None):
     """load_fastq with the record splitting, trimming and packing ON THE DEVICE (mrg_fastq_parse_device):
-    the host reads the file into a pinned buffer (plain text: `read_threads` parallel preads; gzip: one
-    inflate stream), cuts it at record boundaries (mrg_fastq_block_cut) and uploads text blocks.  `-ad none`
+    the host reads the file into a pinned buffer (plain text: `read_threads` parallel preads; gzip: the
+    parallel inflate of mrg_gz_open with `inflate_threads` workers, default one per core), cuts it at record boundaries (mrg_fastq_block_cut) and uploads text blocks.  `-ad none`
     and `-ad +N` only.  Returns dict(words int64 [W, n], lens uint8 [n], nmask int64 [W, n] | None -- DEVICE
     tensors, reads in file order --, total, kept, packed, phred, max_len, long_reads=[])."""
-    import gzip
     from concurrent.futures import ThreadPoolExecutor
     import torch
     ad = resolve_adapter(adapter)
@@ -103,7 +102,11 @@ def load_fastq_device(engine, path, adapter="none", qual_cutoff=QUAL_CUTOFF, min
     pin_mvs = [memoryview(a) for a in pin_nps]
     d_text = torch.empty(block_bytes + (1 << 20), dtype=torch.uint8, device=dev)
     outs, total, kept, max_len, any64, base = [], 0, 0, 0, False, None
-    fh = gzip.open(path, "rb") if is_gz else open(path, "rb", buffering=0)
+    # gzip samples: the parallel inflate of the C-ABI (mrg_gz_open, csrc/pgzip.cpp) writes straight into the pinned buffer
+    gz = C.c_void_p()
+    if is_gz:
+        check(lib.mrg_gz_open(path.encode(), max(1, int(inflate_threads or (os.cpu_count() or 1))), C.byref(gz)))
+    fh = None if is_gz else open(path, "rb", buffering=0)
     pool = None if is_gz else ThreadPoolExecutor(max_workers=max(1, int(read_threads)))
     state = dict(offset=0, eof=False)
     size = None if is_gz else os.fstat(fh.fileno()).st_size
@@ -115,12 +118,11 @@ def load_fastq_device(engine, path, adapter="none", qual_cutoff=QUAL_CUTOFF, min
         room = block_bytes - have
         got = 0
         if is_gz:
-            while got < room:
-                k = fh.readinto(mv[have + got:have + room])
-                if not k:
-                    state["eof"] = True
-                    break
-                got += k
+            k = C.c_uint64(0)
+            check(lib.mrg_gz_read(gz, C.c_void_p(pins[which].data_ptr() + have), room, C.byref(k)))
+            got = int(k.value)
+            if got < room:
+                state["eof"] = True
         else:
             got = max(0, min(room, size - state["offset"]))
             if got:
@@ -196,7 +198,10 @@ def load_fastq_device(engine, path, adapter="none", qual_cutoff=QUAL_CUTOFF, min
             n_buf = fill(nxt, have)
             cur = nxt
     finally:
-        fh.close()
+        if fh is not None:
+            fh.close()
+        if gz:
+            lib.mrg_gz_close(gz)
         if pool is not None:
             pool.shutdown()
     W = max([o[0].shape[0] for o in outs] + [1])
