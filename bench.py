@@ -517,7 +517,16 @@ def main():
             for j, sq in enumerate(all_seqs):
                 where.setdefault(sq, j)
             seqs = list(where)
-            bref = bowtie_probe.reference_cascade(found[0], found[1], {k: libs.libs[k] for k in keys}, seqs, threads=cores)
+            def read_ebwt(prefix):  # the product's `.1.ebwt` reader on what THIS box's bowtie-build just wrote
+                ix = FmIndex.from_ebwt(prefix)
+                return ix.names, [ix.sequence(i) for i in range(ix.n_ref)]
+            bref = bowtie_probe.reference_cascade(found[0], found[1], {k: libs.libs[k] for k in keys}, seqs, threads=cores,
+                                                  ebwt_reader=read_ebwt)
+            bad_e = {k: v["detail"] for k, v in (bref.get("ebwt") or {}).items() if not v["ok"]}
+            parity["ebwt_reader"] = ("PINNED: every index bowtie-build wrote here (%s) read back by mrg_index_build_ebwt = the "
+                                     "indexed FASTA" % ", ".join(sorted(bref["ebwt"]))) if not bad_e else "MISMATCH: %s" % bad_e
+            if bad_e:
+                raise SystemExit("PARITY FAILURE: the .1.ebwt reader differs from bowtie-build's files: %s" % bad_e)
             names = {k: index[k].names for k in keys}
             mine_pass = np.array([got[0][where[sq]] for sq in seqs], dtype=np.int8)
             mine_name = [names[table[got[0][where[sq]]][0]][got[1][where[sq]]] if got[0][where[sq]] >= 0 else ""

@@ -220,7 +220,8 @@ struct mrg_ctx {
   int64_t seed_buckets = 1;  // large libraries get seed buckets where they pay (set before add_library); 0 at run time: not used
   int64_t seed_wgs = 0;      // seed_kernel workgroups (256 threads) per CU; 0 = what the launch's instantiation keeps resident
   int64_t seed_units = 1;    // ... and their runs of passes with at most one seed mismatch go through seed_kernel
-  int64_t seed_impl = 1;   // 1 = wave_seed_kernel (every wave on its own), 0 = seed_kernel (tiles, barriers)
+  int64_t grid_pct = 100;  // share of the workgroups every cascade launch gets (see scale_grid)
+  int64_t seed_impl = -1;  // -1 = per launch (run_seed), 0 = seed_kernel (tiles), 1 = wave_seed_kernel, 2 = the same with more registers
   std::vector<DevLib> libs;
   std::vector<std::unique_ptr<SeedLib>> seed_libs;
   // last run
@@ -649,8 +650,11 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->seed_buckets = value != 0;
   } else if (k == "seed_wgs") {
     ctx->seed_wgs = value;
+  } else if (k == "grid_pct") {
+    if (value < 1 || value > 100) return fail(MRG_ERR_ARG, "grid_pct must be in [1,100]");
+    ctx->grid_pct = value;
   } else if (k == "seed_impl") {
-    if (value < 0 || value > 4) return fail(MRG_ERR_ARG, "seed_impl must be in [0,4]");
+    if (value < -1 || value > 4) return fail(MRG_ERR_ARG, "seed_impl must be in [-1,4]");
     ctx->seed_impl = value;
   } else if (k == "seed_units") {
     ctx->seed_units = value != 0;
@@ -827,6 +831,12 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   // "unannotated" values for whatever it does not claim)
   HIP_TRY(hipMemsetAsync(stats, 0, kWsStatsBytes, stream));
   uint32_t prev_grid = 0, prev_seg_cap = 0;
+  // "grid_pct": every launch with this share of its workgroups (the kernels loop over their chunks, so fewer
+  // workgroups only means more trips each): leaves room on the CUs for the launches of ANOTHER cascade
+  // running on another stream at the same time
+  auto scale_grid = [&](uint32_t grid) -> uint32_t {
+    return std::max<uint32_t>(1u, (uint32_t)((uint64_t)grid * (uint64_t)ctx->grid_pct / 100u));
+  };
   // Capacity of a producer workgroup's list segment: it must hold every read the workgroup may be
   // offered -- its share of an identity list in chunks of `chunk` reads, or, reading a list, the
   // chunks it walks (chunk c belongs to segment c % in_nseg and goes to workgroup c % grid: of
@@ -945,6 +955,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       e.pass_index = (int32_t)i;
       uint32_t grid = (uint32_t)ctx->n_cu * 2u;
       if (grid > 512u) grid = 512u;
+      grid = scale_grid(grid);
       // (a workgroup takes chunks of 4096 reads: four per lane)
       const uint32_t seg_cap = segment_capacity(grid, mrg::kExactChunk, have_list);
       if (!seg_cap && n) return fail(MRG_ERR_ARG, "mrg_cascade_run: survivor lists outgrew the workspace");
@@ -1088,6 +1099,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     const uint32_t per_cu = (lds_total * 2u <= 160u * 1024u) ? 2u : 1u;
     uint32_t grid = (uint32_t)ctx->n_cu * per_cu;
     if (grid > mrg::kMaxSegments) grid = mrg::kMaxSegments;
+    grid = scale_grid(grid);
     // a workgroup's segment must hold every read it may be offered
     const uint32_t seg_cap = segment_capacity(grid, 1024, have_list);
     if (!seg_cap && n) return fail(MRG_ERR_ARG, "mrg_cascade_run: survivor lists outgrew the workspace");
@@ -1297,6 +1309,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     const uint32_t per_cu = 1u;
     uint32_t grid = (uint32_t)ctx->n_cu * per_cu;
     if (grid > mrg::kMaxSegments) grid = mrg::kMaxSegments;
+    grid = scale_grid(grid);
     const uint32_t seg_cap = segment_capacity(grid, 1024, have_list);
     if (!seg_cap && n) return fail(MRG_ERR_ARG, "mrg_cascade_run: survivor lists outgrew the workspace");
     fp.out_seg_cap = seg_cap;
@@ -1378,8 +1391,15 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
         ctx->last_kbits_log2[i] = un.kbits ? 22u : 0u;
       }
     }
-    sp.impl = ctx->seed_impl ? 1u : 0u;
-    sp.wave_regs = ctx->seed_impl >= 2 ? (uint32_t)(ctx->seed_impl - 1) : 0u;  // 2: more registers, 3: the same in lockstep, 4: lockstep only
+    // which kernel: by default (-1) the tile kernel for the small libraries' launch (its waves are bound by what
+    // they do per read; with more registers and fewer waves the wave kernel only draws level, and its parked
+    // reads leave the list's order) and the wave kernel, 96 registers, for a launch on large libraries (bound by
+    // the L2 misses of its bucket / slot lines: no barrier, nothing parked but overflowing buckets: 2.08 -> 1.8 ms)
+    {
+      const int64_t impl = ctx->seed_impl >= 0 ? ctx->seed_impl : (small ? 0 : 2);
+      sp.impl = impl ? 1u : 0u;
+      sp.wave_regs = impl >= 2 ? (uint32_t)(impl - 1) : 0u;  // 2: more registers, 3: lockstep (experiment), 4: both
+    }
     sp.reads_per_lane = 1u;
     sp.item_cap = mrg::kSeedThreads * sp.reads_per_lane * 2u;
     sp.row_cap = sp.impl ? 192u : (small ? 1024u : 2048u);
@@ -1411,6 +1431,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     (void)lds;
     uint32_t grid = (uint32_t)ctx->n_cu * (ctx->seed_wgs > 0 ? (uint32_t)ctx->seed_wgs : mrg::seed_wgs_per_cu(sp));
     if (grid > mrg::kMaxSegments) grid = mrg::kMaxSegments;
+    grid = scale_grid(grid);
     const uint32_t seg_cap = segment_capacity(grid, (uint64_t)mrg::kSeedThreads * sp.reads_per_lane, have_list);
     if (!seg_cap && n) return fail(MRG_ERR_ARG, "mrg_cascade_run: survivor lists outgrew the workspace");
     sp.out_seg_cap = seg_cap;

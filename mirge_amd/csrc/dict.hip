@@ -1510,9 +1510,12 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
         if (ui == pre_ui && pre_direct) {
           ++c_dl;
           const uint32_t chain = (pre_sl.w >> kDictChainShift) & kDictChainMask;
-          if (chain == 0u) {
-            uint32_t dl = 0;  // (the slot is in hand: the probe neither loads nor counts it again)
+          if (chain != kDictChainOverflow) {
+            // (the home slot is in hand: the probe neither loads nor counts it again; the few lanes whose key
+            // chains further walk their chain here -- parked, they would leave the stream's order)
+            uint32_t dl = 0;
             my_best = min(my_best, dict_unit_probe(un, q, L, true, pre_sl, dl, c_dc));
+            c_dl += dl;
             queued = 0u;
           }
         }
@@ -1544,25 +1547,51 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
                 for (int i = 0; i < 4; ++i) rb[i] = un.buckets[base1 + i];
               }
             }
+            // the first four rows of each bucket are verified here; a fuller bucket (5..8 rows: one seed in
+            // eight) gets its second half line in a second trip of the lanes that need one -- parked
+            // instead, those reads would leave the stream's order (the next launch's gathers then fetch
+            // their lines twice: 14 M more L2 misses in the 2-mismatch pass behind this launch); only an
+            // overflowing bucket (the jump table serves that k-mer) is parked
+            bool more0 = false, more1 = false;
             if (inl) {
               const uint32_t cnt0 = (ra[0].y >> 12) & 15u, cnt1 = two ? ((rb[0].y >> 12) & 15u) : 0u;
               c_bl += two ? 2u : 1u;
               queued = 0u;
-              if (cnt0 <= 4u) {
+              if (cnt0 != kSeedBucketOverflow) {
                 c_bc += cnt0;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) my_best = min(my_best, seed_row_key(ut, ra[i], q, L, 0u, un.bucket_k, true));
+                more0 = cnt0 > 4u;
               } else {
                 queued |= 1u;
               }
               if (two) {
-                if (cnt1 <= 4u) {
+                if (cnt1 != kSeedBucketOverflow) {
                   c_bc += cnt1;
 #pragma unroll
                   for (int i = 0; i < 4; ++i) my_best = min(my_best, seed_row_key(ut, rb[i], q, L, un.bucket_k, un.bucket_k, true));
+                  more1 = cnt1 > 4u;
                 } else {
                   queued |= 2u;
                 }
+              }
+            }
+            if (__any(more0 || more1)) {
+              if (more0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ra[i] = un.buckets[base0 + 4u + i];
+              }
+              if (more1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rb[i] = un.buckets[base1 + 4u + i];
+              }
+              if (more0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) my_best = min(my_best, seed_row_key(ut, ra[i], q, L, 0u, un.bucket_k, true));
+              }
+              if (more1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) my_best = min(my_best, seed_row_key(ut, rb[i], q, L, un.bucket_k, un.bucket_k, true));
               }
             }
           }

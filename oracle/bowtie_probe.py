@@ -70,11 +70,50 @@ def _parse_sam(path):
     return out
 
 
-def reference_cascade(bowtie, bowtie_build, libraries, reads, threads=1, workdir=None, keep=False):
+def check_ebwt_reader(prefix, names, seqs, ebwt_reader, bowtie_inspect=None):
+    """The one moment the product's `.1.ebwt` reader (bowtie-inspect's job: summarize.py:6,
+    runAnnotationPipeline.py:610-611,630) can be PINNED: a bowtie-build of this box has just written
+    `<prefix>.*.ebwt` from (names, seqs).  ebwt_reader(prefix) -> (names, seqs) is the product's reader;
+    what it returns must be what was indexed (names up to their first blank, sequences upper-case) and,
+    when `bowtie-inspect` exists too, what that prints.  Returns a dict(ok, entries, detail)."""
+    want_names = [n.split()[0] if n.split() else n for n in names]
+    want_seqs = [s.upper() for s in seqs]
+    try:
+        got_names, got_seqs = ebwt_reader(prefix)
+    except Exception as e:  # the reader refuses files whose redundant fields it cannot re-derive
+        return dict(ok=False, entries=len(names), detail="reader raised: %s" % e)
+    got_names, got_seqs = list(got_names), [s.upper() for s in got_seqs]
+    if got_names != want_names:
+        k = next((i for i, (a, b) in enumerate(zip(got_names, want_names)) if a != b), min(len(got_names), len(want_names)))
+        return dict(ok=False, entries=len(names), detail="names differ from the indexed FASTA at entry %d (%d vs %d entries)"
+                    % (k, len(got_names), len(want_names)))
+    if got_seqs != want_seqs:
+        k = next(i for i, (a, b) in enumerate(zip(got_seqs, want_seqs)) if a != b)
+        return dict(ok=False, entries=len(names), detail="sequence of entry %d (%s) differs from the indexed FASTA" % (k, want_names[k]))
+    detail = "names + sequences = the FASTA bowtie-build indexed"
+    if bowtie_inspect:
+        out = subprocess.run([bowtie_inspect, prefix], capture_output=True, text=True)
+        if out.returncode == 0:
+            i_names, i_seqs, cur = [], [], None
+            for line in out.stdout.splitlines():
+                if line.startswith(">"):
+                    i_names.append(line[1:].split()[0] if line[1:].split() else line[1:])
+                    i_seqs.append([])
+                elif i_seqs:
+                    i_seqs[-1].append(line.strip())
+            i_seqs = ["".join(x).upper() for x in i_seqs]
+            if i_names != got_names or i_seqs != got_seqs:
+                return dict(ok=False, entries=len(names), detail="differs from what bowtie-inspect prints")
+            detail += " = what bowtie-inspect prints"
+    return dict(ok=True, entries=len(names), detail=detail)
+
+
+def reference_cascade(bowtie, bowtie_build, libraries, reads, threads=1, workdir=None, keep=False, ebwt_reader=None):
     """libraries: {key: (names, seqs)} for the keys of PASSES; reads: list of DISTINCT ASCII reads.
     Returns dict(pass_id int8 [n] (-1 = unannotated), ref_name [n], pos int32 [n] (SAM POS - 1),
     stats [(processed, aligned)] per pass, seconds (the nine bowtie runs + SAM parsing, index
-    construction excluded), build_seconds)."""
+    construction excluded), build_seconds, ebwt {key: check_ebwt_reader(...)} when ebwt_reader is given:
+    every index bowtie-build wrote is handed to the product's `.1.ebwt` reader)."""
     own = workdir is None
     workdir = workdir or tempfile.mkdtemp(prefix="mrg_bowtie_")
     os.makedirs(workdir, exist_ok=True)
@@ -90,6 +129,11 @@ def reference_cascade(bowtie, bowtie_build, libraries, reads, threads=1, workdir
             prefix[key] = os.path.join(workdir, key)
             subprocess.run([bowtie_build, "-q", fa, prefix[key]], check=True, stdout=subprocess.DEVNULL)
         build_s = time.perf_counter() - t0
+        ebwt = None
+        if ebwt_reader is not None:
+            inspect = shutil.which("bowtie-inspect", path=os.pathsep.join([os.path.dirname(bowtie), os.environ.get("PATH", "")]))
+            ebwt = {key: check_ebwt_reader(prefix[key], libraries[key][0], libraries[key][1], ebwt_reader, inspect)
+                    for key in prefix}
         n = len(reads)
         index_of = {r: i for i, r in enumerate(reads)}
         pass_id = np.full(n, -1, dtype=np.int8)
@@ -139,7 +183,7 @@ def reference_cascade(bowtie, bowtie_build, libraries, reads, threads=1, workdir
                     ref_name[k] = rname
                     pos[k] = int(p1) - 1
         return dict(pass_id=pass_id, ref_name=ref_name, pos=pos, stats=stats,
-                    seconds=time.perf_counter() - t1, build_seconds=build_s, threads=threads)
+                    seconds=time.perf_counter() - t1, build_seconds=build_s, threads=threads, ebwt=ebwt)
     finally:
         if own and not keep:
             shutil.rmtree(workdir, ignore_errors=True)

@@ -22,9 +22,16 @@ STAND_IN = textwrap.dedent('''\
     argv = sys.argv[1:]
     if os.path.basename(sys.argv[0]) == "bowtie-build":
         pos = [a for a in argv if not a.startswith("-")]
-        open(pos[1] + ".1.ebwt", "w").write("stand-in")
         assert os.path.exists(pos[1] + ".fa")
-        sys.exit(0)
+        # a real `.1.ebwt` through the test suite's stand-alone writer (tests/helpers/ebwt_writer.cpp)
+        import ctypes as C
+        lib = model.Library.from_fasta(pos[1] + ".fa")
+        w = C.CDLL(%(writer)r)
+        n = len(lib.names)
+        a = (C.c_char_p * n)(*[x.encode() for x in lib.names])
+        b = (C.c_char_p * n)(*[x.encode() for x in lib.seqs])
+        w.ebwt_write.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_uint32, C.c_int32, C.c_int32, C.c_int32]
+        sys.exit(w.ebwt_write(pos[1].encode(), a, b, n, 10, 6, 1))
     mode, mm, t5, t3, pos, i = "n", 2, 0, 0, [], 0
     while i < len(argv):
         a = argv[i]
@@ -63,7 +70,7 @@ def _install(bindir):
     for name in ("bowtie", "bowtie-build"):
         path = os.path.join(bindir, name)
         with open(path, "w") as fh:
-            fh.write(STAND_IN % dict(python=sys.executable, root=ROOT))
+            fh.write(STAND_IN % dict(python=sys.executable, root=ROOT, writer=os.path.join(ROOT, "tests", "_build", "libebwt_writer.so")))
         os.chmod(path, os.stat(path).st_mode | stat.S_IXUSR)
 
 
@@ -72,14 +79,25 @@ def test_probe_reports_absence(tmp_path, monkeypatch):
     assert bowtie_probe.find_bowtie() is None
 
 
-def test_reference_cascade_through_stand_in_bowtie(tmp_path, oracle_lib, native_lib):
+def test_reference_cascade_through_stand_in_bowtie(tmp_path, oracle_lib, native_lib, ebwt_writer):
     bindir = str(tmp_path / "bin")
     _install(bindir)
     found = bowtie_probe.find_bowtie(extra_dirs=[bindir])
     assert found is not None
     w = World(scale=0.02, n_fixed=1500, n_var=400, with_n=False)
+    from mirge_amd.index import FmIndex
+
+    def read_ebwt(prefix):
+        ix = FmIndex.from_ebwt(prefix)
+        return ix.names, [ix.sequence(i) for i in range(ix.n_ref)]
     ref = bowtie_probe.reference_cascade(found[0], found[1], w.libs.libs, w.reads, threads=2,
-                                         workdir=str(tmp_path / "work"))
+                                         workdir=str(tmp_path / "work"), ebwt_reader=read_ebwt)
+    # every index the (stand-in) bowtie-build wrote went through the product's `.1.ebwt` reader: the hook that
+    # pins the reader the moment a real bowtie-build exists on a box
+    assert sorted(ref["ebwt"]) == sorted(set(k for k, _, _ in bowtie_probe.PASSES))
+    assert all(v["ok"] for v in ref["ebwt"].values()), ref["ebwt"]
+    wrong = bowtie_probe.check_ebwt_reader("x", ["a", "b"], ["ACGT", "GGCC"], lambda p: (["a", "b"], ["ACGT", "GGCA"]))
+    assert not wrong["ok"] and "entry 1" in wrong["detail"]
     # the oracle's own dict-shaped cascade on the same reads
     libs = {k: model.Library(*w.libs.libs[k]) for k in LIB_ORDER}
     seq_dic = {r: cascade.new_seq_record(r, 1) for r in w.reads}
