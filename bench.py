@@ -101,7 +101,12 @@ def kernel_name(W, table_row, s, n_bases):
     if s["lds_mode"] == 7:
         # (FIRST = the pass streams the whole read set; KBITS = its library has the 9-mer bitmap)
         return "mrg::exact_dict_kernel<%s, %s>" % ("true" if s.get("first_pass") else "false", "true" if n_bases <= 190000 else "false")
+    if s["lds_mode"] == 11:
+        return "mrg::pair_wave_kernel"
     if s["lds_mode"] in (8, 9):
+        v = s.get("variant", 0)
+        if v:
+            return "mrg::wave_seed_kernel<%s>" % {(8, 1): "false, 8", (9, 1): "true, 6", (8, 2): "false, 6", (9, 2): "true, 5"}[(s["lds_mode"], v)]
         return "mrg::seed_kernel<false, 8>" if s["lds_mode"] == 8 else "mrg::seed_kernel<true, 6>"
     has_ctx = n_bases >= (1 << 20) and s["lds_mode"] in (0, 1)
     return "mrg::match_kernel<%d, %s, %s, %s, %s>" % (

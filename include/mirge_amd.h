@@ -261,6 +261,13 @@ typedef struct mrg_pass_stats {
   float ms_rest;       /* a split batch ("split_mixed"): device time of this pass in the FIRST cascade (the
                           long reads, reads with N, very short reads: FM kernels); ms and the kernel fields
                           above describe the second one (the one-word reads); 0 when the batch was not split */
+  uint32_t variant;    /* which instantiation behind lds_mode 8 / 9 (round 4): 0 = seed_kernel (tiles of 256 reads,
+                          three barriers per tile), 1 = wave_seed_kernel<false, 8> / <true, 6> (every wave on its
+                          own: a read with nothing left to look up is finished on the spot, the others are parked
+                          and worked off 64 at a time), 2 = wave_seed_kernel<false, 6> / <true, 5> (more registers).
+                          lds_mode 11 (round 4) = pair_wave_kernel: the anchor-pair search of a 2-mismatch pass for
+                          one-word reads without N, items and rows compacted over the wave */
+  uint32_t reserved;
 } mrg_pass_stats;
 
 /* Bytes of device workspace mrg_cascade_run needs for n reads (three index lists of n + 2^23 entries,
@@ -504,6 +511,13 @@ typedef struct mrg_fastq_device_info {
   int32_t reserved;
 } mrg_fastq_device_info;
 int mrg_fastq_block_cut(const char *buf, uint64_t len, int32_t at_eof, uint64_t *cut);
+/* (round 4) mrg_fastq_parse_device_ad: the same with adapter SEQUENCES -- `adapters` = the `-ad` value after
+ * __main__.py:123-127 resolved its aliases, "SEQ[,SEQ...]" (at most 4 of at most 64 bases; NULL or "" = none):
+ * cutadapt's 3' search (`-a`, error rate 0.12, minimum overlap 3: trim_file.py:30-41), one thread per read,
+ * after the quality trim and the cutter; the adapter with the most matched bases cuts the read. */
+int mrg_fastq_parse_device_ad(mrg_ctx *ctx, const char *d_text, uint64_t n_bytes, int32_t phred, int32_t qual_cutoff,
+                              int32_t min_len, int32_t cut, const char *adapters, uint32_t words_per_read, uint64_t cap,
+                              uint64_t *d_words, uint8_t *d_lens, uint64_t *d_nmask, mrg_fastq_device_info *info, void *stream);
 int mrg_fastq_parse_device(mrg_ctx *ctx, const char *d_text, uint64_t n_bytes, int32_t phred, int32_t qual_cutoff,
                            int32_t min_len, int32_t cut, uint32_t words_per_read, uint64_t cap, uint64_t *d_words,
                            uint8_t *d_lens, uint64_t *d_nmask, mrg_fastq_device_info *info, void *stream);

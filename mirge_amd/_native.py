@@ -33,7 +33,7 @@ class PassStats(C.Structure):
                 ("candidates", C.c_uint64), ("lookups", C.c_uint64), ("ms", C.c_float),
                 ("lds_bytes", C.c_uint32), ("lds_mode", C.c_uint32), ("group", C.c_uint32),
                 ("n_launches", C.c_uint32), ("kbits_log2", C.c_uint32),
-                ("pair_anchor", C.c_uint32), ("ms_rest", C.c_float)]
+                ("pair_anchor", C.c_uint32), ("ms_rest", C.c_float), ("variant", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class IndexInfo(C.Structure):
@@ -149,6 +149,9 @@ SIGNATURES = {
     "mrg_gz_close": (None, [C.c_void_p]),
     "mrg_fastq_parse_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32,
                                          C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FastqDeviceInfo), C.c_void_p]),
+    "mrg_fastq_parse_device_ad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_char_p,
+                                            C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FastqDeviceInfo),
+                                            C.c_void_p]),
     "mrg_expand_compact": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
                                      C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mrg_collapse_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -220,6 +220,7 @@ struct mrg_ctx {
   int64_t seed_buckets = 1;  // large libraries get seed buckets where they pay (set before add_library); 0 at run time: not used
   int64_t seed_wgs = 0;      // seed_kernel workgroups (256 threads) per CU; 0 = what the launch's instantiation keeps resident
   int64_t seed_units = 1;    // ... and their runs of passes with at most one seed mismatch go through seed_kernel
+  int64_t pair_impl = 1;   // 1 = pair_wave_kernel for the anchor-pair search of one-word batches, 0 = stratum_kernel
   int64_t grid_pct = 100;  // share of the workgroups every cascade launch gets (see scale_grid)
   int64_t seed_impl = -1;  // -1 = per launch (run_seed), 0 = seed_kernel (tiles), 1 = wave_seed_kernel, 2 = the same with more registers
   std::vector<DevLib> libs;
@@ -235,6 +236,7 @@ struct mrg_ctx {
   uint32_t last_split = 0;  // the last run split its batch into one-word reads and the rest
   uint32_t last_kbits_log2[MRG_MAX_PASSES] = {0};
   uint32_t last_pair_anchor[MRG_MAX_PASSES] = {0};
+  uint32_t last_variant[MRG_MAX_PASSES] = {0};
   hipEvent_t ev[MRG_MAX_PASSES + 1] = {nullptr};
   hipEvent_t ev0[MRG_MAX_PASSES + 1] = {nullptr};  // the first cascade of a split batch
   bool ev_ready = false;
@@ -650,6 +652,8 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->seed_buckets = value != 0;
   } else if (k == "seed_wgs") {
     ctx->seed_wgs = value;
+  } else if (k == "pair_impl") {
+    ctx->pair_impl = value != 0;
   } else if (k == "grid_pct") {
     if (value < 1 || value > 100) return fail(MRG_ERR_ARG, "grid_pct must be in [1,100]");
     ctx->grid_pct = value;
@@ -884,6 +888,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     ctx->last_launches[i] = 0;
     ctx->last_kbits_log2[i] = 0;
     ctx->last_pair_anchor[i] = 0;
+    ctx->last_variant[i] = 0;
   }
   auto fusable = [&](uint32_t i) {
     // the first launched pass streams the whole read set and keeps the classic kernel (library
@@ -1093,10 +1098,18 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       lds_mode = rows_lds_text ? 3 : 0;
       lib_bytes = rows_lds_text ? txt_bytes : 0;
     }
-    const uint32_t lds_total = rows_kernel ? (uint32_t)((uint64_t)l.nsup * 16 + mrg::kStratumCtlBytes + (use_kbits ? kb_bytes : 0) + lib_bytes)
-                                           : (uint32_t)(overhead + lib_bytes);
+    // one-word reads without N through the anchor pairs: pair_wave_kernel (dict.hip; every wave on its own, items
+    // and rows compacted over the wave; nothing staged in LDS but the wave's 256 reads)
+    const bool pair_wave = rows_kernel && by_pairs && dict_batch && ctx->pair_impl != 0;
+    if (pair_wave) {
+      lds_mode = 0;
+      lib_bytes = 0;
+    }
+    const uint32_t lds_total = pair_wave ? mrg::pair_wave_lds_total()
+                               : rows_kernel ? (uint32_t)((uint64_t)l.nsup * 16 + mrg::kStratumCtlBytes + (use_kbits ? kb_bytes : 0) + lib_bytes)
+                                             : (uint32_t)(overhead + lib_bytes);
     const uint32_t lds_bytes = (uint32_t)lib_bytes;
-    const uint32_t per_cu = (lds_total * 2u <= 160u * 1024u) ? 2u : 1u;
+    const uint32_t per_cu = pair_wave ? std::min<uint32_t>(6u, (160u * 1024u) / lds_total) : ((lds_total * 2u <= 160u * 1024u) ? 2u : 1u);
     uint32_t grid = (uint32_t)ctx->n_cu * per_cu;
     if (grid > mrg::kMaxSegments) grid = mrg::kMaxSegments;
     grid = scale_grid(grid);
@@ -1109,8 +1122,10 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     ctx->last_group[i] = i;
     ctx->last_kbits_log2[i] = use_kbits ? 18u : 0u;
     ctx->last_pair_anchor[i] = p.pair_anchor;
-    if (rows_kernel) ctx->last_mode[i] = rows_lds_text ? 5u : 6u;
-    if (n && rows_kernel) {
+    if (rows_kernel) ctx->last_mode[i] = pair_wave ? 11u : (rows_lds_text ? 5u : 6u);
+    if (n && pair_wave) {
+      HIP_TRY(mrg::launch_pair_wave(p, grid, stream));
+    } else if (n && rows_kernel) {
       HIP_TRY(mrg::launch_stratum(p, words_eff, rows_lds_text, grid, lds_total, stream));
     } else if (n) {
       HIP_TRY(mrg::launch_match(p, words_eff, lds_mode, grid, lds_total, stream));
@@ -1399,6 +1414,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       const int64_t impl = ctx->seed_impl >= 0 ? ctx->seed_impl : (small ? 0 : 2);
       sp.impl = impl ? 1u : 0u;
       sp.wave_regs = impl >= 2 ? (uint32_t)(impl - 1) : 0u;  // 2: more registers, 3: lockstep (experiment), 4: both
+      for (uint32_t q = first; q < end; ++q) ctx->last_variant[q] = sp.impl ? ((sp.wave_regs & 1u) ? 2u : 1u) : 0u;
     }
     sp.reads_per_lane = 1u;
     sp.item_cap = mrg::kSeedThreads * sp.reads_per_lane * 2u;
@@ -1666,6 +1682,8 @@ int mrg_cascade_stats(mrg_ctx* ctx, mrg_pass_stats* out, uint32_t n_pass) {
     out[i].n_launches = ctx->last_launches[i];
     out[i].kbits_log2 = ctx->last_kbits_log2[i];
     out[i].pair_anchor = ctx->last_pair_anchor[i];
+    out[i].variant = ctx->last_variant[i];
+    out[i].reserved = 0;
   }
   return MRG_OK;
 }
@@ -2239,7 +2257,35 @@ int mrg_fastq_block_cut(const char* buf, uint64_t len, int32_t at_eof, uint64_t*
 int mrg_fastq_parse_device(mrg_ctx* ctx, const char* d_text, uint64_t n_bytes, int32_t phred, int32_t qual_cutoff, int32_t min_len,
                            int32_t cut, uint32_t words_per_read, uint64_t cap, uint64_t* d_words, uint8_t* d_lens, uint64_t* d_nmask,
                            mrg_fastq_device_info* info, void* stream) {
+  return mrg_fastq_parse_device_ad(ctx, d_text, n_bytes, phred, qual_cutoff, min_len, cut, nullptr, words_per_read, cap, d_words, d_lens,
+                                   d_nmask, info, stream);
+}
+
+int mrg_fastq_parse_device_ad(mrg_ctx* ctx, const char* d_text, uint64_t n_bytes, int32_t phred, int32_t qual_cutoff, int32_t min_len,
+                              int32_t cut, const char* adapters, uint32_t words_per_read, uint64_t cap, uint64_t* d_words,
+                              uint8_t* d_lens, uint64_t* d_nmask, mrg_fastq_device_info* info, void* stream) {
   if (!ctx || !info) return fail(MRG_ERR_ARG, "mrg_fastq_parse_device: null argument");
+  mrg::AdapterSet ads;
+  std::memset(&ads, 0, sizeof ads);
+  if (adapters && *adapters) {
+    mrg::TrimSpec spec;
+    try {
+      spec = mrg::parse_trim_spec(adapters);
+    } catch (const std::exception& e) {
+      return fail(MRG_ERR_ARG, "mrg_fastq_parse_device_ad: %s", e.what());
+    }
+    if (spec.cut) return fail(MRG_ERR_ARG, "mrg_fastq_parse_device_ad: `+N` goes in `cut`, adapters takes sequences");
+    if (spec.adapters.size() > mrg::kAdapterMax)
+      return fail(MRG_ERR_ARG, "mrg_fastq_parse_device_ad: at most %u adapter sequences", mrg::kAdapterMax);
+    for (const std::string& a : spec.adapters) {
+      if (a.size() > mrg::kAdapterMaxLen)
+        return fail(MRG_ERR_ARG, "mrg_fastq_parse_device_ad: adapters of at most %u bases", mrg::kAdapterMaxLen);
+      const uint32_t q = ads.n++;
+      ads.len[q] = (uint8_t)a.size();
+      ads.k[q] = (uint8_t)(int)(0.12 * (double)a.size());
+      std::memcpy(ads.seq[q], a.data(), a.size());
+    }
+  }
   if (n_bytes && (!d_text || !d_words || !d_lens)) return fail(MRG_ERR_ARG, "mrg_fastq_parse_device: null buffers");
   if (words_per_read != 1 && words_per_read != 2 && words_per_read != 4)
     return fail(MRG_ERR_ARG, "mrg_fastq_parse_device: words_per_read must be 1, 2 or 4");
@@ -2247,7 +2293,7 @@ int mrg_fastq_parse_device(mrg_ctx* ctx, const char* d_text, uint64_t n_bytes, i
   if (n_bytes >= 0x7fffffffull) return fail(MRG_ERR_ARG, "mrg_fastq_parse_device: at most 2^31 - 2 bytes of text per call");
   HIP_TRY(hipSetDevice(ctx->device));
   uint64_t h[7];
-  HIP_TRY(mrg::fastq_parse_device(d_text, n_bytes, phred, qual_cutoff, min_len, cut, words_per_read, cap, d_words, d_lens, d_nmask, h,
+  HIP_TRY(mrg::fastq_parse_device(d_text, n_bytes, phred, qual_cutoff, min_len, cut, ads, words_per_read, cap, d_words, d_lens, d_nmask, h,
                                   (hipStream_t)stream));
   info->n_records = h[0];
   info->n_kept = h[1];

@@ -80,9 +80,18 @@ __device__ __forceinline__ uint32_t pick_seed_table(const Tabs& t, int32_t k, ui
 }
 
 // 32 text bases from position p (2-bit packed text in global memory, 3 dword loads)
+// (ONE 12-byte request: the three words are consecutive and 4-byte aligned, which is all a multi-dword global load needs;
+// as three dword loads every candidate verification cost three L1 / L2 requests)
+struct __attribute__((packed, aligned(4))) TextWords3 {
+  uint32_t w0, w1, w2;
+};
+struct __attribute__((packed, aligned(4))) TableEntry2 {  // two neighbouring boundaries of a jump table: one 8-byte request
+  uint32_t lo, hi;
+};
 __device__ __forceinline__ uint64_t text_window(const uint32_t* __restrict__ text, uint32_t p) {
   const uint32_t i = p >> 4, sh = (p & 15) * 2;
-  const uint32_t w0 = text[i], w1 = text[i + 1], w2 = text[i + 2];
+  const TextWords3 t3 = *reinterpret_cast<const TextWords3*>(text + i);
+  const uint32_t w0 = t3.w0, w1 = t3.w1, w2 = t3.w2;
   const uint64_t lo64 = (uint64_t)w0 | ((uint64_t)w1 << 32);
   return (lo64 >> sh) | ((((uint64_t)w2) << 1) << (63 - sh));
 }

@@ -1664,6 +1664,324 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
   if (p.idx_out && tid == 0) p.out_count[blockIdx.x] = ctl[0];
 }
 
+// ---------------------------------------------------------------------------
+// pair_wave_kernel: the 2-mismatch pass (`-5 1 -3 2 -v 2 --best`, RAP:585/599) through the anchor pairs
+// of stratum_kernel (kernels.hip, fm_index.hpp: PairTables), for one-word reads without N, every wave on
+// its own.  stratum_kernel holds 64 reads per wave and walks the six pairs with all of them: a pair's
+// jump-table load, row compaction, verification and stratum test are issued for the wave as long as ONE
+// lane is still open, and after the first pair 45 % of the lanes are closed (1 400 VALU lane-instructions
+// per read for 3.4 lookups and 3.9 rows).  Here a wave takes 256 reads per trip into its LDS region
+// (four per lane) and works in three rounds -- pair (0,1) for every read; (2,3) for the reads whose best
+// is worse than exact; the other four for the reads still worse than one mismatch (bowtie's --best is
+// stratum first: a hit below the bound is final) -- with the ITEMS (read, pair) of a round compacted
+// over the wave, 64 lookups per trip, and their ROWS through a row queue, 64 verifications per trip.
+// Same tables, same candidates, same assignment (fewest mismatches, lowest text position).
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr uint32_t kPairReads = 256u;   // reads of a wave per trip
+constexpr uint32_t kPairItems = 192u;   // item list (fewer than 128 pending + the 64 of one sweep over the lanes)
+constexpr uint32_t kPairRowCap = 160u;  // row queue
+constexpr uint32_t kPairSharedWords = 16u;  // ctl[4], counters [5] x 8 bytes
+
+struct PairLds {
+  unsigned long long* rd;    // [kPairReads] trimmed read
+  unsigned long long* best;  // [kPairReads] mm : 8 | text position : 32 | segment : 16 | before : 8, ~0 = none
+  uint8_t* len;              // [kPairReads] trimmed length, 0 = not searched
+  uint8_t* st;               // [kPairReads] anchor length (bits 0-2), bit 6 = no anchors fit (scan), bit 7 = a read sits here
+  uint2* rows;               // [kPairRowCap] (row index, slot | need_before << 8)
+  uint16_t* items;           // [kPairItems] slot | pair << 8
+};
+__host__ __device__ constexpr uint32_t pair_wave_lds_bytes() { return kPairReads * (8u + 8u + 1u + 1u) + kPairRowCap * 8u + kPairItems * 2u; }
+
+}  // namespace
+
+__global__ void __launch_bounds__(kSeedThreads, 6) pair_wave_kernel(const MatchParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  uint32_t* const ctl = smem;  // [0] survivors of the workgroup, [1] longest input segment
+  unsigned long long* const wg_cnt = reinterpret_cast<unsigned long long*>(smem + 4);
+  PairLds w;
+  {
+    uint8_t* base = reinterpret_cast<uint8_t*>(smem + kPairSharedWords) + (size_t)wv * pair_wave_lds_bytes();
+    w.rd = reinterpret_cast<unsigned long long*>(base);
+    w.best = w.rd + kPairReads;
+    w.rows = reinterpret_cast<uint2*>(w.best + kPairReads);
+    w.items = reinterpret_cast<uint16_t*>(w.rows + kPairRowCap);
+    w.len = reinterpret_cast<uint8_t*>(w.items + kPairItems);
+    w.st = w.len + kPairReads;
+  }
+  if (tid < 4u) ctl[tid] = 0u;
+  if (tid < 5u) wg_cnt[tid] = 0ull;
+  __syncthreads();
+  if (p.idx_in) longest_segment(p.in_count, p.in_nseg, &ctl[1]);
+  __syncthreads();
+
+  const uint32_t PA = p.pair_anchor;
+  const uint32_t in_nseg = p.idx_in ? p.in_nseg : 1u;
+  const uint32_t depth_chunks = p.idx_in ? (ctl[1] + kPairReads - 1u) / kPairReads : (p.n_total + kPairReads - 1u) / kPairReads;
+  const uint32_t n_chunks = in_nseg * depth_chunks;
+  SegTables segs{p.seg_start, p.seg_ref, p.seg_off, p.chunk_seg, p.simple_segs};
+  uint32_t c_processed = 0, c_aligned = 0, c_cands = 0, c_lookups = 0;
+  uint32_t rpend = 0;  // rows waiting in the queue (wave-uniform)
+
+  // A row of a pair list (or of the suffix array) as a candidate of the read in `slot`, in two steps so that a lane can
+  // have the loads of TWO candidates in flight (a wave works through dependent L2 trips -- row, then text window --
+  // and was waiting for them half of its time): row_start checks the room and says where the alignment starts,
+  // row_finish compares the text window.
+  auto row_start = [&](uint64_t row, uint32_t slot, uint32_t need_before, uint32_t& s) __attribute__((always_inline)) -> bool {
+    const uint32_t before = (uint32_t)(row >> 32) & 255u, after = (uint32_t)(row >> 40) & 255u;
+    const uint32_t need_after = (uint32_t)w.len[slot] - need_before;
+    s = (uint32_t)row - need_before;
+    return !((need_before > before) | (need_after > after));
+  };
+  auto row_finish = [&](uint64_t row, uint32_t slot, uint32_t need_before, uint32_t s, uint64_t win) __attribute__((always_inline)) {
+    const uint64_t q = w.rd[slot];
+    const int32_t L = (int32_t)w.len[slot];
+    const uint64_t m = mismatch_bits(win, q) & low_bits(2u * (uint32_t)L);
+    const uint32_t mm_total = (uint32_t)__popcll(m);
+    uint32_t mm_seed = mm_total;
+    if (L > p.seed_len) mm_seed = (uint32_t)__popcll(m & low_bits(2u * (uint32_t)p.seed_len));
+    if (((int32_t)mm_seed > p.max_mm_seed) | ((int32_t)mm_total > p.max_mm_total)) return;
+    const uint32_t before = (uint32_t)(row >> 32) & 255u;
+    const uint32_t rbefore = before < 255u ? before - need_before : 255u;
+    const unsigned long long key = ((unsigned long long)mm_total << 56) | ((unsigned long long)s << 24) | ((unsigned long long)(row >> 48) << 8) |
+                                   (unsigned long long)rbefore;
+    atomicMin(&w.best[slot], key);
+  };
+  auto verify_one = [&](uint64_t row, uint32_t slot, uint32_t need_before) __attribute__((always_inline)) {
+    uint32_t s;
+    if (row_start(row, slot, need_before, s)) row_finish(row, slot, need_before, s, text_window(p.text, s));
+  };
+  auto verify_rows = [&](uint32_t from, uint32_t n) __attribute__((always_inline)) {  // rows [from, from + n), n <= 128: two per lane
+    wave_lds_sync();
+    const bool h0 = lane < n, h1 = lane + 64u < n;
+    uint2 e0 = make_uint2(0u, 0u), e1 = make_uint2(0u, 0u);
+    if (h0) e0 = w.rows[from + lane];
+    if (h1) e1 = w.rows[from + 64u + lane];
+    uint64_t r0 = 0, r1 = 0;
+    if (h0) r0 = p.pair_rows[e0.x];
+    if (h1) r1 = p.pair_rows[e1.x];
+    uint32_t s0 = 0, s1 = 0;
+    const bool ok0 = h0 && row_start(r0, e0.y & 255u, e0.y >> 8, s0);
+    const bool ok1 = h1 && row_start(r1, e1.y & 255u, e1.y >> 8, s1);
+    uint64_t w0 = 0, w1 = 0;
+    if (ok0) w0 = text_window(p.text, s0);
+    if (ok1) w1 = text_window(p.text, s1);
+    if (ok0) row_finish(r0, e0.y & 255u, e0.y >> 8, s0, w0);
+    if (ok1) row_finish(r1, e1.y & 255u, e1.y >> 8, s1, w1);
+  };
+  auto push_rows = [&](uint32_t lo, uint32_t n_rows, uint32_t tag) __attribute__((always_inline)) {
+    uint32_t left = n_rows;
+    while (__any(left != 0u)) {
+      const uint32_t incl = wave_incl_scan(left);
+      const uint32_t room = kPairRowCap - rpend;
+      const bool fits = left != 0u && incl <= room;
+      const uint64_t fm = __ballot(fits);
+      const uint32_t total = fm ? __shfl(incl, 63 - __clzll((long long)fm), 64) : 0u;
+      if (fits) {
+        const uint32_t first = rpend + incl - left;
+        for (uint32_t i = 0; i < left; ++i) w.rows[first + i] = make_uint2(lo + i, tag);
+        left = 0u;
+      }
+      rpend += total;
+      while (rpend >= 128u) {
+        rpend -= 128u;
+        verify_rows(rpend, 128u);
+      }
+    }
+  };
+  // items [from, from + m), m <= 128, two per lane: (slot, pair) -> its jump-table entry (both loads in flight) -> its
+  // rows into the queue
+  auto run_items = [&](uint32_t from, uint32_t m) __attribute__((always_inline)) {
+    wave_lds_sync();
+    uint32_t lo[2] = {0u, 0u}, n_rows[2] = {0u, 0u}, tag[2] = {0u, 0u};
+    const TableEntry2* tp[2] = {nullptr, nullptr};
+    uint32_t roff[2] = {0u, 0u};
+#pragma unroll
+    for (uint32_t h = 0; h < 2u; ++h) {
+      if (lane + 64u * h < m) {
+        const uint32_t e = w.items[from + 64u * h + lane];
+        const uint32_t slot = e & 255u, pr = e >> 8;
+        // (i, j) = (0,1) (2,3) (1,2) (0,2) (1,3) (0,3): table j - i - 1
+        const uint32_t i = (0x010120u >> (4u * pr)) & 15u, j = (0x332231u >> (4u * pr)) & 15u;
+        const uint64_t q = w.rd[slot];
+        const uint32_t A = w.st[slot] & 7u;
+        const bool second = A != PA;
+        const uint32_t kb = 2u * A, amask = (1u << kb) - 1u, n_codes1 = (1u << (2u * kb)) + 1u;
+        const uint32_t ai = (uint32_t)(q >> (i * kb)) & amask, aj = (uint32_t)(q >> (j * kb)) & amask;
+        const uint32_t t = j - i - 1u;
+        tp[h] = reinterpret_cast<const TableEntry2*>((second ? p.pair_jump_s : p.pair_jump) + t * n_codes1 + (ai | (aj << kb)));
+        const uint32_t r0 = second ? p.pair_row_off_s[0] : p.pair_row_off[0], r1 = second ? p.pair_row_off_s[1] : p.pair_row_off[1],
+                       r2 = second ? p.pair_row_off_s[2] : p.pair_row_off[2];
+        roff[h] = t == 0u ? r0 : (t == 1u ? r1 : r2);
+        tag[h] = slot | ((i * A) << 8);
+      }
+    }
+    TableEntry2 te[2] = {{0u, 0u}, {0u, 0u}};
+    if (tp[0]) te[0] = *tp[0];
+    if (tp[1]) te[1] = *tp[1];
+#pragma unroll
+    for (uint32_t h = 0; h < 2u; ++h) {
+      if (tp[h]) {
+        lo[h] = te[h].lo + roff[h];
+        n_rows[h] = te[h].hi - te[h].lo;
+        ++c_lookups;
+        c_cands += n_rows[h];
+      }
+    }
+    // a key of a repeat family can have hundreds of rows: the whole wave verifies those, one item after the other
+    for (uint32_t h = 0; h < 2u; ++h) {
+      uint64_t wide_m = __ballot(n_rows[h] > kSeedRowsPerItem);
+      while (wide_m) {
+        const int src = __ffsll((long long)wide_m) - 1;
+        wide_m &= wide_m - 1ull;
+        const uint32_t w_lo = __shfl(lo[h], src, 64), w_n = __shfl(n_rows[h], src, 64), w_tag = __shfl(tag[h], src, 64);
+        for (uint32_t x = lane; x < w_n; x += 64u) verify_one(p.pair_rows[w_lo + x], w_tag & 255u, w_tag >> 8);
+      }
+      push_rows(lo[h], n_rows[h] > kSeedRowsPerItem ? 0u : n_rows[h], tag[h]);
+    }
+  };
+
+  for (uint32_t wc = blockIdx.x * 4u + wv; wc < n_chunks; wc += gridDim.x * 4u) {
+    const uint32_t sgi = wc % in_nseg, depth = wc / in_nseg;
+    const uint32_t count = p.idx_in ? p.in_count[sgi] : p.n_total;
+    // ---- the wave's 256 reads into its LDS region (RAP:543-554: which of them this pass's FASTA holds) ----
+    uint32_t scan_m = 0;  // bit u: my read u has no anchors that fit (scan)
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; ++u) {
+      const uint32_t slot = lane + 64u * u, t = depth * kPairReads + slot;
+      const bool active = t < count;
+      uint32_t r = 0, L0 = 0;
+      uint64_t rd = 0;
+      if (active) {
+        r = p.idx_in ? p.idx_in[(size_t)sgi * p.in_seg_cap + t] : t;
+        L0 = p.lens[r];
+        rd = p.reads[r];
+      }
+      const bool eligible = active && (int32_t)L0 >= p.min_len && (int32_t)L0 <= p.max_len;
+      const int32_t L = (int32_t)L0 - p.trim5 - p.trim3;
+      if (eligible && p.count_processed) ++c_processed;
+      const bool searching = eligible && L > p.max_mm_seed;
+      const int32_t R = min(L, p.seed_len);
+      uint32_t A = 0u;
+      if (searching) {
+        if (R >= (int32_t)(4u * PA)) A = PA;
+        else if (p.pair_jump_s && R >= (int32_t)(4u * (PA - 1u))) A = PA - 1u;
+      }
+      const bool scan = searching && A == 0u;
+      scan_m |= scan ? 1u << u : 0u;
+      w.rd[slot] = rd >> (2 * p.trim5);
+      w.best[slot] = ~0ull;
+      w.len[slot] = (uint8_t)(searching ? L : 0);
+      w.st[slot] = (uint8_t)(A | (scan ? 0x40u : 0u) | (active ? 0x80u : 0u));
+    }
+    wave_lds_sync();
+    // ---- reads too short for anchors (fewer than 4 x 3 seed bases: under 15 nt): every text position, by the wave ----
+    for (uint32_t u = 0; u < 4u; ++u) {
+      uint64_t sm = __ballot((scan_m >> u) & 1u);
+      while (sm) {
+        const int src = __ffsll((long long)sm) - 1;
+        sm &= sm - 1ull;
+        const uint32_t slot = (uint32_t)src + 64u * u;
+        for (uint32_t x = lane; x <= p.n; x += 64u) verify_one(p.sa[x], slot, 0u);
+        c_cands += lane == 0u ? p.n + 1u : 0u;
+      }
+    }
+    // ---- three rounds: pair (0,1); (2,3) for best > 0 mismatches; the other four for best > 1 ----
+    const uint32_t dbg_rounds = p.wstop >= 1000u ? p.wstop - 1000u : 3u;  // (TEMPORARY timing knob: rounds run; results wrong below 3)
+    for (uint32_t round = 0; round < dbg_rounds; ++round) {
+      const uint32_t pr_lo = round < 2u ? round : 2u, pr_hi = round < 2u ? round + 1u : 6u;
+      uint32_t n_it = 0;
+      wave_lds_sync();
+      for (uint32_t pr = pr_lo; pr < pr_hi; ++pr) {
+        for (uint32_t u = 0; u <= 4u; ++u) {  // (the last trip of the last pair only works off what is left)
+          if (u < 4u) {
+            const uint32_t slot = lane + 64u * u;
+            const bool open = w.len[slot] != 0u && (w.st[slot] & 7u) != 0u && (uint32_t)(w.best[slot] >> 56) >= round;
+            const uint64_t mask = __ballot(open);
+            if (open) w.items[n_it + mbcnt(mask)] = (uint16_t)(slot | (pr << 8));
+            n_it += (uint32_t)__popcll(mask);
+          }
+          if (n_it >= 128u || (u == 4u && pr + 1u == pr_hi && n_it)) {
+            const uint32_t m = min(n_it, 128u);
+            n_it -= m;
+            run_items(n_it, m);
+          }
+        }
+      }
+      if (rpend) {
+        verify_rows(0u, rpend);
+        rpend = 0u;
+      }
+    }
+    wave_lds_sync();
+    // ---- the claim, outputs, survivors (RAP:341-345) ----
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; ++u) {
+      const uint32_t slot = lane + 64u * u;
+      const bool active = (w.st[slot] & 0x80u) != 0u;
+      const unsigned long long key = w.best[slot];
+      const bool aligned = active && key != ~0ull;
+      // (the read's index again from the list: 1 KB of LDS per wave less = a sixth workgroup per CU)
+      const uint32_t t = depth * kPairReads + slot;
+      const uint32_t r = active ? (p.idx_in ? p.idx_in[(size_t)sgi * p.in_seg_cap + t] : t) : 0u;
+      if (aligned) {
+        ++c_aligned;
+        uint32_t ref, pos;
+        locate_entry(segs, (uint32_t)(key >> 24), (uint32_t)(key >> 8) & 0xFFFFu, (uint32_t)key & 0xFFu, ref, pos);
+        const uint32_t mm = (uint32_t)(key >> 56);
+        if (p.packed) {
+          p.packed[r] = pack_assignment(p.pass_index, ref, pos, mm);
+        } else {
+          p.pass_id[r] = (int8_t)p.pass_index;
+          p.ref_id[r] = (int32_t)ref;
+          p.pos[r] = (int32_t)pos;
+          p.mm[r] = (uint8_t)mm;
+        }
+      } else if (active && !p.idx_out) {
+        if (p.packed) {
+          p.packed[r] = 0u;
+        } else {
+          p.pass_id[r] = (int8_t)-1;
+          p.ref_id[r] = -1;
+          p.pos[r] = -1;
+          p.mm[r] = 0;
+        }
+      }
+      if (p.idx_out) {
+        const bool survive = active && !aligned;
+        const uint64_t mask = __ballot(survive);
+        if (mask) {
+          uint32_t wbase = 0;
+          if (lane == 0) wbase = atomicAdd(&ctl[0], (uint32_t)__popcll(mask));
+          wbase = __shfl(wbase, 0, 64);
+          if (survive) p.idx_out[(size_t)blockIdx.x * p.out_seg_cap + wbase + mbcnt(mask)] = r;
+        }
+      }
+    }
+    wave_lds_sync();  // (the next trip overwrites the region)
+  }
+  const uint64_t t_processed = wave_sum(c_processed), t_aligned = wave_sum(c_aligned);
+  const uint64_t t_cands = wave_sum(c_cands), t_lookups = wave_sum(c_lookups);
+  if (lane == 0) {
+    if (t_processed) atomicAdd(&wg_cnt[0], (unsigned long long)t_processed);
+    if (t_aligned) atomicAdd(&wg_cnt[1], (unsigned long long)t_aligned);
+    if (t_cands) atomicAdd(&wg_cnt[3], (unsigned long long)t_cands);
+    if (t_lookups) atomicAdd(&wg_cnt[4], (unsigned long long)t_lookups);
+  }
+  __syncthreads();
+  if (tid < 5u && wg_cnt[tid]) atomicAdd((unsigned long long*)&p.counters[tid], wg_cnt[tid]);
+  if (p.idx_out && tid == 0) p.out_count[blockIdx.x] = ctl[0];
+}
+
+uint32_t pair_wave_lds_total() { return kPairSharedWords * 4u + (kSeedThreads / 64u) * pair_wave_lds_bytes(); }
+
+hipError_t launch_pair_wave(const MatchParams& p, uint32_t grid, hipStream_t stream) {
+  hipLaunchKernelGGL(pair_wave_kernel, dim3(grid), dim3(kSeedThreads), pair_wave_lds_total(), stream, p);
+  return hipGetLastError();
+}
+
 // mrg_pack_assignments: the four output arrays as one word per read (include/mirge_amd.h); four reads per lane
 __global__ void __launch_bounds__(256) pack_assignments_kernel(const int8_t* __restrict__ pass_id, const int32_t* __restrict__ ref_id,
                                                                const int32_t* __restrict__ pos, const uint8_t* __restrict__ mm, uint64_t n,

@@ -6,9 +6,10 @@
 // Why: csrc/fastq.cpp does this on the host at 85 M reads/s on the GPU box's 256 cores
 // (profiles/r03_ingest_scale.json) -- 1.2 s for what the cascade annotates in 6 ms.  Here a block of text
 // is one upload and three kernels; the packed reads never exist on the host.
-// Scope: strict four-line records ('\n' or "\r\n", last newline optional), `-ad none` and `-ad +N`;
-// anything else (blank lines between records, an adapter SEQUENCE: cutadapt's alignment) is reported
-// (status != 0) or not offered here, and the caller takes the host parser, which also words the errors.
+// Scope: strict four-line records ('\n' or "\r\n", last newline optional), `-ad none`, `-ad +N` and (round 4)
+// adapter SEQUENCES (`-ad illumina`, the reference's own usage example, parseArgument.py:29: cutadapt's 3'
+// search, one thread per read); anything else (blank lines between records) is reported (status != 0) and
+// the caller takes the host parser, which also words the errors.
 // Rules restated exactly as csrc/fastq.cpp / oracle/ingest.py state them:
 //   quality  walk from the 3' end accumulating (cutoff - q), stop when the sum turns negative, cut at the
 //            position of the maximum (cutadapt's / BWA's rule);
@@ -31,11 +32,102 @@ struct IsNewline {
 
 constexpr uint32_t kIngestThreads = 256;
 
+__device__ __forceinline__ char upper_char(char c) { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
+
+// cutadapt's 3' adapter search (`-a ADAPTER`, error rate 0.12, minimum overlap 3: trim_file.py:30-41) on one
+// read: csrc/fastq.cpp's locate_adapter_3p restated cell for cell -- an exact occurrence first, else the
+// semi-global alignment (the adapter from its first base, free start in the read, the adapter may run off the
+// read's 3' end) column by column with Ukkonen's band, the candidate rule "more matches, then fewer errors",
+// and the last column's rows examined as the original examines them.  rd[0, n): the read (any case).
+// Returns true and where the read is cut / how many bases matched.
+__device__ bool locate_adapter_dev(const char* ad, int m, int k, const char* rd, int n, int& read_start, int& n_matches) {
+  if (m == 0) return false;
+  if (n >= m) {
+    for (int p0 = 0; p0 + m <= n; ++p0) {
+      int i = 0;
+      while (i < m && upper_char(rd[p0 + i]) == ad[i]) ++i;
+      if (i == m) {
+        read_start = p0;
+        n_matches = m;
+        return true;
+      }
+    }
+  }
+  constexpr double kRate = 0.12;
+  const int min_overlap = m < 3 ? m : 3;
+  short cost[kAdapterMaxLen + 1], mat[kAdapterMaxLen + 1], org[kAdapterMaxLen + 1];
+  for (int i = 0; i <= m; ++i) {
+    cost[i] = (short)i;
+    mat[i] = 0;
+    org[i] = 0;
+  }
+  int best_cost = m + n, best_matches = 0, best_origin = 0;
+  auto consider = [&](int i) -> bool {
+    const int length = i + (org[i] < 0 ? (int)org[i] : 0);
+    const int c = cost[i], mt = mat[i];
+    if (length >= min_overlap && (double)c <= (double)length * kRate && (mt > best_matches || (mt == best_matches && c < best_cost))) {
+      best_matches = mt;
+      best_cost = c;
+      best_origin = org[i];
+      return true;
+    }
+    return false;
+  };
+  int last = m < k + 1 ? m : k + 1;
+  bool exact_full = false;
+  for (int j = 1; j <= n && !exact_full; ++j) {
+    int d_cost = cost[0], d_mat = mat[0], d_org = org[0];
+    org[0] = (short)j;
+    const char c = upper_char(rd[j - 1]);
+    for (int i = 1; i <= last; ++i) {
+      int c_cost, c_mat, c_org;
+      if (ad[i - 1] == c) {
+        c_cost = d_cost;
+        c_mat = d_mat + 1;
+        c_org = d_org;
+      } else {
+        const int c_diag = d_cost + 1, c_del = cost[i] + 1, c_ins = cost[i - 1] + 1;
+        if (c_diag <= c_del && c_diag <= c_ins) {
+          c_cost = c_diag;
+          c_mat = d_mat;
+          c_org = d_org;
+        } else if (c_ins <= c_del) {
+          c_cost = c_ins;
+          c_mat = mat[i - 1];
+          c_org = org[i - 1];
+        } else {
+          c_cost = c_del;
+          c_mat = mat[i];
+          c_org = org[i];
+        }
+      }
+      d_cost = cost[i];
+      d_mat = mat[i];
+      d_org = org[i];
+      cost[i] = (short)c_cost;
+      mat[i] = (short)c_mat;
+      org[i] = (short)c_org;
+    }
+    while (last >= 0 && cost[last] > k) --last;
+    if (last < m) {
+      ++last;
+    } else if (consider(m) && best_cost == 0 && best_matches == m) {
+      exact_full = true;
+    }
+  }
+  if (!exact_full)
+    for (int i = 0; i <= m; ++i) consider(i);
+  if (best_cost == m + n) return false;
+  read_start = best_origin >= 0 ? best_origin : 0;
+  n_matches = best_matches;
+  return true;
+}
+
 // per record: where its trimmed read starts in the text and how long it is (0 = dropped)
 __global__ void __launch_bounds__(kIngestThreads) ingest_trim_kernel(const char* __restrict__ text, uint64_t n_bytes,
                                                                       const uint32_t* __restrict__ nl, uint32_t n_nl, uint32_t n_records,
                                                                       int32_t phred, int32_t cutoff, int32_t min_len, int32_t cut,
-                                                                      uint32_t max_packed, uint32_t* __restrict__ rec_start,
+                                                                      const AdapterSet ads, uint32_t max_packed, uint32_t* __restrict__ rec_start,
                                                                       uint32_t* __restrict__ rec_len, uint32_t* __restrict__ keep,
                                                                       uint32_t* __restrict__ info /* status, bad record, n_long, max_len */) {
   const uint32_t r = blockIdx.x * kIngestThreads + threadIdx.x;
@@ -74,6 +166,21 @@ __global__ void __launch_bounds__(kIngestThreads) ingest_trim_kernel(const char*
     else if (cut < 0) b = b > (uint32_t)(-cut) ? b - (uint32_t)(-cut) : 0u;
     len = b - a;
     start = s1 + a;
+    // adapter sequences (trim_file.py:34-41; fastq.cpp: apply_trim_spec): the adapter with the most matched bases
+    // decides, the first one on ties; the read is cut where its match begins
+    if (ads.n) {
+      bool found = false;
+      int best_start = 0, best_matches = 0;
+      for (uint32_t q = 0; q < ads.n; ++q) {
+        int rs = 0, nm = 0;
+        if (locate_adapter_dev(ads.seq[q], (int)ads.len[q], (int)ads.k[q], text + start, (int)len, rs, nm) && (!found || nm > best_matches)) {
+          found = true;
+          best_start = rs;
+          best_matches = nm;
+        }
+      }
+      if (found) len = (uint32_t)best_start;
+    }
   }
   uint32_t k = (!bad && (int32_t)len >= min_len) ? 1u : 0u;
   if (k && len > max_packed) {  // kept by the rules, too long for the words the caller offers
@@ -137,8 +244,8 @@ struct Scratch {
 }  // namespace
 
 hipError_t fastq_parse_device(const char* d_text, uint64_t n_bytes, int32_t phred, int32_t cutoff, int32_t min_len, int32_t cut,
-                              uint32_t W, uint64_t cap, uint64_t* d_words, uint8_t* d_lens, uint64_t* d_nmask, uint64_t* h_info,
-                              hipStream_t stream) {
+                              const AdapterSet& ads, uint32_t W, uint64_t cap, uint64_t* d_words, uint8_t* d_lens, uint64_t* d_nmask,
+                              uint64_t* h_info, hipStream_t stream) {
   // h_info: records, kept (packed), too long, max_len, has_n, status (0 ok; 1-3 ill-formed record, 4 line count not a
   // multiple of four, 5 more kept reads than `cap`), first bad record
   for (int i = 0; i < 7; ++i) h_info[i] = 0;
@@ -197,7 +304,7 @@ hipError_t fastq_parse_device(const char* d_text, uint64_t n_bytes, int32_t phre
   }
   const uint32_t grid = (n_records + kIngestThreads - 1) / kIngestThreads;
   hipLaunchKernelGGL(ingest_trim_kernel, dim3(grid), dim3(kIngestThreads), 0, stream, d_text, n_bytes, (const uint32_t*)s_nl.p, n_nl,
-                     n_records, phred, cutoff, min_len, cut, 32u * W, rec_start, rec_len, keep, (uint32_t*)s_info.p);
+                     n_records, phred, cutoff, min_len, cut, ads, 32u * W, rec_start, rec_len, keep, (uint32_t*)s_info.p);
   CK(hipGetLastError());
   // ---- output positions: exclusive prefix of the keep flags ----
   size_t scan_bytes = 0;

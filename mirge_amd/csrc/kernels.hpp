@@ -320,9 +320,17 @@ hipError_t launch_seed(const SeedParams& p, uint32_t grid, hipStream_t stream);
 
 // ingest.hip: FASTQ text (whole four-line records) on the device -> packed reads.  h_info[7]: records, kept
 // (packed), kept but longer than 32 W bases, longest packed read, has N, status (0 ok), first bad record.
+// ads: the adapter sequences of `-ad <sequence>[,<sequence>...]` (upper case; n = 0: none), searched after the quality trim
+// and the cutter as cutadapt does (error rate 0.12, k = floor(0.12 x length) errors in the band, minimum overlap 3)
+constexpr uint32_t kAdapterMaxLen = 64u, kAdapterMax = 4u;
+struct AdapterSet {
+  uint32_t n;
+  uint8_t len[kAdapterMax], k[kAdapterMax];
+  char seq[kAdapterMax][kAdapterMaxLen];
+};
 hipError_t fastq_parse_device(const char* d_text, uint64_t n_bytes, int32_t phred, int32_t cutoff, int32_t min_len, int32_t cut,
-                              uint32_t W, uint64_t cap, uint64_t* d_words, uint8_t* d_lens, uint64_t* d_nmask, uint64_t* h_info,
-                              hipStream_t stream);
+                              const AdapterSet& ads, uint32_t W, uint64_t cap, uint64_t* d_words, uint8_t* d_lens, uint64_t* d_nmask,
+                              uint64_t* h_info, hipStream_t stream);
 // ingest.hip: the compact wire form of a host-resident collapsed read set (mrg_expand_compact) -> the
 // arrays of the cascade and the tally.  Run r: reads [end[r-1], end[r]) have len[r] bases, 2 len[r] bits each
 // from word base[r] of the bit stream.
@@ -421,6 +429,10 @@ hipError_t launch_match(const MatchParams& p, uint32_t words_per_read, int lds_m
 constexpr uint32_t kStratumCtlBytes = 16u + 1024u * 8u + 5u * 8u;
 hipError_t launch_stratum(const MatchParams& p, uint32_t words_per_read, bool lds_text, uint32_t grid,
                           uint32_t lds_bytes, hipStream_t stream);
+// dict.hip: pair_wave_kernel, the anchor-pair search of a 2-mismatch pass for one-word reads without N, every wave
+// on its own with items and rows compacted over the wave (workgroups of kSeedThreads; chunks of 1024 list entries)
+uint32_t pair_wave_lds_total();
+hipError_t launch_pair_wave(const MatchParams& p, uint32_t grid, hipStream_t stream);
 hipError_t launch_tally(const TallyParams& p, bool lds_hist, uint32_t grid,
                         uint32_t lds_bytes, hipStream_t stream);
 // collapse.hip: raw reads -> unique reads + per-sample counts + length histogram

@@ -285,7 +285,7 @@ class Engine:
                      candidates=int(s.candidates), lookups=int(s.lookups), ms=float(s.ms),
                      lds_bytes=int(s.lds_bytes), lds_mode=int(s.lds_mode), group=int(s.group),
                      n_launches=int(s.n_launches), kbits_log2=int(s.kbits_log2),
-                     pair_anchor=int(s.pair_anchor), ms_rest=float(s.ms_rest))
+                     pair_anchor=int(s.pair_anchor), ms_rest=float(s.ms_rest), variant=int(s.variant))
                 for s in st]
 
     def counts_len(self, n_mirna, n_samples, n_pass):
@@ -504,7 +504,7 @@ class Engine:
                       candidates=int(s.candidates), lookups=int(s.lookups), ms=float(s.ms),
                      lds_bytes=int(s.lds_bytes), lds_mode=int(s.lds_mode), group=int(s.group),
                       n_launches=int(s.n_launches), kbits_log2=int(s.kbits_log2),
-                     pair_anchor=int(s.pair_anchor), ms_rest=float(s.ms_rest))
+                     pair_anchor=int(s.pair_anchor), ms_rest=float(s.ms_rest), variant=int(s.variant))
                  for s in st]
         return dict(pass_id=pass_id, ref_id=ref_id, pos=pos, mm=mm, stats=stats, counts=counts)
 

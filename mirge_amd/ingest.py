@@ -78,18 +78,23 @@ def load_fastq_device(engine, path, adapter="none", qual_cutoff=QUAL_CUTOFF, min
                       read_threads=8, inflate_threads=None):
     """load_fastq with the record splitting, trimming and packing ON THE DEVICE (mrg_fastq_parse_device):
     the host reads the file into a pinned buffer (plain text: `read_threads` parallel preads; gzip: the
-    parallel inflate of mrg_gz_open with `inflate_threads` workers, default one per core), cuts it at record boundaries (mrg_fastq_block_cut) and uploads text blocks.  `-ad none`
-    and `-ad +N` only.  Returns dict(words int64 [W, n], lens uint8 [n], nmask int64 [W, n] | None -- DEVICE
+    parallel inflate of mrg_gz_open with `inflate_threads` workers, default one per core), cuts it at record boundaries (mrg_fastq_block_cut) and uploads text blocks.  `-ad none`,
+    `-ad +N` and adapter sequences (`-ad illumina`: cutadapt's 3' search, one thread per read).  Returns dict(words int64 [W, n], lens uint8 [n], nmask int64 [W, n] | None -- DEVICE
     tensors, reads in file order --, total, kept, packed, phred, max_len, long_reads=[])."""
     from concurrent.futures import ThreadPoolExecutor
     import torch
     ad = resolve_adapter(adapter)
+    cut, ad_seqs = 0, None
     if ad in (None, "", "none"):
-        cut = 0
+        pass
     elif ad.startswith("+"):
         cut = int(ad)
     else:
-        raise DeviceIngestUnsupported("adapter sequences are trimmed on the host (cutadapt's alignment)")
+        # adapter sequences: cutadapt's 3' search, one thread per read (mrg_fastq_parse_device_ad)
+        seqs = [a for a in ad.upper().split(",") if a]
+        if len(seqs) > 4 or any(len(a) > 64 for a in seqs):
+            raise DeviceIngestUnsupported("more than 4 adapters, or an adapter of more than 64 bases")
+        ad_seqs = ",".join(seqs).encode()
     lib = engine._lib
     dev = engine.device
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -176,8 +181,9 @@ def load_fastq_device(engine, path, adapter="none", qual_cutoff=QUAL_CUTOFF, min
                 words = torch.empty((W, cap), dtype=torch.int64, device=dev)
                 lens = torch.empty(cap, dtype=torch.uint8, device=dev)
                 nmask = torch.empty((W, cap), dtype=torch.int64, device=dev)
-                check(lib.mrg_fastq_parse_device(engine._h, d_text.data_ptr(), n_blk, base, int(qual_cutoff), int(min_len), cut, W, cap,
-                                                 words.data_ptr(), lens.data_ptr(), nmask.data_ptr(), C.byref(info), stream))
+                check(lib.mrg_fastq_parse_device_ad(engine._h, d_text.data_ptr(), n_blk, base, int(qual_cutoff), int(min_len), cut,
+                                                    ad_seqs, W, cap, words.data_ptr(), lens.data_ptr(), nmask.data_ptr(),
+                                                    C.byref(info), stream))
                 if info.status:
                     raise DeviceIngestUnsupported("record %d of a block is not a plain four-line record (status %d)"
                                                   % (info.bad_record, info.status))

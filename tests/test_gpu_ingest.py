@@ -1,5 +1,5 @@
 """GPU parity (-m gpu) of the device-side FASTQ ingest (csrc/ingest.hip, mrg_fastq_parse_device): record
-splitting, the 3' quality rule, the `-ad +N` cutter, the 16-nt minimum and the 2-bit packing of
+splitting, the 3' quality rule, the `-ad +N` cutter, adapter sequences (cutadapt's 3' search), the 16-nt minimum and the 2-bit packing of
 trim_file.py:24-66,89-134 / quantReads.py:4-24 on raw text blocks.  Checked against the oracle's Python
 restatement (oracle/ingest.py) and, array for array, against the host parser (csrc/fastq.cpp)."""
 import gzip
@@ -20,12 +20,25 @@ def engine(native_lib):
     return Engine(0)
 
 
-def make_fastq(path, rng, n=6000, max_len=50, phred=33, crlf=False, final_newline=True, long_reads=0):
+ILLUMINA = "TGGAATTCTCGGGTGCCAAGGAACTCCAG"   # `-ad illumina` (__main__.py:123-127)
+
+
+def make_fastq(path, rng, n=6000, max_len=50, phred=33, crlf=False, final_newline=True, long_reads=0, adapters=()):
     eol = "\r\n" if crlf else "\n"
     recs = []
     for i in range(n):
         L = int(rng.integers(14, max_len + 1))
         seq = "".join("ACGTN"[c] for c in rng.choice(5, L, p=[0.245, 0.245, 0.245, 0.245, 0.02]))
+        if adapters and rng.random() < 0.8:
+            # an insert followed by (a prefix of) an adapter, sometimes with an error in it, sometimes run off the 3' end
+            ad = list(adapters[int(rng.integers(0, len(adapters)))])
+            kind = rng.random()
+            if kind < 0.3:
+                k = int(rng.integers(0, len(ad)))
+                ad[k] = "ACGT"[("ACGT".index(ad[k]) + 1) % 4] if kind < 0.2 else ""   # substitution / deletion
+            ins = int(rng.integers(0, 36))
+            seq = (seq[:ins] + "".join(ad))[:max(L, int(rng.integers(14, max_len + 1)))]
+            L = len(seq)
         if rng.random() < 0.1:
             seq = seq.lower()
         q = rng.integers(20, 41, L)
@@ -76,6 +89,15 @@ def test_device_ingest_equals_host_and_oracle(engine, tmp_path):
         make_fastq(p, rng, **kw)
         dev = same_as_host_and_oracle(engine, p, adapter)
         assert 500 < dev["kept"] < dev["total"]
+    # adapter sequences (`-ad illumina`, a list of two): cutadapt's 3' search, one thread per read
+    for name, adapter, ads in (("ill.fastq", "illumina", (ILLUMINA,)), ("two.fastq", "ACGTTGCAAGGCTTAC,TGGAATTCTCGG", ("ACGTTGCAAGGCTTAC", "TGGAATTCTCGG")),
+                               ("ill.fastq.gz", "illumina", (ILLUMINA,))):
+        p = str(tmp_path / name)
+        make_fastq(p, rng, adapters=ads)
+        dev = same_as_host_and_oracle(engine, p, adapter)
+        assert 500 < dev["kept"] < dev["total"]
+        untrimmed = ingest.load_fastq(p, adapter="none")
+        assert untrimmed["kept"] > dev["kept"] + 500          # the adapters did cut reads below the minimum length
     # many small blocks: the tail behind the last record boundary is carried into the next block
     p = str(tmp_path / "plain.fastq")
     a = same_as_host_and_oracle(engine, p, "none", block_bytes=64 << 10, read_threads=3)
@@ -84,13 +106,13 @@ def test_device_ingest_equals_host_and_oracle(engine, tmp_path):
 
 
 def test_what_the_device_parser_refuses(engine, tmp_path):
-    """An adapter sequence, blank lines between records, a missing '+' line, reads beyond 128 nt: the
-    device parser says so (the caller then takes the host parser)."""
+    """An adapter of more than 64 bases, blank lines between records, a missing '+' line, reads beyond 128 nt:
+    the device parser says so (the caller then takes the host parser)."""
     rng = np.random.default_rng(32)
     p = str(tmp_path / "ok.fastq")
     make_fastq(p, rng, n=200)
     with pytest.raises(ingest.DeviceIngestUnsupported):
-        ingest.load_fastq_device(engine, p, adapter="illumina")
+        ingest.load_fastq_device(engine, p, adapter="ACGT" * 17)
     text = open(p).read()
     blank = str(tmp_path / "blank.fastq")
     recs = text.split("\n@r")
