@@ -104,10 +104,10 @@ def kernel_name(W, table_row, s, n_bases):
     if s["lds_mode"] == 11:
         return "mrg::pair_wave_kernel"
     if s["lds_mode"] in (8, 9):
-        v = s.get("variant", 0)
+        v, fat = s.get("variant", 0) & 3, "true" if s.get("variant", 0) & 4 else "false"
         if v:
             return "mrg::wave_seed_kernel<%s>" % {(8, 1): "false, 8", (9, 1): "true, 6", (8, 2): "false, 6", (9, 2): "true, 5"}[(s["lds_mode"], v)]
-        return "mrg::seed_kernel<false, 8>" if s["lds_mode"] == 8 else "mrg::seed_kernel<true, 6>"
+        return "mrg::seed_kernel<%s, %s>" % ("false, 8" if s["lds_mode"] == 8 else "true, 6", fat)
     has_ctx = n_bases >= (1 << 20) and s["lds_mode"] in (0, 1)
     return "mrg::match_kernel<%d, %s, %s, %s, %s>" % (
         W, {0: "false, false", 1: "true, false", 2: "true, true", 3: "false, true"}[s["lds_mode"]],

@@ -264,7 +264,9 @@ typedef struct mrg_pass_stats {
   uint32_t variant;    /* which instantiation behind lds_mode 8 / 9 (round 4): 0 = seed_kernel (tiles of 256 reads,
                           three barriers per tile), 1 = wave_seed_kernel<false, 8> / <true, 6> (every wave on its
                           own: a read with nothing left to look up is finished on the spot, the others are parked
-                          and worked off 64 at a time), 2 = wave_seed_kernel<false, 6> / <true, 5> (more registers).
+                          and worked off 64 at a time), 2 = wave_seed_kernel<false, 6> / <true, 5> (more registers);
+                          + 4 = the launch's input list carried its reads (16-byte entries written by the seed
+                          launch in front of it: seed_kernel<.., .., true>).
                           lds_mode 11 (round 4) = pair_wave_kernel: the anchor-pair search of a 2-mismatch pass for
                           one-word reads without N, items and rows compacted over the wave */
   uint32_t reserved;

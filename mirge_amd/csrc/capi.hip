@@ -703,8 +703,10 @@ int mrg_ctx_release_scratch(mrg_ctx* ctx) {
 //            workgroup's segment holds every read of its chunks, 256, 1024 or 4096 reads each; C parks
 //            the one-word reads of a split batch while the other reads run their cascade)
 //            [segment counts A, B, C: kMaxSegments u32 each][stats: MRG_MAX_PASSES * 5 u64]
+// (16 bytes per entry: the seed launches of a one-word batch write lists that carry their reads -- index, length, read --;
+// exact_dict_kernel and the FM kernels keep 4-byte index lists in the same buffers)
 static uint64_t ws_idx_bytes(uint64_t n) {
-  return (((n + mrg::kListSlack) * 4 + 255) / 256) * 256;
+  return (((n + mrg::kListSlack) * 16 + 255) / 256) * 256;
 }
 static const uint64_t kWsCountsBytes = 3 * mrg::kMaxSegments * 4;
 static const uint64_t kWsStatsBytes = MRG_MAX_PASSES * kStatsPerPass * 8;
@@ -861,8 +863,22 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   };
   int cur_list = 0;        // which list buffer holds the newest survivor list
   bool have_list = false;  // false: the next pass that runs reads the identity list of all reads
+  bool list_fat = false;   // the newest list carries its reads (16-byte entries, written by a seed launch or pair_wave_kernel)
+  bool out_init = false;   // the first launch wrote every output (exact_dict_kernel, streaming): later ones write claims only
   int pair0 = 0, pair1 = 1;  // the two buffers the running cascade alternates between
   auto other_list = [&](int cur) { return cur == pair0 ? pair1 : pair0; };
+
+  // exact_dict_kernel and the FM kernels read index lists: a list that carries its reads is thinned into the other buffer
+  // first (the spike-in pass and non-default plans only)
+  auto want_thin_list = [&]() -> int {
+    if (!have_list || !list_fat) return MRG_OK;
+    const int other = other_list(cur_list);
+    HIP_TRY(mrg::launch_list_thin(reinterpret_cast<const uint4*>(idx[cur_list]), idx[other], counts + cur_list * mrg::kMaxSegments,
+                                  counts + other * mrg::kMaxSegments, prev_grid, prev_seg_cap, stream));
+    cur_list = other;
+    list_fat = false;
+    return MRG_OK;
+  };
 
   hipEvent_t* evs = ctx->ev;  // the per-pass events of the cascade that is being issued
   HIP_TRY(hipEventRecord(evs[0], stream));
@@ -916,6 +932,12 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   auto run_single = [&](uint32_t i, int32_t k_first, int32_t k_last, bool first_part, bool last_part, bool by_pairs = false) -> int {
     const mrg_pass_cfg& c = passes[i];
     const DevLib& l = ctx->libs[c.lib];
+    // (pair_wave_kernel reads either list form; everything else launched here reads index lists)
+    const bool pair_wave_route = by_pairs && dict_batch && ctx->pair_impl != 0 && c.max_mm_seed == 2 && ctx->force_lds_mode < 0;
+    if (!pair_wave_route) {
+      const int rc_form = want_thin_list();
+      if (rc_form != MRG_OK) return rc_form;
+    }
     // (the dictionary's key is matched letter for letter: only a pass whose seed covers it may take it)
     if (dict_batch && c.max_mm_seed == 0 && l.dict_slots && c.seed_len >= (int32_t)l.dict_key && ctx->force_lds_mode < 0) {
       // no seed mismatch, one-word reads, a library with an exact-match dictionary: dict.hip
@@ -971,9 +993,11 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       if (n) HIP_TRY(mrg::launch_exact_dict(e, grid, stream));
       ctx->last_launches[i] += 1;
       HIP_TRY(hipEventRecord(evs[i + 1], stream));
+      if (!have_list && n && ((uintptr_t)d_reads % 16 == 0) && ((uintptr_t)d_lens % 4 == 0)) out_init = true;  // (launch_exact_dict: the streaming instantiation)
       if (e.idx_out) {
         cur_list = next_list;
         have_list = true;
+        list_fat = false;
         prev_grid = grid;
         prev_seg_cap = seg_cap;
       }
@@ -1008,6 +1032,8 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     p.in_nseg = prev_grid;
     p.in_seg_cap = prev_seg_cap;
     p.idx_out = (i + 1 < n_pass || !last_part) ? idx[next_list] : nullptr;
+    p.in_stride = list_fat ? 4u : 1u;
+    p.out_init = out_init ? 1u : 0u;
     p.k_first = k_first;
     p.k_last = k_last;
     p.count_processed = first_part ? 1u : 0u;
@@ -1100,7 +1126,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     }
     // one-word reads without N through the anchor pairs: pair_wave_kernel (dict.hip; every wave on its own, items
     // and rows compacted over the wave; nothing staged in LDS but the wave's 256 reads)
-    const bool pair_wave = rows_kernel && by_pairs && dict_batch && ctx->pair_impl != 0;
+    const bool pair_wave = pair_wave_route && rows_kernel;
     if (pair_wave) {
       lds_mode = 0;
       lib_bytes = 0;
@@ -1109,7 +1135,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
                                : rows_kernel ? (uint32_t)((uint64_t)l.nsup * 16 + mrg::kStratumCtlBytes + (use_kbits ? kb_bytes : 0) + lib_bytes)
                                              : (uint32_t)(overhead + lib_bytes);
     const uint32_t lds_bytes = (uint32_t)lib_bytes;
-    const uint32_t per_cu = pair_wave ? std::min<uint32_t>(6u, (160u * 1024u) / lds_total) : ((lds_total * 2u <= 160u * 1024u) ? 2u : 1u);
+    const uint32_t per_cu = pair_wave ? std::min<uint32_t>(5u, (160u * 1024u) / lds_total) : ((lds_total * 2u <= 160u * 1024u) ? 2u : 1u);
     uint32_t grid = (uint32_t)ctx->n_cu * per_cu;
     if (grid > mrg::kMaxSegments) grid = mrg::kMaxSegments;
     grid = scale_grid(grid);
@@ -1135,6 +1161,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     if (p.idx_out) {
       cur_list = next_list;
       have_list = true;
+      list_fat = pair_wave;
       prev_grid = grid;
       prev_seg_cap = seg_cap;
     }
@@ -1306,6 +1333,10 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     fp.nmask = nmask_eff;
     fp.n_total = (uint32_t)n;
     fp.uniform_len = 0u;  // (see run_single)
+    {
+      const int rc_form = want_thin_list();
+      if (rc_form != MRG_OK) return rc_form;
+    }
     const int next_list = have_list ? other_list(cur_list) : pair0;
     fp.idx_in = have_list ? idx[cur_list] : nullptr;
     fp.in_count = counts + cur_list * mrg::kMaxSegments;
@@ -1334,6 +1365,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     if (fp.idx_out) {
       cur_list = next_list;
       have_list = true;
+      list_fat = false;
       prev_grid = grid;
       prev_seg_cap = seg_cap;
     }
@@ -1414,7 +1446,8 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       const int64_t impl = ctx->seed_impl >= 0 ? ctx->seed_impl : (small ? 0 : 2);
       sp.impl = impl ? 1u : 0u;
       sp.wave_regs = impl >= 2 ? (uint32_t)(impl - 1) : 0u;  // 2: more registers, 3: lockstep (experiment), 4: both
-      for (uint32_t q = first; q < end; ++q) ctx->last_variant[q] = sp.impl ? ((sp.wave_regs & 1u) ? 2u : 1u) : 0u;
+      for (uint32_t q = first; q < end; ++q)
+        ctx->last_variant[q] = (sp.impl ? ((sp.wave_regs & 1u) ? 2u : 1u) : 0u) | ((have_list && list_fat) ? 4u : 0u);
     }
     sp.reads_per_lane = 1u;
     sp.item_cap = mrg::kSeedThreads * sp.reads_per_lane * 2u;
@@ -1425,6 +1458,8 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     sp.n_total = (uint32_t)n;
     const int next_list = have_list ? other_list(cur_list) : pair0;
     sp.idx_in = have_list ? idx[cur_list] : nullptr;
+    sp.in_stride = list_fat ? 4u : 1u;
+    sp.out_init = out_init ? 1u : 0u;
     sp.in_count = counts + cur_list * mrg::kMaxSegments;
     sp.in_nseg = prev_grid;
     sp.in_seg_cap = prev_seg_cap;
@@ -1457,6 +1492,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     if (sp.idx_out) {
       cur_list = next_list;
       have_list = true;
+      list_fat = true;
       prev_grid = grid;
       prev_seg_cap = seg_cap;
     }
@@ -1497,6 +1533,8 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     prev_grid = split_grid;
     prev_seg_cap = split_cap;
     for (auto& b : stratum0_done) b = false;
+    list_fat = false;  // (split_kernel writes index lists)
+    out_init = false;
     if (chain == 0) {  // long reads and reads with N: lists in buffers 0 / 1
       pair0 = 0, pair1 = 1, cur_list = 0;
       dict_batch = false;

@@ -489,7 +489,9 @@ __device__ __forceinline__ void verify_seed_row(const uint32_t* ut, const uint4 
 
 // BUCKETS: some unit has seed buckets (the instantiation without them needs fewer registers: WAVES = 8
 // workgroups per CU instead of 6)
-template <bool BUCKETS, int WAVES>
+// FAT: the input list carries its reads (SeedParams::in_stride = 4) -- an instantiation of its own: as a run-time
+// branch of the walk it cost the index-list instantiation 28 more bytes of scratch and 40 % of its speed
+template <bool BUCKETS, int WAVES, bool FAT>
 __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t T = p.reads_per_lane, tile = kSeedThreads * T;
@@ -534,7 +536,10 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
   // so the division is done once)
   uint32_t f_chunk = blockIdx.x, f_sgi = blockIdx.x % in_nseg, f_depth = blockIdx.x / in_nseg;
   const uint32_t f_dsgi = gridDim.x % in_nseg, f_ddepth = gridDim.x / in_nseg;
-  auto fetch_next = [&](uint32_t& r_out) -> bool {
+  // (an index list: the entry two tiles ahead, then the gathers of the tile ahead; a list that carries its reads --
+  // in_stride = 4, SeedParams -- delivers index, length and read in one load: one tile ahead, no gather)
+  constexpr bool fat_in = FAT;
+  auto fetch_next = [&](uint32_t& r_out, uint32_t& L_out, uint64_t& rd_out) -> bool {
     bool act = false;
     r_out = 0;
     if (f_chunk < n_chunks) {
@@ -547,8 +552,19 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
       if (idx_in) {
         typedef const __attribute__((address_space(4))) uint32_t* const_u32_t;  // (written by the launch before this one)
         act = t < ((const_u32_t)(uintptr_t)kp->in_count)[sgi];
-        const uint32_t* seg = idx_in + (size_t)sgi * kp->in_seg_cap + t_base;
-        if (act) r_out = seg[tid];
+        // (entries of in_stride words: 1 = indices, 4 = a list that carries its reads; the index is word 0)
+        if (fat_in) {
+          // a list that carries its reads: the whole entry, one 16-byte load -- the caller's read registers directly
+          if (act) {
+            const uint4 e = reinterpret_cast<const uint4*>(idx_in)[(size_t)sgi * kp->in_seg_cap + t_base + tid];
+            r_out = e.x;
+            L_out = e.y;
+            rd_out = (uint64_t)e.z | ((uint64_t)e.w << 32);
+          }
+        } else {
+          const uint32_t* seg = idx_in + (size_t)sgi * kp->in_seg_cap + t_base;
+          if (act) r_out = seg[tid];
+        }
       } else {
         act = t < kp->n_total;
         r_out = act ? t : 0u;
@@ -571,11 +587,16 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
   // lane 2c / 2c + 1 = the two counters of member c (units in order, members in order) -- two dozen
   // scalar accumulators live across the loop would be spilled
   uint32_t acc_v = 0;
-  bool act_b = fetch_next(r_b);
-  bool act_c = fetch_next(r_c);
-  if (act_b) {
-    L_b = p.lens[r_b];
-    rd_b = p.reads[r_b];
+  uint32_t L_unused = 0;
+  uint64_t rd_unused = 0;
+  bool act_b = fetch_next(r_b, L_b, rd_b);
+  bool act_c = false;
+  if (!fat_in) {
+    act_c = fetch_next(r_c, L_unused, rd_unused);
+    if (act_b) {
+      L_b = p.lens[r_b];
+      rd_b = p.reads[r_b];
+    }
   }
   // The item counters are double-buffered by tile parity: a tile without items has no barrier behind
   // the one that closes phase 1, so a fast wave may already be pushing the NEXT tile's items while a
@@ -586,15 +607,19 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
     const bool active = act_b;
     const uint32_t r = r_b, L0 = active ? L_b : 255u, slot = tid;
     const uint64_t rd = rd_b;
-    act_b = act_c;
-    r_b = r_c;
     L_b = 255u;
     rd_b = 0;
-    if (act_b) {
-      L_b = p.lens[r_b];
-      rd_b = p.reads[r_b];
+    if (fat_in) {
+      act_b = fetch_next(r_b, L_b, rd_b);
+    } else {
+      act_b = act_c;
+      r_b = r_c;
+      if (act_b) {
+        L_b = p.lens[r_b];
+        rd_b = p.reads[r_b];
+      }
+      act_c = fetch_next(r_c, L_unused, rd_unused);
     }
-    act_c = fetch_next(r_c);
     // ================= phase 1: the tile's reads into LDS, and their items =================
     // A seed of exactly bucket_k bases in a unit with seed buckets is answered right here: the first four
     // rows of both seeds' buckets are requested together (one 128-byte line per seed, eight loads in
@@ -951,13 +976,13 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
       }
       if (p.packed) {
         if (claimed) p.packed[r] = pack_assignment(cp, o_ref, o_pos, (uint32_t)((key >> 48) & 255u));
-        else if (active && !p.idx_out) p.packed[r] = 0u;
+        else if (active && !p.idx_out && !p.out_init) p.packed[r] = 0u;
       } else if (claimed) {
         p.pass_id[r] = (int8_t)cp;
         p.ref_id[r] = (int32_t)o_ref;
         p.pos[r] = (int32_t)o_pos;
         p.mm[r] = (uint8_t)((key >> 48) & 255u);
-      } else if (active && !p.idx_out) {
+      } else if (active && !p.idx_out && !p.out_init) {
         p.pass_id[r] = (int8_t)-1;
         p.ref_id[r] = -1;
         p.pos[r] = -1;
@@ -970,7 +995,14 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
           uint32_t wbase = 0;
           if (lane == 0) wbase = atomicAdd(&l.ctl[0], (uint32_t)__popcll(mask));
           wbase = __shfl(wbase, 0, 64);
-          if (survive) p.idx_out[(size_t)blockIdx.x * p.out_seg_cap + wbase + mbcnt(mask)] = r;
+          // (the survivor takes its read along: the next launch streams 16-byte entries instead of gathering; from the
+          // lane's own LDS slot -- kept in registers across phase 2 they were spilled, and the launch took 1.87 ms
+          // instead of 1.32)
+          if (survive) {
+            const unsigned long long own = l.srd[slot];
+            reinterpret_cast<uint4*>(p.idx_out)[(size_t)blockIdx.x * p.out_seg_cap + wbase + mbcnt(mask)] =
+                make_uint4(r, (uint32_t)l.sL0[slot], (uint32_t)own, (uint32_t)(own >> 32));
+          }
         }
       }
     }
@@ -1187,7 +1219,8 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
   // + grid and the list entry of chunk + 2 grid are in flight while a chunk is worked on ----
   uint32_t f_chunk = blockIdx.x, f_sgi = blockIdx.x % in_nseg, f_depth = blockIdx.x / in_nseg;
   const uint32_t f_dsgi = gridDim.x % in_nseg, f_ddepth = gridDim.x / in_nseg;
-  auto fetch_next = [&](uint32_t& r_out) __attribute__((always_inline)) -> bool {
+  const bool fat_in = p.idx_in && p.in_stride == 4u;  // (seed_kernel's walk: index list two chunks deep, or entries with their reads)
+  auto fetch_next = [&](uint32_t& r_out, uint32_t& L_out, uint64_t& rd_out) __attribute__((always_inline)) -> bool {
     bool act = false;
     r_out = 0;
     if (f_chunk < n_chunks) {
@@ -1198,8 +1231,17 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
       if (idx_in) {
         typedef const __attribute__((address_space(4))) uint32_t* const_u32_t;
         act = t < ((const_u32_t)(uintptr_t)kp->in_count)[sgi];
-        const uint32_t* seg = idx_in + (size_t)sgi * kp->in_seg_cap + t_base;
-        if (act) r_out = seg[tid];
+        if (fat_in) {
+          if (act) {  // a list that carries its reads: the whole entry in one 16-byte load
+            const uint4 e = reinterpret_cast<const uint4*>(idx_in)[(size_t)sgi * kp->in_seg_cap + t_base + tid];
+            r_out = e.x;
+            L_out = e.y;
+            rd_out = (uint64_t)e.z | ((uint64_t)e.w << 32);
+          }
+        } else {
+          const uint32_t* seg = idx_in + (size_t)sgi * kp->in_seg_cap + t_base;
+          if (act) r_out = seg[tid];
+        }
       } else {
         act = t < kp->n_total;
         r_out = act ? t : 0u;
@@ -1220,7 +1262,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
   // the stream by bucket units / dictionary units (flushed once, to the first unit of that kind)
   uint32_t c_lookups = 0, c_cands = 0, c_bl = 0, c_bc = 0, c_dl = 0, c_dc = 0;
   // ---- a read is finished: the claim in cascade order, ONE entry decode, output, survivor list, counters ----
-  auto finalize = [&](bool valid, uint32_t r, uint32_t el_mask, unsigned long long key) __attribute__((always_inline)) {
+  auto finalize = [&](bool valid, uint32_t r, uint32_t L0, uint64_t rd, uint32_t el_mask, unsigned long long key) __attribute__((always_inline)) {
     const bool claimed = valid && key != ~0ull;
     const int32_t cp = claimed ? (int32_t)(key >> 56) : 255;
     uint32_t o_ref = 0, o_pos = 0;
@@ -1254,13 +1296,13 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
     }
     if (p.packed) {
       if (claimed) p.packed[r] = pack_assignment(cp, o_ref, o_pos, (uint32_t)((key >> 48) & 255u));
-      else if (valid && !p.idx_out) p.packed[r] = 0u;
+      else if (valid && !p.idx_out && !p.out_init) p.packed[r] = 0u;
     } else if (claimed) {
       p.pass_id[r] = (int8_t)cp;
       p.ref_id[r] = (int32_t)o_ref;
       p.pos[r] = (int32_t)o_pos;
       p.mm[r] = (uint8_t)((key >> 48) & 255u);
-    } else if (valid && !p.idx_out) {
+    } else if (valid && !p.idx_out && !p.out_init) {
       p.pass_id[r] = (int8_t)-1;
       p.ref_id[r] = -1;
       p.pos[r] = -1;
@@ -1273,7 +1315,9 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
         uint32_t wbase = 0;
         if (lane == 0) wbase = atomicAdd(&ctl[0], (uint32_t)__popcll(mask));
         wbase = __shfl(wbase, 0, 64);
-        if (survive) p.idx_out[(size_t)blockIdx.x * p.out_seg_cap + wbase + mbcnt(mask)] = r;
+        if (survive)
+          reinterpret_cast<uint4*>(p.idx_out)[(size_t)blockIdx.x * p.out_seg_cap + wbase + mbcnt(mask)] =
+              make_uint4(r, L0, (uint32_t)rd, (uint32_t)(rd >> 32));
       }
     }
   };
@@ -1435,7 +1479,8 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
       rpend = 0u;
     }
     wave_lds_sync();
-    finalize(valid, valid ? w.r[cbase + lane] : 0u, (my_meta >> 8) & 255u, valid ? w.best[cbase + lane] : ~0ull);
+    finalize(valid, valid ? w.r[cbase + lane] : 0u, my_meta & 255u, valid ? w.rd[cbase + lane] : 0ull, (my_meta >> 8) & 255u,
+             valid ? w.best[cbase + lane] : ~0ull);
   };
 
   uint32_t r_b = 0, r_c = 0, L_b = 255u;
@@ -1444,11 +1489,16 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
   uint32_t pre_ui = kSeedMaxUnits;  // the first dictionary unit (none: kSeedMaxUnits)
   for (uint32_t ui = p.n_units; ui-- > 0u;)
     if (kargs->unit[ui].kind == 1u) pre_ui = ui;
-  bool act_b = fetch_next(r_b);
-  bool act_c = fetch_next(r_c);
-  if (act_b) {
-    L_b = p.lens[r_b];
-    rd_b = p.reads[r_b];
+  uint32_t L_unused = 0;
+  uint64_t rd_unused = 0;
+  bool act_b = fetch_next(r_b, L_b, rd_b);
+  bool act_c = false;
+  if (!fat_in) {
+    act_c = fetch_next(r_c, L_unused, rd_unused);
+    if (act_b) {
+      L_b = p.lens[r_b];
+      rd_b = p.reads[r_b];
+    }
   }
   // (one trip more than there are chunks: the last one has no reads and works off what is still parked)
   for (uint32_t chunk = blockIdx.x;; chunk += gridDim.x) {
@@ -1457,15 +1507,19 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
     const bool active = act_b;
     const uint32_t r = r_b, L0 = active ? L_b : 255u;
     const uint64_t rd = rd_b;
-    act_b = act_c;
-    r_b = r_c;
     L_b = 255u;
     rd_b = 0;
-    if (act_b) {
-      L_b = p.lens[r_b];
-      rd_b = p.reads[r_b];
+    if (fat_in) {
+      act_b = fetch_next(r_b, L_b, rd_b);
+    } else {
+      act_b = act_c;
+      r_b = r_c;
+      if (act_b) {
+        L_b = p.lens[r_b];
+        rd_b = p.reads[r_b];
+      }
+      act_c = fetch_next(r_c, L_unused, rd_unused);
     }
-    act_c = fetch_next(r_c);
     // ================= the stream: eligibility, filters, inline answers =================
     unsigned long long my_best = ~0ull;
     uint32_t el_mask = 0u, queued_all = 0u;
@@ -1611,7 +1665,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
     }
     // ================= finished on the spot, or parked =================
     const bool park = queued_all != 0u;
-    finalize(active && !park, r, el_mask, my_best);
+    finalize(active && !park, r, L0, rd, el_mask, my_best);
     const uint64_t pm = __ballot(park);
     if (pm) {
       const uint32_t c = pend + mbcnt(pm);
@@ -1696,7 +1750,7 @@ __host__ __device__ constexpr uint32_t pair_wave_lds_bytes() { return kPairReads
 
 }  // namespace
 
-__global__ void __launch_bounds__(kSeedThreads, 6) pair_wave_kernel(const MatchParams p) {
+__global__ void __launch_bounds__(kSeedThreads, 5) pair_wave_kernel(const MatchParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
   uint32_t* const ctl = smem;  // [0] survivors of the workgroup, [1] longest input segment
@@ -1843,22 +1897,90 @@ __global__ void __launch_bounds__(kSeedThreads, 6) pair_wave_kernel(const MatchP
     }
   };
 
-  for (uint32_t wc = blockIdx.x * 4u + wv; wc < n_chunks; wc += gridDim.x * 4u) {
-    const uint32_t sgi = wc % in_nseg, depth = wc / in_nseg;
-    const uint32_t count = p.idx_in ? p.in_count[sgi] : p.n_total;
-    // ---- the wave's 256 reads into its LDS region (RAP:543-554: which of them this pass's FASTA holds) ----
-    uint32_t scan_m = 0;  // bit u: my read u has no anchors that fit (scan)
+  // ---- the walk, software-pipelined (as seed_kernel's): while a trip's 256 reads are searched, the reads of the
+  // next trip and the list entries of the one after it are in flight (loaded where they were needed, they cost
+  // 0.37 of this launch's 0.98 ms: two dependent memory trips per 256 reads with nothing else to do) ----
+  const uint32_t wc_stride = gridDim.x * 4u;
+  auto load_entries = [&](uint32_t wc, uint32_t (&r)[4]) __attribute__((always_inline)) -> uint32_t {
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; ++u) r[u] = 0u;
+    if (wc < n_chunks) {
+      const uint32_t sgi = wc % in_nseg, depth = wc / in_nseg;
+      const uint32_t count = p.idx_in ? p.in_count[sgi] : p.n_total;
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; ++u) {
+        const uint32_t t = depth * kPairReads + lane + 64u * u;
+        if (t < count) {
+          r[u] = p.idx_in ? p.idx_in[((size_t)sgi * p.in_seg_cap + t) * p.in_stride] : t;
+          m |= 1u << u;
+        }
+      }
+    }
+    return m;
+  };
+  auto load_reads = [&](const uint32_t (&r)[4], uint32_t m, uint32_t (&L)[4], uint64_t (&d)[4]) __attribute__((always_inline)) {
 #pragma unroll
     for (uint32_t u = 0; u < 4u; ++u) {
-      const uint32_t slot = lane + 64u * u, t = depth * kPairReads + slot;
-      const bool active = t < count;
-      uint32_t r = 0, L0 = 0;
-      uint64_t rd = 0;
-      if (active) {
-        r = p.idx_in ? p.idx_in[(size_t)sgi * p.in_seg_cap + t] : t;
-        L0 = p.lens[r];
-        rd = p.reads[r];
+      L[u] = 0u;
+      d[u] = 0ull;
+      if ((m >> u) & 1u) {
+        L[u] = p.lens[r[u]];
+        d[u] = p.reads[r[u]];
       }
+    }
+  };
+  // a list that carries its reads (in_stride = 4: the seed launches write such lists): entry = index, length, read --
+  // streamed, 16 bytes per read, where the gathers through an index list touch 4.5 lines per line's worth of reads
+  // (this pass walks 22 % of the batch): 0.36 -> 0.23 ms of this launch
+  auto load_fat = [&](uint32_t wc, uint32_t (&r)[4], uint32_t (&L)[4], uint64_t (&d)[4]) __attribute__((always_inline)) -> uint32_t {
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; ++u) {
+      r[u] = 0u;
+      L[u] = 0u;
+      d[u] = 0ull;
+    }
+    if (wc < n_chunks) {
+      const uint32_t sgi = wc % in_nseg, depth = wc / in_nseg;
+      const uint32_t count = p.in_count[sgi];
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; ++u) {
+        const uint32_t t = depth * kPairReads + lane + 64u * u;
+        if (t < count) {
+          const uint4 e = reinterpret_cast<const uint4*>(p.idx_in)[(size_t)sgi * p.in_seg_cap + t];
+          r[u] = e.x;
+          L[u] = e.y;
+          d[u] = (uint64_t)e.z | ((uint64_t)e.w << 32);
+          m |= 1u << u;
+        }
+      }
+    }
+    return m;
+  };
+  const bool fat = p.idx_in && p.in_stride == 4u;
+  uint32_t r_b[4], L_b[4], r_c[4];
+  uint64_t d_b[4];
+  uint32_t m_b, m_c = 0;
+  if (fat) {
+    m_b = load_fat(blockIdx.x * 4u + wv, r_b, L_b, d_b);
+  } else {
+    m_b = load_entries(blockIdx.x * 4u + wv, r_b);
+    load_reads(r_b, m_b, L_b, d_b);
+    m_c = load_entries(blockIdx.x * 4u + wv + wc_stride, r_c);
+  }
+  for (uint32_t wc = blockIdx.x * 4u + wv; wc < n_chunks; wc += wc_stride) {
+    // ---- the wave's 256 reads into its LDS region (RAP:543-554: which of them this pass's FASTA holds) ----
+    uint32_t scan_m = 0;  // bit u: my read u has no anchors that fit (scan)
+    uint32_t cur_r[4];
+    const uint32_t cur_m = m_b;
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; ++u) {
+      const uint32_t slot = lane + 64u * u;
+      const bool active = ((m_b >> u) & 1u) != 0u;
+      const uint32_t L0 = L_b[u];
+      const uint64_t rd = d_b[u];
+      cur_r[u] = r_b[u];
       const bool eligible = active && (int32_t)L0 >= p.min_len && (int32_t)L0 <= p.max_len;
       const int32_t L = (int32_t)L0 - p.trim5 - p.trim3;
       if (eligible && p.count_processed) ++c_processed;
@@ -1875,6 +1997,16 @@ __global__ void __launch_bounds__(kSeedThreads, 6) pair_wave_kernel(const MatchP
       w.best[slot] = ~0ull;
       w.len[slot] = (uint8_t)(searching ? L : 0);
       w.st[slot] = (uint8_t)(A | (scan ? 0x40u : 0u) | (active ? 0x80u : 0u));
+    }
+    // the pipeline moves on: the next trip's reads, the entries of the trip after it
+    if (fat) {
+      m_b = load_fat(wc + wc_stride, r_b, L_b, d_b);
+    } else {
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; ++u) r_b[u] = r_c[u];
+      m_b = m_c;
+      load_reads(r_b, m_b, L_b, d_b);
+      m_c = load_entries(wc + 2u * wc_stride, r_c);
     }
     wave_lds_sync();
     // ---- reads too short for anchors (fewer than 4 x 3 seed bases: under 15 nt): every text position, by the wave ----
@@ -1920,12 +2052,10 @@ __global__ void __launch_bounds__(kSeedThreads, 6) pair_wave_kernel(const MatchP
 #pragma unroll
     for (uint32_t u = 0; u < 4u; ++u) {
       const uint32_t slot = lane + 64u * u;
-      const bool active = (w.st[slot] & 0x80u) != 0u;
+      const bool active = ((cur_m >> u) & 1u) != 0u;
       const unsigned long long key = w.best[slot];
       const bool aligned = active && key != ~0ull;
-      // (the read's index again from the list: 1 KB of LDS per wave less = a sixth workgroup per CU)
-      const uint32_t t = depth * kPairReads + slot;
-      const uint32_t r = active ? (p.idx_in ? p.idx_in[(size_t)sgi * p.in_seg_cap + t] : t) : 0u;
+      const uint32_t r = cur_r[u];
       if (aligned) {
         ++c_aligned;
         uint32_t ref, pos;
@@ -1939,7 +2069,7 @@ __global__ void __launch_bounds__(kSeedThreads, 6) pair_wave_kernel(const MatchP
           p.pos[r] = (int32_t)pos;
           p.mm[r] = (uint8_t)mm;
         }
-      } else if (active && !p.idx_out) {
+      } else if (active && !p.idx_out && !p.out_init) {
         if (p.packed) {
           p.packed[r] = 0u;
         } else {
@@ -1956,7 +2086,11 @@ __global__ void __launch_bounds__(kSeedThreads, 6) pair_wave_kernel(const MatchP
           uint32_t wbase = 0;
           if (lane == 0) wbase = atomicAdd(&ctl[0], (uint32_t)__popcll(mask));
           wbase = __shfl(wbase, 0, 64);
-          if (survive) p.idx_out[(size_t)blockIdx.x * p.out_seg_cap + wbase + mbcnt(mask)] = r;
+          if (survive) {  // (only with a pass behind this one -- spike-in: the entry is put together again)
+            const uint64_t whole = p.reads[r];
+            reinterpret_cast<uint4*>(p.idx_out)[(size_t)blockIdx.x * p.out_seg_cap + wbase + mbcnt(mask)] =
+                make_uint4(r, (uint32_t)p.lens[r], (uint32_t)whole, (uint32_t)(whole >> 32));
+          }
         }
       }
     }
@@ -2049,13 +2183,17 @@ hipError_t launch_seed(const SeedParams& p, uint32_t grid, hipStream_t stream) {
     else hipLaunchKernelGGL((wave_seed_kernel<false, 8>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
     return hipGetLastError();
   }
-  const void* kern = buckets ? reinterpret_cast<const void*>(seed_kernel<true, 6>) : reinterpret_cast<const void*>(seed_kernel<false, 8>);
+  const bool fat = p.idx_in && p.in_stride == 4u;
+  const void* kern = buckets ? (fat ? reinterpret_cast<const void*>(seed_kernel<true, 6, true>) : reinterpret_cast<const void*>(seed_kernel<true, 6, false>))
+                             : (fat ? reinterpret_cast<const void*>(seed_kernel<false, 8, true>) : reinterpret_cast<const void*>(seed_kernel<false, 8, false>));
   if (lds > 48u * 1024u) {
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  if (buckets) hipLaunchKernelGGL((seed_kernel<true, 6>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
-  else hipLaunchKernelGGL((seed_kernel<false, 8>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+  if (buckets && fat) hipLaunchKernelGGL((seed_kernel<true, 6, true>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+  else if (buckets) hipLaunchKernelGGL((seed_kernel<true, 6, false>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+  else if (fat) hipLaunchKernelGGL((seed_kernel<false, 8, true>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+  else hipLaunchKernelGGL((seed_kernel<false, 8, false>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
   return hipGetLastError();
 }
 

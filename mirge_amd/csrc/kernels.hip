@@ -2367,6 +2367,25 @@ hipError_t launch_count(const CountParams& p, uint32_t words_per_read, uint32_t 
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void list_thin_kernel(const uint4* __restrict__ fat_in, uint32_t* __restrict__ thin_out,
+                                                         const uint32_t* __restrict__ in_count, uint32_t* __restrict__ out_count,
+                                                         uint32_t n_seg, uint32_t seg_cap) {
+  for (uint32_t sg = blockIdx.x; sg < n_seg; sg += gridDim.x) {
+    const uint32_t cnt = in_count[sg];
+    const size_t base = (size_t)sg * seg_cap;
+    for (uint32_t t = threadIdx.x; t < cnt; t += 256u) thin_out[base + t] = fat_in[base + t].x;
+    if (threadIdx.x == 0) out_count[sg] = cnt;
+  }
+}
+
+hipError_t launch_list_thin(const uint4* fat_in, uint32_t* thin_out, const uint32_t* in_count, uint32_t* out_count, uint32_t n_seg,
+                            uint32_t seg_cap, hipStream_t stream) {
+  if (!n_seg) return hipSuccess;
+  hipLaunchKernelGGL(list_thin_kernel, dim3(n_seg < 2048u ? n_seg : 2048u), dim3(256), 0, stream, fat_in, thin_out, in_count, out_count,
+                     n_seg, seg_cap);
+  return hipGetLastError();
+}
+
 hipError_t launch_split(const SplitParams& p, uint32_t grid, hipStream_t stream) {
   hipLaunchKernelGGL(split_kernel, dim3(grid), dim3(1024), 0, stream, p);
   return hipGetLastError();

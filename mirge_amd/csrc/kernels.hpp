@@ -64,6 +64,9 @@ struct MatchParams {
   uint32_t* idx_out;         // null on the last pass
   uint32_t* out_count;       // [gridDim.x]
   uint32_t out_seg_cap;
+  // pair_wave_kernel (dict.hip) only: words per entry of the input list (1 = indices, 4 = index, length, read:
+  // SeedParams); it writes 16-byte entries; out_init: the cascade's first launch wrote every output already
+  uint32_t in_stride, out_init;
   // outputs
   int8_t* pass_id;
   int32_t* ref_id;
@@ -301,12 +304,18 @@ struct SeedParams {
   const uint64_t* reads;
   const uint8_t* lens;
   uint32_t n_total;
+  // the input list: entries of in_stride words, word 0 = the read's index (1: an index list as exact_dict_kernel and
+  // the FM kernels write them; 4: a list that CARRIES its reads -- index, length, the packed read: 16 bytes).  The
+  // seed launches WRITE the second form: the launch behind them streams its reads instead of gathering them through
+  // the indices (pair_wave_kernel walks 22 % of the batch: 4.5 lines touched per line's worth of reads)
   const uint32_t* idx_in;
+  uint32_t in_stride;
   const uint32_t* in_count;
   uint32_t in_nseg, in_seg_cap;
-  uint32_t* idx_out;  // null: the launch ends the cascade
+  uint32_t* idx_out;  // null: the launch ends the cascade; else 16-byte entries
   uint32_t* out_count;
   uint32_t out_seg_cap;
+  uint32_t out_init;  // the first launch of the cascade wrote every output ("unannotated" included): the last one need not
   int8_t* pass_id;
   int32_t* ref_id;
   int32_t* pos;
@@ -462,5 +471,9 @@ struct SplitParams {
   uint32_t* cnt_rest;
 };
 hipError_t launch_split(const SplitParams& p, uint32_t grid, hipStream_t stream);
+// A segmented survivor list that carries its reads (16-byte entries: SeedParams) -> the index list the FM kernels
+// and exact_dict_kernel read, segment for segment (non-default plans and the spike-in pass only)
+hipError_t launch_list_thin(const uint4* fat_in, uint32_t* thin_out, const uint32_t* in_count, uint32_t* out_count, uint32_t n_seg,
+                            uint32_t seg_cap, hipStream_t stream);
 
 }  // namespace mrg
