@@ -215,7 +215,7 @@ struct mrg_ctx {
   // for that library (16 B x 2..4 slots per base of HBM), as mirge_amd/engine.py does
   int64_t dict_max_bases = (int64_t)mrg::kDictSmallBases;
   int64_t split_mixed = 1;    // a batch with long reads / reads with N: its one-word N-free reads take the dictionary kernels
-  int64_t split_min_len = 20;  // ... and so do not reads shorter than this: their seeds (half a read in a 1-mismatch pass) name hundreds of rows of a large library
+  int64_t split_min_len = 16;  // ... and so do not reads shorter than this (the reference's own minimum length, trim_file.py:33; shorter seed regions than 15 bases have no pair tables)
   int64_t stratum0_unit = 0;  // (measured slower, default off) the exact stratum of a 2-mismatch pass behind a seed launch rides in that launch
   int64_t seed_buckets = 1;  // large libraries get seed buckets where they pay (set before add_library); 0 at run time: not used
   int64_t seed_wgs = 0;      // seed_kernel workgroups (256 threads) per CU; 0 = what the launch's instantiation keeps resident
@@ -1168,6 +1168,35 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     return MRG_OK;
   };
 
+  // pair tables of a large library (three anchors of A bases, gaps A and 2 A: pairs.hip), built on the device the first
+  // time a cascade meets reads whose seed region is 3 A .. 4 A - 1 bases under a one-mismatch policy
+  auto ensure_bpair = [&](DevLib& lm, int64_t A) -> int {
+    if (lm.bpair_anchor == (uint32_t)A || lm.bpair_failed) return MRG_OK;
+    (void)hipFree(lm.bpair_jump);
+    (void)hipFree(lm.bpair_rows);
+    lm.bpair_jump = nullptr;
+    lm.bpair_rows = nullptr;
+    lm.bpair_anchor = 0;
+    const uint64_t n_rows = (uint64_t)lm.n + 1, n_codes1 = (1ull << (4u * (uint32_t)A)) + 1ull;
+    const uint64_t need = 2 * n_codes1 * 4 + 2 * n_rows * 8 + 4 * n_rows * 4 + (256ull << 20);
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if (free_b < need || hipMalloc((void**)&lm.bpair_jump, 2 * n_codes1 * 4) != hipSuccess ||
+        hipMalloc((void**)&lm.bpair_rows, 2 * n_rows * 8) != hipSuccess ||
+        mrg::build_pair_tables_device(lm.sa, lm.text, (uint32_t)n_rows, (uint32_t)A, 2, lm.bpair_jump, lm.bpair_rows, lm.bpair_row_off,
+                                      stream) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(lm.bpair_jump);
+      (void)hipFree(lm.bpair_rows);
+      lm.bpair_jump = nullptr;
+      lm.bpair_rows = nullptr;
+      lm.bpair_failed = true;
+    } else {
+      lm.bpair_anchor = (uint32_t)A;
+    }
+    return MRG_OK;
+  };
+
   // one fused_kernel launch for the running passes among [first, last]
   auto run_fused = [&](const uint32_t* members, uint32_t n_sub, bool ends_cascade) -> int {
     mrg::FusedParams fp;
@@ -1242,29 +1271,9 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
         if (A && c.max_mm_seed == 1 && !c.poly_t && l.n >= mrg::kWideRowMinBases && !ctx->round_large && r_min < 4 * A &&
             r_max >= 3 * A) {
           DevLib& lm = ctx->libs[c.lib];
-          if (lm.bpair_anchor != (uint32_t)A && !lm.bpair_failed) {
-            (void)hipFree(lm.bpair_jump);
-            (void)hipFree(lm.bpair_rows);
-            lm.bpair_jump = nullptr;
-            lm.bpair_rows = nullptr;
-            lm.bpair_anchor = 0;
-            const uint64_t n_rows = (uint64_t)lm.n + 1, n_codes1 = (1ull << (4u * (uint32_t)A)) + 1ull;
-            const uint64_t need = 2 * n_codes1 * 4 + 2 * n_rows * 8 + 4 * n_rows * 4 + (256ull << 20);
-            size_t free_b = 0, total_b = 0;
-            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            if (free_b < need || hipMalloc((void**)&lm.bpair_jump, 2 * n_codes1 * 4) != hipSuccess ||
-                hipMalloc((void**)&lm.bpair_rows, 2 * n_rows * 8) != hipSuccess ||
-                mrg::build_pair_tables_device(lm.sa, lm.text, (uint32_t)n_rows, (uint32_t)A, 2, lm.bpair_jump, lm.bpair_rows,
-                                              lm.bpair_row_off, stream) != hipSuccess) {
-              (void)hipGetLastError();
-              (void)hipFree(lm.bpair_jump);
-              (void)hipFree(lm.bpair_rows);
-              lm.bpair_jump = nullptr;
-              lm.bpair_rows = nullptr;
-              lm.bpair_failed = true;
-            } else {
-              lm.bpair_anchor = (uint32_t)A;
-            }
+          {
+            const int rc_bp = ensure_bpair(lm, A);
+            if (rc_bp != MRG_OK) return rc_bp;
           }
           if (lm.bpair_anchor == (uint32_t)A) {
             sp.pair_jump = lm.bpair_jump;
@@ -1399,6 +1408,26 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
         un.slots = reinterpret_cast<const uint4*>(fm->dict_slots);
         un.log2_slots = fm->dict_log2;
         un.key_bases = fm->dict_key;
+      }
+      // one large library under a one-mismatch policy, and (by the length hint) reads whose seed region is 3 A .. 4 A - 1
+      // bases: its pair tables (wave_seed_kernel parks those reads for the three anchor pairs)
+      if (un.kind == 0u && plan[u].members.size() == 1 && !c0.poly_t && c0.max_mm_seed == 1 && ctx->pair_big && !plan[u].stratum0 &&
+          ctx->libs[c0.lib].n >= mrg::kWideRowMinBases) {
+        const int64_t A = ctx->pair_big;
+        const int64_t r_min = std::min<int64_t>(std::max<int64_t>(ctx->hint_min_len, c0.min_len) - c0.trim5 - c0.trim3, c0.seed_len);
+        const int64_t r_max = std::min<int64_t>(std::min<int64_t>(ctx->hint_max_len, c0.max_len) - c0.trim5 - c0.trim3, c0.seed_len);
+        if (r_min < 4 * A && r_max >= 3 * A) {
+          DevLib& lm = ctx->libs[c0.lib];
+          const int rc_bp = ensure_bpair(lm, A);
+          if (rc_bp != MRG_OK) return rc_bp;
+          if (lm.bpair_anchor == (uint32_t)A) {
+            un.bpair_jump = lm.bpair_jump;
+            un.bpair_rows = lm.bpair_rows;
+            un.bpair_row_off[0] = lm.bpair_row_off[0];
+            un.bpair_row_off[1] = lm.bpair_row_off[1];
+            un.bpair_anchor = (uint32_t)A;
+          }
+        }
       }
       un.ftab = fm->ftab;
       un.tabs = fm->tabs;

@@ -355,10 +355,11 @@ __global__ void __launch_bounds__(kBlock, 8) exact_dict_kernel(const ExactParams
 // ---------------------------------------------------------------------------
 namespace {
 
-constexpr uint32_t kUnitWords = 26u;  // LDS table entry of a unit (what a row's verification needs)
+constexpr uint32_t kUnitWords = 28u;  // LDS table entry of a unit (what a row's verification needs)
 enum UnitWord : uint32_t { UW_SA16 = 0, UW_TEXT = 2, UW_SEGSTART = 4, UW_SEGREF = 6, UW_SEGOFF = 8, UW_CHUNKSEG = 10, UW_FLAGS = 12,
-                           UW_LIMITS = 13, UW_MEMBERS = 14, UW_BUCKETS = 22, UW_SA = 24 };
+                           UW_LIMITS = 13, UW_MEMBERS = 14, UW_BUCKETS = 22, UW_SA = 24, UW_BPAIR = 26 };
 constexpr uint32_t kRowFromBucket = 1u << 23;  // tag bit of a row-queue entry: x indexes the unit's buckets, not its wide rows
+constexpr uint32_t kRowFromPair = 1u << 24;    // ... x indexes the unit's pair rows (wave_seed_kernel: 8-byte rows, the text decides)
 constexpr uint32_t kSeedCtlWords = 16u;
 static_assert(4u + 2u * kSeedMaxUnits <= kSeedCtlWords, "seed_kernel: two sets of item counters");
 static_assert(2u * kSeedMaxUnits * kSeedMaxMembers <= 64u && kSeedMaxMembers <= 4u, "seed_kernel: one lane per member counter");
@@ -1197,6 +1198,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
     put(UW_CHUNKSEG, un.chunk_seg);
     put(UW_BUCKETS, un.buckets);
     put(UW_SA, un.sa);
+    put(UW_BPAIR, un.bpair_rows);
     t[UW_FLAGS] = (uint32_t)un.trim5 | ((uint32_t)un.trim3 << 8) | (un.poly_t ? 1u << 16 : 0u) | (un.simple_segs ? 1u << 17 : 0u) |
                   (un.n_members << 18) | ((uint32_t)un.max_mm_seed << 21) | (un.kind == 1u ? 1u << 23 : 0u);
     t[UW_LIMITS] = (uint32_t)min(un.min_seed_len, 0xFFFF) | ((uint32_t)min(un.max_total, 0xFFFF) << 16);
@@ -1345,7 +1347,10 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
       int32_t L;
       unit_view(0, 255, (int32_t)((flags >> 16) & 1u), (int32_t)(flags & 255u), (int32_t)((flags >> 8) & 255u), w.rd[c], w.meta[c] & 255u, q, L);
       const uint4* wide = reinterpret_cast<const uint4*>(lds_pointer(ut, from_bucket ? UW_BUCKETS : UW_SA16));
-      if (wide) {
+      if (e.y & kRowFromPair) {
+        const uint64_t row = reinterpret_cast<const uint64_t*>(lds_pointer(ut, UW_BPAIR))[e.x];
+        verify_seed_row(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), q, L, off, 0u, &w.best[c]);
+      } else if (wide) {
         verify_seed_row(ut, wide[e.x], q, L, off, kp, &w.best[c], from_bucket);
       } else {
         const uint64_t row = reinterpret_cast<const uint64_t*>(lds_pointer(ut, UW_SA))[e.x];
@@ -1383,7 +1388,8 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
     const uint32_t my_meta = valid ? w.meta[cbase + lane] : 0u;
     for (uint32_t ui = 0; ui < p.n_units; ++ui) {
       const KUnit& un = kargs->unit[ui];
-      const uint32_t n_seeds = un.kind == 1u ? 1u : (uint32_t)un.max_mm_seed + 1u;
+      // (a unit with pair tables: three items per read in pair mode -- bit 3 of the read's four item bits)
+      const uint32_t n_seeds = un.kind == 1u ? 1u : ((BUCKETS && un.bpair_anchor) ? 3u : (uint32_t)un.max_mm_seed + 1u);
       uint32_t n_it = 0;  // items of this unit waiting in the list (wave-uniform)
       // lane < m: item (candidate lane, seed) from the list
       auto run_items = [&](uint32_t from, uint32_t m) __attribute__((always_inline)) {
@@ -1392,11 +1398,14 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
         uint32_t cl = 0, j = 0;
         uint64_t q = 0;
         int32_t L = 0;
+        bool pair_mode = false;
         if (has) {
           const uint32_t e = w.items[from + lane];
           cl = e & 63u;
           j = e >> 6;
-          unit_view(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, w.rd[cbase + cl], w.meta[cbase + cl] & 255u, q, L);
+          const uint32_t cm = w.meta[cbase + cl];
+          pair_mode = BUCKETS && ((cm >> (16u + 4u * ui + 3u)) & 1u) != 0u;
+          unit_view(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, w.rd[cbase + cl], cm & 255u, q, L);
         }
         if (un.kind == 1u) {
           if (has) {
@@ -1407,7 +1416,19 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
         }
         // ---- a seed: bucket count or jump-table load, then its rows into the row queue ----
         uint32_t lo = 0, n_rows = 0, tag = 0;
-        if (has) {
+        if (BUCKETS && has && pair_mode) {
+          // item j = anchor pair (0,1), (1,2), (0,2): one mismatch in the seed region leaves one of them clean
+          const uint32_t A = un.bpair_anchor, kb = 2u * A, amask = (1u << kb) - 1u, n_codes1 = (1u << (2u * kb)) + 1u;
+          const uint32_t i0 = j == 1u ? 1u : 0u, i1 = j == 0u ? 1u : 2u;
+          const uint32_t a0 = (uint32_t)(q >> (i0 * kb)) & amask, a1 = (uint32_t)(q >> (i1 * kb)) & amask;
+          const uint32_t t = i1 - i0 - 1u;
+          const TableEntry2 te = *reinterpret_cast<const TableEntry2*>(un.bpair_jump + t * n_codes1 + (a0 | (a1 << kb)));
+          lo = te.lo + (t ? un.bpair_row_off[1] : un.bpair_row_off[0]);
+          n_rows = te.hi - te.lo;
+          ++c_lookups;
+          c_cands += n_rows;
+          tag = cl | (ui << 11) | ((i0 * A) << 13) | kRowFromPair;
+        } else if (has) {
           const int32_t k = seed_bases(L, un.min_seed_len, un.max_mm_seed);
           const uint32_t off = j * (uint32_t)k;
           uint32_t kp = 0, bcnt = kSeedBucketOverflow;
@@ -1449,7 +1470,10 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
           const uint32_t* ut = utab + ui * kUnitWords;
           unsigned long long* slot = &w.best[cbase + (w_tag & 63u)];
           for (uint32_t i = lane; i < w_n; i += 64u) {
-            if (un.sa16) {
+            if (BUCKETS && (w_tag & kRowFromPair)) {
+              const uint64_t row = un.bpair_rows[w_lo + i];
+              verify_seed_row(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), w_q, w_L, (w_tag >> 13) & 63u, 0u, slot);
+            } else if (un.sa16) {
               verify_seed_row(ut, un.sa16[w_lo + i], w_q, w_L, (w_tag >> 13) & 63u, (w_tag >> 19) & 15u, slot);
             } else {
               const uint64_t row = un.sa[w_lo + i];
@@ -1461,7 +1485,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
       };
       for (uint32_t j = 0; j <= n_seeds; ++j) {  // (the last trip only works off what is left in the list)
         if (j < n_seeds) {
-          const bool need = ((my_meta >> (16u + 2u * ui + j)) & 1u) != 0u;
+          const bool need = ((my_meta >> (16u + 4u * ui + j)) & 1u) != 0u;
           const uint64_t mask = __ballot(need);
           if (need) w.items[n_it + mbcnt(mask)] = (uint16_t)(lane | (j << 6));
           n_it += (uint32_t)__popcll(mask);
@@ -1577,7 +1601,13 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
         const uint32_t n_seeds = (uint32_t)V + 1u;
         const int32_t k = seed_bases(L, un.min_seed_len, V);
         queued = search ? (1u << n_seeds) - 1u : 0u;  // seeds that need the index
-        if (BUCKETS && un.buckets) {
+        // a seed region of 3 A .. 4 A - 1 bases in a large library: the three anchor pairs instead of two seeds of
+        // 8..9 bases (40..170 rows each in 11 Mbp); parked, the pair lookups run with dense lanes
+        if (BUCKETS && un.bpair_anchor && search) {
+          const int32_t R = min(L, un.min_seed_len);
+          if (R >= (int32_t)(3u * un.bpair_anchor) && R < (int32_t)(4u * un.bpair_anchor)) queued = 15u;
+        }
+        if (BUCKETS && un.buckets && !(queued & 8u)) {
           // a seed of exactly bucket_k bases: the first four rows of both seeds' buckets are requested together
           // (one 64-byte half line per seed) and verified here; a fuller or overflowing bucket is parked
           const bool inl = search && (uint32_t)k == un.bucket_k;
@@ -1651,7 +1681,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
           }
         }
         // the unit's presence bitmaps: both seeds' words are requested before either is looked at
-        if (un.kbits && k >= 8) {
+        if (un.kbits && k >= 8 && !(queued & 8u)) {
           const uint32_t kb = (uint32_t)min(k, 11), woff = seed_kbits_word_off(kb), cmask = (1u << (2u * kb)) - 1u;
           const uint32_t code0 = (uint32_t)q & cmask, code1 = (uint32_t)(q >> (2u * (uint32_t)k)) & cmask;
           uint32_t w0 = ~0u, w1 = ~0u;
@@ -1661,7 +1691,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
           if (!((w1 >> (code1 & 31u)) & 1u)) queued &= ~2u;
         }
       }
-      queued_all |= queued << (2u * ui);
+      queued_all |= queued << (4u * ui);  // (four bits per unit: three items, pair mode)
     }
     // ================= finished on the spot, or parked =================
     const bool park = queued_all != 0u;

@@ -284,6 +284,13 @@ struct SeedUnit {
   const uint32_t* seg_off;
   const uint32_t* chunk_seg;
   uint32_t simple_segs;
+  // wave_seed_kernel, one large library searched with ONE seed mismatch: pair tables of three anchors of bpair_anchor
+  // bases (pairs.hip; gaps A and 2 A) for the reads whose seed region is 3 A .. 4 A - 1 bases (16..19-nt reads:
+  // their two seeds of 8..9 bases would name 40..170 rows each in 11 Mbp); 0 = none
+  const uint32_t* bpair_jump;
+  const uint64_t* bpair_rows;
+  uint32_t bpair_row_off[2];
+  uint32_t bpair_anchor;
   const uint4* slots;  // kind 1
   uint32_t log2_slots, key_bases;
   const uint32_t* kbits;  // presence bitmaps of the k-mers, k = 8..11, at word offsets seed_kbits_word_off(k); null = none

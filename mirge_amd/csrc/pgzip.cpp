@@ -242,6 +242,51 @@ size_t parse_gzip_header(const uint8_t* p, size_t n, size_t off) {
   return q < n ? q : 0;
 }
 
+// ------------------------------------------------------------------ buffers
+// A chunk's symbols (16 MB and more) and bytes live in raw buffers that are recycled: std::vector would zero-fill
+// every growth and hand the pages back on release, and dozens of threads faulting fresh pages in and out of one
+// address space serialise in the kernel (the first version fell from 22 to 17 M reads/s between 32 and 128 threads).
+struct RawBuf {
+  void* p = nullptr;
+  size_t cap = 0;  // bytes
+  void ensure(size_t bytes, size_t keep) {  // at least `bytes`; the first `keep` bytes survive
+    if (bytes <= cap) return;
+    size_t want = std::max(bytes, cap + cap / 2);
+    want = (want + (1u << 20)) & ~(size_t)((1u << 20) - 1);
+    void* q = std::malloc(want);
+    if (!q) throw std::bad_alloc();
+    if (keep) std::memcpy(q, p, keep);
+    std::free(p);
+    p = q;
+    cap = want;
+  }
+  void release() {
+    std::free(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+struct BufPool {
+  std::mutex mu;
+  std::vector<RawBuf> spare;
+  RawBuf take() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (spare.empty()) return RawBuf();
+    RawBuf b = spare.back();
+    spare.pop_back();
+    return b;
+  }
+  void give(RawBuf& b) {
+    if (!b.p) return;
+    std::lock_guard<std::mutex> lk(mu);
+    spare.push_back(b);
+    b = RawBuf();
+  }
+  ~BufPool() {
+    for (RawBuf& b : spare) b.release();
+  }
+};
+
 // ------------------------------------------------------------------ one chunk
 struct MemberEnd {
   uint64_t out_off;  // symbols of this chunk that belong to the member that ends here
@@ -257,8 +302,10 @@ struct Chunk {
   bool dropped = false;        // start was not a block start, or none found: the chunk in front covers it
   bool at_eof = false;         // its decoder reached the end of the file
   bool clean_start = false;    // starts a member: nothing in front of it can be referenced
-  std::vector<uint16_t> sym;
-  std::vector<uint8_t> bytes;
+  RawBuf sym;        // n_sym 16-bit symbols
+  size_t n_sym = 0;
+  size_t sym_hint = 0;  // bytes the symbol buffer starts with (a chunk of FASTQ text inflates 4-6 x)
+  RawBuf bytes;      // n_sym bytes once resolved
   std::vector<uint8_t> window;  // the last 32 KB of the stream up to and including this chunk
   std::vector<MemberEnd> ends;
   std::vector<uint32_t> seg_crc;  // crc of the bytes between member ends (ends.size() + 1 segments)
@@ -270,14 +317,18 @@ struct Chunk {
 template <class StopAt>
 void decode_chunk(const BitSrc& src, Chunk& c, StopAt&& stop_at) {
   uint64_t pos = c.start_bit;
-  std::vector<uint16_t>& out = c.sym;
-  out.clear();
+  RawBuf& ob = c.sym;
+  ob.ensure(c.sym_hint ? c.sym_hint : (8u << 20), 0);
+  uint16_t* out = static_cast<uint16_t*>(ob.p);
   size_t n_out = 0;
   size_t member_base = 0;  // symbols before the current member (within this chunk): references cannot go in front of it
   bool member_clean = c.clean_start;
   BlockCodes dyn;
   auto need = [&](size_t extra) {
-    if (out.size() < n_out + extra) out.resize(std::max(out.size() * 2, n_out + extra + (1u << 20)));
+    if (ob.cap < (n_out + extra) * 2) {
+      ob.ensure((n_out + extra) * 2, n_out * 2);
+      out = static_cast<uint16_t*>(ob.p);
+    }
   };
   for (;;) {
     if (pos + 3 > src.n_bits) throw std::runtime_error("unexpected end of the deflate stream");
@@ -349,8 +400,8 @@ void decode_chunk(const BitSrc& src, Chunk& c, StopAt&& stop_at) {
           const uint32_t w0 = kWindow - (uint32_t)(dist - n_out);
           for (; i < front; ++i) out[n_out + i] = (uint16_t)(0x8000u | (w0 + (uint32_t)i));
         }
-        const uint16_t* s = out.data() + n_out - dist;
-        uint16_t* d = out.data() + n_out;
+        const uint16_t* s = out + n_out - dist;
+        uint16_t* d = out + n_out;
         for (; i < length; ++i) d[i] = s[i];
         n_out += length;
       }
@@ -378,7 +429,7 @@ void decode_chunk(const BitSrc& src, Chunk& c, StopAt&& stop_at) {
     if (pos >= src.n_bits) throw std::runtime_error("unexpected end of the deflate stream");
     if (stop_at(pos)) break;
   }
-  out.resize(n_out);
+  c.n_sym = n_out;
   c.end_bit = pos;
 }
 
@@ -450,6 +501,7 @@ struct GzipReader::Impl {
   size_t map_len = 0;
   BitSrc src;
   std::vector<Chunk> chunks;
+  BufPool bufs;
   size_t lookahead = 0;
   std::mutex mu;
   std::condition_variable cv_work, cv_ready;
@@ -474,6 +526,10 @@ struct GzipReader::Impl {
     cv_work.notify_all();
     for (auto& t : pool)
       if (t.joinable()) t.join();
+    for (Chunk& c : chunks) {
+      c.sym.release();
+      c.bytes.release();
+    }
     if (gz) gzclose(gz);
     if (map) munmap(const_cast<uint8_t*>(map), map_len);
     if (fd >= 0) close(fd);
@@ -571,6 +627,7 @@ struct GzipReader::Impl {
       } else if (what == 2) {
         c.busy = true;
         lk.unlock();
+        c.sym = bufs.take();
         std::string err;
         size_t swallowed_to = k;  // chunks (k, swallowed_to] turned out to be covered by this one
         try {
@@ -627,12 +684,13 @@ struct GzipReader::Impl {
         lk.unlock();
         std::vector<uint8_t> win(kWindow, 0);
         std::string err;
-        const size_t n = c.sym.size();
+        const size_t n = c.n_sym;
+        const uint16_t* sym = static_cast<const uint16_t*>(c.sym.p);
         const size_t take = std::min<size_t>(n, kWindow);
         // (window index w of THIS chunk's references = byte w of the previous window)
         if (take < kWindow && pw) std::memcpy(win.data(), pw + take, kWindow - take);
         for (size_t i = 0; i < take; ++i) {
-          const uint16_t v = c.sym[n - take + i];
+          const uint16_t v = sym[n - take + i];
           if (v & 0x8000u) {
             if (!pw) {
               err = "distance beyond the start of the gzip stream";
@@ -657,10 +715,13 @@ struct GzipReader::Impl {
         c.resolving = true;
         lk.unlock();
         std::string err;
-        const size_t n = c.sym.size();
-        std::vector<uint8_t> bytes(n);
+        const size_t n = c.n_sym;
+        const uint16_t* sym = static_cast<const uint16_t*>(c.sym.p);
+        RawBuf bb = bufs.take();
+        bb.ensure(n + 64, 0);
+        uint8_t* bytes = static_cast<uint8_t*>(bb.p);
         for (size_t i = 0; i < n; ++i) {
-          const uint16_t v = c.sym[i];
+          const uint16_t v = sym[i];
           if (v & 0x8000u) {
             if (!pw) {
               err = "distance beyond the start of the gzip stream";
@@ -678,7 +739,7 @@ struct GzipReader::Impl {
           uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
           for (size_t o = seg_from; o < to;) {  // (crc32 takes a 32-bit length)
             const size_t m_ = std::min<size_t>(to - o, 1u << 30);
-            crc = (uint32_t)crc32(crc, bytes.data() + o, (uInt)m_);
+            crc = (uint32_t)crc32(crc, bytes + o, (uInt)m_);
             o += m_;
           }
           seg_crc.push_back(crc);
@@ -686,7 +747,7 @@ struct GzipReader::Impl {
         }
         lk.lock();
         // (the symbols stay until the chunk's window has been cut from them)
-        c.bytes = std::move(bytes);
+        c.bytes = bb;
         c.seg_crc = std::move(seg_crc);
         if (!err.empty() && c.error.empty()) c.error = err;
         c.resolving = false;
@@ -700,8 +761,9 @@ struct GzipReader::Impl {
 
 GzipReader::GzipReader(const std::string& path, int threads, size_t chunk_bytes) : impl_(new Impl()) {
   Impl& m = *impl_;
+  if (threads > 64) threads = 64;  // (more workers only add memory: 3 x threads chunks of ~18 MB are in flight)
   if (!chunk_bytes) {
-    chunk_bytes = 2u << 20;
+    chunk_bytes = 1u << 20;
     // (tests cut small files into many chunks)
     if (const char* e = std::getenv("MIRGE_AMD_GZ_CHUNK")) {
       const long v = std::atol(e);
@@ -729,13 +791,18 @@ GzipReader::GzipReader(const std::string& path, int threads, size_t chunk_bytes)
       } else {
         m.src.data = m.map;
         m.src.n_bits = (uint64_t)m.map_len * 8;
+        // (a file of few chunks: smaller ones, so that every thread has some)
+        while (chunk_bytes > (256u << 10) && (m.map_len - data0) / chunk_bytes < 4u * (size_t)threads) chunk_bytes /= 2;
         const size_t n_chunks = (m.map_len - data0 + chunk_bytes - 1) / chunk_bytes;
         m.chunks.resize(std::max<size_t>(n_chunks, 1));
-        for (size_t k = 0; k < m.chunks.size(); ++k) m.chunks[k].nominal_bit = (uint64_t)(data0 + k * chunk_bytes) * 8;
+        for (size_t k = 0; k < m.chunks.size(); ++k) {
+          m.chunks[k].nominal_bit = (uint64_t)(data0 + k * chunk_bytes) * 8;
+          m.chunks[k].sym_hint = chunk_bytes * 14;
+        }
         m.chunks[0].start_bit = (uint64_t)data0 * 8;
         m.chunks[0].find_done = true;
         m.chunks[0].clean_start = true;
-        m.lookahead = std::max<size_t>(8, 3 * (size_t)threads);
+        m.lookahead = std::max<size_t>(8, 2 * (size_t)threads + 4);
         for (int t = 0; t < threads; ++t) m.pool.emplace_back([&m] { m.worker(); });
       }
     }
@@ -790,16 +857,16 @@ size_t GzipReader::read(char* dst, size_t n) {
     if (!c.error.empty()) throw std::runtime_error("corrupt gzip stream: " + c.error);
     lk.unlock();
     // hand out bytes, folding the member checks as their ends go by
-    const size_t avail = c.bytes.size() - m.cur_off;
+    const size_t avail = c.n_sym - m.cur_off;
     const size_t take = std::min(avail, n - total);
-    std::memcpy(dst + total, c.bytes.data() + m.cur_off, take);
+    std::memcpy(dst + total, static_cast<const uint8_t*>(c.bytes.p) + m.cur_off, take);
     total += take;
     m.cur_off += take;
-    if (m.cur_off == c.bytes.size()) {
+    if (m.cur_off == c.n_sym) {
       // the whole chunk is out: its crc segments
       size_t from = 0;
       for (size_t e = 0; e <= c.ends.size(); ++e) {
-        const size_t to = e < c.ends.size() ? (size_t)c.ends[e].out_off : c.bytes.size();
+        const size_t to = e < c.ends.size() ? (size_t)c.ends[e].out_off : c.n_sym;
         m.m_crc = (uint32_t)crc32_combine(m.m_crc, c.seg_crc[e], (z_off_t)(to - from));
         m.m_len += to - from;
         if (e < c.ends.size()) {
@@ -812,9 +879,9 @@ size_t GzipReader::read(char* dst, size_t n) {
       }
       const bool eof = c.at_eof;
       lk.lock();
-      std::vector<uint8_t>().swap(c.bytes);
+      m.bufs.give(c.bytes);
       // (the 32 KB windows stay: the chunks behind are cut from them)
-      if (c.window_done) std::vector<uint16_t>().swap(c.sym);
+      if (c.window_done) m.bufs.give(c.sym);
       ++m.cur;
       m.cur_off = 0;
       m.base = m.cur;

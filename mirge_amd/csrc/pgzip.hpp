@@ -18,7 +18,7 @@ namespace mrg {
 class GzipReader {
  public:
   // threads <= 1, a plain (not gzip) file or a file of less than two chunks: zlib's gzread.
-  // chunk_bytes: compressed bytes per chunk (0 = default 2 MiB; tests use small ones).
+  // chunk_bytes: compressed bytes per chunk (0 = default 1 MiB, less for small files; tests use small ones).
   GzipReader(const std::string& path, int threads, size_t chunk_bytes = 0);
   ~GzipReader();
   GzipReader(const GzipReader&) = delete;

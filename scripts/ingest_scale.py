@@ -76,12 +76,12 @@ def main():
         if torch.cuda.is_available():
             from mirge_amd.engine import Engine
             eng = Engine(0)
-            for name, path in (("plain", plain), ("gzip", gz)):
+            for name, path, ad in (("plain", plain, "none"), ("gzip", gz, "none"), ("illumina_adapter", trimmed, "illumina")):
                 for th in (4, 16, 32):
                     best = None
                     for _ in range(2):
                         t1 = time.perf_counter()
-                        fq = ingest.load_fastq_device(eng, path, adapter="none", read_threads=th)
+                        fq = ingest.load_fastq_device(eng, path, adapter=ad, read_threads=th)
                         torch.cuda.synchronize()
                         dt = time.perf_counter() - t1
                         assert fq["kept"] == n, (name, fq["kept"])

@@ -1,5 +1,7 @@
 """GPU parity (-m gpu): the HIP path, called through the C-ABI, against the
 oracle on the same seeded inputs.  Bit-exact: every array is integer."""
+import os
+
 import numpy as np
 import pytest
 
@@ -630,3 +632,62 @@ def test_c_abi_allreduce_single_rank(native_lib):
     torch.cuda.synchronize()
     assert torch.equal(t, want)
     eng.comm_destroy()
+
+
+_TWO_RANK_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+rank, world, uid_path = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+import time
+import torch
+from mirge_amd.engine import Engine
+eng = Engine(rank)                                   # one process per GPU
+if rank == 0:
+    uid = Engine.comm_unique_id()
+    with open(uid_path + ".tmp", "wb") as fh:
+        fh.write(uid)
+    os.replace(uid_path + ".tmp", uid_path)
+else:
+    for _ in range(600):
+        if os.path.exists(uid_path):
+            break
+        time.sleep(0.1)
+    uid = open(uid_path, "rb").read()
+eng.comm_init(uid, rank, world)
+t = (torch.arange(5000, dtype=torch.int64, device=eng.device) + 1) * (rank + 1)
+eng.allreduce(t)
+torch.cuda.synchronize()
+want = (torch.arange(5000, dtype=torch.int64) + 1) * sum(r + 1 for r in range(world))
+assert torch.equal(t.cpu(), want), "rank %d: all-reduce sum is wrong" % rank
+eng.comm_destroy()
+print("rank %d ok" % rank)
+'''
+
+
+@pytest.mark.gpu
+def test_c_abi_allreduce_two_ranks_over_rccl(native_lib, tmp_path):
+    """mrg_comm_init / mrg_allreduce with world = 2: two processes, one GPU each, the unique id through a
+    file, the fused count vector's reduce (SURVEY.md 8e) over RCCL.  Runs whenever the box shows two
+    devices (the round's one-GPU boxes skip it: the multi-GPU path is then covered by the gloo tests only)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    worker = tmp_path / "worker.py"
+    worker.write_text(_TWO_RANK_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(worker), root, str(r), "2", str(tmp_path / "uid")], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=300)
+            outs.append(out)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)
