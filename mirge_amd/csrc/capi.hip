@@ -658,7 +658,7 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     if (value < 1 || value > 100) return fail(MRG_ERR_ARG, "grid_pct must be in [1,100]");
     ctx->grid_pct = value;
   } else if (k == "seed_impl") {
-    if (value < -1 || value > 4) return fail(MRG_ERR_ARG, "seed_impl must be in [-1,4]");
+    if (value < -1 || value > 2) return fail(MRG_ERR_ARG, "seed_impl must be in [-1,2]");
     ctx->seed_impl = value;
   } else if (k == "seed_units") {
     ctx->seed_units = value != 0;
@@ -1474,7 +1474,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     {
       const int64_t impl = ctx->seed_impl >= 0 ? ctx->seed_impl : (small ? 0 : 2);
       sp.impl = impl ? 1u : 0u;
-      sp.wave_regs = impl >= 2 ? (uint32_t)(impl - 1) : 0u;  // 2: more registers, 3: lockstep (experiment), 4: both
+      sp.wave_regs = impl >= 2 ? 1u : 0u;
       for (uint32_t q = first; q < end; ++q)
         ctx->last_variant[q] = (sp.impl ? ((sp.wave_regs & 1u) ? 2u : 1u) : 0u) | ((have_list && list_fat) ? 4u : 0u);
     }

@@ -1527,7 +1527,6 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
   // (one trip more than there are chunks: the last one has no reads and works off what is still parked)
   for (uint32_t chunk = blockIdx.x;; chunk += gridDim.x) {
     const bool last_trip = chunk >= n_chunks;
-    if (p.wave_regs & 2u) __syncthreads();  // (experiment: the workgroup's waves kept on the same chunk)
     const bool active = act_b;
     const uint32_t r = r_b, L0 = active ? L_b : 255u;
     const uint64_t rd = rd_b;
@@ -2051,8 +2050,7 @@ __global__ void __launch_bounds__(kSeedThreads, 5) pair_wave_kernel(const MatchP
       }
     }
     // ---- three rounds: pair (0,1); (2,3) for best > 0 mismatches; the other four for best > 1 ----
-    const uint32_t dbg_rounds = p.wstop >= 1000u ? p.wstop - 1000u : 3u;  // (TEMPORARY timing knob: rounds run; results wrong below 3)
-    for (uint32_t round = 0; round < dbg_rounds; ++round) {
+    for (uint32_t round = 0; round < 3u; ++round) {
       const uint32_t pr_lo = round < 2u ? round : 2u, pr_hi = round < 2u ? round + 1u : 6u;
       uint32_t n_it = 0;
       wave_lds_sync();

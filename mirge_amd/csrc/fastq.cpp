@@ -200,7 +200,26 @@ struct Batch {
   uint32_t max_len = 0;
   bool has_n = false;
   std::string error;
-  std::vector<char> raw;      // the block's text (whole records), split by a worker
+  // the block's text (whole records), split by a worker: the reader inflates / reads straight into it (no zero fill,
+  // no second copy: at 4-5 GB/s of text the reader thread is what bounds a plain or parallel-gzip file)
+  struct Raw {
+    std::unique_ptr<char[]> p;
+    size_t n = 0, cap = 0;
+    char* data() { return p.get(); }
+    const char* data() const { return p.get(); }
+    size_t size() const { return n; }
+    void reserve(size_t want, size_t keep) {
+      if (want <= cap) return;
+      std::unique_ptr<char[]> q(new char[want]);
+      if (keep) std::memcpy(q.get(), p.get(), keep);
+      p = std::move(q);
+      cap = want;
+    }
+    void release() {
+      p.reset();
+      n = cap = 0;
+    }
+  } raw;
   uint64_t n_records = 0;
   uint64_t bad_record = 0;    // 1-based number (inside the block) of an ill-formed record
   int bad_kind = 0;           // 1 no '@', 2 truncated, 3 sequence / quality lengths differ
@@ -319,7 +338,7 @@ void split_block(Batch& b, bool* any_hi_first1000) {
     b.off.push_back((uint32_t)b.seq.size());
     pos = nx;
   }
-  std::vector<char>().swap(b.raw);
+  b.raw.release();
 }
 
 }  // namespace
@@ -385,12 +404,21 @@ void load_fastq(const std::string& path, int qual_cutoff, int min_len, const cha
 
   // (gzip samples: inflated by `threads` workers, pgzip.cpp; plain text and threads = 1: zlib's reader)
   GzipReader f(path, threads);
-  std::vector<char> buf;
+  // the batch being filled: the reader reads straight into its buffer; what lies behind the last record boundary
+  // starts the next batch
+  std::unique_ptr<Batch> cur(new Batch());
+  cur->raw.reserve(kBlockBytes + (1u << 20), 0);
   size_t have = 0;
   bool at_eof = false, started = false;
   auto hand_over = [&](size_t n_bytes) {
-    std::unique_ptr<Batch> bt(new Batch());
-    bt->raw.assign(buf.data(), buf.data() + n_bytes);
+    std::unique_ptr<Batch> next(new Batch());
+    const size_t tail = have - n_bytes;
+    next->raw.reserve(std::max<size_t>(kBlockBytes + (1u << 20), tail + kBlockBytes), 0);
+    if (tail) std::memcpy(next->raw.data(), cur->raw.data() + n_bytes, tail);
+    cur->raw.n = n_bytes;
+    std::unique_ptr<Batch> bt = std::move(cur);
+    cur = std::move(next);
+    have = tail;
     if (!started) {
       // trim_file.py:104-106 sniffs the first 1000 records for a quality character > 'J' (74); the
       // trimming workers are created while the first record is being read (:107-110), so only
@@ -423,28 +451,29 @@ void load_fastq(const std::string& path, int qual_cutoff, int min_len, const cha
       batches.push_back(std::move(bt));
     }
     cv.notify_one();
-    std::memmove(buf.data(), buf.data() + n_bytes, have - n_bytes);
-    have -= n_bytes;
+  };
+  auto read_more = [&](size_t until) {  // fill the current batch up to `until` bytes (or the end of the file)
+    while (!at_eof && have < until) {
+      if (cur->raw.cap < until) cur->raw.reserve(until + (1u << 20), have);
+      const size_t got = f.read(cur->raw.data() + have, std::min<size_t>(cur->raw.cap - have, 1u << 30));
+      if (got == 0) at_eof = true;
+      have += got;
+    }
   };
   for (;;) {
     // the first block must hold the 1000 records the quality sniff looks at
     const size_t want = started ? kBlockBytes : std::max<size_t>(kBlockBytes, 1u << 20);
-    while (!at_eof && have < want) {
-      if (buf.size() < have + (1u << 20)) buf.resize(std::max<size_t>(buf.size() * 2, have + (2u << 20)));
-      const size_t got = f.read(buf.data() + have, std::min<size_t>(buf.size() - have, 1u << 30));
-      if (got == 0) at_eof = true;
-      have += (size_t)got;
-    }
+    read_more(want);
     if (at_eof) {
       if (have) hand_over(have);
       break;
     }
-    size_t cut = last_record_start(buf.data(), have);
+    size_t cut = last_record_start(cur->raw.data(), have);
     if (!started) {
       // (at least 1000 records in the first block: count the lines before the cut)
       size_t lines = 0;
-      for (const char* q = buf.data(); cut && lines < 4004;) {
-        q = (const char*)std::memchr(q, '\n', buf.data() + cut - q);
+      for (const char* q = cur->raw.data(); cut && lines < 4004;) {
+        q = (const char*)std::memchr(q, '\n', cur->raw.data() + cut - q);
         if (!q) break;
         ++lines;
         ++q;
@@ -452,13 +481,7 @@ void load_fastq(const std::string& path, int qual_cutoff, int min_len, const cha
       if (cut && lines < 4004) cut = 0;
     }
     if (cut == 0) {  // no boundary yet (a record longer than the block, or a short first block): read on
-      const size_t more = have + kBlockBytes;
-      while (!at_eof && have < more) {
-        if (buf.size() < have + (1u << 20)) buf.resize(std::max<size_t>(buf.size() * 2, have + (2u << 20)));
-        const size_t got = f.read(buf.data() + have, std::min<size_t>(buf.size() - have, 1u << 30));
-        if (got == 0) at_eof = true;
-        have += (size_t)got;
-      }
+      read_more(have + kBlockBytes);
       if (at_eof) {
         if (have) hand_over(have);
         break;

@@ -86,3 +86,51 @@ def test_split_batch_with_an_empty_side(engine, world, keep):
     if keep == "n_only":
         res1 = engine.cascade(ReadSet(words[:1].copy(), lens, nmask[:1].copy(), None, device=engine.device), engine.mirge_passes())
         same(res1, ref)
+
+
+def test_which_kernels_serve_which_length_class(engine, world):
+    """Round 4: reads of 16..32 nt without N -- the reference's own length floor is 16 (trim_file.py:33) -- run the
+    cascade through the dictionary kernels (exact_dict_kernel, seed_kernel / wave_seed_kernel with the pair tables
+    of three anchors for the 16..19-nt reads' one-mismatch passes on a large library, pair_wave_kernel); reads
+    beyond 32 nt, reads with N and reads under 16 nt take the FM kernels.  Told from the per-pass statistics of
+    single-class batches: a batch of one class launches one cascade, and `lds_mode` / `variant` name its kernels."""
+    from mirge_amd.engine import ReadSet
+    clean = world.nmask[0] == 0
+    passes = engine.mirge_passes()
+    classes = {
+        "16..19": (world.lens >= 16) & (world.lens <= 19) & clean,
+        "20..32": (world.lens >= 20) & (world.lens <= 32) & clean,
+        "33..60": world.lens > 32,
+        "with N": (world.lens <= 32) & ~clean,
+    }
+    for name, mask in classes.items():
+        sel = np.flatnonzero(mask)
+        assert len(sel) > 50, name
+        words = np.ascontiguousarray(world.words[:, sel])
+        lens = np.ascontiguousarray(world.lens[sel])
+        nmask = np.ascontiguousarray(world.nmask[:, sel])
+        ref = model.fm_cascade(world.views, world.passes, words, lens, nmask, wstop=DEFAULT_WSTOP, ftab=True)
+        if name in ("16..19", "20..32"):   # what a trimmed small-RNA batch is: one word per read, no N mask
+            words, nmask = np.ascontiguousarray(words[:1]), None
+        res = engine.cascade(ReadSet(words, lens, nmask, None, device=engine.device), passes)
+        same(res, ref)
+        st = res.stats
+        launched = [s for s in st if s["n_launches"]]
+        if name in ("16..19", "20..32"):
+            # (the hairpin pass, len > 25, is skipped by the hint for the short class)
+            assert st[0]["lds_mode"] == 7, name                                  # exact_dict_kernel
+            assert st[2]["lds_mode"] in (8, 9) and st[7]["lds_mode"] in (8, 9), name   # seed launches
+            assert st[2]["variant"] & 3 == 0, name                               # the small libraries: seed_kernel (tiles)
+            assert st[7]["variant"] & 3 == 2, name                               # the large one (mRNA, 6.8 Mbp here): wave_seed_kernel, 96 registers
+            assert st[8]["lds_mode"] == 11, name                                 # pair_wave_kernel
+            assert all(s["ms_rest"] == 0 and s["n_launches"] <= 1 for s in st), name   # one cascade: nothing went to the FM kernels
+            if name == "16..19":
+                assert st[8]["pair_anchor"] == 4
+                # (the pair tables of three anchors for these reads' one-mismatch passes on a LARGE library are exercised
+                # by tests/test_gpu_dict.py::test_seed_buckets_and_jump_tables_on_a_large_library)
+        elif name == "33..60":
+            assert all(s["lds_mode"] not in (7, 8, 9, 11) for s in launched), name   # match / fused / stratum kernels only
+        else:
+            # reads with N of at most 32 nt: the mask says "some read has an N", not which -- the batch is split on the
+            # device, every read lands on the FM side (its cascade does the work), the one-word list stays empty
+            assert st[0]["n_launches"] == 2 and st[0]["ms_rest"] > 0, name
