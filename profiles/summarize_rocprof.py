@@ -25,7 +25,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-CASCADE_KERNELS = ("match_kernel", "fused_kernel", "stratum_kernel", "exact_dict_kernel", "seed_kernel")   # one launch per entry of the bench line's plan
+CASCADE_KERNELS = ("match_kernel", "fused_kernel", "stratum_kernel", "exact_dict_kernel", "seed_kernel", "pair_wave_kernel")   # one launch per entry of the bench line's plan (seed_kernel also matches wave_seed_kernel)
 
 
 def newest(pattern):

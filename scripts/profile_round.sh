@@ -21,6 +21,12 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$
 # ... and of the exact (BASELINE configs[1], the roofline configuration) and varlen workloads
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_exact_stats -- $B --workload exact --steps 20 --warmup 2 > gpurun_out/${tag}_exact_stats.json 2> gpurun_out/${tag}_exact_stats.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_varlen_stats -- $B --workload varlen --steps 5 --warmup 1 > gpurun_out/${tag}_varlen_stats.json 2> gpurun_out/${tag}_varlen_stats.err
+# HBM traffic of the exact (BASELINE configs[1]: where the 40 % target is quoted) and a2i legs, for roofline.traffic of those lines
+for wl in exact a2i; do
+  st="--steps 1 --warmup 0"
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_${wl}_fetch -- $B --workload $wl $st > /dev/null 2> gpurun_out/${tag}_${wl}_fetch.err
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_${wl}_write -- $B --workload $wl $st > /dev/null 2> gpurun_out/${tag}_${wl}_write.err
+done
 # the bench lines proper (no profiler attached)
 python bench.py 2> gpurun_out/${tag}_bench_cascade.err > gpurun_out/${tag}_bench_cascade.json
 python bench.py --workload exact 2> gpurun_out/${tag}_bench_exact.err > gpurun_out/${tag}_bench_exact.json
