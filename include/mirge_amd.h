@@ -190,13 +190,21 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * reads shorter than the key take the FM index); "seed_units" = 1 (default) / 0: in such batches the runs
  * of passes with at most one seed mismatch after the first launch go through seed_kernel (libraries of at
  * most 4 Mbp searched with one policy as ONE index of their concatenation, built when a cascade first
- * plans it); "split_mixed" = 1 (default) / 0 and "split_min_len" = 20 (default) / 0..32: a batch with more
+ * plans it); "split_mixed" = 1 (default) / 0 and "split_min_len" = 16 (default: the reference's own length floor, trim_file.py:33; round 3: 20) / 0..32: a batch with more
  * than one word per read, an N mask, or (by the length hint) reads under split_min_len nt -- unless the hint
  * puts every read on one side: all longer than 32 nt, or all under split_min_len -- is split on the
  * device into the reads of split_min_len .. 32 nt without N, which run the cascade through the dictionary
  * kernels as the one-word batch they are, and the rest, which runs it through the FM kernels first -- two
  * cascades over disjoint lists adding to the same counters (mrg_pass_stats then names the kernels and times
  * of the second one, ms_rest the times of the first, n_launches counts both);
+ * (round 4) "dict_max_bases" = 1 << 22 (default): libraries up to this size get an exact-match dictionary;
+ * raise it (e.g. 1 << 30) BEFORE adding a large library that a pass searches without seed mismatch (mRNA
+ * `-n 0`, runAnnotationPipeline.py:584/598) -- 16 B x 2..4 slots per base of HBM, skipped when less than that
+ * + 8 GB is free -- and that pass becomes one 16-byte gather per read; "seed_impl" = -1 (default: seed_kernel
+ * for a launch on small libraries, wave_seed_kernel with 96 registers for one on large libraries) / 0
+ * seed_kernel / 1, 2 wave_seed_kernel (64-80 / 80-96 registers); "pair_impl" = 1 (default) / 0: the anchor-pair
+ * search of one-word batches in pair_wave_kernel / stratum_kernel; "grid_pct" = 100 (default) / 1..100: every
+ * cascade launch with this share of its workgroups (room for another cascade's launches on another stream);
  * "wide_rows_16", "round_large": see DESIGN.md. */
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);
 int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,
