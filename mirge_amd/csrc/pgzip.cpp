@@ -30,11 +30,12 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
-#include <future>
 #include <mutex>
 #include <stdexcept>
 #include <thread>
@@ -243,6 +244,160 @@ size_t parse_gzip_header(const uint8_t* p, size_t n, size_t off) {
   return q < n ? q : 0;
 }
 
+// ------------------------------------------------------------------ symbols -> bytes, CRC-32
+// The resolve stage was a third of the reader's CPU time (2 ns per byte: a branch per symbol, then zlib's table-driven
+// crc32 over the bytes).  Markers only sit near a chunk's front, so 16 symbols at a time are packed with one SSE2
+// instruction when none of them is a marker; the CRC-32 (gzip's polynomial) is folded 64 bytes at a time with carry-less
+// multiplication (the published PCLMULQDQ scheme: Gopal et al., "Fast CRC Computation for Generic Polynomials Using
+// PCLMULQDQ"), checked against zlib's crc32 once at start-up and left to zlib when the CPU lacks the instruction.
+#if defined(__x86_64__)
+#include <immintrin.h>
+#define MRG_X86 1
+#else
+#define MRG_X86 0
+#endif
+
+// bytes[i] = sym[i] < 0x8000 ? sym[i] : window[sym[i] & 0x7FFF]; returns false when a marker meets no window
+bool resolve_symbols(const uint16_t* sym, size_t n, const uint8_t* window, uint8_t* bytes) {
+  size_t i = 0;
+#if MRG_X86
+  for (; i + 16 <= n; i += 16) {
+    const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(sym + i));
+    const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(sym + i + 8));
+    if ((_mm_movemask_epi8(_mm_or_si128(a, b)) & 0xAAAA) == 0) {  // no symbol has its top bit set: sixteen literals
+      _mm_storeu_si128(reinterpret_cast<__m128i*>(bytes + i), _mm_packus_epi16(a, b));
+      continue;
+    }
+    for (size_t j = i; j < i + 16; ++j) {
+      const uint16_t v = sym[j];
+      if (v & 0x8000u) {
+        if (!window) return false;
+        bytes[j] = window[v & 0x7FFFu];
+      } else {
+        bytes[j] = (uint8_t)v;
+      }
+    }
+  }
+#endif
+  for (; i < n; ++i) {
+    const uint16_t v = sym[i];
+    if (v & 0x8000u) {
+      if (!window) return false;
+      bytes[i] = window[v & 0x7FFFu];
+    } else {
+      bytes[i] = (uint8_t)v;
+    }
+  }
+  return true;
+}
+
+#if MRG_X86
+// CRC-32 (reflected, polynomial 0xEDB88320) of p[0, len), len a multiple of 16 and >= 64, continuing from `crc`
+// (the raw register: pre- and post-inversion are the caller's)
+__attribute__((target("pclmul,sse4.1"))) uint32_t crc32_clmul_blocks(const uint8_t* p, size_t len, uint32_t crc) {
+  const __m128i k1k2 = _mm_set_epi64x(0x01c6e41596ll, 0x0154442bd4ll);
+  const __m128i k3k4 = _mm_set_epi64x(0x00ccaa009ell, 0x01751997d0ll);
+  const __m128i k5k0 = _mm_set_epi64x(0x0000000000ll, 0x0163cd6124ll);
+  const __m128i poly = _mm_set_epi64x(0x01f7011641ll, 0x01db710641ll);
+  __m128i x0, x1, x2, x3, x4, x5, x6, x7, x8, y5, y6, y7, y8;
+  x1 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p + 0x00));
+  x2 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p + 0x10));
+  x3 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p + 0x20));
+  x4 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p + 0x30));
+  x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)crc));
+  x0 = k1k2;
+  p += 64;
+  len -= 64;
+  while (len >= 64) {  // four lanes of 16 bytes, folded 64 bytes ahead
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
+    x7 = _mm_clmulepi64_si128(x3, x0, 0x00);
+    x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
+    x3 = _mm_clmulepi64_si128(x3, x0, 0x11);
+    x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+    y5 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p + 0x00));
+    y6 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p + 0x10));
+    y7 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p + 0x20));
+    y8 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p + 0x30));
+    x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), y5);
+    x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), y6);
+    x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), y7);
+    x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), y8);
+    p += 64;
+    len -= 64;
+  }
+  x0 = k3k4;  // the four lanes into one
+  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+  x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+  x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+  x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+  while (len >= 16) {  // single blocks
+    x2 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p));
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
+    x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+    p += 16;
+    len -= 16;
+  }
+  // 128 -> 64 bits
+  x2 = _mm_clmulepi64_si128(x1, x0, 0x10);
+  x3 = _mm_setr_epi32(~0, 0, ~0, 0);
+  x1 = _mm_srli_si128(x1, 8);
+  x1 = _mm_xor_si128(x1, x2);
+  x0 = k5k0;
+  x2 = _mm_srli_si128(x1, 4);
+  x1 = _mm_and_si128(x1, x3);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_xor_si128(x1, x2);
+  // Barrett reduction 64 -> 32 bits
+  x0 = poly;
+  x2 = _mm_and_si128(x1, x3);
+  x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
+  x2 = _mm_and_si128(x2, x3);
+  x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+  x1 = _mm_xor_si128(x1, x2);
+  return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+#endif
+
+// zlib's crc32(crc, p, len) (same value), through carry-less multiplication where the CPU has it and the start-up
+// check against zlib agreed
+uint32_t fast_crc32(uint32_t crc, const uint8_t* p, size_t len) {
+#if MRG_X86
+  static const bool use_clmul = [] {
+    if (!__builtin_cpu_supports("pclmul") || !__builtin_cpu_supports("sse4.1")) return false;
+    uint8_t t[1024 + 7];
+    for (size_t i = 0; i < sizeof t; ++i) t[i] = (uint8_t)(i * 131u + (i >> 3) * 7u + 5u);
+    for (size_t n : {64u, 80u, 128u, 1008u, 1024u}) {
+      const uint32_t want = (uint32_t)crc32(0x1234567ul, t + 3, (uInt)n);
+      const uint32_t got = ~crc32_clmul_blocks(t + 3, n, ~0x1234567u);
+      if (want != got) return false;
+    }
+    return true;
+  }();
+  if (use_clmul && len >= 64) {
+    const size_t body = len & ~(size_t)15;
+    crc = ~crc32_clmul_blocks(p, body, ~crc);
+    p += body;
+    len -= body;
+  }
+#endif
+  while (len) {
+    const size_t m_ = std::min<size_t>(len, 1u << 30);
+    crc = (uint32_t)crc32(crc, p, (uInt)m_);
+    p += m_;
+    len -= m_;
+  }
+  return crc;
+}
+
 // ------------------------------------------------------------------ buffers
 // A chunk's symbols (16 MB and more) and bytes live in raw buffers that are recycled: std::vector would zero-fill
 // every growth and hand the pages back on release, and dozens of threads faulting fresh pages in and out of one
@@ -443,6 +598,18 @@ uint64_t find_block_start(const BitSrc& src, uint64_t from, uint64_t to) {
     // BFINAL = 0, BTYPE = 10b, HLIT <= 29, HDIST <= 29
     if ((bits & 7u) != 4u) continue;
     if (((bits >> 3) & 31u) > 29u || ((bits >> 8) & 31u) > 29u) continue;
+    {
+      // the code-length code must be complete (Kraft sum of its up to 19 three-bit lengths): decided from the bits in
+      // hand, before any table is built -- one position in nine gets this far, one in a few hundred beyond
+      const uint32_t hclen = (uint32_t)((bits >> 13) & 15u) + 4u;
+      uint64_t cb = src.peek(pos + 17);
+      uint32_t kraft = 0;
+      for (uint32_t i = 0; i < hclen; ++i) {
+        const uint32_t l = (uint32_t)(cb >> (3u * i)) & 7u;
+        kraft += l ? (128u >> l) : 0u;
+      }
+      if (kraft != 128u) continue;
+    }
     uint64_t p = pos + 3;
     if (!read_dynamic_header(src, p, bc, true)) continue;
     // a few hundred symbols: text-like literals, legal lengths and distances
@@ -502,7 +669,7 @@ struct GzipReader::Impl {
   size_t map_len = 0;
   BitSrc src;
   std::vector<Chunk> chunks;
-  BufPool bufs;
+  BufPool bufs, byte_bufs;  // (symbol buffers are seven times the byte buffers: one pool each, or every take reallocates)
   size_t lookahead = 0;
   std::mutex mu;
   std::condition_variable cv_work, cv_ready;
@@ -527,6 +694,16 @@ struct GzipReader::Impl {
     cv_work.notify_all();
     for (auto& t : pool)
       if (t.joinable()) t.join();
+    {
+      std::lock_guard<std::mutex> lk(copy_mu);
+      copy_stop = true;
+    }
+    copy_cv.notify_all();
+    for (auto& t : copiers)
+      if (t.joinable()) t.join();
+    if (std::getenv("MIRGE_AMD_GZ_PROFILE"))
+      std::fprintf(stderr, "[pgzip] reader: %.3f s waiting, %.3f s copying; workers (summed): find %.3f s, decode %.3f s, window %.3f s, resolve %.3f s\n",
+                   t_wait, t_copy, us_find.load() / 1e6, us_decode.load() / 1e6, us_window.load() / 1e6, us_resolve.load() / 1e6);
     for (Chunk& c : chunks) {
       c.sym.release();
       c.bytes.release();
@@ -549,7 +726,60 @@ struct GzipReader::Impl {
     return false;
   }
 
+  // ---- copy helpers: the reader's memcpy out of a chunk, split four ways ----
+  static constexpr int kCopiers = 3;
+  struct CopyJob {
+    char* dst = nullptr;
+    const uint8_t* src = nullptr;
+    size_t len = 0;
+    uint64_t posted = 0;             // generation the reader posted
+    std::atomic<uint64_t> done{0};   // generation the helper finished
+  } copy_jobs[kCopiers];
+  std::mutex copy_mu;
+  std::condition_variable copy_cv;
+  std::vector<std::thread> copiers;
+  bool copy_stop = false;
+  void copier(int id) {
+    uint64_t seen = 0;
+    for (;;) {
+      CopyJob& j = copy_jobs[id];
+      {
+        std::unique_lock<std::mutex> lk(copy_mu);
+        copy_cv.wait(lk, [&] { return copy_stop || j.posted != seen; });
+        if (copy_stop) return;
+        seen = j.posted;
+      }
+      std::memcpy(j.dst, j.src, j.len);
+      j.done.store(seen, std::memory_order_release);
+    }
+  }
+  void copy_out(char* dst, const uint8_t* src, size_t len) {
+    if (len < (256u << 10) || copiers.empty()) {
+      std::memcpy(dst, src, len);
+      return;
+    }
+    const size_t step = (len / (kCopiers + 1)) & ~(size_t)4095;
+    uint64_t gen;
+    {
+      std::lock_guard<std::mutex> lk(copy_mu);
+      gen = copy_jobs[0].posted + 1;
+      for (int q = 0; q < kCopiers; ++q) {
+        copy_jobs[q].dst = dst + (size_t)q * step;
+        copy_jobs[q].src = src + (size_t)q * step;
+        copy_jobs[q].len = step;
+        copy_jobs[q].posted = gen;
+      }
+    }
+    copy_cv.notify_all();
+    std::memcpy(dst + (size_t)kCopiers * step, src + (size_t)kCopiers * step, len - (size_t)kCopiers * step);
+    for (int q = 0; q < kCopiers; ++q)
+      while (copy_jobs[q].done.load(std::memory_order_acquire) != gen) std::this_thread::yield();
+  }
+
+  double t_wait = 0, t_copy = 0;  // reader: seconds waiting for chunks / copying them out (MIRGE_AMD_GZ_PROFILE prints them)
+  std::atomic<uint64_t> us_find{0}, us_decode{0}, us_window{0}, us_resolve{0};
   size_t next_find = 1;  // chunks below it have their find done or running
+  size_t win_cur = 0, res_cur = 0, dec_cur = 0;  // cursors of the chain, the resolves and the decodes (worker())
 
   // runs chunk k's find here unless it is done or another thread has it (then waits for that one); lk held on entry and exit
   void ensure_find(std::unique_lock<std::mutex>& lk, size_t k) {
@@ -576,30 +806,40 @@ struct GzipReader::Impl {
     std::unique_lock<std::mutex> lk(mu);
     for (;;) {
       if (stop) return;
-      // ---- the most urgent runnable task ----
+      // ---- the most urgent runnable task; cursors keep a pick O(1): with a scan of the look-ahead window under
+      // the one mutex, 64 workers woken by every state change spent more time in the lock than a chunk takes
+      // to decode (the reader stopped scaling at 16 threads, 3 GB/s) ----
       const size_t hi = std::min(chunks.size(), base + lookahead);
       int what = 0;  // 1 find, 2 decode, 3 window, 4 resolve
       size_t k = 0;
-      // the chain first (everything behind waits for it): the first live, decoded chunk without a window
-      for (size_t j = base; j < hi; ++j) {
-        Chunk& c = chunks[j];
-        if (c.find_done && c.dropped) continue;
-        if (c.window_done) continue;
+      if (win_cur < base) win_cur = base;
+      if (res_cur < base) res_cur = base;
+      if (dec_cur < base) dec_cur = base;
+      // the chain first (everything behind waits for it): the first live chunk without a window
+      while (win_cur < chunks.size() && ((chunks[win_cur].find_done && chunks[win_cur].dropped) || chunks[win_cur].window_done)) ++win_cur;
+      if (win_cur < hi) {
+        Chunk& c = chunks[win_cur];
         size_t pv = 0;
         if (c.decode_done && c.error.empty() && !c.windowing &&
-            (j == 0 || c.clean_start || (prev_live(j, pv) && chunks[pv].window_done))) {
+            (win_cur == 0 || c.clean_start || (prev_live(win_cur, pv) && chunks[pv].window_done))) {
           what = 3;
-          k = j;
+          k = win_cur;
         }
-        break;
       }
-      for (size_t j = base; j < hi && !what; ++j) {
-        Chunk& c = chunks[j];
-        if (c.dropped || !c.decode_done || !c.error.empty() || c.resolving || c.resolve_done) continue;
-        size_t pv = 0;
-        if (j == 0 || c.clean_start || (prev_live(j, pv) && chunks[pv].window_done)) {
-          what = 4;
-          k = j;
+      // resolve: every decoded chunk up to the chain's position has its window in front of it
+      if (!what) {
+        while (res_cur < chunks.size() && (chunks[res_cur].dropped || chunks[res_cur].resolving || chunks[res_cur].resolve_done) &&
+               (chunks[res_cur].find_done || chunks[res_cur].resolve_done))
+          ++res_cur;
+        for (size_t j = res_cur; j < hi && j <= win_cur; ++j) {
+          Chunk& c = chunks[j];
+          if (c.dropped || !c.decode_done || !c.error.empty() || c.resolving || c.resolve_done) continue;
+          size_t pv = 0;
+          if (j == 0 || c.clean_start || (prev_live(j, pv) && chunks[pv].window_done)) {
+            what = 4;
+            k = j;
+            break;
+          }
         }
       }
       while (!what && next_find < chunks.size() && (chunks[next_find].find_done || chunks[next_find].busy)) ++next_find;
@@ -607,15 +847,22 @@ struct GzipReader::Impl {
         what = 1;
         k = next_find++;
       }
-      for (size_t j = base; j < hi && !what; ++j) {
-        Chunk& c = chunks[j];
-        if (c.dropped || !c.find_done || c.busy || c.decode_done) continue;
-        // the next chunks' finds should be known: the decoder stops at the first live start behind it
-        bool known = true;
-        for (size_t q = j + 1; q < std::min(chunks.size(), j + 3); ++q) known &= chunks[q].find_done;
-        if (known) {
-          what = 2;
-          k = j;
+      if (!what) {
+        while (dec_cur < chunks.size() && ((chunks[dec_cur].find_done && chunks[dec_cur].dropped) || chunks[dec_cur].decode_done ||
+                                            (chunks[dec_cur].find_done && chunks[dec_cur].busy)))
+          ++dec_cur;
+        for (size_t j = dec_cur; j < hi; ++j) {
+          Chunk& c = chunks[j];
+          if (!c.find_done) break;  // (finds complete in order of their start: nothing behind is ready either)
+          if (c.dropped || c.busy || c.decode_done) continue;
+          // the next chunks' finds should be known: the decoder stops at the first live start behind it
+          bool known = true;
+          for (size_t q = j + 1; q < std::min(chunks.size(), j + 3); ++q) known &= chunks[q].find_done;
+          if (known) {
+            what = 2;
+            k = j;
+          }
+          break;
         }
       }
       if (!what) {
@@ -623,6 +870,12 @@ struct GzipReader::Impl {
         continue;
       }
       Chunk& c = chunks[k];
+      const auto tt0 = std::chrono::steady_clock::now();
+      struct Tick {
+        std::atomic<uint64_t>* to;
+        std::chrono::steady_clock::time_point t0;
+        ~Tick() { *to += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); }
+      } tick{what == 1 ? &us_find : what == 2 ? &us_decode : what == 3 ? &us_window : &us_resolve, tt0};
       if (what == 1) {
         ensure_find(lk, k);
       } else if (what == 2) {
@@ -718,32 +971,15 @@ struct GzipReader::Impl {
         std::string err;
         const size_t n = c.n_sym;
         const uint16_t* sym = static_cast<const uint16_t*>(c.sym.p);
-        RawBuf bb = bufs.take();
+        RawBuf bb = byte_bufs.take();
         bb.ensure(n + 64, 0);
         uint8_t* bytes = static_cast<uint8_t*>(bb.p);
-        for (size_t i = 0; i < n; ++i) {
-          const uint16_t v = sym[i];
-          if (v & 0x8000u) {
-            if (!pw) {
-              err = "distance beyond the start of the gzip stream";
-              break;
-            }
-            bytes[i] = pw[v & 0x7FFFu];
-          } else {
-            bytes[i] = (uint8_t)v;
-          }
-        }
+        if (!resolve_symbols(sym, n, pw, bytes)) err = "distance beyond the start of the gzip stream";
         std::vector<uint32_t> seg_crc;
         size_t seg_from = 0;
         for (size_t e = 0; e <= c.ends.size(); ++e) {
           const size_t to = e < c.ends.size() ? (size_t)c.ends[e].out_off : n;
-          uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
-          for (size_t o = seg_from; o < to;) {  // (crc32 takes a 32-bit length)
-            const size_t m_ = std::min<size_t>(to - o, 1u << 30);
-            crc = (uint32_t)crc32(crc, bytes + o, (uInt)m_);
-            o += m_;
-          }
-          seg_crc.push_back(crc);
+          seg_crc.push_back(fast_crc32((uint32_t)crc32(0L, Z_NULL, 0), bytes + seg_from, to - seg_from));
           seg_from = to;
         }
         lk.lock();
@@ -805,6 +1041,8 @@ GzipReader::GzipReader(const std::string& path, int threads, size_t chunk_bytes)
         m.chunks[0].clean_start = true;
         m.lookahead = std::max<size_t>(8, 2 * (size_t)threads + 4);
         for (int t = 0; t < threads; ++t) m.pool.emplace_back([&m] { m.worker(); });
+        if (threads >= 8)
+          for (int q = 0; q < Impl::kCopiers; ++q) m.copiers.emplace_back([&m, q] { m.copier(q); });
       }
     }
     if (!par) {
@@ -853,28 +1091,20 @@ size_t GzipReader::read(char* dst, size_t n) {
       break;
     }
     Chunk& c = m.chunks[m.cur];
+    const auto tw0 = std::chrono::steady_clock::now();
     m.cv_ready.wait(lk, [&] { return (c.find_done && c.dropped) || (c.resolve_done && c.window_done) || (c.decode_done && !c.error.empty()); });
+    m.t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
     if (c.find_done && c.dropped) continue;  // (swallowed by the chunk in front while we waited)
     if (!c.error.empty()) throw std::runtime_error("corrupt gzip stream: " + c.error);
     lk.unlock();
     // hand out bytes, folding the member checks as their ends go by
     const size_t avail = c.n_sym - m.cur_off;
     const size_t take = std::min(avail, n - total);
-    {
-      // (a chunk's bytes were written by another core, often on the other socket: four threads copy a large piece)
-      const uint8_t* src = static_cast<const uint8_t*>(c.bytes.p) + m.cur_off;
-      constexpr size_t kPar = 4;
-      if (take >= (4u << 20)) {
-        std::future<void> parts[kPar - 1];
-        const size_t step = (take / kPar) & ~(size_t)4095;
-        for (size_t q = 0; q + 1 < kPar; ++q)
-          parts[q] = std::async(std::launch::async, [=] { std::memcpy(dst + total + q * step, src + q * step, step); });
-        std::memcpy(dst + total + (kPar - 1) * step, src + (kPar - 1) * step, take - (kPar - 1) * step);
-        for (auto& f : parts) f.get();
-      } else {
-        std::memcpy(dst + total, src, take);
-      }
-    }
+    // (a chunk's bytes were written by another core, often on the other socket: one thread copies them out at
+    // 3 GB/s, which capped the whole reader whatever the worker count; the copy helpers take three quarters of a piece)
+    const auto tc0 = std::chrono::steady_clock::now();
+    m.copy_out(dst + total, static_cast<const uint8_t*>(c.bytes.p) + m.cur_off, take);
+    m.t_copy += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
     total += take;
     m.cur_off += take;
     if (m.cur_off == c.n_sym) {
@@ -894,7 +1124,7 @@ size_t GzipReader::read(char* dst, size_t n) {
       }
       const bool eof = c.at_eof;
       lk.lock();
-      m.bufs.give(c.bytes);
+      m.byte_bufs.give(c.bytes);
       // (the 32 KB windows stay: the chunks behind are cut from them)
       if (c.window_done) m.bufs.give(c.sym);
       ++m.cur;
