@@ -993,7 +993,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       if (n) HIP_TRY(mrg::launch_exact_dict(e, grid, stream));
       ctx->last_launches[i] += 1;
       HIP_TRY(hipEventRecord(evs[i + 1], stream));
-      if (!have_list && n && ((uintptr_t)d_reads % 16 == 0) && ((uintptr_t)d_lens % 4 == 0)) out_init = true;  // (launch_exact_dict: the streaming instantiation)
+      if (n && mrg::exact_dict_streams(e)) out_init = true;  // (every output of the batch is written: later launches write claims only)
       if (e.idx_out) {
         cur_list = next_list;
         have_list = true;

@@ -2225,12 +2225,17 @@ hipError_t launch_seed(const SeedParams& p, uint32_t grid, hipStream_t stream) {
   return hipGetLastError();
 }
 
-hipError_t launch_exact_dict(const ExactParams& p, uint32_t grid, hipStream_t stream) {
-  // the streaming instantiation needs the identity list and arrays it can address 16 bytes at a time
+// the streaming instantiation needs the identity list and arrays it can address 16 bytes at a time; it writes EVERY output
+// of the batch (the "unannotated" values for what it does not claim)
+bool exact_dict_streams(const ExactParams& p) {
   const bool out_ok = p.packed ? ((uintptr_t)p.packed % 16 == 0)
                                : (((uintptr_t)p.pass_id % 4 == 0) && ((uintptr_t)p.mm % 4 == 0) && ((uintptr_t)p.ref_id % 16 == 0) &&
                                   ((uintptr_t)p.pos % 16 == 0));
-  const bool first = !p.idx_in && ((uintptr_t)p.reads % 16 == 0) && ((uintptr_t)p.lens % 4 == 0) && out_ok;
+  return !p.idx_in && ((uintptr_t)p.reads % 16 == 0) && ((uintptr_t)p.lens % 4 == 0) && out_ok;
+}
+
+hipError_t launch_exact_dict(const ExactParams& p, uint32_t grid, hipStream_t stream) {
+  const bool first = exact_dict_streams(p);
   const bool kb = p.kbits != nullptr && p.key_bases >= kKmerBitsK;
   if (first && kb) hipLaunchKernelGGL((exact_dict_kernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, p);
   else if (first) hipLaunchKernelGGL((exact_dict_kernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, p);

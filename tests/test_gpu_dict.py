@@ -212,3 +212,20 @@ def test_packed_cascade_and_tallies_equal_the_four_array_form(engine, world, nat
         eng2.add_library(k, w2.index[k])
     check(eng2, w2)
     eng2.close()
+
+
+def test_unaligned_outputs_take_the_non_streaming_first_pass(engine, world):
+    """The first pass's streaming instantiation writes EVERY output of the batch, and the launches behind it then
+    write claims only (round 4).  An output array it cannot address 16 bytes at a time gets the other instantiation,
+    which leaves the unclaimed reads to the cascade's last launch: same words either way, no stale value."""
+    import torch
+    from mirge_amd.engine import ReadSet
+    rs = ReadSet(world.words, world.lens, None, None, device=engine.device)
+    passes = engine.mirge_passes()
+    n = rs.n
+    want = engine.cascade_packed(rs, passes).packed.cpu().numpy()
+    big = torch.full((n + 8,), -1, dtype=torch.int32, device=engine.device)      # poisoned: a word nobody writes would show
+    counts = torch.zeros(2 * len(passes), dtype=torch.int64, device=engine.device)
+    got = engine.cascade_packed(rs, passes, out=(big[1:1 + n], counts)).packed.cpu().numpy()
+    assert np.array_equal(got, want)
+    assert int(big[0].item()) == -1 and int(big[n + 1].item()) == -1
