@@ -50,7 +50,7 @@ extern "C" {
 #define MRG_ERR_FORMAT (-6)
 
 #define MRG_MAX_PASSES 16
-#define MRG_MAX_WORDS 4 /* reads up to 128 nt */
+#define MRG_MAX_WORDS 8 /* reads up to 255 nt (the length is one byte) */
 
 typedef struct mrg_index mrg_index; /* host-side FM index of one library */
 typedef struct mrg_ctx mrg_ctx;     /* one per GPU: HBM copies + workspaces */
@@ -463,10 +463,10 @@ typedef struct mrg_fastq_info {
   uint64_t n_total;        /* records read ("totalReads") */
   uint64_t n_kept;         /* records kept after trimming ("trimmedReads") */
   int32_t phred;           /* 33 or 64, as trim_file.py:104-106 reports it */
-  uint32_t words_per_read; /* 1, 2 or 4 */
+  uint32_t words_per_read; /* 1, 2, 4 or 8 */
   uint32_t max_len;
   int32_t has_n;
-  uint64_t n_long;         /* kept reads longer than 128 nt (MRG_MAX_WORDS words): not among n_kept, not
+  uint64_t n_long;         /* kept reads longer than 255 nt (MRG_MAX_WORDS words, one length byte): not among n_kept, not
                               packed; read them with mrg_fastq_long_read.  The reference accepts any
                               length; the host carries these as unannotated reads */
 } mrg_fastq_info;
@@ -506,8 +506,8 @@ void mrg_fastq_free(mrg_fastq *fq);
  * blank line, no '+' line, sequence and quality of different length; 4: the line count is not a
  * multiple of four; 5: more kept reads than `cap`) means nothing was packed: use mrg_fastq_load,
  * which also accepts blank lines between records and words the errors as the reference's loader
- * does.  info.n_long = kept reads longer than 32 * words_per_read bases (not packed: call again with
- * more words).  An adapter SEQUENCE (`-ad illumina`, cutadapt's alignment) is host-only.
+ * does.  info.n_long = kept reads longer than min(32 * words_per_read, 255) bases (not packed: call again
+ * with more words, up to MRG_MAX_WORDS).  Adapter SEQUENCES (`-ad illumina`): mrg_fastq_parse_device_ad below.
  * Synchronises `stream`; at most 2^31 - 2 bytes per call.
  */
 typedef struct mrg_fastq_device_info {

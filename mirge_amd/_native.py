@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmirge_amd.so")
 
 MRG_MAX_PASSES = 16
-MRG_MAX_WORDS = 4
+MRG_MAX_WORDS = 8
 MRG_ERR_NO_DEVICE = -3
 
 

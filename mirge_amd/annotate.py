@@ -66,8 +66,8 @@ def runAnnotationPipeline(engine, seqDic, numCPU, phred64, annotNameList, output
         files["spike-in"] = file_spikeIn
     try:
         _ensure_libraries(engine, files)
-        # reads beyond the 128-nt packing limit stay unannotated (annot[0] = 0), as the CLI carries them
-        seqs = [s for s in seqDic.keys() if len(s) <= 128]
+        # reads beyond the 255-nt packing limit stay unannotated (annot[0] = 0), as the CLI carries them
+        seqs = [s for s in seqDic.keys() if len(s) <= 255]
         words, lens, nmask = pack.pack_reads(seqs) if seqs else \
             (np.zeros((1, 0), np.uint64), np.zeros(0, np.uint8), None)
         passes = engine.mirge_passes(spike_in=bool(spikeIn))

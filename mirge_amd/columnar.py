@@ -61,7 +61,7 @@ def write_read_tables(outdir, annot_names, sample_list, words, lens, nmask, quan
                       names_per_pass, extra_unmapped=None):
     """mapped.csv and unmapped.csv from the host arrays, in array order, without a Python row loop.
     extra_unmapped: {sequence: [count per sample]} of reads that never entered the arrays (reads
-    beyond the 128-nt packing limit), appended to unmapped.csv as unannotated rows."""
+    beyond the 255-nt packing limit), appended to unmapped.csv as unannotated rows."""
     lib = _native.load()
     words = np.ascontiguousarray(words, dtype=np.uint64)
     W, n = words.shape

@@ -805,8 +805,8 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   if (d_packed && n_pass > 15) return fail(MRG_ERR_ARG, "mrg_cascade_run_packed: at most 15 passes fit the packed word");
   if (n_pass == 0 || n_pass > MRG_MAX_PASSES)
     return fail(MRG_ERR_ARG, "mrg_cascade_run: n_pass %u not in [1,%d]", n_pass, MRG_MAX_PASSES);
-  if (words_per_read != 1 && words_per_read != 2 && words_per_read != 4)
-    return fail(MRG_ERR_ARG, "mrg_cascade_run: words_per_read must be 1, 2 or 4 (got %u)", words_per_read);
+  if (words_per_read != 1 && words_per_read != 2 && words_per_read != 4 && words_per_read != 8)
+    return fail(MRG_ERR_ARG, "mrg_cascade_run: words_per_read must be 1, 2, 4 or 8 (got %u)", words_per_read);
   if (n >= 0xfffffff0ull) return fail(MRG_ERR_ARG, "mrg_cascade_run: at most 2^32-16 reads per call");
   uint64_t need = 0;
   mrg_cascade_workspace_bytes(n, &need);
@@ -1898,8 +1898,8 @@ int edit_tally_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_re
   if (n && (!d_reads || !d_lens || (!d_packed && (!d_pass_id || !d_ref_id || !d_pos)) || !d_quant))
     return fail(MRG_ERR_ARG, "mrg_edit_tally_run: null buffers");
   if (lib < 0 || (size_t)lib >= ctx->libs.size()) return fail(MRG_ERR_ARG, "mrg_edit_tally_run: unknown library %d", lib);
-  if (words_per_read != 1 && words_per_read != 2 && words_per_read != 4)
-    return fail(MRG_ERR_ARG, "mrg_edit_tally_run: words_per_read must be 1, 2 or 4");
+  if (words_per_read != 1 && words_per_read != 2 && words_per_read != 4 && words_per_read != 8)
+    return fail(MRG_ERR_ARG, "mrg_edit_tally_run: words_per_read must be 1, 2, 4 or 8");
   if (n_samples == 0 || n_bins == 0 || from_base > 3 || to_base > 3 || from_base == to_base)
     return fail(MRG_ERR_ARG, "mrg_edit_tally_run: bad n_samples / n_bins / bases");
   const DevLib& l = ctx->libs[lib];
@@ -1997,8 +1997,8 @@ int fill_count_params(mrg_ctx* ctx, const char* who, const uint64_t* d_reads, ui
   if (!ctx) return fail(MRG_ERR_ARG, "%s: null argument", who);
   if (n && (!d_reads || !d_lens)) return fail(MRG_ERR_ARG, "%s: null buffers", who);
   if (lib < 0 || (size_t)lib >= ctx->libs.size()) return fail(MRG_ERR_ARG, "%s: unknown library %d", who, lib);
-  if (words_per_read != 1 && words_per_read != 2 && words_per_read != 4)
-    return fail(MRG_ERR_ARG, "%s: words_per_read must be 1, 2 or 4", who);
+  if (words_per_read != 1 && words_per_read != 2 && words_per_read != 4 && words_per_read != 8)
+    return fail(MRG_ERR_ARG, "%s: words_per_read must be 1, 2, 4 or 8", who);
   if (max_mm_seed < 0 || max_mm_seed > 2 || max_mm_total < max_mm_seed || seed_len < 1)
     return fail(MRG_ERR_ARG, "%s: invalid policy", who);
   if (n >= 0x7fffffffull) return fail(MRG_ERR_ARG, "%s: too many reads for one call", who);
@@ -2354,8 +2354,8 @@ int mrg_fastq_parse_device_ad(mrg_ctx* ctx, const char* d_text, uint64_t n_bytes
     }
   }
   if (n_bytes && (!d_text || !d_words || !d_lens)) return fail(MRG_ERR_ARG, "mrg_fastq_parse_device: null buffers");
-  if (words_per_read != 1 && words_per_read != 2 && words_per_read != 4)
-    return fail(MRG_ERR_ARG, "mrg_fastq_parse_device: words_per_read must be 1, 2 or 4");
+  if (words_per_read != 1 && words_per_read != 2 && words_per_read != 4 && words_per_read != 8)
+    return fail(MRG_ERR_ARG, "mrg_fastq_parse_device: words_per_read must be 1, 2, 4 or 8");
   if (phred != 33 && phred != 64) return fail(MRG_ERR_ARG, "mrg_fastq_parse_device: phred must be 33 or 64");
   if (n_bytes >= 0x7fffffffull) return fail(MRG_ERR_ARG, "mrg_fastq_parse_device: at most 2^31 - 2 bytes of text per call");
   HIP_TRY(hipSetDevice(ctx->device));

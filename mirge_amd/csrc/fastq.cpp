@@ -241,9 +241,9 @@ void trim_batch(Batch& b, const TrimSpec& spec, int qual_cutoff, int base, int m
       sq = tmp.data();
     }
     if ((int)stop < min_len) continue;
-    if (stop > 32 * 4) {
-      // longer than four packed words (e.g. `-ad none` on a 151-cycle run): the reference accepts
-      // any length, so the read is kept -- counted, listed as unannotated -- but not packed
+    if (stop > 255) {
+      // longer than the packed form holds (eight words, one length byte): the reference accepts any
+      // length, so the read is kept -- counted, listed as unannotated -- but not packed
       b.long_reads.emplace_back(sq, stop);
       continue;
     }
@@ -518,7 +518,7 @@ void load_fastq(const std::string& path, int qual_cutoff, int min_len, const cha
     out.max_len = std::max(out.max_len, batches[b]->max_len);
   }
   out.n_kept = first.back();
-  out.words_per_read = out.max_len <= 32 ? 1 : (out.max_len <= 64 ? 2 : 4);
+  out.words_per_read = out.max_len <= 32 ? 1 : (out.max_len <= 64 ? 2 : (out.max_len <= 128 ? 4 : 8));
   const uint32_t W = out.words_per_read;
   const uint64_t n = out.n_kept;
   out.words.assign((size_t)W * n, 0);

@@ -14,7 +14,7 @@ struct FastqData {
   bool has_n = false;
   std::vector<uint64_t> words, nmask;  // [W][n_kept]
   std::vector<uint8_t> lens;
-  // trimmed reads longer than 128 nt: survive trimming (they count towards "trimmedReads" on the
+  // trimmed reads longer than 255 nt: survive trimming (they count towards "trimmedReads" on the
   // host) but cannot be packed; the host carries them as unannotated reads
   std::vector<std::string> long_reads;
 };

@@ -304,7 +304,7 @@ hipError_t fastq_parse_device(const char* d_text, uint64_t n_bytes, int32_t phre
   }
   const uint32_t grid = (n_records + kIngestThreads - 1) / kIngestThreads;
   hipLaunchKernelGGL(ingest_trim_kernel, dim3(grid), dim3(kIngestThreads), 0, stream, d_text, n_bytes, (const uint32_t*)s_nl.p, n_nl,
-                     n_records, phred, cutoff, min_len, cut, ads, 32u * W, rec_start, rec_len, keep, (uint32_t*)s_info.p);
+                     n_records, phred, cutoff, min_len, cut, ads, 32u * W < 255u ? 32u * W : 255u /* one length byte */, rec_start, rec_len, keep, (uint32_t*)s_info.p);
   CK(hipGetLastError());
   // ---- output positions: exclusive prefix of the keep flags ----
   size_t scan_bytes = 0;

@@ -2270,6 +2270,7 @@ hipError_t launch_match(const MatchParams& p, uint32_t words_per_read, int lds_m
     case 1: return launch_match_w<1>(p, lds_mode, grid, lds_bytes, stream);
     case 2: return launch_match_w<2>(p, lds_mode, grid, lds_bytes, stream);
     case 4: return launch_match_w<4>(p, lds_mode, grid, lds_bytes, stream);
+    case 8: return launch_match_w<8>(p, lds_mode, grid, lds_bytes, stream);
     default: return hipErrorInvalidValue;
   }
 }
@@ -2290,6 +2291,7 @@ hipError_t launch_stratum(const MatchParams& p, uint32_t words_per_read, bool ld
     case 1: MRG_STRATUM(1) break;
     case 2: MRG_STRATUM(2) break;
     case 4: MRG_STRATUM(4) break;
+    case 8: MRG_STRATUM(8) break;
     default: return hipErrorInvalidValue;
   }
 #undef MRG_STRATUM
@@ -2317,6 +2319,7 @@ hipError_t launch_fused(const FusedParams& p, uint32_t words_per_read, uint32_t 
     case 1: MRG_FUSED(1) break;
     case 2: MRG_FUSED(2) break;
     case 4: MRG_FUSED(4) break;
+    case 8: MRG_FUSED(8) break;
     default: return hipErrorInvalidValue;
   }
 #undef MRG_FUSED_K
@@ -2344,9 +2347,10 @@ hipError_t launch_tally(const TallyParams& p, bool lds_hist, uint32_t grid,
 hipError_t launch_count(const CountParams& p, uint32_t words_per_read, uint32_t grid, uint32_t lds_bytes,
                         hipStream_t stream) {
   if (lds_bytes > 48 * 1024) {  // a genome part beyond ~200 Mbp: superblock table above the default dynamic-LDS cap
-    const void* kerns[6] = {reinterpret_cast<const void*>(count_kernel<1, true>), reinterpret_cast<const void*>(count_kernel<1, false>),
+    const void* kerns[8] = {reinterpret_cast<const void*>(count_kernel<1, true>), reinterpret_cast<const void*>(count_kernel<1, false>),
                             reinterpret_cast<const void*>(count_kernel<2, true>), reinterpret_cast<const void*>(count_kernel<2, false>),
-                            reinterpret_cast<const void*>(count_kernel<4, true>), reinterpret_cast<const void*>(count_kernel<4, false>)};
+                            reinterpret_cast<const void*>(count_kernel<4, true>), reinterpret_cast<const void*>(count_kernel<4, false>),
+                            reinterpret_cast<const void*>(count_kernel<8, true>), reinterpret_cast<const void*>(count_kernel<8, false>)};
     for (const void* k : kerns) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) return e;
@@ -2361,6 +2365,7 @@ hipError_t launch_count(const CountParams& p, uint32_t words_per_read, uint32_t 
     case 1: MRG_COUNT(1) break;
     case 2: MRG_COUNT(2) break;
     case 4: MRG_COUNT(4) break;
+    case 8: MRG_COUNT(8) break;
     default: return hipErrorInvalidValue;
   }
 #undef MRG_COUNT

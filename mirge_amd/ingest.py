@@ -43,7 +43,7 @@ def load_fastq(path, words_per_read=None, qual_cutoff=QUAL_CUTOFF, min_len=MIN_L
                threads=0):
     """Returns dict(words [W, n], lens, nmask|None, total, kept, packed, phred, max_len, long_reads):
     `kept` = reads that survive trimming (the reference's trimmedReads), `packed` = n of them in the
-    arrays, `long_reads` = the kept reads beyond 128 nt (ASCII; too long for four packed words)."""
+    arrays, `long_reads` = the kept reads beyond 255 nt (ASCII; too long for eight packed words and a length byte)."""
     lib = _native.load()
     h = C.c_void_p()
     check(lib.mrg_fastq_load(os.fsencode(path), qual_cutoff, min_len, resolve_adapter(adapter).encode(),
@@ -71,7 +71,7 @@ def load_fastq(path, words_per_read=None, qual_cutoff=QUAL_CUTOFF, min_len=MIN_L
 
 class DeviceIngestUnsupported(Exception):
     """The device parser does not take this input (adapter sequence, ill-formed or blank-line-separated
-    records, reads beyond 128 nt): the caller uses load_fastq, which does and which words the errors."""
+    records, reads beyond 255 nt): the caller uses load_fastq, which does and which words the errors."""
 
 
 def load_fastq_device(engine, path, adapter="none", qual_cutoff=QUAL_CUTOFF, min_len=MIN_LENGTH, block_bytes=256 << 20,
@@ -189,8 +189,8 @@ def load_fastq_device(engine, path, adapter="none", qual_cutoff=QUAL_CUTOFF, min
                                                   % (info.bad_record, info.status))
                 if info.n_long == 0:
                     break
-                if W == 4:
-                    raise DeviceIngestUnsupported("reads beyond 128 nt")
+                if W == _native.MRG_MAX_WORDS:
+                    raise DeviceIngestUnsupported("reads beyond 255 nt")
                 W *= 2
             k = int(info.n_kept)
             total += int(info.n_records)

@@ -14,14 +14,16 @@ _LETTERS = np.frombuffer(b"ACGT", dtype=np.uint8)
 
 
 def words_for(max_len):
-    """Words per read the kernels are instantiated for (1, 2 or 4)."""
+    """Words per read the kernels are instantiated for (1, 2, 4 or 8)."""
     if max_len <= 32:
         return 1
     if max_len <= 64:
         return 2
     if max_len <= 128:
         return 4
-    raise ValueError("reads longer than 128 nt are not supported (got %d)" % max_len)
+    if max_len <= 255:
+        return 8
+    raise ValueError("reads longer than 255 nt are not supported (got %d)" % max_len)
 
 
 def pack_codes(codes, W=None):
@@ -45,7 +47,7 @@ def pack_codes(codes, W=None):
 
 
 def pack_reads(seqs, W=None):
-    """seqs: sequence of str (any lengths <= 128).  Returns (words, lens, nmask|None)."""
+    """seqs: sequence of str (any lengths <= 255).  Returns (words, lens, nmask|None)."""
     n = len(seqs)
     lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=n)
     max_len = int(lens.max()) if n else 1

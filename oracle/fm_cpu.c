@@ -326,7 +326,7 @@ void orc_run_cascade(const orc_lib *libs, const orc_pass *passes, int n_pass, co
       if (pass_id[r] >= 0) continue;
       int L = lens[r];
       if (L < p->min_len || L > p->max_len) continue;
-      uint64_t rd[4] = {0, 0, 0, 0}, nm[4] = {0, 0, 0, 0};
+      uint64_t rd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int w = 0; w < W; ++w) {
         rd[w] = reads[(size_t)w * n + r];
         nm[w] = nmask ? nmask[(size_t)w * n + r] : 0ull;

@@ -162,7 +162,8 @@ def test_cli_ranks_write_the_same_tables_as_one(native_lib, oracle_lib, tmp_path
     fastqs = []
     for si in range(2):
         reads = [synth.codes_to_str(c) for c in synth.synth_reads(libs, 1200, seed=70 + si, zipf_s=1.3)]
-        reads += ["ACGTNACGTTAGCATCGATCGA", "A" * 140]   # an N, and a read beyond the 128-nt packing limit
+        # an N, a read of eight packed words, and a read beyond the 255-nt packing limit
+        reads += ["ACGTNACGTTAGCATCGATCGA", libs.libs["mrna"][1][si][3:160], "A" * 300]
         p = str(tmp_path / ("s%d.fastq" % si))
         write_fastq(p, reads, rng)
         fastqs.append(p)
@@ -185,6 +186,7 @@ def test_cli_ranks_write_the_same_tables_as_one(native_lib, oracle_lib, tmp_path
         else:
             assert sorted(a.split("\n")) == sorted(b.split("\n")), fn
     # the over-long read is carried as an unannotated unique read of its sample
-    assert any(line.startswith("A" * 140 + ",0,") for line in open(os.path.join(two_dir, "unmapped.csv")))
+    assert any(line.startswith("A" * 300 + ",0,") for line in open(os.path.join(two_dir, "unmapped.csv")))
+    assert any(line.startswith(libs.libs["mrna"][1][1][3:160] + ",1,") for line in open(os.path.join(two_dir, "mapped.csv")))
     rep = open(os.path.join(two_dir, "annotation.report.csv")).read().split("\n")[1].split(",")
-    assert int(rep[1]) == 1202 and int(rep[2]) == one["logDic"]["quantStats"][0]["trimmedReads"]
+    assert int(rep[1]) == 1203 and int(rep[2]) == one["logDic"]["quantStats"][0]["trimmedReads"]

@@ -50,8 +50,8 @@ def make_fastq(path, rng, n=6000, max_len=50, phred=33, crlf=False, final_newlin
             qual = "h" * L   # (the first record decides the base: make it unmistakably phred 64)
         recs.append("@r%d some text%s%s%s+%s%s" % (i, eol, seq, eol, eol, qual))
     for i in range(long_reads):
-        L = 150
-        recs.append("@long%d%s%s%s+%s%s" % (i, eol, "ACGT" * 37 + "AC", eol, eol, "I" * L))
+        L = 302
+        recs.append("@long%d%s%s%s+%s%s" % (i, eol, "ACGT" * 75 + "AC", eol, eol, "I" * L))
     text = eol.join(recs) + (eol if final_newline else "")
     if path.endswith(".gz"):
         with gzip.open(path, "wt", newline="") as fh:
@@ -84,11 +84,15 @@ def test_device_ingest_equals_host_and_oracle(engine, tmp_path):
     rng = np.random.default_rng(31)
     for name, kw, adapter in (("plain.fastq", {}, "none"), ("crlf.fastq", dict(crlf=True), "none"),
                               ("nofinal.fastq", dict(final_newline=False), "+3"), ("p64.fastq", dict(phred=64), "none"),
-                              ("short.fastq", dict(max_len=30), "+2"), ("z.fastq.gz", {}, "none")):
+                              ("short.fastq", dict(max_len=30), "+2"), ("z.fastq.gz", {}, "none"),
+                              # untrimmed 151- and 250-cycle runs: four and eight packed words per read
+                              ("c151.fastq", dict(max_len=151, n=3000), "none"), ("c250.fastq", dict(max_len=250, n=3000), "+1")):
         p = str(tmp_path / name)
         make_fastq(p, rng, **kw)
         dev = same_as_host_and_oracle(engine, p, adapter)
         assert 500 < dev["kept"] < dev["total"]
+        if "max_len" in kw:
+            assert dev["words"].shape[0] == pack.words_for(kw["max_len"] - (1 if adapter == "+1" else 0)) and dev["max_len"] > kw["max_len"] - 12
     # adapter sequences (`-ad illumina`, a list of two): cutadapt's 3' search, one thread per read
     for name, adapter, ads in (("ill.fastq", "illumina", (ILLUMINA,)), ("two.fastq", "ACGTTGCAAGGCTTAC,TGGAATTCTCGG", ("ACGTTGCAAGGCTTAC", "TGGAATTCTCGG")),
                                ("ill.fastq.gz", "illumina", (ILLUMINA,))):
@@ -106,7 +110,7 @@ def test_device_ingest_equals_host_and_oracle(engine, tmp_path):
 
 
 def test_what_the_device_parser_refuses(engine, tmp_path):
-    """An adapter of more than 64 bases, blank lines between records, a missing '+' line, reads beyond 128 nt:
+    """An adapter of more than 64 bases, blank lines between records, a missing '+' line, reads beyond 255 nt:
     the device parser says so (the caller then takes the host parser)."""
     rng = np.random.default_rng(32)
     p = str(tmp_path / "ok.fastq")

@@ -567,10 +567,12 @@ def test_count_and_list_best_on_a_20mbp_library(native_lib, oracle_lib):
 
 
 @pytest.mark.gpu
-def test_long_reads_four_words(native_lib, oracle_lib):
-    """Reads of 65..128 nt (four packed words, the W = 4 instantiations): cascade = CPU port, and
-    the port = the exhaustive scan on the same reads (seed rule: mismatches beyond the first 28
-    bases count only towards the total)."""
+@pytest.mark.parametrize("lo,hi,W,per_entry", [(65, 128, 4, 6), (129, 255, 8, 12)])
+def test_long_reads_four_and_eight_words(native_lib, oracle_lib, lo, hi, W, per_entry):
+    """Reads of 65..128 nt (four packed words, the W = 4 instantiations) and of 129..255 nt (eight words: what
+    `-ad none` leaves of a 151- or 250-cycle run, RAP:543-554 offers them to every pass without a length cap):
+    cascade = CPU port, and the port = the exhaustive scan on the same reads (seed rule: mismatches beyond the
+    first 28 bases count only towards the total)."""
     from mirge_amd import pack
     from mirge_amd.engine import Engine, ReadSet
     from tests.util import World, pass_dicts
@@ -579,18 +581,19 @@ def test_long_reads_four_words(native_lib, oracle_lib):
     reads = []
     for key in ("mrna", "ncrna_others", "hairpin", "snorna", "mature_trna"):
         for s in w.libs.libs[key][1]:
-            if len(s) < 66:
+            if len(s) < lo + 1:
                 continue
-            for _ in range(6):
-                L = int(rng.integers(65, min(128, len(s)) + 1))
+            for _ in range(per_entry):
+                L = int(rng.integers(lo, min(hi, len(s)) + 1))
                 o = int(rng.integers(0, len(s) - L + 1))
                 r = list(s[o:o + L])
                 for _ in range(int(rng.integers(0, 4))):
                     r[int(rng.integers(0, L))] = "ACGTN"[int(rng.integers(0, 5))]
                 reads.append("".join(r))
-    reads = list(dict.fromkeys(reads))[:3000]
+    reads = list(dict.fromkeys(reads))
+    reads = [reads[i] for i in rng.permutation(len(reads))[:3000]]   # (every library with entries that long, not the first one's only)
     words, lens, nmask = pack.pack_reads(reads)
-    assert words.shape[0] == 4 and int(lens.max()) > 120
+    assert words.shape[0] == W and int(lens.max()) > hi - 8 and int(lens.min()) >= lo and len(reads) > 500
     eng = Engine(0)
     for k in LIB_ORDER:
         eng.add_library(k, w.index[k])

@@ -41,6 +41,27 @@ def test_fastq_loader_matches_oracle(native_lib, tmp_path, gz, first_hi):
     assert 0 < len(want) < total
 
 
+def test_fastq_loader_reads_of_every_packed_width(native_lib, tmp_path):
+    """Untrimmed long-cycle runs (`-ad none`): reads of up to 255 nt are packed (1, 2, 4 or 8 words, the smallest
+    that holds the file's longest read), longer ones are kept aside in file order and counted among the kept."""
+    rng = np.random.default_rng(5)
+    for cycles, W in ((32, 1), (33, 2), (128, 4), (129, 8), (255, 8), (300, 8)):
+        p = str(tmp_path / ("c%d.fastq" % cycles))
+        with open(p, "w") as fh:
+            for i in range(400):
+                L = cycles if i % 50 == 0 else int(rng.integers(16, cycles + 1))
+                seq = "".join("ACGTN"[int(c)] for c in rng.choice(5, L, p=[0.245, 0.245, 0.245, 0.245, 0.02]))
+                fh.write("@r%d\n%s\n+\n%s\n" % (i, seq, "I" * L))
+        want, total, phred = oingest.load_fastq(p)
+        got = ingest.load_fastq(p)
+        assert got["words"].shape[0] == W and (got["total"], got["kept"]) == (400, len(want)) == (400, 400)
+        assert pack.unpack_reads(got["words"], got["lens"], got["nmask"]) == [s for s in want if len(s) <= 255]
+        assert got["long_reads"] == [s for s in want if len(s) > 255] and (len(got["long_reads"]) > 0) == (cycles > 255)
+        assert got["max_len"] == min(cycles, 255) or cycles > 255
+        w2, l2, n2 = pack.pack_reads([s for s in want if len(s) <= 255])
+        assert np.array_equal(w2, got["words"]) and np.array_equal(l2, got["lens"])
+
+
 @pytest.mark.parametrize("crlf", [False, True])
 def test_fastq_loader_block_boundaries(native_lib, tmp_path, crlf):
     """A file of several reader blocks (the reader cuts the text at the last record header of each

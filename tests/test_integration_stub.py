@@ -25,7 +25,7 @@ def test_ctypes_stub_of_integration_md_runs_verbatim(native_lib, tmp_path):
         prefix[key] = str(tmp_path / key)
         FmIndex.build(names, seqs).save(prefix[key] + ".mrgfm")
     reads = list(dict.fromkeys(synth.codes_to_str(c) for c in synth.synth_reads(libs, 800, seed=3, zipf_s=1.3)))
-    reads += ["ACGTNACGTTAGCATCGATCGA", "A" * 140]
+    reads += ["ACGTNACGTTAGCATCGATCGA", "A" * 140, "A" * 300, libs.libs["mrna"][1][0][7:180]]
     make = lambda: {s: {"quant": [1], "annot": [0] + [""] * 9, "length": len(s)} for s in reads}
     seq_dic = make()
     env = dict(LIB=_native.LIB_PATH, index_prefix=prefix, seqDic=seq_dic)
@@ -39,4 +39,5 @@ def test_ctypes_stub_of_integration_md_runs_verbatim(native_lib, tmp_path):
                                    None, "miRBase", False, None, None, ["s"])
     assert {s: r["annot"] for s, r in seq_dic.items()} == {s: r["annot"] for s, r in want.items()}
     assert sum(r["annot"][0] for r in seq_dic.values()) > len(reads) // 2
-    assert seq_dic["A" * 140]["annot"][0] == 0
+    assert seq_dic["A" * 140]["annot"][0] == 0 and seq_dic["A" * 300]["annot"][0] == 0
+    assert seq_dic[libs.libs["mrna"][1][0][7:180]]["annot"][0] == 1   # a 173-nt read, aligned (eight words)

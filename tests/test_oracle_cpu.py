@@ -95,6 +95,45 @@ def test_fm_port_equals_exhaustive_scan(world):
     assert all(int(res["stats"][i][1]) > 0 for i in range(9))
 
 
+def test_fm_port_equals_exhaustive_scan_on_reads_of_eight_words(native_lib, oracle_lib):
+    """Reads of 129..255 nt (what `-ad none` leaves of a 151- or 250-cycle run; RAP:543-554 caps no pass but the
+    first at a length): the FM port on eight packed words = the exhaustive scan on the strings -- seed in the
+    first 28 bases, mismatches behind it count towards the total only, Ns mismatch."""
+    from mirge_amd import pack
+    from tests.util import pass_dicts
+    w = World(with_n=True, n_fixed=50, n_var=20)
+    rng = np.random.default_rng(77)
+    reads = []
+    for key in ("mrna", "ncrna_others", "snorna", "rrna"):
+        for s in w.libs.libs[key][1]:
+            if len(s) < 130:
+                continue
+            for _ in range(2):
+                L = int(rng.integers(129, min(255, len(s)) + 1))
+                o = int(rng.integers(0, len(s) - L + 1))
+                r = list(s[o:o + L])
+                for _ in range(int(rng.integers(0, 4))):
+                    r[int(rng.integers(0, L))] = "ACGTN"[int(rng.integers(0, 5))]
+                reads.append("".join(r))
+    reads = list(dict.fromkeys(reads))
+    reads = [reads[i] for i in rng.permutation(len(reads))[:500]] + ["A" * 255, w.libs.libs["mrna"][1][0][:255]]
+    words, lens, nmask = pack.pack_reads(reads)
+    assert words.shape[0] == 8 and int(lens.max()) == 255 and int(lens.min()) >= 129
+    res = model.fm_cascade(w.views, pass_dicts(), words, lens, nmask)
+    libs = {k: model.Library(*w.libs.libs[k]) for k in LIB_ORDER}
+    seq_dic = {r: cascade.new_seq_record(r, 1) for r in reads}
+    align = {}
+    cascade.run_annotation_pipeline(seq_dic, libs, {"quantStats": [{}], "annotStats": []}, align_dic=align)
+    for i, r in enumerate(reads):
+        got = None
+        if res["pass_id"][i] >= 0:
+            got = (int(res["pass_id"][i]), int(res["ref_id"][i]), int(res["pos"][i]), int(res["mm"][i]))
+        assert align.get(r) == got, r
+    claimed = [int(res["stats"][i][1]) for i in range(9)]
+    assert sum(claimed) > len(reads) // 3 and claimed[4] > 0 and claimed[6] > 0 and claimed[7] > 0   # snoRNA, ncRNA, mRNA
+    assert res["pass_id"][len(reads) - 1] == 7 and res["pos"][len(reads) - 1] == 0 and res["pass_id"][len(reads) - 2] < 0
+
+
 def test_pair_seed_port_equals_piece_search(world):
     """The 2-mismatch pass searched through anchor pairs (mrg_pass_stats.pair_anchor = 4) claims the
     same reads at the same place as the stratum-first pigeonhole search, without an LF step for the
