@@ -247,6 +247,11 @@ def build_world(seed=77, snpc=False):
 
 
 def main():
+    if os.environ.get("PYTHONHASHSEED") != "2":
+        # the reference iterates over sets of strings (tRF report columns): a fixed hash seed makes the capture
+        # reproducible byte for byte; run this script again as a child with the seed set
+        env = dict(os.environ, PYTHONHASHSEED="2")
+        sys.exit(subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env).returncode)
     scratch = tempfile.mkdtemp(prefix="mirge_golden_")
     try:
         pkg = os.path.join(scratch, "mirge")
@@ -374,6 +379,7 @@ def main():
         make_a2i_golden(scratch, bindir)
         make_trf_golden(scratch, bindir)
         make_flags_golden(scratch, bindir)
+        make_long_golden(scratch, bindir)
     finally:
         shutil.rmtree(scratch, ignore_errors=True)
 
@@ -681,6 +687,85 @@ def make_trf_golden(scratch, bindir):
         json.dump(golden, fh, separators=(",", ":"), sort_keys=True)
     print("wrote", out, os.path.getsize(out), "bytes; tRF reads", len(content_after_cascade),
           "report rows", len(files["tRFs.potential.report.tsv"]) - 2)
+
+
+def make_long_golden(scratch, bindir):
+    """Reads of 33..300 nt -- what `-ad none` leaves of a 151- / 250- / 300-cycle run: the reference writes every
+    unannotated read of any length into a pass's FASTA (RAP:543-554; only the first pass has an upper bound,
+    the hairpin pass a lower one) -> tests/golden/long_reads.json (collapse + cascade only)."""
+    import importlib
+    import numpy as np
+    from mirge_amd import synth
+    RAP = importlib.import_module("mirge.utils.runAnnotationPipeline")
+    from mirge.utils.quantReads import quantReads
+
+    libs = synth.SynthLibraries(seed=606, scale=1.0, n_paralogs=4, n_snp=4, shapes=SHAPES)
+    rng = np.random.default_rng(66)
+    reads = [synth.codes_to_str(c) for c in synth.synth_reads(libs, 300, seed=607, zipf_s=1.3)]
+    for key, per_entry in (("hairpin", 3), ("snorna", 6), ("rrna", 20), ("ncrna_others", 4), ("mrna", 6), ("pre_trna", 2)):
+        for s in libs.libs[key][1]:
+            for _ in range(per_entry):
+                ln = int(rng.integers(33, min(len(s), 300) + 1)) if len(s) >= 33 else len(s)
+                o = int(rng.integers(0, len(s) - ln + 1))
+                r = list(s[o:o + ln])
+                for _ in range(int(rng.integers(0, 4))):
+                    r[int(rng.integers(0, ln))] = "ACGTN"[int(rng.integers(0, 5))]
+                if key == "pre_trna":
+                    r += list("T" * int(rng.integers(3, 7)))
+                reads.append("".join(r))
+    reads += ["A" * 151, "ACGT" * 70, libs.libs["mrna"][1][0][:255], libs.libs["mrna"][1][0][:256]]
+    order = rng.permutation(len(reads))
+    samples = [[reads[i] for i in order]]
+    libroot = os.path.join(scratch, "libs_long")
+    prefix = libs.write_layout(libroot, species="syn", db="miRBase")
+    outdir = os.path.join(scratch, "out_long")
+    os.makedirs(outdir)
+    sample_list = ["l0.fastq"]
+    seq_dic, len_dic = {}, {}
+    fq = os.path.join(outdir, "l0.trim.fastq")
+    with open(fq, "w") as fh:
+        for k, r in enumerate(samples[0]):
+            fh.write("@r%d\n%s\n+\n%s\n" % (k, r, "I" * len(r)))
+    quantReads(fq, seq_dic, len_dic, 1, 0, sample_list, False, False)
+    log_dic = {"quantStats": [{"filename": s} for s in sample_list], "annotStats": []}
+    annot_names = ["exact miRNA", "hairpin miRNA", "mature tRNA", "primary tRNA", "snoRNA", "rRNA",
+                   "ncrna others", "mRNA", "isomiR miRNA"]
+    ix = lambda k: prefix + k
+    RAP.runAnnotationPipeline(bindir, seq_dic, "1", False, annot_names, outdir, log_dic,
+                              ix("mirna_miRBase"), ix("hairpin_miRBase"), ix("mature_trna"), ix("pre_trna"),
+                              ix("snorna"), ix("rrna"), ix("ncrna_others"), ix("mrna"), False, None, False,
+                              None, None, "miRBase", False, None, None, sample_list)
+    # the same without the reads a length byte cannot hold (> 255 nt: the product carries them unannotated, a
+    # documented deviation): the counters the product must then report
+    import copy
+    seq_le = {s: {"quant": list(r["quant"]), "annot": [0] + [""] * 9, "length": r["length"]} for s, r in seq_dic.items() if len(s) <= 255}
+    log_le = {"quantStats": [{"filename": s} for s in sample_list], "annotStats": []}
+    outdir_le = os.path.join(scratch, "out_long_le255")
+    os.makedirs(outdir_le)
+    RAP.runAnnotationPipeline(bindir, seq_le, "1", False, annot_names, outdir_le, log_le,
+                              ix("mirna_miRBase"), ix("hairpin_miRBase"), ix("mature_trna"), ix("pre_trna"),
+                              ix("snorna"), ix("rrna"), ix("ncrna_others"), ix("mrna"), False, None, False,
+                              None, None, "miRBase", False, None, None, sample_list)
+    assert all(seq_le[s]["annot"] == seq_dic[s]["annot"] for s in seq_le)
+    golden = {
+        "about": "captured from the reference's Python (reads of 33..300 nt, collapse + cascade) by "
+                 "tests/golden/make_golden.py; bowtie is the stand-in (parity unpinned)",
+        "libraries": {k: [list(v[0]), list(v[1])] for k, v in libs.libs.items()},
+        "samples": samples, "sample_list": sample_list,
+        "expected": {"seqDic": {s: {"quant": r["quant"], "annot": r["annot"], "length": r["length"]}
+                                for s, r in seq_dic.items()},
+                     "readLengthDic": {str(k): v for k, v in len_dic.items()},
+                     "annotStats": [{"readsProcessed": a["readsProcessed"], "readsAligned": a["readsAligned"]}
+                                    for a in log_dic["annotStats"]],
+                     "annotStats_le255": [{"readsProcessed": a["readsProcessed"], "readsAligned": a["readsAligned"]}
+                                          for a in log_le["annotStats"]]},
+    }
+    out = os.path.join(ROOT, "tests", "golden", "long_reads.json")
+    with open(out, "w") as fh:
+        json.dump(golden, fh, separators=(",", ":"), sort_keys=True)
+    n_long = [sum(1 for s, r in seq_dic.items() if lo < len(s) <= hi and r["annot"][0]) for lo, hi in ((32, 64), (64, 128), (128, 255), (255, 999))]
+    print("wrote", out, os.path.getsize(out), "bytes;", len(seq_dic), "unique reads; annotated of 33..64 / 65..128 / 129..255 / > 255 nt:",
+          n_long, "annotStats", golden["expected"]["annotStats"])
 
 
 def make_flags_golden(scratch, bindir):

@@ -46,6 +46,30 @@ def test_cascade_annot_and_counters(golden, oracle_run):
     assert all(a["readsAligned"] > 0 for a in exp["annotStats"])
 
 
+def test_reads_of_every_length_are_offered_to_the_passes(oracle_lib):
+    """tests/golden/long_reads.json: reads of 33..300 nt through the reference's collapse + cascade (RAP:543-554
+    caps only the first pass at a length): the oracle's restatement gives the same annot rows and per-pass
+    counters -- for all reads, and for the run without the reads beyond 255 nt (what the product aligns)."""
+    with open(os.path.join(ROOT, "tests", "golden", "long_reads.json")) as fh:
+        g = json.load(fh)
+    exp = g["expected"]
+    libs = {k: model.Library(*v) for k, v in g["libraries"].items()}
+    seq_dic, len_dic = cascade.collapse(g["samples"])
+    assert {str(k): v for k, v in len_dic.items()} == exp["readLengthDic"]
+    log_dic = {"quantStats": [{}], "annotStats": []}
+    cascade.run_annotation_pipeline(seq_dic, libs, log_dic)
+    assert set(seq_dic) == set(exp["seqDic"])
+    for s, rec in seq_dic.items():
+        assert rec["annot"] == exp["seqDic"][s]["annot"] and rec["quant"] == exp["seqDic"][s]["quant"], s
+    assert log_dic["annotStats"] == exp["annotStats"]
+    by_len = lambda lo, hi: sum(1 for s, r in exp["seqDic"].items() if lo < len(s) <= hi and r["annot"][0])
+    assert min(by_len(32, 64), by_len(64, 128), by_len(128, 255), by_len(255, 999)) > 20
+    seq_le = {s: cascade.new_seq_record(s, r["quant"][0]) for s, r in exp["seqDic"].items() if len(s) <= 255}
+    log_le = {"quantStats": [{}], "annotStats": []}
+    cascade.run_annotation_pipeline(seq_le, libs, log_le)
+    assert log_le["annotStats"] == exp["annotStats_le255"] != exp["annotStats"]
+
+
 def test_summarize_merge_filter(golden, oracle_run):
     libs, seq_dic, _, log_dic = oracle_run
     exp = golden["expected"]

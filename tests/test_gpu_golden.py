@@ -69,6 +69,51 @@ def test_reference_shaped_pipeline_matches_golden(golden, native_lib, tmp_path):
     assert log_dic["quantStats"] == exp["quantStats_after_filter"]
 
 
+def test_reads_of_up_to_255_nt_match_the_reference(native_lib, tmp_path):
+    """tests/golden/long_reads.json (reads of 33..300 nt through the reference's own collapse + cascade): the
+    product's annot rows equal the reference's for every read of up to 255 nt -- two, four and eight packed
+    words --, its per-pass counters those of the reference's run without the longer reads, and the reads beyond
+    255 nt stay unannotated (the documented deviation; the reference annotates 28 of them)."""
+    from mirge_amd import annotate
+    from mirge_amd.engine import Engine
+    with open(os.path.join(ROOT, "tests", "golden", "long_reads.json")) as fh:
+        g = json.load(fh)
+    exp = g["expected"]
+    fname = {"mirna": "mirna_miRBase", "hairpin": "hairpin_miRBase"}
+    prefix = {}
+    for key, (names, seqs) in g["libraries"].items():
+        prefix[key] = str(tmp_path / ("syn_" + fname.get(key, key)))
+        with open(prefix[key] + ".fa", "w") as fh:
+            for n, s in zip(names, seqs):
+                fh.write(">%s\n%s\n" % (n, s))
+    seq_dic, len_dic = {}, {}
+    annotate.quantReads(g["samples"][0], seq_dic, len_dic, 1, 0)
+    assert {str(k): v for k, v in len_dic.items()} == exp["readLengthDic"]
+    log_dic = {"quantStats": [{}], "annotStats": []}
+    eng = Engine(0)
+    annot_names = ["exact miRNA", "hairpin miRNA", "mature tRNA", "primary tRNA", "snoRNA", "rRNA",
+                   "ncrna others", "mRNA", "isomiR miRNA"]
+    annotate.runAnnotationPipeline(
+        eng, seq_dic, "1", False, annot_names, str(tmp_path), log_dic, prefix["mirna"],
+        prefix["hairpin"], prefix["mature_trna"], prefix["pre_trna"], prefix["snorna"], prefix["rrna"],
+        prefix["ncrna_others"], prefix["mrna"], False, None, False, None, None, "miRBase", False, None,
+        None, g["sample_list"])
+    assert set(seq_dic) == set(exp["seqDic"])
+    n_by_words = {2: 0, 4: 0, 8: 0}
+    for s, rec in seq_dic.items():
+        assert rec["quant"] == exp["seqDic"][s]["quant"]
+        if len(s) <= 255:
+            assert rec["annot"] == exp["seqDic"][s]["annot"], s
+            if len(s) > 32 and rec["annot"][0]:
+                n_by_words[2 if len(s) <= 64 else (4 if len(s) <= 128 else 8)] += 1
+        else:
+            assert rec["annot"] == [0] + [""] * 9, s
+    assert min(n_by_words.values()) > 100
+    assert sum(1 for s, r in exp["seqDic"].items() if len(s) > 255 and r["annot"][0]) == 28
+    got_stats = [{k: a[k] for k in ("readsProcessed", "readsAligned")} for a in log_dic["annotStats"]]
+    assert got_stats == exp["annotStats_le255"]
+
+
 def test_gff_path_matches_reference(native_lib, tmp_path):
     """-gff: the isomiRContentDic the reference fills during its cascade and the per-sample
     GFF files, reproduced from the GPU alignments (tests/golden/isomir_gff.json)."""
