@@ -456,6 +456,13 @@ def main():
             raise SystemExit("PARITY FAILURE: the count vector differs from the CPU port's tally")
         parity["cpu_port"] = "pass_id/ref_id/pos/mm identical on %d reads%s (oracle/fm_cpu.c, which reads the " \
                              "product's index arrays)" % (m, "; count vector identical" if m == n_reads else "")
+        # -- the arrays the port and the kernels share, pinned to the library strings at full size (a failure raises)
+        t1 = time.perf_counter()
+        rows = sum(model.check_index(v, libs.libs[k][1], threads=cores)["rows"] for k, v in zip(keys, views))
+        parity["index_check"] = "text, segments, suffix array (permutation, ascending suffixes, row fields), BWT blocks, " \
+                                "jump tables and 9-mer bitmaps of all %d libraries = the FM index of their strings by " \
+                                "definition (oracle/index_check.c: %d rows, %.1f s on %d threads)" % (
+                                    len(keys), rows, time.perf_counter() - t1, cores)
         cpu = dict(value=round(m / dt / 1e6, 4), unit="M reads/s", cores=cores, kind="port",
                    sample="first %d reads of rank 0's shard, full %d-pass cascade + tally, oracle/fm_cpu.c with "
                           "OpenMP on %d threads (%.1f s)" % (m, n_pass, cores, dt),

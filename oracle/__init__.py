@@ -19,4 +19,8 @@ Pinning status
     /root/reference/README.md:49), which is neither vendored in the reference
     nor installed here, and the reference has no tests.  bowtie_model.c
     restates bowtie's published rules by exhaustive scan.
+  * the index arrays the CPU port (fm_cpu.c) shares with the kernels: checked
+    by definition against the library strings by index_check.c (suffix order,
+    permutation, row fields, BWT blocks, jump tables) -- in tests and, at full
+    size, in bench.py's parity gate.
 """

@@ -1,4 +1,4 @@
-"""ctypes bindings of oracle/_build/liboracle.so (bowtie_model.c + fm_cpu.c).
+"""ctypes bindings of oracle/_build/liboracle.so (bowtie_model.c + fm_cpu.c + index_check.c).
 
 TEST INFRASTRUCTURE, see oracle/__init__.py.  `build()` compiles the C sources
 with gcc; nothing here touches a GPU.
@@ -16,7 +16,7 @@ _lib = None
 
 def build(force=False):
     """Compile oracle/*.c -> oracle/_build/liboracle.so (gcc -O2 -fopenmp)."""
-    srcs = [os.path.join(_HERE, f) for f in ("bowtie_model.c", "fm_cpu.c", "edit_tally.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("bowtie_model.c", "fm_cpu.c", "edit_tally.c", "index_check.c", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(
         os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
@@ -245,6 +245,49 @@ def fm_cascade(lib_views, passes, reads, lens, nmask=None, wstop=0, threads=None
     if threads and old is not None:
         os.environ["OMP_NUM_THREADS"] = old
     return dict(pass_id=pass_id, ref_id=ref_id, pos=pos, mm=mm, stats=stats, steps_per_read=steps)
+
+
+_CHECKS = {1: "segment tables", 2: "text", 3: "chunk_seg", 4: "suffix array is not a permutation", 5: "suffix array order",
+           6: "suffix-array row fields", 7: "BWT blocks / superblocks / primary", 8: "jump table", 9: "9-mer bitmap"}
+
+
+def check_index(view, seqs, threads=None):
+    """oracle/index_check.c: every array of an index view (mirge_amd FmIndex.view(): what the GPU uploads and
+    what fm_cascade reads) against the library's strings, by definition -- text and segments, the suffix array a
+    permutation in ascending suffix order with the right row fields, the BWT blocks it implies, every jump
+    table, the 9-mer bitmap.  Returns dict(rows, jump_entries); raises AssertionError naming the array and the
+    place of the first violation."""
+    keep = []
+    l = _OrcLib()
+    for k in ("blocks", "super", "text", "sa", "ftab", "seg_start", "seg_ref", "seg_off", "chunk_seg"):
+        a = np.ascontiguousarray(view[k], dtype=np.uint64 if k == "sa" else np.uint32)
+        keep.append(a)
+        setattr(l, k, a.ctypes.data)
+    kb = view.get("kbits")
+    if kb is not None:
+        kb = np.ascontiguousarray(kb, dtype=np.uint32)
+        keep.append(kb)
+        l.kbits = kb.ctypes.data
+    l.n = int(view["n"])
+    l.primary = int(view["primary"])
+    for t, k in enumerate(view["ftab_ks"]):
+        l.ftab_ks[t] = int(k)
+    concat = "".join(seqs).encode("ascii")
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    np.cumsum([len(s) for s in seqs], out=off[1:])
+    report = np.zeros(8, dtype=np.uint64)
+    if threads:
+        try:
+            C.CDLL("libgomp.so.1").omp_set_num_threads(int(threads))
+        except OSError:
+            pass
+    f = lib().orc_check_index
+    f.restype = C.c_int
+    rc = f(C.byref(l), concat, off.ctypes.data_as(C.c_void_p), C.c_uint32(len(seqs)),
+           C.c_uint32(len(view["seg_ref"])), report.ctypes.data_as(C.c_void_p))
+    assert rc == 0, "index check failed: %s at %d (got %d, want %d)" % (_CHECKS.get(rc, rc), int(report[1]) & ((1 << 56) - 1),
+                                                                        int(report[2]), int(report[3]))
+    return dict(rows=int(report[4]), jump_entries=int(report[6]))
 
 
 def tally(pass_id, ref_id, quant, n_mirna, n_pass, canon_pass, isomir_pass):

@@ -52,6 +52,7 @@ def test_headline_line_has_the_contract_keys():
     assert r["compulsory_floor_ms"] > 0 and r["whole_step"]["algorithmic_bytes"] == 16 * 300000 + 64 * sum(p["steps"] for p in d["passes"])
     assert r["whole_step"]["frac_per_pass_offered"] >= r["whole_step"]["frac"]
     assert "identical" in d["parity"]["cpu_port"] and "identical" in d["parity"]["exhaustive_scan"]
+    assert "by definition" in d["parity"]["index_check"]
     assert "bowtie" in d["parity"]
     assert "identical" in d["e2e"]["parity"] and d["e2e"]["value"] > 0 and d["e2e"]["h2d_ms"] > 0
     assert "identical" in d["collapsed"]["parity"] and d["collapsed"]["unique_reads"] < d["collapsed"]["raw_reads"]

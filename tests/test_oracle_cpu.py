@@ -134,6 +134,61 @@ def test_fm_port_equals_exhaustive_scan_on_reads_of_eight_words(native_lib, orac
     assert res["pass_id"][len(reads) - 1] == 7 and res["pos"][len(reads) - 1] == 0 and res["pass_id"][len(reads) - 2] < 0
 
 
+def test_index_arrays_are_the_fm_index_of_the_strings(world):
+    """oracle/index_check.c: every array the GPU uploads and the CPU port reads, checked by definition against
+    the libraries' strings (entries with N runs: several segments) -- and a single wrong value in any of them
+    is found (the port and the kernels share these arrays: a construction bug would not show in their
+    comparison)."""
+    for k, v in zip(LIB_ORDER, world.views):
+        rep = model.check_index(v, world.libs.libs[k][1])
+        assert rep["rows"] == v["n"] + 1 and rep["jump_entries"] > 0
+    from mirge_amd.index import FmIndex
+    names, seqs = world.libs.libs["ncrna_others"]
+    seqs = list(seqs)
+    for r in range(0, len(seqs), 7):                # N runs: several segments per entry, one entry starting with N
+        s = seqs[r]
+        seqs[r] = ("N" if r % 14 == 0 else "") + s[:40] + "NNN" + s[43:90] + "n" + s[91:]
+    v = FmIndex.build(names, seqs).view()
+    assert len(v["seg_ref"]) > len(seqs) + 100
+    model.check_index(v, seqs)
+
+    def broken(key, edit):
+        w = dict(v)
+        w[key] = np.array(v[key], copy=True)
+        edit(w[key])
+        with pytest.raises(AssertionError, match="index check failed"):
+            model.check_index(w, seqs)
+
+    def swap_rows(a):
+        a[1000], a[1001] = int(a[1001]), int(a[1000])
+
+    def flip(i, bit):
+        def f(a):
+            a[i] ^= type(a[i])(bit)
+        return f
+    broken("sa", swap_rows)                                      # two suffixes out of order
+    broken("sa", flip(5000, 1 << 32))                            # a row's distance to its segment start
+    broken("sa", flip(5000, 1 << 48))                            # a row's segment id
+    broken("sa", lambda a: a.__setitem__(7, a[8]))               # a position twice
+    broken("text", flip(300, 1 << 7))                            # one base
+    broken("blocks", flip(4 * 100 + 2, 1 << 5))                  # one BWT bit
+    broken("blocks", flip(4 * 100 + 1, 1))                       # one 16-bit count
+    broken("super", flip(5, 1))
+    broken("ftab", flip(12345, 1))                               # one jump-table boundary
+    broken("ftab", flip(len(v["ftab"]) - 1, 1))
+    broken("chunk_seg", flip(50, 1))
+    broken("seg_off", flip(3, 1))
+    v0 = world.views[LIB_ORDER.index("mirna")]
+    w = dict(v0, kbits=np.array(v0["kbits"], copy=True))
+    set_word = int(np.flatnonzero(w["kbits"])[0])
+    w["kbits"][set_word] &= w["kbits"][set_word] - np.uint32(1)  # a 9-mer of the text missing from the bitmap
+    with pytest.raises(AssertionError, match="9-mer bitmap"):
+        model.check_index(w, world.libs.libs["mirna"][1])
+    w = dict(v, primary=int(v["primary"]) + 1)
+    with pytest.raises(AssertionError, match="BWT"):
+        model.check_index(w, seqs)
+
+
 def test_pair_seed_port_equals_piece_search(world):
     """The 2-mismatch pass searched through anchor pairs (mrg_pass_stats.pair_anchor = 4) claims the
     same reads at the same place as the stratum-first pigeonhole search, without an LF step for the
