@@ -294,17 +294,37 @@ def main():
 
     packed_out = torch.empty(n_reads, dtype=torch.int32, device=eng.device) if args.outputs == "packed" else None
 
+    # N > 1: the all-reduce of step k runs beside the cascade of step k + 1 (RCCL's stream; two count vectors used in
+    # turn, a vector is not touched again before its own all-reduce has finished); every step's reduced vector is
+    # complete when the timed region ends
+    bufs = [fused, torch.zeros_like(fused)] if world > 1 else [fused]
+    pending = [None] * len(bufs)
+    state = dict(k=0)
+
     def step():
-        fused.zero_()
+        b = state["k"] % len(bufs)
+        state["k"] += 1
+        f = bufs[b]
+        if pending[b] is not None:
+            pending[b].wait()          # (the current stream waits; the host does not, on RCCL)
+            pending[b] = None
+        f.zero_()
         if packed_out is not None:
-            res = eng.cascade_packed(rs, passes, out=(packed_out, fused[ln:]))
+            res = eng.cascade_packed(rs, passes, out=(packed_out, f[ln:]))
         else:
-            res = eng.cascade(rs, passes, out=out)
-        eng.tally(rs, res, M, canon, iso, counts=fused[:ln_tally])
+            res = eng.cascade(rs, passes, out=out[:4] + (f[ln:],))
+        eng.tally(rs, res, M, canon, iso, counts=f[:ln_tally])
         if wl == "a2i":
-            eng.edit_tally(rs, res, "mirna", canon, iso, counts=fused[ln_tally:ln])
-        mdist.allreduce_counts(fused)
+            eng.edit_tally(rs, res, "mirna", canon, iso, counts=f[ln_tally:ln])
+        pending[b] = mdist.allreduce_counts(f, async_op=True)
+        state["last"] = f
         return res
+
+    def drain():
+        for b, w in enumerate(pending):
+            if w is not None:
+                w.wait()
+                pending[b] = None
 
     def fence():
         torch.cuda.synchronize()
@@ -317,12 +337,24 @@ def main():
     eng.prepare(passes, rs.W, rs.min_len, rs.max_len)
     for _ in range(args.warmup):
         step()
+    drain()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
+    drain()
     fence()
     elapsed = time.perf_counter() - t0
+    fused = state.get("last", fused)   # the last step's (reduced) count vector
+    reduce_check = None
+    if world > 1:
+        # every read falls into exactly one category: the reduced category totals sum to the reads of ALL ranks
+        tot = torch.tensor([int(quant.sum())], dtype=torch.int64, device=eng.device)
+        torch.distributed.all_reduce(tot)
+        got_total = int(fused[2 * M * S:2 * M * S + (n_pass + 1) * S].sum().item())
+        if got_total != int(tot.item()):
+            raise SystemExit("PARITY FAILURE: the reduced category totals sum to %d, the ranks hold %d reads" % (got_total, int(tot.item())))
+        reduce_check = "category totals of the last step's all-reduced count vector sum to the %d reads (with their counts) of all %d ranks" % (got_total, world)
     # per-pass HIP-event times (recorded on the kernels' stream by mrg_cascade_run) of the last
     # timed step; reading them synchronises, so it is done after the timed region
     st = res.stats
@@ -411,6 +443,8 @@ def main():
 
     # ---- parity gates + CPU baseline (rank 0, N = 1 only) ----
     cpu, parity = None, {}
+    if reduce_check:
+        parity["all_reduce"] = reduce_check
     got = None
     if world == 1 and not (args.no_cpu_baseline and args.no_extras):
         if packed_out is not None:

@@ -77,12 +77,16 @@ def fused_buffer(engine_or_len, n_mirna=None, n_samples=None, n_pass=None, devic
     return torch.zeros(ln + 2 * n_pass, dtype=torch.int64, device=device), ln
 
 
-def allreduce_counts(fused):
-    """Sum the fused vector over all ranks in place (no-op for one process)."""
+def allreduce_counts(fused, async_op=False):
+    """Sum the fused vector over all ranks in place (no-op for one process).  async_op: returns the collective's
+    work handle (None for one process) instead of making the current stream wait for it -- `handle.wait()` does
+    that later, so the next batch's kernels can run beside the all-reduce (the caller must not touch `fused`
+    before)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(fused, op=dist.ReduceOp.SUM)
-    return fused
+        work = dist.all_reduce(fused, op=dist.ReduceOp.SUM, async_op=bool(async_op))
+        return work if async_op else fused
+    return None if async_op else fused
 
 
 def broadcast_from_rank0(obj):

@@ -88,3 +88,32 @@ def test_strong_scaling_is_the_default_and_names_the_whole_job():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["scaling"] == "strong" and d["config"]["reads_total"] == 200000 == d["config"]["reads_per_gpu"]
+
+
+def test_two_ranks_share_the_gpu_and_the_all_reduce_overlaps_the_next_step():
+    """The N > 1 path of bench.py on a one-GPU box (MRG_BENCH_SHARE_GPU=1: both ranks on device 0, gloo instead of
+    RCCL; timings mean nothing): contiguous shards of one read set, the all-reduce of step k issued asynchronously
+    beside step k + 1 on two count vectors used in turn, and rank 0's line -- whose gate checks that the reduced
+    category totals of the LAST step sum to the reads of all ranks."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MRG_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "5", "--warmup", "2", "--reads", "300001", "--scale", "0.05",
+                          "--no-cpu-baseline", "--no-extras", "--no-legs"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["reads_total"] == 300001
+    assert d["config"]["reads_per_gpu"] in (150000, 150001)
+    # (the gate inside bench.py compared the reduced totals with the all-reduced sum of the ranks' read counts)
+    assert "of all 2 ranks" in d["parity"]["all_reduce"]
+    assert int(d["parity"]["all_reduce"].split(" sum to the ")[1].split()[0]) >= 300001
+    assert abs(d["value"] - 300001 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-2 * d["value"]
