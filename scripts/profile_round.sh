@@ -33,3 +33,7 @@ python bench.py --workload exact 2> gpurun_out/${tag}_bench_exact.err > gpurun_o
 python bench.py --workload a2i 2> gpurun_out/${tag}_bench_a2i.err > gpurun_out/${tag}_bench_a2i.json
 python bench.py --workload varlen 2> gpurun_out/${tag}_bench_varlen.err > gpurun_out/${tag}_bench_varlen.json
 python bench.py --sorted --no-cpu-baseline --no-extras 2> /dev/null > gpurun_out/${tag}_bench_sorted.json
+# the shards a 2 / 4 / 8-GPU strong-scaling job gives every rank, on this one GPU (the all-reduce is not in them)
+for pair in 12500000:12m5 25000000:25m 50000000:50m 100000000:full; do
+  python bench.py --no-cpu-baseline --no-extras --reads ${pair%%:*} 2> /dev/null > gpurun_out/${tag}_shard_${pair##*:}.json
+done
