@@ -227,3 +227,30 @@ def test_cascade_over_a_compact_upload_equals_the_arrays(engine, native_lib, ora
     for a, b in zip(got.stats, want_stats):
         assert (a["processed"], a["aligned"]) == (b["processed"], b["aligned"])
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_device_ingest_on_random_adapter_sets(engine, tmp_path, seed):
+    """Random adapter sets (one to four adapters of 6..48 bases, some of them prefixes of each other or low in
+    complexity), read lengths, phred bases and line ends: the device parser's adapter search (cutadapt's semi-global
+    alignment, one thread per read) = the host parser = oracle/ingest.py, array for array."""
+    rng = np.random.default_rng(500 + seed)
+    ads = []
+    for _ in range(int(rng.integers(1, 5))):
+        L = int(rng.integers(6, 49))
+        kind = rng.random()
+        if kind < 0.2 and ads:
+            a = ads[0][:max(6, L // 2)]                                   # a prefix of another adapter
+        elif kind < 0.35:
+            a = ("ACGT"[int(rng.integers(0, 4))] * L)[:L]                 # a homopolymer
+        elif kind < 0.5:
+            a = ("AC" * L)[:L]                                            # a dinucleotide repeat
+        else:
+            a = "".join("ACGT"[c] for c in rng.integers(0, 4, L))
+        ads.append(a)
+    ads = list(dict.fromkeys(ads))
+    p = str(tmp_path / ("r%d.fastq" % seed))
+    make_fastq(p, rng, n=4000, max_len=int(rng.choice([36, 50, 76, 101])), phred=int(rng.choice([33, 33, 64])), crlf=bool(rng.random() < 0.3),
+               final_newline=bool(rng.random() < 0.7), adapters=tuple(ads))
+    dev = same_as_host_and_oracle(engine, p, ",".join(ads))
+    assert 0 < dev["kept"] < dev["total"]
