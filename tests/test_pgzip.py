@@ -144,3 +144,43 @@ def test_fastq_loader_reads_gzip_through_the_parallel_reader(native_lib, tmp_pat
         assert a[k] == b[k], k
     assert np.array_equal(a["words"], b["words"]) and np.array_equal(a["lens"], b["lens"])
     assert (a["nmask"] is None) == (b["nmask"] is None) and (a["nmask"] is None or np.array_equal(a["nmask"], b["nmask"]))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_parallel_inflate_on_random_streams(native_lib, tmp_path, monkeypatch, seed):
+    """Deflate streams as other writers make them: every zlib strategy (fixed-Huffman blocks only, Huffman without
+    matches, run-length, filtered), small memLevels (many short blocks), full flushes in odd places (empty stored
+    blocks, byte-aligned restarts), several members, text of three kinds (FASTQ, long repeats, random bytes), chunk
+    sizes that put chunk starts anywhere: the parallel reader returns zlib's bytes."""
+    rng = np.random.default_rng(900 + seed)
+    chunk = int(rng.choice([4096, 20000, 65536]))
+    monkeypatch.setenv("MIRGE_AMD_GZ_CHUNK", str(chunk))
+    parts = []
+    for _ in range(int(rng.integers(1, 4))):
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            parts.append(fastq_text(rng, int(rng.integers(3000, 20000))))
+        elif kind == 1:
+            unit = bytes(rng.integers(65, 91, int(rng.integers(1, 300))).astype(np.uint8))
+            parts.append(unit * int(rng.integers(2000, 20000)))                     # matches at every distance up to the window
+        else:
+            parts.append(bytes(rng.integers(0, 256, int(rng.integers(100000, 900000))).astype(np.uint8)))   # stored blocks mostly
+    blob, text = [], b"".join(parts)
+    for part in parts:     # one member per part
+        co = zlib.compressobj(int(rng.integers(1, 10)), zlib.DEFLATED, 31, int(rng.integers(1, 10)),
+                              int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED])))
+        at = 0
+        while at < len(part):
+            step = int(rng.integers(1, 400000))
+            blob.append(co.compress(part[at:at + step]))
+            at += step
+            if rng.random() < 0.3:
+                blob.append(co.flush(zlib.Z_FULL_FLUSH if rng.random() < 0.5 else zlib.Z_SYNC_FLUSH))
+        blob.append(co.flush())
+    p = str(tmp_path / "r.gz")
+    with open(p, "wb") as fh:
+        fh.write(b"".join(blob))
+    assert gzip.open(p).read() == text
+    big = os.path.getsize(p) >= 4 * chunk     # (a file of less than two chunks is zlib's)
+    for threads in (3, 8):
+        assert inflate(native_lib, p, threads, want_parallel=1 if big else None) == text
