@@ -272,6 +272,36 @@ def test_gpu_collapse_fused_and_general_paths(native_lib):
     assert out["words"].shape == (1, 0) and out["quant"].shape[0] == 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_read,W", [(32, 1), (60, 2), (128, 4), (255, 8)])
+def test_gpu_collapse_of_reads_of_every_packed_width(native_lib, max_read, W):
+    """quantReads.py:3-24 on the device for one to eight packed words per read, reads with N, three samples: the
+    unique reads, their per-sample counts and the length histogram of a dict keyed by the read string."""
+    from mirge_amd.engine import Engine
+    rng = np.random.default_rng(max_read)
+    pool = []
+    for _ in range(4000):
+        L = int(rng.integers(16, max_read + 1))
+        pool.append("".join("ACGTN"[c] for c in rng.choice(5, L, p=[.2475, .2475, .2475, .2475, .01])))
+    pool += [pool[0][:-1], pool[0] + "A" if len(pool[0]) < max_read else pool[1][:-2], "A" * max_read, "A" * (max_read - 1), "N" * 16]
+    idx = rng.zipf(1.3, 60000) % len(pool)
+    reads = [pool[i] for i in idx]
+    sample = rng.integers(0, 3, len(reads)).astype(np.uint16)
+    words, lens, nmask = pack.pack_reads(reads)
+    assert words.shape[0] == W
+    want, hist = {}, {}
+    for r, s in zip(reads, sample.tolist()):
+        want.setdefault(r, [0, 0, 0])[s] += 1
+        hist.setdefault(len(r), [0, 0, 0])[s] += 1
+    eng = Engine(0)
+    out = ingest.collapse(eng, words, lens, nmask, sample, n_samples=3, max_len=int(lens.max()))
+    got = pack.unpack_reads(np.ascontiguousarray(out["words"]), out["lens"], out["nmask"])
+    assert len(got) == len(want) == len(set(got))
+    for r, q in zip(got, out["quant"].tolist()):
+        assert q == want[r], r
+    assert out["length_hist"] == hist
+
+
 def test_compact_read_set_groups_by_length_and_escapes_large_counts():
     """pack.compact_read_set (the host side of mrg_expand_compact): a bit stream of 2 L bits per read in
     length groups, one-byte counts, escapes for counts >= 255 -- and back, bit by bit."""
