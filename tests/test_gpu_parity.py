@@ -438,6 +438,44 @@ def test_count_best_matches_exhaustive_scan(native_lib, oracle_lib):
 
 
 @pytest.mark.gpu
+def test_count_and_list_best_on_reads_of_four_and_eight_words(native_lib, oracle_lib):
+    """mrg_count_best / mrg_list_best_* (the -ai genome filters, the -trf listings) on reads of 65..255 nt: the
+    W = 4 and W = 8 instantiations of count_kernel = the exhaustive scan (seed in the first 28 bases or the whole
+    read; repeats, an N, a low-complexity stretch in the library)."""
+    from mirge_amd import pack
+    from mirge_amd.engine import ReadSet
+    eng, olib, _, _ = _repeat_world()
+    rng = np.random.default_rng(78)
+    seqs = olib.seqs
+    for lo, hi, W in ((65, 128, 4), (129, 255, 8)):
+        reads = []
+        for s in seqs[:2]:
+            for _ in range(120):
+                L = int(rng.integers(lo, hi + 1))
+                o = int(rng.integers(0, len(s) - L))
+                r = list(s[o:o + L].replace("N", "A"))
+                for _ in range(int(rng.integers(0, 4))):
+                    r[int(rng.integers(0, L))] = "ACGTN"[int(rng.integers(0, 5))]
+                reads.append("".join(r))
+        reads += ["A" * hi, ("ACGT" * 64)[:hi], seqs[0][:hi], seqs[1][-hi:]]
+        words, lens, nmask = pack.pack_reads(reads)
+        assert words.shape[0] == W
+        rs = ReadSet(words, lens, nmask, None, device=eng.device)
+        for seed_len, n_seed, n_total in ((28, 1, 2), (28, 0, 2), (1024, 2, 2), (1024, 0, 0)):
+            mm, cnt = eng.count_best(rs, "g", seed_len=seed_len, max_mm_seed=n_seed, max_mm_total=n_total)
+            bm, off, ref, pos = eng.list_best(rs, "g", seed_len=seed_len, max_mm_seed=n_seed, max_mm_total=n_total)
+            hits = 0
+            for i, r in enumerate(reads):
+                em, ec = model.best_stratum(olib, r, seed_len, n_seed, n_total)
+                assert (int(mm[i]), int(cnt[i])) == (em, min(ec, 255)), (r, seed_len, n_seed, n_total)
+                want, want_mm = model.align_all_best(olib, r, seed_len, n_seed, n_total)
+                got = list(zip(ref[off[i]:off[i + 1]].tolist(), pos[off[i]:off[i + 1]].tolist()))
+                assert got == want and (not want or int(bm[i]) == want_mm), (r, seed_len, n_seed, n_total)
+                hits += bool(want)
+            assert hits > (60 if n_total else 10)
+
+
+@pytest.mark.gpu
 def test_big_library_jump_tables(native_lib, oracle_lib):
     """A 4.8 Mbp library served from HBM with the k = 12 / 11 / 6 / 4 tables: GPU = CPU port,
     for W = 1 and W = 2 reads."""
