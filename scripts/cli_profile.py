@@ -42,7 +42,7 @@ t0 = time.time()
 pr.enable()
 out = cli.annotate_main(args)
 pr.disable()
-print("annotate: %.1f s for %d raw reads, %d unique" % (time.time() - t0, 2 * n, len(out["seqDic"])))
+print("annotate: %.1f s for %d raw reads, %d unique" % (time.time() - t0, 2 * n, out["n_unique"]))
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(22)
 print(s.getvalue()[:6000])

@@ -88,3 +88,54 @@ def test_python2_float_formatting():
              2.5e-05: "2.5e-05", 100.0: "100.0", 66.66666666666666: "66.6666666667"}
     for x, want in cases.items():
         assert report.py2_float_str(x) == want
+
+
+def test_read_table_writer_many_blocks_equals_one_thread(native_lib, tmp_path, monkeypatch):
+    """mapped.csv / unmapped.csv of 700 000 reads (several blocks of rows per formatting thread, one to four packed
+    words, reads with N, three samples): the same bytes whatever the number of formatting threads, and the rows a
+    Python loop over the arrays writes."""
+    import numpy as np
+    from mirge_amd import columnar, pack
+    rng = np.random.default_rng(12)
+    n = 700_000
+    lens = rng.integers(16, 41, n).astype(np.uint8)
+    lens[::1000] = 128
+    W = 4
+    words = rng.integers(0, 1 << 63, (W, n), dtype=np.uint64)
+    nmask = np.zeros((W, n), dtype=np.uint64)
+    nmask[0, ::777] = 1 << 10
+    pass_id = rng.integers(-1, 3, n).astype(np.int8)
+    names = [["a%d" % i for i in range(50)], ["b%d" % i for i in range(7)], ["c%d" % i for i in range(300)]]
+    ref_id = np.where(pass_id >= 0, rng.integers(0, 7, n), -1).astype(np.int32)
+    quant = rng.integers(0, 1000, (n, 3)).astype(np.uint32)
+    outs = {}
+    for threads in ("1", "5", None):
+        if threads is None:
+            monkeypatch.delenv("MIRGE_AMD_TABLE_THREADS", raising=False)
+        else:
+            monkeypatch.setenv("MIRGE_AMD_TABLE_THREADS", threads)
+        d = tmp_path / ("t%s" % threads)
+        d.mkdir()
+        rows = columnar.write_read_tables(str(d), ["A", "B", "C"], ["s0", "s1", "s2"], words, lens, nmask, quant, pass_id, ref_id, names)
+        assert rows["mapped.csv"] == int((pass_id >= 0).sum()) and rows["unmapped.csv"] == int((pass_id < 0).sum())
+        outs[threads] = {fn: open(str(d / fn), "rb").read() for fn in ("mapped.csv", "unmapped.csv")}
+    assert outs["1"] == outs["5"] == outs[None]
+    seqs = pack.unpack_reads(words[:, :3000].copy(), lens[:3000], nmask[:, :3000].copy())
+    want_m, want_u = [], []
+    for i, s in enumerate(seqs):
+        p = int(pass_id[i])
+        slots = ["", "", ""]
+        if p >= 0:
+            slots[p] = names[p][int(ref_id[i])]
+        row = "%s,%d,%s,%s" % (s, 1 if p >= 0 else 0, ",".join(slots), ",".join(str(int(x)) for x in quant[i]))
+        (want_m if p >= 0 else want_u).append(row)
+    got_m = outs["1"]["mapped.csv"].decode().split("\n")
+    got_u = outs["1"]["unmapped.csv"].decode().split("\n")
+    assert got_m[0] == "uniqueSequence,annotFlag,A,B,C,s0,s1,s2" and got_m[1:1 + len(want_m)] == want_m
+    assert got_u[1:1 + len(want_u)] == want_u
+    # an entry index beyond its pass's names is an error, not a crash or a wrong row
+    bad = ref_id.copy()
+    bad[np.flatnonzero(pass_id == 1)[-1]] = 7
+    from mirge_amd._native import MirgeAmdError
+    with pytest.raises(MirgeAmdError, match="out of range"):
+        columnar.write_read_tables(str(tmp_path), ["A", "B", "C"], ["s0", "s1", "s2"], words, lens, nmask, quant, pass_id, bad, names)
