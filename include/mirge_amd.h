@@ -224,7 +224,7 @@ typedef struct mrg_pass_cfg {
   int32_t trim5;        /* -5 */
   int32_t trim3;        /* -3 */
   int32_t min_len;      /* length filter of RAP:543-554: process min_len<=len<=max_len */
-  int32_t max_len;
+  int32_t max_len;      /* (255 = no upper bound: the reference's filters are `< 26`, `> 25` or none) */
   int32_t poly_t;       /* 1 = pass 3 (RAP:664-686): need T{3,}$, strip all 3' T, >=11 nt */
   int32_t reserved;
 } mrg_pass_cfg;
@@ -280,8 +280,8 @@ typedef struct mrg_pass_stats {
   uint32_t reserved;
 } mrg_pass_stats;
 
-/* Bytes of device workspace mrg_cascade_run needs for n reads (three index lists of n + 2^23 entries,
- * segment counts, counters: 12 B per read + 96 MB). */
+/* Bytes of device workspace mrg_cascade_run needs for n reads (three survivor lists of n + 2^23 entries of 16 bytes --
+ * the seed launches' lists carry their reads --, segment counts, counters: 48 B per read + 400 MB). */
 int mrg_cascade_workspace_bytes(uint64_t n, uint64_t *bytes);
 
 /*
@@ -337,6 +337,29 @@ int mrg_edit_tally_run_packed(mrg_ctx *ctx, const uint64_t *d_reads, uint32_t wo
                               uint32_t n_bins, int32_t lib, int32_t canon_pass, int32_t isomir_pass, int32_t isomir_trim5,
                               uint32_t flank5, uint32_t flank3, uint32_t from_base, uint32_t to_base, uint64_t *d_counts,
                               void *stream);
+/*
+ * The cascade for reads of ANY length (round 5).  writeSeqToAnnot (RAP:543-554) writes every unannotated read
+ * into a pass's FASTA whatever its length -- the length filters of RAP:574 are `< 26`, `> 25` or none -- and bowtie
+ * aligns it end to end; the batches of mrg_cascade_run describe a length in one byte.  A host sends the reads
+ * beyond 255 nt (an untrimmed long-cycle run, a read-through: a handful per sample) here, in the RAGGED form:
+ *   d_words     read r = d_words[d_word_off[r] .. d_word_off[r + 1]), ceil(len / 32) words, 32 bases per word,
+ *               base i of the read in bits [2 (i % 32), 2 (i % 32) + 1] of word i / 32 (as in the packed batches)
+ *   d_nmask     the same shape, or NULL when no read has an N
+ *   d_word_off  n + 1 offsets in words;  d_lens  n lengths in bases (any length < 2^31; short reads are fine too)
+ * Same passes, same policy fields and the same outputs as mrg_cascade_run -- fewest mismatches, then lowest entry,
+ * then lowest offset; -1 / -1 / -1 / 0 for an unannotated read -- with two differences: a pass's max_len of 255 or
+ * more means "no upper bound" (the reference has none), and trim5 may be any non-negative number.  One wave per read
+ * over the library's FM index (csrc/long_reads.hip): written for any length, not for speed.
+ *   d_pass_counts  NULL, or the 2 * n_pass uint64 (processed, aligned per pass) of the batch's mrg_cascade_run:
+ *                  the long reads' counts are ADDED to them (run it after that call, on the same stream)
+ *   stats          NULL, or n_pass host entries: processed / aligned / steps / candidates / lookups / ms are ADDED
+ *                  to what they hold (hand in mrg_cascade_stats' array, or a zeroed one)
+ * Synchronises `stream`.
+ */
+int mrg_cascade_run_long(mrg_ctx *ctx, const uint64_t *d_words, const uint64_t *d_nmask, const uint64_t *d_word_off,
+                         const uint32_t *d_lens, uint64_t n, const mrg_pass_cfg *passes, uint32_t n_pass,
+                         int8_t *d_pass_id, int32_t *d_ref_id, int32_t *d_pos, uint8_t *d_mm, uint64_t *d_pass_counts,
+                         mrg_pass_stats *stats, void *stream);
 /* Number of cascade runs this context has launched (a caller that reads statistics later can tell
  * whether they are still those of its own run). */
 int mrg_cascade_run_id(const mrg_ctx *ctx, uint64_t *run_id);
@@ -467,8 +490,8 @@ typedef struct mrg_fastq_info {
   uint32_t max_len;
   int32_t has_n;
   uint64_t n_long;         /* kept reads longer than 255 nt (MRG_MAX_WORDS words, one length byte): not among n_kept, not
-                              packed; read them with mrg_fastq_long_read.  The reference accepts any
-                              length; the host carries these as unannotated reads */
+                              in the packed batch; read them with mrg_fastq_long_read / mrg_fastq_copy_long and annotate
+                              them with mrg_cascade_run_long (the reference accepts any length) */
 } mrg_fastq_info;
 /* Plain or gzip FASTQ.  qual_cutoff 10 and min_len 16 are the reference's values
  * (trim_file.py:30,33).  adapter = the `-ad` value after __main__.py:123-127: NULL or "none",
@@ -486,6 +509,11 @@ int mrg_adapter_locate(const char *adapter, const char *read, double max_error_r
 int mrg_fastq_get_info(const mrg_fastq *fq, mrg_fastq_info *info);
 /* i-th over-long read (upper-case ASCII, valid until mrg_fastq_free). */
 int mrg_fastq_long_read(const mrg_fastq *fq, uint64_t i, const char **seq);
+/* The info.n_long over-long reads packed into the ragged form of mrg_cascade_run_long (same two-call protocol as
+ * mrg_pack_reads_ragged: words == NULL fills word_off[n_long + 1] and lens only).  In file order, duplicates included:
+ * the host collapses them (by their text, mrg_fastq_long_read) before it annotates them. */
+int mrg_fastq_copy_long(const mrg_fastq *fq, uint64_t *words, uint64_t *nmask, uint64_t *word_off, uint32_t *lens,
+                        int *has_n);
 /* Copy the packed reads out, widened to words_per_read words (>= the file's own);
  * nmask may be NULL when has_n is 0. */
 int mrg_fastq_copy(const mrg_fastq *fq, uint32_t words_per_read, uint64_t *words, uint8_t *lens,
@@ -607,6 +635,10 @@ int mrg_write_read_table(const char *path, int32_t mapped, const char *header, i
 /* Packing helper used by hosts without numpy: ASCII reads -> SoA words. */
 int mrg_pack_reads(const char *const *seqs, uint64_t n, uint32_t words_per_read,
                    uint64_t *reads, uint8_t *lens, uint64_t *nmask, int *has_n);
+/* ... and -> the ragged form of mrg_cascade_run_long.  Two calls: with words == NULL only word_off[n + 1] (and lens,
+ * if given) are filled -- word_off[n] is the number of words to allocate --, then with the buffers. */
+int mrg_pack_reads_ragged(const char *const *seqs, uint64_t n, uint64_t *words, uint64_t *nmask, uint64_t *word_off,
+                          uint32_t *lens, int *has_n);
 
 #ifdef __cplusplus
 }

@@ -105,6 +105,9 @@ SIGNATURES = {
                                             C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
                                             C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                             C.c_void_p]),
+    "mrg_cascade_run_long": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(PassCfg),
+                                       C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PassStats),
+                                       C.c_void_p]),
     "mrg_cascade_run_id": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "mrg_cascade_stats": (C.c_int, [C.c_void_p, C.POINTER(PassStats), C.c_uint32]),
     "mrg_tally_counts_len": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32,
@@ -163,6 +166,9 @@ SIGNATURES = {
                                        C.POINTER(C.c_uint64)]),
     "mrg_pack_reads": (C.c_int, [C.POINTER(C.c_char_p), C.c_uint64, C.c_uint32, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "mrg_pack_reads_ragged": (C.c_int, [C.POINTER(C.c_char_p), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_int)]),
+    "mrg_fastq_copy_long": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
 }
 
 _lib = None

@@ -66,8 +66,10 @@ def runAnnotationPipeline(engine, seqDic, numCPU, phred64, annotNameList, output
         files["spike-in"] = file_spikeIn
     try:
         _ensure_libraries(engine, files)
-        # reads beyond the 255-nt packing limit stay unannotated (annot[0] = 0), as the CLI carries them
+        # one length byte per read in the packed batch: reads beyond 255 nt run the same passes through
+        # mrg_cascade_run_long (the reference offers a read of any length to every pass: RAP:543-554)
         seqs = [s for s in seqDic.keys() if len(s) <= 255]
+        long_seqs = [s for s in seqDic.keys() if len(s) > 255]
         words, lens, nmask = pack.pack_reads(seqs) if seqs else \
             (np.zeros((1, 0), np.uint64), np.zeros(0, np.uint8), None)
         passes = engine.mirge_passes(spike_in=bool(spikeIn))
@@ -76,6 +78,11 @@ def runAnnotationPipeline(engine, seqDic, numCPU, phred64, annotNameList, output
         res = engine.cascade(rs, passes)
         stats = res.stats
         pass_id, ref_id, pos, mm = res.to_host()
+        if long_seqs:
+            lp, lr, lo, lm, _ = engine.cascade_long(long_seqs, passes, stats=stats)
+            seqs = seqs + long_seqs
+            pass_id, ref_id = np.concatenate([pass_id, lp]), np.concatenate([ref_id, lr])
+            pos, mm = np.concatenate([pos, lo]), np.concatenate([mm, lm])
         wall = time.time() - t0
     except MirgeAmdError as e:
         # RAP:661-663 / RAP:702-704: message + exit status 1

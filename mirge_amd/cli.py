@@ -271,7 +271,7 @@ def annotate_main(args, engine_factory=None, materialize=False):
     for i, (fq, dt) in zip(mine, loaded):
         quant_stats[i] = {"filename": sample_list[i], "totalReads": fq["total"], "trimmedReads": fq["kept"],
                           "cpuTime-trim": dt, "cpuTime-uniq": 0.0}
-        for r in fq["long_reads"]:   # beyond the packing limit: carried on the host, never aligned
+        for r in fq["long_reads"]:   # beyond the one-byte length of the packed batch: collapsed here, annotated by cascade_long
             long_counts.setdefault(r, [0] * S)[i] += 1
     t1 = time.time()
     # the batch's shape must be the same on every rank: words per read, N mask or not, longest read
@@ -385,17 +385,31 @@ def annotate_main(args, engine_factory=None, materialize=False):
     print("Summarizing and tabulating results...")
     t3 = time.time()
     fused_h = fused.cpu().numpy()
+    # ---- the reads beyond 255 nt (RAP:543-554 offers a read of any length to every pass): the same passes through
+    # mrg_cascade_run_long, their counters and tallies added to the reduced vector, their rows to the tables ----
+    long_seqs = list(long_counts)
+    long_res = None
+    if long_seqs:
+        lp, lr, lo, lm, lstats = engine.cascade_long(long_seqs, passes)
+        lq = np.array([long_counts[s] for s in long_seqs], dtype=np.uint32).reshape(len(long_seqs), S)
+        for i, st in enumerate(lstats):
+            fused_h[ln + 2 * i] += st["processed"]
+            fused_h[ln + 2 * i + 1] += st["aligned"]
+            stats[i]["ms"] += st["ms"]
+
+        class _LongResult:
+            pass
+        lres = _LongResult()
+        lres.pass_id, lres.ref_id, lres.n_pass = torch.from_numpy(lp).to(dev), torch.from_numpy(lr).to(dev), n_pass
+        lrs = ReadSet(np.zeros((1, len(long_seqs)), np.uint64), np.zeros(len(long_seqs), np.uint8), None, lq, device=dev)
+        fused_h[:ln] += engine.tally(lrs, lres, M, CANON_PASS, ISOMIR_PASS).cpu().numpy()
+        long_res = (long_seqs, lq, lp, lr, lo, lm)
     gpu_ms = sum(s["ms"] for s in stats) or 1.0
     for i, s in enumerate(stats):   # RAP:640-705 (the reference stores wall seconds per bowtie run)
         log_dic["annotStats"].append({"cpuTime": wall * s["ms"] / gpu_ms, "readsProcessed": int(fused_h[ln + 2 * i]),
                                       "readsAligned": int(fused_h[ln + 2 * i + 1])})
     mir_dic, name_seq = {}, {}
     annotate.summarize_from_counts(fused_h[:ln], engine.indexes["mirna"].names, sample_list, log_dic, mir_dic, spike)
-    for seq, q in long_counts.items():   # the unpacked reads: unique, unannotated (SUM:34-66)
-        for i in range(S):
-            if q[i]:
-                log_dic["quantStats"][i]["trimmedUniq"] += 1
-                log_dic["quantStats"][i]["remReads"] += q[i]
     annotate.miRNAmerge(merge_file, sample_list, mir_dic, mirna_fa, name_seq)
     annotate.filter(mir_dic, sample_list, log_dic, args.canoRatio)
     h_pass, h_ref, h_pos, h_mm = (t.cpu().numpy() for t in (pass_id, ref_id, pos, mm))
@@ -423,10 +437,12 @@ def annotate_main(args, engine_factory=None, materialize=False):
 
     report.write_annotation_report_csv(os.path.join(outdir, "annotation.report.csv"), sample_list, log_dic, spike)
     columnar.write_read_tables(outdir, names, sample_list, h_words, h_lens, h_nmask, h_quant, h_pass, h_ref, npp,
-                               extra_unmapped=long_counts)
+                               extra=long_res)
     # the reads the remaining consumers look at
     want = {CANON_PASS, ISOMIR_PASS} | ({2, 3} if args.trf_output else set())
     sub, align = columnar.read_subset(h_words, h_lens, h_nmask, h_quant, h_pass, h_ref, h_pos, h_mm, npp, want, spike)
+    if long_res is not None:
+        columnar.add_long_records(sub, align, long_res, npp, want, spike)
     if args.gff_output:   # RAP:609-619, :653-656
         from . import isomir
         hairpin_seqs = engine.indexes["hairpin"].name_seq_dict()
@@ -458,8 +474,8 @@ def annotate_main(args, engine_factory=None, materialize=False):
     if materialize:
         seq_dic = columnar.full_seq_dic(h_words, h_lens, h_nmask, h_quant, h_pass, h_ref, npp, spike)
         width = 11 if spike else 10
-        for s, q in long_counts.items():
-            seq_dic[s] = {"quant": list(q), "annot": [0] + [""] * (width - 1), "length": len(s)}
+        if long_res is not None:
+            columnar.add_long_records(seq_dic, {}, long_res, npp, None, spike)
         out["seqDic"] = seq_dic
     return out
 

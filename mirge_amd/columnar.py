@@ -58,10 +58,10 @@ def names_by_pass(engine, spike_in=False):
 
 
 def write_read_tables(outdir, annot_names, sample_list, words, lens, nmask, quant, pass_id, ref_id,
-                      names_per_pass, extra_unmapped=None):
+                      names_per_pass, extra=None):
     """mapped.csv and unmapped.csv from the host arrays, in array order, without a Python row loop.
-    extra_unmapped: {sequence: [count per sample]} of reads that never entered the arrays (reads
-    beyond the 255-nt packing limit), appended to unmapped.csv as unannotated rows."""
+    extra: (sequences, quant [k, S], pass_id, ref_id, ...) of the reads that never entered the packed arrays (reads
+    beyond 255 nt, annotated by Engine.cascade_long): their rows are appended to the table they belong in."""
     lib = _native.load()
     words = np.ascontiguousarray(words, dtype=np.uint64)
     W, n = words.shape
@@ -85,12 +85,34 @@ def write_read_tables(outdir, annot_names, sample_list, words, lens, nmask, quan
             None if nm is None else nm.ctypes.data, n, pass_id.ctypes.data, ref_id.ctypes.data, quant.ctypes.data, S,
             n_slots, arr, off.ctypes.data, C.byref(k)))
         rows[fn] = int(k.value)
-    if extra_unmapped:
-        with open(os.path.join(outdir, "unmapped.csv"), "a") as fh:
-            for seq, q in extra_unmapped.items():
-                fh.write(seq + ",0" + "," * n_slots + "," + ",".join(str(int(x)) for x in q) + "\n")
-                rows["unmapped.csv"] += 1
+    if extra is not None:
+        e_seqs, e_quant, e_pass, e_ref = extra[:4]
+        with open(os.path.join(outdir, "mapped.csv"), "a") as fm, open(os.path.join(outdir, "unmapped.csv"), "a") as fu:
+            for k, seq in enumerate(e_seqs):
+                p = int(e_pass[k])
+                slots = [""] * n_slots
+                if p >= 0:
+                    slots[p] = names_per_pass[p][int(e_ref[k])]
+                row = "%s,%d,%s,%s\n" % (seq, 1 if p >= 0 else 0, ",".join(slots), ",".join(str(int(x)) for x in e_quant[k]))
+                (fm if p >= 0 else fu).write(row)
+                rows["mapped.csv" if p >= 0 else "unmapped.csv"] += 1
     return rows
+
+
+def add_long_records(records, align, extra, names_per_pass, passes=None, spike_in=False):
+    """The reads of `extra` (write_read_tables) as seqDic-shaped records / alignments, as read_subset and
+    full_seq_dic build them for the packed reads: those claimed by one of `passes` (None: every read)."""
+    e_seqs, e_quant, e_pass, e_ref, e_pos, e_mm = extra
+    width = 11 if spike_in else 10
+    for k, seq in enumerate(e_seqs):
+        p = int(e_pass[k])
+        if passes is not None and p not in passes:
+            continue
+        annot = [1 if p >= 0 else 0] + [""] * (width - 1)
+        if p >= 0:
+            annot[p + 1] = names_per_pass[p][int(e_ref[k])]
+            align[seq] = (p, int(e_ref[k]), int(e_pos[k]), int(e_mm[k]))
+        records[seq] = {"quant": [int(x) for x in e_quant[k]], "annot": annot, "length": len(seq)}
 
 
 def read_subset(words, lens, nmask, quant, pass_id, ref_id, pos, mm, names_per_pass, passes, spike_in=False,

@@ -1777,6 +1777,114 @@ int mrg_cascade_stats(mrg_ctx* ctx, mrg_pass_stats* out, uint32_t n_pass) {
   return MRG_OK;
 }
 
+// ------------------------------------------------------- reads of any length
+int mrg_cascade_run_long(mrg_ctx* ctx, const uint64_t* d_words, const uint64_t* d_nmask, const uint64_t* d_word_off,
+                         const uint32_t* d_lens, uint64_t n, const mrg_pass_cfg* passes, uint32_t n_pass, int8_t* d_pass_id,
+                         int32_t* d_ref_id, int32_t* d_pos, uint8_t* d_mm, uint64_t* d_pass_counts, mrg_pass_stats* stats,
+                         void* stream_) {
+  if (!ctx || !passes) return fail(MRG_ERR_ARG, "mrg_cascade_run_long: null argument");
+  if (n && (!d_words || !d_word_off || !d_lens || !d_pass_id || !d_ref_id || !d_pos || !d_mm))
+    return fail(MRG_ERR_ARG, "mrg_cascade_run_long: null read/output buffers");
+  if (n_pass == 0 || n_pass > MRG_MAX_PASSES)
+    return fail(MRG_ERR_ARG, "mrg_cascade_run_long: n_pass %u not in [1,%d]", n_pass, MRG_MAX_PASSES);
+  if (n >= 0xfffffff0ull) return fail(MRG_ERR_ARG, "mrg_cascade_run_long: at most 2^32-16 reads per call");
+  std::vector<mrg::LongPass> host(n_pass);
+  for (uint32_t i = 0; i < n_pass; ++i) {
+    const mrg_pass_cfg& c = passes[i];
+    if (c.lib < 0 || (size_t)c.lib >= ctx->libs.size())
+      return fail(MRG_ERR_ARG, "mrg_cascade_run_long: pass %u names unknown library %d", i, c.lib);
+    if (c.max_mm_seed < 0 || c.max_mm_seed > 3 || c.max_mm_total < c.max_mm_seed || c.max_mm_total > 255 || c.trim5 < 0 ||
+        c.trim3 < 0 || c.seed_len < 1)
+      return fail(MRG_ERR_ARG, "mrg_cascade_run_long: pass %u has an invalid policy", i);
+    const DevLib& l = ctx->libs[c.lib];
+    mrg::LongPass& q = host[i];
+    std::memset(&q, 0, sizeof q);
+    q.blocks = l.blocks;
+    q.super = l.super;
+    q.text = l.text;
+    q.sa = l.sa;
+    q.ftab = l.ftab;
+    q.tabs = l.tabs;
+    if (!ctx->use_ftab || !l.ftab) q.tabs.k[0] = 0u;
+    q.seg_start = l.seg_start;
+    q.seg_ref = l.seg_ref;
+    q.seg_off = l.seg_off;
+    q.chunk_seg = l.chunk_seg;
+    q.n = l.n;
+    q.primary = l.primary;
+    q.simple_segs = l.simple ? 1u : 0u;
+    q.seed_len = c.seed_len;
+    q.max_mm_seed = c.max_mm_seed;
+    q.max_mm_total = c.max_mm_total;
+    q.trim5 = c.trim5;
+    q.trim3 = c.trim3;
+    q.min_len = c.min_len;
+    q.max_len = c.max_len;
+    q.poly_t = c.poly_t;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  struct Scratch {
+    void* p = nullptr;
+    ~Scratch() { (void)hipFree(p); }
+  } scratch;
+  const size_t table_bytes = ((size_t)n_pass * sizeof(mrg::LongPass) + 255) / 256 * 256;
+  const size_t stats_bytes = (size_t)n_pass * kStatsPerPass * 8;
+  HIP_TRY(hipMalloc(&scratch.p, table_bytes + stats_bytes));
+  uint64_t* d_stats = reinterpret_cast<uint64_t*>((char*)scratch.p + table_bytes);
+  HIP_TRY(hipMemcpyAsync(scratch.p, host.data(), (size_t)n_pass * sizeof(mrg::LongPass), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemsetAsync(d_stats, 0, stats_bytes, stream));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  hipError_t err = hipEventRecord(e0, stream);
+  if (err == hipSuccess && n) {
+    mrg::LongParams p;
+    std::memset(&p, 0, sizeof p);
+    p.pass = reinterpret_cast<const mrg::LongPass*>(scratch.p);
+    p.n_pass = n_pass;
+    p.words = d_words;
+    p.nmask = d_nmask;
+    p.word_off = d_word_off;
+    p.lens = d_lens;
+    p.n = (uint32_t)n;
+    p.wstop = (uint32_t)ctx->wstop;
+    p.pass_id = d_pass_id;
+    p.ref_id = d_ref_id;
+    p.pos = d_pos;
+    p.mm = d_mm;
+    p.counters = d_stats;
+    p.pass_counts = d_pass_counts;
+    // one wave per read, four per workgroup; more reads than resident waves: the kernel strides
+    const uint64_t want = (n + 3) / 4;
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)ctx->n_cu * 8u));
+    err = mrg::launch_long_reads(p, grid, stream);
+  }
+  if (err == hipSuccess) err = hipEventRecord(e1, stream);
+  uint64_t got[MRG_MAX_PASSES * kStatsPerPass];
+  if (err == hipSuccess) err = hipMemcpyAsync(got, d_stats, stats_bytes, hipMemcpyDeviceToHost, stream);
+  if (err == hipSuccess) err = hipStreamSynchronize(stream);
+  float ms = 0.f;
+  if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  HIP_TRY(err);
+  if (stats) {
+    uint64_t offered = 0;
+    for (uint32_t i = 0; i < n_pass; ++i) offered += got[i * kStatsPerPass];
+    for (uint32_t i = 0; i < n_pass; ++i) {
+      stats[i].processed += got[i * kStatsPerPass + 0];
+      stats[i].aligned += got[i * kStatsPerPass + 1];
+      stats[i].steps += got[i * kStatsPerPass + 2];
+      stats[i].candidates += got[i * kStatsPerPass + 3];
+      stats[i].lookups += got[i * kStatsPerPass + 4];
+      // one launch carries every pass: its time is shared out by the reads each pass was offered
+      if (offered) stats[i].ms += ms * (float)((double)got[i * kStatsPerPass] / (double)offered);
+    }
+  }
+  return MRG_OK;
+}
+
 // ----------------------------------------------------------------- tally
 int mrg_tally_counts_len(uint32_t n_mirna, uint32_t n_samples, uint32_t n_pass, uint64_t* len) {
   if (!len) return fail(MRG_ERR_ARG, "mrg_tally_counts_len: null argument");
@@ -2527,6 +2635,62 @@ int mrg_pack_reads(const char* const* seqs, uint64_t n, uint32_t words_per_read,
   }
   if (has_n) *has_n = any_n;
   return MRG_OK;
+}
+
+// the ragged form of mrg_cascade_run_long: read r = words[word_off[r] .. word_off[r + 1]), ceil(len / 32) words
+static int pack_ragged(const char* const* seqs, uint64_t n, uint64_t* words, uint64_t* nmask, uint64_t* word_off, uint32_t* lens,
+                       int* has_n) {
+  int any_n = 0;
+  uint64_t at = 0;
+  for (uint64_t r = 0; r < n; ++r) {
+    const char* s = seqs[r];
+    const size_t L = std::strlen(s);
+    if (L > 0x7fffffffull) return fail(MRG_ERR_ARG, "mrg_pack_reads_ragged: read %llu is too long", (unsigned long long)r);
+    const uint64_t nw = (L + 31) / 32;
+    if (word_off) word_off[r] = at;
+    if (lens) lens[r] = (uint32_t)L;
+    if (words) {
+      for (uint64_t w = 0; w < nw; ++w) {
+        words[at + w] = 0;
+        if (nmask) nmask[at + w] = 0;
+      }
+      for (size_t i = 0; i < L; ++i) {
+        uint64_t code = 0;
+        bool isn = false;
+        switch (s[i]) {
+          case 'A': case 'a': code = 0; break;
+          case 'C': case 'c': code = 1; break;
+          case 'G': case 'g': code = 2; break;
+          case 'T': case 't': code = 3; break;
+          default: isn = true; break;
+        }
+        words[at + (i >> 5)] |= code << ((i & 31) * 2);
+        if (isn) {
+          any_n = 1;
+          if (nmask) nmask[at + (i >> 5)] |= 1ull << ((i & 31) * 2);
+        }
+      }
+    }
+    at += nw;
+  }
+  if (word_off) word_off[n] = at;
+  if (has_n) *has_n = any_n;
+  return MRG_OK;
+}
+
+int mrg_pack_reads_ragged(const char* const* seqs, uint64_t n, uint64_t* words, uint64_t* nmask, uint64_t* word_off,
+                          uint32_t* lens, int* has_n) {
+  if (n && !seqs) return fail(MRG_ERR_ARG, "mrg_pack_reads_ragged: null argument");
+  if (!word_off) return fail(MRG_ERR_ARG, "mrg_pack_reads_ragged: word_off is required");
+  return pack_ragged(seqs, n, words, nmask, word_off, lens, has_n);
+}
+
+int mrg_fastq_copy_long(const mrg_fastq* fq, uint64_t* words, uint64_t* nmask, uint64_t* word_off, uint32_t* lens, int* has_n) {
+  if (!fq || !word_off) return fail(MRG_ERR_ARG, "mrg_fastq_copy_long: null argument");
+  const auto& lr = fq->d.long_reads;
+  std::vector<const char*> ptrs(lr.size());
+  for (size_t i = 0; i < lr.size(); ++i) ptrs[i] = lr[i].c_str();
+  return pack_ragged(ptrs.data(), lr.size(), words, nmask, word_off, lens, has_n);
 }
 
 }  // extern "C"

@@ -363,6 +363,44 @@ hipError_t expand_compact(const uint64_t* d_bits, const CompactRuns& runs, const
 hipError_t launch_pack_assignments(const int8_t* pass_id, const int32_t* ref_id, const int32_t* pos, const uint8_t* mm, uint64_t n,
                                    uint32_t* packed, hipStream_t stream);
 
+// long_reads.hip: the cascade for reads of ANY length (runAnnotationPipeline.py:543-554 writes every unannotated
+// read into a pass's FASTA whatever its length; the packed batches of mrg_cascade_run stop at 255 nt, one length
+// byte).  Such reads are rare (an untrimmed long-cycle run, a read-through): one WAVE per read, the read left in
+// global memory in the ragged form (word_off[r] .. word_off[r + 1]), every pass of the cascade in turn over the
+// library's own FM index -- pigeonhole pieces of the seed region by backward search, every row of a piece's
+// interval located through the suffix array and verified against the text, 32 bases per step, by the wave's lanes.
+struct LongPass {
+  const uint32_t* blocks;
+  const uint32_t* super;
+  const uint32_t* text;
+  const uint64_t* sa;
+  const uint32_t* ftab;
+  JumpTables tabs;
+  const uint32_t* seg_start;
+  const uint32_t* seg_ref;
+  const uint32_t* seg_off;
+  const uint32_t* chunk_seg;
+  uint32_t n, primary, simple_segs;
+  int32_t seed_len, max_mm_seed, max_mm_total, trim5, trim3, min_len, max_len, poly_t;
+};
+struct LongParams {
+  const LongPass* pass;  // device array, n_pass entries
+  uint32_t n_pass;
+  const uint64_t* words;     // ragged: read r = words[word_off[r] .. word_off[r + 1]), 32 bases per word
+  const uint64_t* nmask;     // same shape or null
+  const uint64_t* word_off;  // n + 1
+  const uint32_t* lens;
+  uint32_t n;
+  uint32_t wstop;
+  int8_t* pass_id;
+  int32_t* ref_id;
+  int32_t* pos;
+  uint8_t* mm;
+  uint64_t* counters;     // [n_pass][5]: processed, aligned, steps, candidates, lookups (added to)
+  uint64_t* pass_counts;  // null, or [n_pass][2]: processed, aligned (added to: the count vector a sharded run reduces)
+};
+hipError_t launch_long_reads(const LongParams& p, uint32_t grid, hipStream_t stream);
+
 constexpr uint32_t kCountThreads = 256u;
 
 struct CountParams {

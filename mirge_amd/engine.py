@@ -229,6 +229,39 @@ class Engine:
             pass_counts.data_ptr(), ws.data_ptr(), ws.numel(), self._stream_ptr()))
         return CascadeResult(pass_id, ref_id, pos, mm, pass_counts, self, n_pass)
 
+    def cascade_long(self, seqs, passes, pass_counts=None, stats=None):
+        """The cascade for reads of ANY length (mrg_cascade_run_long; RAP:543-554 offers every unannotated read,
+        whatever its length, to every pass): `seqs` = ASCII reads the packed batches cannot describe (beyond 255 nt;
+        any length works).  Returns host arrays (pass_id int8, ref_id int32, pos int32, mm uint8) and the per-pass
+        dicts (processed, aligned, steps, candidates, lookups, ms) of these reads.  pass_counts: the device int64
+        [2 n_pass] vector of the batch's own cascade -- the long reads' processed / aligned are ADDED to it;
+        stats: the per-pass dicts of that cascade (CascadeResult.stats) -- added to in place.  Synchronises."""
+        torch = _torch()
+        from . import pack
+        n, n_pass = len(seqs), len(passes)
+        dev = self.device
+        words, nmask, word_off, lens = pack.pack_ragged(list(seqs))
+
+        def up(a, dt):
+            return torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev) if a is not None else None
+        d_words = up(np.append(words, np.uint64(0)), np.int64)   # (one word of padding: an empty batch still has a buffer)
+        d_nmask = up(None if nmask is None else np.append(nmask, np.uint64(0)), np.int64)
+        d_off, d_lens = up(word_off, np.int64), up(lens, np.int32)
+        out = (torch.empty(n, dtype=torch.int8, device=dev), torch.empty(n, dtype=torch.int32, device=dev),
+               torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.uint8, device=dev))
+        st = (PassStats * n_pass)()
+        check(self._lib.mrg_cascade_run_long(
+            self._h, d_words.data_ptr(), d_nmask.data_ptr() if d_nmask is not None else None, d_off.data_ptr(),
+            d_lens.data_ptr(), n, passes, n_pass, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
+            pass_counts.data_ptr() if pass_counts is not None else None, st, self._stream_ptr()))
+        own = [dict(processed=int(s.processed), aligned=int(s.aligned), steps=int(s.steps), candidates=int(s.candidates),
+                    lookups=int(s.lookups), ms=float(s.ms)) for s in st]
+        if stats is not None:
+            for mine, theirs in zip(own, stats):
+                for k, v in mine.items():
+                    theirs[k] += v
+        return tuple(t.cpu().numpy() for t in out) + (own,)
+
     def pack_assignments(self, result, out=None):
         """The four assignment arrays of a CascadeResult as one int32 word per read (mrg_pack_assignments:
         pass + 1 in bits 28-31, mismatches 26-27, entry 8-25, offset 0-7, the last three saturating):

@@ -78,6 +78,35 @@ def pack_reads(seqs, W=None):
     return words, lens.astype(np.uint8), (nmask if any_n else None)
 
 
+def pack_ragged(seqs):
+    """seqs: sequence of str of ANY length -> the ragged form of mrg_cascade_run_long: (words uint64 [total],
+    nmask uint64 [total] | None, word_off uint64 [n + 1], lens uint32 [n]); read r is words[word_off[r] :
+    word_off[r + 1]], ceil(len / 32) words (mrg_pack_reads_ragged; pure numpy, no library needed)."""
+    n = len(seqs)
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=n)
+    nw = (lens + 31) // 32
+    word_off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(nw, out=word_off[1:].view(np.int64))
+    total = int(word_off[n])
+    words = np.zeros(total, dtype=np.uint64)
+    nmask = np.zeros(total, dtype=np.uint64)
+    any_n = False
+    if total:
+        codes = _CODE[np.frombuffer("".join(seqs).encode("ascii"), dtype=np.uint8)]
+        base_off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lens, out=base_off[1:])
+        read_of = np.repeat(np.arange(n), lens)            # the read of every base
+        i = np.arange(codes.size) - base_off[read_of]      # its index in the read
+        slot = word_off[read_of].astype(np.int64) + (i >> 5)
+        sh = ((i & 31) * 2).astype(np.uint64)
+        isn = codes > 3
+        np.bitwise_or.at(words, slot, np.where(isn, 0, codes).astype(np.uint64) << sh)
+        if isn.any():
+            any_n = True
+            np.bitwise_or.at(nmask, slot[isn], np.uint64(1) << sh[isn])
+    return words, (nmask if any_n else None), word_off, lens.astype(np.uint32)
+
+
 def unpack_reads(words, lens, nmask=None):
     """Inverse of pack_reads (reports, tests, the dict-shaped host path): vectorised over reads."""
     words = np.asarray(words, dtype=np.uint64)

@@ -134,6 +134,48 @@ def run_annotation_pipeline(seq_dic, libraries, log_dic, spike_in=False, align_d
         log_dic["annotStats"].append({"readsProcessed": processed, "readsAligned": aligned})
 
 
+def scan_cascade(libraries, passes, seqs):
+    """The cascade of runAnnotationPipeline.py:636-705 for an ARBITRARY pass table and reads of ANY length, by
+    exhaustive scan, one read at a time (writeSeqToAnnot :543-554 + the length filter of :574, the poly-T rule of
+    :664-686, `-5` / `-3`, then the bowtie model): what the product's long-read lane and its random pass tables
+    are checked against.  libraries: {key: oracle.model.Library}; passes: dicts with lib (a key of `libraries`),
+    min_len, max_len (255 or more = no upper bound, as in include/mirge_amd.h), seed_len, max_mm_seed, max_mm_total,
+    trim5, trim3, poly_t.  Returns (pass_id, ref_id, pos, mm, [(processed, aligned) per pass])."""
+    import numpy as np
+    n = len(seqs)
+    pass_id = np.full(n, -1, np.int8)
+    ref_id = np.full(n, -1, np.int32)
+    pos = np.full(n, -1, np.int32)
+    mm = np.zeros(n, np.uint8)
+    counts = [[0, 0] for _ in passes]
+    open_reads = list(range(n))
+    for i, p in enumerate(passes):
+        offered, subs = [], []
+        for r in open_reads:
+            seq = seqs[r]
+            if len(seq) < p["min_len"] or (p["max_len"] < 255 and len(seq) > p["max_len"]):
+                continue
+            sub = seq
+            if p["poly_t"]:
+                if re.search("T{3,}$", seq) is None:
+                    continue
+                sub = seq.rstrip("T")
+                if len(sub) < 11:
+                    continue
+            offered.append(r)
+            subs.append(sub[p["trim5"]:len(sub) - p["trim3"]] if p["trim3"] else sub[p["trim5"]:])
+        ref, ps, m = model.align_batch(libraries[p["lib"]], subs, p["seed_len"], p["max_mm_seed"], p["max_mm_total"])
+        counts[i][0] = len(offered)
+        claimed = set()
+        for k, r in enumerate(offered):
+            if ref[k] >= 0:
+                counts[i][1] += 1
+                pass_id[r], ref_id[r], pos[r], mm[r] = i, ref[k], ps[k], m[k]
+                claimed.add(r)
+        open_reads = [r for r in open_reads if r not in claimed]
+    return pass_id, ref_id, pos, mm, counts
+
+
 CATEGORY_KEYS = ["mirnaReads", "hairpinReads", "maturetrnaReads", "pretrnaReads", "snornaReads",
                  "rrnaReads", "ncrnaOthersReads", "mrnaReads"]
 

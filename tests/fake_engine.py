@@ -79,3 +79,20 @@ class OracleEngine:
             return t
         counts += t
         return counts
+
+    def cascade_long(self, seqs, passes, pass_counts=None, stats=None):
+        """Engine.cascade_long by the oracle's exhaustive scan (oracle.cascade.scan_cascade: no index, reads of any
+        length)."""
+        from oracle import cascade as ocas
+        libs = {}
+        for p in passes:
+            ix = self.indexes[p["lib"]]
+            if p["lib"] not in libs:
+                libs[p["lib"]] = model.Library(ix.names, [ix.sequence(i) for i in range(ix.n_ref)])
+        pass_id, ref_id, pos, mm, counts = ocas.scan_cascade(libs, passes, list(seqs))
+        own = [dict(processed=c[0], aligned=c[1], steps=0, candidates=0, lookups=0, ms=0.0) for c in counts]
+        if stats is not None:
+            for a, b in zip(own, stats):
+                for k, v in a.items():
+                    b[k] += v
+        return pass_id, ref_id, pos, mm, own

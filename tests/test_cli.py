@@ -149,11 +149,12 @@ def test_cli_spikein_tcf_matches_reference_files(native_lib, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("device_ingest", [False, True])
-def test_cli_aligns_reads_of_up_to_255_nt_as_the_reference_does(native_lib, tmp_path, device_ingest):
+def test_cli_aligns_reads_of_every_length_as_the_reference_does(native_lib, tmp_path, device_ingest):
     """`annotate -ad none` on an untrimmed long-cycle run (tests/golden/long_reads.json: reads of 33..300 nt through
-    the reference's own collapse + cascade): FASTQ -> host or device parser (eight packed words per read) -> device
-    collapse -> cascade -> tables.  Every read of up to 255 nt carries the reference's annotation, the per-pass
-    counters are those of the reference's run without the longer reads, which are listed unannotated."""
+    the reference's own collapse + cascade): FASTQ -> host parser (the device parser hands a file with reads beyond
+    255 nt over to it) -> device collapse of the packed reads, host collapse of the longer ones -> cascade +
+    long-read lane -> tables.  EVERY read carries the reference's annotation, the per-pass counters and the
+    read-length table are those of the reference's run, and the annotated long reads are rows of mapped.csv."""
     import json
     import types
     from mirge_amd import synth
@@ -164,8 +165,7 @@ def test_cli_aligns_reads_of_up_to_255_nt_as_the_reference_does(native_lib, tmp_
     root = str(tmp_path / "libs")
     synth.SynthLibraries.write_layout(ns, root, species="syn", db="miRBase")
     p = str(tmp_path / golden["sample_list"][0])
-    # (the device parser hands a file with reads beyond 255 nt to the host parser: its variant gets the file without them)
-    reads = [r for r in golden["samples"][0] if len(r) <= 255 or not device_ingest]
+    reads = golden["samples"][0]
     with open(p, "w") as fh:
         for k, r in enumerate(reads):
             fh.write("@r%d\n%s\n+\n%s\n" % (k, r, "I" * len(r)))
@@ -176,16 +176,19 @@ def test_cli_aligns_reads_of_up_to_255_nt_as_the_reference_does(native_lib, tmp_
     assert set(out["seqDic"]) == set(reads)
     for s, rec in out["seqDic"].items():
         assert rec["quant"] == exp["seqDic"][s]["quant"], s
-        assert rec["annot"] == (exp["seqDic"][s]["annot"] if len(s) <= 255 else [0] + [""] * 9), s
+        assert rec["annot"] == exp["seqDic"][s]["annot"], s
     got_stats = [{k: a[k] for k in ("readsProcessed", "readsAligned")} for a in out["logDic"]["annotStats"]]
-    assert got_stats == exp["annotStats_le255"]
-    if not device_ingest:
-        assert out["readLengthDic"] == {int(k): v for k, v in exp["readLengthDic"].items()}
+    assert got_stats == exp["annotStats"]
+    assert out["readLengthDic"] == {int(k): v for k, v in exp["readLengthDic"].items()}
     mapped = open(os.path.join(out["outdir"], "mapped.csv")).read().split("\n")
     unmapped = open(os.path.join(out["outdir"], "unmapped.csv")).read().split("\n")
-    longest = max((s for s, r in exp["seqDic"].items() if len(s) <= 255 and r["annot"][0]), key=len)
-    assert len(longest) > 240 and any(l.startswith(longest + ",1,") for l in mapped)
-    assert sum(1 for l in unmapped if l.split(",")[0] and len(l.split(",")[0]) > 255) == sum(1 for s in set(reads) if len(s) > 255)
+    for table, flag in ((mapped, 1), (unmapped, 0)):
+        want = {s for s, r in exp["seqDic"].items() if r["annot"][0] == flag}
+        rows = {l.split(",")[0]: l.split(",") for l in table[1:] if l}
+        assert set(rows) == want
+        for s, f in rows.items():
+            assert f[1:11] == [str(x) for x in exp["seqDic"][s]["annot"]] and f[11:] == [str(q) for q in exp["seqDic"][s]["quant"]]
+    assert sum(1 for l in mapped if len(l.split(",")[0]) > 255) == 28
 
 
 @pytest.mark.gpu
