@@ -475,6 +475,11 @@ int mrg_annotate_host(mrg_ctx *ctx, const uint64_t *reads, uint32_t words_per_re
                       uint32_t n_samples, uint32_t n_mirna, int32_t canon_pass,
                       int32_t isomir_pass, uint64_t *counts);
 
+/* mrg_cascade_run_long with HOST buffers (same ragged form; stats may be NULL, else it is added to). */
+int mrg_annotate_long_host(mrg_ctx *ctx, const uint64_t *words, const uint64_t *nmask, const uint64_t *word_off,
+                           const uint32_t *lens, uint64_t n, const mrg_pass_cfg *passes, uint32_t n_pass,
+                           int8_t *pass_id, int32_t *ref_id, int32_t *pos, uint8_t *mm, mrg_pass_stats *stats);
+
 /* ------------------------------------------------------------------ *
  * Ingest: FASTQ -> packed reads (host), raw reads -> unique reads with
  * per-sample counts (device).  Replaces trim_file with `-ad none`

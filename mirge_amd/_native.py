@@ -138,6 +138,8 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PassStats),
                                     C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32,
                                     C.c_void_p]),
+    "mrg_annotate_long_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(PassCfg),
+                                         C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PassStats)]),
     "mrg_fastq_load": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32,
                                  C.POINTER(C.c_void_p)]),
     "mrg_adapter_locate": (C.c_int, [C.c_char_p, C.c_char_p, C.c_double, C.c_int32, C.POINTER(C.c_int32)]),

@@ -2334,6 +2334,56 @@ int mrg_annotate_host(mrg_ctx* ctx, const uint64_t* reads, uint32_t words_per_re
   return MRG_OK;
 }
 
+// the long-read lane for a caller without a device allocator (the ctypes stub of INTEGRATION.md)
+int mrg_annotate_long_host(mrg_ctx* ctx, const uint64_t* words, const uint64_t* nmask, const uint64_t* word_off, const uint32_t* lens,
+                           uint64_t n, const mrg_pass_cfg* passes, uint32_t n_pass, int8_t* pass_id, int32_t* ref_id, int32_t* pos,
+                           uint8_t* mm, mrg_pass_stats* stats) {
+  if (!ctx || !passes) return fail(MRG_ERR_ARG, "mrg_annotate_long_host: null argument");
+  if (n && (!words || !word_off || !lens || !pass_id || !ref_id || !pos || !mm))
+    return fail(MRG_ERR_ARG, "mrg_annotate_long_host: null read/output buffers");
+  if (n == 0) return MRG_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  struct Bufs {
+    std::vector<void*> v;
+    ~Bufs() {
+      for (void* p : v) (void)hipFree(p);
+    }
+    int get(void** p, size_t bytes) {
+      hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+      if (e != hipSuccess) return fail(MRG_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+      v.push_back(*p);
+      return MRG_OK;
+    }
+  } bufs;
+  const size_t wbytes = (size_t)word_off[n] * 8;
+  uint64_t *d_words = nullptr, *d_nmask = nullptr, *d_off = nullptr;
+  uint32_t* d_lens = nullptr;
+  int8_t* d_pass = nullptr;
+  int32_t *d_ref = nullptr, *d_pos = nullptr;
+  uint8_t* d_mm = nullptr;
+  int rc;
+  if ((rc = bufs.get((void**)&d_words, wbytes))) return rc;
+  if (nmask && (rc = bufs.get((void**)&d_nmask, wbytes))) return rc;
+  if ((rc = bufs.get((void**)&d_off, (n + 1) * 8))) return rc;
+  if ((rc = bufs.get((void**)&d_lens, n * 4))) return rc;
+  if ((rc = bufs.get((void**)&d_pass, n))) return rc;
+  if ((rc = bufs.get((void**)&d_ref, n * 4))) return rc;
+  if ((rc = bufs.get((void**)&d_pos, n * 4))) return rc;
+  if ((rc = bufs.get((void**)&d_mm, n))) return rc;
+  if (wbytes) HIP_TRY(hipMemcpy(d_words, words, wbytes, hipMemcpyHostToDevice));
+  if (nmask && wbytes) HIP_TRY(hipMemcpy(d_nmask, nmask, wbytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_off, word_off, (n + 1) * 8, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_lens, lens, n * 4, hipMemcpyHostToDevice));
+  if ((rc = mrg_cascade_run_long(ctx, d_words, d_nmask, d_off, d_lens, n, passes, n_pass, d_pass, d_ref, d_pos, d_mm, nullptr, stats,
+                                 nullptr)))
+    return rc;
+  HIP_TRY(hipMemcpy(pass_id, d_pass, n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(ref_id, d_ref, n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(pos, d_pos, n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(mm, d_mm, n, hipMemcpyDeviceToHost));
+  return MRG_OK;
+}
+
 // -------------------------------------------------------------- ingest
 int mrg_adapter_locate(const char* adapter, const char* read, double max_error_rate, int32_t min_overlap,
                        int32_t* out6) {

@@ -162,8 +162,11 @@ def test_cli_ranks_write_the_same_tables_as_one(native_lib, oracle_lib, tmp_path
     fastqs = []
     for si in range(2):
         reads = [synth.codes_to_str(c) for c in synth.synth_reads(libs, 1200, seed=70 + si, zipf_s=1.3)]
-        # an N, a read of eight packed words, and a read beyond the 255-nt packing limit
-        reads += ["ACGTNACGTTAGCATCGATCGA", libs.libs["mrna"][1][si][3:160], "A" * 300]
+        # an N, a read of eight packed words, and reads beyond the 255 nt of a packed batch (the long-read lane): one that
+        # aligns nowhere, one cut from an mRNA entry that occurs in BOTH files (its copies meet on rank 0)
+        long_mrna = max(libs.libs["mrna"][1], key=len)
+        assert len(long_mrna) > 300
+        reads += ["ACGTNACGTTAGCATCGATCGA", libs.libs["mrna"][1][si][3:160], "A" * 300, long_mrna[2:290]]
         p = str(tmp_path / ("s%d.fastq" % si))
         write_fastq(p, reads, rng)
         fastqs.append(p)
@@ -185,8 +188,11 @@ def test_cli_ranks_write_the_same_tables_as_one(native_lib, oracle_lib, tmp_path
             assert a == b, fn
         else:
             assert sorted(a.split("\n")) == sorted(b.split("\n")), fn
-    # the over-long read is carried as an unannotated unique read of its sample
+    # the reads beyond 255 nt: annotated by the long-read lane on rank 0, one row each, counts per sample
     assert any(line.startswith("A" * 300 + ",0,") for line in open(os.path.join(two_dir, "unmapped.csv")))
+    long_mrna = max(libs.libs["mrna"][1], key=len)
+    rows = [line.strip().split(",") for line in open(os.path.join(two_dir, "mapped.csv")) if line.startswith(long_mrna[2:290] + ",")]
+    assert len(rows) == 1 and rows[0][1] == "1" and rows[0][9] != "" and rows[0][-2:] == ["1", "1"]
     assert any(line.startswith(libs.libs["mrna"][1][1][3:160] + ",1,") for line in open(os.path.join(two_dir, "mapped.csv")))
     rep = open(os.path.join(two_dir, "annotation.report.csv")).read().split("\n")[1].split(",")
-    assert int(rep[1]) == 1203 and int(rep[2]) == one["logDic"]["quantStats"][0]["trimmedReads"]
+    assert int(rep[1]) == 1204 and int(rep[2]) == one["logDic"]["quantStats"][0]["trimmedReads"]

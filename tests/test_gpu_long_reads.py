@@ -75,6 +75,10 @@ def _random_passes(rng, keys, n_pass):
         if p["max_len"] == 600:
             p["max_len"] = 255   # (only "< 255" bounds bind; 255 and more is unbounded)
         out.append(p)
+    # (a last pass every read is offered to: a drawn table may exclude every read by its length windows)
+    out.append(dict(lib=keys[0], seed_len=28, max_mm_seed=1, max_mm_total=2, trim5=0, trim3=0, min_len=0, max_len=255, poly_t=0))
+    out.insert(len(out) // 2, dict(lib=keys[-1], seed_len=V_MODE_SEED, max_mm_seed=2, max_mm_total=2, trim5=0, trim3=0, min_len=0,
+                                  max_len=255, poly_t=0))
     return out
 
 
@@ -91,7 +95,7 @@ def test_long_lane_equals_exhaustive_scan(native_lib, oracle_lib, seed):
     for k, (names, seqs) in libs.items():
         eng.add_library(k, FmIndex.build(names, seqs))
         olibs[k] = model.Library(names, seqs)
-    rows = _random_passes(rng, list(libs), int(rng.integers(3, 10)))
+    rows = _random_passes(rng, list(libs), int(rng.integers(2, 9)))
     got = eng.cascade_long(reads, eng.make_passes(rows))
     want = ocas.scan_cascade(olibs, rows, reads)
     for name, a, b in zip(("pass_id", "ref_id", "pos", "mm"), got[:4], want[:4]):
@@ -109,7 +113,18 @@ def test_long_lane_equals_the_packed_cascade_on_reads_both_take(native_lib):
     import torch
     from mirge_amd.engine import Engine, ReadSet
     from tests.util import World
-    w = World(scale=0.03, n_fixed=1500, n_var=1500, with_n=True, max_var_len=250)
+    w = World(scale=0.03, n_fixed=1500, n_var=1500, with_n=True, max_var_len=44)
+    rng = np.random.default_rng(3)
+    for key in ("ncrna_others", "mrna", "rrna", "snorna", "hairpin") * 60:   # reads of four and eight words too
+        s = w.libs.libs[key][1][int(rng.integers(0, len(w.libs.libs[key][1])))]
+        ln = int(min(len(s), rng.integers(33, 256)))
+        o = int(rng.integers(0, len(s) - ln + 1))
+        r = list(s[o:o + ln])
+        for _ in range(int(rng.integers(0, 3))):
+            r[int(rng.integers(0, ln))] = "ACGTN"[int(rng.integers(0, 5))]
+        w.reads.append("".join(r))
+    w.reads = list(dict.fromkeys(w.reads))
+    w.words, w.lens, w.nmask = pack.pack_reads(w.reads)
     eng = Engine(0)
     for k in w.index:
         eng.add_library(k, w.index[k])

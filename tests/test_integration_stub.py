@@ -25,7 +25,9 @@ def test_ctypes_stub_of_integration_md_runs_verbatim(native_lib, tmp_path):
         prefix[key] = str(tmp_path / key)
         FmIndex.build(names, seqs).save(prefix[key] + ".mrgfm")
     reads = list(dict.fromkeys(synth.codes_to_str(c) for c in synth.synth_reads(libs, 800, seed=3, zipf_s=1.3)))
-    reads += ["ACGTNACGTTAGCATCGATCGA", "A" * 140, "A" * 300, libs.libs["mrna"][1][0][7:180]]
+    long_mrna = max(libs.libs["mrna"][1], key=len)
+    reads += ["ACGTNACGTTAGCATCGATCGA", "A" * 140, "A" * 300, libs.libs["mrna"][1][0][7:180], long_mrna[1:299],
+              long_mrna[4:150] + "N" + long_mrna[151:290]]
     make = lambda: {s: {"quant": [1], "annot": [0] + [""] * 9, "length": len(s)} for s in reads}
     seq_dic = make()
     env = dict(LIB=_native.LIB_PATH, index_prefix=prefix, seqDic=seq_dic)
@@ -41,3 +43,4 @@ def test_ctypes_stub_of_integration_md_runs_verbatim(native_lib, tmp_path):
     assert sum(r["annot"][0] for r in seq_dic.values()) > len(reads) // 2
     assert seq_dic["A" * 140]["annot"][0] == 0 and seq_dic["A" * 300]["annot"][0] == 0
     assert seq_dic[libs.libs["mrna"][1][0][7:180]]["annot"][0] == 1   # a 173-nt read, aligned (eight words)
+    assert seq_dic[long_mrna[1:299]]["annot"][8] != "" and seq_dic[long_mrna[4:150] + "N" + long_mrna[151:290]]["annot"][8] != ""
