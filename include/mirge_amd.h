@@ -205,6 +205,8 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * seed_kernel / 1, 2 wave_seed_kernel (64-80 / 80-96 registers); "pair_impl" = 1 (default) / 0: the anchor-pair
  * search of one-word batches in pair_wave_kernel / stratum_kernel; "grid_pct" = 100 (default) / 1..100: every
  * cascade launch with this share of its workgroups (room for another cascade's launches on another stream);
+ * (round 5) "collapse_fast" = 1 (default) / 0: mrg_collapse_run takes its duplication-aware path for batches that fit it
+ * (one-word reads without N, at most 29 nt) / always the general column-by-column sort;
  * "wide_rows_16", "round_large": see DESIGN.md. */
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);
 int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,
@@ -609,10 +611,11 @@ int mrg_expand_compact(mrg_ctx *ctx, const uint64_t *d_bits, uint64_t n_words, c
  *   d_u_reads [words_per_read][cap], d_u_lens [cap], d_u_nmask ([..][cap] or NULL),
  *   d_quant [n_unique][n_samples] (uint32), d_len_hist [256][n_samples] (uint64, the
  *   reference's readLengthDic), *n_unique on the host.  cap >= n is always enough.
- * max_len (0 = unknown) lets reads of <= 29 nt sort in one pass over fused keys; the call checks it
- * against the batch (one pass over the lengths): a longer read sends the batch down the general
- * path, a sample id >= n_samples is MRG_ERR_ARG.
- * Uniques come out ordered by (length, bases); the call synchronises `stream`.
+ * max_len is a hint nobody needs any more (the call reads the lengths: its histogram is an output anyway); a batch
+ * of one-word reads without N of at most 29 nt (2 max_len + sample bits <= 58, at most 16 distinct lengths) takes
+ * the duplication-aware path (csrc/collapse.hip: copies of a sequence are merged in LDS before anything is
+ * partitioned), everything else a stable radix sort of read ids column by column; a sample id >= n_samples is
+ * MRG_ERR_ARG.  Uniques come out ordered by (length, bases); the call synchronises `stream`.
  */
 int mrg_collapse_run(mrg_ctx *ctx, const uint64_t *d_reads, uint32_t words_per_read,
                      const uint8_t *d_lens, const uint64_t *d_nmask, const uint16_t *d_sample,

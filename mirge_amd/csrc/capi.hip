@@ -222,6 +222,7 @@ struct mrg_ctx {
   int64_t seed_units = 1;    // ... and their runs of passes with at most one seed mismatch go through seed_kernel
   int64_t pair_impl = 1;   // 1 = pair_wave_kernel for the anchor-pair search of one-word batches, 0 = stratum_kernel
   int64_t grid_pct = 100;  // share of the workgroups every cascade launch gets (see scale_grid)
+  int64_t collapse_fast = 1;  // mrg_collapse_run: batches that fit it take the duplication-aware path (0: always the general sort)
   int64_t seed_impl = -1;  // -1 = per launch (run_seed), 0 = seed_kernel (tiles), 1 = wave_seed_kernel, 2 = the same with more registers
   std::vector<DevLib> libs;
   std::vector<std::unique_ptr<SeedLib>> seed_libs;
@@ -665,6 +666,8 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->seed_impl = value;
   } else if (k == "seed_units") {
     ctx->seed_units = value != 0;
+  } else if (k == "collapse_fast") {
+    ctx->collapse_fast = value != 0;
   } else if (k == "dict_max_bases") {
     if (value < 0) return fail(MRG_ERR_ARG, "dict_max_bases must be >= 0");
     ctx->dict_max_bases = value;  // takes effect for libraries added afterwards
@@ -2617,7 +2620,7 @@ int mrg_collapse_run(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   }
   hipError_t e = mrg::collapse_reads(d_reads, words_per_read, d_lens, d_nmask, d_sample, (uint32_t)n, n_samples,
                                      max_len, cap, d_u_reads, d_u_lens, d_u_nmask, d_quant, d_len_hist, &nu,
-                                     (hipStream_t)stream, ctx->scratch, ctx->scratch_bytes);
+                                     (hipStream_t)stream, ctx->scratch, ctx->scratch_bytes, ctx->n_cu, ctx->collapse_fast != 0);
   if (e == hipErrorInvalidValue)
     return fail(MRG_ERR_ARG, "mrg_collapse_run: cap %llu is smaller than the number of unique reads",
                 (unsigned long long)cap);

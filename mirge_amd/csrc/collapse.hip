@@ -1,19 +1,45 @@
-// Collapse of raw reads into unique sequences with per-sample counts on the GPU.
+// Collapse of raw reads into unique sequences with per-sample counts on the GPU (gfx950, wave64).
 //
-// Reference role: quantReads (utils/quantReads.py:3-24) -- a Python dict keyed by the
-// read string, one increment per FASTQ record, plus the read-length histogram
-// (readLengthDic).  Here: stable LSD radix sort (hipCUB) of read ids by
-// (sample, packed words, N mask, length), head flags on the sorted order, a scan for
-// the unique id, and run lengths for the counts.  No atomics on read keys, so a
-// sequence that makes up 30 % of a sample (miRNA-seq is that skewed) costs nothing
-// extra, and the result is deterministic: uniques come out ordered by (length, bases).
+// Reference role: quantReads (utils/quantReads.py:3-24) -- a Python dict keyed by the read string, one increment
+// per FASTQ record, plus the read-length histogram (readLengthDic).  Uniques come out ordered by (length, bases),
+// deterministically.  Every kernel here is this library's own (rounds 1-4 called a radix-sort library: sorting 100 M
+// records to find 18 M distinct ones ignores what small-RNA data is -- a few sequences are most of a sample).
+//
+// FAST PATH (one-word reads without N, 2 max_len + sample bits <= 58, at most 16 distinct lengths): duplication-aware.
+//   bounds + length histogram   one pass over lengths / sample ids (what readLengthDic needs anyway): longest read,
+//                  largest sample id, which lengths occur;
+//   K0 l1_hist     raw reads per (workgroup chunk, L1 bucket).  An L1 bucket = (length, the 8 most significant bits
+//                  of the 2 L-bit packed read): buckets are ORDERED as the output is.  A prefix sum over
+//                  [bucket][workgroup] gives every (bucket, workgroup) a private region sized for its raw reads --
+//                  an upper bound of what K1 writes there, so K1 needs no global atomic at all;
+//   K1 aggregate   a workgroup streams its chunk through an LDS hash table (4096 slots, 64-bit compare-and-swap on
+//                  the key, add on the count): the copies of a sequence inside a flush interval become ONE (rest of
+//                  key, count) pair of 8 bytes -- the miRNA that is 30 % of a sample leaves a chunk as a handful of
+//                  pairs, not as 30 M same-address atomics.  The table is flushed (pairs appended to their L1
+//                  regions through LDS cursors) when it is half full or 15 batches old (the count field is 14 bits);
+//   K2 subdivide   one workgroup per L1 bucket: the bucket's pairs (at most 1024 segments, one per K1 workgroup) are
+//                  counted by their next b2 <= 8 bits and copied into contiguous FINAL buckets of ~1000 pairs;
+//   K3 reduce      one workgroup per final bucket: pairs into an LDS table whose slot is the MONOTONE function "top
+//                  12 bits of the remaining key", linear probing without wrap-around.  Runs of occupied slots are then
+//                  ordered among themselves, so the bucket is sorted once every run is (a few entries each: the head
+//                  thread of a run insertion-sorts it) -- no sorting network, no second hash.  Counts of equal keys
+//                  were summed by the inserts.  Sorted (key, count) entries go back to the bucket's region;
+//   K4 emit        prefix sum of the buckets' read counts, entries -> u_words / u_lens / quant[u][sample].
+//   Anything that does not fit (a bucket with more distinct keys than its table, a run of more than 256 slots:
+//   sequences that share 20 leading bits of their key by the thousand) raises a flag and the batch takes the general
+//   path: slower, never wrong.
+//
+// GENERAL PATH (several words per read, N masks, reads beyond 29 nt): stable LSD radix sort (prims.hip) of read ids
+// by (sample, packed words, N mask, length) column by column, head flags on the sorted order, prefix sums for the
+// unique id and the run starts, one thread per (read, sample) run for the counts.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <vector>
 
+#include "device_util.hpp"
 #include "kernels.hpp"
+#include "prims.hpp"
 
 namespace mrg {
 
@@ -32,69 +58,6 @@ __global__ void gather_key_kernel(const T* __restrict__ col, const uint32_t* __r
                                   uint64_t* __restrict__ key, uint32_t n) {
   uint32_t i = blockIdx.x * kT + threadIdx.x;
   if (i < n) key[i] = (uint64_t)col[idx[i]];
-}
-
-// fused key for reads of at most 29 nt in one word: the length in six bits right above the 2 max_len
-// bits of the bases (the radix sort then runs over 2 max_len + 6 bits, not 64: seven 8-bit passes
-// instead of eight for 22-nt reads)
-__global__ void gather_fused_key_kernel(const uint64_t* __restrict__ words, const uint8_t* __restrict__ lens,
-                                        const uint32_t* __restrict__ idx, uint64_t* __restrict__ key,
-                                        uint32_t n, uint32_t len_shift) {
-  uint32_t i = blockIdx.x * kT + threadIdx.x;
-  if (i < n) {
-    const uint32_t r = idx[i];
-    key[i] = words[r] | ((uint64_t)lens[r] << len_shift);
-  }
-}
-
-// keys-only path (one sample, one word, no N, <= 29 nt): key of read i, in place of the index gather
-__global__ void fused_key_kernel(const uint64_t* __restrict__ words, const uint8_t* __restrict__ lens,
-                                 uint64_t* __restrict__ key, uint32_t n, uint32_t len_shift) {
-  uint32_t i = blockIdx.x * kT + threadIdx.x;
-  if (i < n) key[i] = words[i] | ((uint64_t)lens[i] << len_shift);
-}
-
-// unique key -> unique read (bases below len_shift, length above)
-__global__ void split_key_kernel(const uint64_t* __restrict__ ukey, const uint32_t* __restrict__ n_runs,
-                                 uint64_t* __restrict__ u_words, uint8_t* __restrict__ u_lens, uint32_t len_shift) {
-  uint32_t i = blockIdx.x * kT + threadIdx.x;
-  if (i < *n_runs) {
-    const uint64_t k = ukey[i];
-    u_words[i] = k & ((1ull << len_shift) - 1ull);
-    u_lens[i] = (uint8_t)(k >> len_shift);
-  }
-}
-
-// keys-only path with several samples: the sample id in the low `sb` bits of the key
-__global__ void fused_key_sample_kernel(const uint64_t* __restrict__ words, const uint8_t* __restrict__ lens,
-                                        const uint16_t* __restrict__ sample, uint64_t* __restrict__ key, uint32_t n,
-                                        uint32_t len_shift, uint32_t sb) {
-  uint32_t i = blockIdx.x * kT + threadIdx.x;
-  if (i < n) key[i] = ((words[i] | ((uint64_t)lens[i] << len_shift)) << sb) | (uint64_t)sample[i];
-}
-
-// runs of (read, sample): 1 where a new read starts
-__global__ void run_heads_kernel(const uint64_t* __restrict__ rkey, const uint32_t* __restrict__ n_runs,
-                                 uint32_t* __restrict__ flag, uint32_t n, uint32_t sb) {
-  uint32_t j = blockIdx.x * kT + threadIdx.x;
-  if (j >= n) return;
-  flag[j] = (j < *n_runs && (j == 0 || (rkey[j] >> sb) != (rkey[j - 1] >> sb))) ? 1u : 0u;
-}
-
-__global__ void emit_runs_kernel(const uint64_t* __restrict__ rkey, const uint32_t* __restrict__ rcount,
-                                 const uint32_t* __restrict__ n_runs, const uint32_t* __restrict__ uid_incl,
-                                 uint64_t* __restrict__ u_words, uint8_t* __restrict__ u_lens, uint32_t* __restrict__ quant,
-                                 uint32_t n_samples, uint32_t len_shift, uint32_t sb) {
-  uint32_t j = blockIdx.x * kT + threadIdx.x;
-  if (j >= *n_runs) return;
-  const uint64_t k = rkey[j];
-  const uint32_t u = uid_incl[j] - 1u;
-  quant[(size_t)u * n_samples + (uint32_t)(k & ((1ull << sb) - 1ull))] = rcount[j];
-  if (j == 0 || (k >> sb) != (rkey[j - 1] >> sb)) {
-    const uint64_t rk = k >> sb;
-    u_words[u] = rk & ((1ull << len_shift) - 1ull);
-    u_lens[u] = (uint8_t)(rk >> len_shift);
-  }
 }
 
 struct CollapseCols {
@@ -116,7 +79,7 @@ __device__ __forceinline__ bool same_read(const CollapseCols& c, uint32_t a, uin
 
 // head flags on the sorted order: new unique read / new (read, sample) run
 __global__ void head_flags_kernel(CollapseCols c, const uint32_t* __restrict__ idx,
-                                  uint32_t* __restrict__ new_read, uint8_t* __restrict__ new_run) {
+                                  uint32_t* __restrict__ new_read, uint32_t* __restrict__ new_run) {
   uint32_t i = blockIdx.x * kT + threadIdx.x;
   if (i >= c.n) return;
   bool nr = true, ns = true;
@@ -129,14 +92,21 @@ __global__ void head_flags_kernel(CollapseCols c, const uint32_t* __restrict__ i
   new_run[i] = ns ? 1u : 0u;
 }
 
+// run_start[k] = sorted position of the first record of run k (run_incl = inclusive prefix of the run heads)
+__global__ void run_starts_kernel(const uint32_t* __restrict__ run_incl, uint32_t n, uint32_t* __restrict__ run_start) {
+  uint32_t i = blockIdx.x * kT + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t r = run_incl[i];
+  if (i == 0 || run_incl[i - 1] != r) run_start[r - 1u] = i;
+}
+
 // one thread per (read, sample) run: its length is the count
 __global__ void emit_kernel(CollapseCols c, const uint32_t* __restrict__ idx,
                             const uint32_t* __restrict__ uid_incl, const uint32_t* __restrict__ run_start,
-                            const uint32_t* __restrict__ n_runs_ptr, uint32_t n_samples, uint64_t cap,
+                            uint32_t n_runs, uint32_t n_samples, uint64_t cap,
                             uint64_t* __restrict__ u_words, uint8_t* __restrict__ u_lens,
                             uint64_t* __restrict__ u_nmask, uint32_t* __restrict__ quant) {
   const uint32_t k = blockIdx.x * kT + threadIdx.x;
-  const uint32_t n_runs = *n_runs_ptr;
   if (k >= n_runs) return;
   const uint32_t i = run_start[k];
   const uint32_t end = (k + 1 < n_runs) ? run_start[k + 1] : c.n;
@@ -215,24 +185,446 @@ struct DevBuf {
     if (e_ != hipSuccess) return e_;   \
   } while (0)
 
-// longest read and largest sample id of the batch: the fused sort keys put the length right above
-// 2 max_len base bits and the sample id below them, so both bounds must HOLD, not be hoped for
-__global__ void __launch_bounds__(256) bounds_kernel(const uint8_t* __restrict__ lens, const uint16_t* __restrict__ sample, uint32_t n,
-                                                     uint32_t* __restrict__ out) {
-  uint32_t ml = 0, ms = 0;
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-    ml = max(ml, (uint32_t)lens[i]);
-    if (sample) ms = max(ms, (uint32_t)sample[i]);
-  }
+// largest sample id of the batch (the longest read comes out of the length histogram)
+__global__ void __launch_bounds__(256) max_sample_kernel(const uint16_t* __restrict__ sample, uint32_t n, uint32_t* __restrict__ out) {
+  uint32_t ms = 0;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) ms = max(ms, (uint32_t)sample[i]);
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    ml = max(ml, (uint32_t)__shfl_down(ml, off, 64));
-    ms = max(ms, (uint32_t)__shfl_down(ms, off, 64));
+  for (int off = 32; off > 0; off >>= 1) ms = max(ms, (uint32_t)__shfl_down(ms, off, 64));
+  if ((threadIdx.x & 63u) == 0u) atomicMax(out, ms);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fast path
+// ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kFastThreads = 1024u;     // K0, K1, K2
+constexpr uint32_t kMaxChunks = 1024u;       // K1 workgroups = segments of an L1 bucket
+constexpr uint32_t kMaxLenSlots = 16u;       // distinct read lengths a batch may hold
+constexpr uint32_t kL1Bits = 8u;
+constexpr uint32_t kAggSlots = 4096u;        // K1's LDS table
+constexpr uint32_t kAggFlushAt = 2048u;      // ... flushed once it holds this many distinct keys
+constexpr uint32_t kAggMaxBatches = 15u;     // ... or after 15 x 1024 reads: a pair's count has 14 bits
+constexpr uint32_t kCountShift = 50u;        // pair = count << 50 | rest of the key
+constexpr uint64_t kRestMask = (1ull << kCountShift) - 1ull;
+constexpr uint32_t kRedThreads = 256u;       // K3, K4
+constexpr uint32_t kRedHomeBits = 12u;
+constexpr uint32_t kRedSlots = (1u << kRedHomeBits) + 256u;  // no wrap-around: probing may run 256 slots past the last home
+constexpr uint32_t kRedMaxRun = 256u;
+constexpr uint64_t kEmpty = ~0ull;
+
+struct FastShape {
+  uint32_t n, n_chunks, chunk;  // reads, K1 workgroups, reads per workgroup (a multiple of 1024)
+  uint32_t n_slots, n_bins;     // lengths present, n_slots x 256
+  uint32_t sb;                  // sample bits below the bases in a key
+  uint8_t slot_of_len[64];      // length -> slot (0xFF: absent)
+  uint8_t len_of_slot[kMaxLenSlots];
+};
+
+__device__ __forceinline__ uint32_t l1_shift(uint32_t L) { return 2u * L > kL1Bits ? 2u * L - kL1Bits : 0u; }
+
+// K0: raw reads per (chunk, L1 bucket), stored [bucket][chunk]
+__global__ void __launch_bounds__(kFastThreads) l1_hist_kernel(const uint64_t* __restrict__ words, const uint8_t* __restrict__ lens,
+                                                               FastShape f, uint32_t* __restrict__ counts_t) {
+  extern __shared__ uint32_t hist[];
+  for (uint32_t b = threadIdx.x; b < f.n_bins; b += kFastThreads) hist[b] = 0u;
+  __syncthreads();
+  const uint64_t lo = (uint64_t)blockIdx.x * f.chunk;
+  const uint64_t hi = min((uint64_t)f.n, lo + f.chunk);
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += kFastThreads) {
+    const uint32_t L = lens[i];
+    const uint32_t bin = (uint32_t)f.slot_of_len[L & 63u] * 256u + (uint32_t)(words[i] >> l1_shift(L));
+    atomicAdd(&hist[bin], 1u);
   }
-  if ((threadIdx.x & 63u) == 0u) {
-    atomicMax(&out[0], ml);
-    atomicMax(&out[1], ms);
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < f.n_bins; b += kFastThreads) counts_t[(size_t)b * f.n_chunks + blockIdx.x] = hist[b];
+}
+
+// K1: aggregate a chunk through an LDS hash table, append (rest, count) pairs to the chunk's L1 regions
+__global__ void __launch_bounds__(kFastThreads) aggregate_kernel(const uint64_t* __restrict__ words, const uint8_t* __restrict__ lens,
+                                                                 const uint16_t* __restrict__ sample, FastShape f,
+                                                                 const uint32_t* __restrict__ off_t, uint32_t* __restrict__ fill_t,
+                                                                 uint64_t* __restrict__ pairs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* tkey = reinterpret_cast<unsigned long long*>(smem);
+  uint32_t* tcnt = reinterpret_cast<uint32_t*>(smem + kAggSlots * 8u);
+  uint32_t* cursor = tcnt + kAggSlots;
+  uint32_t* ctl = cursor + f.n_bins;  // [0] distinct keys in the table
+  for (uint32_t s = threadIdx.x; s < kAggSlots; s += kFastThreads) {
+    tkey[s] = kEmpty;
+    tcnt[s] = 0u;
   }
+  for (uint32_t b = threadIdx.x; b < f.n_bins; b += kFastThreads) cursor[b] = off_t[(size_t)b * f.n_chunks + blockIdx.x];
+  if (threadIdx.x == 0) ctl[0] = 0u;
+  __syncthreads();
+  const uint64_t lo = (uint64_t)blockIdx.x * f.chunk;
+  const uint64_t hi = min((uint64_t)f.n, lo + f.chunk);
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t batches = 0;
+  for (uint64_t base = lo; base < hi; base += kFastThreads) {
+    const uint64_t i = base + threadIdx.x;
+    bool fresh = false;
+    if (i < hi) {
+      const uint32_t L = lens[i];
+      const uint64_t v = (words[i] << f.sb) | (sample ? (uint64_t)sample[i] : 0ull);
+      const unsigned long long key = ((unsigned long long)L << 58) | v;
+      uint32_t s = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 52);
+      for (;;) {
+        const unsigned long long old = atomicCAS(&tkey[s], kEmpty, key);
+        if (old == kEmpty || old == key) {
+          atomicAdd(&tcnt[s], 1u);
+          fresh = old == kEmpty;
+          break;
+        }
+        s = (s + 1u) & (kAggSlots - 1u);
+      }
+    }
+    const uint64_t fm = __ballot(fresh);
+    if (lane == 0 && fm) atomicAdd(&ctl[0], (uint32_t)__popcll(fm));
+    ++batches;
+    __syncthreads();
+    const bool last = base + kFastThreads >= hi;
+    if (ctl[0] > kAggFlushAt || batches == kAggMaxBatches || last) {
+      // flush: every occupied slot becomes a pair in its L1 bucket's region
+      for (uint32_t s = threadIdx.x; s < kAggSlots; s += kFastThreads) {
+        const unsigned long long key = tkey[s];
+        if (key != kEmpty) {
+          const uint32_t L = (uint32_t)(key >> 58);
+          const uint64_t v = key & ((1ull << 58) - 1ull);
+          const uint32_t sh = l1_shift(L) + f.sb;
+          const uint32_t bin = (uint32_t)f.slot_of_len[L] * 256u + (uint32_t)(v >> sh);
+          const uint32_t dst = atomicAdd(&cursor[bin], 1u);
+          pairs[dst] = ((uint64_t)tcnt[s] << kCountShift) | (v & ((1ull << sh) - 1ull));
+          tkey[s] = kEmpty;
+          tcnt[s] = 0u;
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) ctl[0] = 0u;
+      batches = 0;
+      __syncthreads();
+    }
+  }
+  for (uint32_t b = threadIdx.x; b < f.n_bins; b += kFastThreads)
+    fill_t[(size_t)b * f.n_chunks + blockIdx.x] = cursor[b] - off_t[(size_t)b * f.n_chunks + blockIdx.x];
+}
+
+// K2: one workgroup per L1 bucket: its pairs (one segment per K1 workgroup) counted by their next b2 bits and copied
+// into contiguous final buckets.  fb_* are indexed by final bucket id = L1 bucket x 256 + sub.
+__global__ void __launch_bounds__(kFastThreads) subdivide_kernel(FastShape f, const uint32_t* __restrict__ off_t,
+                                                                 const uint32_t* __restrict__ fill_t, const uint64_t* __restrict__ pairs_in,
+                                                                 uint64_t* __restrict__ pairs_out, uint32_t* __restrict__ fb_start,
+                                                                 uint32_t* __restrict__ fb_count, uint8_t* __restrict__ l1_b2,
+                                                                 uint32_t* __restrict__ work, uint32_t* __restrict__ n_work) {
+  __shared__ uint32_t seg_start[kMaxChunks], seg_fill[kMaxChunks];
+  __shared__ uint32_t sub_hist[256], sub_start[256], sub_cursor[256];
+  __shared__ uint32_t wtot[kFastThreads / 64u];
+  __shared__ uint32_t ctl[4];
+  const uint32_t b = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  uint32_t fill = 0;
+  if (tid < f.n_chunks) {
+    seg_start[tid] = off_t[(size_t)b * f.n_chunks + tid];
+    fill = fill_t[(size_t)b * f.n_chunks + tid];
+    seg_fill[tid] = fill;
+  }
+  if (tid < 256u) sub_hist[tid] = 0u, sub_cursor[tid] = 0u;
+  // pairs of the bucket
+  uint32_t t = fill;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+  if (lane == 0) wtot[wave] = t;
+  __syncthreads();
+  uint32_t P = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < kFastThreads / 64u; ++w) P += wtot[w];
+  if (P == 0) return;
+  const uint32_t L = f.len_of_slot[b >> 8];
+  const uint32_t r1 = l1_shift(L) + f.sb;
+  uint32_t b2 = 0;
+  while (b2 < 8u && b2 < r1 && ((P + 1023u) >> 10) > (1u << b2)) ++b2;
+  const uint32_t sh = r1 - b2;
+  for (uint32_t w = wave; w < f.n_chunks; w += kFastThreads / 64u) {
+    const uint32_t s0 = seg_start[w], fl = seg_fill[w];
+    for (uint32_t j = lane; j < fl; j += 64u) {
+      const uint64_t rest = pairs_in[s0 + j] & kRestMask;
+      atomicAdd(&sub_hist[(uint32_t)(rest >> sh) & 255u], 1u);
+    }
+  }
+  __syncthreads();
+  // final buckets: exclusive prefix of the 256 counts (the first four waves), descriptors, work list
+  const uint32_t base = seg_start[0];
+  uint32_t cnt = 0, incl = 0;
+  if (tid < 256u) {
+    cnt = sub_hist[tid];
+    incl = dev::wave_incl_scan(cnt);
+    if (lane == 63u) wtot[wave] = incl;
+  }
+  const uint64_t live = __ballot(tid < 256u && cnt != 0u);
+  if (tid < 256u && lane == 0) ctl[wave] = (uint32_t)__popcll(live);
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t n_live = ctl[0] + ctl[1] + ctl[2] + ctl[3];
+    const uint32_t at = atomicAdd(n_work, n_live);
+    ctl[3] = at + ctl[0] + ctl[1] + ctl[2];
+    ctl[2] = at + ctl[0] + ctl[1];
+    ctl[1] = at + ctl[0];
+    ctl[0] = at;
+    l1_b2[b] = (uint8_t)b2;
+  }
+  __syncthreads();
+  if (tid < 256u) {
+    uint32_t pre = incl - cnt;
+    for (uint32_t w = 0; w < wave; ++w) pre += wtot[w];
+    sub_start[tid] = pre;
+    fb_start[(size_t)b * 256u + tid] = base + pre;
+    fb_count[(size_t)b * 256u + tid] = cnt;
+    if (cnt) work[ctl[wave] + (uint32_t)__popcll(live & ((1ull << lane) - 1ull))] = b * 256u + tid;
+  }
+  __syncthreads();
+  for (uint32_t w = wave; w < f.n_chunks; w += kFastThreads / 64u) {
+    const uint32_t s0 = seg_start[w], fl = seg_fill[w];
+    for (uint32_t j = lane; j < fl; j += 64u) {
+      const uint64_t pr = pairs_in[s0 + j];
+      const uint32_t sub = (uint32_t)((pr & kRestMask) >> sh) & 255u;
+      pairs_out[base + sub_start[sub] + atomicAdd(&sub_cursor[sub], 1u)] = pr;
+    }
+  }
+}
+
+// K3: one final bucket per trip: pairs -> LDS table addressed by a monotone function of the key -> runs sorted ->
+// sorted (full key, count) entries back to the bucket's region in `ent_key` / `ent_cnt`
+__global__ void __launch_bounds__(kRedThreads) reduce_kernel(FastShape f, const uint32_t* __restrict__ work,
+                                                             const uint32_t* __restrict__ n_work_p, const uint32_t* __restrict__ fb_start,
+                                                             const uint32_t* __restrict__ fb_count, const uint8_t* __restrict__ l1_b2,
+                                                             const uint64_t* __restrict__ pairs, uint64_t* __restrict__ ent_key,
+                                                             uint32_t* __restrict__ ent_cnt, uint32_t* __restrict__ fb_entries,
+                                                             uint32_t* __restrict__ fb_reads, uint32_t* __restrict__ overflow) {
+  __shared__ unsigned long long tkey[kRedSlots];
+  __shared__ uint32_t tcnt[kRedSlots];
+  __shared__ uint32_t wtot[2][kRedThreads / 64u];
+  constexpr uint32_t kPerThread = kRedSlots / kRedThreads;  // 17 consecutive slots per thread
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t n_work = *n_work_p;
+  for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+    const uint32_t fb = work[wi];
+    const uint32_t l1 = fb >> 8, sub = fb & 255u;
+    const uint32_t L = f.len_of_slot[l1 >> 8];
+    const uint32_t r1 = l1_shift(L) + f.sb, b2 = l1_b2[l1], r2 = r1 - b2;
+    const uint32_t start = fb_start[fb], P = fb_count[fb];
+    for (uint32_t s = tid; s < kRedSlots; s += kRedThreads) {
+      tkey[s] = kEmpty;
+      tcnt[s] = 0u;
+    }
+    __syncthreads();
+    bool lost = false;
+    for (uint32_t j = tid; j < P; j += kRedThreads) {
+      const uint64_t pr = pairs[start + j];
+      const unsigned long long rest = pr & kRestMask;
+      const uint64_t rest2 = rest & ((1ull << r2) - 1ull);
+      uint32_t s = r2 >= kRedHomeBits ? (uint32_t)(rest2 >> (r2 - kRedHomeBits)) : (uint32_t)(rest2 << (kRedHomeBits - r2));
+      for (;;) {
+        if (s >= kRedSlots) {
+          lost = true;
+          break;
+        }
+        const unsigned long long old = atomicCAS(&tkey[s], kEmpty, rest);
+        if (old == kEmpty || old == rest) {
+          atomicAdd(&tcnt[s], (uint32_t)(pr >> kCountShift));
+          break;
+        }
+        ++s;
+      }
+    }
+    __syncthreads();
+    // runs of occupied slots are ordered among themselves (monotone home, no wrap): sort every run in place
+    const uint32_t s_lo = tid * kPerThread;
+    for (uint32_t s = s_lo; s < s_lo + kPerThread; ++s) {
+      if (tkey[s] == kEmpty || (s > 0 && tkey[s - 1] != kEmpty)) continue;
+      uint32_t e = s + 1;
+      while (e < kRedSlots && tkey[e] != kEmpty) ++e;
+      if (e - s > kRedMaxRun) {
+        lost = true;
+        continue;
+      }
+      for (uint32_t i = s + 1; i < e; ++i) {
+        const unsigned long long k = tkey[i];
+        const uint32_t c = tcnt[i];
+        uint32_t j = i;
+        while (j > s && tkey[j - 1] > k) {
+          tkey[j] = tkey[j - 1];
+          tcnt[j] = tcnt[j - 1];
+          --j;
+        }
+        tkey[j] = k;
+        tcnt[j] = c;
+      }
+    }
+    if (lost) atomicOr(overflow, 1u);
+    __syncthreads();
+    // entries and reads (an entry whose bases differ from the entry in front of it) of the thread's slots
+    uint32_t n_ent = 0, n_rd = 0;
+    for (uint32_t s = s_lo; s < s_lo + kPerThread; ++s) {
+      const unsigned long long k = tkey[s];
+      if (k == kEmpty) continue;
+      ++n_ent;
+      n_rd += (s == 0 || tkey[s - 1] == kEmpty || (tkey[s - 1] >> f.sb) != (k >> f.sb)) ? 1u : 0u;
+    }
+    const uint32_t ie = dev::wave_incl_scan(n_ent), ir = dev::wave_incl_scan(n_rd);
+    if (lane == 63u) {
+      wtot[0][wave] = ie;
+      wtot[1][wave] = ir;
+    }
+    __syncthreads();
+    uint32_t pos = ie - n_ent, tot_e = 0, tot_r = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kRedThreads / 64u; ++w) {
+      pos += w < wave ? wtot[0][w] : 0u;
+      tot_e += wtot[0][w];
+      tot_r += wtot[1][w];
+    }
+    const uint64_t prefix = ((uint64_t)(l1 & 255u) << r1) | ((uint64_t)sub << r2);  // the key bits the bucket stands for
+    for (uint32_t s = s_lo; s < s_lo + kPerThread; ++s) {
+      const unsigned long long k = tkey[s];
+      if (k == kEmpty) continue;
+      ent_key[start + pos] = prefix | (k & ((1ull << r2) - 1ull));
+      ent_cnt[start + pos] = tcnt[s];
+      ++pos;
+    }
+    if (tid == 0) {
+      fb_entries[fb] = tot_e;
+      fb_reads[fb] = tot_r;
+    }
+    __syncthreads();
+  }
+}
+
+// K4: entries of a final bucket -> the output arrays at the bucket's first read (read_base = exclusive prefix of fb_reads)
+__global__ void __launch_bounds__(kRedThreads) emit_fast_kernel(FastShape f, const uint32_t* __restrict__ work,
+                                                                const uint32_t* __restrict__ n_work_p, const uint32_t* __restrict__ fb_start,
+                                                                const uint32_t* __restrict__ fb_entries, const uint32_t* __restrict__ read_base,
+                                                                const uint64_t* __restrict__ ent_key, const uint32_t* __restrict__ ent_cnt,
+                                                                uint32_t n_samples, uint64_t* __restrict__ u_words, uint8_t* __restrict__ u_lens,
+                                                                uint32_t* __restrict__ quant) {
+  __shared__ uint32_t wtot[kRedThreads / 64u];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t n_work = *n_work_p;
+  const uint64_t smask = (1ull << f.sb) - 1ull;
+  for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+    const uint32_t fb = work[wi];
+    const uint32_t L = f.len_of_slot[fb >> 16];
+    const uint32_t start = fb_start[fb], E = fb_entries[fb];
+    uint32_t u0 = read_base[fb];  // index of the first read of this trip
+    for (uint32_t j0 = 0; j0 < E; j0 += kRedThreads) {
+      const uint32_t j = j0 + tid;
+      uint64_t v = 0;
+      bool head = false;
+      if (j < E) {
+        v = ent_key[start + j];
+        head = j == 0 || (ent_key[start + j - 1] >> f.sb) != (v >> f.sb);
+      }
+      const uint32_t h = head ? 1u : 0u;
+      const uint32_t incl = dev::wave_incl_scan(h);
+      if (lane == 63u) wtot[wave] = incl;
+      __syncthreads();
+      uint32_t idx = incl, tot = 0;
+#pragma unroll
+      for (uint32_t w = 0; w < kRedThreads / 64u; ++w) {
+        idx += w < wave ? wtot[w] : 0u;
+        tot += wtot[w];
+      }
+      if (j < E) {
+        const uint32_t u = u0 + idx - 1u;
+        if (head) {
+          u_words[u] = v >> f.sb;
+          u_lens[u] = (uint8_t)L;
+        }
+        quant[(size_t)u * n_samples + (uint32_t)(v & smask)] = ent_cnt[start + j];
+      }
+      u0 += tot;
+      __syncthreads();
+    }
+  }
+}
+
+// The fast path.  *took = false: the batch does not fit it (or overflowed a table): nothing was written that the
+// general path does not overwrite.  h_len_hist: the length histogram of the batch ([256][S], already on the host).
+hipError_t collapse_fast(const uint64_t* d_reads, const uint8_t* d_lens, const uint16_t* d_sample, uint32_t n, uint32_t n_samples,
+                         const std::vector<uint64_t>& h_len_hist, uint64_t cap, uint64_t* d_u_words, uint8_t* d_u_lens, uint32_t* d_quant,
+                         uint32_t* h_n_unique, int n_cu, hipStream_t stream, bool* took) {
+  *took = false;
+  FastShape f;
+  std::fill(f.slot_of_len, f.slot_of_len + 64, (uint8_t)0xFF);
+  f.n = n;
+  f.sb = 0;
+  while ((1u << f.sb) < n_samples) ++f.sb;
+  f.n_slots = 0;
+  uint32_t max_len = 0;
+  for (uint32_t L = 0; L < 256u; ++L) {
+    uint64_t c = 0;
+    for (uint32_t s = 0; s < n_samples; ++s) c += h_len_hist[(size_t)L * n_samples + s];
+    if (!c) continue;
+    if (L > 29u || f.n_slots == kMaxLenSlots) return hipSuccess;
+    f.slot_of_len[L] = (uint8_t)f.n_slots;
+    f.len_of_slot[f.n_slots++] = (uint8_t)L;
+    max_len = L;
+  }
+  if (2u * max_len + f.sb > 58u || f.n_slots == 0) return hipSuccess;
+  f.n_bins = f.n_slots * 256u;
+  f.n_chunks = std::max<uint32_t>(1u, std::min<uint32_t>(kMaxChunks, (n + 8191u) / 8192u));
+  f.chunk = (uint32_t)((((uint64_t)n + f.n_chunks - 1) / f.n_chunks + 1023u) & ~1023ull);
+  const size_t n_ct = (size_t)f.n_bins * f.n_chunks, n_fb = (size_t)f.n_bins * 256u;
+  DevBuf off_t, fill_t, bufA, bufB, cnt, fbs, misc, work, stmp;
+  CK(off_t.alloc(n_ct * 4));
+  CK(fill_t.alloc(n_ct * 4));
+  CK(bufA.alloc((size_t)n * 8));
+  CK(bufB.alloc((size_t)n * 8));
+  CK(cnt.alloc((size_t)n * 4));
+  CK(fbs.alloc(n_fb * 4 * 5));  // start, count, entries, reads, read_base
+  CK(misc.alloc(f.n_bins + 64));  // l1_b2 bytes, then (64-byte aligned) n_work, overflow
+  CK(work.alloc(n_fb * 4));
+  CK(stmp.alloc(std::max(prims::scan_temp_bytes(n_ct), prims::scan_temp_bytes(n_fb))));
+  uint32_t* fb_start = fbs.as<uint32_t>();
+  uint32_t* fb_count = fb_start + n_fb;
+  uint32_t* fb_entries = fb_count + n_fb;
+  uint32_t* fb_reads = fb_entries + n_fb;
+  uint32_t* read_base = fb_reads + n_fb;
+  uint8_t* l1_b2 = misc.as<uint8_t>();
+  uint32_t* n_work = reinterpret_cast<uint32_t*>(misc.as<uint8_t>() + ((f.n_bins + 15u) & ~15u));
+  uint32_t* overflow = n_work + 1;
+  CK(hipMemsetAsync(fb_count, 0, n_fb * 4 * 3, stream));  // count, entries, reads
+  CK(hipMemsetAsync(misc.p, 0, f.n_bins + 64, stream));
+  const uint16_t* smp = n_samples > 1 ? d_sample : nullptr;
+  hipLaunchKernelGGL(l1_hist_kernel, dim3(f.n_chunks), dim3(kFastThreads), f.n_bins * 4u, stream, d_reads, d_lens, f, off_t.as<uint32_t>());
+  CK(hipGetLastError());
+  CK(prims::exclusive_sum_u32(off_t.as<uint32_t>(), off_t.as<uint32_t>(), n_ct, stmp.p, stream));
+  const uint32_t agg_lds = kAggSlots * 12u + f.n_bins * 4u + 16u;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(aggregate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)agg_lds));
+  hipLaunchKernelGGL(aggregate_kernel, dim3(f.n_chunks), dim3(kFastThreads), agg_lds, stream, d_reads, d_lens, smp, f, off_t.as<uint32_t>(),
+                     fill_t.as<uint32_t>(), bufA.as<uint64_t>());
+  CK(hipGetLastError());
+  hipLaunchKernelGGL(subdivide_kernel, dim3(f.n_bins), dim3(kFastThreads), 0, stream, f, off_t.as<uint32_t>(), fill_t.as<uint32_t>(),
+                     bufA.as<uint64_t>(), bufB.as<uint64_t>(), fb_start, fb_count, l1_b2, work.as<uint32_t>(), n_work);
+  CK(hipGetLastError());
+  const uint32_t red_grid = (uint32_t)std::max(1, n_cu) * 6u;
+  hipLaunchKernelGGL(reduce_kernel, dim3(red_grid), dim3(kRedThreads), 0, stream, f, work.as<uint32_t>(), n_work, fb_start, fb_count, l1_b2,
+                     bufB.as<uint64_t>(), bufA.as<uint64_t>(), cnt.as<uint32_t>(), fb_entries, fb_reads, overflow);
+  CK(hipGetLastError());
+  CK(prims::exclusive_sum_u32(fb_reads, read_base, n_fb, stmp.p, stream));
+  uint32_t h_over = 0, h_last[2] = {0, 0};
+  CK(hipMemcpyAsync(&h_over, overflow, 4, hipMemcpyDeviceToHost, stream));
+  CK(hipMemcpyAsync(&h_last[0], read_base + (n_fb - 1), 4, hipMemcpyDeviceToHost, stream));
+  CK(hipMemcpyAsync(&h_last[1], fb_reads + (n_fb - 1), 4, hipMemcpyDeviceToHost, stream));
+  CK(hipStreamSynchronize(stream));
+  if (h_over) return hipSuccess;  // (general path)
+  const uint64_t n_unique = (uint64_t)h_last[0] + h_last[1];
+  if (n_unique > cap) return hipErrorInvalidValue;
+  if (n_samples > 1) CK(hipMemsetAsync(d_quant, 0, (size_t)n_unique * n_samples * 4, stream));
+  hipLaunchKernelGGL(emit_fast_kernel, dim3(red_grid), dim3(kRedThreads), 0, stream, f, work.as<uint32_t>(), n_work, fb_start, fb_entries,
+                     read_base, bufA.as<uint64_t>(), cnt.as<uint32_t>(), n_samples, d_u_words, d_u_lens, d_quant);
+  CK(hipGetLastError());
+  CK(hipStreamSynchronize(stream));
+  *h_n_unique = (uint32_t)n_unique;
+  *took = true;
+  return hipSuccess;
 }
 
 }  // namespace
@@ -242,7 +634,7 @@ hipError_t collapse_reads(const uint64_t* d_reads, uint32_t W, const uint8_t* d_
                           uint32_t n_samples, uint32_t max_len, uint64_t cap, uint64_t* d_u_words,
                           uint8_t* d_u_lens, uint64_t* d_u_nmask, uint32_t* d_quant,
                           uint64_t* d_len_hist, uint32_t* h_n_unique, hipStream_t stream, void* arena_base,
-                          uint64_t arena_bytes) {
+                          uint64_t arena_bytes, int n_cu, bool allow_fast) {
   Arena arena;
   arena.base = (char*)arena_base;
   arena.size = arena_base ? (size_t)arena_bytes : 0;
@@ -251,229 +643,114 @@ hipError_t collapse_reads(const uint64_t* d_reads, uint32_t W, const uint8_t* d_
     ~ArenaScope() { g_arena = nullptr; }
   } scope(&arena);
   *h_n_unique = 0;
+  (void)max_len;  // (a hint of rounds 1-4: the length histogram below says what the batch holds)
   CK(hipMemsetAsync(d_len_hist, 0, (size_t)256 * n_samples * 8, stream));
   if (n == 0) return hipStreamSynchronize(stream);
   const uint32_t grid = (n + kT - 1) / kT;
-  {
-    // the caller's max_len is only a hint: a read longer than it would overlap the length bits of a
-    // fused key and merge or split sequences silently.  One pass over the lengths (and sample ids):
-    // an out-of-range sample id is an error, an exceeded max_len sends the batch down the general path.
+  const uint16_t* smp = (d_sample && n_samples > 1) ? d_sample : nullptr;
+  if (n_cu <= 0) n_cu = 256;
+  // ---- readLengthDic + the largest sample id: what the batch holds decides the path; an out-of-range sample id is
+  // an error (it would index past a row of quant) ----
+  std::vector<uint64_t> h_hist((size_t)256 * n_samples);
+  if (smp) {
+    // (first, and on its own: the histogram below indexes its bins with the sample id)
+    uint32_t h_ms = 0;
     DevBuf b;
-    CK(b.alloc(8));
-    CK(hipMemsetAsync(b.p, 0, 8, stream));
-    hipLaunchKernelGGL(bounds_kernel, dim3(min(grid, 2048u)), dim3(256), 0, stream, d_lens, n_samples > 1 ? d_sample : nullptr, n, b.as<uint32_t>());
-    uint32_t h[2] = {0, 0};
-    CK(hipMemcpyAsync(h, b.p, 8, hipMemcpyDeviceToHost, stream));
+    CK(b.alloc(4));
+    CK(hipMemsetAsync(b.p, 0, 4, stream));
+    hipLaunchKernelGGL(max_sample_kernel, dim3(min(grid, 2048u)), dim3(256), 0, stream, smp, n, b.as<uint32_t>());
+    CK(hipMemcpyAsync(&h_ms, b.p, 4, hipMemcpyDeviceToHost, stream));
     CK(hipStreamSynchronize(stream));
-    if (n_samples > 1 && h[1] >= n_samples) return hipErrorInvalidDevicePointer;  // (mapped to MRG_ERR_ARG by the C-ABI)
-    if (max_len && h[0] > max_len) max_len = 0;
+    if (h_ms >= n_samples) return hipErrorInvalidDevicePointer;  // (mapped to MRG_ERR_ARG by the C-ABI)
   }
-  if (W == 1 && max_len > 0 && max_len <= 29 && !d_nmask && !(d_sample && n_samples > 1) && n_samples == 1) {
-    // One sample, reads of one word without N: the packed read + its length IS the sort key and the
-    // unique read; nothing has to be carried through the sort or gathered afterwards.  Sort the
-    // keys alone over their 2 max_len + 6 bits, run-length encode them (unique keys + multiplicities
-    // = quant), split the unique keys into words and lengths.
-    const uint32_t len_shift = 2u * max_len;
-    DevBuf k0, k1, ukey, runs, tmp;
-    CK(k0.alloc((size_t)n * 8));
-    CK(k1.alloc((size_t)n * 8));
-    CK(ukey.alloc((size_t)n * 8));
-    CK(runs.alloc(4));
-    hipcub::DoubleBuffer<uint64_t> keys(k0.as<uint64_t>(), k1.as<uint64_t>());
-    size_t tb_sort = 0, tb_rle = 0;
-    CK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb_sort, keys, (int)n, 0, (int)(len_shift + 6u), stream));
-    CK(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb_rle, k0.as<uint64_t>(), ukey.as<uint64_t>(), d_quant,
-                                             runs.as<uint32_t>(), (int)n, stream));
-    const size_t tbytes = tb_sort > tb_rle ? tb_sort : tb_rle;
-    CK(tmp.alloc(tbytes));
-    hipLaunchKernelGGL(fused_key_kernel, dim3(grid), dim3(kT), 0, stream, d_reads, d_lens, keys.Current(), n, len_shift);
-    size_t tb = tbytes;
-    CK(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, keys, (int)n, 0, (int)(len_shift + 6u), stream));
-    uint32_t n_unique = 0;
-    if ((uint64_t)n <= cap) {
-      // (every run fits: multiplicities straight into quant)
-      tb = tbytes;
-      CK(hipcub::DeviceRunLengthEncode::Encode(tmp.p, tb, keys.Current(), ukey.as<uint64_t>(), d_quant, runs.as<uint32_t>(),
-                                               (int)n, stream));
-      CK(hipMemcpyAsync(&n_unique, runs.as<uint32_t>(), 4, hipMemcpyDeviceToHost, stream));
-      hipLaunchKernelGGL(split_key_kernel, dim3(grid), dim3(kT), 0, stream, ukey.as<uint64_t>(), runs.as<uint32_t>(), d_u_words,
-                         d_u_lens, len_shift);
-      const uint32_t lds = 256u * 4u;
-      hipLaunchKernelGGL(length_hist_kernel<true>, dim3(min(grid, 1024u)), dim3(kT), lds, stream, d_lens,
-                         (const uint16_t*)nullptr, n, 1u, reinterpret_cast<unsigned long long*>(d_len_hist));
-      CK(hipGetLastError());
-      CK(hipStreamSynchronize(stream));
-      *h_n_unique = n_unique;
-      return hipSuccess;
-    }
-    // (an output capacity below n: the general path below checks it)
-  }
-  uint32_t sb = 0;
-  while ((1u << sb) < n_samples) ++sb;
-  if (W == 1 && max_len > 0 && !d_nmask && d_sample && n_samples > 1 && 2u * max_len + 6u + sb <= 64u && (uint64_t)n <= cap) {
-    // Several samples: the same, with the sample id in the low bits of the key.  The runs of the
-    // sorted keys are (read, sample) pairs with their counts; a read's runs are neighbours.
-    const uint32_t len_shift = 2u * max_len;
-    DevBuf k0, k1, rkey, rcount, runs, flag, uidb, tmp;
-    CK(k0.alloc((size_t)n * 8));
-    CK(k1.alloc((size_t)n * 8));
-    CK(rkey.alloc((size_t)n * 8));
-    CK(rcount.alloc((size_t)n * 4));
-    CK(flag.alloc((size_t)n * 4));
-    CK(uidb.alloc((size_t)n * 4));
-    CK(runs.alloc(4));
-    hipcub::DoubleBuffer<uint64_t> keys(k0.as<uint64_t>(), k1.as<uint64_t>());
-    const int bits = (int)(len_shift + 6u + sb);
-    size_t tb_sort = 0, tb_rle = 0, tb_scan = 0;
-    CK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb_sort, keys, (int)n, 0, bits, stream));
-    CK(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb_rle, k0.as<uint64_t>(), rkey.as<uint64_t>(), rcount.as<uint32_t>(),
-                                             runs.as<uint32_t>(), (int)n, stream));
-    CK(hipcub::DeviceScan::InclusiveSum(nullptr, tb_scan, flag.as<uint32_t>(), uidb.as<uint32_t>(), (int)n, stream));
-    const size_t tbytes = std::max(tb_sort, std::max(tb_rle, tb_scan));
-    CK(tmp.alloc(tbytes));
-    hipLaunchKernelGGL(fused_key_sample_kernel, dim3(grid), dim3(kT), 0, stream, d_reads, d_lens, d_sample, keys.Current(), n,
-                       len_shift, sb);
-    size_t tb = tbytes;
-    CK(hipcub::DeviceRadixSort::SortKeys(tmp.p, tb, keys, (int)n, 0, bits, stream));
-    tb = tbytes;
-    CK(hipcub::DeviceRunLengthEncode::Encode(tmp.p, tb, keys.Current(), rkey.as<uint64_t>(), rcount.as<uint32_t>(),
-                                             runs.as<uint32_t>(), (int)n, stream));
-    uint32_t h_runs = 0;
-    CK(hipMemcpyAsync(&h_runs, runs.as<uint32_t>(), 4, hipMemcpyDeviceToHost, stream));
-    CK(hipStreamSynchronize(stream));
-    const uint32_t rgrid = (h_runs + kT - 1) / kT;
-    hipLaunchKernelGGL(run_heads_kernel, dim3(rgrid), dim3(kT), 0, stream, rkey.as<uint64_t>(), runs.as<uint32_t>(),
-                       flag.as<uint32_t>(), h_runs, sb);
-    tb = tbytes;
-    CK(hipcub::DeviceScan::InclusiveSum(tmp.p, tb, flag.as<uint32_t>(), uidb.as<uint32_t>(), (int)h_runs, stream));
-    uint32_t n_unique = 0;
-    CK(hipMemcpyAsync(&n_unique, uidb.as<uint32_t>() + (h_runs - 1), 4, hipMemcpyDeviceToHost, stream));
-    CK(hipStreamSynchronize(stream));
-    CK(hipMemsetAsync(d_quant, 0, (size_t)n_unique * n_samples * 4, stream));
-    hipLaunchKernelGGL(emit_runs_kernel, dim3(rgrid), dim3(kT), 0, stream, rkey.as<uint64_t>(), rcount.as<uint32_t>(),
-                       runs.as<uint32_t>(), uidb.as<uint32_t>(), d_u_words, d_u_lens, d_quant, n_samples, len_shift, sb);
-    const uint32_t lds = 256u * n_samples * 4u;
+  {
     auto* hist = reinterpret_cast<unsigned long long*>(d_len_hist);
+    const uint32_t lds = 256u * n_samples * 4u;
     if (lds <= 48u * 1024u)
-      hipLaunchKernelGGL(length_hist_kernel<true>, dim3(min(grid, 1024u)), dim3(kT), lds, stream, d_lens, d_sample, n, n_samples,
-                         hist);
+      hipLaunchKernelGGL(length_hist_kernel<true>, dim3(min(grid, 1024u)), dim3(kT), lds, stream, d_lens, smp, n, n_samples, hist);
     else
-      hipLaunchKernelGGL(length_hist_kernel<false>, dim3(min(grid, 1024u)), dim3(kT), 0, stream, d_lens, d_sample, n, n_samples,
-                         hist);
+      hipLaunchKernelGGL(length_hist_kernel<false>, dim3(min(grid, 1024u)), dim3(kT), 0, stream, d_lens, smp, n, n_samples, hist);
     CK(hipGetLastError());
+    CK(hipMemcpyAsync(h_hist.data(), d_len_hist, h_hist.size() * 8, hipMemcpyDeviceToHost, stream));
     CK(hipStreamSynchronize(stream));
-    *h_n_unique = n_unique;
-    return hipSuccess;
   }
-  DevBuf idx0, idx1, key0, key1, flags_read, flags_run, uid, starts, n_runs, temp;
+  if (W == 1 && !d_nmask && allow_fast) {
+    bool took = false;
+    const size_t mark = arena.used;
+    CK(collapse_fast(d_reads, d_lens, smp, n, n_samples, h_hist, cap, d_u_words, d_u_lens, d_quant, h_n_unique, n_cu, stream, &took));
+    if (took) return hipSuccess;
+    arena.used = mark;
+  }
+
+  // ---- general path ----
+  DevBuf idx0, idx1, key0, key1, flags_read, flags_run, starts, temp;
   CK(idx0.alloc((size_t)n * 4));
   CK(idx1.alloc((size_t)n * 4));
   CK(key0.alloc((size_t)n * 8));
   CK(key1.alloc((size_t)n * 8));
   CK(flags_read.alloc((size_t)n * 4));
-  CK(flags_run.alloc((size_t)n));
-  CK(uid.alloc((size_t)n * 4));
+  CK(flags_run.alloc((size_t)n * 4));
   CK(starts.alloc((size_t)n * 4));
-  CK(n_runs.alloc(4));
-
-  hipcub::DoubleBuffer<uint64_t> keys(key0.as<uint64_t>(), key1.as<uint64_t>());
-  hipcub::DoubleBuffer<uint32_t> vals(idx0.as<uint32_t>(), idx1.as<uint32_t>());
-  size_t temp_bytes = 0, need = 0;
-  CK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, keys, vals, (int)n, 0, 64, stream));
-  temp_bytes = need;
-  CK(hipcub::DeviceScan::InclusiveSum(nullptr, need, flags_read.as<uint32_t>(), uid.as<uint32_t>(), (int)n, stream));
-  if (need > temp_bytes) temp_bytes = need;
-  CK(hipcub::DeviceSelect::Flagged(nullptr, need, hipcub::CountingInputIterator<uint32_t>(0),
-                                   flags_run.as<uint8_t>(), starts.as<uint32_t>(), n_runs.as<uint32_t>(),
-                                   (int)n, stream));
-  if (need > temp_bytes) temp_bytes = need;
-  CK(temp.alloc(temp_bytes));
-
-  hipLaunchKernelGGL(iota_kernel, dim3(grid), dim3(kT), 0, stream, vals.Current(), n);
-
-  auto sort_pass = [&](int bits) -> hipError_t {
-    size_t tb = temp_bytes;
-    return hipcub::DeviceRadixSort::SortPairs(temp.p, tb, keys, vals, (int)n, 0, bits, stream);
+  CK(temp.alloc(std::max(prims::radix_temp_bytes(n), prims::scan_temp_bytes(n))));
+  uint64_t* keys[2] = {key0.as<uint64_t>(), key1.as<uint64_t>()};
+  uint32_t* vals[2] = {idx0.as<uint32_t>(), idx1.as<uint32_t>()};
+  int cur = 0;  // which pair of buffers holds the current order
+  hipLaunchKernelGGL(iota_kernel, dim3(grid), dim3(kT), 0, stream, vals[cur], n);
+  // (the key column of a pass is gathered into keys[cur] through vals[cur])
+  auto sort_pass = [&](uint32_t bits) -> hipError_t {
+    bool second = false;
+    hipError_t e = prims::radix_sort_pairs_u64(keys[cur], keys[cur ^ 1], vals[cur], vals[cur ^ 1], n, bits, temp.p, stream, &second);
+    if (second) cur ^= 1;
+    return e;
   };
   // least significant column first (stable sorts): sample, words, N mask, length
-  if (d_sample && n_samples > 1) {
-    hipLaunchKernelGGL(gather_key_kernel<uint16_t>, dim3(grid), dim3(kT), 0, stream, d_sample, vals.Current(),
-                       keys.Current(), n);
-    CK(sort_pass(16));
+  if (smp) {
+    hipLaunchKernelGGL(gather_key_kernel<uint16_t>, dim3(grid), dim3(kT), 0, stream, smp, vals[cur], keys[cur], n);
+    uint32_t sbits = 1;
+    while ((1u << sbits) < n_samples) ++sbits;
+    CK(sort_pass(sbits));
   }
-  const bool fused = (W == 1 && max_len > 0 && max_len <= 29 && !d_nmask);
-  if (fused) {
-    hipLaunchKernelGGL(gather_fused_key_kernel, dim3(grid), dim3(kT), 0, stream, d_reads, d_lens,
-                       vals.Current(), keys.Current(), n, 2u * max_len);
-    CK(sort_pass((int)(2u * max_len + 6u)));
-  } else {
+  for (uint32_t w = 0; w < W; ++w) {
+    hipLaunchKernelGGL(gather_key_kernel<uint64_t>, dim3(grid), dim3(kT), 0, stream, d_reads + (size_t)w * n, vals[cur], keys[cur], n);
+    CK(sort_pass(64));
+  }
+  if (d_nmask)
     for (uint32_t w = 0; w < W; ++w) {
-      hipLaunchKernelGGL(gather_key_kernel<uint64_t>, dim3(grid), dim3(kT), 0, stream,
-                         d_reads + (size_t)w * n, vals.Current(), keys.Current(), n);
+      hipLaunchKernelGGL(gather_key_kernel<uint64_t>, dim3(grid), dim3(kT), 0, stream, d_nmask + (size_t)w * n, vals[cur], keys[cur], n);
       CK(sort_pass(64));
     }
-    if (d_nmask)
-      for (uint32_t w = 0; w < W; ++w) {
-        hipLaunchKernelGGL(gather_key_kernel<uint64_t>, dim3(grid), dim3(kT), 0, stream,
-                           d_nmask + (size_t)w * n, vals.Current(), keys.Current(), n);
-        CK(sort_pass(64));
-      }
-    hipLaunchKernelGGL(gather_key_kernel<uint8_t>, dim3(grid), dim3(kT), 0, stream, d_lens, vals.Current(),
-                       keys.Current(), n);
-    CK(sort_pass(8));
-  }
+  hipLaunchKernelGGL(gather_key_kernel<uint8_t>, dim3(grid), dim3(kT), 0, stream, d_lens, vals[cur], keys[cur], n);
+  CK(sort_pass(8));
 
-  CollapseCols c{d_reads, d_nmask, d_lens, (d_sample && n_samples > 1) ? d_sample : nullptr, W, n};
-  hipLaunchKernelGGL(head_flags_kernel, dim3(grid), dim3(kT), 0, stream, c, vals.Current(),
-                     flags_read.as<uint32_t>(), flags_run.as<uint8_t>());
-  {
-    size_t tb = temp_bytes;
-    CK(hipcub::DeviceScan::InclusiveSum(temp.p, tb, flags_read.as<uint32_t>(), uid.as<uint32_t>(), (int)n, stream));
-    tb = temp_bytes;
-    CK(hipcub::DeviceSelect::Flagged(temp.p, tb, hipcub::CountingInputIterator<uint32_t>(0),
-                                     flags_run.as<uint8_t>(), starts.as<uint32_t>(), n_runs.as<uint32_t>(),
-                                     (int)n, stream));
-  }
-  uint32_t n_unique = 0;
-  CK(hipMemcpyAsync(&n_unique, uid.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+  CollapseCols c{d_reads, d_nmask, d_lens, smp, W, n};
+  uint32_t* uid = flags_read.as<uint32_t>();   // head flags, then their inclusive prefix = unique id + 1
+  uint32_t* runs = flags_run.as<uint32_t>();   // run heads, then their inclusive prefix = run number + 1
+  hipLaunchKernelGGL(head_flags_kernel, dim3(grid), dim3(kT), 0, stream, c, vals[cur], uid, runs);
+  CK(hipGetLastError());
+  CK(prims::inclusive_sum_u32(uid, uid, n, temp.p, stream));
+  CK(prims::inclusive_sum_u32(runs, runs, n, temp.p, stream));
+  uint32_t n_unique = 0, n_runs = 0;
+  CK(hipMemcpyAsync(&n_unique, uid + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+  CK(hipMemcpyAsync(&n_runs, runs + (n - 1), 4, hipMemcpyDeviceToHost, stream));
   CK(hipStreamSynchronize(stream));
   if (n_unique > cap) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(run_starts_kernel, dim3(grid), dim3(kT), 0, stream, runs, n, starts.as<uint32_t>());
   CK(hipMemsetAsync(d_quant, 0, (size_t)n_unique * n_samples * 4, stream));
-  hipLaunchKernelGGL(emit_kernel, dim3(grid), dim3(kT), 0, stream, c, vals.Current(), uid.as<uint32_t>(),
-                     starts.as<uint32_t>(), n_runs.as<uint32_t>(), n_samples, cap, d_u_words, d_u_lens,
-                     d_u_nmask, d_quant);
-  {
-    const uint16_t* smp = (d_sample && n_samples > 1) ? d_sample : nullptr;
-    auto* hist = reinterpret_cast<unsigned long long*>(d_len_hist);
-    const uint32_t lds = 256u * n_samples * 4u;
-    if (lds <= 48u * 1024u)
-      hipLaunchKernelGGL(length_hist_kernel<true>, dim3(min(grid, 1024u)), dim3(kT), lds, stream, d_lens, smp,
-                         n, n_samples, hist);
-    else
-      hipLaunchKernelGGL(length_hist_kernel<false>, dim3(min(grid, 1024u)), dim3(kT), 0, stream, d_lens, smp,
-                         n, n_samples, hist);
-  }
+  hipLaunchKernelGGL(emit_kernel, dim3((n_runs + kT - 1) / kT), dim3(kT), 0, stream, c, vals[cur], uid, starts.as<uint32_t>(), n_runs,
+                     n_samples, cap, d_u_words, d_u_lens, d_u_nmask, d_quant);
   CK(hipGetLastError());
   CK(hipStreamSynchronize(stream));
   *h_n_unique = n_unique;
   return hipSuccess;
 }
 
-
 // Exclusive prefix sum of n+1 uint32 values into uint64 (out[n] = total when in[n] == 0):
 // offsets of the per-read alignment lists of mrg_list_best.
-struct U32ToU64 {
-  __host__ __device__ uint64_t operator()(uint32_t v) const { return (uint64_t)v; }
-};
 hipError_t exclusive_sum_u32_u64(const uint32_t* in, uint64_t* out, uint64_t n_plus_1, hipStream_t stream) {
-  hipcub::TransformInputIterator<uint64_t, U32ToU64, const uint32_t*> it(in, U32ToU64());
-  size_t need = 0;
-  hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, need, it, out, (int)n_plus_1, stream);
-  if (e != hipSuccess) return e;
   void* tmp = nullptr;
-  e = hipMalloc(&tmp, need ? need : 16);
+  hipError_t e = hipMalloc(&tmp, prims::scan_temp_bytes(n_plus_1));
   if (e != hipSuccess) return e;
-  e = hipcub::DeviceScan::ExclusiveSum(tmp, need, it, out, (int)n_plus_1, stream);
+  e = prims::exclusive_sum_u32_to_u64(in, out, n_plus_1, tmp, stream);
   hipError_t e2 = hipStreamSynchronize(stream);
   (void)hipFree(tmp);
   return e != hipSuccess ? e : e2;

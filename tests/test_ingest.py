@@ -261,12 +261,14 @@ def test_gpu_collapse_fused_and_general_paths(native_lib):
         want = {}
         for key, s in zip(w.tolist(), sample.tolist()):
             want.setdefault(key, [0] * n_samples)[s] += 1
-        for max_len in (22, 0):   # 22 -> single fused 64-bit sort; 0 -> general multi-pass path
-            out = ingest.collapse(eng, w[None, :], lens, None, sample, n_samples=n_samples, max_len=max_len)
+        for fast in (1, 0):   # the duplication-aware path; the general column-by-column sort
+            eng.set_option("collapse_fast", fast)
+            out = ingest.collapse(eng, w[None, :], lens, None, sample, n_samples=n_samples, max_len=22)
             assert out["words"].shape[1] == len(want)
             for key, q in zip(out["words"][0].tolist(), out["quant"].tolist()):
                 assert q == want[key]
             assert out["length_hist"] == {22: [int((sample == s).sum()) for s in range(n_samples)]}
+    eng.set_option("collapse_fast", 1)
     # empty input
     out = ingest.collapse(eng, np.zeros((1, 0), np.uint64), np.zeros(0, np.uint8))
     assert out["words"].shape == (1, 0) and out["quant"].shape[0] == 0
