@@ -13,7 +13,7 @@ import sys
 
 
 def short(name):
-    name = name.replace("void ", "").split("(")[0].replace("mrg::", "")
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].replace("mrg::", "")
     return name[:60]
 
 

@@ -85,7 +85,7 @@ def test_batches_the_fast_path_hands_over_are_still_right(native_lib):
     eng = Engine(0)
     n = 300_000
     low = rng.integers(0, 200_000, n, dtype=np.uint64)
-    words = (np.uint64(0x3A5F1C2B6) << np.uint64(18)) | low     # 44-bit keys: the top 26 bits constant
+    words = (np.uint64(0x2A5F1C2) << np.uint64(18)) | low       # 44-bit keys: the top 26 bits constant
     lens = np.full(n, 22, np.uint8)
     sample = np.zeros(n, np.uint16)
     out = ingest.collapse(eng, words[None, :], lens, None, None, n_samples=1, max_len=22)
