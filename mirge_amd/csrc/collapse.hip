@@ -5,29 +5,35 @@
 // deterministically.  Every kernel here is this library's own (rounds 1-4 called a radix-sort library: sorting 100 M
 // records to find 18 M distinct ones ignores what small-RNA data is -- a few sequences are most of a sample).
 //
-// FAST PATH (one-word reads without N, 2 max_len + sample bits <= 58, at most 16 distinct lengths): duplication-aware.
-//   bounds + length histogram   one pass over lengths / sample ids (what readLengthDic needs anyway): longest read,
-//                  largest sample id, which lengths occur;
-//   K0 l1_hist     raw reads per (workgroup chunk, L1 bucket).  An L1 bucket = (length, the 8 most significant bits
-//                  of the 2 L-bit packed read): buckets are ORDERED as the output is.  A prefix sum over
-//                  [bucket][workgroup] gives every (bucket, workgroup) a private region sized for its raw reads --
-//                  an upper bound of what K1 writes there, so K1 needs no global atomic at all;
-//   K1 aggregate   a workgroup streams its chunk through an LDS hash table (4096 slots, 64-bit compare-and-swap on
-//                  the key, add on the count): the copies of a sequence inside a flush interval become ONE (rest of
-//                  key, count) pair of 8 bytes -- the miRNA that is 30 % of a sample leaves a chunk as a handful of
-//                  pairs, not as 30 M same-address atomics.  The table is flushed (pairs appended to their L1
-//                  regions through LDS cursors) when it is half full or 15 batches old (the count field is 14 bits);
-//   K2 subdivide   one workgroup per L1 bucket: the bucket's pairs (at most 1024 segments, one per K1 workgroup) are
-//                  counted by their next b2 <= 8 bits and copied into contiguous FINAL buckets of ~1000 pairs;
-//   K3 reduce      one workgroup per final bucket: pairs into an LDS table whose slot is the MONOTONE function "top
-//                  11 bits of the remaining key", linear probing without wrap-around.  Runs of occupied slots are then
-//                  ordered among themselves, so the bucket is sorted once every run is (a few entries each: the head
-//                  thread of a run insertion-sorts it) -- no sorting network, no second hash.  Counts of equal keys
-//                  were summed by the inserts.  Sorted (key, count) entries go back to the bucket's region;
+// FAST PATH (one-word reads without N of at most 29 nt, 2 max_len + sample bits <= 58, at most 16 distinct lengths,
+// at most 16 samples): duplication-aware.  What the measurements of round 5 said about this chip decides its shape:
+// scattered 8-byte stores run at ~100 G/s whatever they carry (so every scatter is staged in LDS and written run by
+// run), a wave waits for its slowest lane (so every data-dependent loop runs once per lane, never once per slot), and
+// 64 same-address LDS atomics are 64 serial ones (so the hot keys are counted apart).
+//   K0 prepass     ONE pass over the batch: readLengthDic (what the call returns anyway), the largest sample id, the raw
+//                  reads per (workgroup chunk, L1 bucket), and a SAMPLE (the first 256 reads of each of the 1024 chunks)
+//                  into a global hash table.  An L1 bucket = (length, the 8 most significant bits of the 2 L-bit packed
+//                  read): buckets are ORDERED as the output is.  A prefix sum over [bucket][chunk] gives every (bucket,
+//                  chunk) a private region sized for its raw reads -- an upper bound of what K1 writes there, so K1
+//                  needs no global atomic at all;
+//   hot keys       the (at most 1024) sample entries seen most often: the sequences that are most of a small-RNA sample;
+//   K1 split       a workgroup copies the hot keys into an LDS table (buckets of four keys, one 32-byte read per
+//                  lookup) with a counter each and streams its chunk: a read that is a hot key bumps a counter -- the
+//                  miRNA that is 8 % of the sample leaves a chunk as ONE (rest of key, count) pair, not as 8 000 --,
+//                  every other read becomes a pair with count 1.  A trip's pairs are grouped by L1 bucket in LDS and
+//                  appended to the chunk's regions run by run; what a region has left at the end is filled with zero
+//                  pairs, so that K2 streams whole buckets;
+//   K2 subdivide   a workgroup = (L1 bucket, one of 32 parts of its region): the pairs counted by their next b2 <= 8 bits
+//                  (K2a), one prefix sum over [final bucket][part], and the pairs copied -- staged in LDS by final
+//                  bucket, written run by run -- into contiguous FINAL buckets of ~1000 pairs, in key order (K2b);
+//   K3 reduce      one workgroup per final bucket: pairs into an LDS hash table (equal keys summed by the inserts), its
+//                  occupied slots counting-sorted by the top 8 bits the bucket leaves open, an entry's place = its bin's
+//                  start + the members of its bin with a smaller key (a handful: it looks at each).  Sorted (key, count)
+//                  entries go back to the bucket's region;
 //   K4 emit        prefix sum of the buckets' read counts, entries -> u_words / u_lens / quant[u][sample].
-//   Anything that does not fit (a bucket with more distinct keys than its table, a run of more than 256 slots:
-//   sequences that share 20 leading bits of their key by the thousand) raises a flag and the batch takes the general
-//   path: slower, never wrong.
+//   A final bucket with more distinct keys than its table (~1500: an L1 bucket with more than 400 000 distinct reads --
+//   a batch whose reads all END in the same 4 bases) raises a flag and the batch takes the general path: slower,
+//   never wrong.
 //
 // GENERAL PATH (several words per read, N masks, reads beyond 29 nt): stable LSD radix sort (prims.hip) of read ids
 // by (sample, packed words, N mask, length) column by column, head flags on the sorted order, prefix sums for the
@@ -205,9 +211,11 @@ constexpr uint32_t kMaxLenSlots = 16u;       // distinct read lengths a batch ma
 constexpr uint32_t kFastMaxLen = 29u;
 constexpr uint32_t kLenBins = (kFastMaxLen + 1u) * 256u;  // K0 counts by (length, top 8 bits), whatever lengths occur
 constexpr uint32_t kL1Bits = 8u;
-constexpr uint32_t kAggSlots = 4096u;        // K1's LDS table
-constexpr uint32_t kAggFlushAt = 2048u;      // ... flushed once it holds this many distinct keys
-constexpr uint32_t kAggKeep = 1024u;         // ... of which about this many (the most frequent) stay
+constexpr uint32_t kAggSlotBits = 11u;
+constexpr uint32_t kAggSlots = 1u << kAggSlotBits;  // K1's LDS table of hot keys
+constexpr uint32_t kHotKeys = 1024u;         // ... holds at most this many
+constexpr uint32_t kSampleLanes = 64u;       // K0: the first 4 x 64 reads of a chunk are the sample (256 K reads of 1024 chunks)
+constexpr uint32_t kSampleBits = 19u;        // slots of the sample's global hash table
 constexpr uint32_t kPairMaxCount = 16383u;   // a pair's count has 14 bits
 constexpr uint32_t kCountShift = 50u;        // pair = count << 50 | rest of the key (count 0: an unused position)
 constexpr uint64_t kRestMask = (1ull << kCountShift) - 1ull;
@@ -234,7 +242,9 @@ template <bool LENH>
 __global__ void __launch_bounds__(kFastThreads) prepass_kernel(const uint64_t* __restrict__ words, const uint8_t* __restrict__ lens,
                                                                const uint16_t* __restrict__ sample, uint32_t n, uint32_t chunk,
                                                                uint32_t n_chunks, uint32_t n_samples, uint32_t* __restrict__ counts_t,
-                                                               unsigned long long* __restrict__ len_hist, uint32_t* __restrict__ max_sample) {
+                                                               unsigned long long* __restrict__ len_hist, uint32_t* __restrict__ max_sample,
+                                                               unsigned long long* __restrict__ smp_key, uint32_t* __restrict__ smp_cnt,
+                                                               uint32_t sb) {
   extern __shared__ uint32_t smem_u32[];
   uint32_t* hist = smem_u32;             // kLenBins
   uint32_t* lhist = smem_u32 + kLenBins;  // 256 x n_samples (LENH)
@@ -274,6 +284,25 @@ __global__ void __launch_bounds__(kFastThreads) prepass_kernel(const uint64_t* _
         }
       }
     }
+    if (i0 == lo && threadIdx.x < kSampleLanes) {
+      // the SAMPLE: the first 4 x kSampleLanes reads of every chunk into a global hash table (key -> occurrences):
+      // what occurs there more than once is probably frequent everywhere (K1's hot table is chosen from it)
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t L = (L4 >> (8u * k)) & 255u;
+        if (i + k >= hi || L > kFastMaxLen) continue;
+        const unsigned long long key = ((unsigned long long)L << 58) | ((w[k] << sb) | (uint64_t)min(sm[k], n_samples - 1u));
+        uint32_t s = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64u - kSampleBits));
+        for (uint32_t tries = 0; tries < 64u; ++tries) {
+          const unsigned long long old = atomicCAS(&smp_key[s], kEmpty, key);
+          if (old == kEmpty || old == key) {
+            atomicAdd(&smp_cnt[s], 1u);
+            break;
+          }
+          s = (s + 1u) & ((1u << kSampleBits) - 1u);
+        }
+      }
+    }
 #pragma unroll
     for (uint32_t k = 0; k < 4u; ++k) {
       if (i + k >= hi) break;
@@ -310,110 +339,206 @@ __global__ void __launch_bounds__(kFastThreads) prepass_kernel(const uint64_t* _
   }
 }
 
-// K1: aggregate a chunk through an LDS hash table, append (rest, count) pairs to the chunk's L1 regions.
-// The table is flushed when it holds more than kAggFlushAt distinct keys -- but only its COLD entries leave: the
-// entries seen at least T times since they entered stay (T doubles while more than kAggKeep would stay, halves when
-// few do), so a sequence that is a percent of the sample leaves the chunk once, at the end, with its whole count
-// instead of once per flush.  (Emptied slots are not tombstoned: a key whose probe chain was cut is inserted a
-// second time, the two entries are summed by K3 like any two pairs of one key.)  A region is sized for the chunk's
-// raw reads of the bucket: what the pairs leave of it is filled with zero pairs, so that K2 streams whole buckets.
-// off_t: exclusive prefix of K0's counts (indexed by length x 256 + top, one entry past the end).
-__global__ void __launch_bounds__(kFastThreads) aggregate_kernel(const uint64_t* __restrict__ words, const uint8_t* __restrict__ lens,
-                                                                 const uint16_t* __restrict__ sample, FastShape f,
-                                                                 const uint32_t* __restrict__ off_t, uint32_t* __restrict__ bin_pairs,
-                                                                 uint64_t* __restrict__ pairs) {
+// The hot keys: sample entries seen at least T times, T = the lowest count that keeps at most kHotKeys of them
+// (hist: entries by min(count, 255), filled by hot_hist_kernel; every workgroup of hot_pick_kernel derives T for itself).
+__global__ void __launch_bounds__(256) hot_hist_kernel(const uint32_t* __restrict__ smp_cnt, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0u;
+  __syncthreads();
+  for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < (1u << kSampleBits); s += gridDim.x * 256u) {
+    const uint32_t c = smp_cnt[s];
+    if (c >= 2u) atomicAdd(&h[min(c, 255u)], 1u);
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void __launch_bounds__(256) hot_pick_kernel(const unsigned long long* __restrict__ smp_key, const uint32_t* __restrict__ smp_cnt,
+                                                       const uint32_t* __restrict__ hist, unsigned long long* __restrict__ hot,
+                                                       uint32_t* __restrict__ n_hot) {
+  __shared__ uint32_t T;
+  if (threadIdx.x == 0) {
+    uint32_t keep = 0, t = 256u;
+    for (uint32_t c = 255u; c >= 2u; --c) {
+      if (keep + hist[c] > kHotKeys) break;
+      keep += hist[c];
+      t = c;
+    }
+    T = t;
+  }
+  __syncthreads();
+  for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < (1u << kSampleBits); s += gridDim.x * 256u) {
+    if (smp_cnt[s] >= T) {
+      const uint32_t at = atomicAdd(n_hot, 1u);
+      if (at < kHotKeys) hot[at] = smp_key[s];
+    }
+  }
+}
+
+// K1: split a chunk into what its hot table absorbs and what leaves at once.  The workgroup copies the hot keys into
+// an LDS hash table (read-only from then on) with a counter each; a read whose key is there bumps the counter -- the
+// sequence that is a percent of the sample leaves the chunk ONCE, at the end, with its count -- every other read
+// becomes a (rest of key, 1) pair in its L1 bucket's region on the spot: no flush, no barrier in the loop.
+// A region is sized for the chunk's raw reads of the bucket: what the pairs leave of it is filled with zero pairs, so
+// that K2 streams whole buckets.  off_t: exclusive prefix of K0's counts (by length x 256 + top, one entry past the end).
+__global__ void __launch_bounds__(kFastThreads) split_kernel(const uint64_t* __restrict__ words, const uint8_t* __restrict__ lens,
+                                                             const uint16_t* __restrict__ sample, FastShape f,
+                                                             const uint32_t* __restrict__ off_t, const unsigned long long* __restrict__ hot,
+                                                             const uint32_t* __restrict__ n_hot_p, uint32_t* __restrict__ bin_pairs,
+                                                             uint64_t* __restrict__ pairs) {
+  constexpr uint32_t kPer = 4u, kTrip = kPer * kFastThreads;  // reads per lane and trip; reads per trip
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned long long* tkey = reinterpret_cast<unsigned long long*>(smem);
-  uint32_t* tcnt = reinterpret_cast<uint32_t*>(smem + kAggSlots * 8u);
-  uint32_t* cursor = tcnt + kAggSlots;  // n_bins: where the next pair of a bucket goes
-  uint32_t* ctl = cursor + f.n_bins;    // [0] distinct keys in the table, [1] entries that stay, [2] T
+  unsigned long long* tkey = reinterpret_cast<unsigned long long*>(smem);         // kAggSlots: the hot keys
+  uint64_t* stage = reinterpret_cast<uint64_t*>(smem + kAggSlots * 8u);            // kTrip: a trip's pairs, grouped by bucket
+  uint32_t* tcnt = reinterpret_cast<uint32_t*>(smem + kAggSlots * 8u + kTrip * 8u);  // kAggSlots: what a hot key counted
+  uint32_t* cursor = tcnt + kAggSlots;   // n_bins: where the next pair of a bucket goes
+  uint32_t* tcount = cursor + f.n_bins;  // n_bins: pairs of the trip per bucket
+  uint32_t* tstart = tcount + f.n_bins;  // n_bins: their first position in `stage`
+  uint32_t* wtot = tstart + f.n_bins;    // 16 + 1
+  uint16_t* stage_bin = reinterpret_cast<uint16_t*>(wtot + 32);  // kTrip
   for (uint32_t s = threadIdx.x; s < kAggSlots; s += kFastThreads) {
     tkey[s] = kEmpty;
     tcnt[s] = 0u;
   }
-  for (uint32_t b = threadIdx.x; b < f.n_bins; b += kFastThreads)
+  for (uint32_t b = threadIdx.x; b < f.n_bins; b += kFastThreads) {
     cursor[b] = off_t[((size_t)f.len_of_slot[b >> 8] * 256u + (b & 255u)) * f.n_chunks + blockIdx.x];
-  if (threadIdx.x == 0) ctl[0] = 0u, ctl[1] = 0u, ctl[2] = 2u;
+    tcount[b] = 0u;
+  }
+  __syncthreads();
+  // buckets of four keys (one 32-byte read looks at a whole bucket): a key sits in the first free slot of its home
+  // bucket or, when that is full, of the buckets behind it -- a lookup that meets a bucket with a free slot is over
+  const uint32_t n_hot = min(*n_hot_p, kHotKeys);
+  for (uint32_t h = threadIdx.x; h < n_hot; h += kFastThreads) {
+    const unsigned long long key = hot[h];
+    uint32_t s = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (66u - kAggSlotBits)) * 4u;
+    while (atomicCAS(&tkey[s], kEmpty, key) != kEmpty) s = (s + 1u) & (kAggSlots - 1u);
+  }
   __syncthreads();
   const uint64_t lo = (uint64_t)blockIdx.x * f.chunk;
   const uint64_t hi = min((uint64_t)f.n, lo + f.chunk);
-  const uint32_t lane = threadIdx.x & 63u;
-  // the next batch's read is requested before this batch's goes into the table
-  uint64_t nw = 0;
-  uint32_t nl = 0, ns = 0;
-  if (lo + threadIdx.x < hi) {
-    nw = words[lo + threadIdx.x];
-    nl = lens[lo + threadIdx.x];
-    if (sample) ns = sample[lo + threadIdx.x];
-  }
-  for (uint64_t base = lo; base < hi; base += kFastThreads) {
-    const uint64_t i = base + threadIdx.x;
-    const uint64_t w = nw;
-    const uint32_t L = nl, smp = ns;
-    if (i + kFastThreads < hi) {
-      nw = words[i + kFastThreads];
-      nl = lens[i + kFastThreads];
-      if (sample) ns = sample[i + kFastThreads];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t per_thread = (f.n_bins + kFastThreads - 1u) / kFastThreads;  // buckets a thread sums in the trip's prefix
+  for (uint64_t t0 = lo; t0 < hi; t0 += kTrip) {
+    const uint64_t i0 = t0 + (uint64_t)kPer * threadIdx.x;
+    uint64_t w[kPer];
+    uint32_t L4 = 0;
+    uint32_t sm[kPer] = {0u, 0u, 0u, 0u};
+    if (i0 + kPer <= hi) {
+      L4 = *reinterpret_cast<const uint32_t*>(lens + i0);
+      const uint4 a = *reinterpret_cast<const uint4*>(words + i0), b = *reinterpret_cast<const uint4*>(words + i0 + 2);
+      w[0] = (uint64_t)a.x | ((uint64_t)a.y << 32);
+      w[1] = (uint64_t)a.z | ((uint64_t)a.w << 32);
+      w[2] = (uint64_t)b.x | ((uint64_t)b.y << 32);
+      w[3] = (uint64_t)b.z | ((uint64_t)b.w << 32);
+      if (sample) {
+        const uint2 s2 = *reinterpret_cast<const uint2*>(sample + i0);
+        sm[0] = s2.x & 0xFFFFu, sm[1] = s2.x >> 16, sm[2] = s2.y & 0xFFFFu, sm[3] = s2.y >> 16;
+      }
+    } else {
+#pragma unroll
+      for (uint32_t k = 0; k < kPer; ++k) {
+        w[k] = 0ull;
+        if (i0 + k < hi) {
+          L4 |= (uint32_t)lens[i0 + k] << (8u * k);
+          w[k] = words[i0 + k];
+          if (sample) sm[k] = sample[i0 + k];
+        }
+      }
     }
-    bool fresh = false;
-    if (i < hi) {
-      const uint64_t v = (w << f.sb) | (uint64_t)smp;
+    uint64_t pr[kPer];   // 0: absorbed by the hot table (or no read)
+    uint32_t pb[kPer];   // bucket << 16 | rank among the trip's pairs of that bucket
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k) {
+      pr[k] = 0ull;
+      pb[k] = 0u;
+      if (i0 + k >= hi) continue;
+      const uint32_t L = (L4 >> (8u * k)) & 255u;
+      const uint64_t v = (w[k] << f.sb) | (uint64_t)sm[k];
       const unsigned long long key = ((unsigned long long)L << 58) | v;
-      uint32_t s = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 52);
+      uint32_t s = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (66u - kAggSlotBits)) * 4u;
+      bool hit = false;
       for (;;) {
-        const unsigned long long old = atomicCAS(&tkey[s], kEmpty, key);
-        if (old == kEmpty || old == key) {
-          atomicAdd(&tcnt[s], 1u);
-          fresh = old == kEmpty;
+        const ulonglong2 p0 = *reinterpret_cast<const ulonglong2*>(tkey + s), p1 = *reinterpret_cast<const ulonglong2*>(tkey + s + 2u);
+        const uint32_t m = (p0.x == key ? 1u : 0u) | (p0.y == key ? 2u : 0u) | (p1.x == key ? 4u : 0u) | (p1.y == key ? 8u : 0u);
+        if (m) {
+          hit = true;
+          s += (uint32_t)__ffs((int)m) - 1u;
           break;
         }
-        s = (s + 1u) & (kAggSlots - 1u);
+        if (p1.y == kEmpty) break;  // (slots fill from the front: a free last slot = nothing of this home went further)
+        s = (s + 4u) & (kAggSlots - 1u);
+      }
+      if (hit) {
+        atomicAdd(&tcnt[s], 1u);
+      } else {
+        const uint32_t sh = l1_shift(L) + f.sb;
+        const uint32_t bin = (uint32_t)f.slot_of_len[L & 63u] * 256u + ((uint32_t)(v >> sh) & 255u);
+        pr[k] = (1ull << kCountShift) | (v & ((1ull << sh) - 1ull));
+        pb[k] = (bin << 16) | atomicAdd(&tcount[bin], 1u);
       }
     }
-    const uint64_t fm = __ballot(fresh);
-    if (lane == 0 && fm) atomicAdd(&ctl[0], (uint32_t)__popcll(fm));
     __syncthreads();
-    const bool last = base + kFastThreads >= hi;
-    if (ctl[0] > kAggFlushAt || last) {
-      for (;;) {
-        const uint32_t T = last ? 0xFFFFFFFFu : ctl[2];
-        // every entry seen fewer than T times becomes a pair in its L1 bucket's region
-        for (uint32_t s = threadIdx.x; s < kAggSlots; s += kFastThreads) {
-          const unsigned long long key = tkey[s];
-          uint32_t c = key != kEmpty ? tcnt[s] : 0u;
-          const bool stays = c >= T;
-          const uint64_t sm_ = __ballot(stays);
-          if (lane == 0 && sm_) atomicAdd(&ctl[1], (uint32_t)__popcll(sm_));
-          if (c == 0u || stays) continue;
-          const uint32_t KL = (uint32_t)(key >> 58);
-          const uint64_t v = key & ((1ull << 58) - 1ull);
-          const uint32_t sh = l1_shift(KL) + f.sb;
-          const uint32_t bin = (uint32_t)f.slot_of_len[KL] * 256u + ((uint32_t)(v >> sh) & 255u);
-          const uint64_t rest = v & ((1ull << sh) - 1ull);
-          while (c) {  // (a count beyond the pair's 14 bits leaves in pieces: each stands for at least one read of the region)
-            const uint32_t piece = min(c, kPairMaxCount);
-            pairs[atomicAdd(&cursor[bin], 1u)] = ((uint64_t)piece << kCountShift) | rest;
-            c -= piece;
-          }
-          tkey[s] = kEmpty;
-          tcnt[s] = 0u;
-        }
-        __syncthreads();
-        const uint32_t kept = ctl[1];
-        __syncthreads();
-        if (threadIdx.x == 0) {
-          ctl[0] = kept;
-          ctl[1] = 0u;
-          if (kept > kAggKeep) ctl[2] = T * 2u;                       // too many stay: a higher bar from now on
-          else if (kept < kAggKeep / 4u && T > 2u) ctl[2] = T / 2u;   // the table runs cold: a lower one
-        }
-        __syncthreads();
-        if (last || kept <= kAggKeep + kAggKeep / 2u) break;  // (else: sweep again with the higher bar)
+    // the trip's pairs grouped by bucket in LDS, then written run by run: neighbouring lanes write neighbouring pairs
+    // (scattered 8-byte stores run at ~100 G/s on this chip whatever they carry)
+    {
+      uint32_t sum = 0;
+      for (uint32_t q = 0; q < per_thread; ++q) {
+        const uint32_t b = threadIdx.x * per_thread + q;
+        sum += b < f.n_bins ? tcount[b] : 0u;
       }
+      const uint32_t incl = dev::wave_incl_scan(sum);
+      if (lane == 63u) wtot[wave] = incl;
+      __syncthreads();
+      uint32_t st = incl - sum;
+      for (uint32_t ww = 0; ww < wave; ++ww) st += wtot[ww];
+      for (uint32_t q = 0; q < per_thread; ++q) {
+        const uint32_t b = threadIdx.x * per_thread + q;
+        if (b < f.n_bins) {
+          tstart[b] = st;
+          st += tcount[b];
+        }
+      }
+      if (threadIdx.x == kFastThreads - 1u) wtot[16] = st;
+    }
+    __syncthreads();
+    const uint32_t total = wtot[16];
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k)
+      if (pr[k]) {
+        const uint32_t at = tstart[pb[k] >> 16] + (pb[k] & 0xFFFFu);
+        stage[at] = pr[k];
+        stage_bin[at] = (uint16_t)(pb[k] >> 16);
+      }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < total; i += kFastThreads) {
+      const uint32_t bin = stage_bin[i];
+      pairs[cursor[bin] + (i - tstart[bin])] = stage[i];
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < f.n_bins; b += kFastThreads) {
+      cursor[b] += tcount[b];
+      tcount[b] = 0u;
+    }
+    // (the next trip's first barrier orders this against its uses)
+  }
+  __syncthreads();
+  // the hot entries with what they counted
+  for (uint32_t s = threadIdx.x; s < kAggSlots; s += kFastThreads) {
+    const unsigned long long key = tkey[s];
+    uint32_t c = key != kEmpty ? tcnt[s] : 0u;
+    if (!c) continue;
+    const uint32_t KL = (uint32_t)(key >> 58);
+    const uint64_t v = key & ((1ull << 58) - 1ull);
+    const uint32_t sh = l1_shift(KL) + f.sb;
+    const uint32_t bin = (uint32_t)f.slot_of_len[KL] * 256u + ((uint32_t)(v >> sh) & 255u);
+    const uint64_t rest = v & ((1ull << sh) - 1ull);
+    while (c) {  // (a count beyond the pair's 14 bits leaves in pieces: each stands for at least one read of the region)
+      const uint32_t piece = min(c, kPairMaxCount);
+      pairs[atomicAdd(&cursor[bin], 1u)] = ((uint64_t)piece << kCountShift) | rest;
+      c -= piece;
     }
   }
+  __syncthreads();
   // unused positions of the chunk's regions -> zero pairs; pairs of the chunk per bucket -> the buckets' totals
-  const uint32_t wave = threadIdx.x >> 6;
   for (uint32_t b = wave; b < f.n_bins; b += kFastThreads / 64u) {
     const size_t at = ((size_t)f.len_of_slot[b >> 8] * 256u + (b & 255u)) * f.n_chunks + blockIdx.x;
     const uint32_t first = off_t[at], end = off_t[at + 1], cur = cursor[b];
@@ -437,9 +562,16 @@ __global__ void __launch_bounds__(kFastThreads) subdivide_kernel(FastShape f, co
                                                                  const uint32_t* __restrict__ bin_pairs, const uint64_t* __restrict__ pairs_in,
                                                                  uint32_t* __restrict__ hist_t /* SCATTER: its exclusive prefix */,
                                                                  uint64_t* __restrict__ pairs_out, uint8_t* __restrict__ l1_b2) {
-  __shared__ uint32_t sub[256];  // counts, or (SCATTER) write cursors
+  // SCATTER stages a tile of 8192 positions in LDS, grouped by final bucket, and writes it out run by run: the lanes of
+  // a store instruction then write neighbouring pairs (a 128-byte line takes ONE request, not sixteen 8-byte ones:
+  // scattered 8-byte stores run at ~100 G/s on this chip whatever they carry)
+  constexpr uint32_t kTilePos = 2u * 4u * kFastThreads;
+  __shared__ uint32_t sub[256];    // counts (hist pass); SCATTER: where the next tile's run of a final bucket goes
+  __shared__ uint32_t tcount[256], tstart[256];
+  __shared__ uint32_t wtot[kFastThreads / 64u];
+  __shared__ uint64_t stage[SCATTER ? kTilePos : 1];
   const uint32_t b = blockIdx.x / f.groups, g = blockIdx.x % f.groups;
-  const uint32_t tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t P = bin_pairs[b];
   if (P == 0) return;
   if (tid < 256u) sub[tid] = SCATTER ? hist_t[((size_t)b * 256u + tid) * f.groups + g] : 0u;
@@ -455,25 +587,60 @@ __global__ void __launch_bounds__(kFastThreads) subdivide_kernel(FastShape f, co
   const uint32_t span = (((r_hi - a0) + f.groups - 1u) / f.groups + 1u) & ~1u;  // (even: 16-byte loads stay aligned)
   const uint32_t lo = a0 + g * span, hi = min(r_hi, lo + span);
   constexpr uint32_t kUnroll = 4u;  // 16-byte loads a lane keeps in flight
-  for (uint32_t i0 = lo + 2u * tid; i0 < hi; i0 += 2u * kFastThreads * kUnroll) {
+  for (uint32_t t0 = lo; t0 < hi; t0 += kTilePos) {
     uint4 q[kUnroll];
 #pragma unroll
     for (uint32_t u = 0; u < kUnroll; ++u) {
-      const uint32_t i = i0 + u * 2u * kFastThreads;
+      const uint32_t i = t0 + 2u * tid + u * 2u * kFastThreads;
       q[u] = i < hi ? *reinterpret_cast<const uint4*>(pairs_in + i) : make_uint4(0u, 0u, 0u, 0u);
     }
+    if (SCATTER) {
+      if (tid < 256u) tcount[tid] = 0u;
+      __syncthreads();
+    }
+    uint64_t pr[2u * kUnroll];
+    uint32_t rk[2u * kUnroll];  // SCATTER: rank of the pair among the tile's pairs of its final bucket
 #pragma unroll
     for (uint32_t u = 0; u < kUnroll; ++u) {
-      const uint32_t i = i0 + u * 2u * kFastThreads;
-      const uint64_t p0 = (uint64_t)q[u].x | ((uint64_t)q[u].y << 32), p1 = (uint64_t)q[u].z | ((uint64_t)q[u].w << 32);
-      if (i >= r_lo && i < hi && (p0 >> kCountShift)) {
-        const uint32_t at0 = atomicAdd(&sub[(uint32_t)((p0 & kRestMask) >> sh) & 255u], 1u);
-        if (SCATTER) pairs_out[at0] = p0;
+      const uint32_t i = t0 + 2u * tid + u * 2u * kFastThreads;
+      uint64_t p0 = (uint64_t)q[u].x | ((uint64_t)q[u].y << 32), p1 = (uint64_t)q[u].z | ((uint64_t)q[u].w << 32);
+      if (!(i >= r_lo && i < hi)) p0 = 0ull;
+      if (!(i + 1u < hi)) p1 = 0ull;
+      pr[2u * u] = p0;
+      pr[2u * u + 1u] = p1;
+      if (p0 >> kCountShift) rk[2u * u] = atomicAdd(SCATTER ? &tcount[(uint32_t)((p0 & kRestMask) >> sh) & 255u] : &sub[(uint32_t)((p0 & kRestMask) >> sh) & 255u], 1u);
+      if (p1 >> kCountShift) rk[2u * u + 1u] = atomicAdd(SCATTER ? &tcount[(uint32_t)((p1 & kRestMask) >> sh) & 255u] : &sub[(uint32_t)((p1 & kRestMask) >> sh) & 255u], 1u);
+    }
+    if (SCATTER) {
+      __syncthreads();
+      // tile-local starts of the 256 runs
+      uint32_t c = 0, incl = 0;
+      if (tid < 256u) {
+        c = tcount[tid];
+        incl = dev::wave_incl_scan(c);
+        if (lane == 63u) wtot[wave] = incl;
       }
-      if (i + 1u < hi && (p1 >> kCountShift)) {
-        const uint32_t at1 = atomicAdd(&sub[(uint32_t)((p1 & kRestMask) >> sh) & 255u], 1u);
-        if (SCATTER) pairs_out[at1] = p1;
+      __syncthreads();
+      uint32_t total = 0;
+      if (tid < 256u) {
+        uint32_t st = incl - c;
+        for (uint32_t w = 0; w < wave; ++w) st += wtot[w];
+        tstart[tid] = st;
       }
+      total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+      __syncthreads();
+#pragma unroll
+      for (uint32_t k = 0; k < 2u * kUnroll; ++k)
+        if (pr[k] >> kCountShift) stage[tstart[(uint32_t)((pr[k] & kRestMask) >> sh) & 255u] + rk[k]] = pr[k];
+      __syncthreads();
+      for (uint32_t i = tid; i < total; i += kFastThreads) {
+        const uint64_t p = stage[i];
+        const uint32_t sb2 = (uint32_t)((p & kRestMask) >> sh) & 255u;
+        pairs_out[sub[sb2] + (i - tstart[sb2])] = p;
+      }
+      __syncthreads();
+      if (tid < 256u) sub[tid] += tcount[tid];
+      // (the next trip's first barrier orders this against its reads of sub / writes of tcount)
     }
   }
   if (!SCATTER) {
@@ -512,12 +679,11 @@ __global__ void __launch_bounds__(kRedThreads) reduce_kernel(FastShape f, const 
                                                              uint64_t* __restrict__ ent_key, uint32_t* __restrict__ ent_cnt,
                                                              uint32_t* __restrict__ fb_entries, uint32_t* __restrict__ fb_reads,
                                                              uint32_t* __restrict__ overflow) {
-  __shared__ unsigned long long tkey[kRedSlots];   // the table, then the compacted entries
+  __shared__ unsigned long long tkey[kRedSlots];   // the table
   __shared__ uint32_t tcnt[kRedSlots];
-  __shared__ unsigned long long skey[kRedSlots];   // the entries grouped by bin
-  __shared__ uint32_t scnt[kRedSlots];
+  __shared__ uint16_t sidx[kRedSlots];             // the occupied slots grouped by bin
   __shared__ uint32_t bin_cnt[256], bin_start[257];
-  __shared__ uint32_t wtot[2][kRedThreads / 64u];
+  __shared__ uint32_t wtot[kRedThreads / 64u];
   __shared__ uint32_t n_in;
   constexpr uint32_t kPerThread = kRedSlots / kRedThreads;  // consecutive slots per thread
   constexpr uint32_t kLoads = 4u;                           // pairs a lane requests before it inserts any
@@ -576,90 +742,69 @@ __global__ void __launch_bounds__(kRedThreads) reduce_kernel(FastShape f, const 
     }
     if (lost) atomicOr(overflow, 1u);
     __syncthreads();
-    // the occupied slots, compacted in place (every thread holds its slots in registers across the barrier)
-    const uint32_t s_lo = tid * kPerThread;
-    unsigned long long mk[kPerThread];
-    uint32_t mc[kPerThread];
-    uint32_t n_mine = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < kPerThread; ++k) {
-      mk[k] = tkey[s_lo + k];
-      mc[k] = tcnt[s_lo + k];
-      n_mine += mk[k] != kEmpty ? 1u : 0u;
-    }
-    const uint32_t ie = dev::wave_incl_scan(n_mine);
-    if (lane == 63u) wtot[0][wave] = ie;
-    __syncthreads();
-    uint32_t pos = ie - n_mine, D = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < kRedThreads / 64u; ++w) {
-      pos += w < wave ? wtot[0][w] : 0u;
-      D += wtot[0][w];
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < kPerThread; ++k)
-      if (mk[k] != kEmpty) {
-        tkey[pos] = mk[k];
-        tcnt[pos] = mc[k];
-        ++pos;
-      }
-    __syncthreads();
-    // counting sort of the entries by bin = the top 8 bits of the key's open part (monotone in the key)
+    // counting sort of the occupied slots by bin = the top 8 bits of the key's open part (monotone in the key)
     const uint32_t bsh = r2 > 8u ? r2 - 8u : 0u;
     const uint64_t open_mask = (1ull << r2) - 1ull;
-    for (uint32_t e = tid; e < D; e += kRedThreads) atomicAdd(&bin_cnt[(uint32_t)((tkey[e] & open_mask) >> bsh) & 255u], 1u);
+    const uint32_t s_lo = tid * kPerThread;
+#pragma unroll
+    for (uint32_t k = 0; k < kPerThread; ++k) {
+      const unsigned long long key = tkey[s_lo + k];
+      if (key != kEmpty) atomicAdd(&bin_cnt[(uint32_t)((key & open_mask) >> bsh) & 255u], 1u);
+    }
     __syncthreads();
     {
       const uint32_t c = bin_cnt[tid];
       const uint32_t incl = dev::wave_incl_scan(c);
-      if (lane == 63u) wtot[1][wave] = incl;
+      if (lane == 63u) wtot[wave] = incl;
       __syncthreads();
       uint32_t st = incl - c;
 #pragma unroll
-      for (uint32_t w = 0; w < kRedThreads / 64u; ++w) st += w < wave ? wtot[1][w] : 0u;
+      for (uint32_t w = 0; w < kRedThreads / 64u; ++w) st += w < wave ? wtot[w] : 0u;
       bin_start[tid] = st;
       if (tid == 255u) bin_start[256] = st + c;
       bin_cnt[tid] = st;  // (now the bin's write cursor)
     }
     __syncthreads();
-    for (uint32_t e = tid; e < D; e += kRedThreads) {
-      const unsigned long long k = tkey[e];
-      const uint32_t at = atomicAdd(&bin_cnt[(uint32_t)((k & open_mask) >> bsh) & 255u], 1u);
-      skey[at] = k;
-      scnt[at] = tcnt[e];
+#pragma unroll
+    for (uint32_t k = 0; k < kPerThread; ++k) {
+      const unsigned long long key = tkey[s_lo + k];
+      if (key != kEmpty) sidx[atomicAdd(&bin_cnt[(uint32_t)((key & open_mask) >> bsh) & 255u], 1u)] = (uint16_t)(s_lo + k);
     }
     __syncthreads();
+    const uint32_t D = bin_start[256];
     // an entry's place in its bin = members with a smaller key; it is the first entry of its read when no member with
     // a smaller key has the same bases (entries of one read differ in their sample bits only: same bin, or the key is
     // shorter than 8 + sample bits and the bins hold one key each)
     const uint64_t prefix = ((uint64_t)(l1 & 255u) << r1) | ((uint64_t)sub << r2);  // the key bits the bucket stands for
     uint32_t n_rd = 0;
     for (uint32_t e = tid; e < D; e += kRedThreads) {
-      const unsigned long long k = skey[e];
+      const uint32_t slot = sidx[e];
+      const unsigned long long k = tkey[slot];
       const uint32_t bn = (uint32_t)((k & open_mask) >> bsh) & 255u;
       const uint32_t b_lo = bin_start[bn], b_hi = bin_start[bn + 1u];
       uint32_t rank = 0;
       bool head = true;
       for (uint32_t j = b_lo; j < b_hi; ++j) {
-        const unsigned long long o = skey[j];
+        const unsigned long long o = tkey[sidx[j]];
         rank += o < k ? 1u : 0u;
         head = head && !(o < k && (o >> f.sb) == (k >> f.sb));
       }
       if (f.sb && bsh < f.sb && head) {
         // (tiny keys: the read's other samples may sit in the bins in front)
-        for (uint32_t j = 0; j < b_lo; ++j) head = head && (skey[j] >> f.sb) != (k >> f.sb);
+        for (uint32_t j = 0; j < b_lo; ++j) head = head && (tkey[sidx[j]] >> f.sb) != (k >> f.sb);
       }
       n_rd += head ? 1u : 0u;
       const uint32_t at = start + b_lo + rank;
       ent_key[at] = prefix | (k & open_mask);
-      ent_cnt[at] = scnt[e];
+      ent_cnt[at] = tcnt[slot];
     }
     const uint32_t ir = dev::wave_incl_scan(n_rd);
-    if (lane == 63u) wtot[0][wave] = ir;
+    __syncthreads();
+    if (lane == 63u) wtot[wave] = ir;
     __syncthreads();
     if (tid == 0) {
       fb_entries[fb] = D;
-      fb_reads[fb] = wtot[0][0] + wtot[0][1] + wtot[0][2] + wtot[0][3];
+      fb_reads[fb] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
     }
     __syncthreads();
   }
@@ -717,6 +862,7 @@ struct FastPlan {
   uint32_t n_chunks = 0, chunk = 0;
   DevBuf off_t;  // K0's counts, then their exclusive prefix: (kLenBins x n_chunks + 1) entries
   DevBuf max_sample;
+  DevBuf sample;  // keys (8 B x 2^kSampleBits), counts (4 B x 2^kSampleBits), count histogram (256 x 4 B), n_hot, hot keys
 };
 
 // K0 (+ the prefix sum of its counts): issued before the host knows what the batch holds -- the length histogram it
@@ -729,13 +875,27 @@ hipError_t fast_prepass(const uint64_t* d_reads, const uint8_t* d_lens, const ui
   CK(plan->off_t.alloc(n_ct * 4));
   CK(plan->max_sample.alloc(4));
   CK(stmp->alloc(prims::scan_temp_bytes(n_ct)));
+  const size_t n_smp = (size_t)1 << kSampleBits;
+  CK(plan->sample.alloc(n_smp * 12 + 1024 + 64 + (size_t)kHotKeys * 8));
+  unsigned long long* smp_key = plan->sample.as<unsigned long long>();
+  uint32_t* smp_cnt = reinterpret_cast<uint32_t*>(smp_key + n_smp);
+  uint32_t* smp_hist = smp_cnt + n_smp;
+  uint32_t* n_hot = smp_hist + 256;
+  unsigned long long* hot = reinterpret_cast<unsigned long long*>(n_hot + 16);
+  CK(hipMemsetAsync(smp_key, 0xFF, n_smp * 8, stream));
+  CK(hipMemsetAsync(smp_cnt, 0, n_smp * 4 + 1024 + 64, stream));
   CK(hipMemsetAsync(plan->max_sample.p, 0, 4, stream));
   CK(hipMemsetAsync(plan->off_t.as<uint32_t>() + (n_ct - 1), 0, 4, stream));
+  uint32_t sb = 0;
+  while ((1u << sb) < n_samples) ++sb;
   const uint32_t lds = (kLenBins + 256u * n_samples) * 4u;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(prepass_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(prepass_kernel<true>, dim3(plan->n_chunks), dim3(kFastThreads), lds, stream, d_reads, d_lens, smp, n, plan->chunk,
                      plan->n_chunks, n_samples, plan->off_t.as<uint32_t>(), reinterpret_cast<unsigned long long*>(d_len_hist),
-                     plan->max_sample.as<uint32_t>());
+                     plan->max_sample.as<uint32_t>(), smp_key, smp_cnt, sb);
+  CK(hipGetLastError());
+  hipLaunchKernelGGL(hot_hist_kernel, dim3(256), dim3(256), 0, stream, smp_cnt, smp_hist);
+  hipLaunchKernelGGL(hot_pick_kernel, dim3(256), dim3(256), 0, stream, smp_key, smp_cnt, smp_hist, hot, n_hot);
   CK(hipGetLastError());
   return prims::exclusive_sum_u32(plan->off_t.as<uint32_t>(), plan->off_t.as<uint32_t>(), n_ct, stmp->p, stream);
 }
@@ -766,7 +926,7 @@ hipError_t collapse_fast(const uint64_t* d_reads, const uint8_t* d_lens, const u
   f.n_bins = f.n_slots * 256u;
   f.n_chunks = plan.n_chunks;
   f.chunk = plan.chunk;
-  f.groups = getenv("MIRGE_COLLAPSE_GROUPS") ? (uint32_t)std::max(1, atoi(getenv("MIRGE_COLLAPSE_GROUPS"))) : 8u;
+  f.groups = getenv("MIRGE_COLLAPSE_GROUPS") ? (uint32_t)std::max(1, atoi(getenv("MIRGE_COLLAPSE_GROUPS"))) : 32u;
   const size_t n_fb = (size_t)f.n_bins * 256u, n_ht = n_fb * f.groups;
   DevBuf bufA, bufB, cnt, hist_t, fbs, misc, work, stmp;
   CK(bufA.alloc((size_t)n * 8 + 16));
@@ -788,9 +948,12 @@ hipError_t collapse_fast(const uint64_t* d_reads, const uint8_t* d_lens, const u
   CK(hipMemsetAsync(fb_entries, 0, (n_fb + 1) * 4 * 2, stream));  // entries, reads (empty buckets count nothing)
   CK(hipMemsetAsync(misc.p, 0, f.n_bins * 5 + 64, stream));
   CK(hipMemsetAsync(hist_t.p, 0, (n_ht + 1) * 4, stream));        // (workgroups of empty L1 buckets write nothing)
-  const uint32_t agg_lds = kAggSlots * 12u + f.n_bins * 4u + 64u;
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(aggregate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)agg_lds));
-  hipLaunchKernelGGL(aggregate_kernel, dim3(f.n_chunks), dim3(kFastThreads), agg_lds, stream, d_reads, d_lens, smp, f, off_t, bin_pairs,
+  const uint32_t agg_lds = kAggSlots * 12u + 4096u * 10u + f.n_bins * 12u + 128u;
+  const size_t n_smp = (size_t)1 << kSampleBits;
+  const uint32_t* n_hot = reinterpret_cast<const uint32_t*>(plan.sample.as<unsigned long long>() + n_smp) + n_smp + 256;
+  const unsigned long long* hot = reinterpret_cast<const unsigned long long*>(n_hot + 16);
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)agg_lds));
+  hipLaunchKernelGGL(split_kernel, dim3(f.n_chunks), dim3(kFastThreads), agg_lds, stream, d_reads, d_lens, smp, f, off_t, hot, n_hot, bin_pairs,
                      bufA.as<uint64_t>());
   CK(hipGetLastError());
   const uint32_t sub_grid = f.n_bins * f.groups;
