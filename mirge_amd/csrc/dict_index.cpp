@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <stdexcept>
+#include <exception>
 #include <thread>
 
 namespace mrg {
@@ -69,10 +70,30 @@ uint64_t fill(const FmIndex& ix, uint32_t key_bases, uint32_t log2_slots, ExactD
         }
       }
     };
-    std::vector<std::thread> pool;
-    for (uint32_t t = 1; t < threads; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (auto& th : pool) th.join();
+    // (a worker that throws -- std::bad_alloc from late[t].push_back -- is caught where it runs and rethrown here, after
+    // every thread is joined, also when starting one fails)
+    std::vector<std::exception_ptr> failed(threads);
+    auto guarded = [&](uint32_t t) {
+      try {
+        work(t);
+      } catch (...) {
+        failed[t] = std::current_exception();
+      }
+    };
+    {
+      std::vector<std::thread> pool;
+      struct Joiner {
+        std::vector<std::thread>& p;
+        ~Joiner() {
+          for (auto& th : p)
+            if (th.joinable()) th.join();
+        }
+      } joiner{pool};
+      for (uint32_t t = 1; t < threads; ++t) pool.emplace_back(guarded, t);
+      guarded(0);
+    }
+    for (uint32_t t = 0; t < threads; ++t)
+      if (failed[t]) std::rethrow_exception(failed[t]);
     uint64_t overflow = 0;
     for (uint32_t t = 0; t < threads; ++t) {
       overflow += over[t];

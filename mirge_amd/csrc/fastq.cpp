@@ -402,8 +402,11 @@ void load_fastq(const std::string& path, int qual_cutoff, int min_len, const cha
     }
   } joiner{pool, mu, cv, eof};
 
-  // (gzip samples: inflated by `threads` workers, pgzip.cpp; plain text and threads = 1: zlib's reader)
-  GzipReader f(path, threads);
+  // (gzip samples: inflated by pgzip.cpp's workers; plain text and one thread: zlib's reader.  The inflate gets HALF the
+  // budget, at most 32: its reader thread saturates around there (scripts/pgzip_scale.sh), the trim / split pool below
+  // has the same `threads`, and 2 x threads busy workers with 2 x threads + 4 look-ahead chunks of ~21 MB each were
+  // 2.7 GB of transient buffers at 64)
+  GzipReader f(path, threads <= 1 ? threads : std::min(32, std::max(2, threads / 2)));
   // the batch being filled: the reader reads straight into its buffer; what lies behind the last record boundary
   // starts the next batch
   std::unique_ptr<Batch> cur(new Batch());

@@ -589,6 +589,44 @@ void decode_chunk(const BitSrc& src, Chunk& c, StopAt&& stop_at) {
   c.end_bit = pos;
 }
 
+// A gzip member header at a byte position of [from, to) (bit positions) whose deflate data starts with a plausible block:
+// a file of many members (bgzip / BGZF: 64 KB members of ONE final block each; `cat a.gz b.gz`) has no non-final
+// dynamic block to find, but every member is a chunk start -- and a CLEAN one: nothing in front of it can be referenced.
+// Returns the bit position of the member's first block header (what the decoder in front stops at), kNoStart = none.
+// Like every found start it only counts once the decoder of the chunk in front lands exactly on it.
+uint64_t find_member_start(const BitSrc& src, uint64_t from, uint64_t to) {
+  const size_t n = (size_t)(src.n_bits >> 3);
+  size_t p = (size_t)((from + 7) >> 3);
+  const size_t end = std::min<size_t>((size_t)(to >> 3), n > 32 ? n - 32 : 0);
+  while (p < end) {
+    const uint8_t* hit = static_cast<const uint8_t*>(std::memchr(src.data + p, 0x1f, end - p));
+    if (!hit) break;
+    p = (size_t)(hit - src.data);
+    if (src.data[p + 1] == 0x8b && src.data[p + 2] == 8 && (src.data[p + 3] & 0xE0) == 0) {
+      const size_t data0 = parse_gzip_header(src.data, n, p);
+      if (data0 && (uint64_t)data0 * 8 + 64 < src.n_bits) {
+        uint64_t pos = (uint64_t)data0 << 3;
+        const uint64_t bits = src.peek(pos);
+        const uint32_t type = (uint32_t)(bits >> 1) & 3u;
+        bool ok = false;
+        if (type == 0u) {  // stored: LEN and its complement
+          const size_t b = (size_t)((pos + 3 + 7) >> 3);
+          ok = b + 4 <= n && ((src.data[b] | (src.data[b + 1] << 8)) ^ (src.data[b + 2] | (src.data[b + 3] << 8))) == 0xFFFF;
+        } else if (type == 1u) {
+          ok = true;  // (fixed codes: nothing to check in the header; the landing rule decides)
+        } else if (type == 2u) {
+          BlockCodes bc;
+          uint64_t q = pos + 3;
+          ok = read_dynamic_header(src, q, bc, true);
+        }
+        if (ok) return pos;
+      }
+    }
+    ++p;
+  }
+  return kNoStart;
+}
+
 // The first plausible dynamic-block start in [from, to) (bit positions), kNoStart = none.
 uint64_t find_block_start(const BitSrc& src, uint64_t from, uint64_t to) {
   BlockCodes bc;
@@ -792,9 +830,17 @@ struct GzipReader::Impl {
     c.busy = true;
     lk.unlock();
     const uint64_t to = k + 1 < chunks.size() ? chunks[k + 1].nominal_bit : src.n_bits;
-    const uint64_t found = find_block_start(src, c.nominal_bit, to);
+    // a member start in range bounds the search for a block start (whichever comes first is the chunk's start)
+    const uint64_t member = find_member_start(src, c.nominal_bit, to);
+    uint64_t found = find_block_start(src, c.nominal_bit, member == kNoStart ? to : std::min(to, member));
+    bool clean = false;
+    if (found == kNoStart && member != kNoStart) {
+      found = member;
+      clean = true;
+    }
     lk.lock();
     c.busy = false;
+    c.clean_start = clean;
     c.start_bit = found;
     if (found == kNoStart) c.dropped = true;
     c.find_done = true;
@@ -911,7 +957,9 @@ struct GzipReader::Impl {
           err = e.what();
         }
         lk.lock();
-        if (err.empty()) {
+        // (a chunk that was itself swallowed meanwhile -- its start was no block start: the decoder in front ran past
+        // it -- has nothing to say about the chunks behind it: that decoder may have stopped at one of them)
+        if (err.empty() && !c.dropped) {
           for (size_t q = k + 1; q < chunks.size() && (q <= swallowed_to || c.at_eof); ++q) {
             if (!chunks[q].dropped && q <= swallowed_to) ++merged;
             chunks[q].dropped = true;

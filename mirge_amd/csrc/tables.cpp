@@ -15,6 +15,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <exception>
 #include <thread>
 #include <vector>
 
@@ -96,17 +97,42 @@ uint64_t write_read_table(const char* path, bool mapped, const char* header, boo
   std::vector<std::string> text(n_threads);
   std::vector<uint64_t> got(n_threads, 0);
   uint64_t rows = 0;
+  // (a worker that throws -- std::bad_alloc from a growing row buffer -- must not take the process down: the exception is
+  // kept, every thread is joined -- also when starting one fails --, and it is rethrown here, where the C-ABI turns it
+  // into an error code)
+  std::vector<std::exception_ptr> failed(n_threads);
+  struct Joiner {
+    std::vector<std::thread>& p;
+    ~Joiner() {
+      for (auto& th : p)
+        if (th.joinable()) th.join();
+    }
+  };
   for (uint64_t base = 0; base < n; base += (uint64_t)n_threads * kBlockRows) {
     std::vector<std::thread> pool;
-    for (unsigned t = 0; t < n_threads; ++t) {
-      const uint64_t lo = std::min(n, base + (uint64_t)t * kBlockRows), hi = std::min(n, lo + kBlockRows);
-      text[t].clear();
-      got[t] = 0;
-      if (lo >= hi) continue;
-      if (n_threads == 1) got[t] = format_rows(a, lo, hi, text[t]);
-      else pool.emplace_back([&a, &text, &got, t, lo, hi] { got[t] = format_rows(a, lo, hi, text[t]); });
+    {
+      Joiner joiner{pool};
+      for (unsigned t = 0; t < n_threads; ++t) {
+        const uint64_t lo = std::min(n, base + (uint64_t)t * kBlockRows), hi = std::min(n, lo + kBlockRows);
+        text[t].clear();
+        got[t] = 0;
+        if (lo >= hi) continue;
+        if (n_threads == 1) got[t] = format_rows(a, lo, hi, text[t]);
+        else
+          pool.emplace_back([&a, &text, &got, &failed, t, lo, hi] {
+            try {
+              got[t] = format_rows(a, lo, hi, text[t]);
+            } catch (...) {
+              failed[t] = std::current_exception();
+            }
+          });
+      }
     }
-    for (auto& th : pool) th.join();
+    for (unsigned t = 0; t < n_threads; ++t)
+      if (failed[t]) {
+        std::fclose(f);
+        std::rethrow_exception(failed[t]);
+      }
     for (unsigned t = 0; t < n_threads; ++t) {
       if (got[t] == ~0ull) {
         std::fclose(f);

@@ -78,7 +78,7 @@ def load_fastq_device(engine, path, adapter="none", qual_cutoff=QUAL_CUTOFF, min
                       read_threads=8, inflate_threads=None):
     """load_fastq with the record splitting, trimming and packing ON THE DEVICE (mrg_fastq_parse_device):
     the host reads the file into a pinned buffer (plain text: `read_threads` parallel preads; gzip: the
-    parallel inflate of mrg_gz_open with `inflate_threads` workers, default one per core), cuts it at record boundaries (mrg_fastq_block_cut) and uploads text blocks.  `-ad none`,
+    parallel inflate of mrg_gz_open with `inflate_threads` workers, default half the cores, at most 32: its reader saturates there), cuts it at record boundaries (mrg_fastq_block_cut) and uploads text blocks.  `-ad none`,
     `-ad +N` and adapter sequences (`-ad illumina`: cutadapt's 3' search, one thread per read).  Returns dict(words int64 [W, n], lens uint8 [n], nmask int64 [W, n] | None -- DEVICE
     tensors, reads in file order --, total, kept, packed, phred, max_len, long_reads=[])."""
     from concurrent.futures import ThreadPoolExecutor
@@ -110,7 +110,7 @@ def load_fastq_device(engine, path, adapter="none", qual_cutoff=QUAL_CUTOFF, min
     # gzip samples: the parallel inflate of the C-ABI (mrg_gz_open, csrc/pgzip.cpp) writes straight into the pinned buffer
     gz = C.c_void_p()
     if is_gz:
-        check(lib.mrg_gz_open(path.encode(), max(1, int(inflate_threads or (os.cpu_count() or 1))), C.byref(gz)))
+        check(lib.mrg_gz_open(path.encode(), max(1, int(inflate_threads or min(32, max(2, (os.cpu_count() or 2) // 2)))), C.byref(gz)))
     fh = None if is_gz else open(path, "rb", buffering=0)
     pool = None if is_gz else ThreadPoolExecutor(max_workers=max(1, int(read_threads)))
     state = dict(offset=0, eof=False)

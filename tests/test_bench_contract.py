@@ -55,6 +55,7 @@ def test_headline_line_has_the_contract_keys():
     assert "by definition" in d["parity"]["index_check"]
     assert "bowtie" in d["parity"]
     assert "identical" in d["e2e"]["parity"] and d["e2e"]["value"] > 0 and d["e2e"]["h2d_ms"] > 0
+    assert d["value_e2e"] == d["e2e"]["value"] < d["value"]   # SURVEY 8d's PCIe-inclusive region, at the top of the line
     assert "identical" in d["collapsed"]["parity"] and d["collapsed"]["unique_reads"] < d["collapsed"]["raw_reads"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "identical" in c["parity"]

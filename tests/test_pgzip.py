@@ -23,7 +23,7 @@ def fastq_text(rng, n, qual_hi=74):
     return b"".join(out)
 
 
-def inflate(lib, path, threads, want_parallel=None):
+def inflate(lib, path, threads, want_parallel=None, info=None):
     from mirge_amd._native import check
     h = C.c_void_p()
     check(lib.mrg_gz_open(path.encode(), threads, C.byref(h)))
@@ -43,6 +43,9 @@ def inflate(lib, path, threads, want_parallel=None):
             if not got.value:
                 break
             out.append(buf.raw[:got.value])
+        if info is not None:   # chunk starts that turned out not to be any (dropped, their chunk merged into the one in front)
+            check(lib.mrg_gz_info(h, C.byref(par), C.byref(merged)))
+            info["merged"] = int(merged.value)
         return b"".join(out)
     finally:
         lib.mrg_gz_close(h)
@@ -82,7 +85,26 @@ def test_concatenated_members_and_stored_blocks(native_lib, tmp_path, text, smal
     with open(p2, "wb") as fh:
         for o in range(0, len(text), 60000):
             fh.write(gzip.compress(text[o:o + 60000], 5))
-    assert inflate(native_lib, p2, 4, want_parallel=1) == text
+    info = {}
+    assert inflate(native_lib, p2, 4, want_parallel=1, info=info) == text
+    # every member is ONE final block: there is no non-final dynamic block to find in such a file, the members themselves
+    # are the chunk starts (round 4 dropped every chunk and inflated the whole file behind chunk 0: 5 x slower than
+    # zlib, the sample held in memory three times over)
+    n_chunks = os.path.getsize(p2) // 65536
+    assert n_chunks > 15 and info["merged"] <= 2, info
+    # real BGZF members: the extra field "BC" + block size, an empty EOF member at the end
+    p3 = str(tmp_path / "bgzf.fastq.gz")
+    with open(p3, "wb") as fh:
+        for o in list(range(0, len(text), 0xff00)) + [len(text)]:
+            raw = text[o:o + 0xff00]
+            z = zlib.compressobj(6, zlib.DEFLATED, -15)
+            body = z.compress(raw) + z.flush()
+            bsize = 18 + len(body) + 8 - 1
+            fh.write(b"\x1f\x8b\x08\x04" + b"\0" * 4 + b"\x00\xff" + b"\x06\x00" + b"BC\x02\x00" + bsize.to_bytes(2, "little") + body +
+                     (zlib.crc32(raw) & 0xffffffff).to_bytes(4, "little") + len(raw).to_bytes(4, "little"))
+    assert gzip.decompress(open(p3, "rb").read()) == text
+    info = {}
+    assert inflate(native_lib, p3, 6, want_parallel=1, info=info) == text and info["merged"] <= 2, info
 
 
 def test_plain_and_tiny_files_take_zlib(native_lib, tmp_path, text, small_chunks):
