@@ -156,6 +156,10 @@ __global__ void __launch_bounds__(kLongThreads) long_read_kernel(const LongParam
           for (uint32_t i = lo + lane; i < hi; i += 64u) {
             const uint64_t row = ps.sa[i];
             const uint32_t s0 = (uint32_t)row;
+            // the row's own distances to the ends of its segment (they saturate at 255) reject most rows -- and the
+            // rows of the suffixes that are only the sentinel or run into it, which belong to no segment at all
+            const uint32_t r_before = (uint32_t)(row >> 32) & 255u, r_after = (uint32_t)(row >> 40) & 255u;
+            if ((r_after < 255u && need_after > r_after) || (r_before < 255u && need_before > r_before)) continue;
             uint32_t sg = (uint32_t)(row >> 48);
             if (sg == 0xFFFFu) {  // more than 65535 segments: walk the chunk map
               sg = ps.chunk_seg[s0 >> 5];

@@ -163,7 +163,8 @@ def test_long_lane_edge_cases(native_lib, oracle_lib):
     mut[70_000] = "A" if mut[70_000] != "A" else "C"
     mut[99_000] = "A" if mut[99_000] != "A" else "C"
     reads = [seqs[0], big, big[5:100_005], "".join(mut), big + "A", seqs[2][400:600], seqs[2][:500], "T" * 400, "A", "",
-             "AC", seqs[3][3:303], big[1000:1300] + "TTTT", "G" + seqs[0] + "CA"]
+             "AC", seqs[3][3:303], big[1000:1300] + "TTTT", "G" + seqs[0] + "CA",
+             "A" * 300, "A" * 28, "C" * 300]   # (a poly-A seed's interval starts at the sentinel's row, which lies in no segment)
     got = eng.cascade_long(reads, passes)
     want = ocas.scan_cascade(olibs, rows, reads)
     for a, b in zip(got[:4], want[:4]):
