@@ -43,7 +43,7 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 HBM_ACHIEVABLE_GBS = 6300.0  # what a streaming kernel reaches (same guide); used for the floors only
 
-DEFAULT_READS = {"cascade": 100_000_000, "exact": 10_000_000, "varlen": 20_000_000, "a2i": 50_000_000}
+DEFAULT_READS = {"cascade": 100_000_000, "exact": 10_000_000, "varlen": 20_000_000, "a2i": 50_000_000, "repeats": 20_000_000}
 
 
 def log(rank, *a):
@@ -152,10 +152,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["cascade", "exact", "varlen", "a2i"], default="cascade",
+    ap.add_argument("--workload", choices=["cascade", "exact", "varlen", "a2i", "repeats"], default="cascade",
                     help="cascade = headline (100 M x 22 nt, configs[2]/[3]); exact = configs[1]; varlen = secondary "
                          "run with lengths U{16..40}; a2i = configs[4] (mouse-seeded libraries, 50 M reads with "
-                         "A->G edits, cascade + tally + A-to-I position tally)")
+                         "A->G edits, cascade + tally + A-to-I position tally); repeats = the headline's read mixture and "
+                         "cascade on UNFRIENDLY libraries (poly-A/T tails, tandem repeats, paralog families, an element whose "
+                         "core occurs ~10^5 times: synth.decorate_repeats) -- what the hash chains, seed buckets and the FM "
+                         "fallback cost when the libraries are not i.i.d.-uniform")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--reads", type=int, default=None, help="reads of the whole job (strong) / per GPU (weak)")
     ap.add_argument("--reads-per-gpu", type=int, default=None, help="= --scaling weak --reads R")
@@ -223,7 +226,7 @@ def main():
     if wl == "a2i":
         libs = synth.SynthLibraries(seed=synth.MOUSE_SEED, scale=args.scale, shapes=synth.MOUSE_SHAPES)
     else:
-        libs = synth.SynthLibraries(seed=20181, scale=args.scale)
+        libs = synth.SynthLibraries(seed=20181, scale=args.scale, repeats=(wl == "repeats"))
     pool = ThreadPoolExecutor(max_workers=len(keys))
     futures = {k: pool.submit(FmIndex.build, *libs.libs[k]) for k in keys}
 
@@ -652,6 +655,9 @@ def main():
         "exact": "%d M x 22 nt unique reads, exact match vs miRNA library (BASELINE configs[1])" % (n_total // 1_000_000),
         "varlen": "SECONDARY (not the headline): reads of 16..40 nt, two words per read, full 9-pass cascade incl. "
                   "the hairpin pass (SURVEY.md 8d)",
+        "repeats": "SECONDARY (not the headline): %d M x 22 nt reads of the headline's mixture, full 9-pass cascade + tally over "
+                   "libraries with poly-A/T tails, tandem repeats, paralog families and a 10^5-copy element (synth.decorate_repeats)"
+                   % (n_total // 1_000_000),
         "a2i": "%d M x 22 nt reads with seeded A->G edits, mouse-seeded libraries, 9-pass cascade (1-mismatch seed "
                "search) + count tally + A-to-I position tally (BASELINE configs[4])" % (n_total // 1_000_000)}[wl]
     line = {
@@ -686,6 +692,8 @@ def main():
             note="the batch was split on the device: reads of 20..32 nt without N ran the cascade through the dictionary kernels "
                  "(passes[].ms, kernel, roofline), the rest through the FM kernels first (passes[].ms_rest); counters are the sums"),
     }
+    if wl == "repeats":
+        line["repeats"] = repeats_report(libs, index, eng, st, n_reads)
     line.update(extras)
     # SURVEY.md 8d's throughput region (H2D of the packed reads + counts -> cascade -> tally -> D2H) beside the resident
     # `value`: the task contract keeps the PCIe-inclusive rate out of `value`, the reader should still see it first
@@ -912,6 +920,36 @@ def run_e2e(eng, passes, words, lens, quant, M, n_pass, canon, iso, expect, log,
                         ("compact wire form (mrg_expand_compact: reads in length groups as a bit stream of 2 L bits each, one-byte counts + %d escapes), "
                          "%.2f B per read up" % (esc_total, h2d_bytes / max(n, 1))) if compact else "13 B per read up"),
                 wire="compact" if compact else "arrays")
+
+
+def repeats_report(libs, index, eng, st, n_reads):
+    """What the unfriendly libraries did to the structures the dictionary kernels answer from: positions an exact-match
+    dictionary left to the FM index because their home slot's chain overflowed (reads whose key is one of those take
+    fm_exact_fallback: a jump-table interval verified row by row), 11-mers whose seed bucket overflowed (more than 8
+    rows: the wave kernel then asks the jump table), the widest 11-mer interval, and per pass the candidates (slots /
+    rows compared) per lookup -- 1-3 on i.i.d. libraries."""
+    out = dict(decorations=libs.repeat_stats, libraries={}, passes=[])
+    for k in index:
+        d = {}
+        try:
+            nk, nov = eng.library_dict_stats(k)
+            if nk or nov:
+                d.update(dict_positions=nk, dict_positions_overflowed=nov, dict_overflow_frac=round(nov / max(nk + nov, 1), 6))
+        except Exception as e:   # (not fatal for a report)
+            d["dict_stats_error"] = repr(e)
+        v = index[k].view()
+        ks = v["ftab_ks"]
+        if 11 in ks:
+            # the jump tables lie back to back, largest k first, 4^k + 1 words each
+            base = sum((4 ** kk + 1) for kk in ks[:ks.index(11)] if kk)
+            tab = np.asarray(v["ftab"][base:base + 4 ** 11 + 1]).astype(np.int64)
+            w = np.diff(tab)
+            d.update(kmers11_present=int((w > 0).sum()), kmers11_bucket_overflow=int((w > 8).sum()), widest_11mer_rows=int(w.max()))
+        out["libraries"][k] = d
+    for i, s in enumerate(st):
+        out["passes"].append(dict(i=i, lookups=int(s["lookups"]), candidates=int(s["candidates"]),
+                                  candidates_per_lookup=round(s["candidates"] / max(s["lookups"], 1), 2)))
+    return out
 
 
 def run_collapsed(eng, passes, rs, out, M, n_pass, canon, iso, log, reps=3):

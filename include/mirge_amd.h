@@ -211,6 +211,11 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);
 int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,
                         char *arch, uint32_t arch_cap);
+/* What a resident library's derived structures hold (round 5; the bench line of an unfriendly library set reports them):
+ * out4 = { text positions stored in its exact-match dictionary, positions left to the FM index because their home
+ * slot's chain overflowed (a read whose key is one of those is answered by the slow FM fallback), log2 of the
+ * dictionary's slots (0: no dictionary), k of its seed buckets (0: none) }. */
+int mrg_ctx_library_stats(const mrg_ctx *ctx, int32_t lib, uint64_t *out4);
 /* A context is used by one host thread at a time (calls on it are serialised by the caller).  It keeps
  * one device scratch arena, grown on demand by mrg_collapse_run (40 B per raw read + 64 MB) and
  * mrg_list_best_count and reused by later calls; this frees it (after synchronising the device), e.g.
@@ -508,6 +513,15 @@ typedef struct mrg_fastq_info {
  * hardware thread, at most 32.  One thread inflates and splits records, the workers trim. */
 int mrg_fastq_load(const char *path, int32_t qual_cutoff, int32_t min_len, const char *adapter,
                    int32_t threads, mrg_fastq **out);
+/* One sample read by SEVERAL readers (round 5: `--gpus N` on a single FASTQ file; the reference ingests a sample in one
+ * process, __main__.py:289-314): reader `part` of `n_parts`.  A plain file is cut into n_parts byte ranges at record
+ * starts (a line that starts with '@' whose line after next starts with '+': every reader finds the same cuts) and
+ * each reader reads its own; a gzip file cannot be entered in the middle: every reader inflates all of it and takes
+ * every n_parts-th block of records (trimming, adapter search and packing are shared out, the inflate is not).  The
+ * handle's n_total / n_kept / long reads are those of the share (their sums over the parts are the file's); the
+ * quality base is the one the FILE's first record decides, whatever the part; info.phred is 0 unless part == 0. */
+int mrg_fastq_load_part(const char *path, int32_t qual_cutoff, int32_t min_len, const char *adapter,
+                        int32_t threads, int32_t part, int32_t n_parts, mrg_fastq **out);
 /* cutadapt's 3' adapter search on one upper-case read (the AdapterCutter step above, exposed
  * for callers that trim outside a FASTQ file and for the tests): out6 = found, read_start
  * (where the read is cut), read_stop, adapter_stop, matches, errors. */

@@ -89,6 +89,7 @@ SIGNATURES = {
     "mrg_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "mrg_ctx_device_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
                                       C.c_char_p, C.c_uint32]),
+    "mrg_ctx_library_stats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
     "mrg_ctx_release_scratch": (C.c_int, [C.c_void_p]),
     "mrg_cascade_workspace_bytes": (C.c_int, [C.c_uint64, C.POINTER(C.c_uint64)]),
     "mrg_cascade_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
@@ -142,6 +143,8 @@ SIGNATURES = {
                                          C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PassStats)]),
     "mrg_fastq_load": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32,
                                  C.POINTER(C.c_void_p)]),
+    "mrg_fastq_load_part": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32, C.c_int32, C.c_int32,
+                                      C.POINTER(C.c_void_p)]),
     "mrg_adapter_locate": (C.c_int, [C.c_char_p, C.c_char_p, C.c_double, C.c_int32, C.POINTER(C.c_int32)]),
     "mrg_fastq_get_info": (C.c_int, [C.c_void_p, C.POINTER(FastqInfo)]),
     "mrg_fastq_long_read": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_char_p)]),

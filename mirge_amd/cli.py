@@ -240,22 +240,27 @@ def annotate_main(args, engine_factory=None, materialize=False):
     t0 = time.time()
     # ---- ingest (trim_file, MAIN:346-369): every rank its own files (file i -> rank i mod world) ----
     from concurrent.futures import ThreadPoolExecutor
-    mine = [i for i in range(len(raw)) if i % world == rank]
+    # (fewer files than ranks -- `--gpus 8` on ONE sample is the common case, MAIN:289-314 --: a file is read by several
+    # ranks, each its own part of it: mrg_fastq_load_part)
+    shares = mdist.file_shares(len(raw), world)          # per rank: [(file, part, n_parts)]
+    mine = shares[rank]
     n_cpu = max(1, int(args.cpu))
     n_jobs = max(1, min(len(mine), n_cpu))
 
     device_ingest = bool(getattr(args, "device_ingest", False)) and hasattr(engine, "_lib")
 
-    def load_one(i):
+    def load_one(share):
+        i, part, n_parts = share
         t1 = time.time()
         fq = None
-        if device_ingest:
+        if device_ingest and n_parts == 1:
             try:
                 fq = ingest.load_fastq_device(engine, os.path.abspath(raw[i]), adapter=args.adapter)
             except ingest.DeviceIngestUnsupported:
                 fq = None   # the host parser takes it (and words whatever is wrong with the file)
         if fq is None:
-            fq = ingest.load_fastq(os.path.abspath(raw[i]), adapter=args.adapter, threads=max(1, n_cpu // n_jobs))
+            fq = ingest.load_fastq(os.path.abspath(raw[i]), adapter=args.adapter, threads=max(1, n_cpu // n_jobs), part=part,
+                                   n_parts=n_parts)
         return fq, time.time() - t1
 
     if rank == 0:
@@ -263,12 +268,12 @@ def annotate_main(args, engine_factory=None, materialize=False):
             print("Performing quantitation analysis of %s..." % name)
     loaded = []
     if mine and device_ingest:
-        loaded = [load_one(i) for i in mine]   # (one file at a time: each already fills the PCIe link)
+        loaded = [load_one(sh) for sh in mine]   # (one file at a time: each already fills the PCIe link)
     elif mine:
         with ThreadPoolExecutor(max_workers=n_jobs) as pool:
             loaded = list(pool.map(load_one, mine))
     quant_stats, long_counts = {}, {}
-    for i, (fq, dt) in zip(mine, loaded):
+    for (i, _part, _n_parts), (fq, dt) in zip(mine, loaded):
         quant_stats[i] = {"filename": sample_list[i], "totalReads": fq["total"], "trimmedReads": fq["kept"],
                           "cpuTime-trim": dt, "cpuTime-uniq": 0.0}
         for r in fq["long_reads"]:   # beyond the one-byte length of the packed batch: collapsed here, annotated by cascade_long
@@ -284,7 +289,7 @@ def annotate_main(args, engine_factory=None, materialize=False):
     d_nmask = torch.zeros((W, n_raw), dtype=torch.int64, device=dev) if any_n else None
     d_sample = torch.empty(n_raw, dtype=torch.int16, device=dev)
     at = 0
-    for i, (fq, _) in zip(mine, loaded):
+    for (i, _part, _n_parts), (fq, _) in zip(mine, loaded):
         m = fq["packed"]
 
         def on_dev(a, dt):   # a file's arrays: numpy from the host parser, device tensors from the device parser
@@ -324,7 +329,13 @@ def annotate_main(args, engine_factory=None, materialize=False):
         if rank == 0:
             quant_stats, long_counts = {}, {}
             for qs, lc in boxes:
-                quant_stats.update(qs)
+                for i, q in qs.items():   # (the parts of a file several ranks read add up)
+                    if i in quant_stats:
+                        quant_stats[i]["totalReads"] += q["totalReads"]
+                        quant_stats[i]["trimmedReads"] += q["trimmedReads"]
+                        quant_stats[i]["cpuTime-trim"] = max(quant_stats[i]["cpuTime-trim"], q["cpuTime-trim"])
+                    else:
+                        quant_stats[i] = q
                 for seq, q in lc.items():
                     row = long_counts.setdefault(seq, [0] * S)
                     for i in range(S):

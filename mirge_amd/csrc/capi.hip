@@ -98,6 +98,7 @@ struct DevLib {
   // exact-match dictionary (dict_index.hpp) of a library of at most dict_max_bases bases
   mrg::DictSlot* dict_slots = nullptr;
   uint32_t dict_log2 = 0, dict_key = 0;
+  uint64_t dict_n_keys = 0, dict_n_overflow = 0;  // positions stored / left to the FM index (their home's chain overflowed)
   uint32_t* kbits = nullptr;
   std::vector<uint32_t> kbits_host;  // host copy (32 KB): the per-round interleaved tables are built from it
   std::vector<std::string> host_seqs;  // entries of a library of at most kDictSmallBases bases (for seed units over several libraries)
@@ -565,6 +566,8 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
       if ((rc = upload(&l.dict_slots, ed->slots))) return rc;
       l.dict_log2 = ed->log2_slots;
       l.dict_key = ed->key_bases;
+      l.dict_n_keys = ed->n_keys;
+      l.dict_n_overflow = ed->n_overflow;
       if (ix.n > mrg::kDictSmallBases) h->drop_dict((uint32_t)ctx->dict_key);
     }
   }
@@ -691,6 +694,17 @@ int mrg_ctx_device_info(const mrg_ctx* ctx, int32_t* n_cu, uint64_t* hbm_bytes, 
   if (arch && arch_cap) {
     std::snprintf(arch, arch_cap, "%s", ctx->arch.c_str());
   }
+  return MRG_OK;
+}
+
+int mrg_ctx_library_stats(const mrg_ctx* ctx, int32_t lib, uint64_t* out4) {
+  if (!ctx || !out4) return fail(MRG_ERR_ARG, "mrg_ctx_library_stats: null argument");
+  if (lib < 0 || (size_t)lib >= ctx->libs.size()) return fail(MRG_ERR_ARG, "mrg_ctx_library_stats: unknown library %d", lib);
+  const DevLib& l = ctx->libs[lib];
+  out4[0] = l.dict_n_keys;
+  out4[1] = l.dict_n_overflow;
+  out4[2] = l.dict_slots ? l.dict_log2 : 0;
+  out4[3] = l.buckets ? l.bucket_k : 0;
   return MRG_OK;
 }
 
@@ -2418,6 +2432,22 @@ int mrg_fastq_load(const char* path, int32_t qual_cutoff, int32_t min_len, const
     return fail(MRG_ERR_NOMEM, "mrg_fastq_load: out of memory");
   } catch (const std::exception& e) {
     return fail(MRG_ERR_IO, "mrg_fastq_load: %s", e.what());
+  }
+}
+
+int mrg_fastq_load_part(const char* path, int32_t qual_cutoff, int32_t min_len, const char* adapter, int32_t threads, int32_t part,
+                        int32_t n_parts, mrg_fastq** out) {
+  if (!path || !out) return fail(MRG_ERR_ARG, "mrg_fastq_load_part: null argument");
+  if (n_parts < 1 || part < 0 || part >= n_parts) return fail(MRG_ERR_ARG, "mrg_fastq_load_part: part %d of %d", part, n_parts);
+  try {
+    auto h = std::make_unique<mrg_fastq>();
+    mrg::load_fastq(path, qual_cutoff, min_len, adapter, threads, h->d, part, n_parts);
+    *out = h.release();
+    return MRG_OK;
+  } catch (const std::bad_alloc&) {
+    return fail(MRG_ERR_NOMEM, "mrg_fastq_load_part: out of memory");
+  } catch (const std::exception& e) {
+    return fail(MRG_ERR_IO, "mrg_fastq_load_part: %s", e.what());
   }
 }
 

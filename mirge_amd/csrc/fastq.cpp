@@ -26,6 +26,9 @@
 #include <deque>
 #include <memory>
 #include <mutex>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <thread>
 #include <cstdlib>
 #include <cstring>
@@ -352,12 +355,101 @@ size_t fastq_block_cut(const char* buf, size_t len, bool at_eof) {
 // records, trim them) -> parallel 2-bit packing.  The per-record work is in the workers: the
 // reader only finds the last record header of each ~4 MB block.
 // The reference does the same with cutadapt worker processes (trim_file.py:24-66, `-cpu`).
+namespace {
+
+// the base the quality characters of a file are read with: its FIRST record decides (trim_file.py:104-110: the trimming
+// workers are created while the first record is being read)
+int sniff_base(const char* p, size_t len) {
+  size_t pos = 0, lines = 0, qs = 0, qe = 0;
+  while (pos < len && lines < 4) {
+    const char* nl = (const char*)std::memchr(p + pos, '\n', len - pos);
+    const size_t e = nl ? (size_t)(nl - p) : len;
+    if (lines == 0 && e == pos) {  // blank lines before the first record
+      pos = e + 1;
+      continue;
+    }
+    if (lines == 3) {
+      qs = pos;
+      qe = e;
+    }
+    ++lines;
+    pos = e + 1;
+  }
+  bool hi = false;
+  for (size_t i = qs; i < qe; ++i) hi |= (unsigned char)p[i] > 74;
+  return hi ? 64 : 33;
+}
+
+// A plain FASTQ file cut for `n_parts` readers: the first record start at or behind byte `from` -- a line that starts
+// with '@' whose line after next starts with '+' (a quality line may start with '@' too: two lines on it has a
+// sequence, never a '+') -- or `size` when there is none.  Every reader finds the same cuts.
+uint64_t record_start_at_or_after(int fd, uint64_t from, uint64_t size) {
+  if (from == 0) return 0;
+  if (from >= size) return size;
+  std::vector<char> buf;
+  for (size_t window = 1u << 20;; window *= 4) {
+    const size_t want = (size_t)std::min<uint64_t>(window, size - from);
+    buf.resize(want);
+    size_t got = 0;
+    while (got < want) {
+      const ssize_t r = pread(fd, buf.data() + got, want - got, (off_t)(from + got));
+      if (r <= 0) break;
+      got += (size_t)r;
+    }
+    // line starts behind the first newline (the line `from` falls into belongs to the reader in front)
+    std::vector<size_t> starts;
+    for (size_t i = 0; i < got; ++i)
+      if (buf[i] == '\n' && i + 1 < got) starts.push_back(i + 1);
+    for (size_t i = 0; i + 2 < starts.size(); ++i)
+      if (buf[starts[i]] == '@' && buf[starts[i + 2]] == '+') return from + starts[i];
+    if (from + got >= size) return size;
+    if (window > (1u << 28)) throw std::runtime_error("no FASTQ record boundary within 256 MB");
+  }
+}
+
+}  // namespace
+
 void load_fastq(const std::string& path, int qual_cutoff, int min_len, const char* adapter, int threads,
-                FastqData& out) {
+                FastqData& out, int part, int n_parts) {
   out = FastqData();
   const TrimSpec spec = parse_trim_spec(adapter);
   if (threads <= 0) threads = (int)std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
   constexpr size_t kBlockBytes = 4u << 20;
+  if (n_parts < 1 || part < 0 || part >= n_parts) throw std::runtime_error("load_fastq: part out of range");
+  // One file read by several readers (`--gpus N` on a single sample): a PLAIN file is cut into n_parts byte ranges at
+  // record starts, every reader takes its own; a GZIP file cannot be entered in the middle, so every reader inflates
+  // all of it and takes every n_parts-th block of records (the trimming, the adapter search and the packing -- what
+  // the worker threads do -- are shared out, the inflate is not).
+  bool plain_range = false;
+  int range_fd = -1;
+  uint64_t range_pos = 0, range_end = 0;
+  int forced_base = 0;
+  struct FdCloser {
+    int& fd;
+    ~FdCloser() {
+      if (fd >= 0) close(fd);
+    }
+  } fd_closer{range_fd};
+  if (n_parts > 1) {
+    range_fd = open(path.c_str(), O_RDONLY);
+    if (range_fd < 0) throw std::runtime_error("cannot open " + path);
+    unsigned char magic[2] = {0, 0};
+    const ssize_t mg = pread(range_fd, magic, 2, 0);
+    if (!(mg == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
+      struct stat st;
+      if (fstat(range_fd, &st) != 0) throw std::runtime_error("cannot stat " + path);
+      const uint64_t size = (uint64_t)st.st_size;
+      range_pos = record_start_at_or_after(range_fd, size / (uint64_t)n_parts * (uint64_t)part, size);
+      range_end = part + 1 == n_parts ? size : record_start_at_or_after(range_fd, size / (uint64_t)n_parts * (uint64_t)(part + 1), size);
+      plain_range = true;
+      if (part > 0) {  // (the file's first record decides the quality base for every part)
+        std::vector<char> head((size_t)std::min<uint64_t>(size, 1u << 16));
+        const ssize_t r = pread(range_fd, head.data(), head.size(), 0);
+        forced_base = sniff_base(head.data(), r > 0 ? (size_t)r : 0);
+      }
+    }
+  }
+  uint64_t block_no = 0;  // blocks of records handed out so far (gzip parts: block k belongs to part k % n_parts)
 
   std::deque<std::unique_ptr<Batch>> batches;  // in file order; stable addresses
   std::mutex mu;
@@ -366,6 +458,7 @@ void load_fastq(const std::string& path, int qual_cutoff, int min_len, const cha
   bool eof = false;
   int base = 33;
   bool any64 = false;  // written by the worker of block 0 only
+  const bool file_head = part == 0;  // this reader's first block is the file's first block (the 1000-record sniff looks there)
   auto worker = [&]() {
     for (;;) {
       Batch* job = nullptr;
@@ -374,7 +467,7 @@ void load_fastq(const std::string& path, int qual_cutoff, int min_len, const cha
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return next_job < batches.size() || eof; });
         if (next_job >= batches.size()) return;
-        first_block = next_job == 0;
+        first_block = next_job == 0 && file_head;
         job = batches[next_job++].get();
       }
       try {
@@ -406,7 +499,21 @@ void load_fastq(const std::string& path, int qual_cutoff, int min_len, const cha
   // budget, at most 32: its reader thread saturates around there (scripts/pgzip_scale.sh), the trim / split pool below
   // has the same `threads`, and 2 x threads busy workers with 2 x threads + 4 look-ahead chunks of ~21 MB each were
   // 2.7 GB of transient buffers at 64)
-  GzipReader f(path, threads <= 1 ? threads : std::min(32, std::max(2, threads / 2)));
+  std::unique_ptr<GzipReader> gz;
+  if (!plain_range) gz.reset(new GzipReader(path, threads <= 1 ? threads : std::min(32, std::max(2, threads / 2))));
+  auto src_read = [&](char* dst, size_t n) -> size_t {
+    if (!plain_range) return gz->read(dst, n);
+    size_t got = 0;
+    n = (size_t)std::min<uint64_t>(n, range_end - range_pos);
+    while (got < n) {
+      const ssize_t r = pread(range_fd, dst + got, n - got, (off_t)(range_pos + got));
+      if (r < 0) throw std::runtime_error("read error on " + path);
+      if (r == 0) break;
+      got += (size_t)r;
+    }
+    range_pos += got;
+    return got;
+  };
   // the batch being filled: the reader reads straight into its buffer; what lies behind the last record boundary
   // starts the next batch
   std::unique_ptr<Batch> cur(new Batch());
@@ -426,29 +533,13 @@ void load_fastq(const std::string& path, int qual_cutoff, int min_len, const cha
       // trim_file.py:104-106 sniffs the first 1000 records for a quality character > 'J' (74); the
       // trimming workers are created while the first record is being read (:107-110), so only
       // that record decides the base they trim with
-      const char* p = bt->raw.data();
-      const size_t len = bt->raw.size();
-      size_t pos = 0, lines = 0, qs = 0, qe = 0;
-      while (pos < len && lines < 4) {
-        const char* nl = (const char*)std::memchr(p + pos, '\n', len - pos);
-        const size_t e = nl ? (size_t)(nl - p) : len;
-        if (lines == 0 && e == pos) {  // blank lines before the first record
-          pos = e + 1;
-          continue;
-        }
-        if (lines == 3) {
-          qs = pos;
-          qe = e;
-        }
-        ++lines;
-        pos = e + 1;
-      }
-      bool hi = false;
-      for (size_t i = qs; i < qe; ++i) hi |= (unsigned char)p[i] > 74;
-      base = hi ? 64 : 33;
+      base = forced_base ? forced_base : sniff_base(bt->raw.data(), bt->raw.size());
       for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
       started = true;
     }
+    const bool mine = plain_range || n_parts == 1 || (block_no % (uint64_t)n_parts) == (uint64_t)part;
+    ++block_no;
+    if (!mine) return;  // (a gzip file's block of another part: inflated here too, trimmed and packed there)
     {
       std::lock_guard<std::mutex> lk(mu);
       batches.push_back(std::move(bt));
@@ -458,7 +549,7 @@ void load_fastq(const std::string& path, int qual_cutoff, int min_len, const cha
   auto read_more = [&](size_t until) {  // fill the current batch up to `until` bytes (or the end of the file)
     while (!at_eof && have < until) {
       if (cur->raw.cap < until) cur->raw.reserve(until + (1u << 20), have);
-      const size_t got = f.read(cur->raw.data() + have, std::min<size_t>(cur->raw.cap - have, 1u << 30));
+      const size_t got = src_read(cur->raw.data() + have, std::min<size_t>(cur->raw.cap - have, 1u << 30));
       if (got == 0) at_eof = true;
       have += got;
     }
@@ -512,7 +603,7 @@ void load_fastq(const std::string& path, int qual_cutoff, int min_len, const cha
     out.n_total += bt.n_records;
   }
 
-  out.phred = any64 ? 64 : 33;
+  out.phred = file_head ? (any64 ? 64 : 33) : 0;  // (0: this part does not hold the records the sniff reports on)
   std::vector<uint64_t> first(batches.size() + 1, 0);
   for (size_t b = 0; b < batches.size(); ++b) {
     if (!batches[b]->error.empty()) throw std::runtime_error(path + ": " + batches[b]->error);

@@ -45,7 +45,9 @@ size_t apply_trim_spec(const TrimSpec& spec, std::string& read);  // returns the
 size_t fastq_block_cut(const char* buf, size_t len, bool at_eof);
 
 // threads <= 0: one per hardware thread, at most 32
+// part / n_parts: this reader's share of a file several readers ingest (a byte range of a plain file, every n_parts-th
+// block of records of a gzip file); n_total / n_kept then count this share, phred is 0 unless part == 0
 void load_fastq(const std::string& path, int qual_cutoff, int min_len, const char* adapter, int threads,
-                FastqData& out);
+                FastqData& out, int part = 0, int n_parts = 1);
 
 }  // namespace mrg

@@ -232,3 +232,20 @@ def allreduce_max(values):
     t = torch.tensor(list(values), dtype=torch.int64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return [int(x) for x in t.cpu()]
+
+
+def file_shares(n_files, world):
+    """Who ingests what: per rank a list of (file, part, n_parts).  At least as many files as ranks: file i goes to
+    rank i mod world, whole.  Fewer files than ranks (`--gpus 8` on one sample): every file is read by
+    world // n_files ranks, each its own part of it (mrg_fastq_load_part); the ranks left over ingest nothing (they
+    still receive their share of the sequences in the exchange)."""
+    shares = [[] for _ in range(world)]
+    if n_files >= world:
+        for i in range(n_files):
+            shares[i % world].append((i, 0, 1))
+        return shares
+    per = max(1, world // max(n_files, 1))
+    for i in range(n_files):
+        for part in range(per):
+            shares[i * per + part].append((i, part, per))
+    return shares

@@ -169,6 +169,13 @@ class Engine:
         self.indexes[key] = index
         return lid.value
 
+    def library_dict_stats(self, key):
+        """(positions stored in the library's exact-match dictionary, positions left to the FM index because their
+        home slot's chain overflowed) -- mrg_ctx_library_stats."""
+        out = (C.c_uint64 * 4)()
+        check(self._lib.mrg_ctx_library_stats(self._h, self.libs[key], out))
+        return int(out[0]), int(out[1])
+
     # ------------------------------------------------------------------
     def mirge_passes(self, spike_in=False):
         """PassCfg array for the reference's cascade (runAnnotationPipeline.py:574-599)."""

@@ -40,14 +40,20 @@ def adapter_locate(adapter, read, max_error_rate=0.12, min_overlap=3):
 
 
 def load_fastq(path, words_per_read=None, qual_cutoff=QUAL_CUTOFF, min_len=MIN_LENGTH, adapter="none",
-               threads=0):
+               threads=0, part=0, n_parts=1):
     """Returns dict(words [W, n], lens, nmask|None, total, kept, packed, phred, max_len, long_reads):
     `kept` = reads that survive trimming (the reference's trimmedReads), `packed` = n of them in the
-    arrays, `long_reads` = the kept reads beyond 255 nt (ASCII; too long for eight packed words and a length byte)."""
+    arrays, `long_reads` = the kept reads beyond 255 nt (ASCII; too long for eight packed words and a length byte).
+    part / n_parts: this reader's share of a file several processes ingest (mrg_fastq_load_part: a byte range of a
+    plain file, every n_parts-th block of a gzip file); the counts are then those of the share."""
     lib = _native.load()
     h = C.c_void_p()
-    check(lib.mrg_fastq_load(os.fsencode(path), qual_cutoff, min_len, resolve_adapter(adapter).encode(),
-                             int(threads), C.byref(h)))
+    if n_parts > 1:
+        check(lib.mrg_fastq_load_part(os.fsencode(path), qual_cutoff, min_len, resolve_adapter(adapter).encode(),
+                                      int(threads), int(part), int(n_parts), C.byref(h)))
+    else:
+        check(lib.mrg_fastq_load(os.fsencode(path), qual_cutoff, min_len, resolve_adapter(adapter).encode(),
+                                 int(threads), C.byref(h)))
     try:
         info = _native.FastqInfo()
         check(lib.mrg_fastq_get_info(h, C.byref(info)))

@@ -47,10 +47,83 @@ def codes_to_str(codes):
     return _LETTERS[codes].tobytes().decode("ascii")
 
 
+# what `repeats=True` does to a library: fractions of its entries (an entry may get several treatments)
+REPEAT_RECIPES = {
+    "mrna": dict(polya=0.05, polyt=0.01, tail=(20, 60), tandem=0.05, paralog=0.08, element=0.40, core_copies=2.0),
+    "ncrna_others": dict(polya=0.02, polyt=0.0, tail=(15, 40), tandem=0.05, paralog=0.10, element=0.10, core_copies=0.0),
+    "snorna": dict(polya=0.0, polyt=0.0, tail=(0, 0), tandem=0.02, paralog=0.20, element=0.0, core_copies=0.0),
+}
+_ELEMENT = np.random.default_rng(77).integers(0, 4, 280, dtype=np.uint8)   # the interspersed element (SINE-like), 280 nt
+_CORE = (100, 160)                                                           # ... its conserved core: these 60 nt, copied exactly
+
+
+def decorate_repeats(blob, off, rng, polya, polyt, tail, tandem, paralog, element, core_copies):
+    """In place on the concatenated codes of a library (entry i = blob[off[i] : off[i + 1]]):
+      paralog   the entry becomes a copy of another (as far as both reach) with 2 % substitutions
+      element   280-nt interspersed element written at a random position, 5 % divergence outside its core
+      core      the element's 60-nt core written `core_copies` times per entry on average, exactly
+                (137 Mbp of mRNA at scale 1: ~10^5 copies -- every seed cut from it has 10^5 rows)
+      tandem    a stretch of 50..400 nt filled with a motif of period 2..6
+      polya/t   the last 20..60 nt (`tail`) become A / the first become T
+    Returns the counts of each."""
+    n = off.shape[0] - 1
+    lens = np.diff(off)
+    st = dict(paralog=0, element=0, core=0, tandem=0, polya=0, polyt=0)
+    for i in np.nonzero(rng.random(n) < paralog)[0]:
+        j = int(rng.integers(0, n))
+        L = int(min(lens[i], lens[j]))
+        if j == i or L < 50:
+            continue
+        seg = blob[off[j]:off[j] + L].copy()
+        hit = rng.random(L) < 0.02
+        seg[hit] = (seg[hit] + rng.integers(1, 4, int(hit.sum()))) & 3
+        blob[off[i]:off[i] + L] = seg
+        st["paralog"] += 1
+    E = _ELEMENT.shape[0]
+    for i in np.nonzero((rng.random(n) < element) & (lens > E + 20))[0]:
+        p = int(off[i] + rng.integers(0, lens[i] - E))
+        seg = _ELEMENT.copy()
+        hit = rng.random(E) < 0.05
+        hit[_CORE[0]:_CORE[1]] = False
+        seg[hit] = (seg[hit] + rng.integers(1, 4, int(hit.sum()))) & 3
+        blob[p:p + E] = seg
+        st["element"] += 1
+    C = _CORE[1] - _CORE[0]
+    if core_copies > 0:
+        k = rng.poisson(core_copies, n)
+        for i in np.nonzero((k > 0) & (lens > 4 * C))[0]:
+            for _ in range(int(k[i])):
+                p = int(off[i] + rng.integers(0, lens[i] - C))
+                blob[p:p + C] = _ELEMENT[_CORE[0]:_CORE[1]]
+                st["core"] += 1
+    for i in np.nonzero((rng.random(n) < tandem) & (lens > 120))[0]:
+        period = int(rng.integers(2, 7))
+        motif = rng.integers(0, 4, period, dtype=np.uint8)
+        span = int(min(lens[i] - 20, rng.integers(50, 401)))
+        p = int(off[i] + rng.integers(0, lens[i] - span))
+        blob[p:p + span] = np.resize(motif, span)
+        st["tandem"] += 1
+    if tail[1] > 0:
+        for frac, code, at_end, name in ((polya, 0, True, "polya"), (polyt, 3, False, "polyt")):
+            for i in np.nonzero((rng.random(n) < frac) & (lens > 2 * tail[1]))[0]:
+                t = int(rng.integers(tail[0], tail[1] + 1))
+                if at_end:
+                    blob[off[i + 1] - t:off[i + 1]] = code
+                else:
+                    blob[off[i]:off[i] + t] = code
+                st[name] += 1
+    return st
+
+
 class SynthLibraries:
     """libs[key] = (names, seqs); codes[key] = (concatenated uint8 codes, starts)."""
 
-    def __init__(self, seed=20181, scale=1.0, n_paralogs=60, n_snp=120, shapes=None, snpc=False):
+    def __init__(self, seed=20181, scale=1.0, n_paralogs=60, n_snp=120, shapes=None, snpc=False, repeats=False):
+        """repeats: the UNFRIENDLY variant of the large / unstructured libraries (the default is i.i.d.-uniform
+        ACGT, what SURVEY.md 8d asks the headline for): what real rRNA / mRNA / ncRNA libraries hold and hash
+        tables, seed buckets and suffix intervals dislike -- poly-A and poly-T tails on transcripts, tandem
+        repeats, paralog families (copies of other entries with a few substitutions), and one interspersed
+        element whose conserved core occurs ~10^5 times at full scale (`decorate_repeats`)."""
         rng = np.random.default_rng(seed)
         self.libs, self.codes = {}, {}
         FULL_SHAPES = dict(globals()["FULL_SHAPES"])
@@ -112,9 +185,14 @@ class SynthLibraries:
         self.libs["hairpin"] = (["syn-mir-%d" % (h + 1) for h in range(n_hp)],
                                 [codes_to_str(c) for c in hp_codes])
 
+        rep_rng = np.random.default_rng(seed + 977)   # (its own stream: the i.i.d. libraries stay what they were)
+        self.repeat_stats = {}
+
         def uniform_lib(key, prefix, n, lo, hi, suffix=""):
             lens = rng.integers(lo, hi + 1, n)
             blob = rng.integers(0, 4, int(lens.sum()), dtype=np.uint8)
+            if repeats and key in REPEAT_RECIPES:
+                self.repeat_stats[key] = decorate_repeats(blob, np.concatenate([[0], np.cumsum(lens)]), rep_rng, **REPEAT_RECIPES[key])
             text = _LETTERS[blob].tobytes().decode("ascii")
             off = np.concatenate([[0], np.cumsum(lens)])
             self.libs[key] = (["%s-%d" % (prefix, i + 1) for i in range(n)],

@@ -196,3 +196,46 @@ def test_cli_ranks_write_the_same_tables_as_one(native_lib, oracle_lib, tmp_path
     assert any(line.startswith(libs.libs["mrna"][1][1][3:160] + ",1,") for line in open(os.path.join(two_dir, "mapped.csv")))
     rep = open(os.path.join(two_dir, "annotation.report.csv")).read().split("\n")[1].split(",")
     assert int(rep[1]) == 1204 and int(rep[2]) == one["logDic"]["quantStats"][0]["trimmedReads"]
+
+
+def test_cli_one_file_three_ranks(native_lib, oracle_lib, tmp_path):
+    """`annotate --gpus 3` on ONE sample (the common case: MAIN:289-314 takes one file per sample): the file is cut into
+    three byte ranges at record starts, every rank ingests its own (mrg_fastq_load_part), the reads are partitioned by
+    sequence, and rank 0 writes the tables of the single-process run -- totalReads / trimmedReads of the sample are
+    the sums over the parts, a read beyond 255 nt that occurs in two parts is one row."""
+    from mirge_amd import cli, dist as mdist, synth
+    from tests.fake_engine import OracleEngine
+    from tests.golden.make_golden import SHAPES
+    from tests.test_cli import write_fastq
+    assert mdist.file_shares(1, 3) == [[(0, 0, 3)], [(0, 1, 3)], [(0, 2, 3)]]
+    assert mdist.file_shares(2, 5) == [[(0, 0, 2)], [(0, 1, 2)], [(1, 0, 2)], [(1, 1, 2)], []]
+    assert mdist.file_shares(3, 2) == [[(0, 0, 1), (2, 0, 1)], [(1, 0, 1)]]
+    rng = np.random.default_rng(6)
+    libs = synth.SynthLibraries(seed=123, scale=1.0, n_paralogs=6, n_snp=8, shapes=SHAPES)
+    libs.write_layout(str(tmp_path / "libs"), species="syn", db="miRBase")
+    long_mrna = max(libs.libs["mrna"][1], key=len)
+    reads = [synth.codes_to_str(c) for c in synth.synth_reads(libs, 3000, seed=71, zipf_s=1.3)]
+    reads[100:100] = [long_mrna[2:290]]
+    reads += ["ACGTNACGTTAGCATCGATCGA", long_mrna[2:290], "A" * 300]
+    p = str(tmp_path / "only.fastq")
+    write_fastq(p, reads, rng)
+    base = ["annotate", "-s", p, "-lib", str(tmp_path / "libs"), "-sp", "syn", "-di"]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    one = cli.annotate_main(cli.build_parser().parse_args(base + ["-o", str(tmp_path / "one")]), engine_factory=OracleEngine)
+    marker = str(tmp_path / "outdir.txt")
+    mp.spawn(_cli_worker, args=(3, _free_port(), base + ["-o", str(tmp_path / "three")], marker), nprocs=3, join=True)
+    three_dir = open(marker).read()
+    files = sorted(os.listdir(one["outdir"]))
+    assert files == sorted(os.listdir(three_dir)) and "mapped.csv" in files
+    for fn in files:
+        a = open(os.path.join(one["outdir"], fn)).read()
+        b = open(os.path.join(three_dir, fn)).read()
+        if fn == "annotation.report.csv":
+            assert a == b, fn
+        else:
+            assert sorted(a.split("\n")) == sorted(b.split("\n")), fn
+    rep = open(os.path.join(three_dir, "annotation.report.csv")).read().split("\n")[1].split(",")
+    assert int(rep[1]) == len(reads)
+    rows = [l for l in open(os.path.join(three_dir, "mapped.csv")) if l.startswith(long_mrna[2:290] + ",")]
+    assert len(rows) == 1 and rows[0].strip().endswith(",2")

@@ -221,6 +221,37 @@ def test_fastq_errors(native_lib, tmp_path):
         ingest.load_fastq(str(tmp_path / "missing.fastq"))
 
 
+@pytest.mark.parametrize("gz", [False, True])
+def test_one_file_read_in_parts(native_lib, tmp_path, gz, monkeypatch):
+    """mrg_fastq_load_part (`--gpus N` on one sample): a plain file cut into byte ranges at record starts -- quality
+    lines that start with '@', CRLF, blocks of several MB --, a gzip file shared out block by block: whatever the number
+    of parts, their reads together are the file's reads (in file order for a plain file), their counts add up, the
+    quality base is the file's (a phred-64 file whose first record alone says so)."""
+    monkeypatch.setenv("MIRGE_AMD_GZ_CHUNK", "65536")
+    rng = np.random.default_rng(9)
+    p = str(tmp_path / ("one.fastq" + (".gz" if gz else "")))
+    for first_hi, n_parts_list in ((False, (2, 3, 7)), (True, (3,))):
+      write_fastq(p, rng, 60000, gz=gz, first_hi=first_hi)
+      whole = ingest.load_fastq(p, threads=3)
+      want = pack.unpack_reads(whole["words"], whole["lens"], whole["nmask"])
+      assert whole["total"] == 60000 and whole["phred"] == (64 if first_hi else 33) and (len(want) > 30000 or first_hi)
+      for n_parts in n_parts_list:
+        got, total, kept = [], 0, 0
+        for part in range(n_parts):
+            fq = ingest.load_fastq(p, threads=2, part=part, n_parts=n_parts)
+            got.append(pack.unpack_reads(fq["words"], fq["lens"], fq["nmask"]) if fq["packed"] else [])
+            total += fq["total"]
+            kept += fq["kept"]
+            assert fq["phred"] == (whole["phred"] if part == 0 else 0)
+            assert fq["total"] > 0 or gz   # (a gzip file is shared out in blocks of ~4 MB of text: this one has two)
+        assert total == whole["total"] and kept == whole["kept"]
+        flat = [r for g in got for r in g]
+        if gz:
+            assert sorted(flat) == sorted(want)
+        else:
+            assert flat == want
+
+
 @pytest.mark.gpu
 def test_gpu_collapse_matches_quantReads_golden(native_lib):
     from mirge_amd.engine import Engine
