@@ -979,6 +979,9 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       e.log2_slots = l.dict_log2;
       e.key_bases = l.dict_key;
       e.kbits = (ctx->kmer_filter && c.seed_len >= (int32_t)mrg::kKmerBitsK) ? l.kbits : nullptr;
+      e.blocks = l.blocks;
+      e.super = l.super;
+      e.primary = l.primary;
       e.ftab = l.ftab;
       e.tabs = l.tabs;
       e.sa = l.sa;
@@ -1469,6 +1472,9 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       un.bucket_k = fm->bucket_k;
       un.sa = fm->sa;
       un.text = fm->text;
+      un.blocks = fm->blocks;
+      un.super = fm->super;
+      un.primary = fm->primary;
       un.n = fm->n;
       un.seg_start = fm->seg_start;
       un.seg_ref = fm->seg_ref;

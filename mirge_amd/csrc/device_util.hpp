@@ -122,6 +122,75 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   return (uint32_t)s;
 }
 
+// first BWT row of the c-suffixes + rank of c before row i, from the 16-byte occ block of row i and the superblock
+// table in global memory (kernels.hip: Lib::lf with both tables in LDS)
+__device__ __forceinline__ uint32_t lf_step(const uint32_t* __restrict__ blocks, const uint32_t* __restrict__ super, uint32_t primary,
+                                            uint32_t c, uint32_t i) {
+  const uint4 v = *reinterpret_cast<const uint4*>(blocks + (size_t)(i >> 5) * 4u);
+  const uint32_t r = i & 31u;
+  const uint32_t pair = (c & 2u) ? v.y : v.x;
+  const uint32_t cnt = (c & 1u) ? (pair >> 16) : (pair & 0xffffu);
+  uint32_t e = ((c & 1u) ? v.z : ~v.z) & ((c & 2u) ? v.w : ~v.w);
+  e &= (1u << r) - 1u;
+  uint32_t o = super[(size_t)(i >> 16) * 4u + c] + cnt + (uint32_t)__popc(e);
+  o -= (uint32_t)((c == 0u) & (i > primary) & ((i >> 5) == (primary >> 5)));  // the sentinel row is stored as symbol 0
+  return o;
+}
+
+// The FM-index answer for a one-word read whose first R bases must match letter for letter (a pass without seed
+// mismatch; up to max_total mismatches behind base R): what the dictionary kernels fall back to for a read shorter than
+// the dictionary's key or a key whose chain overflowed.  A BACKWARD search of the R bases -- their last k through the
+// largest jump table, the others one LF step each -- leaves exactly the rows whose suffix starts with them: one row
+// for a read that reaches out of a repeat into unique sequence, however many copies the repeat has.  (Round 4 took the
+// rows of the first k bases and compared every one with the text, one lane, one row after the other: 10^5 rows for a
+// key inside an element with 10^5 copies -- 77 ms for 2 M reads on `bench.py --workload repeats`.)
+// Returns the best (mismatches << 32 | text position) or ~0; rows = rows looked at, steps = LF steps made.
+template <class Tabs>
+__device__ __forceinline__ uint64_t fm_exact_search(const uint32_t* __restrict__ blocks, const uint32_t* __restrict__ super, uint32_t primary,
+                                                    const uint32_t* __restrict__ ftab, const Tabs& tabs, const uint64_t* __restrict__ sa,
+                                                    const uint32_t* __restrict__ text, uint32_t n, uint64_t q, int32_t L, int32_t R,
+                                                    int32_t max_total, uint32_t& best_seg, uint32_t& best_before, uint32_t& rows,
+                                                    uint32_t& steps) {
+  uint32_t tab_off = 0;
+  const uint32_t k = tabs.k[0] ? pick_table(tabs, R, tab_off) : 0u;
+  uint32_t lo = 0, hi = n + 1u;
+  int32_t j = R;
+  if (k) {
+    j = R - (int32_t)k;
+    const uint32_t* tab = ftab + tab_off + lex_code((q >> (2u * (uint32_t)j)) & low_bits(2u * k), k);
+    lo = tab[0];
+    hi = tab[1];
+  }
+  steps = 0;
+  while (j > 0 && hi > lo) {
+    --j;
+    const uint32_t c = (uint32_t)(q >> (2u * (uint32_t)j)) & 3u;
+    lo = lf_step(blocks, super, primary, c, lo);
+    hi = lf_step(blocks, super, primary, c, hi);
+    ++steps;
+  }
+  rows = hi > lo ? hi - lo : 0u;
+  uint64_t best = ~0ull;
+  const uint64_t tailmask = low_bits(2u * (uint32_t)L) & ~low_bits(2u * (uint32_t)R);
+  for (uint32_t i = lo; i < hi; ++i) {
+    const uint64_t row = sa[i];
+    if ((uint32_t)L > ((uint32_t)(row >> 40) & 255u)) continue;  // (the read would leave the N-free segment)
+    const uint32_t s = (uint32_t)row;
+    uint32_t mmt = 0;
+    if (L > R) {
+      mmt = (uint32_t)__popcll(mismatch_bits(text_window(text, s), q) & tailmask);
+      if ((int32_t)mmt > max_total) continue;
+    }
+    const uint64_t key = ((uint64_t)mmt << 32) | s;
+    if (key < best) {
+      best = key;
+      best_seg = (uint32_t)(row >> 48);
+      best_before = (uint32_t)(row >> 32) & 255u;
+    }
+  }
+  return best;
+}
+
 // entry (ref, pos) of text position s whose suffix-array row said (seg16, before): the epilogue of
 // every match kernel
 struct SegTables {

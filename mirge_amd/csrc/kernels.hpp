@@ -208,6 +208,9 @@ struct ExactParams {
   uint32_t log2_slots, key_bases;
   const uint32_t* kbits;  // the library's 9-mer presence bitmap (null = none): staged in LDS as a reject filter
   // FM index of the same library, for the fallback
+  const uint32_t* blocks;
+  const uint32_t* super;
+  uint32_t primary;
   const uint32_t* ftab;
   JumpTables tabs;
   const uint64_t* sa;
@@ -279,6 +282,9 @@ struct SeedUnit {
   uint32_t bucket_k;     // bases finds its rows in ONE 128-byte line instead of jump table + rows
   const uint64_t* sa;
   const uint32_t* text;
+  const uint32_t* blocks;  // occ blocks + superblocks + sentinel row: the FM fallback of a dictionary unit (kind 1)
+  const uint32_t* super;
+  uint32_t primary;
   uint32_t n;
   const uint32_t* seg_start;
   const uint32_t* seg_ref;
