@@ -190,6 +190,13 @@ def main():
     ap.add_argument("--outputs", choices=["packed", "arrays"], default="packed",
                     help="per-read output of the timed steps: one 4-byte packed word per read (mrg_cascade_run_packed, "
                          "SURVEY.md 8d's unit) or the four arrays pass_id / ref_id / pos / mm (10 B per read)")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="1: the step (zeroing, cascade, tally) is captured into a hipGraph per count vector and replayed "
+                         "(needs --fused-step 1: no event may live inside a captured step)")
+    ap.add_argument("--fused-step", type=int, default=1,
+                    help="1 (default): the timed steps run with the context option fused_step (no per-pass events, the per-pass "
+                         "counters exported by the tally launch); the per-pass times of the line come from ONE extra untimed step "
+                         "with the option off")
     ap.add_argument("--mix", action="append", default=[],
                     help="override a fraction of the read mixture, e.g. polyt=0 (experiments; not the headline workload)")
     args = ap.parse_args()
@@ -304,13 +311,7 @@ def main():
     pending = [None] * len(bufs)
     state = dict(k=0)
 
-    def step():
-        b = state["k"] % len(bufs)
-        state["k"] += 1
-        f = bufs[b]
-        if pending[b] is not None:
-            pending[b].wait()          # (the current stream waits; the host does not, on RCCL)
-            pending[b] = None
+    def body(f):
         f.zero_()
         if packed_out is not None:
             res = eng.cascade_packed(rs, passes, out=(packed_out, f[ln:]))
@@ -319,6 +320,22 @@ def main():
         eng.tally(rs, res, M, canon, iso, counts=f[:ln_tally])
         if wl == "a2i":
             eng.edit_tally(rs, res, "mirna", canon, iso, counts=f[ln_tally:ln])
+        return res
+
+    graphs = [None] * len(bufs)
+
+    def step():
+        b = state["k"] % len(bufs)
+        state["k"] += 1
+        f = bufs[b]
+        if pending[b] is not None:
+            pending[b].wait()          # (the current stream waits; the host does not, on RCCL)
+            pending[b] = None
+        if graphs[b] is not None:
+            graphs[b].replay()
+            res = state["res"]
+        else:
+            res = body(f)
         pending[b] = mdist.allreduce_counts(f, async_op=True)
         state["last"] = f
         return res
@@ -338,6 +355,27 @@ def main():
     # whatever the launch plan derives lazily (concatenated small libraries, anchor-pair tables) is built
     # here, not inside a step
     eng.prepare(passes, rs.W, rs.min_len, rs.max_len)
+    # the timed steps carry no HIP event and no launch but the kernels' own ("fused_step": the tally launch exports the
+    # per-pass counters); the per-pass times of the line are those of one extra untimed step with the option off
+    fused_step = bool(args.fused_step)
+    if fused_step:
+        eng.set_option("fused_step", 1)
+    graph_note = None
+    if args.graph and fused_step:
+        try:
+            state["res"] = body(bufs[0])      # (everything lazy is built, the result object of a step exists)
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            for b_, f_ in enumerate(bufs):
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_, stream=side):
+                    body(f_)
+                graphs[b_] = g_
+            graph_note = "zeroing + cascade + tally of a step captured once per count vector, replayed"
+        except Exception as e:   # (a runtime that cannot capture these launches: plain steps)
+            graphs = [None] * len(bufs)
+            graph_note = "capture failed (%r): plain launches" % (e,)
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     drain()
@@ -348,6 +386,13 @@ def main():
     drain()
     fence()
     elapsed = time.perf_counter() - t0
+    if fused_step:
+        # per-pass times, launch plan and counters: one more step, untimed, with its events
+        eng.set_option("fused_step", 0)
+        keep = state.get("last")
+        res = body(torch.zeros_like(bufs[0]))
+        torch.cuda.synchronize()
+        state["last"] = keep
     fused = state.get("last", fused)   # the last step's (reduced) count vector
     reduce_check = None
     if world > 1:
@@ -676,6 +721,9 @@ def main():
         "config": {
             "workload": what, "reads_total": n_total, "reads_per_gpu": n_reads, "libraries_scale": args.scale,
             "samples": S,
+            "step": ("fused_step: no per-pass event and no export launch inside the timed steps (per-pass ms from one extra untimed step)"
+                     if fused_step else "per-pass events recorded inside every timed step") +
+                    ("; " + graph_note if graph_note else ""),
             "outputs": ("one 4-byte packed assignment per read (mrg_cascade_run_packed)" if args.outputs == "packed" else
                         "pass_id, ref_id, pos, mm arrays (10 B per read)"),
             "parallelism": ("one read set in %d contiguous shards, libraries replicated, one RCCL all-reduce of the "

@@ -205,7 +205,11 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * seed_kernel / 1, 2 wave_seed_kernel (64-80 / 80-96 registers); "pair_impl" = 1 (default) / 0: the anchor-pair
  * search of one-word batches in pair_wave_kernel / stratum_kernel; "grid_pct" = 100 (default) / 1..100: every
  * cascade launch with this share of its workgroups (room for another cascade's launches on another stream);
- * (round 5) "collapse_fast" = 1 (default) / 0: mrg_collapse_run takes its duplication-aware path for batches that fit it
+ * (round 5) "fused_step" = 0 (default) / 1: for a caller that follows EVERY mrg_cascade_run* with an mrg_tally_run* on the
+ * same stream: the cascade records no per-pass events (mrg_pass_stats.ms = 0: take the times from a run with the option
+ * off) and d_pass_counts is written by the tally launch instead of by a launch of its own -- nothing then sits between
+ * the launches of a step, which may be captured into a hipGraph;
+ * "collapse_fast" = 1 (default) / 0: mrg_collapse_run takes its duplication-aware path for batches that fit it
  * (one-word reads without N, at most 29 nt) / always the general column-by-column sort;
  * "wide_rows_16", "round_large": see DESIGN.md. */
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);

@@ -223,6 +223,11 @@ struct mrg_ctx {
   int64_t seed_units = 1;    // ... and their runs of passes with at most one seed mismatch go through seed_kernel
   int64_t pair_impl = 1;   // 1 = pair_wave_kernel for the anchor-pair search of one-word batches, 0 = stratum_kernel
   int64_t grid_pct = 100;  // share of the workgroups every cascade launch gets (see scale_grid)
+  // "fused_step": a caller that follows EVERY cascade with a tally on the same stream (bench.py's step, the command line):
+  // no per-pass events are recorded (mrg_pass_stats.ms = 0) and d_pass_counts is written by the tally launch
+  int64_t fused_step = 0;
+  uint64_t* pending_export_out = nullptr;
+  hipStream_t pending_export_stream = nullptr;
   int64_t collapse_fast = 1;  // mrg_collapse_run: batches that fit it take the duplication-aware path (0: always the general sort)
   int64_t seed_impl = -1;  // -1 = per launch (run_seed), 0 = seed_kernel (tiles), 1 = wave_seed_kernel, 2 = the same with more registers
   std::vector<DevLib> libs;
@@ -245,6 +250,7 @@ struct mrg_ctx {
   // (an event record costs ~5 us of an idle GPU: five of them less per step)
   uint8_t ev_ix[MRG_MAX_PASSES + 1] = {0}, ev0_ix[MRG_MAX_PASSES + 1] = {0};
   bool ev_ready = false;
+  bool last_timed = true;  // the last run recorded its per-pass events
 };
 
 extern "C" {
@@ -669,6 +675,8 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->seed_impl = value;
   } else if (k == "seed_units") {
     ctx->seed_units = value != 0;
+  } else if (k == "fused_step") {
+    ctx->fused_step = value != 0;
   } else if (k == "collapse_fast") {
     ctx->collapse_fast = value != 0;
   } else if (k == "dict_max_bases") {
@@ -903,11 +911,13 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   hipEvent_t* evs = ctx->ev;  // the per-pass events of the cascade that is being issued
   uint8_t* ev_ix = ctx->ev_ix;
   uint32_t ev_last = 0;
-  HIP_TRY(hipEventRecord(evs[0], stream));
+  const bool timed = !ctx->fused_step;  // ("fused_step": no event lives inside the step: nothing between its launches)
+  ctx->last_timed = timed;
+  if (timed) HIP_TRY(hipEventRecord(evs[0], stream));
   ev_ix[0] = 0;
   // pass i is issued: `fresh` = something was launched since the boundary before
   auto mark = [&](uint32_t i, bool fresh) -> hipError_t {
-    if (!fresh) {
+    if (!fresh || !timed) {
       ev_ix[i + 1] = (uint8_t)ev_last;
       return hipSuccess;
     }
@@ -1610,13 +1620,13 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       ev_ix = ctx->ev0_ix;
       ev_last = 0;
       ev_ix[0] = 0;
-      HIP_TRY(hipEventRecord(evs[0], stream));
+      if (timed) HIP_TRY(hipEventRecord(evs[0], stream));
     } else {
       evs = ctx->ev;
       ev_ix = ctx->ev_ix;
       ev_last = 0;
       ev_ix[0] = 0;
-      HIP_TRY(hipEventRecord(evs[0], stream));
+      if (timed) HIP_TRY(hipEventRecord(evs[0], stream));
     }
     if (chain == 1) {  // the one-word reads: parked in buffer 2, alternating with buffer 1
       pair0 = 2, pair1 = 1, cur_list = 2;
@@ -1724,7 +1734,15 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     launched_any = true;
   }
   }
-  if (d_pass_counts) HIP_TRY(mrg::launch_export_pass_counts(stats, n_pass, d_pass_counts, stream));
+  ctx->pending_export_out = nullptr;
+  if (d_pass_counts) {
+    if (ctx->fused_step) {
+      ctx->pending_export_out = d_pass_counts;  // (the tally launch behind this cascade copies them: mrg_tally_run*)
+      ctx->pending_export_stream = stream;
+    } else {
+      HIP_TRY(mrg::launch_export_pass_counts(stats, n_pass, d_pass_counts, stream));
+    }
+  }
   ctx->last_stream = stream;
   ctx->last_stats_dev = stats;
   ctx->last_n_pass = n_pass;
@@ -1784,10 +1802,10 @@ int mrg_cascade_stats(mrg_ctx* ctx, mrg_pass_stats* out, uint32_t n_pass) {
     out[i].candidates = host[i * kStatsPerPass + 3];
     out[i].lookups = host[i * kStatsPerPass + 4];
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[ctx->ev_ix[i]], ctx->ev[ctx->ev_ix[i + 1]]));
+    if (ctx->last_timed) HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[ctx->ev_ix[i]], ctx->ev[ctx->ev_ix[i + 1]]));
     out[i].ms = ms;
     out[i].ms_rest = 0.f;
-    if (ctx->last_split) HIP_TRY(hipEventElapsedTime(&out[i].ms_rest, ctx->ev0[ctx->ev0_ix[i]], ctx->ev0[ctx->ev0_ix[i + 1]]));
+    if (ctx->last_split && ctx->last_timed) HIP_TRY(hipEventElapsedTime(&out[i].ms_rest, ctx->ev0[ctx->ev0_ix[i]], ctx->ev0[ctx->ev0_ix[i + 1]]));
     out[i].lds_bytes = ctx->last_lds[i];
     out[i].lds_mode = ctx->last_mode[i];
     out[i].group = ctx->last_group[i];
@@ -1940,6 +1958,16 @@ int tally_run_impl(mrg_ctx* ctx, const int8_t* d_pass_id, const int32_t* d_ref_i
   p.canon_pass = canon_pass;
   p.isomir_pass = isomir_pass;
   p.counts = d_counts;
+  p.export_stats = nullptr;
+  p.export_out = nullptr;
+  p.export_n_pass = 0;
+  if (ctx->pending_export_out && ctx->pending_export_stream == (hipStream_t)stream_) {
+    // "fused_step": the cascade in front left its per-pass counters to this launch
+    p.export_stats = ctx->last_stats_dev;
+    p.export_out = ctx->pending_export_out;
+    p.export_n_pass = ctx->last_n_pass;
+  }
+  ctx->pending_export_out = nullptr;
   const bool in_ok = d_packed ? ((uintptr_t)d_packed % 16 == 0) : (((uintptr_t)d_pass_id % 4 == 0) && ((uintptr_t)d_ref_id % 16 == 0));
   p.vec4 = (n_samples == 1 && in_ok && ((uintptr_t)d_quant % 16 == 0)) ? 1u : 0u;
   uint64_t bins = 0;

@@ -1841,6 +1841,8 @@ __global__ void __launch_bounds__(kTallyThreads) tally_kernel(const TallyParams 
   constexpr uint32_t R = kTallyCatReplicas;
   const uint32_t l_cat0 = cat0, l_uniq0 = cat0 + n_cat * R, l_bins = l_uniq0 + S;
   unsigned long long* g = reinterpret_cast<unsigned long long*>(p.counts);
+  if (p.export_stats && blockIdx.x == 0 && threadIdx.x < 2u * p.export_n_pass)
+    p.export_out[threadIdx.x] = p.export_stats[(threadIdx.x >> 1) * 5u + (threadIdx.x & 1u)];
   if (LDSH) {
     for (uint32_t i = threadIdx.x; i < l_bins; i += kTallyThreads) hist[i] = 0ull;
     __syncthreads();

@@ -445,6 +445,11 @@ struct TallyParams {
   int32_t canon_pass, isomir_pass;
   uint64_t* counts;
   uint32_t vec4;  // one sample and 16-byte aligned arrays: four reads per lane and trip
+  // "fused_step": the per-pass processed / aligned of the cascade in front go out with this launch (its first
+  // workgroup copies them) instead of with a launch of their own; null = nothing to export
+  const uint64_t* export_stats;  // [n_pass][5]
+  uint64_t* export_out;          // [n_pass][2]
+  uint32_t export_n_pass;
 };
 
 // A-to-I position tally (writeDataToCSV.py:145-229 on the cascade's own alignments)
