@@ -34,13 +34,43 @@ __device__ __forceinline__ void longest_segment(const uint32_t* in_count, uint32
   if ((threadIdx.x & 63) == 0 && mx) atomicMax(ctl1, mx);
 }
 
-// The FM-index answer for one read of a pass WITHOUT seed mismatches (device_util.hpp: fm_exact_search): reads
-// shorter than the dictionary key, and keys of an overflowed chain that none of the chain's stored positions answers.
+// The FM-index answer for one read of a pass WITHOUT seed mismatches: rows of the prefix interval
+// of the largest jump table the seed region is long enough for, each verified against the text.
+// Slow (a short prefix has many rows) and rare: reads shorter than the dictionary key, and keys
+// of an overflowed chain.  (The seed kernels' dictionary units of LARGE libraries -- where repeats make such keys
+// common -- search backwards instead: device_util.hpp, fm_exact_search; that code in this kernel or in seed_kernel
+// cost their streaming loops 2-6 % on the headline run, same-box A/B.)  Returns the best (mm << 32 | text position) or ~0.
 __device__ __forceinline__ uint64_t fm_exact_fallback(const ExactParams& p, uint64_t rd, int32_t L, uint32_t& best_seg,
                                                    uint32_t& best_before, uint32_t& n_rows) {
-  uint32_t steps = 0;
-  return fm_exact_search(p.blocks, p.super, p.primary, p.ftab, p.tabs, p.sa, p.text, p.n, rd, L, min(L, p.seed_len), p.max_mm_total, best_seg,
-                         best_before, n_rows, steps);
+  const int32_t R = min(L, p.seed_len);
+  uint32_t tab_off = 0;
+  const uint32_t k = p.tabs.k[0] ? pick_table(p.tabs, R, tab_off) : 0u;
+  uint32_t lo = 0, hi = p.n + 1;
+  if (k) {
+    const uint32_t* tab = p.ftab + tab_off + lex_code(rd & low_bits(2 * k), k);
+    lo = tab[0];
+    hi = tab[1];
+  }
+  n_rows = hi > lo ? hi - lo : 0u;
+  uint64_t best = ~0ull;
+  const uint64_t lmask = low_bits(2 * (uint32_t)L), smask = low_bits(2 * (uint32_t)R);
+  for (uint32_t i = lo; i < hi; ++i) {
+    const uint64_t row = p.sa[i];
+    const uint32_t before = (uint32_t)(row >> 32) & 255u, after = (uint32_t)(row >> 40) & 255u;
+    if ((uint32_t)L > after) continue;
+    const uint32_t s = (uint32_t)row;
+    const uint64_t m = mismatch_bits(text_window(p.text, s), rd) & lmask;
+    if ((m & smask) != 0ull) continue;
+    const uint32_t mm_total = (uint32_t)__popcll(m);
+    if ((int32_t)mm_total > p.max_mm_total) continue;
+    const uint64_t key = ((uint64_t)mm_total << 32) | s;
+    if (key < best) {
+      best = key;
+      best_seg = (uint32_t)(row >> 48);
+      best_before = before;
+    }
+  }
+  return best;
 }
 
 }  // namespace
@@ -180,12 +210,8 @@ __global__ void __launch_bounds__(kBlock, 8) exact_dict_kernel(const ExactParams
       o_ref[u] = o_pos[u] = o_mm[u] = 0u;
       if (search[u]) {
         const uint64_t lmask = low_bits(2 * (uint32_t)L[u]);
-        uint32_t chain = (s[u].w >> kDictChainShift) & kDictChainMask;
+        const uint32_t chain = (s[u].w >> kDictChainShift) & kDictChainMask;
         uint4 sl = s[u];
-        // (an overflowed home goes straight to the FM index here: probing its stored positions first -- what the seed
-        // kernels' dictionary units do, dict_unit_probe -- cost this kernel 16 bytes of scratch per lane in its
-        // streaming loop; the first pass's library is the miRNA one, whose keys do not overflow)
-        const bool over = false;
         if (chain == kDictChainOverflow) {
           fallback[u] = true;
         } else if (L[u] <= p.seed_len) {
@@ -202,7 +228,6 @@ __global__ void __launch_bounds__(kBlock, 8) exact_dict_kernel(const ExactParams
             if (j >= chain) break;
             sl = p.slots[(home[u] + j + 1u) & smask];
           }
-          fallback[u] = over && !aligned[u];
         } else {
           // `-n 0` on a read longer than the seed: exact inside it, up to max_mm_total mismatches behind
           const uint64_t seedmask = low_bits(2 * (uint32_t)p.seed_len);
@@ -222,10 +247,6 @@ __global__ void __launch_bounds__(kBlock, 8) exact_dict_kernel(const ExactParams
             }
             if (j >= chain || (best >> 8) == 0u) break;
             sl = p.slots[(home[u] + j + 1u) & smask];
-          }
-          if (over && (best >> 8) != 0u) {  // (a position that did not fit the chain may match with fewer mismatches)
-            fallback[u] = true;
-            aligned[u] = false;
           }
         }
       }
@@ -726,38 +747,56 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
               const uint32_t home = (((uint32_t)q & kmask) * kDictHashMul) >> (32u - un.log2_slots);
               uint4 sl = un.slots[home];
               ++c_lookups;
-              uint32_t chain = (sl.w >> kDictChainShift) & kDictChainMask;
-              // (an overflowed home keeps its first -- lowest -- positions in the chain: an exact match among them is
-              // the answer, anything else asks the FM index: exact_dict_kernel)
-              const bool over = chain == kDictChainOverflow;
-              if (over) chain = kDictChainOverflow - 1u;
-              uint32_t bestj = ~0u;
-              for (uint32_t jj = 0;; ++jj) {
-                const uint64_t win = (uint64_t)sl.x | ((uint64_t)sl.y << 32);
-                ++c_cands;
-                const uint64_t m = mismatch_bits(win, q) & lmask;
-                const uint32_t mmt = (uint32_t)__popcll(m);
-                if ((sl.w & kDictOccBit) && (m & seedmask) == 0ull && (int32_t)mmt <= max_total && (uint32_t)L <= (sl.w & kDictAfterMask) &&
-                    ((mmt << 8) | jj) < bestj) {
-                  bestj = (mmt << 8) | jj;
-                  key = ((unsigned long long)pass_index << 56) | ((unsigned long long)mmt << 48) | ((unsigned long long)sl.z << 21) |
-                        (sl.w >> kDictOffShift);
-                }
-                if (jj >= chain || (bestj >> 8) == 0u) break;
-                sl = un.slots[(home + jj + 1u) & smask];
-              }
-              if (over && (bestj >> 8) != 0u) {
+              const uint32_t chain = (sl.w >> kDictChainShift) & kDictChainMask;
+              if (chain == kDictChainOverflow) {
                 fallback = true;
-                key = ~0ull;
+              } else {
+                uint32_t bestj = ~0u;
+                for (uint32_t jj = 0;; ++jj) {
+                  const uint64_t win = (uint64_t)sl.x | ((uint64_t)sl.y << 32);
+                  ++c_cands;
+                  const uint64_t m = mismatch_bits(win, q) & lmask;
+                  const uint32_t mmt = (uint32_t)__popcll(m);
+                  if ((sl.w & kDictOccBit) && (m & seedmask) == 0ull && (int32_t)mmt <= max_total && (uint32_t)L <= (sl.w & kDictAfterMask) &&
+                      ((mmt << 8) | jj) < bestj) {
+                    bestj = (mmt << 8) | jj;
+                    key = ((unsigned long long)pass_index << 56) | ((unsigned long long)mmt << 48) | ((unsigned long long)sl.z << 21) |
+                          (sl.w >> kDictOffShift);
+                  }
+                  if (jj >= chain || (bestj >> 8) == 0u) break;
+                  sl = un.slots[(home + jj + 1u) & smask];
+                }
               }
             }
             if (fallback) {
-              // the FM index (device_util.hpp: fm_exact_search)
-              uint32_t bseg = 0xFFFFu, bbefore = 255u, rows = 0, steps = 0;
-              const uint64_t bestk = fm_exact_search(un.blocks, un.super, un.primary, un.ftab, un.tabs, un.sa, un.text, un.n, q, L,
-                                                     min(L, seed_len), max_total, bseg, bbefore, rows, steps);
-              c_lookups += 1u + steps;
-              c_cands += rows;
+              // the FM index: rows of the longest prefix a jump table knows, each against the text
+              const int32_t R = min(L, seed_len);
+              uint32_t tab_off = 0;
+              const uint32_t kp = un.tabs.k[0] ? pick_table(un.tabs, R, tab_off) : 0u;
+              uint32_t lo = 0, hi = un.n + 1u;
+              if (kp) {
+                const uint32_t* tab = un.ftab + tab_off + lex_code(q & low_bits(2u * kp), kp);
+                lo = tab[0];
+                hi = tab[1];
+              }
+              ++c_lookups;
+              const uint64_t lmask = low_bits(2u * (uint32_t)L), seedmask = low_bits(2u * (uint32_t)R);
+              uint64_t bestk = ~0ull;
+              uint32_t bseg = 0xFFFFu, bbefore = 255u;
+              for (uint32_t i = lo; i < hi; ++i) {
+                const uint64_t row = un.sa[i];
+                ++c_cands;
+                if ((uint32_t)L > ((uint32_t)(row >> 40) & 255u)) continue;
+                const uint64_t m = mismatch_bits(text_window(un.text, (uint32_t)row), q) & lmask;
+                const uint32_t mmt = (uint32_t)__popcll(m);
+                if ((m & seedmask) != 0ull || (int32_t)mmt > max_total) continue;
+                const uint64_t kk = ((uint64_t)mmt << 32) | (uint32_t)row;
+                if (kk < bestk) {
+                  bestk = kk;
+                  bseg = (uint32_t)(row >> 48);
+                  bbefore = (uint32_t)(row >> 32) & 255u;
+                }
+              }
               if (bestk != ~0ull) {
                 uint32_t ref, pos;
                 SegTables segs{un.seg_start, un.seg_ref, un.seg_off, un.chunk_seg, un.simple_segs};

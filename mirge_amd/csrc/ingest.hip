@@ -16,21 +16,66 @@
 //   +N       N > 0 removes the first N bases, N < 0 the last -N, after the quality trim;
 //   keep     trimmed length >= min_len; bases other than ACGT (any case) are N (code 0 + mask bit).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 
+#include "device_util.hpp"
 #include "kernels.hpp"
+#include "prims.hpp"
 
 namespace mrg {
 
 namespace {
 
-struct IsNewline {
-  const char* text;
-  __host__ __device__ bool operator()(uint32_t i) const { return text[i] == '\n'; }
-};
-
 constexpr uint32_t kIngestThreads = 256;
+
+// Positions of the newlines of a text block, in order: a workgroup takes a tile of 16 KB (64 consecutive bytes per
+// thread), counts its newlines (COUNT: into counts[tile]), and -- behind one prefix sum over the tiles (prims.hip) --
+// writes their positions from the tile's offset on, every thread from its own (workgroup prefix of the thread counts).
+constexpr uint32_t kNlPerThread = 64u, kNlTile = kIngestThreads * kNlPerThread;
+template <bool COUNT>
+__global__ void __launch_bounds__(kIngestThreads) newline_kernel(const char* __restrict__ text, uint32_t n, uint32_t* __restrict__ counts,
+                                                                 const uint32_t* __restrict__ offs, uint32_t* __restrict__ pos, uint32_t pos_cap) {
+  __shared__ uint32_t wtot[kIngestThreads / 64u];
+  const uint32_t base = blockIdx.x * kNlTile + threadIdx.x * kNlPerThread;
+  uint64_t mask = 0;  // bit i: byte base + i is a newline
+  if (base + kNlPerThread <= n) {
+#pragma unroll
+    for (uint32_t q = 0; q < kNlPerThread / 16u; ++q) {
+      const uint4 v = *reinterpret_cast<const uint4*>(text + base + 16u * q);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; ++k)
+#pragma unroll
+        for (uint32_t b = 0; b < 4u; ++b)
+          if (((w[k] >> (8u * b)) & 255u) == (uint32_t)'\n') mask |= 1ull << (16u * q + 4u * k + b);
+    }
+  } else {
+    for (uint32_t i = 0; i < kNlPerThread; ++i)
+      if (base + i < n && text[base + i] == '\n') mask |= 1ull << i;
+  }
+  const uint32_t c = (uint32_t)__popcll(mask);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t incl = dev::wave_incl_scan(c);
+  if (lane == 63u) wtot[wave] = incl;
+  __syncthreads();
+  uint32_t before = incl - c, total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < kIngestThreads / 64u; ++w) {
+    before += w < wave ? wtot[w] : 0u;
+    total += wtot[w];
+  }
+  if (COUNT) {
+    if (threadIdx.x == 0) counts[blockIdx.x] = total;
+  } else {
+    uint32_t at = offs[blockIdx.x] + before;
+    while (mask) {
+      const uint32_t i = (uint32_t)__ffsll((long long)mask) - 1u;
+      mask &= mask - 1ull;
+      if (at < pos_cap) pos[at] = base + i;
+      ++at;
+    }
+  }
+}
 
 __device__ __forceinline__ char upper_char(char c) { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
 
@@ -256,33 +301,30 @@ hipError_t fastq_parse_device(const char* d_text, uint64_t n_bytes, int32_t phre
   Scratch s_nl, s_cnt, s_tmp, s_rec, s_info;
   CK(hipMalloc(&s_nl.p, (size_t)(n / 2 + 16) * 4));  // (a line has at least one byte besides its '\n'... blank lines are errors anyway)
   CK(hipMalloc(&s_cnt.p, 8));
-  hipcub::CountingInputIterator<uint32_t> idx(0u);
-  hipcub::TransformInputIterator<bool, IsNewline, hipcub::CountingInputIterator<uint32_t>> flags(idx, IsNewline{d_text});
-  size_t tmp_bytes = 0;
-  // (a text of nothing but newlines would overflow s_nl: bound the selection by counting first)
-  CK(hipcub::DeviceSelect::Flagged(nullptr, tmp_bytes, idx, flags, (uint32_t*)s_nl.p, (uint32_t*)s_cnt.p, (int)n, stream));
-  CK(hipMalloc(&s_tmp.p, tmp_bytes ? tmp_bytes : 16));
-  {
-    // count pass (reduce over the flags) so that the position array is known to fit
-    size_t rb = 0;
-    CK(hipcub::DeviceReduce::Sum(nullptr, rb, flags, (uint32_t*)s_cnt.p, (int)n, stream));
-    Scratch s_r;
-    CK(hipMalloc(&s_r.p, rb ? rb : 16));
-    CK(hipcub::DeviceReduce::Sum(s_r.p, rb, flags, (uint32_t*)s_cnt.p, (int)n, stream));
-    uint32_t cnt = 0;
-    CK(hipMemcpyAsync(&cnt, s_cnt.p, 4, hipMemcpyDeviceToHost, stream));
-    CK(hipStreamSynchronize(stream));
-    if ((uint64_t)cnt > (uint64_t)n / 2 + 8) {
-      h_info[5] = 1;  // blank lines: not four-line records
-      return hipSuccess;
-    }
-  }
-  CK(hipcub::DeviceSelect::Flagged(s_tmp.p, tmp_bytes, idx, flags, (uint32_t*)s_nl.p, (uint32_t*)s_cnt.p, (int)n, stream));
+  const uint32_t n_tiles = (n + kNlTile - 1) / kNlTile;
+  CK(hipMalloc(&s_tmp.p, (size_t)(n_tiles + 1) * 4));
+  uint32_t* tile_cnt = (uint32_t*)s_tmp.p;
+  Scratch s_scan0;
+  CK(hipMalloc(&s_scan0.p, prims::scan_temp_bytes(n_tiles + 1)));
+  CK(hipMemsetAsync(tile_cnt + n_tiles, 0, 4, stream));
+  const uint32_t pos_cap = n / 2 + 16;
+  hipLaunchKernelGGL(newline_kernel<true>, dim3(n_tiles), dim3(kIngestThreads), 0, stream, d_text, n, tile_cnt, (const uint32_t*)nullptr,
+                     (uint32_t*)nullptr, 0u);
+  CK(hipGetLastError());
+  CK(prims::exclusive_sum_u32(tile_cnt, tile_cnt, n_tiles + 1, s_scan0.p, stream));   // (the entry behind the last tile: the total)
   uint32_t n_nl = 0;
   char last = 0;
-  CK(hipMemcpyAsync(&n_nl, s_cnt.p, 4, hipMemcpyDeviceToHost, stream));
+  CK(hipMemcpyAsync(&n_nl, tile_cnt + n_tiles, 4, hipMemcpyDeviceToHost, stream));
   CK(hipMemcpyAsync(&last, d_text + n_bytes - 1, 1, hipMemcpyDeviceToHost, stream));
   CK(hipStreamSynchronize(stream));
+  // (a text of nothing but newlines would overflow the position array: blank lines are not four-line records anyway)
+  if ((uint64_t)n_nl > (uint64_t)n / 2 + 8) {
+    h_info[5] = 1;
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL(newline_kernel<false>, dim3(n_tiles), dim3(kIngestThreads), 0, stream, d_text, n, (uint32_t*)nullptr, tile_cnt,
+                     (uint32_t*)s_nl.p, pos_cap);
+  CK(hipGetLastError());
   const uint32_t n_lines = n_nl + (last != '\n' ? 1u : 0u);
   if (n_lines % 4u) {
     h_info[5] = 4;
@@ -307,11 +349,9 @@ hipError_t fastq_parse_device(const char* d_text, uint64_t n_bytes, int32_t phre
                      n_records, phred, cutoff, min_len, cut, ads, 32u * W < 255u ? 32u * W : 255u /* one length byte */, rec_start, rec_len, keep, (uint32_t*)s_info.p);
   CK(hipGetLastError());
   // ---- output positions: exclusive prefix of the keep flags ----
-  size_t scan_bytes = 0;
-  CK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, keep, out_idx, (int)n_records, stream));
   Scratch s_scan;
-  CK(hipMalloc(&s_scan.p, scan_bytes ? scan_bytes : 16));
-  CK(hipcub::DeviceScan::ExclusiveSum(s_scan.p, scan_bytes, keep, out_idx, (int)n_records, stream));
+  CK(hipMalloc(&s_scan.p, prims::scan_temp_bytes(n_records)));
+  CK(prims::exclusive_sum_u32(keep, out_idx, n_records, s_scan.p, stream));
   uint32_t last_idx = 0, last_keep = 0, info[8];
   CK(hipMemcpyAsync(&last_idx, out_idx + n_records - 1, 4, hipMemcpyDeviceToHost, stream));
   CK(hipMemcpyAsync(&last_keep, keep + n_records - 1, 4, hipMemcpyDeviceToHost, stream));

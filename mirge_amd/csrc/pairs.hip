@@ -11,10 +11,12 @@
 // cascade needs them, with one stable radix sort per gap (deterministic layout: rows of one key stay
 // in suffix-array order).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
 #include <stdint.h>
 
 #include "kernels.hpp"
+#include "prims.hpp"
 
 namespace mrg {
 
@@ -81,11 +83,7 @@ hipError_t build_pair_tables_device(const uint64_t* sa, const uint32_t* text, ui
   if ((e = hipMalloc((void**)&vals, (size_t)n_rows * 4)) != hipSuccess) return done(e);
   if ((e = hipMalloc((void**)&keys2, (size_t)n_rows * 4)) != hipSuccess) return done(e);
   if ((e = hipMalloc((void**)&vals2, (size_t)n_rows * 4)) != hipSuccess) return done(e);
-  size_t need_sort = 0, need_scan = 0;
-  if ((e = hipcub::DeviceRadixSort::SortPairs(nullptr, need_sort, keys, keys2, vals, vals2, (int)n_rows, 0, 32, stream)) != hipSuccess)
-    return done(e);
-  if ((e = hipcub::DeviceScan::InclusiveSum(nullptr, need_scan, jump, jump, (int)(n_codes + 1), stream)) != hipSuccess) return done(e);
-  const size_t need = need_sort > need_scan ? need_sort : need_scan;
+  const size_t need = std::max(prims::radix_temp_bytes(n_rows), prims::scan_temp_bytes(n_codes + 1));
   if ((e = hipMalloc(&tmp, need ? need : 16)) != hipSuccess) return done(e);
   const uint32_t block = 256, grid = (n_rows + block - 1) / block;
   uint32_t off = 0;
@@ -93,16 +91,18 @@ hipError_t build_pair_tables_device(const uint64_t* sa, const uint32_t* text, ui
     uint32_t* jt = jump + (size_t)t * (n_codes + 1);
     if ((e = hipMemsetAsync(jt, 0, (size_t)(n_codes + 1) * 4, stream)) != hipSuccess) return done(e);
     hipLaunchKernelGGL(pair_keys_kernel, dim3(grid), dim3(block), 0, stream, sa, text, n_rows, anchor, (t + 1u) * anchor, keys, vals);
-    size_t nb = need_sort;
-    if ((e = hipcub::DeviceRadixSort::SortPairs(tmp, nb, keys, keys2, vals, vals2, (int)n_rows, 0, 32, stream)) != hipSuccess) return done(e);
-    hipLaunchKernelGGL(pair_hist_kernel, dim3(grid), dim3(block), 0, stream, keys2, n_rows, jt);
-    nb = need_scan;
-    if ((e = hipcub::DeviceScan::InclusiveSum(tmp, nb, jt, jt, (int)(n_codes + 1), stream)) != hipSuccess) return done(e);
+    // (stable: rows of one key stay in suffix-array order; four passes of eight bits end in the buffers they began in)
+    bool second = false;
+    if ((e = prims::radix_sort_pairs_u32(keys, keys2, vals, vals2, n_rows, 32, tmp, stream, &second)) != hipSuccess) return done(e);
+    const uint32_t* keys_sorted = second ? keys2 : keys;
+    const uint32_t* vals_sorted = second ? vals2 : vals;
+    hipLaunchKernelGGL(pair_hist_kernel, dim3(grid), dim3(block), 0, stream, keys_sorted, n_rows, jt);
+    if ((e = prims::inclusive_sum_u32(jt, jt, n_codes + 1, tmp, stream)) != hipSuccess) return done(e);
     uint32_t n_valid = 0;
     if ((e = hipMemcpyAsync(&n_valid, jt + n_codes, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return done(e);
     if ((e = hipStreamSynchronize(stream)) != hipSuccess) return done(e);
     row_off[t] = off;
-    if (n_valid) hipLaunchKernelGGL(pair_rows_kernel, dim3((n_valid + block - 1) / block), dim3(block), 0, stream, sa, vals2, n_valid, rows + off);
+    if (n_valid) hipLaunchKernelGGL(pair_rows_kernel, dim3((n_valid + block - 1) / block), dim3(block), 0, stream, sa, vals_sorted, n_valid, rows + off);
     off += n_valid;
     if ((e = hipGetLastError()) != hipSuccess) return done(e);
   }
