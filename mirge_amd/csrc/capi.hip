@@ -228,6 +228,7 @@ struct mrg_ctx {
   int64_t fused_step = 0;
   uint64_t* pending_export_out = nullptr;
   hipStream_t pending_export_stream = nullptr;
+  int64_t device_tables = 1;  // mrg_ctx_add_library: a large library's derived tables (dictionary, wide rows, seed buckets) are filled on the device
   int64_t collapse_fast = 1;  // mrg_collapse_run: batches that fit it take the duplication-aware path (0: always the general sort)
   int64_t seed_impl = -1;  // -1 = per launch (run_seed), 0 = seed_kernel (tiles), 1 = wave_seed_kernel, 2 = the same with more registers
   std::vector<DevLib> libs;
@@ -461,6 +462,7 @@ void free_dev_lib(DevLib& l) {
 // The FM arrays of one index into HBM.  wide_rows: also the 16-byte rows; pair_tables: also the
 // anchor-pair tables of 2-mismatch passes.
 int upload_index(mrg_ctx* ctx, const mrg::FmIndex& ix, DevLib& l, bool wide_rows, bool pair_tables) {
+  mrg::StageTimer tm("upload_index");
   int rc;
   l.n = ix.n;
   l.nblk = (uint32_t)ix.blocks.size();
@@ -497,6 +499,7 @@ int upload_index(mrg_ctx* ctx, const mrg::FmIndex& ix, DevLib& l, bool wide_rows
   }
   if ((rc = upload(&l.ftab, ix.ftab))) return rc;
   if (!ix.ctx.empty() && (rc = upload(&l.ctx, ix.ctx))) return rc;
+  tm.lap("blocks, text, sa, jump tables, ctx");
   if (wide_rows) {
     // 16-byte rows for the fused launches: filled on the host in chunks, never kept there
     const size_t n_rows = ix.sa.size(), chunk = 1u << 24;
@@ -509,6 +512,7 @@ int upload_index(mrg_ctx* ctx, const mrg::FmIndex& ix, DevLib& l, bool wide_rows
       HIP_TRY(hipMemcpy(l.sa16 + lo * 4, buf.data(), (hi - lo) * 16, hipMemcpyHostToDevice));
     }
   }
+  tm.lap("wide rows");
   if (pair_tables && ix.n <= mrg::kPairMaxBases && ix.n >= 4u * mrg::kPairAnchor) {
     mrg::PairTables pt, pt_s;
     try {
@@ -527,6 +531,7 @@ int upload_index(mrg_ctx* ctx, const mrg::FmIndex& ix, DevLib& l, bool wide_rows
     if ((rc = upload(&l.pair_rows, pt.rows))) return rc;
     l.pair_anchor = pt.anchor;
   }
+  tm.lap("pair tables");
   if (!ix.kbits.empty() && (rc = upload(&l.kbits, ix.kbits))) return rc;
   l.kbits_host = ix.kbits;  // the interleaved tables of fused rounds are built from it
   if ((rc = upload(&l.seg_start, ix.seg_start))) return rc;
@@ -548,8 +553,10 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
       if (l) free_dev_lib(*l);
     }
   } guard{&l};
+  mrg::StageTimer tm("add_library");
   int rc = upload_index(ctx, ix, l, ix.n >= mrg::kWideRowMinBases && ctx->wide_rows_16, ctx->pair_seeds != 0);
   if (rc) return rc;
+  tm.lap("index arrays + wide rows + pair tables");
   // Exact-match dictionary: every library of at most dict_max_bases bases whose slot array (16 B x 2..4
   // slots per base: 8.6 GB for the 137 Mbp mRNA library) leaves 8 GB of this GPU's HBM free.  A pass
   // without seed mismatch on it -- mRNA `-n 0`, RAP:584/598 -- is then ONE 16-byte gather per read
@@ -560,6 +567,29 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     want_dict = need != 0 && free_b > need + (8ull << 30);
+  }
+  if (want_dict && ctx->device_tables && ix.n > mrg::kDictSmallBases) {
+    // a large library's dictionary is filled on the device, from the text and segment tables uploaded above
+    // (dictbuild.hip): no host build, no 8.6 GB upload
+    const uint64_t bytes = mrg::exact_dict_bytes(ix, (uint32_t)ctx->dict_key);
+    uint32_t l2 = 0;
+    while (bytes && (16ull << l2) < bytes) ++l2;
+    if (bytes && mrg::exact_dict_device_ok(ix.n, (uint32_t)ctx->dict_key, l2)) {
+      void* tmp = nullptr;
+      HIP_TRY(hipMalloc((void**)&l.dict_slots, bytes));
+      hipError_t e = hipMalloc(&tmp, mrg::exact_dict_device_temp_bytes(ix.n));
+      uint64_t counts[2] = {0, 0};
+      if (e == hipSuccess)
+        e = mrg::build_exact_dict_device(l.text, ix.n, l.seg_start, l.seg_ref, l.seg_off, l.chunk_seg, (uint32_t)ctx->dict_key, l2, l.dict_slots, tmp,
+                                         counts, nullptr);
+      (void)hipFree(tmp);
+      if (e != hipSuccess) return fail(MRG_ERR_HIP, "mrg_ctx_add_library: dictionary build on the device: %s", hipGetErrorString(e));
+      l.dict_log2 = l2;
+      l.dict_key = (uint32_t)ctx->dict_key;
+      l.dict_n_keys = counts[0];
+      l.dict_n_overflow = counts[1];
+      want_dict = false;
+    }
   }
   if (want_dict) {
     const mrg::ExactDict* ed = nullptr;
@@ -577,6 +607,7 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
       if (ix.n > mrg::kDictSmallBases) h->drop_dict((uint32_t)ctx->dict_key);
     }
   }
+  tm.lap("dictionary");
   if (ctx->dict && ctx->seed_buckets && l.sa16) {
     // large library where a seed of 11 bases has a few rows: those rows in one line per seed
     const uint32_t bk = mrg::seed_bucket_k(ix);
@@ -604,6 +635,7 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
     l.host_seqs.resize(ix.names.size());
     for (uint32_t i = 0; i < l.host_seqs.size(); ++i) l.host_seqs[i] = mrg::entry_sequence(ix, i);
   }
+  tm.lap("seed buckets + host entries");
   ctx->libs.push_back(l);
   guard.l = nullptr;
   *lib_id = (int32_t)ctx->libs.size() - 1;
@@ -679,6 +711,8 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->fused_step = value != 0;
   } else if (k == "collapse_fast") {
     ctx->collapse_fast = value != 0;
+  } else if (k == "device_tables") {
+    ctx->device_tables = value != 0;  // takes effect for libraries added afterwards
   } else if (k == "dict_max_bases") {
     if (value < 0) return fail(MRG_ERR_ARG, "dict_max_bases must be >= 0");
     ctx->dict_max_bases = value;  // takes effect for libraries added afterwards

@@ -3,6 +3,9 @@
 #include "fm_index.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -11,6 +14,20 @@
 #include <thread>
 
 namespace mrg {
+
+namespace {
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+StageTimer::StageTimer(const char* w) : what(w), on(std::getenv("MIRGE_AMD_TIMING") != nullptr), t0(now_s()), t_last(t0) {}
+void StageTimer::lap(const char* stage) {
+  if (!on) return;
+  const double t = now_s();
+  std::fprintf(stderr, "[timing] %s: %s %.3f s\n", what, stage, t - t_last);
+  t_last = t;
+}
+StageTimer::~StageTimer() {
+  if (on) std::fprintf(stderr, "[timing] %s: total %.3f s\n", what, now_s() - t0);
+}
 
 // ---------------------------------------------------------------------------
 // Suffix array by induced sorting.  `s[n-1]` is the unique smallest symbol.
@@ -616,6 +633,7 @@ void save_index(const FmIndex& ix, const std::string& path) {
 }
 
 void load_index(const std::string& path, FmIndex& ix) {
+  StageTimer tm("load_index");
   std::ifstream in(path, std::ios::binary);
   if (!in) throw std::runtime_error("cannot open " + path);
   char magic[8];
@@ -648,6 +666,7 @@ void load_index(const std::string& path, FmIndex& ix) {
   get_vec(in, ix.seg_ref);
   get_vec(in, ix.seg_off);
   get_vec(in, ix.chunk_seg);
+  tm.lap("read file");
   if (ix.sa.size() != (size_t)ix.n + 1 || ix.blocks.size() != (size_t)((ix.n + 1) >> 5) + 1 ||
       ix.super.size() != ((size_t)((ix.n + 1) >> kSuperShift) + 1) * 4 ||
       ix.text.size() < (size_t)(ix.n >> 4) + 3)
@@ -664,9 +683,13 @@ void load_index(const std::string& path, FmIndex& ix) {
   for (size_t c = 0; ok && c < ix.chunk_seg.size(); ++c) ok = n_seg == 0 || ix.chunk_seg[c] < n_seg;
   for (size_t i = 0; ok && i < ix.sa.size(); ++i) ok = (uint32_t)ix.sa[i] <= ix.n;
   if (!ok) throw std::runtime_error("index file inconsistent (segment tables)");
+  tm.lap("validate");
   build_jump_tables(ix);
+  tm.lap("jump tables");
   build_row_context(ix);
+  tm.lap("row context");
   build_kmer_bits(ix);
+  tm.lap("kmer bits");
 }
 
 }  // namespace mrg

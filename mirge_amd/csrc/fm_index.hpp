@@ -34,6 +34,16 @@
 
 namespace mrg {
 
+// Stage timing of the library-load path, to stderr, when MIRGE_AMD_TIMING is set (scripts/lib_load_timing.py).
+struct StageTimer {
+  const char* what;
+  bool on;
+  double t0, t_last;
+  explicit StageTimer(const char* w);
+  void lap(const char* stage);
+  ~StageTimer();
+};
+
 struct OccBlock {
   uint16_t cnt[4];
   uint32_t lo;

@@ -366,6 +366,15 @@ struct CompactRuns {
 };
 hipError_t expand_compact(const uint64_t* d_bits, const CompactRuns& runs, const uint8_t* d_quant8, const uint32_t* d_esc, uint64_t n_esc,
                           uint64_t n, uint32_t n_samples, uint64_t* d_reads, uint8_t* d_lens, uint32_t* d_quant, hipStream_t stream);
+// dictbuild.hip: the exact-match dictionary of a large library filled on the device (same slot format and rules as
+// dict_index.cpp).  slots: 2^log2_slots x 16 bytes, zeroed by the call; tmp: exact_dict_device_temp_bytes(n) bytes;
+// counts[0] = positions stored, counts[1] = home slots whose chain overflowed.  Synchronises the stream.
+bool exact_dict_device_ok(uint32_t n, uint32_t key_bases, uint32_t log2_slots);
+size_t exact_dict_device_temp_bytes(uint32_t n);
+hipError_t build_exact_dict_device(const uint32_t* text, uint32_t n, const uint32_t* seg_start, const uint32_t* seg_ref, const uint32_t* seg_off,
+                                   const uint32_t* chunk_seg, uint32_t key_bases, uint32_t log2_slots, void* slots, void* tmp, uint64_t counts[2],
+                                   hipStream_t stream);
+
 hipError_t launch_pack_assignments(const int8_t* pass_id, const int32_t* ref_id, const int32_t* pos, const uint8_t* mm, uint64_t n,
                                    uint32_t* packed, hipStream_t stream);
 

@@ -1,0 +1,108 @@
+"""GPU parity (-m gpu): the exact-match dictionary of a LARGE library filled on the device (csrc/dictbuild.hip) answers
+every read as the host-built one does (csrc/dict_index.cpp) and as the exhaustive scan does -- on a library with what
+makes dictionaries hard: an element with thousands of copies (chains overflow into the FM index), duplicated entries,
+N runs (segments), keys that end at a segment's last base."""
+import numpy as np
+import pytest
+
+from oracle import model
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(rng, n):
+    return "".join("ACGT"[c] for c in rng.integers(0, 4, n))
+
+
+def make_library(rng, n_entries=5200, lo=700, hi=1100):
+    element = rnd(rng, 34)
+    seqs = []
+    for i in range(n_entries):
+        s = rnd(rng, int(rng.integers(lo, hi)))
+        if i % 2 == 0:        # the element, 2 600 copies: its 16-mers overflow every chain
+            o = int(rng.integers(0, len(s) - 40))
+            s = s[:o] + element + s[o + 34:]
+        if i % 97 == 0:       # an N run: two segments
+            o = int(rng.integers(100, len(s) - 100))
+            s = s[:o] + "N" * int(rng.integers(1, 40)) + s[o:]
+        seqs.append(s)
+    seqs += [seqs[7], seqs[7], seqs[11][:300]]      # duplicated entries and a prefix copy
+    names = ["big%d" % i for i in range(len(seqs))]
+    return names, seqs, element
+
+
+def make_reads(rng, seqs, element, n=12000):
+    reads = []
+    for _ in range(n):
+        s = seqs[int(rng.integers(0, len(seqs)))]
+        L = int(rng.integers(16, 33))
+        what = rng.random()
+        if what < 0.55:         # a substring somewhere
+            o = int(rng.integers(0, len(s) - L))
+            r = s[o:o + L]
+        elif what < 0.65:       # ... ending at the entry's last base / starting at its first
+            r = s[len(s) - L:] if rng.random() < 0.5 else s[:L]
+        elif what < 0.80:       # inside / across the repeated element
+            k = int(rng.integers(0, 12))
+            r = (element[k:] + rnd(rng, 32))[:L] if rng.random() < 0.5 else element[k:k + min(L, 34 - k)]
+        elif what < 0.90:       # one or two substitutions
+            o = int(rng.integers(0, len(s) - L))
+            r = list(s[o:o + L])
+            for p in rng.integers(0, L, int(rng.integers(1, 3))):
+                r[p] = "ACGT"[("ACGT".find(r[p]) + 1) % 4] if r[p] in "ACGT" else "A"
+            r = "".join(r)
+        else:
+            r = rnd(rng, L)
+        if "N" not in r and len(r) >= 16:
+            reads.append(r)
+    return list(dict.fromkeys(reads))
+
+
+def test_device_built_dictionary_equals_the_host_built_one_and_the_scan(native_lib, oracle_lib):
+    from mirge_amd import pack
+    from mirge_amd.engine import Engine, ReadSet
+    from mirge_amd.index import FmIndex
+    rng = np.random.default_rng(41)
+    names, seqs, element = make_library(rng)
+    assert sum(map(len, seqs)) > (1 << 22)          # beyond kDictSmallBases: the parallel builds
+    ix = FmIndex.build(names, seqs)
+    decoy = FmIndex.build(["decoy"], ["GATTACAGATTACAGGCCTTAAGGCCTTAACGCGCGTATATA" * 3])
+    reads = make_reads(rng, seqs, element)
+    w, l, nm = pack.pack_reads(reads)
+    assert w.shape[0] == 1 and nm is None
+    results, stats = {}, {}
+    for dev_tables in (1, 0):
+        eng = Engine(0)
+        eng.set_option("device_tables", dev_tables)
+        eng.add_library("big", ix, exact_dict=True)
+        eng.add_library("decoy", decoy)
+        stats[dev_tables] = eng.library_dict_stats("big")
+        first = dict(lib="decoy", seed_len=28, max_mm_seed=0, max_mm_total=2)
+        for (seed_len, mm_total, t5, t3) in ((28, 2, 0, 0), (1024, 0, 0, 0), (28, 2, 1, 2)):
+            pol = dict(lib="big", seed_len=seed_len, max_mm_seed=0, max_mm_total=mm_total, trim5=t5, trim3=t3)
+            for plan in ([pol], [first, pol]):      # exact_dict_kernel, and a dictionary unit of a seed launch
+                res = eng.cascade(ReadSet(w, l, None, None, device=eng.device), eng.make_passes(plan))
+                results[(dev_tables, seed_len, t5, len(plan))] = tuple(a.copy() for a in res.to_host())
+        eng.close()
+    # (positions stored, homes whose chain overflowed: the layout -- and so which home overflows first -- depends on the
+    # insertion order, what a lookup finds does not)
+    assert stats[1][1] > 0 and stats[0][1] > 0
+    assert abs(stats[1][0] - stats[0][0]) < 0.01 * stats[0][0]
+    for key, got in results.items():
+        if key[0] != 1:
+            continue
+        want = results[(0,) + key[1:]]
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b), key
+    # ... and both equal the exhaustive scan (a sample: the scan reads 4.6 Mbp per read)
+    lib = model.Library(names, seqs)
+    pick = rng.choice(len(reads), 400, replace=False)
+    sub = [reads[i] for i in pick]
+    for (seed_len, mm_total, t5, t3) in ((28, 2, 0, 0), (1024, 0, 0, 0), (28, 2, 1, 2)):
+        trimmed = [r[t5:len(r) - t3] if t3 else r[t5:] for r in sub]
+        want_ref, want_pos, want_mm = model.align_batch(lib, trimmed, seed_len, 0, mm_total)
+        for n_plan in (1, 2):
+            pass_id, ref_id, pos, mm = results[(1, seed_len, t5, n_plan)]
+            for j, i in enumerate(pick):
+                got = (int(ref_id[i]), int(pos[i]), int(mm[i])) if pass_id[i] == n_plan - 1 else (-1, -1, -1)
+                assert got == (int(want_ref[j]), int(want_pos[j]), int(want_mm[j])), (reads[i], seed_len, t5, n_plan)
