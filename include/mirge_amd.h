@@ -211,6 +211,8 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * the launches of a step, which may be captured into a hipGraph;
  * "collapse_fast" = 1 (default) / 0: mrg_collapse_run takes its duplication-aware path for batches that fit it
  * (one-word reads without N, at most 29 nt) / always the general column-by-column sort;
+ * "device_tables" = 1 (default) / 0: libraries added afterwards get the derived tables of a large library (>= 2^20
+ * bases) filled on the device / built on the host and uploaded (mrg_ctx_library_check_tables);
  * "wide_rows_16", "round_large": see DESIGN.md. */
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);
 int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,
@@ -220,6 +222,15 @@ int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,
  * slot's chain overflowed (a read whose key is one of those is answered by the slow FM fallback), log2 of the
  * dictionary's slots (0: no dictionary), k of its seed buckets (0: none) }. */
 int mrg_ctx_library_stats(const mrg_ctx *ctx, int32_t lib, uint64_t *out4);
+/* Self-check of a resident library's derived tables (round 5).  With "device_tables" = 1 (default) a library of at
+ * least 2^20 bases gets its jump tables, row context, wide rows, seed buckets (csrc/libtables.hip) and exact-match
+ * dictionary (csrc/dictbuild.hip) filled ON THE DEVICE from the suffix-array rows and the packed text -- what replaces
+ * the `.ebwt` load of runAnnotationPipeline.py:643 at the start of a run; the index file stores none of them.  This call
+ * rebuilds the first four on the host (fm_index.cpp) and compares them with the device arrays word by word:
+ * mismatches4 = { jump tables, row context, wide rows, seed buckets }, UINT64_MAX for a table the library does not
+ * have.  (The dictionary's layout depends on who fills it; what a lookup finds does not: tests/test_gpu_dictbuild.py.)
+ * Slow -- seconds of host time for a 137 Mbp library: tests and bench gates call it, a run does not. */
+int mrg_ctx_library_check_tables(mrg_ctx *ctx, int32_t lib, const mrg_index *index, uint64_t *mismatches4);
 /* A context is used by one host thread at a time (calls on it are serialised by the caller).  It keeps
  * one device scratch arena, grown on demand by mrg_collapse_run (40 B per raw read + 64 MB) and
  * mrg_list_best_count and reused by later calls; this frees it (after synchronising the device), e.g.

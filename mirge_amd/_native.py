@@ -90,6 +90,7 @@ SIGNATURES = {
     "mrg_ctx_device_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64),
                                       C.c_char_p, C.c_uint32]),
     "mrg_ctx_library_stats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]),
+    "mrg_ctx_library_check_tables": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_uint64)]),
     "mrg_ctx_release_scratch": (C.c_int, [C.c_void_p]),
     "mrg_cascade_workspace_bytes": (C.c_int, [C.c_uint64, C.POINTER(C.c_uint64)]),
     "mrg_cascade_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,

@@ -24,7 +24,15 @@
 #include "tables.hpp"
 
 struct mrg_index {
-  mrg::FmIndex ix;
+  mutable mrg::FmIndex ix;
+  // A large library's jump tables and row context are built when somebody needs them on the HOST (mrg_index_get_view, a
+  // context without `device_tables`): fm_index.hpp, derive_tables.
+  mutable std::mutex derive_mutex;
+  const mrg::FmIndex& derived() const {
+    std::lock_guard<std::mutex> g(derive_mutex);
+    mrg::derive_tables(ix);
+    return ix;
+  }
   // exact-match dictionaries by key length, built on first request (mrg_index_get_dict,
   // mrg_ctx_add_library) and kept for the life of the index
   mutable std::map<uint32_t, mrg::ExactDict> dicts;
@@ -79,6 +87,7 @@ struct DevLib {
   uint64_t* sa = nullptr;
   uint32_t* ctx = nullptr;
   uint32_t* sa16 = nullptr;  // wide rows of a large library (fm_index.hpp: fill_wide_rows)
+  bool tables_on_device = false;  // jump tables / row context / wide rows / buckets were filled by libtables.hip
   uint32_t* buckets = nullptr;  // seed buckets (fm_index.hpp: fill_seed_buckets), 128 B per k-mer of bucket_k bases
   uint32_t bucket_k = 0;
   // pair tables of a small library (fm_index.hpp: PairTables), for 2-mismatch passes
@@ -373,7 +382,7 @@ int mrg_index_seq(const mrg_index* h, uint32_t i, char* buf, uint32_t cap, uint3
 
 int mrg_index_get_view(const mrg_index* h, mrg_index_view* v) {
   if (!h || !v) return fail(MRG_ERR_ARG, "mrg_index_get_view: null argument");
-  const mrg::FmIndex& ix = h->ix;
+  const mrg::FmIndex& ix = h->derived();
   v->blocks = reinterpret_cast<const uint32_t*>(ix.blocks.data());
   v->super = ix.super.data();
   v->text = ix.text.data();
@@ -497,10 +506,35 @@ int upload_index(mrg_ctx* ctx, const mrg::FmIndex& ix, DevLib& l, bool wide_rows
       l.tabs.off[i] = offs[t];
     }
   }
-  if ((rc = upload(&l.ftab, ix.ftab))) return rc;
-  if (!ix.ctx.empty() && (rc = upload(&l.ctx, ix.ctx))) return rc;
-  tm.lap("blocks, text, sa, jump tables, ctx");
-  if (wide_rows) {
+  const bool on_device = ctx->device_tables && ix.n >= mrg::kLazyDeriveBases;
+  if (on_device) {
+    // jump tables, row context and wide rows from the rows and the text just uploaded (libtables.hip)
+    size_t total = 0;
+    for (int t = 0; t < 4; ++t)
+      if (ix.ftab_ks[t]) total += ((size_t)1 << (2 * ix.ftab_ks[t])) + 1;
+    tm.lap("blocks, text, sa");
+    void* tmp = nullptr;
+    HIP_TRY(hipMalloc((void**)&l.ftab, total * 4));
+    HIP_TRY(hipMalloc(&tmp, mrg::jump_tables_device_temp_bytes(ix.n + 1u)));
+    hipError_t e = mrg::build_jump_tables_device(l.text, l.text_words, reinterpret_cast<const uint64_t*>(l.sa), ix.n, ix.ftab_ks, l.ftab, tmp, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(MRG_ERR_HIP, "mrg_ctx_add_library: jump tables on the device: %s", hipGetErrorString(e));
+    HIP_TRY(hipMalloc((void**)&l.ctx, (size_t)(ix.n + 1u) * 4));
+    HIP_TRY(mrg::build_row_context_device(l.text, l.text_words, reinterpret_cast<const uint64_t*>(l.sa), ix.n, l.ctx, nullptr));
+    if (wide_rows) {
+      HIP_TRY(hipMalloc((void**)&l.sa16, (size_t)(ix.n + 1u) * 16));
+      HIP_TRY(mrg::build_wide_rows_device(l.text, l.text_words, reinterpret_cast<const uint64_t*>(l.sa), ix.n, l.sa16, nullptr));
+    }
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    l.tables_on_device = true;
+    tm.lap("jump tables, row context, wide rows (device)");
+  } else {
+    if ((rc = upload(&l.ftab, ix.ftab))) return rc;
+    if (!ix.ctx.empty() && (rc = upload(&l.ctx, ix.ctx))) return rc;
+    tm.lap("blocks, text, sa, jump tables, ctx");
+  }
+  if (wide_rows && !on_device) {
     // 16-byte rows for the fused launches: filled on the host in chunks, never kept there
     const size_t n_rows = ix.sa.size(), chunk = 1u << 24;
     HIP_TRY(hipMalloc((void**)&l.sa16, n_rows * 16));
@@ -545,7 +579,8 @@ int upload_index(mrg_ctx* ctx, const mrg::FmIndex& ix, DevLib& l, bool wide_rows
 int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
   if (!ctx || !h || !lib_id) return fail(MRG_ERR_ARG, "mrg_ctx_add_library: null argument");
   HIP_TRY(hipSetDevice(ctx->device));
-  const mrg::FmIndex& ix = h->ix;
+  const bool tables_dev = ctx->device_tables && h->ix.n >= mrg::kLazyDeriveBases;
+  const mrg::FmIndex& ix = tables_dev ? h->ix : h->derived();
   DevLib l;
   struct Guard {  // a failed upload must not leak the arrays uploaded before it
     DevLib* l;
@@ -615,7 +650,14 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
       const uint64_t n_codes = 1ull << (2 * bk), chunk = 1ull << 18;
       size_t free_b = 0, total_b = 0;
       HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-      if (free_b > n_codes * 128ull + (4ull << 30) && hipMalloc((void**)&l.buckets, n_codes * 128ull) == hipSuccess) {
+      if (l.tables_on_device && free_b > n_codes * 128ull + (4ull << 30) && hipMalloc((void**)&l.buckets, n_codes * 128ull) == hipSuccess) {
+        size_t tab_base = 0;
+        for (int t = 0; t < 4 && ix.ftab_ks[t] != bk; ++t)
+          if (ix.ftab_ks[t]) tab_base += ((size_t)1 << (2 * ix.ftab_ks[t])) + 1;
+        HIP_TRY(mrg::build_seed_buckets_device(l.text, l.text_words, reinterpret_cast<const uint64_t*>(l.sa), ix.n, l.ftab + tab_base, bk, l.buckets, nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        l.bucket_k = bk;
+      } else if (!l.tables_on_device && free_b > n_codes * 128ull + (4ull << 30) && hipMalloc((void**)&l.buckets, n_codes * 128ull) == hipSuccess) {
         std::vector<uint32_t> buf(chunk * 32);
         for (uint64_t lo = 0; lo < n_codes; lo += chunk) {
           const uint64_t hi = std::min(n_codes, lo + chunk);
@@ -747,6 +789,58 @@ int mrg_ctx_library_stats(const mrg_ctx* ctx, int32_t lib, uint64_t* out4) {
   out4[1] = l.dict_n_overflow;
   out4[2] = l.dict_slots ? l.dict_log2 : 0;
   out4[3] = l.buckets ? l.bucket_k : 0;
+  return MRG_OK;
+}
+
+int mrg_ctx_library_check_tables(mrg_ctx* ctx, int32_t lib, const mrg_index* index, uint64_t* mismatches4) {
+  if (!ctx || !index || !mismatches4) return fail(MRG_ERR_ARG, "mrg_ctx_library_check_tables: null argument");
+  if (lib < 0 || (size_t)lib >= ctx->libs.size()) return fail(MRG_ERR_ARG, "mrg_ctx_library_check_tables: unknown library %d", lib);
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const DevLib& l = ctx->libs[lib];
+  try {
+    const mrg::FmIndex& ix = index->derived();
+    if (ix.n != l.n) return fail(MRG_ERR_ARG, "mrg_ctx_library_check_tables: not the index this library was made from");
+    for (int t = 0; t < 4; ++t) mismatches4[t] = ~0ull;
+    std::vector<uint32_t> got, want;
+    auto compare = [&](const uint32_t* dev, const uint32_t* host, size_t words) -> uint64_t {
+      uint64_t bad = 0;
+      const size_t chunk = (size_t)1 << 24;
+      for (size_t lo = 0; lo < words; lo += chunk) {
+        const size_t m = std::min(chunk, words - lo);
+        got.resize(m);
+        if (hipMemcpy(got.data(), dev + lo, m * 4, hipMemcpyDeviceToHost) != hipSuccess) return ~0ull - 1;
+        for (size_t i = 0; i < m; ++i) bad += got[i] != host[lo + i];
+      }
+      return bad;
+    };
+    if (l.ftab) mismatches4[0] = compare(l.ftab, ix.ftab.data(), ix.ftab.size());
+    if (l.ctx && !ix.ctx.empty()) mismatches4[1] = compare(l.ctx, ix.ctx.data(), ix.ctx.size());
+    if (l.sa16) {
+      uint64_t bad = 0;
+      const size_t n_rows = ix.sa.size(), chunk = (size_t)1 << 22;
+      for (size_t lo = 0; lo < n_rows; lo += chunk) {
+        const size_t hi = std::min(n_rows, lo + chunk);
+        want.resize((hi - lo) * 4);
+        mrg::fill_wide_rows(ix, lo, hi, want.data());
+        bad += compare(l.sa16 + lo * 4, want.data(), want.size());
+      }
+      mismatches4[2] = bad;
+    }
+    if (l.buckets && l.bucket_k) {
+      uint64_t bad = 0;
+      const uint64_t n_codes = 1ull << (2 * l.bucket_k), chunk = 1ull << 18;
+      for (uint64_t lo = 0; lo < n_codes; lo += chunk) {
+        const uint64_t hi = std::min(n_codes, lo + chunk);
+        want.resize((hi - lo) * 32);
+        mrg::fill_seed_buckets(ix, l.bucket_k, lo, hi, want.data());
+        bad += compare(l.buckets + lo * 32, want.data(), want.size());
+      }
+      mismatches4[3] = bad;
+    }
+  } catch (const std::exception& e) {
+    return fail(MRG_ERR_NOMEM, "mrg_ctx_library_check_tables: %s", e.what());
+  }
   return MRG_OK;
 }
 

@@ -315,13 +315,27 @@ void fill_jump_table(const FmIndex& ix, uint32_t k, uint32_t* tab) {
 
 }  // namespace
 
-void build_jump_tables(FmIndex& ix) {
+void plan_jump_tables(FmIndex& ix) {
   uint32_t k_log = 1;
   while (k_log < 14 && (1ull << (2 * k_log)) < ix.n) ++k_log;
   ix.ftab_ks[1] = (uint8_t)std::min(11u, std::max(8u, k_log));
   ix.ftab_ks[0] = k_log > 11 ? (uint8_t)k_log : (ix.ftab_ks[1] < 11 ? (uint8_t)(ix.ftab_ks[1] + 1) : 0);
   ix.ftab_ks[2] = 6;
   ix.ftab_ks[3] = 4;
+}
+
+void derive_tables(FmIndex& ix) {
+  if (ix.derived) return;
+  StageTimer tm("derive_tables (host)");
+  build_jump_tables(ix);
+  tm.lap("jump tables");
+  build_row_context(ix);
+  tm.lap("row context");
+  ix.derived = true;
+}
+
+void build_jump_tables(FmIndex& ix) {
+  plan_jump_tables(ix);
   size_t total = 0, base[4] = {0, 0, 0, 0};
   for (int t = 0; t < 4; ++t) {
     base[t] = total;
@@ -566,9 +580,14 @@ void build_index(const std::vector<std::string>& names,
     }
     ix.sa[i] = row;
   }
-  build_jump_tables(ix);
-  build_row_context(ix);
   build_kmer_bits(ix);
+  if (ix.n >= kLazyDeriveBases) {
+    plan_jump_tables(ix);
+    ix.derived = false;
+  } else {
+    build_jump_tables(ix);
+    build_row_context(ix);
+  }
 }
 
 std::string entry_sequence(const FmIndex& ix, uint32_t r) {
@@ -684,12 +703,15 @@ void load_index(const std::string& path, FmIndex& ix) {
   for (size_t i = 0; ok && i < ix.sa.size(); ++i) ok = (uint32_t)ix.sa[i] <= ix.n;
   if (!ok) throw std::runtime_error("index file inconsistent (segment tables)");
   tm.lap("validate");
-  build_jump_tables(ix);
-  tm.lap("jump tables");
-  build_row_context(ix);
-  tm.lap("row context");
   build_kmer_bits(ix);
-  tm.lap("kmer bits");
+  if (ix.n >= kLazyDeriveBases) {
+    plan_jump_tables(ix);
+    ix.derived = false;
+  } else {
+    build_jump_tables(ix);
+    build_row_context(ix);
+  }
+  tm.lap("derived tables of a small library");
 }
 
 }  // namespace mrg

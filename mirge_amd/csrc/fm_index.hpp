@@ -77,6 +77,9 @@ struct FmIndex {
   std::vector<uint32_t> kbits;
   uint8_t ftab_ks[4] = {0, 0, 0, 0};  // k of each table, descending; 0 = table absent
   std::vector<uint32_t> ftab;         // 4^k + 1 row boundaries per table, the tables of ftab_ks back to back
+  // false: ftab / ctx are not built yet (a library of >= kLazyDeriveBases bases: a context with `device_tables` fills
+  // them on the GPU from sa + text and never needs them here; whoever does calls derive_tables first)
+  bool derived = true;
   std::vector<uint32_t> seg_start, seg_ref, seg_off, chunk_seg;
 };
 
@@ -85,6 +88,9 @@ void build_index(const std::vector<std::string>& names,
                  const std::vector<std::string>& seqs, FmIndex& out);
 void read_fasta(const std::string& path, std::vector<std::string>& names,
                 std::vector<std::string>& seqs);
+void plan_jump_tables(FmIndex& ix);   // ftab_ks only
+void derive_tables(FmIndex& ix);      // jump tables, row context, 9-mer bitmap, if not built yet (not thread safe)
+constexpr uint32_t kLazyDeriveBases = 1u << 20;
 void build_jump_tables(FmIndex& ix);  // from sa + text
 void build_row_context(FmIndex& ix);  // from sa + text
 void build_kmer_bits(FmIndex& ix);    // from text

@@ -366,6 +366,17 @@ struct CompactRuns {
 };
 hipError_t expand_compact(const uint64_t* d_bits, const CompactRuns& runs, const uint8_t* d_quant8, const uint32_t* d_esc, uint64_t n_esc,
                           uint64_t n, uint32_t n_samples, uint64_t* d_reads, uint8_t* d_lens, uint32_t* d_quant, hipStream_t stream);
+// libtables.hip: a large library's derived tables filled on the device from its rows and packed text (each restates the
+// fm_index.cpp function named beside it).  ks: the jump tables' k in storage order (0 = absent); tmp of
+// jump_tables_device_temp_bytes(n + 1) bytes.  Asynchronous on `stream`.
+size_t jump_tables_device_temp_bytes(uint32_t n_rows);
+hipError_t build_jump_tables_device(const uint32_t* text, uint32_t text_words, const uint64_t* sa, uint32_t n, const uint8_t ks[4], uint32_t* ftab,
+                                    void* tmp, hipStream_t stream);                                                              // build_jump_tables
+hipError_t build_row_context_device(const uint32_t* text, uint32_t text_words, const uint64_t* sa, uint32_t n, uint32_t* ctx, hipStream_t stream);  // build_row_context
+hipError_t build_wide_rows_device(const uint32_t* text, uint32_t text_words, const uint64_t* sa, uint32_t n, uint32_t* sa16, hipStream_t stream);   // fill_wide_rows
+hipError_t build_seed_buckets_device(const uint32_t* text, uint32_t text_words, const uint64_t* sa, uint32_t n, const uint32_t* tab, uint32_t k,
+                                     uint32_t* buckets, hipStream_t stream);                                                     // fill_seed_buckets
+
 // dictbuild.hip: the exact-match dictionary of a large library filled on the device (same slot format and rules as
 // dict_index.cpp).  slots: 2^log2_slots x 16 bytes, zeroed by the call; tmp: exact_dict_device_temp_bytes(n) bytes;
 // counts[0] = positions stored, counts[1] = home slots whose chain overflowed.  Synchronises the stream.

@@ -176,6 +176,14 @@ class Engine:
         check(self._lib.mrg_ctx_library_stats(self._h, self.libs[key], out))
         return int(out[0]), int(out[1])
 
+    def check_tables(self, key):
+        """Words in which a resident library's jump tables / row context / wide rows / seed buckets differ from the host
+        functions' (None = the library has no such table) -- mrg_ctx_library_check_tables: 0 everywhere is the bar."""
+        out = (C.c_uint64 * 4)()
+        check(self._lib.mrg_ctx_library_check_tables(self._h, self.libs[key], self.indexes[key]._h, out))
+        names = ("jump_tables", "row_context", "wide_rows", "seed_buckets")
+        return {n: (None if int(v) == 2 ** 64 - 1 else int(v)) for n, v in zip(names, out)}
+
     # ------------------------------------------------------------------
     def mirge_passes(self, spike_in=False):
         """PassCfg array for the reference's cascade (runAnnotationPipeline.py:574-599)."""

@@ -77,6 +77,9 @@ def test_device_built_dictionary_equals_the_host_built_one_and_the_scan(native_l
         eng.add_library("big", ix, exact_dict=True)
         eng.add_library("decoy", decoy)
         stats[dev_tables] = eng.library_dict_stats("big")
+        # jump tables, row context, wide rows (and seed buckets, where a library has them): the device's = the host's
+        chk = eng.check_tables("big")
+        assert chk["jump_tables"] == 0 and chk["row_context"] == 0 and chk["wide_rows"] == 0 and chk["seed_buckets"] in (0, None), (dev_tables, chk)
         first = dict(lib="decoy", seed_len=28, max_mm_seed=0, max_mm_total=2)
         for (seed_len, mm_total, t5, t3) in ((28, 2, 0, 0), (1024, 0, 0, 0), (28, 2, 1, 2)):
             pol = dict(lib="big", seed_len=seed_len, max_mm_seed=0, max_mm_total=mm_total, trim5=t5, trim3=t3)
@@ -106,3 +109,28 @@ def test_device_built_dictionary_equals_the_host_built_one_and_the_scan(native_l
             for j, i in enumerate(pick):
                 got = (int(ref_id[i]), int(pos[i]), int(mm[i])) if pass_id[i] == n_plan - 1 else (-1, -1, -1)
                 assert got == (int(want_ref[j]), int(want_pos[j]), int(want_mm[j])), (reads[i], seed_len, t5, n_plan)
+
+
+def test_device_built_tables_of_a_library_with_seed_buckets(native_lib, oracle_lib):
+    """An 11 Mbp-class library (here 2.2 Mbp .. the size where an 11-mer has 0.25-4 rows) gets seed buckets: jump tables
+    with k = 11 / 12, row context, wide rows and buckets from libtables.hip equal the host's word for word; a library
+    with N runs (text positions that sort out of code order) and a tiny one beside it."""
+    from mirge_amd.engine import Engine
+    from mirge_amd.index import FmIndex
+    rng = np.random.default_rng(43)
+    seqs = [rnd(rng, int(rng.integers(300, 3000))) for _ in range(1400)]
+    for i in range(0, len(seqs), 50):          # N runs, also at the very start / end of an entry
+        s = seqs[i]
+        o = int(rng.integers(0, len(s) - 20))
+        seqs[i] = ("NN" if i % 100 == 0 else "") + s[:o] + "N" * int(rng.integers(1, 30)) + s[o:] + ("N" if i % 150 == 0 else "")
+    seqs += ["A" * 500, "ACGT" * 100, seqs[3]]
+    names = ["e%d" % i for i in range(len(seqs))]
+    assert (1 << 20) <= sum(map(len, seqs)) < (1 << 22)
+    ix = FmIndex.build(names, seqs)
+    eng = Engine(0)
+    eng.add_library("mid", ix)
+    eng.add_library("tiny", FmIndex.build(["t"], ["GATTACA" * 30]))
+    chk = eng.check_tables("mid")
+    assert chk == {"jump_tables": 0, "row_context": 0, "wide_rows": 0, "seed_buckets": 0}, chk
+    assert eng.check_tables("tiny")["jump_tables"] == 0
+    eng.close()
