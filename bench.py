@@ -545,6 +545,15 @@ def main():
                                 "jump tables and 9-mer bitmaps of all %d libraries = the FM index of their strings by " \
                                 "definition (oracle/index_check.c: %d rows, %.1f s on %d threads)" % (
                                     len(keys), rows, time.perf_counter() - t1, cores)
+        # -- ... and the tables the DEVICE derived from them (libtables.hip; the host functions' output is what the check
+        # above pinned): every word equal
+        t1 = time.perf_counter()
+        bad = {k: {t: v for t, v in eng.check_tables(k).items() if v} for k in keys}
+        if any(bad.values()):
+            raise SystemExit("PARITY FAILURE: tables filled on the device differ from the host's: %r" % bad)
+        parity["device_tables"] = "jump tables, row context, wide rows and seed buckets the device filled from rows + text " \
+                                  "(csrc/libtables.hip) = the host functions' word for word, all %d libraries (%.1f s)" % (
+                                      len(keys), time.perf_counter() - t1)
         cpu = dict(value=round(m / dt / 1e6, 4), unit="M reads/s", cores=cores, kind="port",
                    sample="first %d reads of rank 0's shard, full %d-pass cascade + tally, oracle/fm_cpu.c with "
                           "OpenMP on %d threads (%.1f s)" % (m, n_pass, cores, dt),

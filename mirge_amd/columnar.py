@@ -131,12 +131,16 @@ def read_subset(words, lens, nmask, quant, pass_id, ref_id, pos, mm, names_per_p
     width = 11 if spike_in else 10
     quant = np.asarray(quant)
     records, align = {}, {}
-    for k, i in enumerate(idx):
-        p = int(pass_id[i])
-        annot = [1] + [""] * (width - 1)
-        annot[p + 1] = names_per_pass[p][int(ref_id[i])]
-        records[seqs[k]] = {"quant": [int(x) for x in quant[i]], "annot": annot, "length": len(seqs[k])}
-        align[seqs[k]] = (p, int(ref_id[i]), int(pos[i]), int(mm[i]))
+    # (plain Python ints in one go: a numpy scalar per field and read was most of this loop's time at 10^5..10^6 reads)
+    p_l, r_l, o_l, m_l = (np.asarray(a)[idx].tolist() for a in (pass_id, ref_id, pos, mm))
+    q_l = quant[idx].tolist()
+    blank = [1] + [""] * (width - 1)
+    for k, seq in enumerate(seqs):
+        p = p_l[k]
+        annot = list(blank)
+        annot[p + 1] = names_per_pass[p][r_l[k]]
+        records[seq] = {"quant": q_l[k], "annot": annot, "length": len(seq)}
+        align[seq] = (p, r_l[k], o_l[k], m_l[k])
     return records, align
 
 

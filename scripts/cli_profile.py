@@ -2,7 +2,7 @@
 """Where does a FASTQ-to-tables run spend its time?  Writes two synthetic FASTQ samples (adapter
 attached, as raw small-RNA reads have it), builds the library layout, runs `annotate` under
 cProfile and prints the phase log plus the top cumulative entries.
-    python scripts/cli_profile.py [reads per sample] [scale]"""
+    python scripts/cli_profile.py [reads per sample] [scale] [warm]"""
 import cProfile
 import io
 import os
@@ -37,6 +37,8 @@ for si in range(2):
 print("wrote 2 x %d reads in %.1f s" % (n, time.time() - t0))
 args = cli.build_parser().parse_args(["annotate", "-s"] + fastqs + ["-lib", os.path.join(tmp, "libs"), "-sp", "syn",
                                       "-o", tmp, "-ad", "illumina", "-cpu", "16", "-di"])
+if len(sys.argv) > 3 and sys.argv[3] == "warm":     # a first, unprofiled run: the indexes are cached next to the library
+    cli.annotate_main(args)
 pr = cProfile.Profile()
 t0 = time.time()
 pr.enable()
@@ -44,5 +46,5 @@ out = cli.annotate_main(args)
 pr.disable()
 print("annotate: %.1f s for %d raw reads, %d unique" % (time.time() - t0, 2 * n, out["n_unique"]))
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(22)
+pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(34)
 print(s.getvalue()[:6000])
