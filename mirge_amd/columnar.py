@@ -158,7 +158,7 @@ def isomir_dic(records, n_samples):
         if ".SNP" in key:
             key = key.split(".SNP")[0]
         slot = out.setdefault(key, {"mirnas": {}, "isomirs": {}})
-        slot[kind][seq] = [rec["quant"][i] for i in range(n_samples)]
+        slot[kind][seq] = rec["quant"][:n_samples]
     return out
 
 

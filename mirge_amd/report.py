@@ -128,6 +128,10 @@ def write_isomir_tables(isomir_path, sample_path, sampleList, isomirDic, logDic)
             f2.write("," + s + " Canonical RPM")
             f2.write("," + s + " Top Isomir RPM")
         f2.write("\n")
+        # (10^5..10^6 isomiR reads pass through this loop: the per-sample divisors are looked up once, and the one-sample
+        # case -- entropy over one value is 0, its maximum log2(1) = 0: "NA" -- skips the entropy arithmetic)
+        filtered = [logDic["quantStats"][i]["mirnaReadsFiltered"] for i in range(S)]
+        lines = []
         for mirna, groups in isomirDic.items():
             per_sample_isomirs = {i: [] for i in range(S)}
             canon = [0] * S
@@ -135,14 +139,21 @@ def write_isomir_tables(isomir_path, sample_path, sampleList, isomirDic, logDic)
                 for i in range(len(counts)):
                     canon[i] += counts[i]
             for seq, counts in groups["isomirs"].items():
-                for i in range(len(counts)):
-                    per_sample_isomirs[i].append(counts[i])
-                h = calc_entropy(counts)
-                hmax = math.log(len(counts), 2)
-                h_txt = "NA" if hmax == 0 else py2_float_str(h / hmax)
-                rpm = [py2_float_str(counts[i] * 1000000.0 / logDic["quantStats"][i]["mirnaReadsFiltered"])
-                       for i in range(len(counts))]
-                f1.write(",".join([mirna, seq] + rpm + [h_txt]) + "\n")
+                n_c = len(counts)
+                if n_c == 1:
+                    per_sample_isomirs[0].append(counts[0])
+                    lines.append("%s,%s,%s,NA\n" % (mirna, seq, py2_float_str(counts[0] * 1000000.0 / filtered[0])))
+                else:
+                    for i in range(n_c):
+                        per_sample_isomirs[i].append(counts[i])
+                    h = calc_entropy(counts)
+                    hmax = math.log(n_c, 2)
+                    h_txt = "NA" if hmax == 0 else py2_float_str(h / hmax)
+                    rpm = [py2_float_str(counts[i] * 1000000.0 / filtered[i]) for i in range(n_c)]
+                    lines.append(",".join([mirna, seq] + rpm + [h_txt]) + "\n")
+                if len(lines) >= 65536:
+                    f1.write("".join(lines))
+                    lines = []
             # isomirs.samples.csv: the reference appends to ONE row list across the
             # samples and writes it after each sample that has isomiRs (sic)
             row = [mirna]
@@ -162,6 +173,7 @@ def write_isomir_tables(isomir_path, sample_path, sampleList, isomirDic, logDic)
                     row.append(py2_float_str(canon_rpm))
                     row.append(py2_float_str(top))
                     f2.write(",".join(row) + "\n")
+        f1.write("".join(lines))
 
 
 ANNOTATION_REPORT_HEADER = ("File name(s),Total Input Reads,Trimmed Reads(all),Trimmed Reads(unique),"

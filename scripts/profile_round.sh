@@ -37,3 +37,13 @@ python bench.py --sorted --no-cpu-baseline --no-extras 2> /dev/null > gpurun_out
 for pair in 12500000:12m5 25000000:25m 50000000:50m 100000000:full; do
   python bench.py --no-cpu-baseline --no-extras --reads ${pair%%:*} 2> /dev/null > gpurun_out/${tag}_shard_${pair##*:}.json
 done
+# ---- round 5 ----
+# the unfriendly library set (repeats), the collapse kernels alone (stats + HBM bytes), library residency, the command line at scale
+python bench.py --workload repeats --no-extras --no-legs 2> gpurun_out/${tag}_bench_repeats.err > gpurun_out/${tag}_bench_repeats.json
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_collapse_stats -- python3 scripts/collapse_bench.py > gpurun_out/${tag}_collapse.json 2> gpurun_out/${tag}_collapse.err
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_collapse_fetch -- python3 scripts/collapse_bench.py --reps 1 > /dev/null 2> gpurun_out/${tag}_collapse_fetch.err
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_collapse_write -- python3 scripts/collapse_bench.py --reps 1 > /dev/null 2> gpurun_out/${tag}_collapse_write.err
+timeout 600 python scripts/collapse_bench.py > gpurun_out/${tag}_collapse_plain.json 2> /dev/null
+timeout 600 python scripts/lib_load_timing.py 1.0 > /dev/null 2> gpurun_out/${tag}_lib_load.txt
+timeout 900 python scripts/cli_scale_check.py 32000000 1.0 1 > gpurun_out/${tag}_cli_scale_32m.txt 2>&1
+timeout 600 python scripts/cli_scale_check.py 32000000 0.2 1 > gpurun_out/${tag}_cli_scale_32m_s02.txt 2>&1
