@@ -34,7 +34,7 @@ def newest(pattern):
 
 
 def short(name):
-    return name.replace("void ", "").split("(")[0]
+    return name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
 
 
 def counters(tag, kind):
