@@ -684,7 +684,7 @@ __global__ void __launch_bounds__(kRedThreads) reduce_kernel(FastShape f, const 
   __shared__ uint16_t sidx[kRedSlots];             // the occupied slots grouped by bin
   __shared__ uint32_t bin_cnt[256], bin_start[257];
   __shared__ uint32_t wtot[kRedThreads / 64u];
-  __shared__ uint32_t n_in;
+  constexpr uint32_t kRedMaxProbe = 128u;
   constexpr uint32_t kPerThread = kRedSlots / kRedThreads;  // consecutive slots per thread
   constexpr uint32_t kLoads = 4u;                           // pairs a lane requests before it inserts any
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -713,7 +713,6 @@ __global__ void __launch_bounds__(kRedThreads) reduce_kernel(FastShape f, const 
       tcnt[s] = 0u;
     }
     bin_cnt[tid] = 0u;
-    if (tid == 0) n_in = 0u;
     __syncthreads();
     bool lost = false;
     for (uint32_t j0 = tid; j0 < P; j0 += kRedThreads * kLoads) {
@@ -725,15 +724,17 @@ __global__ void __launch_bounds__(kRedThreads) reduce_kernel(FastShape f, const 
         if (j0 + u * kRedThreads >= P) break;
         const unsigned long long rest = pr[u] & kRestMask;
         uint32_t s = (uint32_t)((rest * 0x9E3779B97F4A7C15ull) >> (64u - kRedSlotBits));
-        for (;;) {
+        // (no count of the occupied slots while inserting -- one same-address atomic per new key was a third of the
+        // kernel's LDS time --: a probe that walks kRedMaxProbe slots says the table is not this bucket's size, and the
+        // occupancy is checked once, after the inserts)
+        for (uint32_t step = 0;; ++step) {
           const unsigned long long old = atomicCAS(&tkey[s], kEmpty, rest);
           if (old == kEmpty || old == rest) {
             atomicAdd(&tcnt[s], (uint32_t)(pr[u] >> kCountShift));
-            if (old == kEmpty && atomicAdd(&n_in, 1u) >= kRedSlots - kRedSlots / 4u) lost = true;  // (three quarters full: not this table's bucket)
             break;
           }
           s = (s + 1u) & (kRedSlots - 1u);
-          if (n_in >= kRedSlots - kRedSlots / 4u) {  // (never spin in a full table)
+          if (step >= kRedMaxProbe) {  // (never spin in a full table)
             lost = true;
             break;
           }
@@ -772,6 +773,7 @@ __global__ void __launch_bounds__(kRedThreads) reduce_kernel(FastShape f, const 
     }
     __syncthreads();
     const uint32_t D = bin_start[256];
+    if (tid == 0 && D > kRedSlots - kRedSlots / 4u) atomicOr(overflow, 1u);  // (three quarters full: not this table's bucket)
     // an entry's place in its bin = members with a smaller key; it is the first entry of its read when no member with
     // a smaller key has the same bases (entries of one read differ in their sample bits only: same bin, or the key is
     // shorter than 8 + sample bits and the bins hold one key each)
