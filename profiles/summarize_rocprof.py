@@ -101,6 +101,8 @@ def main():
     except Exception:
         head = "?"
     meta_f = os.path.join(ROOT, "gpurun_out", a.tag + "_meta.json")
+    if not os.path.exists(meta_f) and "_" in a.tag:   # r05_exact, r05_a2i: one collection run, one meta file (r05_meta.json)
+        meta_f = os.path.join(ROOT, "gpurun_out", a.tag.split("_")[0] + "_meta.json")
     kernels_sha = None
     if os.path.exists(meta_f):
         mj = json.load(open(meta_f))
