@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(kFastThreads) split_kernel(const uint64_t* __r
                                                              const uint16_t* __restrict__ sample, FastShape f,
                                                              const uint32_t* __restrict__ off_t, const unsigned long long* __restrict__ hot,
                                                              const uint32_t* __restrict__ n_hot_p, uint32_t* __restrict__ bin_pairs,
-                                                             uint64_t* __restrict__ pairs) {
+                                                             uint32_t* __restrict__ cnt_t, uint64_t* __restrict__ pairs) {
   constexpr uint32_t kPer = 4u, kTrip = kPer * kFastThreads;  // reads per lane and trip; reads per trip
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* tkey = reinterpret_cast<unsigned long long*>(smem);         // kAggSlots: the hot keys
@@ -538,19 +538,21 @@ __global__ void __launch_bounds__(kFastThreads) split_kernel(const uint64_t* __r
     }
   }
   __syncthreads();
-  // unused positions of the chunk's regions -> zero pairs; pairs of the chunk per bucket -> the buckets' totals
-  for (uint32_t b = wave; b < f.n_bins; b += kFastThreads / 64u) {
+  // pairs the chunk left in each of its regions (K2 walks exactly those: a region is sized for the chunk's RAW reads of the
+  // bucket, the hot table and the per-chunk aggregation leave ~35 % of it unused), and the buckets' totals
+  for (uint32_t b = threadIdx.x; b < f.n_bins; b += kFastThreads) {
     const size_t at = ((size_t)f.len_of_slot[b >> 8] * 256u + (b & 255u)) * f.n_chunks + blockIdx.x;
-    const uint32_t first = off_t[at], end = off_t[at + 1], cur = cursor[b];
-    for (uint32_t j = cur + lane; j < end; j += 64u) pairs[j] = 0ull;
-    if (lane == 0 && cur > first) atomicAdd(&bin_pairs[b], cur - first);
+    const uint32_t first = off_t[at], cur = cursor[b];
+    cnt_t[at] = cur - first;
+    if (cur > first) atomicAdd(&bin_pairs[b], cur - first);
   }
 }
 
-// K2a / K2b: the pairs of an L1 bucket (its whole region: zero pairs skipped) counted by their next b2 bits, then copied
-// into contiguous final buckets.  A workgroup = (L1 bucket, one of `groups` equal parts of its region); the counts are
-// stored [final bucket][group], so ONE prefix sum over the array places every (final bucket, group) run: final buckets
-// in key order, dense.  b2 = enough bits for ~1024 pairs per final bucket.
+// K2a / K2b: the pairs of an L1 bucket counted by their next b2 bits, then copied into contiguous final buckets.  A
+// workgroup = (L1 bucket, one of `groups` runs of chunks); a wave walks the regions of its chunks (every 16th of the
+// run), exactly the pairs K1 left there (cnt_t), 64 at a stride.  The counts are stored [final bucket][group], so ONE
+// prefix sum over the array places every (final bucket, group) run: final buckets in key order, dense.
+// b2 = enough bits for ~1024 pairs per final bucket.
 __device__ __forceinline__ uint32_t sub_bits_of(uint32_t P, uint32_t r1) {
   uint32_t b2 = 0;
   while (b2 < 8u && b2 < r1 && ((P + 1023u) >> 10) > (1u << b2)) ++b2;
@@ -558,59 +560,72 @@ __device__ __forceinline__ uint32_t sub_bits_of(uint32_t P, uint32_t r1) {
 }
 
 template <bool SCATTER>
-__global__ void __launch_bounds__(kFastThreads) subdivide_kernel(FastShape f, const uint32_t* __restrict__ off_t,
+__global__ void __launch_bounds__(kFastThreads) subdivide_kernel(FastShape f, const uint32_t* __restrict__ off_t, const uint32_t* __restrict__ cnt_t,
                                                                  const uint32_t* __restrict__ bin_pairs, const uint64_t* __restrict__ pairs_in,
                                                                  uint32_t* __restrict__ hist_t /* SCATTER: its exclusive prefix */,
                                                                  uint64_t* __restrict__ pairs_out, uint8_t* __restrict__ l1_b2) {
-  // SCATTER stages a tile of 8192 positions in LDS, grouped by final bucket, and writes it out run by run: the lanes of
+  // SCATTER stages a tile of up to 8192 pairs in LDS, grouped by final bucket, and writes it out run by run: the lanes of
   // a store instruction then write neighbouring pairs (a 128-byte line takes ONE request, not sixteen 8-byte ones:
   // scattered 8-byte stores run at ~100 G/s on this chip whatever they carry)
-  constexpr uint32_t kTilePos = 2u * 4u * kFastThreads;
+  constexpr uint32_t kSlots = 8u;  // strides of 64 pairs a wave takes per tile
+  constexpr uint32_t kWaves = kFastThreads / 64u;
+  constexpr uint32_t kTilePos = kSlots * kFastThreads;
   __shared__ uint32_t sub[256];    // counts (hist pass); SCATTER: where the next tile's run of a final bucket goes
   __shared__ uint32_t tcount[256], tstart[256];
-  __shared__ uint32_t wtot[kFastThreads / 64u];
+  __shared__ uint32_t wtot[kWaves];
+  __shared__ uint32_t seg_first[kMaxChunks], seg_n[kMaxChunks];  // the regions of this workgroup's chunks
+  __shared__ uint32_t n_tiles_s;
   __shared__ uint64_t stage[SCATTER ? kTilePos : 1];
   const uint32_t b = blockIdx.x / f.groups, g = blockIdx.x % f.groups;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t P = bin_pairs[b];
   if (P == 0) return;
   if (tid < 256u) sub[tid] = SCATTER ? hist_t[((size_t)b * 256u + tid) * f.groups + g] : 0u;
-  __syncthreads();
+  if (tid == 0) n_tiles_s = 0u;
   const uint32_t L = f.len_of_slot[b >> 8];
   const uint32_t r1 = l1_shift(L) + f.sb;
   const uint32_t b2 = sub_bits_of(P, r1);
   const uint32_t sh = r1 - b2;
   if (!SCATTER && g == 0 && tid == 0) l1_b2[b] = (uint8_t)b2;
   const size_t at = ((size_t)L * 256u + (b & 255u)) * f.n_chunks;
-  const uint32_t r_lo = off_t[at], r_hi = off_t[at + f.n_chunks];
-  const uint32_t a0 = r_lo & ~1u;                                              // (the pair in front of an odd start is another bucket's)
-  const uint32_t span = (((r_hi - a0) + f.groups - 1u) / f.groups + 1u) & ~1u;  // (even: 16-byte loads stay aligned)
-  const uint32_t lo = a0 + g * span, hi = min(r_hi, lo + span);
-  constexpr uint32_t kUnroll = 4u;  // 16-byte loads a lane keeps in flight
-  for (uint32_t t0 = lo; t0 < hi; t0 += kTilePos) {
-    uint4 q[kUnroll];
+  const uint32_t cpg = (f.n_chunks + f.groups - 1u) / f.groups;  // chunks per group
+  const uint32_t c_lo = min(f.n_chunks, g * cpg), n_seg = min(f.n_chunks, c_lo + cpg) - c_lo;
+  for (uint32_t j = tid; j < n_seg; j += kFastThreads) {
+    seg_first[j] = off_t[at + c_lo + j];
+    seg_n[j] = cnt_t[at + c_lo + j];
+  }
+  __syncthreads();
+  {
+    // strides of the wave's segments (wave, wave + 16, ...) -> tiles it needs; the workgroup walks the largest number
+    uint32_t strides = 0;
+    for (uint32_t j = wave; j < n_seg; j += kWaves) strides += (seg_n[j] + 63u) >> 6;
+    if (lane == 0 && strides) atomicMax(&n_tiles_s, (strides + kSlots - 1u) / kSlots);
+  }
+  __syncthreads();
+  const uint32_t n_tiles = n_tiles_s;
+  uint32_t sj = wave, spos = 0;  // the wave's current segment and how far it is in (wave-uniform)
+  for (uint32_t tile = 0; tile < n_tiles; ++tile) {
+    uint64_t pr[kSlots];
+    uint32_t rk[kSlots];  // SCATTER: rank of the pair among the tile's pairs of its final bucket
 #pragma unroll
-    for (uint32_t u = 0; u < kUnroll; ++u) {
-      const uint32_t i = t0 + 2u * tid + u * 2u * kFastThreads;
-      q[u] = i < hi ? *reinterpret_cast<const uint4*>(pairs_in + i) : make_uint4(0u, 0u, 0u, 0u);
+    for (uint32_t k = 0; k < kSlots; ++k) {
+      while (sj < n_seg && spos >= seg_n[sj]) {
+        sj += kWaves;
+        spos = 0u;
+      }
+      pr[k] = 0ull;
+      if (sj < n_seg) {
+        if (spos + lane < seg_n[sj]) pr[k] = pairs_in[seg_first[sj] + spos + lane];
+        spos += 64u;
+      }
     }
     if (SCATTER) {
       if (tid < 256u) tcount[tid] = 0u;
       __syncthreads();
     }
-    uint64_t pr[2u * kUnroll];
-    uint32_t rk[2u * kUnroll];  // SCATTER: rank of the pair among the tile's pairs of its final bucket
 #pragma unroll
-    for (uint32_t u = 0; u < kUnroll; ++u) {
-      const uint32_t i = t0 + 2u * tid + u * 2u * kFastThreads;
-      uint64_t p0 = (uint64_t)q[u].x | ((uint64_t)q[u].y << 32), p1 = (uint64_t)q[u].z | ((uint64_t)q[u].w << 32);
-      if (!(i >= r_lo && i < hi)) p0 = 0ull;
-      if (!(i + 1u < hi)) p1 = 0ull;
-      pr[2u * u] = p0;
-      pr[2u * u + 1u] = p1;
-      if (p0 >> kCountShift) rk[2u * u] = atomicAdd(SCATTER ? &tcount[(uint32_t)((p0 & kRestMask) >> sh) & 255u] : &sub[(uint32_t)((p0 & kRestMask) >> sh) & 255u], 1u);
-      if (p1 >> kCountShift) rk[2u * u + 1u] = atomicAdd(SCATTER ? &tcount[(uint32_t)((p1 & kRestMask) >> sh) & 255u] : &sub[(uint32_t)((p1 & kRestMask) >> sh) & 255u], 1u);
-    }
+    for (uint32_t k = 0; k < kSlots; ++k)
+      if (pr[k] >> kCountShift) rk[k] = atomicAdd(SCATTER ? &tcount[(uint32_t)((pr[k] & kRestMask) >> sh) & 255u] : &sub[(uint32_t)((pr[k] & kRestMask) >> sh) & 255u], 1u);
     if (SCATTER) {
       __syncthreads();
       // tile-local starts of the 256 runs
@@ -630,7 +645,7 @@ __global__ void __launch_bounds__(kFastThreads) subdivide_kernel(FastShape f, co
       total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
       __syncthreads();
 #pragma unroll
-      for (uint32_t k = 0; k < 2u * kUnroll; ++k)
+      for (uint32_t k = 0; k < kSlots; ++k)
         if (pr[k] >> kCountShift) stage[tstart[(uint32_t)((pr[k] & kRestMask) >> sh) & 255u] + rk[k]] = pr[k];
       __syncthreads();
       for (uint32_t i = tid; i < total; i += kFastThreads) {
@@ -863,6 +878,7 @@ __global__ void __launch_bounds__(kRedThreads) emit_fast_kernel(FastShape f, con
 struct FastPlan {
   uint32_t n_chunks = 0, chunk = 0;
   DevBuf off_t;  // K0's counts, then their exclusive prefix: (kLenBins x n_chunks + 1) entries
+  DevBuf cnt_t;  // K1: pairs a chunk left in each of its regions (same indexing)
   DevBuf max_sample;
   DevBuf sample;  // keys (8 B x 2^kSampleBits), counts (4 B x 2^kSampleBits), count histogram (256 x 4 B), n_hot, hot keys
 };
@@ -875,6 +891,7 @@ hipError_t fast_prepass(const uint64_t* d_reads, const uint8_t* d_lens, const ui
   plan->chunk = (uint32_t)((((uint64_t)n + plan->n_chunks - 1) / plan->n_chunks + 4095u) & ~4095ull);
   const size_t n_ct = (size_t)kLenBins * plan->n_chunks + 1;
   CK(plan->off_t.alloc(n_ct * 4));
+  CK(plan->cnt_t.alloc(n_ct * 4));
   CK(plan->max_sample.alloc(4));
   CK(stmp->alloc(prims::scan_temp_bytes(n_ct)));
   const size_t n_smp = (size_t)1 << kSampleBits;
@@ -956,15 +973,16 @@ hipError_t collapse_fast(const uint64_t* d_reads, const uint8_t* d_lens, const u
   const unsigned long long* hot = reinterpret_cast<const unsigned long long*>(n_hot + 16);
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)agg_lds));
   hipLaunchKernelGGL(split_kernel, dim3(f.n_chunks), dim3(kFastThreads), agg_lds, stream, d_reads, d_lens, smp, f, off_t, hot, n_hot, bin_pairs,
-                     bufA.as<uint64_t>());
+                     plan.cnt_t.as<uint32_t>(), bufA.as<uint64_t>());
   CK(hipGetLastError());
   const uint32_t sub_grid = f.n_bins * f.groups;
   uint32_t* offs = hist_t.as<uint32_t>();  // counts [final bucket][group] (+ one 0), then their exclusive prefix (+ the number of pairs)
-  hipLaunchKernelGGL(subdivide_kernel<false>, dim3(sub_grid), dim3(kFastThreads), 0, stream, f, off_t, bin_pairs, bufA.as<uint64_t>(), offs,
-                     (uint64_t*)nullptr, l1_b2);
+  hipLaunchKernelGGL(subdivide_kernel<false>, dim3(sub_grid), dim3(kFastThreads), 0, stream, f, off_t, plan.cnt_t.as<uint32_t>(), bin_pairs,
+                     bufA.as<uint64_t>(), offs, (uint64_t*)nullptr, l1_b2);
   CK(hipGetLastError());
   CK(prims::exclusive_sum_u32(offs, offs, n_ht + 1, stmp.p, stream));
-  hipLaunchKernelGGL(subdivide_kernel<true>, dim3(sub_grid), dim3(kFastThreads), 0, stream, f, off_t, bin_pairs, bufA.as<uint64_t>(), offs,
+  hipLaunchKernelGGL(subdivide_kernel<true>, dim3(sub_grid), dim3(kFastThreads), 0, stream, f, off_t, plan.cnt_t.as<uint32_t>(), bin_pairs,
+                     bufA.as<uint64_t>(), offs,
                      bufB.as<uint64_t>(), l1_b2);
   CK(hipGetLastError());
   const uint32_t fgrid = (uint32_t)((n_fb + 1 + 255) / 256);
