@@ -328,7 +328,9 @@ __global__ void __launch_bounds__(kFastThreads) prepass_kernel(const uint64_t* _
     }
   }
   __syncthreads();
-  for (uint32_t b = threadIdx.x; b < kLenBins; b += kFastThreads) counts_t[(size_t)b * n_chunks + blockIdx.x] = hist[b];
+  // (the table was zeroed: 7 680 scattered 4-byte stores per chunk -- 7.8 M a batch -- for the 256 that are not zero)
+  for (uint32_t b = threadIdx.x; b < kLenBins; b += kFastThreads)
+    if (hist[b]) counts_t[(size_t)b * n_chunks + blockIdx.x] = hist[b];
   if (LENH)
     for (uint32_t b = threadIdx.x; b < 256u * n_samples; b += kFastThreads)
       if (lhist[b]) atomicAdd(&len_hist[b], (unsigned long long)lhist[b]);
@@ -904,7 +906,7 @@ hipError_t fast_prepass(const uint64_t* d_reads, const uint8_t* d_lens, const ui
   CK(hipMemsetAsync(smp_key, 0xFF, n_smp * 8, stream));
   CK(hipMemsetAsync(smp_cnt, 0, n_smp * 4 + 1024 + 64, stream));
   CK(hipMemsetAsync(plan->max_sample.p, 0, 4, stream));
-  CK(hipMemsetAsync(plan->off_t.as<uint32_t>() + (n_ct - 1), 0, 4, stream));
+  CK(hipMemsetAsync(plan->off_t.p, 0, n_ct * 4, stream));
   uint32_t sb = 0;
   while ((1u << sb) < n_samples) ++sb;
   const uint32_t lds = (kLenBins + 256u * n_samples) * 4u;
