@@ -134,3 +134,37 @@ def test_device_built_tables_of_a_library_with_seed_buckets(native_lib, oracle_l
     assert chk == {"jump_tables": 0, "row_context": 0, "wide_rows": 0, "seed_buckets": 0}, chk
     assert eng.check_tables("tiny")["jump_tables"] == 0
     eng.close()
+
+
+def test_device_built_dictionary_with_a_shorter_key(native_lib, oracle_lib):
+    """`dict_key` 12 (the option's range is 8..16): positions whose 12-base keys collide far more often -- longer chains,
+    more overflowed homes -- built on the device and on the host; same answers for 16..32-nt reads."""
+    from mirge_amd import pack
+    from mirge_amd.engine import Engine, ReadSet
+    from mirge_amd.index import FmIndex
+    rng = np.random.default_rng(47)
+    names, seqs, element = make_library(rng, n_entries=4800, lo=850, hi=1000)
+    assert sum(map(len, seqs)) > (1 << 22)
+    ix = FmIndex.build(names, seqs)
+    reads = make_reads(rng, seqs, element, n=6000)
+    w, l, nm = pack.pack_reads(reads)
+    got = {}
+    for dev_tables in (1, 0):
+        eng = Engine(0)
+        eng.set_option("device_tables", dev_tables)
+        eng.set_option("dict_key", 12)
+        eng.add_library("big", ix, exact_dict=True)
+        assert eng.library_dict_stats("big")[0] > 4_000_000
+        res = eng.cascade(ReadSet(w, l, None, None, device=eng.device),
+                          eng.make_passes([dict(lib="big", seed_len=28, max_mm_seed=0, max_mm_total=2)]))
+        got[dev_tables] = tuple(a.copy() for a in res.to_host())
+        eng.close()
+    for a, b in zip(got[1], got[0]):
+        assert np.array_equal(a, b)
+    lib = model.Library(names, seqs)
+    pick = rng.choice(len(reads), 200, replace=False)
+    want_ref, want_pos, want_mm = model.align_batch(lib, [reads[i] for i in pick], 28, 0, 2)
+    pass_id, ref_id, pos, mm = got[1]
+    for j, i in enumerate(pick):
+        g = (int(ref_id[i]), int(pos[i]), int(mm[i])) if pass_id[i] == 0 else (-1, -1, -1)
+        assert g == (int(want_ref[j]), int(want_pos[j]), int(want_mm[j])), reads[i]
