@@ -12,12 +12,12 @@ refineName, checkSeqList, align2TargetSeq, A2IEditing; :344-351 is in report.py)
      repetitive-element list; the edited sequence does not occur in the genome -n 0 -3 2),
      a2IEditing.report.newform.csv, a2IEditing.detail.txt                   :1373-1594
 
-Two things are not the reference's own arithmetic and are PARITY UNPINNED:
+Two things are not the reference's own arithmetic:
   * `pairwise2.align.localms(target, seq, 2, -1, -20, -20)` (Biopython, absent from the
-    image): with gap penalties of -20 the optimum is an ungapped diagonal; `local_pair`
-    returns both full sequences padded with '-' to that diagonal (what pairwise2 hands
-    back for a local alignment).  Ties between diagonals: smallest |offset|, then the
-    target-leading one.
+    image and from /root/reference): `local_pair` restates its local alignment with affine gaps
+    and Biopython 1.70-1.76's traceback order (which alignment is listed first among equals);
+    the golden fixture answers the reference's call with an independent restatement of the
+    same published algorithm.  Unpinned against a real Biopython.
   * the two genome bowtie runs: answered by a `genome` object with
       unique_best(reads) -> set of reads whose best stratum (<= 1 seed mismatch, 3' 2 nt
                             trimmed, both strands) holds exactly one alignment
@@ -41,25 +41,107 @@ SAMPLE_LABELS = {"SRR837842": "Colon 1", "SRR837839": "Colon 2", "SRR5127219": "
 
 
 # ------------------------------------------------------------------ alignment
-def local_pair(target, seq, match=2, mismatch=-1):
-    """Best ungapped local alignment, returned as the two full sequences padded to the
-    winning diagonal (stand-in for pairwise2.align.localms(..., -20, -20)[0][:2])."""
-    best = None
-    for off in range(-(len(seq) - 1), len(target)):   # seq[0] sits at target index `off`
-        lo, hi = max(0, off), min(len(target), off + len(seq))
-        run = top = 0
-        for x in range(lo, hi):
-            run = max(0, run) + (match if target[x] == seq[x - off] else mismatch)
-            top = max(top, run)
-        key = (-top, abs(off), off < 0)
-        if best is None or key < best[0]:
-            best = (key, off)
-    off = best[1]
-    head_t, head_s = max(0, -off), max(0, off)
-    n = max(head_t + len(target), head_s + len(seq))
-    tpad = "-" * head_t + target + "-" * (n - head_t - len(target))
-    spad = "-" * head_s + seq + "-" * (n - head_s - len(seq))
-    return tpad, spad
+def _local_scores(target, seq, match, mismatch, gap_open, gap_extend):
+    """Smith-Waterman scores as pairwise2's local mode fills them: score[r][c] = best alignment
+    ending with target[:r] / seq[:c] consumed (floored at 0), a gap of n costing
+    open + (n - 1) * extend, EXCEPT in the last row and the last column, where a gap is free
+    (end gaps are not penalised: the best score is passed along).  `stretched[r][c]` says that the
+    cell's score can come from a gap of two or more."""
+    la, lb = len(target), len(seq)
+    score = [[0] * (lb + 1) for _ in range(la + 1)]
+    stretched = [[False] * (lb + 1) for _ in range(la + 1)]
+    down = [0] + [2 * gap_open + gap_extend * (c - 1) for c in range(1, lb + 1)]   # gap in seq, per column
+    for r in range(1, la + 1):
+        tr = target[r - 1]
+        across = 2 * gap_open + gap_extend * (r - 1)                               # gap in target, this row
+        row, above = score[r], score[r - 1]
+        for c in range(1, lb + 1):
+            pair = above[c - 1] + (match if tr == seq[c - 1] else mismatch)
+            opened, longer = (row[c - 1], across) if r == la else (row[c - 1] + gap_open, across + gap_extend)
+            across = opened if opened >= longer else longer
+            opened_d, longer_d = (above[c], down[c]) if c == lb else (above[c] + gap_open, down[c] + gap_extend)
+            down[c] = opened_d if opened_d >= longer_d else longer_d
+            top = max(pair, across, down[c])
+            row[c] = top if top > 0 else 0
+            stretched[r][c] = (across == top and longer == across) or (down[c] == top and longer_d == down[c])
+    return score, stretched
+
+
+def local_pair(target, seq, match=2, mismatch=-1, gap_open=-20, gap_extend=-20):
+    """The first alignment `pairwise2.align.localms(target, seq, 2, -1, -20, -20)` lists, as the
+    two sequences padded with '-' (W2C:109-111 reads [0][0] and [0][1]).  Biopython's order
+    (releases 1.70-1.76, the ones a Python-2.7 miRge2.0 runs with) decides between alignments of
+    equal score, and this follows it: candidates are the best-scoring cells that end in a pair,
+    tried from the LARGEST (target position, read position) down; from a cell the walk back
+    prefers a gap in the target, then a pair, then a gap in the read, depth first; a walk that
+    meets another best-scoring cell is a zero-score extension of that cell's alignment and is
+    dropped, as is a gap in the read placed right behind a gap in the target.  With -20 per
+    gap base almost every read lands on one ungapped diagonal; the rule shows on low-complexity
+    miRNAs (several diagonals tie: the one ending furthest along the miRNA wins) and on merged
+    families whose members differ by an indel (one gap beats the best ungapped run).
+    tests/golden/a2i.json pins it against the generator's own restatement (make_golden.py:
+    pairwise2_localms, no product code)."""
+    la, lb = len(target), len(seq)
+    if la == 0 or lb == 0:
+        raise ValueError("local_pair: empty sequence")
+    score, stretched = _local_scores(target, seq, match, mismatch, gap_open, gap_extend)
+    best = max(max(row) for row in score)
+    tops = [(r, c) for r in range(la + 1) for c in range(lb + 1) if score[r][c] == best]
+    top_set = set(tops)
+
+    def pairs_here(r, c):
+        return score[r - 1][c - 1] + (match if target[r - 1] == seq[c - 1] else mismatch) == score[r][c]
+
+    candidates = []
+    for (r, c) in tops:
+        if (r - 1, c - 1) in top_set:
+            break
+        if best > 0 and pairs_here(r, c):
+            candidates.append((r, c))
+
+    def walk(r, c, cols, read_gap_last, first):
+        """cols: alignment columns collected back to front as (target char, read char)."""
+        while True:
+            if not first:
+                if (r, c) in top_set:
+                    return None
+                if r == 0 or c == 0 or score[r][c] <= 0:
+                    if c and read_gap_last:
+                        return None
+                    return cols, r, c
+            here = score[r][c]
+            if stretched[r][c] and not first:
+                raise ValueError("local_pair: alignment through a gap of two or more (%r, %r)" % (target, seq))
+            moves = []
+            if not first and not read_gap_last and r < la and score[r][c - 1] + gap_open == here:
+                moves.append((r, c - 1, ("-", seq[c - 1]), False))
+            if pairs_here(r, c):
+                moves.append((r - 1, c - 1, (target[r - 1], seq[c - 1]), False))
+            if not first and c < lb and score[r - 1][c] + gap_open == here:
+                moves.append((r - 1, c, (target[r - 1], "-"), True))
+            if not moves:
+                return None
+            for (r2, c2, col, flag) in moves[:-1]:
+                got = walk(r2, c2, cols + [col], flag, False)
+                if got is not None:
+                    return got
+            r, c, col, read_gap_last = moves[-1]
+            cols = cols + [col]
+            first = False
+
+    for (r, c) in reversed(candidates):
+        got = walk(r, c, [], False, True)
+        if got is None:
+            continue
+        cols, r0, c0 = got
+        body_t = "".join(x for x, _ in reversed(cols))
+        body_s = "".join(y for _, y in reversed(cols))
+        head = max(r0, c0)
+        tail = max(la - r, lb - c)
+        tpad = "-" * (head - r0) + target[:r0] + body_t + target[r:] + "-" * (tail - (la - r))
+        spad = "-" * (head - c0) + seq[:c0] + body_s + seq[c:] + "-" * (tail - (lb - c))
+        return tpad, spad
+    raise ValueError("local_pair: no local alignment of %r and %r" % (target, seq))
 
 
 def dash_count(s):

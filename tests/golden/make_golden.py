@@ -384,28 +384,159 @@ def main():
         shutil.rmtree(scratch, ignore_errors=True)
 
 
+
+def pairwise2_localms(seq_a, seq_b, match, mismatch, gap_open, gap_extend):
+    """Bio.pairwise2.align.localms(seq_a, seq_b, match, mismatch, gap_open, gap_extend) written
+    out HERE, independently of anything in mirge_amd/ (the round-5 fixture answered the
+    reference's call with the product's own function: the step pinned itself).  Biopython is
+    neither in the image nor under /root/reference, so this restates the algorithm as the
+    releases 1.70-1.76 publish it (current when miRge2.0 appeared, the last that run on Python
+    2.7; the reference asks for biopython >= 1.68, setup.py:29): Smith-Waterman with affine gaps
+    (a gap of n costs open + (n - 1) * extend; end gaps are free in local mode: the last row /
+    column pass their score along without a penalty), one score matrix + one matrix of trace
+    bits (1 gap in A opened, 2 pair, 4 gap in B opened, 8 / 16 gap extended), and the
+    documented traceback order, which is the TIE RULE this fixture pins:
+      * start cells = every cell holding the best score, collected row by row (row = position
+        in seq_a, the miRNA; column = position in seq_b, the read); a start whose upper-left
+        neighbour is a start too ends the collection (`break`), a start with a non-positive
+        score or whose score does not come from a pair is skipped;
+      * the starts go onto a stack and are popped from its END: the first alignment listed
+        ends at the best cell with the LARGEST miRNA position, then the largest read position;
+      * walking back, a cell's options are taken in the order gap in A, pair, gap in B; the
+        options not taken go onto the same stack; a walk that passes another best-score cell,
+        or puts a gap in B right behind a gap in A, is dropped;
+      * an alignment is the two WHOLE sequences padded with '-' to the walk's frame.
+    Returns the list of (padded_a, padded_b) in pairwise2's order; the reference reads [0]
+    (writeDataToCSV.py:109-111).  A walk through an EXTENDED gap is not restated: with -20 / -20
+    it needs >= 20 matched bases on both sides of the gap, i.e. a miRNA of 40 nt."""
+    la, lb = len(seq_a), len(seq_b)
+    if la == 0 or lb == 0:
+        return []
+
+    def pen(n, op, ext):          # calc_affine_penalty, penalize_extend_when_opening = False
+        return 0 if n <= 0 else op + ext * (n - 1)
+    S = [[0] * (lb + 1) for _ in range(la + 1)]
+    T = [[0] * (lb + 1) for _ in range(la + 1)]
+    col_gap_score = [0] + [pen(i, 2 * gap_open, gap_extend) for i in range(1, lb + 1)]
+    best = 0
+    for r in range(1, la + 1):
+        row_gap_score = pen(r, 2 * gap_open, gap_extend)
+        for c in range(1, lb + 1):
+            pair = S[r - 1][c - 1] + (match if seq_a[r - 1] == seq_b[c - 1] else mismatch)
+            if r == la:                       # free end gap: the read runs past the miRNA
+                a_open, a_ext = S[r][c - 1], row_gap_score
+            else:
+                a_open, a_ext = S[r][c - 1] + gap_open, row_gap_score + gap_extend
+            row_gap_score = max(a_open, a_ext)
+            if c == lb:                       # free end gap: the miRNA runs past the read
+                b_open, b_ext = S[r - 1][c], col_gap_score[c]
+            else:
+                b_open, b_ext = S[r - 1][c] + gap_open, col_gap_score[c] + gap_extend
+            col_gap_score[c] = max(b_open, b_ext)
+            top = max(pair, row_gap_score, col_gap_score[c])
+            best = max(best, top)
+            S[r][c] = top if top >= 0 else 0
+            bits = 2 if pair == top else 0
+            if row_gap_score == top:
+                bits += (1 if a_open == row_gap_score else 0) + (8 if a_ext == row_gap_score else 0)
+            if col_gap_score[c] == top:
+                bits += (4 if b_open == col_gap_score[c] else 0) + (16 if b_ext == col_gap_score[c] else 0)
+            T[r][c] = bits
+    starts = [(r, c) for r in range(la + 1) for c in range(lb + 1) if S[r][c] == best]
+    stack = []
+    for (r, c) in starts:
+        if (r - 1, c - 1) in starts:
+            break
+        if best <= 0:
+            continue
+        if (T[r][c] - T[r][c] % 2) % 4 != 2:
+            continue
+        T[r][c] = 2
+        tail_a, tail_b = la - r, lb - c
+        out_a = "-" * (tail_b - tail_a) + seq_a[r:][::-1]       # built back to front
+        out_b = "-" * (tail_a - tail_b) + seq_b[c:][::-1]
+        stack.append((out_a, out_b, r, c, False, 2))
+    found = []
+    while stack and len(found) < 1000:
+        out_a, out_b, r, c, after_gap_in_b, bits = stack.pop()
+        dead = False
+        while (r > 0 or c > 0) and not dead:
+            here = (out_a, out_b, r, c, after_gap_in_b)
+            if not bits:
+                if c and after_gap_in_b:
+                    dead = True
+                else:
+                    if r:
+                        out_a += seq_a[:r][::-1]
+                    if c:
+                        out_b += seq_b[:c][::-1]
+                    if r > c:
+                        out_b += "-" * (len(out_a) - len(out_b))
+                    elif c > r:
+                        out_a += "-" * (len(out_b) - len(out_a))
+                break
+            if bits % 2 == 1:                  # gap in A (the read has a base the miRNA lacks)
+                bits -= 1
+                if after_gap_in_b:
+                    dead = True
+                else:
+                    c -= 1
+                    out_a += "-"
+                    out_b += seq_b[c]
+            elif bits % 4 == 2:                # a pair
+                bits -= 2
+                r -= 1
+                c -= 1
+                out_a += seq_a[r]
+                out_b += seq_b[c]
+                after_gap_in_b = False
+            elif bits % 8 == 4:                # gap in B
+                bits -= 4
+                r -= 1
+                out_a += seq_a[r]
+                out_b += "-"
+                after_gap_in_b = True
+            else:
+                raise NotImplementedError("pairwise2 walk through an extended gap: %r %r" % (seq_a, seq_b))
+            if bits:
+                stack.append(here + (bits,))
+            bits = T[r][c]
+            if S[r][c] == best:
+                dead = True
+            elif S[r][c] <= 0:
+                bits = 0
+        if not dead:
+            pair_ = (out_a[::-1], out_b[::-1])
+            if pair_ not in found:
+                found.append(pair_)
+    return found
+
+
 def make_a2i_golden(scratch, bindir):
     """-ai: a2IEditing.report.csv / .newform.csv / .detail.txt from the reference
     (writeDataToCSV.py:1221-1594) -> tests/golden/a2i.json.  pairwise2 is answered by
-    mirge_amd.a2i.local_pair (Biopython is absent: parity unpinned for it), the genome bowtie
+    pairwise2_localms above (Biopython is absent; no product code is involved), the genome bowtie
     runs by the stand-in; the three Python-2 integer divisions `/7)+1` of :1428,:1467,... are
     rewritten `//` in the scratch copy (lib2to3 leaves them)."""
     import copy
     import importlib
     import numpy as np
-    from mirge_amd import a2i as my_a2i
     from mirge_amd import synth
     os.environ["LC_ALL"] = "C"      # the reference sorts its table with sort(1), W2C:1444
     w2c_path = os.path.join(scratch, "mirge", "utils", "writeDataToCSV.py")
     src = open(w2c_path).read().replace("(len(content)-9)/7)+1", "(len(content)-9)//7)+1")
     open(w2c_path, "w").write(src)
     pw = sys.modules["Bio.pairwise2"]
+    tie_log = {"calls": 0, "several_listed": 0, "gapped_first": 0}
 
     class _Align(object):
         @staticmethod
         def localms(a, b, match, mismatch, gap_open, gap_ext):
-            t, s_ = my_a2i.local_pair(a, b, match, mismatch)
-            return [(t, s_, 0, 0, len(t))]
+            listed = pairwise2_localms(a, b, match, mismatch, gap_open, gap_ext)
+            tie_log["calls"] += 1
+            tie_log["several_listed"] += len(listed) > 1
+            tie_log["gapped_first"] += "-" in listed[0][0].strip("-") or "-" in listed[0][1].strip("-")
+            return [(t, s_, 0, 0, len(t)) for (t, s_) in listed]
     pw.align = _Align
     for m in ("mirge.utils.writeDataToCSV",):
         sys.modules.pop(m, None)
@@ -423,6 +554,33 @@ def make_a2i_golden(scratch, bindir):
 
     def rs(n):
         return "".join("ACGT"[c] for c in rng.integers(0, 4, n))
+    # miRNAs on which pairwise2's choice among EQUAL alignments shows (round 6; the i.i.d. entries
+    # above never tie): a homopolymer core and a dinucleotide repeat (a read inside the repeat
+    # scores the same on several diagonals), and two merged families whose second member lacks
+    # the middle base of the first -- its reads are aligned to the FIRST member's sequence
+    # (W2C:1295), where one gap (-20) and 21 / 23 pairs tie with / beat the best ungapped run.
+    trng = np.random.default_rng(1706)
+
+    def trs(n):
+        return "".join("ACGT"[c] for c in trng.integers(0, 4, n))
+    del22, del24 = "TGCATCGGATC" + "G" + "TACCTGAAGT", "CAGTTCGAGCTA" + "T" + "GGACTTCAAGC"
+    tie_mirs = [("syn-miR-tieA-5p", "GC" + "A" * 18 + "TG"), ("syn-miR-tieAC-5p", "TG" + "AC" * 9 + "GT"),
+                ("syn-miR-del22-5p", del22), ("syn-miR-del22b-5p", del22[:11] + del22[12:]),
+                ("syn-miR-del24-5p", del24), ("syn-miR-del24b-5p", del24[:12] + del24[13:])]
+    assert len(del22) == 22 and len(del24) == 24
+    for k, (nm, mature) in enumerate(tie_mirs):
+        entry = trs(2) + mature + trs(6)
+        mir_names.append(nm)
+        mir_seqs.append(entry)
+        hp_names.append("syn-mir-tie%d" % k)
+        hp_seqs.append(trs(14) + entry + trs(30))
+    libs.merges.append("syn-miR-del22-5p/syn-miR-del22b-5p,syn-miR-del22-5p,syn-miR-del22b-5p")
+    libs.merges.append("syn-miR-del24-5p/syn-miR-del24b-5p,syn-miR-del24-5p,syn-miR-del24b-5p")
+    lut = {"A": 0, "C": 1, "G": 2, "T": 3}
+    for key in ("mirna", "hairpin"):
+        seqs_ = libs.libs[key][1]
+        libs.codes[key] = (np.array([lut[ch] for ch in "".join(seqs_)], dtype=np.uint8),
+                           np.concatenate([[0], np.cumsum([len(x) for x in seqs_])]))
     # genome: every hairpin once (its miRNAs map uniquely), some twice (their reads are not
     # unique), random filler, and a few already-edited matures (those sites must be dropped)
     edit_targets = []
@@ -445,7 +603,7 @@ def make_a2i_golden(scratch, bindir):
         chroms[0] += rs(100) + m[:p] + "G" + m[p + 1:] + rs(100)
     chroms[1] = chroms[1] + synth.codes_to_str(np.array([0, 1, 2, 3] * 40, dtype=np.uint8))
     # reverse-strand copy of one hairpin: still one locus for its reads... and a second, RC, copy of another
-    chroms[2] += rs(80) + my_a2i.revcomp(hp_seqs[7]) + rs(80)
+    chroms[2] += rs(80) + hp_seqs[7][::-1].translate(str.maketrans("ACGT", "TGCA")) + rs(80)
     libs.libs["genome"] = (["chr%d" % (c + 1) for c in range(4)], chroms)
 
     samples = []
@@ -462,6 +620,13 @@ def make_a2i_golden(scratch, bindir):
                 if a_pos:
                     q = a_pos[0]
                     reads += [m[:q] + "G" + m[q + 1:]] * int(rng.integers(1, 6))
+        tm = dict(tie_mirs)
+        a, ac = tm["syn-miR-tieA-5p"], tm["syn-miR-tieAC-5p"]
+        reads += [a] * 40 + ["A" * 17] * 6 + ["A" * 16] * 4 + ["C" + "A" * 17] * 3 + ["A" * 18 + "T"] * 3
+        reads += [ac] * 30 + ["AC" * 8] * 5 + ["CA" * 8] * 4 + ["AC" * 9] * 3 + ["G" + "AC" * 8] * 2
+        for fam in ("syn-miR-del22", "syn-miR-del24"):
+            m1, m2 = tm[fam + "-5p"], tm[fam + "b-5p"]
+            reads += [m1] * (50 + 10 * si) + [m2] * 20 + [m2[:-1]] * 5 + [m2 + "A"] * 4 + [m1[:-1]] * 6
         reads = [r for r in reads if len(r) >= 16]
         order = rng.permutation(len(reads))
         samples.append([reads[i] for i in order])
@@ -507,7 +672,9 @@ def make_a2i_golden(scratch, bindir):
         files[fn] = open(os.path.join(outdir, fn)).read().split("\n")
     golden = {
         "about": "captured from the reference's Python (-ai path) by tests/golden/make_golden.py; "
-                 "pairwise2 and the genome bowtie runs are stand-ins (parity unpinned for both)",
+                 "pairwise2.align.localms is answered by the generator's own restatement of Biopython 1.70-1.76 "
+                 "(make_golden.pairwise2_localms: no product code), the genome bowtie runs by the stand-in bowtie",
+        "pairwise2_calls": tie_log,
         "libraries": {k: [list(v[0]), list(v[1])] for k, v in libs.libs.items()},
         "merges": libs.merges, "samples": samples, "sample_list": sample_list,
         "mirNameSeqDic": name_seq, "mirMergedNameDic": merged_name, "removedMiRNAList": removed,

@@ -1,5 +1,7 @@
 """mirge_amd.a2i (the -ai A-to-I tally) against the reference's own run
-(tests/golden/a2i.json; pairwise2 and the genome bowtie runs are stand-ins there)."""
+(tests/golden/a2i.json; the genome bowtie runs are the stand-in bowtie there, pairwise2 is the
+generator's own restatement of Biopython's localms -- make_golden.pairwise2_localms, which imports
+nothing from mirge_amd)."""
 import copy
 import json
 import os
@@ -67,6 +69,62 @@ def test_local_pair_is_the_best_ungapped_diagonal():
     assert a2i.local_pair(t, "TT" + t) == ("--" + t, "TT" + t)
     frame, states = a2i.align_to_target(t, [t, "A" + t, t[1:] + "CC"])
     assert len({len(x) for x in frame}) == 1 and frame[0].strip("-") == t and states == [True, True, True]
+
+
+def test_local_pair_ties_follow_pairwise2_order():
+    """Equal-score alignments: Biopython lists first the one ending furthest along the miRNA; a
+    gapped alignment that runs through another best cell is a zero-score extension and is dropped;
+    a gapped alignment that BEATS every ungapped run is taken (merged families with an indel)."""
+    # homopolymer: A^17 inside A^18 fits at offsets 0 and 1 with 34 each -> the later one
+    assert a2i.local_pair("GC" + "A" * 18 + "TG", "A" * 17) == ("GC" + "A" * 18 + "TG", "---" + "A" * 17 + "--")
+    # dinucleotide repeat: offsets 2 and 4 tie
+    assert a2i.local_pair("TG" + "AC" * 9 + "GT", "AC" * 8) == ("TG" + "AC" * 9 + "GT", "----" + "AC" * 8 + "--")
+    # 22-nt miRNA, read lacks its 12th base: gapped 21 * 2 - 20 = 22 = the ungapped 11 pairs; the gapped
+    # walk passes the cell that ends those 11 pairs -> dropped, the ungapped diagonal is listed first
+    m = "TGCATCGGATC" + "G" + "TACCTGAAGT"
+    assert a2i.local_pair(m, m[:11] + m[12:]) == (m, m[:11] + m[12:] + "-")
+    # 24-nt miRNA, read lacks its 13th base: gapped 23 * 2 - 20 = 26 > 24
+    m = "CAGTTCGAGCTA" + "T" + "GGACTTCAAGC"
+    assert a2i.local_pair(m, m[:12] + m[13:]) == (m, m[:12] + "-" + m[13:])
+
+
+def test_local_pair_equals_the_generators_pairwise2(golden):
+    """Two independent formulations of the published algorithm (the product's depth-first walk over
+    recomputed options, the generator's trace-bit matrix + stack) agree on random, low-complexity
+    and indel pairs; the fixture really holds tie cases."""
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden
+    calls = golden["pairwise2_calls"]
+    assert calls["several_listed"] > 0 and calls["gapped_first"] > 0 and calls["calls"] > 1000
+    rnd = random.Random(606)
+
+    def rs(n, alpha):
+        return "".join(rnd.choice(alpha) for _ in range(n))
+    several = gapped = 0
+    for _ in range(4000):
+        alpha = rnd.choice(["ACGT", "AC", "A", "ACG", "AAAC"])
+        t = rs(rnd.randint(16, 27), alpha)
+        kind = rnd.random()
+        if kind < 0.4:
+            s = list(t[rnd.randint(0, 5):len(t) - rnd.randint(0, 4)])
+            for _k in range(rnd.randint(0, 2)):
+                s[rnd.randrange(len(s))] = rnd.choice("ACGT")
+            s = "".join(s) + rs(rnd.randint(0, 3), "ACGT")
+        elif kind < 0.7:
+            k = rnd.randint(5, len(t) - 5)
+            s = t[:k] + t[k + 1:]
+        elif kind < 0.85:
+            k = rnd.randint(5, len(t) - 5)
+            s = t[:k] + rnd.choice("ACGT") + t[k:]
+        else:
+            s = rs(rnd.randint(16, 26), alpha)
+        listed = make_golden.pairwise2_localms(t, s, 2, -1, -20, -20)
+        several += len(listed) > 1
+        gapped += "-" in listed[0][0].strip("-") or "-" in listed[0][1].strip("-")
+        assert a2i.local_pair(t, s) == listed[0], (t, s)
+    assert several > 300 and gapped > 20
 
 
 @pytest.mark.gpu
