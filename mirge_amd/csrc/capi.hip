@@ -507,6 +507,8 @@ int upload_index(mrg_ctx* ctx, const mrg::FmIndex& ix, DevLib& l, bool wide_rows
     }
   }
   const bool on_device = ctx->device_tables && ix.n >= mrg::kLazyDeriveBases;
+  if (!on_device && !ix.derived)
+    return fail(MRG_ERR_ARG, "upload_index: the index's jump tables are not derived (derive_tables before the upload)");
   if (on_device) {
     // jump tables, row context and wide rows from the rows and the text just uploaded (libtables.hip)
     size_t total = 0;
@@ -911,6 +913,9 @@ int get_seed_lib(mrg_ctx* ctx, const std::vector<int32_t>& lib_ids, SeedLib** ou
     } catch (const std::exception& e) {
       return fail(MRG_ERR_FORMAT, "mrg_cascade_run: indexing libraries %s: %s", key.c_str(), e.what());
     }
+    // build_index leaves jump tables and row context of an index of >= kLazyDeriveBases bases to the
+    // device; a context with device_tables = 0 needs them from the host before upload_index reads them
+    if (!ix.derived && !(ctx->device_tables && ix.n >= mrg::kLazyDeriveBases)) mrg::derive_tables(ix);
     sl->owned = true;
     struct Guard {
       SeedLib* s;

@@ -168,3 +168,53 @@ def test_device_built_dictionary_with_a_shorter_key(native_lib, oracle_lib):
     for j, i in enumerate(pick):
         g = (int(ref_id[i]), int(pos[i]), int(mm[i])) if pass_id[i] == 0 else (-1, -1, -1)
         assert g == (int(want_ref[j]), int(want_pos[j]), int(want_mm[j])), reads[i]
+
+
+def test_seed_unit_over_a_megabase_library_without_device_tables(native_lib, oracle_lib):
+    """Advisor, round 5: a one-mismatch pass on a library of 1..4 Mbp is searched through a seed unit whose index
+    `mrg_cascade_run` builds itself; with `device_tables` = 0 that index must get its jump tables and row context from the
+    host before the upload (they used to be left empty: out-of-bounds table reads).  Both settings answer alike, and as
+    the exhaustive scan does."""
+    from mirge_amd import pack
+    from mirge_amd.engine import Engine, ReadSet
+    from mirge_amd.index import FmIndex
+    rng = np.random.default_rng(47)
+    seqs = [rnd(rng, int(rng.integers(400, 2400))) for _ in range(900)]
+    names = ["m%d" % i for i in range(len(seqs))]
+    assert (1 << 20) <= sum(map(len, seqs)) < (1 << 22)
+    ix = FmIndex.build(names, seqs)
+    decoy = FmIndex.build(["decoy"], ["GATTACAGATTACAGGCCTTAAGGCCTTAACGCGCGTATATA" * 3])
+    reads = []
+    for _ in range(6000):
+        s = seqs[int(rng.integers(0, len(seqs)))]
+        L = int(rng.integers(18, 31))
+        o = int(rng.integers(0, len(s) - L))
+        r = list(s[o:o + L])
+        for p in rng.integers(0, L, int(rng.integers(0, 3))):
+            r[p] = "ACGT"[("ACGT".find(r[p]) + 1) % 4]
+        reads.append("".join(r) if rng.random() < 0.85 else rnd(rng, L))
+    reads = list(dict.fromkeys(reads))
+    w, l, nm = pack.pack_reads(reads)
+    assert w.shape[0] == 1 and nm is None
+    plan = [dict(lib="decoy", seed_len=28, max_mm_seed=0, max_mm_total=2),
+            dict(lib="mid", seed_len=28, max_mm_seed=1, max_mm_total=2)]
+    results = {}
+    for dev_tables in (0, 1):
+        eng = Engine(0)
+        eng.set_option("device_tables", dev_tables)
+        eng.add_library("mid", ix)
+        eng.add_library("decoy", decoy)
+        res = eng.cascade(ReadSet(w, l, None, None, device=eng.device), eng.make_passes(plan))
+        assert res.stats[1]["lds_mode"] in (8, 9, 10), res.stats[1]      # a seed launch served the pass
+        results[dev_tables] = tuple(a.copy() for a in res.to_host())
+        eng.close()
+    for a, b in zip(results[0], results[1]):
+        assert np.array_equal(a, b)
+    lib = model.Library(names, seqs)
+    pick = rng.choice(len(reads), 300, replace=False)
+    want_ref, want_pos, want_mm = model.align_batch(lib, [reads[i] for i in pick], 28, 1, 2)
+    pass_id, ref_id, pos, mm = results[0]
+    for j, i in enumerate(pick):
+        got = (int(ref_id[i]), int(pos[i]), int(mm[i])) if pass_id[i] == 1 else (-1, -1, -1)
+        assert got == (int(want_ref[j]), int(want_pos[j]), int(want_mm[j])), reads[i]
+    assert (pass_id == 1).sum() > 1000
