@@ -143,7 +143,7 @@ typedef struct mrg_dict_view {
   uint32_t log2_slots;
   uint32_t key_bases;
   uint64_t n_keys;     /* positions stored */
-  uint64_t n_overflow; /* positions left to the FM index because their home slot's chain overflowed */
+  uint64_t n_overflow; /* HOME SLOTS whose chain overflowed (a count of homes: every further position of such a home is left to the FM index) */
 } mrg_dict_view;
 int mrg_index_get_dict(const mrg_index *ix, uint32_t key_bases, mrg_dict_view *view);
 
@@ -213,13 +213,19 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * (one-word reads without N, at most 29 nt) / always the general column-by-column sort;
  * "device_tables" = 1 (default) / 0: libraries added afterwards get the derived tables of a large library (>= 2^20
  * bases) filled on the device / built on the host and uploaded (mrg_ctx_library_check_tables);
+ * (round 6) "pos_lists" = 1 (default) / 0, before mrg_ctx_add_library: a library with seed buckets also gets, for every
+ * k-mer whose bucket overflows (an interspersed element, poly-A, a tandem motif: 10^2..10^5 rows), the k-mer's rows in
+ * TEXT ORDER (fm_index.hpp: seed_pos_lists); "pos_scan" = 1 (default) / 0 at run time: a seed launch answers such a
+ * seed by walking that list up to the first valid alignment (plus a 64-ary search of the suffix-sorted rows for an
+ * exact occurrence) instead of verifying every row of the suffix interval -- same answers (runAnnotationPipeline.py:
+ * 581-584 offers every read to every library, whatever the library holds);
  * "wide_rows_16", "round_large": see DESIGN.md. */
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);
 int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,
                         char *arch, uint32_t arch_cap);
 /* What a resident library's derived structures hold (round 5; the bench line of an unfriendly library set reports them):
- * out4 = { text positions stored in its exact-match dictionary, positions left to the FM index because their home
- * slot's chain overflowed (a read whose key is one of those is answered by the slow FM fallback), log2 of the
+ * out4 = { text positions stored in its exact-match dictionary, HOME SLOTS whose chain overflowed (a count of
+ * homes, not of positions: every further position of such a home is left to the FM fallback), log2 of the
  * dictionary's slots (0: no dictionary), k of its seed buckets (0: none) }. */
 int mrg_ctx_library_stats(const mrg_ctx *ctx, int32_t lib, uint64_t *out4);
 /* Self-check of a resident library's derived tables (round 5).  With "device_tables" = 1 (default) a library of at
@@ -227,8 +233,8 @@ int mrg_ctx_library_stats(const mrg_ctx *ctx, int32_t lib, uint64_t *out4);
  * dictionary (csrc/dictbuild.hip) filled ON THE DEVICE from the suffix-array rows and the packed text -- what replaces
  * the `.ebwt` load of runAnnotationPipeline.py:643 at the start of a run; the index file stores none of them.  This call
  * rebuilds the first four on the host (fm_index.cpp) and compares them with the device arrays word by word:
- * mismatches4 = { jump tables, row context, wide rows, seed buckets }, UINT64_MAX for a table the library does not
- * have.  (The dictionary's layout depends on who fills it; what a lookup finds does not: tests/test_gpu_dictbuild.py.)
+ * mismatches4 = { jump tables, row context, wide rows, seed buckets (round 6: with the headers and the position lists
+ * of the overflowing k-mers) }, UINT64_MAX for a table the library does not have.  (The dictionary's layout depends on who fills it; what a lookup finds does not: tests/test_gpu_dictbuild.py.)
  * Slow -- seconds of host time for a 137 Mbp library: tests and bench gates call it, a run does not. */
 int mrg_ctx_library_check_tables(mrg_ctx *ctx, int32_t lib, const mrg_index *index, uint64_t *mismatches4);
 /* A context is used by one host thread at a time (calls on it are serialised by the caller).  It keeps

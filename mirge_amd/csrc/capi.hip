@@ -90,6 +90,8 @@ struct DevLib {
   bool tables_on_device = false;  // jump tables / row context / wide rows / buckets were filled by libtables.hip
   uint32_t* buckets = nullptr;  // seed buckets (fm_index.hpp: fill_seed_buckets), 128 B per k-mer of bucket_k bases
   uint32_t bucket_k = 0;
+  uint32_t* pos_rows = nullptr;  // position lists of the k-mers whose bucket overflows (fm_index.hpp: seed_pos_lists), 16-byte rows
+  uint64_t pos_rows_n = 0;
   // pair tables of a small library (fm_index.hpp: PairTables), for 2-mismatch passes
   uint32_t* pair_jump = nullptr;
   uint64_t* pair_rows = nullptr;
@@ -227,6 +229,11 @@ struct mrg_ctx {
   int64_t split_mixed = 1;    // a batch with long reads / reads with N: its one-word N-free reads take the dictionary kernels
   int64_t split_min_len = 16;  // ... and so do not reads shorter than this (the reference's own minimum length, trim_file.py:33; shorter seed regions than 15 bases have no pair tables)
   int64_t stratum0_unit = 0;  // (measured slower, default off) the exact stratum of a 2-mismatch pass behind a seed launch rides in that launch
+  int64_t walk_diag = 0;
+  void* walk_buf = nullptr;  // wave_seed_kernel: records of the reads left to their position lists (grid x 4 waves x 256 x 32 B)
+  size_t walk_bytes = 0;
+  int64_t pos_scan = 1;   // 0 at run time: the seed launches verify a wide interval row by row as before round 6
+  int64_t pos_lists = 1;  // overflowing seed buckets get their rows in text order too (set before add_library)
   int64_t seed_buckets = 1;  // large libraries get seed buckets where they pay (set before add_library); 0 at run time: not used
   int64_t seed_wgs = 0;      // seed_kernel workgroups (256 threads) per CU; 0 = what the launch's instantiation keeps resident
   int64_t seed_units = 1;    // ... and their runs of passes with at most one seed mismatch go through seed_kernel
@@ -457,13 +464,14 @@ void mrg_ctx_destroy(mrg_ctx* ctx) {
   }
   if (ctx->comm) (void)rccl_api()->CommDestroy(ctx->comm);
   (void)hipFree(ctx->scratch);
+  (void)hipFree(ctx->walk_buf);
   for (auto& kv : ctx->round_tables) (void)hipFree(kv.second);
   delete ctx;
 }
 
 namespace {
 void free_dev_lib(DevLib& l) {
-  void* ptrs[] = {l.blocks, l.super, l.text, l.sa, l.ftab, l.ctx, l.sa16, l.buckets, l.kbits, l.pair_jump, l.pair_jump_s, l.pair_rows, l.dict_slots,
+  void* ptrs[] = {l.blocks, l.super, l.text, l.sa, l.ftab, l.ctx, l.sa16, l.buckets, l.pos_rows, l.kbits, l.pair_jump, l.pair_jump_s, l.pair_rows, l.dict_slots,
                   l.bpair_jump, l.bpair_rows, l.seg_start, l.seg_ref, l.seg_off, l.chunk_seg};
   for (void* p : ptrs) (void)hipFree(p);
 }
@@ -671,6 +679,15 @@ int mrg_ctx_add_library(mrg_ctx* ctx, const mrg_index* h, int32_t* lib_id) {
         (void)hipGetLastError();
         l.buckets = nullptr;
       }
+      if (l.buckets && l.bucket_k && ctx->pos_lists) {
+        // the k-mers whose bucket overflows (repeats, poly-A, tandem motifs): their rows in text order (round 6)
+        size_t tab_base = 0;
+        for (int t = 0; t < 4 && ix.ftab_ks[t] != bk; ++t)
+          if (ix.ftab_ks[t]) tab_base += ((size_t)1 << (2 * ix.ftab_ks[t])) + 1;
+        hipError_t e = mrg::build_seed_pos_lists_device(l.text, l.text_words, reinterpret_cast<const uint64_t*>(l.sa), ix.n, l.ftab + tab_base, bk,
+                                                        l.buckets, &l.pos_rows, &l.pos_rows_n, nullptr);
+        if (e != hipSuccess) return fail(MRG_ERR_HIP, "mrg_ctx_add_library: position lists of the seed buckets: %s", hipGetErrorString(e));
+      }
     }
   }
   // small libraries keep their entries on the host: passes that search several of them with one
@@ -739,6 +756,12 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->stratum0_unit = value != 0;
   } else if (k == "seed_buckets") {
     ctx->seed_buckets = value != 0;
+  } else if (k == "pos_lists") {
+    ctx->pos_lists = value != 0;
+  } else if (k == "pos_scan") {
+    ctx->pos_scan = value != 0;
+  } else if (k == "walk_diag") {
+    ctx->walk_diag = value;
   } else if (k == "seed_wgs") {
     ctx->seed_wgs = value;
   } else if (k == "pair_impl") {
@@ -832,11 +855,29 @@ int mrg_ctx_library_check_tables(mrg_ctx* ctx, int32_t lib, const mrg_index* ind
     if (l.buckets && l.bucket_k) {
       uint64_t bad = 0;
       const uint64_t n_codes = 1ull << (2 * l.bucket_k), chunk = 1ull << 18;
+      std::vector<uint32_t> over_start, over_pos;
+      mrg::seed_pos_lists(ix, l.bucket_k, over_start, over_pos);
+      if (!l.pos_rows && ctx->pos_lists && !over_pos.empty()) bad += 1;
       for (uint64_t lo = 0; lo < n_codes; lo += chunk) {
         const uint64_t hi = std::min(n_codes, lo + chunk);
         want.resize((hi - lo) * 32);
-        mrg::fill_seed_buckets(ix, l.bucket_k, lo, hi, want.data());
+        mrg::fill_seed_buckets(ix, l.bucket_k, lo, hi, want.data(), l.pos_rows ? over_start.data() : nullptr);
         bad += compare(l.buckets + lo * 32, want.data(), want.size());
+      }
+      if (l.pos_rows) {  // the position lists themselves: every row = the wide row of the position the host lists there
+        if (l.pos_rows_n != over_pos.size()) {
+          bad += 1;
+        } else {
+          std::vector<uint64_t> row_of(ix.n + 1u);
+          for (size_t i = 0; i < ix.sa.size(); ++i) row_of[(uint32_t)ix.sa[i]] = ix.sa[i];
+          const size_t chunk_rows = (size_t)1 << 20;
+          for (size_t r0 = 0; r0 < over_pos.size(); r0 += chunk_rows) {
+            const size_t r1 = std::min(over_pos.size(), r0 + chunk_rows);
+            want.resize((r1 - r0) * 4);
+            for (size_t r = r0; r < r1; ++r) mrg::wide_row_of_row(ix, row_of[over_pos[r]], want.data() + 4 * (r - r0));
+            bad += compare(l.pos_rows + r0 * 4, want.data(), want.size());
+          }
+        }
       }
       mismatches4[3] = bad;
     }
@@ -1613,6 +1654,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       un.sa16 = reinterpret_cast<const uint4*>(fm->sa16);
       un.buckets = ctx->seed_buckets ? reinterpret_cast<const uint4*>(fm->buckets) : nullptr;
       un.bucket_k = fm->bucket_k;
+      un.pos_rows = (ctx->seed_buckets && ctx->pos_scan) ? reinterpret_cast<const uint4*>(fm->pos_rows) : nullptr;
       un.sa = fm->sa;
       un.text = fm->text;
       un.blocks = fm->blocks;
@@ -1665,6 +1707,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     sp.row_cap = sp.impl ? 192u : (small ? 1024u : 2048u);
     sp.stats = stats;
     sp.reads = d_reads;
+    sp.reads_hi = nullptr;
     sp.lens = d_lens;
     sp.n_total = (uint32_t)n;
     const int next_list = have_list ? other_list(cur_list) : pair0;
@@ -1697,6 +1740,29 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     const uint32_t seg_cap = segment_capacity(grid, (uint64_t)mrg::kSeedThreads * sp.reads_per_lane, have_list);
     if (!seg_cap && n) return fail(MRG_ERR_ARG, "mrg_cascade_run: survivor lists outgrew the workspace");
     sp.out_seg_cap = seg_cap;
+    sp.walk_buf = nullptr;
+    sp.walk_cap = 0;
+    sp.walk_diag = (uint32_t)ctx->walk_diag;
+    if (sp.impl) {
+      // units with position lists (round 6): every wave keeps the records of the reads it leaves to them in its own stretch
+      // of a context buffer and walks the lists behind its stream
+      bool lists = false;
+      for (uint32_t u = 0; u < sp.n_units; ++u) lists |= sp.unit[u].kind == 0u && sp.unit[u].pos_rows != nullptr;
+      if (lists) {
+        const uint32_t cap = 256u;
+        const size_t need = (size_t)grid * (mrg::kSeedThreads / 64u) * cap * 32u;
+        if (ctx->walk_bytes < need) {
+          HIP_TRY(hipStreamSynchronize(stream));
+          (void)hipFree(ctx->walk_buf);
+          ctx->walk_buf = nullptr;
+          ctx->walk_bytes = 0;
+          HIP_TRY(hipMalloc(&ctx->walk_buf, need));
+          ctx->walk_bytes = need;
+        }
+        sp.walk_buf = reinterpret_cast<uint4*>(ctx->walk_buf);
+        sp.walk_cap = cap;
+      }
+    }
     if (n) HIP_TRY(mrg::launch_seed(sp, grid, stream));
     ctx->last_launches[first] = 1;
     for (uint32_t q = first; q < end; ++q) HIP_TRY(mark(q, q == first));

@@ -145,41 +145,56 @@ __device__ __forceinline__ uint32_t lf_step(const uint32_t* __restrict__ blocks,
 // rows of the first k bases and compared every one with the text, one lane, one row after the other: 10^5 rows for a
 // key inside an element with 10^5 copies -- 77 ms for 2 M reads on `bench.py --workload repeats`.)
 // Returns the best (mismatches << 32 | text position) or ~0; rows = rows looked at, steps = LF steps made.
-template <class Tabs>
+// (LONG: reads of up to 63 bases, q = bases 0..31, qh = bases 32..63)
+template <bool LONG = false, class Tabs>
 __device__ __forceinline__ uint64_t fm_exact_search(const uint32_t* __restrict__ blocks, const uint32_t* __restrict__ super, uint32_t primary,
                                                     const uint32_t* __restrict__ ftab, const Tabs& tabs, const uint64_t* __restrict__ sa,
                                                     const uint32_t* __restrict__ text, uint32_t n, uint64_t q, int32_t L, int32_t R,
                                                     int32_t max_total, uint32_t& best_seg, uint32_t& best_before, uint32_t& rows,
-                                                    uint32_t& steps) {
+                                                    uint32_t& steps, uint32_t rows_cap = 0xFFFFFFFFu, uint64_t qh = 0ull) {
   uint32_t tab_off = 0;
   const uint32_t k = tabs.k[0] ? pick_table(tabs, R, tab_off) : 0u;
   uint32_t lo = 0, hi = n + 1u;
   int32_t j = R;
+  // the bases from read offset j on (32 of them)
+  auto from = [&](int32_t at) -> uint64_t {
+    if (!LONG) return q >> (2u * (uint32_t)at);
+    if (at >= 32) return qh >> (2u * (uint32_t)(at - 32));
+    return at ? ((q >> (2u * (uint32_t)at)) | (qh << (64u - 2u * (uint32_t)at))) : q;
+  };
   if (k) {
     j = R - (int32_t)k;
-    const uint32_t* tab = ftab + tab_off + lex_code((q >> (2u * (uint32_t)j)) & low_bits(2u * k), k);
+    const uint32_t* tab = ftab + tab_off + lex_code(from(j) & low_bits(2u * k), k);
     lo = tab[0];
     hi = tab[1];
   }
   steps = 0;
   while (j > 0 && hi > lo) {
     --j;
-    const uint32_t c = (uint32_t)(q >> (2u * (uint32_t)j)) & 3u;
+    const uint32_t c = (uint32_t)from(j) & 3u;
     lo = lf_step(blocks, super, primary, c, lo);
     hi = lf_step(blocks, super, primary, c, hi);
     ++steps;
   }
   rows = hi > lo ? hi - lo : 0u;
+  if (rows > rows_cap) return ~0ull;  // (the caller leaves a wide interval to the whole wave)
   uint64_t best = ~0ull;
-  const uint64_t tailmask = low_bits(2u * (uint32_t)L) & ~low_bits(2u * (uint32_t)R);
+  // mismatches behind the R exact bases, inside the read: the first word's share, the second word's
+  const uint64_t tailmask = LONG ? (low_bits(2u * (uint32_t)min(L, 32)) & ~low_bits(2u * (uint32_t)min(R, 32)))
+                                 : (low_bits(2u * (uint32_t)L) & ~low_bits(2u * (uint32_t)R));
+  const uint64_t tailmask_h = (LONG && L > 32) ? (low_bits(2u * (uint32_t)(L - 32)) & ~low_bits(2u * (uint32_t)max(R - 32, 0))) : 0ull;
   for (uint32_t i = lo; i < hi; ++i) {
     const uint64_t row = sa[i];
     if ((uint32_t)L > ((uint32_t)(row >> 40) & 255u)) continue;  // (the read would leave the N-free segment)
     const uint32_t s = (uint32_t)row;
     uint32_t mmt = 0;
     if (L > R) {
-      mmt = (uint32_t)__popcll(mismatch_bits(text_window(text, s), q) & tailmask);
+      if (!LONG || tailmask) mmt = (uint32_t)__popcll(mismatch_bits(text_window(text, s), q) & tailmask);
       if ((int32_t)mmt > max_total) continue;
+      if (LONG && tailmask_h) {
+        mmt += (uint32_t)__popcll(mismatch_bits(text_window(text, s + 32u), qh) & tailmask_h);
+        if ((int32_t)mmt > max_total) continue;
+      }
     }
     const uint64_t key = ((uint64_t)mmt << 32) | s;
     if (key < best) {

@@ -408,9 +408,44 @@ __device__ __forceinline__ bool unit_view(int32_t min_len, int32_t max_len, int3
   return el;
 }
 
+// Round 6, reads of 33..63 nt on the seed kernels (LONG instantiations): the read is two words (rd = bases 0..31, rdh =
+// bases 32..63); a unit's view of it is q (the first 32 bases behind the 5' trim) + qh (the rest).  Seeds, bitmaps,
+// buckets and dictionary keys only ever look at q; qh is compared where an alignment is verified.
+__device__ __forceinline__ bool unit_view2(int32_t min_len, int32_t max_len, int32_t poly_t, int32_t trim5, int32_t trim3, uint64_t rd,
+                                           uint64_t rdh, uint32_t L0, uint64_t& q, uint64_t& qh, int32_t& L) {
+  bool el = (int32_t)L0 >= min_len && (int32_t)L0 <= max_len;
+  L = (int32_t)L0;
+  if (poly_t) {
+    int32_t tail;
+    if (L0 > 32u) {
+      const int32_t th = trailing_t(rdh, L - 32);
+      tail = th == L - 32 ? th + trailing_t(rd, 32) : th;
+    } else {
+      tail = trailing_t(rd, L);
+    }
+    el = el && tail >= 3 && (L - tail) >= 11;
+    L -= tail;
+  }
+  L -= trim5 + trim3;
+  q = trim5 ? ((rd >> (2 * trim5)) | (rdh << (64 - 2 * trim5))) : rd;
+  qh = rdh >> (2 * trim5);
+  return el;
+}
+
+template <bool LONG>
+__device__ __forceinline__ bool unit_view_t(int32_t min_len, int32_t max_len, int32_t poly_t, int32_t trim5, int32_t trim3, uint64_t rd,
+                                            uint64_t rdh, uint32_t L0, uint64_t& q, uint64_t& qh, int32_t& L) {
+  if (LONG) return unit_view2(min_len, max_len, poly_t, trim5, trim3, rd, rdh, L0, q, qh, L);
+  qh = 0ull;
+  return unit_view(min_len, max_len, poly_t, trim5, trim3, rd, L0, q, L);
+}
+
 // seed length of a read of L bases in a unit: K = V + 1 seeds of floor(R / K) bases
+// (LONG: the seeds lie in the first word -- V + 1 disjoint stretches of the first min(R, 32) bases still leave one clean)
+template <bool LONG = false>
 __device__ __forceinline__ int32_t seed_bases(int32_t L, int32_t min_seed_len, int32_t V) {
-  const int32_t R = min(L, min_seed_len);
+  int32_t R = min(L, min_seed_len);
+  if (LONG) R = min(R, 32);
   return V ? (R >> 1) : R;
 }
 
@@ -421,8 +456,9 @@ __device__ __forceinline__ const void* lds_pointer(const uint32_t* t, uint32_t w
 // One candidate row of a seed whose k' first bases matched at text position wr.x, `off` read
 // bases left of it: the key of a valid alignment (pass : 8 | mismatches : 8 | start : 32 | segment : 16), ~0 = none.
 // (bucket rows keep their segment room in six bits each: fm_index.hpp)
+template <bool LONG = false>
 __device__ __forceinline__ unsigned long long seed_row_key(const uint32_t* ut, const uint4 wr, uint64_t q, int32_t L, uint32_t off,
-                                                           uint32_t kprime, bool bucket_row) {
+                                                           uint32_t kprime, bool bucket_row, uint64_t qh = 0ull) {
   constexpr unsigned long long kNone = ~0ull;
   const uint32_t before = bucket_row ? (wr.y & 63u) : (wr.y & 255u), after = bucket_row ? ((wr.y >> 6) & 63u) : ((wr.y >> 8) & 255u);
   const uint32_t seg16 = wr.y >> 16;
@@ -445,20 +481,27 @@ __device__ __forceinline__ unsigned long long seed_row_key(const uint32_t* ut, c
     }
     if (need_after > 8u) {
       const uint32_t c2 = min(need_after, 24u) - 8u;
-      const uint32_t want = (uint32_t)(q >> (2u * (off + 8u))) & (uint32_t)low_bits(2u * c2);
+      const uint32_t sh = 2u * (off + 8u);  // (< 64: off <= 16 with wide rows)
+      const uint64_t qq = (LONG && sh) ? ((q >> sh) | (qh << (64u - sh))) : (q >> sh);
+      const uint32_t want = (uint32_t)qq & (uint32_t)low_bits(2u * c2);
       const uint32_t x = (wr.w ^ want) & (uint32_t)low_bits(2u * c2);
       mm += (uint32_t)__popc((x | (x >> 1)) & 0x55555555u);
     }
   }
   if ((int32_t)mm > max_total) return kNone;  // a lower bound of the alignment's mismatches: final
   const uint32_t s = wr.x - off;
-  uint64_t mbits = 0;
+  uint64_t mbits = 0, mbits_h = 0;
   const bool covered = kprime != 0u && off <= 16u && need_after <= 24u && kprime >= 8u && L <= min_seed_len;
   if (!covered) {
     const uint32_t* text = reinterpret_cast<const uint32_t*>(lds_pointer(ut, UW_TEXT));
     mbits = mismatch_bits(text_window(text, s), q) & low_bits(2u * (uint32_t)L);
     mm = (uint32_t)__popcll(mbits);
     if ((int32_t)mm > max_total) return kNone;
+    if (LONG && L > 32) {  // the second word against the text behind the first 32 bases
+      mbits_h = mismatch_bits(text_window(text, s + 32u), qh) & low_bits(2u * (uint32_t)(L - 32));
+      mm += (uint32_t)__popcll(mbits_h);
+      if ((int32_t)mm > max_total) return kNone;
+    }
   }
   // which member (pass) the entry belongs to, and that pass's policy
   const uint32_t n_members = (flags >> 18) & 7u;
@@ -477,14 +520,18 @@ __device__ __forceinline__ unsigned long long seed_row_key(const uint32_t* ut, c
   const uint32_t mw = ut[UW_MEMBERS + 2u * mi];
   const int32_t pass_index = (int32_t)(mw & 0xFFu), seed_len = (int32_t)((mw >> 8) & 0xFFFFu), m_total = (int32_t)(mw >> 24);
   uint32_t mm_seed = mm;
-  if (L > seed_len) mm_seed = (uint32_t)__popcll(mbits & low_bits(2u * (uint32_t)seed_len));  // (then never `covered`)
+  if (L > seed_len) {  // (then never `covered`)
+    mm_seed = (uint32_t)__popcll(mbits & low_bits(2u * (uint32_t)seed_len));
+    if (LONG && seed_len > 32) mm_seed += (uint32_t)__popcll(mbits_h & low_bits(2u * (uint32_t)(seed_len - 32)));
+  }
   if ((int32_t)mm_seed > V || (int32_t)mm > m_total) return kNone;
   return ((unsigned long long)pass_index << 56) | ((unsigned long long)mm << 48) | ((unsigned long long)s << 16) | seg16;
 }
 
+template <bool LONG = false>
 __device__ __forceinline__ void verify_seed_row(const uint32_t* ut, const uint4 wr, uint64_t q, int32_t L, uint32_t off, uint32_t kprime,
-                                                unsigned long long* best_slot, bool bucket_row = false) {
-  const unsigned long long key = seed_row_key(ut, wr, q, L, off, kprime, bucket_row);
+                                                unsigned long long* best_slot, bool bucket_row = false, uint64_t qh = 0ull) {
+  const unsigned long long key = seed_row_key<LONG>(ut, wr, q, L, off, kprime, bucket_row, qh);
   if (key != ~0ull) atomicMin(best_slot, key);
 }
 
@@ -1062,6 +1109,7 @@ constexpr uint32_t kWaveRowsMin = 128u;  // smallest row queue: fewer than 64 pe
 
 struct WaveLds {
   unsigned long long* rd;    // [kWaveCand] packed read
+  unsigned long long* rdh;   // [kWaveCand] its second word (LONG instantiations; else = rd)
   unsigned long long* best;  // [kWaveCand] best key
   uint32_t* r;               // [kWaveCand] read index
   uint32_t* meta;            // [kWaveCand] length | eligibility mask << 8 | queued seeds << 16
@@ -1069,8 +1117,8 @@ struct WaveLds {
   uint16_t* items;           // [kWaveItems] candidate lane | seed << 6
 };
 
-__host__ __device__ constexpr uint32_t wave_lds_bytes(uint32_t row_cap) {
-  return kWaveCand * (8u + 8u + 4u + 4u) + row_cap * 8u + kWaveItems * 2u;
+__host__ __device__ constexpr uint32_t wave_lds_bytes(uint32_t row_cap, bool long_reads) {
+  return kWaveCand * (8u + 8u + 4u + 4u) + (long_reads ? kWaveCand * 8u : 0u) + row_cap * 8u + kWaveItems * 2u;
 }
 __host__ __device__ constexpr uint32_t wave_shared_words() { return kSeedMaxUnits * kUnitWords + kSeedCtlWords + 2u * kSeedCntSlots; }
 
@@ -1084,13 +1132,21 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // A dictionary unit's answer for one read (exact_dict_kernel's probe): the best key, ~0 = none.
 // `first`: the home slot when the caller has loaded it already (first.w's occupied bit may be clear).
-template <class Unit>
+// `wide` (may be null): set when the FM fallback's interval holds more than kDictFallbackRows rows -- the rows are then
+// NOT compared here (one lane, one row after the other: 50 000 rows for a poly-A read whose home's first positions sit
+// in a tail too short for it = a millisecond of ONE lane, and the launch waits for it); the caller leaves the read to
+// the wave (dict_fallback_wave, behind the stream).
+constexpr uint32_t kDictFallbackRows = 64u;
+// LONG: a read of more than 32 bases (qh = bases 32..) always takes the FM search: a slot's window shows 32 bases, and a
+// position whose window and room equal an earlier one's was left out of the table -- for a longer read the text behind the
+// window decides, which the table does not know.
+template <bool LONG = false, class Unit>
 __device__ __forceinline__ unsigned long long dict_unit_probe(const Unit& un, uint64_t q, int32_t L, bool have_first, uint4 first,
-                                                              uint32_t& c_lookups, uint32_t& c_cands) {
+                                                              uint32_t& c_lookups, uint32_t& c_cands, bool* wide = nullptr, uint64_t qh = 0ull) {
   const int32_t pass_index = un.m[0].pass_index, seed_len = un.m[0].seed_len, max_total = un.m[0].max_mm_total;
   const uint32_t smask = (1u << un.log2_slots) - 1u;
   const uint32_t kmask = un.key_bases >= 16u ? 0xFFFFFFFFu : ((1u << (2u * un.key_bases)) - 1u);
-  bool fallback = (uint32_t)L < un.key_bases;
+  bool fallback = (uint32_t)L < un.key_bases || (LONG && L > 32);
   unsigned long long key = ~0ull;
   if (!fallback) {
     const uint64_t lmask = low_bits(2u * (uint32_t)L), seedmask = low_bits(2u * (uint32_t)min(L, seed_len));
@@ -1128,8 +1184,13 @@ __device__ __forceinline__ unsigned long long dict_unit_probe(const Unit& un, ui
   if (fallback) {
     // the FM index (device_util.hpp: fm_exact_search)
     uint32_t bseg = 0xFFFFu, bbefore = 255u, rows = 0, steps = 0;
-    const uint64_t bestk = fm_exact_search(un.blocks, un.super, un.primary, un.ftab, un.tabs, un.sa, un.text, un.n, q, L, min(L, seed_len),
-                                           max_total, bseg, bbefore, rows, steps);
+    const uint64_t bestk = fm_exact_search<LONG>(un.blocks, un.super, un.primary, un.ftab, un.tabs, un.sa, un.text, un.n, q, L, min(L, seed_len),
+                                                 max_total, bseg, bbefore, rows, steps, wide ? kDictFallbackRows : 0xFFFFFFFFu, qh);
+    if (wide && rows > kDictFallbackRows) {
+      *wide = true;
+      c_lookups += 1u + steps;
+      return ~0ull;
+    }
     c_lookups += 1u + steps;
     c_cands += rows;
     if (bestk != ~0ull) {
@@ -1142,9 +1203,262 @@ __device__ __forceinline__ unsigned long long dict_unit_probe(const Unit& un, ui
   return key;
 }
 
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(v, off, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+// The FM fallback of a dictionary unit by the whole wave (wave-uniform arguments): the backward search as in
+// fm_exact_search (every lane the same addresses), the interval's rows 64 a trip.  Returns the unit's key for the read.
+template <bool LONG = false, class Unit>
+__device__ __forceinline__ unsigned long long dict_fallback_wave(const Unit& un, uint64_t q, int32_t L, uint32_t* cands, uint64_t qh = 0ull) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const int32_t pass_index = un.m[0].pass_index, seed_len = un.m[0].seed_len, max_total = un.m[0].max_mm_total;
+  const int32_t R = min(L, seed_len);
+  uint32_t tab_off = 0;
+  const uint32_t k = un.tabs.k[0] ? pick_table(un.tabs, R, tab_off) : 0u;
+  uint32_t lo = 0, hi = un.n + 1u;
+  int32_t j = R;
+  auto from = [&](int32_t at) -> uint64_t {  // the bases from read offset `at` on (fm_exact_search)
+    if (!LONG) return q >> (2u * (uint32_t)at);
+    if (at >= 32) return qh >> (2u * (uint32_t)(at - 32));
+    return at ? ((q >> (2u * (uint32_t)at)) | (qh << (64u - 2u * (uint32_t)at))) : q;
+  };
+  if (k) {
+    j = R - (int32_t)k;
+    const uint32_t* tab = un.ftab + tab_off + lex_code(from(j) & low_bits(2u * k), k);
+    lo = tab[0];
+    hi = tab[1];
+  }
+  while (j > 0 && hi > lo) {
+    --j;
+    const uint32_t c = (uint32_t)from(j) & 3u;
+    lo = lf_step(un.blocks, un.super, un.primary, c, lo);
+    hi = lf_step(un.blocks, un.super, un.primary, c, hi);
+  }
+  const uint64_t tailmask = LONG ? (low_bits(2u * (uint32_t)min(L, 32)) & ~low_bits(2u * (uint32_t)min(R, 32)))
+                                 : (low_bits(2u * (uint32_t)L) & ~low_bits(2u * (uint32_t)R));
+  const uint64_t tailmask_h = (LONG && L > 32) ? (low_bits(2u * (uint32_t)(L - 32)) & ~low_bits(2u * (uint32_t)max(R - 32, 0))) : 0ull;
+  unsigned long long best = ~0ull;  // mismatches : 8 | position : 32 | before : 8 | segment : 16
+  for (uint32_t i = lo + lane; i < hi; i += 64u) {
+    const uint64_t row = un.sa[i];
+    ++*cands;
+    if ((uint32_t)L > ((uint32_t)(row >> 40) & 255u)) continue;
+    const uint32_t s = (uint32_t)row;
+    uint32_t mmt = 0;
+    if (L > R) {
+      if (!LONG || tailmask) mmt = (uint32_t)__popcll(mismatch_bits(text_window(un.text, s), q) & tailmask);
+      if ((int32_t)mmt > max_total) continue;
+      if (LONG && tailmask_h) {
+        mmt += (uint32_t)__popcll(mismatch_bits(text_window(un.text, s + 32u), qh) & tailmask_h);
+        if ((int32_t)mmt > max_total) continue;
+      }
+    }
+    const unsigned long long key = ((unsigned long long)mmt << 56) | ((unsigned long long)s << 24) | (((row >> 32) & 255ull) << 16) | (row >> 48);
+    best = key < best ? key : best;
+  }
+  best = wave_min_u64(best);
+  if (best == ~0ull) return ~0ull;
+  uint32_t ref, pos;
+  SegTables segs{un.seg_start, un.seg_ref, un.seg_off, un.chunk_seg, un.simple_segs};
+  locate_entry(segs, (uint32_t)(best >> 24), (uint32_t)best & 0xFFFFu, (uint32_t)(best >> 16) & 255u, ref, pos);
+  return ((unsigned long long)pass_index << 56) | ((best >> 56) << 48) | ((unsigned long long)ref << 21) | pos;
+}
+
+constexpr uint32_t kMetaWalkLater = 1u << 31;
+constexpr uint32_t kMetaDictLaterShift = 28u;  // ... bits 28-30: the dictionary probe of unit 0 / 1 / 2 is left to the end too  // candidate meta word: a seed of the read is left to its position list
+
+// A seed whose bucket row 0 is `hdr`: its k-mer overflows, has a position list, and the unit is one where a walk in text
+// order may stop early -- ONE library, one seed mismatch, the whole read inside the seed region.
+template <class KU>
+__device__ __forceinline__ bool seed_is_listed(const KU& un, const uint4 hdr, int32_t L) {
+  return ((hdr.y >> 12) & 15u) == kSeedBucketOverflow && un.pos_rows != nullptr && hdr.w > kSeedRowsPerItem && un.n_members == 1u &&
+         un.max_mm_seed == 1 && L <= un.min_seed_len;
+}
+
+
+// A read of a one-mismatch unit (ONE library, the whole read is the seed region, two seeds of k = bucket_k bases) with a
+// seed whose k-mer has 10^2..10^5 rows (an interspersed element, poly-A, a tandem motif): the best alignment through
+// such seeds, by the whole wave, WITHOUT verifying every row of their suffix intervals (round 5: 64 rows a trip; one
+// poly-A seed is 350 trips of ONE wave, and the launch waits for that wave).  s0 / s1: (first row, rows) of the POSITION
+// LIST (fm_index.hpp: seed_pos_lists -- the k-mer's rows in text order) of seed 0 (read offset 0) / seed 1 (offset k);
+// .y == 0: that seed is not wide -- the caller has verified EVERY row of it, and found no exact alignment.
+//   * ONE wide seed: an alignment through it has the other half of the read with at most one substitution.  Without a
+//     substitution it lies in the other seed's rows (verified).  With one, the other half is one of 3 k variants, and
+//     each variant's rows sit in its own seed bucket: 33 bucket lines, one per lane, every row verified -- complete, and
+//     the wide seed's rows are never touched.  (A variant whose own bucket overflows: the list is walked after all.)
+//   * BOTH seeds wide: a list is in TEXT ORDER and the answer within a stratum is the lowest position, so a walk stops
+//     at the first 64-row stretch with a valid alignment; an exact alignment beats every other wherever it lies, and
+//     lies in BOTH lists: when a list's first valid stretch holds an exact row, its lowest is the lowest exact
+//     alignment.  Both first hits with a mismatch: whether an exact alignment exists LATER is decided in the
+//     suffix-sorted rows of seed 0, ordered by the text behind the seed -- a 64-ary search for seed 1's bases (two or
+//     three trips, from the rows' own context words) names the rows where BOTH seeds match; up to 64 are verified where
+//     they are, more are looked for along the list.  A walk that finds nothing in its first stretches (a long list, few
+//     alignments) is cut short and that side completed through the other half's variants, as above.
+// Returns the best key (~0: none); *cands += rows looked at.  Wave-uniform arguments.
+template <class KU>
+__device__ __forceinline__ unsigned long long pos_list_answer(const KU* un, const uint32_t* ut, uint64_t q, int32_t L, uint2 s0, uint2 s1,
+                                                              uint32_t* cands) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t k = un->bucket_k;
+  const uint4* pos_rows = un->pos_rows;
+  uint32_t looked = 0;
+  constexpr uint32_t kAll = 0xFFFFFFFFu;
+  // the first 64-row stretch of a list with a valid alignment: its best key (exact_only: rows with a mismatch do not
+  // count); gives up after max_chunks stretches (resolved = false: the list holds more rows, none valid so far)
+  auto walk = [&](uint2 s, uint32_t off, bool exact_only, uint32_t max_chunks, bool& resolved, uint32_t from_chunk = 0u) -> unsigned long long {
+    resolved = true;
+    uint32_t chunks = from_chunk;
+    for (uint32_t base = 64u * from_chunk; base < s.y; base += 64u, ++chunks) {
+      if (chunks == max_chunks) {
+        resolved = false;
+        return ~0ull;
+      }
+      unsigned long long key = ~0ull;
+      if (base + lane < s.y) {
+        key = seed_row_key(ut, pos_rows[s.x + base + lane], q, L, off, k, false);
+        ++looked;
+        if (exact_only && ((key >> 48) & 255ull) != 0ull) key = ~0ull;
+      }
+      const unsigned long long m = wave_min_u64(key);
+      if (m != ~0ull) return m;
+    }
+    return ~0ull;
+  };
+  // every alignment with exactly one substitution in the k bases at read offset `off`, through the 3 k variants' buckets
+  // (a lane a variant); overflow: some variant's bucket does not hold all of its rows
+  const uint32_t cmask = (1u << (2u * k)) - 1u;
+  auto variants = [&](uint32_t off, bool& overflow) -> unsigned long long {
+    unsigned long long key = ~0ull;
+    bool over = false;
+    if (lane < 3u * k) {
+      // (seed_row_key takes the k bases at `off` as matched -- they are what the bucket was addressed with -- so the row
+      // is judged against the read WITH the substitution: nothing else may differ, and the substitution is the one mismatch)
+      const uint64_t flip = (uint64_t)(lane % 3u + 1u) << (2u * (off + lane / 3u));
+      const uint64_t qv = q ^ flip;
+      const uint4* line = un->buckets + (size_t)((uint32_t)(qv >> (2u * off)) & cmask) * kSeedBucketRows;
+      const uint4 r0 = line[0];
+      const uint32_t cnt = (r0.y >> 12) & 15u;
+      ++looked;
+      if (cnt == kSeedBucketOverflow) {
+        over = true;
+      } else {
+        for (uint32_t i = 0; i < cnt; ++i) {
+          unsigned long long kk = seed_row_key(ut, i ? line[i] : r0, qv, L, off, k, true);
+          kk = (kk != ~0ull && ((kk >> 48) & 255ull) == 0ull) ? kk + (1ull << 48) : ~0ull;
+          key = kk < key ? kk : key;
+        }
+      }
+    }
+    overflow = __any(over) != 0;
+    return wave_min_u64(key);
+  };
+  unsigned long long best = ~0ull;
+  bool res = true, over = false;
+  if (!s0.y || !s1.y) {
+    // ---- one wide seed: the other half's variants ----
+    const bool wide0 = s0.y != 0u;
+    best = variants(wide0 ? k : 0u, over);
+    if (over) {
+      const unsigned long long w = walk(wide0 ? s0 : s1, wide0 ? 0u : k, false, kAll, res);
+      best = w < best ? w : best;
+    }
+    *cands += looked;
+    return best;
+  }
+  // ---- both seeds wide ----
+  // (one trip for what does not depend on anything: the first stretch of both lists and seed 0's interval bounds)
+  uint32_t tab_off = 0, shift = 0;
+  pick_seed_table(un->tabs, (int32_t)k, tab_off, shift);
+  const uint32_t* tab = un->ftab + tab_off + (lex_code(q & low_bits(2u * k), k) << shift);
+  uint4 f0 = make_uint4(0u, 0u, 0u, 0u), f1 = f0;
+  if (lane < s0.y) f0 = pos_rows[s0.x + lane];
+  if (lane < s1.y) f1 = pos_rows[s1.x + lane];
+  uint32_t lo = tab[0];
+  const uint32_t hi = tab[1u << shift];
+  bool res0 = true, res1 = true;
+  unsigned long long a = lane < s0.y ? seed_row_key(ut, f0, q, L, 0u, k, false) : ~0ull;
+  unsigned long long b = lane < s1.y ? seed_row_key(ut, f1, q, L, k, k, false) : ~0ull;
+  looked += (lane < s0.y ? 1u : 0u) + (lane < s1.y ? 1u : 0u);
+  a = wave_min_u64(a);
+  b = wave_min_u64(b);
+  if (a == ~0ull && s0.y > 64u) a = walk(s0, 0u, false, 4u, res0, 1u);
+  if (b == ~0ull && s1.y > 64u) b = walk(s1, k, false, 4u, res1, 1u);
+  if (!res0) {  // (alignments with seed 0 clean and a substitution in the other half; without one: the exact search below)
+    a = variants(k, over);
+    if (over) a = walk(s0, 0u, false, kAll, res);
+  }
+  if (!res1) {
+    b = variants(0u, over);
+    if (over) b = walk(s1, k, false, kAll, res);
+  }
+  best = a < b ? a : b;
+  // an exact alignment further along?  not when a side was walked to its end without any hit (an exact alignment lies
+  // in both lists), not when a walk's first valid stretch already held one
+  const bool none0 = res0 && a == ~0ull, none1 = res1 && b == ~0ull;
+  if (!none0 && !none1 && ((best >> 48) & 255ull) != 0ull) {
+    // ---- seed 0's rows, sorted by what follows the seed ----
+    // (the k bases of seed 1, not the whole rest: a 23-nt read's last base lies outside both seeds, and an alignment with
+    // both seeds clean and THAT base different is in neither side's variants -- the rows found here are verified in full)
+    const uint32_t rest = k;  // inside the row's right context (bases 8..23 behind its position)
+    const uint32_t want = lex_code((q >> (2u * k)) & low_bits(2u * rest), rest);
+    auto row_rest = [&](uint32_t i) -> uint32_t {
+      const uint4 r = un->sa16[i];
+      return lex_code((uint64_t)(r.w >> (2u * (k - kWideRowRightSkip))) & low_bits(2u * rest), rest);
+    };
+    uint32_t n = hi > lo ? hi - lo : 0u;
+    while (n > 64u) {  // lower bound of `want`: 64 probes a trip
+      const uint32_t step = (n + 63u) / 64u;
+      const uint32_t i = lo + lane * step;
+      const bool in = lane * step < n;
+      const bool less = in && row_rest(i) < want;
+      looked += in ? 1u : 0u;
+      const uint32_t n_less = (uint32_t)__popcll(__ballot(less));  // (a prefix of the lanes: the rows are sorted)
+      if (n_less == 0u) {
+        n = 0u;  // the first row is not smaller: the lower bound is `lo` itself
+        break;
+      }
+      const uint32_t nlo = lo + (n_less - 1u) * step + 1u;
+      const uint32_t nend = min(lo + n, lo + n_less * step);
+      lo = nlo;
+      n = nend > nlo ? nend - nlo : 0u;
+    }
+    if (n) {
+      const bool less = lane < n && row_rest(lo + lane) < want;
+      looked += lane < n ? 1u : 0u;
+      lo += (uint32_t)__popcll(__ballot(less));
+    }
+    // rows [lo, ...) whose rest equals `want`: the exact occurrences (contiguous)
+    unsigned long long e = ~0ull;
+    bool eq = false;
+    if (lo + lane < hi) {
+      const uint4 r = un->sa16[lo + lane];
+      ++looked;
+      eq = lex_code((uint64_t)(r.w >> (2u * (k - kWideRowRightSkip))) & low_bits(2u * rest), rest) == want;
+      if (eq) e = seed_row_key(ut, r, q, L, 0u, k, false);
+    }
+    const uint64_t eqm = __ballot(eq);
+    e = wave_min_u64(e);
+    if (eqm == ~0ull) {  // more than 64 of them: the list in text order -- its first valid row, and its first exact one
+      const unsigned long long e2 = walk(s0, 0u, false, kAll, res), e3 = walk(s0, 0u, true, kAll, res);
+      e = e2 < e ? e2 : e;
+      e = e3 < e ? e3 : e;
+    }
+    best = e < best ? e : best;
+  }
+  *cands += looked;
+  return best;
+}
+
 }  // namespace
 
-template <bool BUCKETS, int WAVES>
+// LONG: the batch holds reads of 33..63 nt (second word in p.reads_hi; unit_view2, seed_bases<LONG>, seed_row_key<LONG>):
+// the instantiations <.., .., true>; <.., .., false> is the code of round 5, nothing of that in it.
+template <bool BUCKETS, int WAVES, bool LONG>
 __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const SeedParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -1157,9 +1471,10 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
   unsigned long long* const cnt = reinterpret_cast<unsigned long long*>(ctl + kSeedCtlWords);
   WaveLds w;
   {
-    uint8_t* base = reinterpret_cast<uint8_t*>(smem + wave_shared_words()) + (size_t)wv * wave_lds_bytes(p.row_cap);
+    uint8_t* base = reinterpret_cast<uint8_t*>(smem + wave_shared_words()) + (size_t)wv * wave_lds_bytes(p.row_cap, LONG);
     w.rd = reinterpret_cast<unsigned long long*>(base);
-    w.best = w.rd + kWaveCand;
+    w.rdh = LONG ? w.rd + kWaveCand : w.rd;   // (second words of the candidates; no array of its own without long reads)
+    w.best = w.rdh + (LONG ? kWaveCand : 0u);
     w.rows = reinterpret_cast<uint2*>(w.best + kWaveCand);
     w.r = reinterpret_cast<uint32_t*>(w.rows + p.row_cap);
     w.meta = w.r + kWaveCand;
@@ -1329,16 +1644,18 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
       const uint32_t flags = ut[UW_FLAGS];
       uint64_t q;
       int32_t L;
-      unit_view(0, 255, (int32_t)((flags >> 16) & 1u), (int32_t)(flags & 255u), (int32_t)((flags >> 8) & 255u), w.rd[c], w.meta[c] & 255u, q, L);
+      uint64_t qh = 0;
+      unit_view_t<LONG>(0, 255, (int32_t)((flags >> 16) & 1u), (int32_t)(flags & 255u), (int32_t)((flags >> 8) & 255u), w.rd[c], LONG ? w.rdh[c] : 0ull,
+                 w.meta[c] & 255u, q, qh, L);
       const uint4* wide = reinterpret_cast<const uint4*>(lds_pointer(ut, from_bucket ? UW_BUCKETS : UW_SA16));
       if (e.y & kRowFromPair) {
         const uint64_t row = reinterpret_cast<const uint64_t*>(lds_pointer(ut, UW_BPAIR))[e.x];
-        verify_seed_row(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), q, L, off, 0u, &w.best[c]);
+        verify_seed_row<LONG>(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), q, L, off, 0u, &w.best[c], false, qh);
       } else if (wide) {
-        verify_seed_row(ut, wide[e.x], q, L, off, kp, &w.best[c], from_bucket);
+        verify_seed_row<LONG>(ut, wide[e.x], q, L, off, kp, &w.best[c], from_bucket, qh);
       } else {
         const uint64_t row = reinterpret_cast<const uint64_t*>(lds_pointer(ut, UW_SA))[e.x];
-        verify_seed_row(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), q, L, off, 0u, &w.best[c]);
+        verify_seed_row<LONG>(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), q, L, off, 0u, &w.best[c], false, qh);
       }
     }
   };
@@ -1365,6 +1682,11 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
     }
   };
 
+  // the wave's walk buffer: records (32 bytes: index, length | eligibility, read, best key so far) of the reads with a seed
+  // left to its position list; full -> the seed is verified row by row after all
+  uint4* const walk_buf = BUCKETS && p.walk_buf ? p.walk_buf + 2u * (size_t)(blockIdx.x * (kSeedThreads / 64u) + wv) * p.walk_cap : nullptr;
+  uint32_t n_walk = 0;
+  bool walk_room = BUCKETS && p.walk_buf != nullptr && p.walk_cap >= 64u;
   // ---- 64 parked candidates (or what is left at the end): items unit by unit, rows, the claim ----
   auto work_off = [&](uint32_t cbase, uint32_t n_cand) __attribute__((always_inline)) {
     wave_lds_sync();
@@ -1380,7 +1702,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
         wave_lds_sync();
         const bool has = lane < m;
         uint32_t cl = 0, j = 0;
-        uint64_t q = 0;
+        uint64_t q = 0, qh = 0;
         int32_t L = 0;
         bool pair_mode = false;
         if (has) {
@@ -1389,17 +1711,27 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
           j = e >> 6;
           const uint32_t cm = w.meta[cbase + cl];
           pair_mode = BUCKETS && ((cm >> (16u + 4u * ui + 3u)) & 1u) != 0u;
-          unit_view(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, w.rd[cbase + cl], cm & 255u, q, L);
+          unit_view_t<LONG>(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, w.rd[cbase + cl], LONG ? w.rdh[cbase + cl] : 0ull, cm & 255u, q, qh, L);
         }
         if (un.kind == 1u) {
           if (has) {
-            const unsigned long long key = dict_unit_probe(un, q, L, false, make_uint4(0u, 0u, 0u, 0u), c_lookups, c_cands);
-            if (key != ~0ull) atomicMin(&w.best[cbase + cl], key);
+            // a read already left to the end of the kernel (a seed with a position list in a unit in front): its probe goes
+            // there too -- the pass in front may claim it; so does a probe whose FM fallback meets a wide interval
+            if (BUCKETS && walk_room && (w.meta[cbase + cl] & kMetaWalkLater)) {
+              atomicOr(&w.meta[cbase + cl], 1u << (kMetaDictLaterShift + ui));
+            } else {
+              bool wide = false;
+              const unsigned long long key = dict_unit_probe<LONG>(un, q, L, false, make_uint4(0u, 0u, 0u, 0u), c_lookups, c_cands,
+                                                                   (BUCKETS && walk_room) ? &wide : nullptr, qh);
+              if (wide) atomicOr(&w.meta[cbase + cl], kMetaWalkLater | (1u << (kMetaDictLaterShift + ui)));
+              else if (key != ~0ull) atomicMin(&w.best[cbase + cl], key);
+            }
           }
           return;
         }
         // ---- a seed: bucket count or jump-table load, then its rows into the row queue ----
         uint32_t lo = 0, n_rows = 0, tag = 0;
+        bool listed = false;  // the seed's k-mer has a position list: answered behind the unit's other items
         if (BUCKETS && has && pair_mode) {
           // item j = anchor pair (0,1), (1,2), (0,2): one mismatch in the seed region leaves one of them clean
           const uint32_t A = un.bpair_anchor, kb = 2u * A, amask = (1u << kb) - 1u, n_codes1 = (1u << (2u * kb)) + 1u;
@@ -1413,16 +1745,25 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
           c_cands += n_rows;
           tag = cl | (ui << 11) | ((i0 * A) << 13) | kRowFromPair;
         } else if (has) {
-          const int32_t k = seed_bases(L, un.min_seed_len, un.max_mm_seed);
+          const int32_t k = seed_bases<LONG>(L, un.min_seed_len, un.max_mm_seed);
           const uint32_t off = j * (uint32_t)k;
           uint32_t kp = 0, bcnt = kSeedBucketOverflow;
           if (BUCKETS && un.buckets && (uint32_t)k == un.bucket_k) {
             kp = un.bucket_k;
             lo = ((uint32_t)(q >> (2u * off)) & ((1u << (2u * kp)) - 1u)) * kSeedBucketRows;
-            bcnt = (un.buckets[lo].y >> 12) & 15u;
+            const uint4 hdr = un.buckets[lo];
+            bcnt = (hdr.y >> 12) & 15u;
             ++c_lookups;
+            // an overflowing k-mer with a position list, in a unit where a walk in text order may stop early (ONE
+            // library, one seed mismatch, the whole read is the seed region): answered behind the unit's other items
+            if (walk_room && seed_is_listed(un, hdr, L)) {
+              listed = true;
+              atomicOr(&w.meta[cbase + cl], kMetaWalkLater);
+            }
           }
-          if (bcnt != kSeedBucketOverflow) {
+          if (listed) {
+            n_rows = 0u;
+          } else if (bcnt != kSeedBucketOverflow) {
             n_rows = bcnt;
             tag = cl | (ui << 11) | (off << 13) | (kp << 19) | kRowFromBucket;
           } else {
@@ -1450,18 +1791,19 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
           wide_m &= wide_m - 1ull;
           const uint32_t w_lo = __shfl(lo, src, 64), w_n = __shfl(n_rows, src, 64), w_tag = __shfl(tag, src, 64);
           const uint64_t w_q = __shfl((unsigned long long)q, src, 64);
+          const uint64_t w_qh = LONG ? __shfl((unsigned long long)qh, src, 64) : 0ull;
           const int32_t w_L = __shfl(L, src, 64);
           const uint32_t* ut = utab + ui * kUnitWords;
           unsigned long long* slot = &w.best[cbase + (w_tag & 63u)];
           for (uint32_t i = lane; i < w_n; i += 64u) {
             if (BUCKETS && (w_tag & kRowFromPair)) {
               const uint64_t row = un.bpair_rows[w_lo + i];
-              verify_seed_row(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), w_q, w_L, (w_tag >> 13) & 63u, 0u, slot);
+              verify_seed_row<LONG>(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), w_q, w_L, (w_tag >> 13) & 63u, 0u, slot, false, w_qh);
             } else if (un.sa16) {
-              verify_seed_row(ut, un.sa16[w_lo + i], w_q, w_L, (w_tag >> 13) & 63u, (w_tag >> 19) & 15u, slot);
+              verify_seed_row<LONG>(ut, un.sa16[w_lo + i], w_q, w_L, (w_tag >> 13) & 63u, (w_tag >> 19) & 15u, slot, false, w_qh);
             } else {
               const uint64_t row = un.sa[w_lo + i];
-              verify_seed_row(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), w_q, w_L, (w_tag >> 13) & 63u, 0u, slot);
+              verify_seed_row<LONG>(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), w_q, w_L, (w_tag >> 13) & 63u, 0u, slot, false, w_qh);
             }
           }
         }
@@ -1487,7 +1829,25 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
       rpend = 0u;
     }
     wave_lds_sync();
-    finalize(valid, valid ? w.r[cbase + lane] : 0u, my_meta & 255u, valid ? w.rd[cbase + lane] : 0ull, (my_meta >> 8) & 255u,
+    // a candidate with a seed left to its position list (run_items): everything else about it is known -- its record goes
+    // to the wave's walk buffer, the walk and its claim happen behind the stream (the end of this kernel)
+    const bool later = BUCKETS && valid && (w.meta[cbase + lane] & kMetaWalkLater) != 0u;
+    if (BUCKETS) {
+      const uint64_t lm = __ballot(later);
+      if (lm) {
+        if (later) {
+          uint4* rec = walk_buf + 2u * (size_t)(n_walk + mbcnt(lm));
+          const unsigned long long bk = w.best[cbase + lane], rdv = w.rd[cbase + lane];
+          rec[0] = make_uint4(w.r[cbase + lane], (my_meta & 0xFFFFu) | (w.meta[cbase + lane] & (7u << kMetaDictLaterShift)), (uint32_t)rdv,
+                              (uint32_t)(rdv >> 32));
+          const unsigned long long rh = LONG ? w.rdh[cbase + lane] : 0ull;
+          rec[1] = make_uint4((uint32_t)bk, (uint32_t)(bk >> 32), (uint32_t)rh, (uint32_t)(rh >> 32));
+        }
+        n_walk += (uint32_t)__popcll(lm);
+        walk_room = n_walk + 64u <= p.walk_cap;
+      }
+    }
+    finalize(valid && !later, valid ? w.r[cbase + lane] : 0u, my_meta & 255u, valid ? w.rd[cbase + lane] : 0ull, (my_meta >> 8) & 255u,
              valid ? w.best[cbase + lane] : ~0ull);
   };
 
@@ -1514,6 +1874,8 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
     const bool active = act_b;
     const uint32_t r = r_b, L0 = active ? L_b : 255u;
     const uint64_t rd = rd_b;
+    // (a long read's second word: gathered here, where it is needed -- the lists carry the first word only)
+    const uint64_t rdh = (LONG && active && L0 > 32u) ? p.reads_hi[r] : 0ull;
     L_b = 255u;
     rd_b = 0;
     if (fat_in) {
@@ -1536,13 +1898,13 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
     bool pre_direct = false;
     if (pre_ui < p.n_units) {
       const KUnit& un = kargs->unit[pre_ui];
-      uint64_t q = 0;
+      uint64_t q = 0, qh = 0;
       int32_t L = 0;
-      const bool el = active && unit_view(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, rd, L0, q, L);
+      const bool el = active && unit_view_t<LONG>(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, rd, rdh, L0, q, qh, L);
       const bool search = el && L > 0;
       if ((uint32_t)__popcll(__ballot(search)) >= 16u) {
         const uint32_t kmask = un.key_bases >= 16u ? 0xFFFFFFFFu : ((1u << (2u * un.key_bases)) - 1u);
-        pre_direct = search && (uint32_t)L >= un.key_bases;
+        pre_direct = search && (uint32_t)L >= un.key_bases && !(LONG && L > 32);   // (a long read takes the FM search: parked)
         if (pre_direct) {
           // (one 16-byte load: left to itself the compiler loads the meta half, tests the chain, then loads the window)
           const uint4* sp = un.slots + ((((uint32_t)q & kmask) * kDictHashMul) >> (32u - un.log2_slots));
@@ -1554,9 +1916,9 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
     }
     for (uint32_t ui = 0; ui < p.n_units; ++ui) {
       const KUnit& un = kargs->unit[ui];
-      uint64_t q = 0;
+      uint64_t q = 0, qh = 0;
       int32_t L = 0;
-      const bool el = active && unit_view(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, rd, L0, q, L);
+      const bool el = active && unit_view_t<LONG>(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, rd, rdh, L0, q, qh, L);
       el_mask |= el ? 1u << ui : 0u;
       const int32_t V = un.max_mm_seed;
       const bool search = el && L > V;
@@ -1575,14 +1937,14 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
             // (the home slot is in hand: the probe neither loads nor counts it again; the few lanes whose key
             // chains further walk their chain here -- parked, they would leave the stream's order)
             uint32_t dl = 0;
-            my_best = min(my_best, dict_unit_probe(un, q, L, true, pre_sl, dl, c_dc));
+            my_best = min(my_best, dict_unit_probe<LONG>(un, q, L, true, pre_sl, dl, c_dc, nullptr, qh));
             c_dl += dl;
             queued = 0u;
           }
         }
       } else {
         const uint32_t n_seeds = (uint32_t)V + 1u;
-        const int32_t k = seed_bases(L, un.min_seed_len, V);
+        const int32_t k = seed_bases<LONG>(L, un.min_seed_len, V);
         queued = search ? (1u << n_seeds) - 1u : 0u;  // seeds that need the index
         // a seed region of 3 A .. 4 A - 1 bases in a large library: the three anchor pairs instead of two seeds of
         // 8..9 bases (40..170 rows each in 11 Mbp); parked, the pair lookups run with dense lanes
@@ -1684,6 +2046,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
       const uint32_t c = pend + mbcnt(pm);
       if (park) {
         w.rd[c] = rd;
+        if (LONG) w.rdh[c] = rdh;
         w.best[c] = my_best;
         w.r[c] = r;
         w.meta[c] = L0 | (el_mask << 8) | (queued_all << 16);
@@ -1696,6 +2059,73 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
       work_off(pend, m);
     }
     if (last_trip) break;
+  }
+  // ---- the reads left to their position lists, 64 records a round: the walks one read after the other by the whole wave
+  // (pos_list_answer), then the claim of the 64 ----
+  if (BUCKETS && n_walk) {
+    __threadfence();
+    if (lane == 0u && p.walk_diag) atomicAdd((unsigned long long*)&p.stats[(uint32_t)kargs->unit[0].m[0].pass_index * 5u + 2u], (unsigned long long)n_walk);
+    for (uint32_t base = 0; base < n_walk; base += 64u) {
+      const uint32_t m = min(64u, n_walk - base);
+      wave_lds_sync();
+      if (lane < m) {
+        const uint4 a = walk_buf[2u * (size_t)(base + lane)], b = walk_buf[2u * (size_t)(base + lane) + 1u];
+        w.r[lane] = a.x;
+        w.meta[lane] = a.y;
+        w.rd[lane] = (unsigned long long)a.z | ((unsigned long long)a.w << 32);
+        if (LONG) w.rdh[lane] = (unsigned long long)b.z | ((unsigned long long)b.w << 32);
+        w.best[lane] = (unsigned long long)b.x | ((unsigned long long)b.y << 32);
+      }
+      wave_lds_sync();
+      for (uint32_t i = 0; i < m; ++i) {
+        const uint32_t cm = w.meta[i];
+        const unsigned long long rdv = w.rd[i], rdhv = LONG ? w.rdh[i] : 0ull;
+        for (uint32_t ui = 0; ui < p.n_units; ++ui) {
+          const KUnit& un = kargs->unit[ui];
+          if (!((cm >> (8u + ui)) & 1u)) continue;
+          uint64_t q = 0, qh = 0;
+          int32_t L = 0;
+          unit_view_t<LONG>(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, rdv, rdhv, cm & 255u, q, qh, L);
+          if (un.kind == 1u) {
+            // a dictionary probe left to the end: not needed once a pass in front has the read; else the slots as ever
+            // (every lane the same loads), and a wide FM interval by the whole wave
+            if (!((cm >> (kMetaDictLaterShift + ui)) & 1u) || (w.best[i] >> 56) < (unsigned long long)un.m[0].pass_index) continue;
+            bool wide = false;
+            uint32_t dl = 0, dc = 0;
+            unsigned long long key = dict_unit_probe<LONG>(un, q, L, false, make_uint4(0u, 0u, 0u, 0u), dl, dc, &wide, qh);
+            if (wide) key = dict_fallback_wave<LONG>(un, q, L, &dc, qh);
+            if (lane == 0u) {
+              c_lookups += dl;
+              c_cands += dc;
+              if (key < w.best[i]) w.best[i] = key;
+            }
+            wave_lds_sync();
+            flush_diag(ui);
+            continue;
+          }
+          if (!un.pos_rows) continue;
+          if (L <= un.max_mm_seed || (uint32_t)seed_bases<LONG>(L, un.min_seed_len, un.max_mm_seed) != un.bucket_k) continue;
+          const unsigned long long cur = w.best[i];
+          // an earlier pass has the read, or this one has it without a mismatch (found by a seed verified completely: every
+          // exact alignment lies in its rows): nothing here can be better
+          if ((cur >> 48) <= ((unsigned long long)un.m[0].pass_index << 8)) continue;
+          const uint32_t cmask = (1u << (2u * un.bucket_k)) - 1u;
+          const uint4 h0 = un.buckets[((uint32_t)q & cmask) * kSeedBucketRows];
+          const uint4 h1 = un.buckets[((uint32_t)(q >> (2u * un.bucket_k)) & cmask) * kSeedBucketRows];
+          const uint2 none = make_uint2(0u, 0u);
+          const uint2 s0 = seed_is_listed(un, h0, L) ? make_uint2(h0.z, h0.w) : none, s1 = seed_is_listed(un, h1, L) ? make_uint2(h1.z, h1.w) : none;
+          if (!(s0.y | s1.y)) continue;
+          const unsigned long long key = p.walk_diag >= 2u ? ~0ull : pos_list_answer(&un, utab + ui * kUnitWords, q, L, s0, s1, &c_cands);
+          if (lane == 0u && key < cur) w.best[i] = key;
+          wave_lds_sync();
+          flush_diag(ui);
+        }
+      }
+      wave_lds_sync();
+      const bool valid = lane < m;
+      const uint32_t mt = valid ? w.meta[lane] : 0u;
+      finalize(valid, valid ? w.r[lane] : 0u, mt & 255u, valid ? w.rd[lane] : 0ull, (mt >> 8) & 255u, valid ? w.best[lane] : ~0ull);
+    }
   }
   // ---- counters: one global atomic per non-zero counter and workgroup ----
   {
@@ -2161,7 +2591,7 @@ hipError_t launch_pack_assignments(const int8_t* pass_id, const int32_t* ref_id,
 }
 
 uint32_t seed_lds_bytes(const SeedParams& p) {
-  if (p.impl == 1u) return wave_shared_words() * 4u + (kSeedThreads / 64u) * wave_lds_bytes(p.row_cap);
+  if (p.impl == 1u) return wave_shared_words() * 4u + (kSeedThreads / 64u) * wave_lds_bytes(p.row_cap, p.reads_hi != nullptr);
   const uint32_t tile = kSeedThreads * p.reads_per_lane;
   return tile * 8u + tile * 8u + p.row_cap * 8u + kSeedWideCap * 16u + p.n_units * p.item_cap * 4u +
          kSeedMaxUnits * kUnitWords * 4u + kSeedCtlWords * 4u + kSeedCntSlots * 8u + tile;
@@ -2183,16 +2613,29 @@ hipError_t launch_seed(const SeedParams& p, uint32_t grid, hipStream_t stream) {
     if (p.row_cap < kWaveRowsMin) return hipErrorInvalidValue;
     // (p.wave_regs: the instantiation with more registers and fewer resident workgroups -- an A/B knob)
     const bool more_regs = (p.wave_regs & 1u) != 0u;
-    const void* wk = buckets ? (more_regs ? reinterpret_cast<const void*>(wave_seed_kernel<true, 5>) : reinterpret_cast<const void*>(wave_seed_kernel<true, 6>))
-                             : (more_regs ? reinterpret_cast<const void*>(wave_seed_kernel<false, 6>) : reinterpret_cast<const void*>(wave_seed_kernel<false, 8>));
+    const void* wk = buckets ? (more_regs ? reinterpret_cast<const void*>(wave_seed_kernel<true, 5, false>) : reinterpret_cast<const void*>(wave_seed_kernel<true, 6, false>))
+                             : (more_regs ? reinterpret_cast<const void*>(wave_seed_kernel<false, 6, false>) : reinterpret_cast<const void*>(wave_seed_kernel<false, 8, false>));
     if (lds > 48u * 1024u) {
       hipError_t e = hipFuncSetAttribute(wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
-    if (buckets && more_regs) hipLaunchKernelGGL((wave_seed_kernel<true, 5>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
-    else if (buckets) hipLaunchKernelGGL((wave_seed_kernel<true, 6>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
-    else if (more_regs) hipLaunchKernelGGL((wave_seed_kernel<false, 6>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
-    else hipLaunchKernelGGL((wave_seed_kernel<false, 8>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+    if (p.reads_hi) {  // a batch with reads of 33..63 nt: the instantiations that carry the second word
+      const void* lk = buckets ? (more_regs ? reinterpret_cast<const void*>(wave_seed_kernel<true, 5, true>) : reinterpret_cast<const void*>(wave_seed_kernel<true, 6, true>))
+                               : (more_regs ? reinterpret_cast<const void*>(wave_seed_kernel<false, 6, true>) : reinterpret_cast<const void*>(wave_seed_kernel<false, 8, true>));
+      if (lds > 48u * 1024u) {
+        hipError_t e = hipFuncSetAttribute(lk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+      }
+      if (buckets && more_regs) hipLaunchKernelGGL((wave_seed_kernel<true, 5, true>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+      else if (buckets) hipLaunchKernelGGL((wave_seed_kernel<true, 6, true>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+      else if (more_regs) hipLaunchKernelGGL((wave_seed_kernel<false, 6, true>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+      else hipLaunchKernelGGL((wave_seed_kernel<false, 8, true>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+      return hipGetLastError();
+    }
+    if (buckets && more_regs) hipLaunchKernelGGL((wave_seed_kernel<true, 5, false>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+    else if (buckets) hipLaunchKernelGGL((wave_seed_kernel<true, 6, false>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+    else if (more_regs) hipLaunchKernelGGL((wave_seed_kernel<false, 6, false>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+    else hipLaunchKernelGGL((wave_seed_kernel<false, 8, false>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
     return hipGetLastError();
   }
   const bool fat = p.idx_in && p.in_stride == 4u;

@@ -434,7 +434,8 @@ uint32_t seed_bucket_k(const FmIndex& ix) {
   return (has && fill >= 0.25 && fill <= 4.0) ? k : 0u;
 }
 
-void fill_seed_buckets(const FmIndex& ix, uint32_t k, uint64_t code_lo, uint64_t code_hi, uint32_t* out) {
+namespace {
+const uint32_t* jump_table_of(const FmIndex& ix, uint32_t k) {
   size_t tab_base = 0;
   bool found = false;
   for (int t = 0; t < 4 && !found; ++t) {
@@ -442,12 +443,34 @@ void fill_seed_buckets(const FmIndex& ix, uint32_t k, uint64_t code_lo, uint64_t
     else if (ix.ftab_ks[t]) tab_base += ((size_t)1 << (2 * ix.ftab_ks[t])) + 1;
   }
   if (!found) throw std::runtime_error("seed buckets: the index has no jump table of that k");
-  const uint32_t* tab = ix.ftab.data() + tab_base;
+  return ix.ftab.data() + tab_base;
+}
+}  // namespace
+
+void wide_row_of_row(const FmIndex& ix, uint64_t row, uint32_t* out4) { wide_row_of(ix, row, out4); }
+
+void seed_pos_lists(const FmIndex& ix, uint32_t k, std::vector<uint32_t>& start_by_lex, std::vector<uint32_t>& positions) {
+  const uint32_t* tab = jump_table_of(ix, k);
+  const uint64_t n_codes = 1ull << (2 * k);
+  start_by_lex.assign(n_codes, 0u);
+  positions.clear();
+  for (uint64_t c = 0; c < n_codes; ++c) {
+    start_by_lex[c] = (uint32_t)positions.size();
+    const uint32_t lo = tab[c], hi = tab[c + 1];
+    if (hi - lo <= kSeedBucketRows) continue;
+    const size_t at = positions.size();
+    for (uint32_t i = lo; i < hi; ++i) positions.push_back((uint32_t)ix.sa[i]);
+    std::sort(positions.begin() + at, positions.end());
+  }
+}
+
+void fill_seed_buckets(const FmIndex& ix, uint32_t k, uint64_t code_lo, uint64_t code_hi, uint32_t* out, const uint32_t* over_start) {
+  const uint32_t* tab = jump_table_of(ix, k);
   const unsigned n_threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   std::vector<std::thread> pool;
   const uint64_t n = code_hi - code_lo;
   for (unsigned t = 0; t < n_threads; ++t)
-    pool.emplace_back([&ix, tab, k, code_lo, n, n_threads, t, out] {
+    pool.emplace_back([&ix, tab, k, code_lo, n, n_threads, t, out, over_start] {
       for (uint64_t q = n * t / n_threads; q < n * (t + 1) / n_threads; ++q) {
         const uint64_t code = code_lo + q;                  // first base in the low two bits
         const uint64_t lex = reverse_pairs(code, k);        // the jump table's numbering
@@ -466,6 +489,10 @@ void fill_seed_buckets(const FmIndex& ix, uint32_t k, uint64_t code_lo, uint64_t
           }
         }
         b[1] |= (cnt <= kSeedBucketRows ? cnt : kSeedBucketOverflow) << 12;
+        if (cnt > kSeedBucketRows && over_start) {  // the k-mer's position list (seed_pos_lists)
+          b[2] = over_start[lex];
+          b[3] = cnt;
+        }
       }
     });
   for (auto& th : pool) th.join();

@@ -112,9 +112,21 @@ void fill_wide_rows(const FmIndex& ix, size_t row_lo, size_t row_hi, uint32_t* o
 // jump table serves that k-mer), 16-31 segment id; unused rows have position 0xFFFFFFFF.
 // seed_bucket_k: the k a library gets buckets for (0 = none: only libraries where a k-mer has
 // 0.25..4 rows on average).  Buckets [code_lo, code_hi) into out[32 * (code_hi - code_lo)].
+// Round 6: an OVERFLOWING k-mer (poly-A, a tandem repeat, an interspersed element: 10^3..10^5 rows) also gets its
+// rows as a POSITION LIST -- the wide rows of its text positions in ascending position order, all lists back to back
+// in one array (seed_pos_lists); words 2 and 3 of its bucket's row 0 hold the list's first row and its length.  A
+// seed launch that must verify such an interval walks it in text order and stops at the first valid alignment
+// (the lowest position IS the answer within a stratum) instead of verifying every row of the suffix interval.
 constexpr uint32_t kSeedBucketK = 11, kSeedBucketRows = 8, kSeedBucketOverflow = 15;
 uint32_t seed_bucket_k(const FmIndex& ix);
-void fill_seed_buckets(const FmIndex& ix, uint32_t k, uint64_t code_lo, uint64_t code_hi, uint32_t* out);
+// over_start: null, or seed_pos_lists' start_by_lex (the headers of the overflowing buckets are filled from it)
+void fill_seed_buckets(const FmIndex& ix, uint32_t k, uint64_t code_lo, uint64_t code_hi, uint32_t* out, const uint32_t* over_start = nullptr);
+// Position lists of the k-mers with more than kSeedBucketRows rows: start_by_lex[c] = rows of overflowing k-mers
+// in front of k-mer c (jump-table numbering, 4^k entries), positions = the text positions of every list, ascending
+// inside a list, lists in k-mer order.  (Host restatement of libtables.hip: build_seed_pos_lists_device.)
+void seed_pos_lists(const FmIndex& ix, uint32_t k, std::vector<uint32_t>& start_by_lex, std::vector<uint32_t>& positions);
+// the wide row (fill_wide_rows' format) of one 8-byte suffix-array row
+void wide_row_of_row(const FmIndex& ix, uint64_t row, uint32_t* out4);
 // Pair tables of a small library, for policies with two seed mismatches (kernels.hip,
 // stratum_kernel).  Four disjoint anchors of `anchor` bases at read offsets 0, A, 2A, 3A: two
 // mismatches touch at most two of them, so every alignment with <= 2 seed mismatches matches

@@ -280,6 +280,7 @@ struct SeedUnit {
   const uint4* sa16;
   const uint4* buckets;  // seed buckets of the library (fm_index.hpp), null = none: a seed of exactly bucket_k
   uint32_t bucket_k;     // bases finds its rows in ONE 128-byte line instead of jump table + rows
+  const uint4* pos_rows;  // position lists of the k-mers whose bucket overflows (fm_index.hpp: seed_pos_lists), null = none
   const uint64_t* sa;
   const uint32_t* text;
   const uint32_t* blocks;  // occ blocks + superblocks + sentinel row: the FM fallback of a dictionary unit (kind 1)
@@ -316,6 +317,7 @@ struct SeedParams {
   uint32_t row_cap;         // rows a tile (seed_kernel) / a wave (wave_seed_kernel) can queue
   uint64_t* stats;          // counter slots [pass][5]: processed, aligned, steps, candidates, lookups
   const uint64_t* reads;
+  const uint64_t* reads_hi;  // round 6: the second word of every read (a two-word batch whose reads of 33..63 nt ride the seed kernels), null = none
   const uint8_t* lens;
   uint32_t n_total;
   // the input list: entries of in_stride words, word 0 = the read's index (1: an index list as exact_dict_kernel and
@@ -335,6 +337,10 @@ struct SeedParams {
   int32_t* pos;
   uint8_t* mm;
   uint32_t* packed;  // non-null: the one output array
+  // wave_seed_kernel, units with position lists: walk_cap records of 32 bytes per wave (grid x 4 waves), null = none
+  uint4* walk_buf;
+  uint32_t walk_cap;
+  uint32_t walk_diag;  // experiments: the number of such reads goes into the `steps` counter of the launch's first pass
 };
 uint32_t seed_lds_bytes(const SeedParams& p);
 // workgroups per CU the instantiation a launch gets can keep resident (registers; LDS permitting)
@@ -376,6 +382,10 @@ hipError_t build_row_context_device(const uint32_t* text, uint32_t text_words, c
 hipError_t build_wide_rows_device(const uint32_t* text, uint32_t text_words, const uint64_t* sa, uint32_t n, uint32_t* sa16, hipStream_t stream);   // fill_wide_rows
 hipError_t build_seed_buckets_device(const uint32_t* text, uint32_t text_words, const uint64_t* sa, uint32_t n, const uint32_t* tab, uint32_t k,
                                      uint32_t* buckets, hipStream_t stream);                                                     // fill_seed_buckets
+// position lists of the k-mers whose bucket overflows + the headers in their buckets (fm_index.hpp: seed_pos_lists);
+// *out_rows is hipMalloc'ed by the call (null: no k-mer overflows); synchronises the stream
+hipError_t build_seed_pos_lists_device(const uint32_t* text, uint32_t text_words, const uint64_t* sa, uint32_t n, const uint32_t* tab, uint32_t k,
+                                       uint32_t* buckets, uint32_t** out_rows, uint64_t* out_n, hipStream_t stream);
 
 // dictbuild.hip: the exact-match dictionary of a large library filled on the device (same slot format and rules as
 // dict_index.cpp).  slots: 2^log2_slots x 16 bytes, zeroed by the call; tmp: exact_dict_device_temp_bytes(n) bytes;

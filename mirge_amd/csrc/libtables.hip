@@ -19,6 +19,7 @@
 #include "device_util.hpp"
 #include "fm_index.hpp"
 #include "kernels.hpp"
+#include "prims.hpp"
 
 namespace mrg {
 
@@ -192,7 +193,118 @@ __global__ void __launch_bounds__(256) seed_buckets_kernel(const TabLib b, const
   out[t] = o;
 }
 
+// ---- position lists of the overflowing k-mers (fm_index.cpp: seed_pos_lists) ----
+// one thread per k-mer: an interval of more rows than a bucket holds marks its first row (start[]) and brackets itself
+// in diff[] (+1 at its first row, -1 behind its last: the running sum of diff is "row i lies in such an interval")
+__global__ void __launch_bounds__(256) pos_mark_kernel(const uint32_t* __restrict__ tab, uint32_t k, uint32_t* __restrict__ diff,
+                                                       uint32_t* __restrict__ start) {
+  const uint64_t c = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (c >= (1ull << (2u * k))) return;
+  const uint32_t lo = tab[c], hi = tab[c + 1u];
+  if (hi - lo <= kSeedBucketRows) return;
+  atomicAdd(&diff[lo], 1u);
+  atomicAdd(&diff[hi], 0xFFFFFFFFu);
+  start[lo] = 1u;
+}
+
+// flagged row i -> (list number : position) key at its place among the flagged rows, value = the row
+__global__ void __launch_bounds__(256) pos_compact_kernel(const uint64_t* __restrict__ sa, uint32_t n_rows, const uint32_t* __restrict__ flag,
+                                                          const uint32_t* __restrict__ idx, const uint32_t* __restrict__ seg, uint32_t pos_bits,
+                                                          uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n_rows || !flag[i]) return;
+  const uint32_t j = idx[i];
+  keys[j] = ((uint64_t)seg[i] << pos_bits) | (uint32_t)sa[i];
+  vals[j] = i;
+}
+
+__global__ void __launch_bounds__(256) pos_rows_kernel(const TabLib b, const uint32_t* __restrict__ vals, uint32_t n_over, uint4* __restrict__ out) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j < n_over) out[j] = wide_row_dev(b, b.sa[vals[j]]);
+}
+
+// header of an overflowing bucket: words 2 / 3 of its row 0 = first row of the k-mer's position list, its length
+__global__ void __launch_bounds__(256) pos_header_kernel(const uint32_t* __restrict__ tab, const uint32_t* __restrict__ idx, uint32_t k,
+                                                         uint4* __restrict__ buckets) {
+  const uint64_t code = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (code >= (1ull << (2u * k))) return;
+  const uint32_t lex = lex_code(code, k);
+  const uint32_t lo = tab[lex], cnt = tab[lex + 1u] - lo;
+  if (cnt <= kSeedBucketRows) return;
+  uint4 h = buckets[code * kSeedBucketRows];
+  h.z = idx[lo];
+  h.w = cnt;
+  buckets[code * kSeedBucketRows] = h;
+}
+
 }  // namespace
+
+// Position lists (fm_index.hpp) of the k-mers whose bucket overflows, and the headers in their buckets.  *out_rows:
+// hipMalloc'ed here (null when no k-mer overflows), *out_n rows of 16 bytes.  Synchronises `stream`.
+hipError_t build_seed_pos_lists_device(const uint32_t* text, uint32_t text_words, const uint64_t* sa, uint32_t n, const uint32_t* tab, uint32_t k,
+                                       uint32_t* buckets, uint32_t** out_rows, uint64_t* out_n, hipStream_t stream) {
+  const TabLib b{text, sa, n, n + 1u, text_words};
+  *out_rows = nullptr;
+  *out_n = 0;
+  uint32_t *flag = nullptr, *idx = nullptr, *seg = nullptr, *vals0 = nullptr, *vals1 = nullptr;
+  uint64_t *keys0 = nullptr, *keys1 = nullptr;
+  void *scan_tmp = nullptr, *sort_tmp = nullptr;
+  uint32_t* rows = nullptr;
+  auto done = [&](hipError_t e) {
+    (void)hipFree(flag);
+    (void)hipFree(idx);
+    (void)hipFree(seg);
+    (void)hipFree(vals0);
+    (void)hipFree(vals1);
+    (void)hipFree(keys0);
+    (void)hipFree(keys1);
+    (void)hipFree(scan_tmp);
+    (void)hipFree(sort_tmp);
+    if (e != hipSuccess) (void)hipFree(rows);
+    return e;
+  };
+  hipError_t e;
+  const uint32_t m = b.n_rows + 1u;  // (one element behind the last row: where the last interval's bracket closes)
+  const uint32_t grid_rows = (b.n_rows + 255u) / 256u, grid_codes = (uint32_t)(((1ull << (2u * k)) + 255u) / 256u);
+  if ((e = hipMalloc((void**)&flag, (size_t)m * 4u)) != hipSuccess) return done(e);
+  if ((e = hipMalloc((void**)&idx, (size_t)m * 4u)) != hipSuccess) return done(e);
+  if ((e = hipMalloc((void**)&seg, (size_t)m * 4u)) != hipSuccess) return done(e);
+  if ((e = hipMalloc(&scan_tmp, prims::scan_temp_bytes(m))) != hipSuccess) return done(e);
+  if ((e = hipMemsetAsync(flag, 0, (size_t)m * 4u, stream)) != hipSuccess) return done(e);
+  if ((e = hipMemsetAsync(seg, 0, (size_t)m * 4u, stream)) != hipSuccess) return done(e);
+  hipLaunchKernelGGL(pos_mark_kernel, dim3(grid_codes), dim3(256), 0, stream, tab, k, flag, seg);
+  if ((e = hipGetLastError()) != hipSuccess) return done(e);
+  if ((e = prims::inclusive_sum_u32(flag, flag, m, scan_tmp, stream)) != hipSuccess) return done(e);  // diff -> "in an overflowing interval"
+  if ((e = prims::exclusive_sum_u32(flag, idx, m, scan_tmp, stream)) != hipSuccess) return done(e);   // its place among those rows
+  if ((e = prims::inclusive_sum_u32(seg, seg, m, scan_tmp, stream)) != hipSuccess) return done(e);    // number of its list
+  uint32_t last[2] = {0, 0};
+  if ((e = hipMemcpyAsync(&last[0], idx + b.n_rows, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return done(e);
+  if ((e = hipMemcpyAsync(&last[1], seg + b.n_rows, 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return done(e);
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return done(e);
+  const uint32_t n_over = last[0], n_lists = last[1];
+  if (!n_over) return done(hipSuccess);
+  uint32_t pos_bits = 1, seg_bits = 1;
+  while (pos_bits < 32u && (1ull << pos_bits) <= (uint64_t)n) ++pos_bits;
+  while (seg_bits < 32u && (1ull << seg_bits) <= (uint64_t)n_lists) ++seg_bits;
+  if ((e = hipMalloc((void**)&keys0, (size_t)n_over * 8u)) != hipSuccess) return done(e);
+  if ((e = hipMalloc((void**)&keys1, (size_t)n_over * 8u)) != hipSuccess) return done(e);
+  if ((e = hipMalloc((void**)&vals0, (size_t)n_over * 4u)) != hipSuccess) return done(e);
+  if ((e = hipMalloc((void**)&vals1, (size_t)n_over * 4u)) != hipSuccess) return done(e);
+  if ((e = hipMalloc(&sort_tmp, prims::radix_temp_bytes(n_over))) != hipSuccess) return done(e);
+  if ((e = hipMalloc((void**)&rows, (size_t)n_over * 16u)) != hipSuccess) return done(e);
+  hipLaunchKernelGGL(pos_compact_kernel, dim3(grid_rows), dim3(256), 0, stream, sa, b.n_rows, flag, idx, seg, pos_bits, keys0, vals0);
+  if ((e = hipGetLastError()) != hipSuccess) return done(e);
+  bool second = false;
+  if ((e = prims::radix_sort_pairs_u64(keys0, keys1, vals0, vals1, n_over, pos_bits + seg_bits, sort_tmp, stream, &second)) != hipSuccess) return done(e);
+  hipLaunchKernelGGL(pos_rows_kernel, dim3((n_over + 255u) / 256u), dim3(256), 0, stream, b, second ? vals1 : vals0, n_over, reinterpret_cast<uint4*>(rows));
+  if ((e = hipGetLastError()) != hipSuccess) return done(e);
+  hipLaunchKernelGGL(pos_header_kernel, dim3(grid_codes), dim3(256), 0, stream, tab, idx, k, reinterpret_cast<uint4*>(buckets));
+  if ((e = hipGetLastError()) != hipSuccess) return done(e);
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return done(e);
+  *out_rows = rows;
+  *out_n = n_over;
+  return done(hipSuccess);
+}
 
 size_t jump_tables_device_temp_bytes(uint32_t n_rows) {
   const size_t tiles = ((size_t)n_rows + kScanTile - 1) / kScanTile;

@@ -170,8 +170,8 @@ class Engine:
         return lid.value
 
     def library_dict_stats(self, key):
-        """(positions stored in the library's exact-match dictionary, positions left to the FM index because their
-        home slot's chain overflowed) -- mrg_ctx_library_stats."""
+        """(positions stored in the library's exact-match dictionary, HOME SLOTS whose chain overflowed -- every further
+        position of such a home is left to the FM index: a count of homes, not of positions) -- mrg_ctx_library_stats."""
         out = (C.c_uint64 * 4)()
         check(self._lib.mrg_ctx_library_stats(self._h, self.libs[key], out))
         return int(out[0]), int(out[1])

@@ -111,7 +111,10 @@ def main():
     lines = ["# rocprofv3 summary `%s` (%s workload, %s reads per GPU, tree %s)\n" % (a.tag, a.workload, reads, head)]
 
     stats = newest(os.path.join(ROOT, "gpurun_out", a.tag + "_stats", "**", "*_kernel_stats.csv"))
+    kernel_avg_ms = {}   # rocprofv3's own duration per kernel (no event bracket around it): bench.py reports it beside its HIP-event figure
     if stats:
+        for r in csv.DictReader(open(stats)):
+            kernel_avg_ms[r["Name"].split("(")[0].replace("void ", "")] = float(r["AverageNs"]) / 1e6
         shutil.copy(stats, os.path.join(out, a.tag + "_kernel_stats.csv"))
         lines.append("## `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras`\n")
         lines.append("| kernel | calls | avg ms | total ms | % |\n|---|---|---|---|---|")
@@ -163,6 +166,8 @@ def main():
                                fetch_bytes_doubled=int(sum(v["dbl"] for v in vals) / n),
                                write_bytes=int(sum(v["wb"] for v in vals) / n),
                                applies=vals[0]["applies"] if all(v["applies"] == vals[0]["applies"] for v in vals) else "mixed")
+            if kn in kernel_avg_ms:
+                traffic[kn]["kernel_avg_ms"] = round(kernel_avg_ms[kn], 5)
         lines.append("")
     for kind, title, keys in (
             ("sq", "SQ counters per launch (one step)",

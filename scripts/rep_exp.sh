@@ -1,11 +1,19 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT"
-python -m pytest tests/test_gpu_dict.py tests/test_gpu_dict_edges.py tests/test_gpu_random_worlds.py tests/test_gpu_parity.py -q -m gpu -x 2>&1 | grep -E "passed|failed|error" | tail -3
-for v in "" "--mix mrna=0" "--mix rrna_ncrna=0" "--mix mrna=0 --mix rrna_ncrna=0"; do
-  timeout 600 python bench.py --workload repeats --reads 2000000 --steps 2 --warmup 1 --no-extras --no-cpu-baseline --scan-sample 0 $v > gpurun_out/rx.json 2> gpurun_out/rx.err
-  python - "$v" <<'PY'
-import json, sys
-d = json.load(open("gpurun_out/rx.json"))
-print(sys.argv[1], d["ms_per_step"], [round(p["ms"], 3) for p in d["passes"]], [(p["candidates"], p["lookups"]) for p in d["passes"]][6:8])
+# repeats experiments (one gpurun call): where the large launch's time goes
+mkdir -p gpurun_out
+i=0
+run() {
+  timeout 600 python bench.py --workload repeats --steps 5 --no-legs --no-extras --no-cpu-baseline --scan-sample 0 "$@" > gpurun_out/rexp_$i.json 2> gpurun_out/rexp_$i.err
+  python - <<PY
+import json
+try:
+    d = json.load(open("gpurun_out/rexp_$i.json"))
+    print("$*", d["ms_per_step"], [(p["kernel"][:9], round(p["ms"], 3), p["processed"], p["aligned"], p.get("steps"), p["candidates"]) for p in d["passes"] if p["ms"] > 0.01 or p["lib"] in ("ncrna_others", "mrna")])
+except Exception as e:
+    print("$*", "failed", e); print(open("gpurun_out/rexp_$i.err").read()[-400:])
 PY
-done
+  i=$((i+1))
+}
+run --opt walk_diag=1
+run --opt walk_diag=1 --mix mrna=0 --mix random=0.12
+run --opt walk_diag=1 --mix mrna=0 --mix rrna_ncrna=0 --mix random=0.17
