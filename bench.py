@@ -102,14 +102,14 @@ def kernel_name(W, table_row, s, n_bases):
         # (FIRST = the pass streams the whole read set; KBITS = its library has the 9-mer bitmap)
         return "mrg::exact_dict_kernel<%s, %s>" % ("true" if s.get("first_pass") else "false", "true" if n_bases <= 190000 else "false")
     if s["lds_mode"] == 11:
-        return "mrg::pair_wave_kernel"
+        return "mrg::pair_wave_kernel<%s>" % ("true" if s.get("variant", 0) & 8 else "false")
     if s["lds_mode"] in (8, 9):
         v, fat = s.get("variant", 0) & 3, "true" if s.get("variant", 0) & 4 else "false"
         if v:
             # (third argument, round 6: the instantiation that carries the second word of reads of 33..63 nt -- variant + 8)
             return "mrg::wave_seed_kernel<%s, %s>" % ({(8, 1): "false, 8", (9, 1): "true, 6", (8, 2): "false, 6", (9, 2): "true, 5"}[(s["lds_mode"], v)],
                                                       "true" if s.get("variant", 0) & 8 else "false")
-        return "mrg::seed_kernel<%s, %s>" % ("false, 8" if s["lds_mode"] == 8 else "true, 6", fat)
+        return "mrg::seed_kernel<%s, %s, %s>" % ("false, 8" if s["lds_mode"] == 8 else "true, 6", fat, "true" if s.get("variant", 0) & 8 else "false")
     has_ctx = n_bases >= (1 << 20) and s["lds_mode"] in (0, 1)
     return "mrg::match_kernel<%d, %s, %s, %s, %s>" % (
         W, {0: "false, false", 1: "true, false", 2: "true, true", 3: "false, true"}[s["lds_mode"]],

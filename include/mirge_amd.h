@@ -219,6 +219,10 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * seed by walking that list up to the first valid alignment (plus a 64-ary search of the suffix-sorted rows for an
  * exact occurrence) instead of verifying every row of the suffix interval -- same answers (runAnnotationPipeline.py:
  * 581-584 offers every read to every library, whatever the library holds);
+ * "long_lane" = 1 (default) / 0: in a batch of two words per read, the N-free reads of 33..63 nt go with the one-word
+ * reads through the dictionary kernels (exact_dict_kernel and the FM kernels of that lane cannot see them: a length is
+ * taken only when every pass either runs in a seed launch, keeps it out by its window, or -- pair_wave_kernel -- sees at
+ * most 32 bases of it behind the trims or could not align it at all) / they take the FM kernels as before round 6;
  * "wide_rows_16", "round_large": see DESIGN.md. */
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);
 int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,
@@ -302,7 +306,9 @@ typedef struct mrg_pass_stats {
                           own: a read with nothing left to look up is finished on the spot, the others are parked
                           and worked off 64 at a time), 2 = wave_seed_kernel<false, 6> / <true, 5> (more registers);
                           + 4 = the launch's input list carried its reads (16-byte entries written by the seed
-                          launch in front of it: seed_kernel<.., .., true>).
+                          launch in front of it: seed_kernel<.., .., true>);
+                          + 8 (round 6) = the LONG instantiation: the batch's reads of 33..63 nt ride this launch too
+                          (seeds from their first 32 bases, the second word compared where an alignment is verified).
                           lds_mode 11 (round 4) = pair_wave_kernel: the anchor-pair search of a 2-mismatch pass for
                           one-word reads without N, items and rows compacted over the wave */
   uint32_t reserved;

@@ -259,7 +259,9 @@ def annotate_main(args, engine_factory=None, materialize=False):
             except ingest.DeviceIngestUnsupported:
                 fq = None   # the host parser takes it (and words whatever is wrong with the file)
         if fq is None:
-            fq = ingest.load_fastq(os.path.abspath(raw[i]), adapter=args.adapter, threads=max(1, n_cpu // n_jobs), part=part,
+            # (every rank of the node runs its own loader: the thread budget is -cpu shared out over the ranks -- eight ranks
+            # inflating one .gz with -cpu threads each were 8 x -cpu threads on one host: advisor, round 5)
+            fq = ingest.load_fastq(os.path.abspath(raw[i]), adapter=args.adapter, threads=max(1, n_cpu // (n_jobs * max(1, world))), part=part,
                                    n_parts=n_parts)
         return fq, time.time() - t1
 

@@ -230,6 +230,7 @@ struct mrg_ctx {
   int64_t split_min_len = 16;  // ... and so do not reads shorter than this (the reference's own minimum length, trim_file.py:33; shorter seed regions than 15 bases have no pair tables)
   int64_t stratum0_unit = 0;  // (measured slower, default off) the exact stratum of a 2-mismatch pass behind a seed launch rides in that launch
   int64_t walk_diag = 0;
+  int64_t long_lane = 1;   // round 6: the reads of 33..63 nt of a split batch ride the dictionary kernels too (their LONG instantiations)
   void* walk_buf = nullptr;  // wave_seed_kernel: records of the reads left to their position lists (grid x 4 waves x 256 x 32 B)
   size_t walk_bytes = 0;
   int64_t pos_scan = 1;   // 0 at run time: the seed launches verify a wide interval row by row as before round 6
@@ -762,6 +763,8 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->pos_scan = value != 0;
   } else if (k == "walk_diag") {
     ctx->walk_diag = value;
+  } else if (k == "long_lane") {
+    ctx->long_lane = value != 0;
   } else if (k == "seed_wgs") {
     ctx->seed_wgs = value;
   } else if (k == "pair_impl") {
@@ -1143,8 +1146,23 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   const uint64_t* nmask_eff = d_nmask;
   const bool split = ctx->dict && ctx->split_mixed && n > 0 && ctx->force_lds_mode < 0 &&
                      (!dict_batch || ctx->hint_min_len < ctx->split_min_len) &&
-                     ctx->hint_min_len <= 32 && ctx->hint_max_len >= ctx->split_min_len;  // (some read may be on either side)
+                     (ctx->hint_min_len <= 32 || (ctx->long_lane && words_per_read >= 2 && ctx->hint_min_len <= 63)) &&
+                     ctx->hint_max_len >= ctx->split_min_len;  // (some read may be on either side)
 
+  // Round 6: which read lengths beyond 32 nt the one-word lane of a split batch takes (bit b = length 33 + b, up to 63): the
+  // seed kernels have instantiations that carry a read's second word (seeds from the first 32 bases, the rest compared
+  // where an alignment is verified; dictionary units answer such reads by FM search); exact_dict_kernel and the FM kernels
+  // of the lane do not, pair_wave_kernel takes a read whose TRIMMED length fits one word.  A length is let in when every
+  // pass of the cascade either runs in a seed launch, or cannot hold a read of that length in its window, or
+  // (pair_wave_kernel) sees at most 32 bases of it or could not align it at all (longer than the library's longest entry).
+  // Decided below, once the lambdas that route a pass exist; 0 = the lane is for reads of at most 32 nt, as before.
+  uint64_t long_mask = 0;
+  auto window_bits = [](const mrg_pass_cfg& c) -> uint64_t {
+    uint64_t m = 0;
+    for (int L = 33; L <= 63; ++L)
+      if (L >= c.min_len && L <= c.max_len) m |= 1ull << (L - 33);
+    return m;
+  };
   // the classic path: one match_kernel launch for pass i
   auto run_single = [&](uint32_t i, int32_t k_first, int32_t k_last, bool first_part, bool last_part, bool by_pairs = false) -> int {
     const mrg_pass_cfg& c = passes[i];
@@ -1210,6 +1228,8 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       ctx->last_lds[i] = 0u;
       ctx->last_mode[i] = 7u;
       ctx->last_group[i] = i;
+      if (long_mask & window_bits(c))
+        return fail(MRG_ERR_ARG, "mrg_cascade_run: internal: reads of more than 32 nt reached exact_dict_kernel (pass %u)", i);
       if (n) HIP_TRY(mrg::launch_exact_dict(e, grid, stream));
       ctx->last_launches[i] += 1;
       HIP_TRY(mark(i, true));
@@ -1243,6 +1263,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     p.text_words = l.text_words;
     p.simple_segs = l.simple ? 1u : 0u;
     p.reads = d_reads;
+    p.reads_hi = nullptr;
     p.lens = d_lens;
     p.nmask = nmask_eff;
     p.n_total = (uint32_t)n;
@@ -1369,7 +1390,11 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
     ctx->last_kbits_log2[i] = use_kbits ? 18u : 0u;
     ctx->last_pair_anchor[i] = p.pair_anchor;
     if (rows_kernel) ctx->last_mode[i] = pair_wave ? 11u : (rows_lds_text ? 5u : 6u);
+    if (long_mask && !pair_wave && (long_mask & window_bits(c)))
+      return fail(MRG_ERR_ARG, "mrg_cascade_run: internal: reads of more than 32 nt reached a one-word kernel (pass %u)", i);
     if (n && pair_wave) {
+      p.reads_hi = long_mask ? d_reads + n : nullptr;
+      ctx->last_variant[i] = long_mask ? 8u : 0u;
       HIP_TRY(mrg::launch_pair_wave(p, grid, stream));
     } else if (n && rows_kernel) {
       HIP_TRY(mrg::launch_stratum(p, words_eff, rows_lds_text, grid, lds_total, stream));
@@ -1419,6 +1444,9 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
 
   // one fused_kernel launch for the running passes among [first, last]
   auto run_fused = [&](const uint32_t* members, uint32_t n_sub, bool ends_cascade) -> int {
+    for (uint32_t q = 0; q < n_sub; ++q)
+      if (long_mask & window_bits(passes[members[q]]))
+        return fail(MRG_ERR_ARG, "mrg_cascade_run: internal: reads of more than 32 nt reached fused_kernel<1> (pass %u)", members[q]);
     mrg::FusedParams fp;
     std::memset(&fp, 0, sizeof fp);
     fp.n_sub = n_sub;
@@ -1700,14 +1728,14 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       sp.impl = impl ? 1u : 0u;
       sp.wave_regs = impl >= 2 ? 1u : 0u;
       for (uint32_t q = first; q < end; ++q)
-        ctx->last_variant[q] = (sp.impl ? ((sp.wave_regs & 1u) ? 2u : 1u) : 0u) | ((have_list && list_fat) ? 4u : 0u);
+        ctx->last_variant[q] = (sp.impl ? ((sp.wave_regs & 1u) ? 2u : 1u) : 0u) | ((have_list && list_fat) ? 4u : 0u) | (long_mask ? 8u : 0u);
     }
     sp.reads_per_lane = 1u;
     sp.item_cap = mrg::kSeedThreads * sp.reads_per_lane * 2u;
     sp.row_cap = sp.impl ? 192u : (small ? 1024u : 2048u);
     sp.stats = stats;
     sp.reads = d_reads;
-    sp.reads_hi = nullptr;
+    sp.reads_hi = long_mask ? d_reads + n : nullptr;
     sp.lens = d_lens;
     sp.n_total = (uint32_t)n;
     const int next_list = have_list ? other_list(cur_list) : pair0;
@@ -1785,12 +1813,46 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   };
   auto small_class = [&](uint32_t i) { return !ctx->libs[passes[i].lib].host_seqs.empty(); };
 
+  uint64_t long_plan = 0;  // the lengths the lane will take (long_mask is set while the lane's cascade runs)
+  bool long_plan_tried = false;
+  if (split && ctx->long_lane && words_per_read >= 2 && ctx->hint_max_len > 32) {
+    long_plan_tried = true;
+    // a dry run of the lane's launch plan (the loop below with dict_batch = true)
+    long_plan = (1ull << 31) - 1ull;
+    const bool saved = dict_batch;
+    dict_batch = true;
+    bool la = false;
+    for (uint32_t i = 0; i < n_pass && long_plan; ++i) {
+      if (!runs[i]) continue;
+      const mrg_pass_cfg& c = passes[i];
+      const DevLib& l = ctx->libs[c.lib];
+      // a seed launch: every length (the lane's first launch may be one when its pass can hold such reads: below)
+      if ((la || window_bits(c)) && seedable(i)) {
+        la = true;
+        continue;
+      }
+      la = true;
+      const bool pair_route = c.max_mm_seed == 2 && ctx->pair_seeds && l.pair_anchor && ctx->force_lds_mode < 0 && !c.poly_t &&
+                              c.seed_len >= (int32_t)(4u * l.pair_anchor) && ctx->pair_impl != 0;
+      if (pair_route) {
+        for (int L = 33; L <= 63; ++L) {
+          const int Lt = L - c.trim5 - c.trim3;
+          if (L >= c.min_len && L <= c.max_len && Lt > 32 && Lt <= (int)l.max_ref_len) long_plan &= ~(1ull << (L - 33));
+        }
+      } else {
+        long_plan &= ~window_bits(c);  // exact_dict_kernel, an FM kernel: only lengths its window keeps out
+      }
+    }
+    dict_batch = saved;
+  }
   uint32_t split_grid = 0, split_cap = 0;
   if (split) {
     mrg::SplitParams sp;
     sp.lens = d_lens;
     sp.nmask = d_nmask;
     sp.n_total = (uint32_t)n;
+    sp.long_ok = long_plan;
+    sp.nmask_hi = (d_nmask && words_per_read >= 2) ? d_nmask + n : nullptr;
     sp.min_len = (uint32_t)ctx->split_min_len;
     split_grid = std::min<uint32_t>((uint32_t)ctx->n_cu * 2u, mrg::kMaxSegments);
     split_cap = segment_capacity(split_grid, 1024, false);
@@ -1832,6 +1894,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       dict_batch = true;
       words_eff = 1u;
       nmask_eff = nullptr;
+      long_mask = long_plan;  // (... and the reads of 33..63 nt the plan lets in)
     }
   }
   bool launched_any = false;
@@ -1841,7 +1904,10 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       ++i;
       continue;
     }
-    if (launched_any && seedable(i)) {
+    // (a batch that may hold reads of 33..63 nt: the one-word lane reads a list from its first launch on, and only a seed
+    // launch can take such reads -- e.g. a batch of long reads only, whose first pass to run is the hairpin pass, len > 25)
+    const bool lane_first = split && chain == 1 && ctx->long_lane && words_per_read >= 2 && long_plan_tried && window_bits(passes[i]) != 0;
+    if ((launched_any || lane_first) && seedable(i)) {
       std::vector<UnitPlan> plan;
       const bool cls = small_class(i);
       uint32_t j = i;
@@ -2074,9 +2140,16 @@ int mrg_cascade_run_long(mrg_ctx* ctx, const uint64_t* d_words, const uint64_t* 
   uint64_t* d_stats = reinterpret_cast<uint64_t*>((char*)scratch.p + table_bytes);
   HIP_TRY(hipMemcpyAsync(scratch.p, host.data(), (size_t)n_pass * sizeof(mrg::LongPass), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemsetAsync(d_stats, 0, stats_bytes, stream));
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
+  struct Events {  // (destroyed on every way out: advisor, round 5)
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Events() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } evs_long;
+  HIP_TRY(hipEventCreate(&evs_long.a));
+  HIP_TRY(hipEventCreate(&evs_long.b));
+  const hipEvent_t e0 = evs_long.a, e1 = evs_long.b;
   hipError_t err = hipEventRecord(e0, stream);
   if (err == hipSuccess && n) {
     mrg::LongParams p;
@@ -2106,8 +2179,6 @@ int mrg_cascade_run_long(mrg_ctx* ctx, const uint64_t* d_words, const uint64_t* 
   if (err == hipSuccess) err = hipStreamSynchronize(stream);
   float ms = 0.f;
   if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   HIP_TRY(err);
   if (stats) {
     uint64_t offered = 0;

@@ -1059,7 +1059,10 @@ hipError_t collapse_reads(const uint64_t* d_reads, uint32_t W, const uint8_t* d_
   // ---- readLengthDic + the largest sample id: what the batch holds decides the path; an out-of-range sample id is
   // an error (it would index past a row of quant) ----
   std::vector<uint64_t> h_hist((size_t)256 * n_samples);
-  const bool try_fast = W == 1 && !d_nmask && allow_fast && n_samples <= 16u;
+  // (the fast path loads reads 16 bytes, lengths 4 and sample ids 8 bytes at a time: a caller's sliced arrays -- d_lens + 1 --
+  // take the general path: advisor, round 5)
+  const bool aligned = ((uintptr_t)d_reads % 16u == 0u) && ((uintptr_t)d_lens % 4u == 0u) && (!smp || (uintptr_t)smp % 8u == 0u);
+  const bool try_fast = W == 1 && !d_nmask && allow_fast && n_samples <= 16u && aligned;
   if (try_fast) {
     // one pass for the histogram, the sample bound and the raw counts the fast path partitions by (K0)
     const size_t mark = arena.used;

@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "device_util.hpp"
 #include "dict_index.hpp"
@@ -377,6 +378,7 @@ struct SeedLds {
   uint32_t* ctl;             // [0] survivors, [1] longest input segment, [2] rows, [3] wide, [4 + 3 parity + u] items of unit u (by tile parity)
   unsigned long long* cnt;   // [kSeedCntSlots]
   uint8_t* sL0;              // [tile] read length, 255 = no read
+  unsigned long long* srh;   // [tile] second word of the read (LONG instantiations only: behind everything else)
 };
 
 __device__ __forceinline__ SeedLds carve_seed_lds(uint32_t* smem, uint32_t tile, uint32_t row_cap, uint32_t item_cap, uint32_t n_units) {
@@ -390,6 +392,7 @@ __device__ __forceinline__ SeedLds carve_seed_lds(uint32_t* smem, uint32_t tile,
   l.ctl = l.utab + kSeedMaxUnits * kUnitWords;
   l.cnt = reinterpret_cast<unsigned long long*>(l.ctl + kSeedCtlWords);
   l.sL0 = reinterpret_cast<uint8_t*>(l.cnt + kSeedCntSlots);
+  l.srh = reinterpret_cast<unsigned long long*>(l.sL0 + ((tile + 7u) & ~7u));
   return l;
 }
 
@@ -541,7 +544,9 @@ __device__ __forceinline__ void verify_seed_row(const uint32_t* ut, const uint4 
 // workgroups per CU instead of 6)
 // FAT: the input list carries its reads (SeedParams::in_stride = 4) -- an instantiation of its own: as a run-time
 // branch of the walk it cost the index-list instantiation 28 more bytes of scratch and 40 % of its speed
-template <bool BUCKETS, int WAVES, bool FAT>
+// LONG: the batch holds reads of 33..63 nt (second word in p.reads_hi): the <.., true> instantiations carry it; <.., false> is
+// the code of round 5
+template <bool BUCKETS, int WAVES, bool FAT, bool LONG>
 __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t T = p.reads_per_lane, tile = kSeedThreads * T;
@@ -678,18 +683,21 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
     {
       unsigned long long my_best = ~0ull;
       el_mask = 0u;
+      // (a long read's second word: gathered here -- the lists carry the first word only)
+      const uint64_t rdh = (LONG && active && L0 > 32u) ? p.reads_hi[r] : 0ull;
       l.srd[slot] = rd;
+      if (LONG) l.srh[slot] = rdh;
       l.sL0[slot] = (uint8_t)L0;
       for (uint32_t ui = 0; ui < p.n_units; ++ui) {
         const SeedUnit& un = p.unit[ui];
-        uint64_t q = 0;
+        uint64_t q = 0, qh = 0;
         int32_t L = 0;
-        const bool el = active && unit_view(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, rd, L0, q, L);
+        const bool el = active && unit_view_t<LONG>(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, rd, rdh, L0, q, qh, L);
         el_mask |= el ? 1u << ui : 0u;
         const int32_t V = un.max_mm_seed;
         const bool search = el && L > V;
         const uint32_t n_seeds = un.kind == 1u ? 1u : (uint32_t)V + 1u;
-        const int32_t k = seed_bases(L, un.min_seed_len, V);
+        const int32_t k = seed_bases<LONG>(L, un.min_seed_len, V);
         uint32_t queued = search ? (1u << n_seeds) - 1u : 0u;  // seeds that need the item queue
         if (BUCKETS && un.kind == 0u && un.buckets) {
           const bool inl = search && (uint32_t)k == un.bucket_k;
@@ -773,13 +781,13 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
         const uint32_t it = it0 + tid;
         const bool has = it < n_items;
         uint32_t slot = 0, j = 0;
-        uint64_t q = 0;
+        uint64_t q = 0, qh = 0;
         int32_t L = 0;
         if (has) {
           const uint32_t e = l.items[ui * p.item_cap + it];
           slot = e & 2047u;
           j = e >> 11;
-          unit_view(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, l.srd[slot], l.sL0[slot], q, L);
+          unit_view_t<LONG>(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, l.srd[slot], LONG ? l.srh[slot] : 0ull, l.sL0[slot], q, qh, L);
         }
         if (un.kind == 1u) {
           // ---- exact-match dictionary (see exact_dict_kernel) ----
@@ -787,7 +795,8 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
             const int32_t pass_index = un.m[0].pass_index, seed_len = un.m[0].seed_len, max_total = un.m[0].max_mm_total;
             const uint32_t smask = (1u << un.log2_slots) - 1u;
             const uint32_t kmask = un.key_bases >= 16u ? 0xFFFFFFFFu : ((1u << (2u * un.key_bases)) - 1u);
-            bool fallback = (uint32_t)L < un.key_bases;
+            // (a read of more than 32 bases always takes the FM rows: dict_unit_probe says why)
+            bool fallback = (uint32_t)L < un.key_bases || (LONG && L > 32);
             unsigned long long key = ~0ull;
             if (!fallback) {
               const uint64_t lmask = low_bits(2u * (uint32_t)L), seedmask = low_bits(2u * (uint32_t)min(L, seed_len));
@@ -835,8 +844,13 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
                 ++c_cands;
                 if ((uint32_t)L > ((uint32_t)(row >> 40) & 255u)) continue;
                 const uint64_t m = mismatch_bits(text_window(un.text, (uint32_t)row), q) & lmask;
-                const uint32_t mmt = (uint32_t)__popcll(m);
+                uint32_t mmt = (uint32_t)__popcll(m);
                 if ((m & seedmask) != 0ull || (int32_t)mmt > max_total) continue;
+                if (LONG && L > 32) {  // the second word against the text behind the first 32 bases
+                  const uint64_t mh = mismatch_bits(text_window(un.text, (uint32_t)row + 32u), qh) & low_bits(2u * (uint32_t)(L - 32));
+                  mmt += (uint32_t)__popcll(mh);
+                  if ((R > 32 && (mh & low_bits(2u * (uint32_t)(R - 32))) != 0ull) || (int32_t)mmt > max_total) continue;
+                }
                 const uint64_t kk = ((uint64_t)mmt << 32) | (uint32_t)row;
                 if (kk < bestk) {
                   bestk = kk;
@@ -858,7 +872,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
         // ---- a seed: jump-table load, then its rows into the row queue ----
         uint32_t lo = 0, n_rows = 0, tag = 0;
         if (has) {
-          const int32_t k = seed_bases(L, un.min_seed_len, un.max_mm_seed);
+          const int32_t k = seed_bases<LONG>(L, un.min_seed_len, un.max_mm_seed);
           const uint32_t off = j * (uint32_t)k;
           uint32_t kp = 0, cnt = kSeedBucketOverflow;
           if (BUCKETS && un.buckets && (uint32_t)k == un.bucket_k) {
@@ -906,11 +920,11 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
           for (uint32_t i = 0; i < mine; ++i) {
             if (first + i < p.row_cap) l.rows[first + i] = make_uint2(lo + i, tag);
             else if ((tag & kRowFromBucket) || un.sa16)
-              verify_seed_row(ut, (tag & kRowFromBucket) ? un.buckets[lo + i] : un.sa16[lo + i], q, L, (tag >> 13) & 63u, (tag >> 19) & 15u,
-                              &l.best[slot], (tag & kRowFromBucket) != 0u);
+              verify_seed_row<LONG>(ut, (tag & kRowFromBucket) ? un.buckets[lo + i] : un.sa16[lo + i], q, L, (tag >> 13) & 63u, (tag >> 19) & 15u,
+                                    &l.best[slot], (tag & kRowFromBucket) != 0u, qh);
             else {
               const uint64_t row = un.sa[lo + i];
-              verify_seed_row(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), q, L, (tag >> 13) & 63u, 0u, &l.best[slot]);
+              verify_seed_row<LONG>(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), q, L, (tag >> 13) & 63u, 0u, &l.best[slot], false, qh);
             }
           }
         }
@@ -922,10 +936,10 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
             const uint32_t* ut = l.utab + ui * kUnitWords;
             for (uint32_t i = 0; i < n_rows; ++i) {
               if (un.sa16) {
-                verify_seed_row(ut, un.sa16[lo + i], q, L, (tag >> 13) & 63u, (tag >> 19) & 15u, &l.best[slot]);
+                verify_seed_row<LONG>(ut, un.sa16[lo + i], q, L, (tag >> 13) & 63u, (tag >> 19) & 15u, &l.best[slot], false, qh);
               } else {
                 const uint64_t row = un.sa[lo + i];
-                verify_seed_row(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), q, L, (tag >> 13) & 63u, 0u, &l.best[slot]);
+                verify_seed_row<LONG>(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), q, L, (tag >> 13) & 63u, 0u, &l.best[slot], false, qh);
               }
             }
           }
@@ -949,15 +963,16 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
         const bool from_bucket = (e.y & kRowFromBucket) != 0u;
         const uint32_t* ut = l.utab + ui * kUnitWords;
         const uint32_t flags = ut[UW_FLAGS];
-        uint64_t q;
+        uint64_t q, qh;
         int32_t L;
-        unit_view(0, 255, (int32_t)((flags >> 16) & 1u), (int32_t)(flags & 255u), (int32_t)((flags >> 8) & 255u), l.srd[slot], l.sL0[slot], q, L);
+        unit_view_t<LONG>(0, 255, (int32_t)((flags >> 16) & 1u), (int32_t)(flags & 255u), (int32_t)((flags >> 8) & 255u), l.srd[slot],
+                          LONG ? l.srh[slot] : 0ull, l.sL0[slot], q, qh, L);
         const uint4* wide = reinterpret_cast<const uint4*>(lds_pointer(ut, from_bucket ? UW_BUCKETS : UW_SA16));
         if (wide) {
-          verify_seed_row(ut, wide[e.x], q, L, off, kp, &l.best[slot], from_bucket);
+          verify_seed_row<LONG>(ut, wide[e.x], q, L, off, kp, &l.best[slot], from_bucket, qh);
         } else {
           const uint64_t row = reinterpret_cast<const uint64_t*>(lds_pointer(ut, UW_SA))[e.x];
-          verify_seed_row(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), q, L, off, 0u, &l.best[slot]);
+          verify_seed_row<LONG>(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), q, L, off, 0u, &l.best[slot], false, qh);
         }
       }
       const uint32_t n_wide = min(l.ctl[3], kSeedWideCap);
@@ -966,17 +981,18 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
         const uint32_t slot = e.z & 2047u, ui = (e.z >> 11) & 3u, off = (e.z >> 13) & 63u, kp = (e.z >> 19) & 15u;
         const uint32_t* ut = l.utab + ui * kUnitWords;
         const uint32_t flags = ut[UW_FLAGS];
-        uint64_t q;
+        uint64_t q, qh;
         int32_t L;
-        unit_view(0, 255, (int32_t)((flags >> 16) & 1u), (int32_t)(flags & 255u), (int32_t)((flags >> 8) & 255u), l.srd[slot], l.sL0[slot], q, L);
+        unit_view_t<LONG>(0, 255, (int32_t)((flags >> 16) & 1u), (int32_t)(flags & 255u), (int32_t)((flags >> 8) & 255u), l.srd[slot],
+                          LONG ? l.srh[slot] : 0ull, l.sL0[slot], q, qh, L);
         const uint4* sa16 = reinterpret_cast<const uint4*>(lds_pointer(ut, UW_SA16));
         const uint64_t* sa8 = reinterpret_cast<const uint64_t*>(lds_pointer(ut, UW_SA));
         for (uint32_t i = e.x + tid; i < e.y; i += kSeedThreads) {
           if (sa16) {
-            verify_seed_row(ut, sa16[i], q, L, off, kp, &l.best[slot]);
+            verify_seed_row<LONG>(ut, sa16[i], q, L, off, kp, &l.best[slot], false, qh);
           } else {
             const uint64_t row = sa8[i];
-            verify_seed_row(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), q, L, off, 0u, &l.best[slot]);
+            verify_seed_row<LONG>(ut, make_uint4((uint32_t)row, (uint32_t)(row >> 32), 0u, 0u), q, L, off, 0u, &l.best[slot], false, qh);
           }
         }
       }
@@ -1474,7 +1490,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
     uint8_t* base = reinterpret_cast<uint8_t*>(smem + wave_shared_words()) + (size_t)wv * wave_lds_bytes(p.row_cap, LONG);
     w.rd = reinterpret_cast<unsigned long long*>(base);
     w.rdh = LONG ? w.rd + kWaveCand : w.rd;   // (second words of the candidates; no array of its own without long reads)
-    w.best = w.rdh + (LONG ? kWaveCand : 0u);
+    w.best = w.rd + (LONG ? 2u : 1u) * kWaveCand;
     w.rows = reinterpret_cast<uint2*>(w.best + kWaveCand);
     w.r = reinterpret_cast<uint32_t*>(w.rows + p.row_cap);
     w.meta = w.r + kWaveCand;
@@ -2193,6 +2209,9 @@ __host__ __device__ constexpr uint32_t pair_wave_lds_bytes() { return kPairReads
 
 }  // namespace
 
+// LONG: the batch holds reads of 33..63 nt (p.reads_hi): a read whose trimmed length is still beyond 32 bases is counted as
+// offered and not searched -- the planner lets such a read in only when the library's longest entry is shorter
+template <bool LONG>
 __global__ void __launch_bounds__(kSeedThreads, 5) pair_wave_kernel(const MatchParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -2427,7 +2446,7 @@ __global__ void __launch_bounds__(kSeedThreads, 5) pair_wave_kernel(const MatchP
       const bool eligible = active && (int32_t)L0 >= p.min_len && (int32_t)L0 <= p.max_len;
       const int32_t L = (int32_t)L0 - p.trim5 - p.trim3;
       if (eligible && p.count_processed) ++c_processed;
-      const bool searching = eligible && L > p.max_mm_seed;
+      const bool searching = eligible && L > p.max_mm_seed && !(LONG && L > 32);
       const int32_t R = min(L, p.seed_len);
       uint32_t A = 0u;
       if (searching) {
@@ -2436,7 +2455,9 @@ __global__ void __launch_bounds__(kSeedThreads, 5) pair_wave_kernel(const MatchP
       }
       const bool scan = searching && A == 0u;
       scan_m |= scan ? 1u << u : 0u;
-      w.rd[slot] = rd >> (2 * p.trim5);
+      uint64_t rdv = rd >> (2 * p.trim5);
+      if (LONG && searching && L0 > 32u && p.trim5) rdv |= p.reads_hi[r_b[u]] << (64 - 2 * p.trim5);  // (bases 32.. that the 5' trim lets in)
+      w.rd[slot] = rdv;
       w.best[slot] = ~0ull;
       w.len[slot] = (uint8_t)(searching ? L : 0);
       w.st[slot] = (uint8_t)(A | (scan ? 0x40u : 0u) | (active ? 0x80u : 0u));
@@ -2554,7 +2575,8 @@ __global__ void __launch_bounds__(kSeedThreads, 5) pair_wave_kernel(const MatchP
 uint32_t pair_wave_lds_total() { return kPairSharedWords * 4u + (kSeedThreads / 64u) * pair_wave_lds_bytes(); }
 
 hipError_t launch_pair_wave(const MatchParams& p, uint32_t grid, hipStream_t stream) {
-  hipLaunchKernelGGL(pair_wave_kernel, dim3(grid), dim3(kSeedThreads), pair_wave_lds_total(), stream, p);
+  if (p.reads_hi) hipLaunchKernelGGL(pair_wave_kernel<true>, dim3(grid), dim3(kSeedThreads), pair_wave_lds_total(), stream, p);
+  else hipLaunchKernelGGL(pair_wave_kernel<false>, dim3(grid), dim3(kSeedThreads), pair_wave_lds_total(), stream, p);
   return hipGetLastError();
 }
 
@@ -2594,7 +2616,7 @@ uint32_t seed_lds_bytes(const SeedParams& p) {
   if (p.impl == 1u) return wave_shared_words() * 4u + (kSeedThreads / 64u) * wave_lds_bytes(p.row_cap, p.reads_hi != nullptr);
   const uint32_t tile = kSeedThreads * p.reads_per_lane;
   return tile * 8u + tile * 8u + p.row_cap * 8u + kSeedWideCap * 16u + p.n_units * p.item_cap * 4u +
-         kSeedMaxUnits * kUnitWords * 4u + kSeedCtlWords * 4u + kSeedCntSlots * 8u + tile;
+         kSeedMaxUnits * kUnitWords * 4u + kSeedCtlWords * 4u + kSeedCntSlots * 8u + ((tile + 7u) & ~7u) + (p.reads_hi ? tile * 8u : 0u);
 }
 
 uint32_t seed_wgs_per_cu(const SeedParams& p) {
@@ -2639,17 +2661,22 @@ hipError_t launch_seed(const SeedParams& p, uint32_t grid, hipStream_t stream) {
     return hipGetLastError();
   }
   const bool fat = p.idx_in && p.in_stride == 4u;
-  const void* kern = buckets ? (fat ? reinterpret_cast<const void*>(seed_kernel<true, 6, true>) : reinterpret_cast<const void*>(seed_kernel<true, 6, false>))
-                             : (fat ? reinterpret_cast<const void*>(seed_kernel<false, 8, true>) : reinterpret_cast<const void*>(seed_kernel<false, 8, false>));
-  if (lds > 48u * 1024u) {
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  if (buckets && fat) hipLaunchKernelGGL((seed_kernel<true, 6, true>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
-  else if (buckets) hipLaunchKernelGGL((seed_kernel<true, 6, false>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
-  else if (fat) hipLaunchKernelGGL((seed_kernel<false, 8, true>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
-  else hipLaunchKernelGGL((seed_kernel<false, 8, false>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
-  return hipGetLastError();
+  // (the same four instantiations with and without the second word of long reads)
+  auto go = [&](auto long_tag) -> hipError_t {
+    constexpr bool LONG = decltype(long_tag)::value;
+    const void* kern = buckets ? (fat ? reinterpret_cast<const void*>(seed_kernel<true, 6, true, LONG>) : reinterpret_cast<const void*>(seed_kernel<true, 6, false, LONG>))
+                               : (fat ? reinterpret_cast<const void*>(seed_kernel<false, 8, true, LONG>) : reinterpret_cast<const void*>(seed_kernel<false, 8, false, LONG>));
+    if (lds > 48u * 1024u) {
+      hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+    if (buckets && fat) hipLaunchKernelGGL((seed_kernel<true, 6, true, LONG>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+    else if (buckets) hipLaunchKernelGGL((seed_kernel<true, 6, false, LONG>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+    else if (fat) hipLaunchKernelGGL((seed_kernel<false, 8, true, LONG>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+    else hipLaunchKernelGGL((seed_kernel<false, 8, false, LONG>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+    return hipGetLastError();
+  };
+  return p.reads_hi ? go(std::true_type{}) : go(std::false_type{});
 }
 
 // the streaming instantiation needs the identity list and arrays it can address 16 bytes at a time; it writes EVERY output

@@ -2194,6 +2194,8 @@ __global__ __launch_bounds__(1024) void split_kernel(SplitParams p) {
     if (live) {
       const uint32_t len = p.lens[r];
       is_short = len >= p.min_len && len <= 32u && (!p.nmask || p.nmask[r] == 0ull);
+      if (p.long_ok && len > 32u && len <= 63u && ((p.long_ok >> (len - 33u)) & 1ull))
+        is_short = !p.nmask || (p.nmask[r] == 0ull && (!p.nmask_hi || p.nmask_hi[r] == 0ull));
     }
     const uint64_t m_short = __ballot(live && is_short), m_rest = __ballot(live && !is_short);
     const uint32_t lane = threadIdx.x & 63u;

@@ -67,6 +67,9 @@ struct MatchParams {
   // pair_wave_kernel (dict.hip) only: words per entry of the input list (1 = indices, 4 = index, length, read:
   // SeedParams); it writes 16-byte entries; out_init: the cascade's first launch wrote every output already
   uint32_t in_stride, out_init;
+  // pair_wave_kernel, round 6: the second word of every read when the batch's reads of 33..63 nt ride the dictionary kernels
+  // (a read of 33..35 nt is 32 bases or fewer behind `-5 1 -3 2`), null = none
+  const uint64_t* reads_hi;
   // outputs
   int8_t* pass_id;
   int32_t* ref_id;
@@ -551,6 +554,8 @@ struct SplitParams {
   const uint64_t* nmask;  // null = no read has an N
   uint32_t n_total;
   uint32_t min_len;
+  uint64_t long_ok;         // round 6: bit b = reads of 33 + b nt go with the one-word reads too (the seed kernels' LONG instantiations)
+  const uint64_t* nmask_hi;  // the second mask word of every read (null: none has an N)
   uint32_t seg_cap;
   uint32_t* idx_short;
   uint32_t* cnt_short;

@@ -91,8 +91,8 @@ def test_split_batch_with_an_empty_side(engine, world, keep):
 def test_which_kernels_serve_which_length_class(engine, world):
     """Round 4: reads of 16..32 nt without N -- the reference's own length floor is 16 (trim_file.py:33) -- run the
     cascade through the dictionary kernels (exact_dict_kernel, seed_kernel / wave_seed_kernel with the pair tables
-    of three anchors for the 16..19-nt reads' one-mismatch passes on a large library, pair_wave_kernel); reads
-    beyond 32 nt, reads with N and reads under 16 nt take the FM kernels.  Told from the per-pass statistics of
+    of three anchors for the 16..19-nt reads' one-mismatch passes on a large library, pair_wave_kernel); round 6: so
+    do the N-free reads of 33..63 nt (the LONG instantiations); reads with N, reads under 16 nt and beyond 63 take the FM kernels.  Told from the per-pass statistics of
     single-class batches: a batch of one class launches one cascade, and `lds_mode` / `variant` name its kernels."""
     from mirge_amd.engine import ReadSet
     clean = world.nmask[0] == 0
@@ -129,7 +129,19 @@ def test_which_kernels_serve_which_length_class(engine, world):
                 # (the pair tables of three anchors for these reads' one-mismatch passes on a LARGE library are exercised
                 # by tests/test_gpu_dict.py::test_seed_buckets_and_jump_tables_on_a_large_library)
         elif name == "33..60":
-            assert all(s["lds_mode"] not in (7, 8, 9, 11) for s in launched), name   # match / fused / stratum kernels only
+            # round 6: the N-free reads of 33..63 nt ride the dictionary kernels' LONG instantiations (variant + 8): the
+            # hairpin pass (len > 25) and the other one-mismatch passes in the seed launches, the 2-mismatch pass in
+            # pair_wave_kernel (it sees at most 32 bases of a 33..35-nt read behind `-5 1 -3 2`; a 36-nt read could still
+            # align to a 33-nt miRNA entry with all of its 33 bases: that length stays with the FM kernels, as do reads with N)
+            assert st[1]["lds_mode"] in (8, 9) and st[1]["variant"] & 8, (name, st[1])
+            assert st[6]["lds_mode"] in (8, 9) and st[6]["variant"] & 8 and st[7]["variant"] & 3 == 2, name
+            assert st[8]["lds_mode"] == 11 and st[8]["variant"] & 8, name
+            assert st[1]["aligned"] > 50 and st[1]["ms_rest"] > 0, name          # two cascades: some reads (N, 36 nt) stayed with the FM kernels
+            engine.set_option("long_lane", 0)
+            old = engine.cascade(ReadSet(words, lens, nmask, None, device=engine.device), passes)
+            engine.set_option("long_lane", 1)
+            same(old, ref)
+            assert all(s["lds_mode"] not in (7, 8, 9, 11) for s in old.stats if s["n_launches"]), name   # match / fused / stratum kernels only
         else:
             # reads with N of at most 32 nt: the mask says "some read has an N", not which -- the batch is split on the
             # device, every read lands on the FM side (its cascade does the work), the one-word list stays empty
