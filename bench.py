@@ -250,6 +250,7 @@ def main():
     ap.add_argument("--bowtie-sample", type=int, default=100_000, help="reads for the bowtie probe, if bowtie exists")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the e2e and collapsed legs (and the workload legs)")
+    ap.add_argument("--keep-lens", default=None, help="experiments: keep only the reads of lo,hi nt of the generated batch (N = 1)")
     ap.add_argument("--no-cold", action="store_true", help="--workload exact: skip the cache-cold protocol (rotating read sets)")
     ap.add_argument("--no-legs", action="store_true", help="skip the exact / a2i child runs of the default workload")
     ap.add_argument("--legs-reads", type=int, default=None, help="reads of each leg (default: the workloads' own sizes)")
@@ -339,6 +340,12 @@ def main():
     words, lens, quant = synth.global_read_slice(
         libs, n_job, lo, hi, workload=("varlen" if wl == "varlen" else "cascade"),
         seed0=seed0 + (4000 if wl == "a2i" else 0), mix=mix, n_samples=args.samples)
+    if args.keep_lens:
+        # (experiments: the reads of one length class only, e.g. 33,40 -- what a lane of their own would see)
+        lo_, hi_ = (int(x) for x in args.keep_lens.split(","))
+        sel_ = (lens >= lo_) & (lens <= hi_)
+        words, lens, quant = np.ascontiguousarray(words[:, sel_]), np.ascontiguousarray(lens[sel_]), np.ascontiguousarray(quant[sel_])
+        n_reads = n_total = n_job = int(lens.shape[0])
     if args.sorted:
         key = words[0] if args.sort_key == "word" else (words[0] >> np.uint64(22 * int(args.sort_key[-1]))) & np.uint64((1 << 22) - 1)
         order = np.argsort(key, kind="stable")

@@ -219,10 +219,14 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * seed by walking that list up to the first valid alignment (plus a 64-ary search of the suffix-sorted rows for an
  * exact occurrence) instead of verifying every row of the suffix interval -- same answers (runAnnotationPipeline.py:
  * 581-584 offers every read to every library, whatever the library holds);
- * "long_lane" = 1 (default) / 0: in a batch of two words per read, the N-free reads of 33..63 nt go with the one-word
- * reads through the dictionary kernels (exact_dict_kernel and the FM kernels of that lane cannot see them: a length is
- * taken only when every pass either runs in a seed launch, keeps it out by its window, or -- pair_wave_kernel -- sees at
- * most 32 bases of it behind the trims or could not align it at all) / they take the FM kernels as before round 6;
+ * "long_lane" = 0 (default) / 1: in a batch of two words per read, the N-free reads of 33..63 nt take the FM kernels / go
+ * with the one-word reads through the dictionary kernels' LONG instantiations (seeds from the first 32 bases, the second
+ * word fetched where an alignment is verified; exact_dict_kernel and the FM kernels of that lane cannot see them: a length
+ * is taken only when every pass either runs in a seed launch, keeps it out by its window, or -- pair_wave_kernel -- sees
+ * at most 32 bases of it behind the trims or could not align it at all).  Same results (tests/test_gpu_split.py,
+ * test_gpu_random_worlds.py); measured no faster -- 1.10 against 1.08 ms for the 6.4 M reads of 33..40 nt of
+ * `bench.py --workload varlen`: a long read's candidate costs two or three dependent text trips where a short one is
+ * judged from its 16-byte row -- hence off;
  * "wide_rows_16", "round_large": see DESIGN.md. */
 int mrg_ctx_set_option(mrg_ctx *ctx, const char *key, int64_t value);
 int mrg_ctx_device_info(const mrg_ctx *ctx, int32_t *n_cu, uint64_t *hbm_bytes,

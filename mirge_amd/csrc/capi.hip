@@ -230,7 +230,7 @@ struct mrg_ctx {
   int64_t split_min_len = 16;  // ... and so do not reads shorter than this (the reference's own minimum length, trim_file.py:33; shorter seed regions than 15 bases have no pair tables)
   int64_t stratum0_unit = 0;  // (measured slower, default off) the exact stratum of a 2-mismatch pass behind a seed launch rides in that launch
   int64_t walk_diag = 0;
-  int64_t long_lane = 1;   // round 6: the reads of 33..63 nt of a split batch ride the dictionary kernels too (their LONG instantiations)
+  int64_t long_lane = 0;   // round 6: 1 = the reads of 33..63 nt of a split batch ride the dictionary kernels too (their LONG instantiations; measured no faster than the FM kernels: off)
   void* walk_buf = nullptr;  // wave_seed_kernel: records of the reads left to their position lists (grid x 4 waves x 256 x 32 B)
   size_t walk_bytes = 0;
   int64_t pos_scan = 1;   // 0 at run time: the seed launches verify a wide interval row by row as before round 6

@@ -411,17 +411,25 @@ __device__ __forceinline__ bool unit_view(int32_t min_len, int32_t max_len, int3
   return el;
 }
 
-// Round 6, reads of 33..63 nt on the seed kernels (LONG instantiations): the read is two words (rd = bases 0..31, rdh =
-// bases 32..63); a unit's view of it is q (the first 32 bases behind the 5' trim) + qh (the rest).  Seeds, bitmaps,
-// buckets and dictionary keys only ever look at q; qh is compared where an alignment is verified.
+// Round 6, reads of 33..63 nt on the seed kernels (LONG instantiations): the read is two words (rd = bases 0..31, the second
+// word = bases 32..63); a unit's view of it is q (the first 32 bases behind the 5' trim) + what lies behind.  Seeds,
+// bitmaps, buckets and dictionary keys only ever look at q; the second word is compared where an alignment is verified --
+// so it is not carried along but FETCHED THERE (QH: where it lies, `v()` loads it): as a value in every lane's registers
+// and LDS slot it cost the kernels 30..60 bytes of scratch in their hot loops, and every read of the batch paid for it.
+struct QH {
+  const uint64_t* p;  // the read's second word in the batch's second plane (null: the read has none)
+  uint32_t sh;        // 2 x trim5
+  __device__ __forceinline__ uint64_t v() const { return p ? (*p >> sh) : 0ull; }
+};
 __device__ __forceinline__ bool unit_view2(int32_t min_len, int32_t max_len, int32_t poly_t, int32_t trim5, int32_t trim3, uint64_t rd,
-                                           uint64_t rdh, uint32_t L0, uint64_t& q, uint64_t& qh, int32_t& L) {
+                                           uint64_t hpv, uint32_t L0, uint64_t& q, QH& qh, int32_t& L) {
   bool el = (int32_t)L0 >= min_len && (int32_t)L0 <= max_len;
   L = (int32_t)L0;
+  const uint64_t* hp = L0 > 32u ? reinterpret_cast<const uint64_t*>(hpv) : nullptr;
   if (poly_t) {
     int32_t tail;
-    if (L0 > 32u) {
-      const int32_t th = trailing_t(rdh, L - 32);
+    if (hp) {
+      const int32_t th = trailing_t(*hp, L - 32);
       tail = th == L - 32 ? th + trailing_t(rd, 32) : th;
     } else {
       tail = trailing_t(rd, L);
@@ -430,16 +438,17 @@ __device__ __forceinline__ bool unit_view2(int32_t min_len, int32_t max_len, int
     L -= tail;
   }
   L -= trim5 + trim3;
-  q = trim5 ? ((rd >> (2 * trim5)) | (rdh << (64 - 2 * trim5))) : rd;
-  qh = rdh >> (2 * trim5);
+  q = rd;
+  if (trim5) q = (rd >> (2 * trim5)) | ((hp ? *hp : 0ull) << (64 - 2 * trim5));
+  qh = QH{hp, 2u * (uint32_t)trim5};
   return el;
 }
 
 template <bool LONG>
 __device__ __forceinline__ bool unit_view_t(int32_t min_len, int32_t max_len, int32_t poly_t, int32_t trim5, int32_t trim3, uint64_t rd,
-                                            uint64_t rdh, uint32_t L0, uint64_t& q, uint64_t& qh, int32_t& L) {
-  if (LONG) return unit_view2(min_len, max_len, poly_t, trim5, trim3, rd, rdh, L0, q, qh, L);
-  qh = 0ull;
+                                            uint64_t hpv, uint32_t L0, uint64_t& q, QH& qh, int32_t& L) {
+  if (LONG) return unit_view2(min_len, max_len, poly_t, trim5, trim3, rd, hpv, L0, q, qh, L);
+  qh = QH{nullptr, 0u};
   return unit_view(min_len, max_len, poly_t, trim5, trim3, rd, L0, q, L);
 }
 
@@ -456,12 +465,43 @@ __device__ __forceinline__ const void* lds_pointer(const uint32_t* t, uint32_t w
   return reinterpret_cast<const void*>((uint64_t)t[w] | ((uint64_t)t[w + 1] << 32));
 }
 
+// Does the chain of the read's home slot hold a window that agrees with the read's first 32 bases: the seed part (the first
+// min(32, seed_len) bases) letter for letter, at most max_mm_total differences in the rest of the window?  (The negative
+// filter of the LONG instantiations: a read of more than 32 bases without such a window cannot align.)
+template <class Unit>
+__device__ __forceinline__ bool dict_window_hit(const Unit& un, uint64_t q, uint4 first) {
+  const int32_t seed_len = un.m[0].seed_len, max_total = un.m[0].max_mm_total;
+  const uint32_t smask = (1u << un.log2_slots) - 1u;
+  const uint32_t kmask = un.key_bases >= 16u ? 0xFFFFFFFFu : ((1u << (2u * un.key_bases)) - 1u);
+  const uint32_t home = (((uint32_t)q & kmask) * kDictHashMul) >> (32u - un.log2_slots);
+  const uint64_t seedmask = low_bits(2u * (uint32_t)min(32, seed_len));
+  uint4 sl = first;
+  const uint32_t chain = (sl.w >> kDictChainShift) & kDictChainMask;
+  for (uint32_t jj = 0;; ++jj) {
+    const uint64_t m = mismatch_bits((uint64_t)sl.x | ((uint64_t)sl.y << 32), q);
+    if ((sl.w & kDictOccBit) && (m & seedmask) == 0ull && (int32_t)__popcll(m) <= max_total && (sl.w & kDictAfterMask) > 32u) return true;
+    if (jj >= chain) break;
+    sl = un.slots[(home + jj + 1u) & smask];
+  }
+  return false;
+}
+
+// ... and in a unit with seed buckets a long read takes seeds of bucket_k bases where its seed region holds two of them
+// (a 28-base region: [0, 11) and [11, 22) -- one mismatch still leaves one clean, and a seed of exactly that length is
+// answered in the stream from one bucket line instead of parking the read for the jump table)
+template <bool LONG, class KU>
+__device__ __forceinline__ int32_t unit_seed_bases(const KU& un, int32_t L) {
+  const int32_t k = seed_bases<LONG>(L, un.min_seed_len, un.max_mm_seed);
+  if (LONG && L > 32 && un.kind == 0u && un.buckets && un.max_mm_seed == 1 && k > (int32_t)un.bucket_k) return (int32_t)un.bucket_k;
+  return k;
+}
+
 // One candidate row of a seed whose k' first bases matched at text position wr.x, `off` read
 // bases left of it: the key of a valid alignment (pass : 8 | mismatches : 8 | start : 32 | segment : 16), ~0 = none.
 // (bucket rows keep their segment room in six bits each: fm_index.hpp)
 template <bool LONG = false>
 __device__ __forceinline__ unsigned long long seed_row_key(const uint32_t* ut, const uint4 wr, uint64_t q, int32_t L, uint32_t off,
-                                                           uint32_t kprime, bool bucket_row, uint64_t qh = 0ull) {
+                                                           uint32_t kprime, bool bucket_row, QH qh = QH{nullptr, 0u}) {
   constexpr unsigned long long kNone = ~0ull;
   const uint32_t before = bucket_row ? (wr.y & 63u) : (wr.y & 255u), after = bucket_row ? ((wr.y >> 6) & 63u) : ((wr.y >> 8) & 255u);
   const uint32_t seg16 = wr.y >> 16;
@@ -485,7 +525,7 @@ __device__ __forceinline__ unsigned long long seed_row_key(const uint32_t* ut, c
     if (need_after > 8u) {
       const uint32_t c2 = min(need_after, 24u) - 8u;
       const uint32_t sh = 2u * (off + 8u);  // (< 64: off <= 16 with wide rows)
-      const uint64_t qq = (LONG && sh) ? ((q >> sh) | (qh << (64u - sh))) : (q >> sh);
+      const uint64_t qq = (LONG && sh && L > 32) ? ((q >> sh) | (qh.v() << (64u - sh))) : (q >> sh);
       const uint32_t want = (uint32_t)qq & (uint32_t)low_bits(2u * c2);
       const uint32_t x = (wr.w ^ want) & (uint32_t)low_bits(2u * c2);
       mm += (uint32_t)__popc((x | (x >> 1)) & 0x55555555u);
@@ -501,7 +541,7 @@ __device__ __forceinline__ unsigned long long seed_row_key(const uint32_t* ut, c
     mm = (uint32_t)__popcll(mbits);
     if ((int32_t)mm > max_total) return kNone;
     if (LONG && L > 32) {  // the second word against the text behind the first 32 bases
-      mbits_h = mismatch_bits(text_window(text, s + 32u), qh) & low_bits(2u * (uint32_t)(L - 32));
+      mbits_h = mismatch_bits(text_window(text, s + 32u), qh.v()) & low_bits(2u * (uint32_t)(L - 32));
       mm += (uint32_t)__popcll(mbits_h);
       if ((int32_t)mm > max_total) return kNone;
     }
@@ -533,7 +573,7 @@ __device__ __forceinline__ unsigned long long seed_row_key(const uint32_t* ut, c
 
 template <bool LONG = false>
 __device__ __forceinline__ void verify_seed_row(const uint32_t* ut, const uint4 wr, uint64_t q, int32_t L, uint32_t off, uint32_t kprime,
-                                                unsigned long long* best_slot, bool bucket_row = false, uint64_t qh = 0ull) {
+                                                unsigned long long* best_slot, bool bucket_row = false, QH qh = QH{nullptr, 0u}) {
   const unsigned long long key = seed_row_key<LONG>(ut, wr, q, L, off, kprime, bucket_row, qh);
   if (key != ~0ull) atomicMin(best_slot, key);
 }
@@ -684,13 +724,14 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
       unsigned long long my_best = ~0ull;
       el_mask = 0u;
       // (a long read's second word: gathered here -- the lists carry the first word only)
-      const uint64_t rdh = (LONG && active && L0 > 32u) ? p.reads_hi[r] : 0ull;
+      const uint64_t rdh = (LONG && active && L0 > 32u) ? (uint64_t)(uintptr_t)(p.reads_hi + r) : 0ull;  // (where it lies: QH)
       l.srd[slot] = rd;
       if (LONG) l.srh[slot] = rdh;
       l.sL0[slot] = (uint8_t)L0;
       for (uint32_t ui = 0; ui < p.n_units; ++ui) {
         const SeedUnit& un = p.unit[ui];
-        uint64_t q = 0, qh = 0;
+        uint64_t q = 0;
+        QH qh{nullptr, 0u};
         int32_t L = 0;
         const bool el = active && unit_view_t<LONG>(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, rd, rdh, L0, q, qh, L);
         el_mask |= el ? 1u << ui : 0u;
@@ -781,7 +822,8 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
         const uint32_t it = it0 + tid;
         const bool has = it < n_items;
         uint32_t slot = 0, j = 0;
-        uint64_t q = 0, qh = 0;
+        uint64_t q = 0;
+        QH qh{nullptr, 0u};
         int32_t L = 0;
         if (has) {
           const uint32_t e = l.items[ui * p.item_cap + it];
@@ -795,10 +837,17 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
             const int32_t pass_index = un.m[0].pass_index, seed_len = un.m[0].seed_len, max_total = un.m[0].max_mm_total;
             const uint32_t smask = (1u << un.log2_slots) - 1u;
             const uint32_t kmask = un.key_bases >= 16u ? 0xFFFFFFFFu : ((1u << (2u * un.key_bases)) - 1u);
-            // (a read of more than 32 bases always takes the FM rows: dict_unit_probe says why)
+            // (a read of more than 32 bases always takes the FM rows: dict_unit_probe says why -- unless the table says no)
             bool fallback = (uint32_t)L < un.key_bases || (LONG && L > 32);
             unsigned long long key = ~0ull;
-            if (!fallback) {
+            bool hopeless = false;
+            if (LONG && L > 32 && (uint32_t)L >= un.key_bases) {
+              const uint4 sl0 = un.slots[(((uint32_t)q & kmask) * kDictHashMul) >> (32u - un.log2_slots)];
+              ++c_lookups;
+              hopeless = ((sl0.w >> kDictChainShift) & kDictChainMask) != kDictChainOverflow && !dict_window_hit(un, q, sl0);
+              fallback = !hopeless;
+            }
+            if (!fallback && !hopeless) {
               const uint64_t lmask = low_bits(2u * (uint32_t)L), seedmask = low_bits(2u * (uint32_t)min(L, seed_len));
               const uint32_t home = (((uint32_t)q & kmask) * kDictHashMul) >> (32u - un.log2_slots);
               uint4 sl = un.slots[home];
@@ -847,7 +896,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
                 uint32_t mmt = (uint32_t)__popcll(m);
                 if ((m & seedmask) != 0ull || (int32_t)mmt > max_total) continue;
                 if (LONG && L > 32) {  // the second word against the text behind the first 32 bases
-                  const uint64_t mh = mismatch_bits(text_window(un.text, (uint32_t)row + 32u), qh) & low_bits(2u * (uint32_t)(L - 32));
+                  const uint64_t mh = mismatch_bits(text_window(un.text, (uint32_t)row + 32u), qh.v()) & low_bits(2u * (uint32_t)(L - 32));
                   mmt += (uint32_t)__popcll(mh);
                   if ((R > 32 && (mh & low_bits(2u * (uint32_t)(R - 32))) != 0ull) || (int32_t)mmt > max_total) continue;
                 }
@@ -963,7 +1012,8 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
         const bool from_bucket = (e.y & kRowFromBucket) != 0u;
         const uint32_t* ut = l.utab + ui * kUnitWords;
         const uint32_t flags = ut[UW_FLAGS];
-        uint64_t q, qh;
+        uint64_t q;
+        QH qh{nullptr, 0u};
         int32_t L;
         unit_view_t<LONG>(0, 255, (int32_t)((flags >> 16) & 1u), (int32_t)(flags & 255u), (int32_t)((flags >> 8) & 255u), l.srd[slot],
                           LONG ? l.srh[slot] : 0ull, l.sL0[slot], q, qh, L);
@@ -981,7 +1031,8 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) seed_kernel(const SeedPar
         const uint32_t slot = e.z & 2047u, ui = (e.z >> 11) & 3u, off = (e.z >> 13) & 63u, kp = (e.z >> 19) & 15u;
         const uint32_t* ut = l.utab + ui * kUnitWords;
         const uint32_t flags = ut[UW_FLAGS];
-        uint64_t q, qh;
+        uint64_t q;
+        QH qh{nullptr, 0u};
         int32_t L;
         unit_view_t<LONG>(0, 255, (int32_t)((flags >> 16) & 1u), (int32_t)(flags & 255u), (int32_t)((flags >> 8) & 255u), l.srd[slot],
                           LONG ? l.srh[slot] : 0ull, l.sL0[slot], q, qh, L);
@@ -1158,12 +1209,21 @@ constexpr uint32_t kDictFallbackRows = 64u;
 // window decides, which the table does not know.
 template <bool LONG = false, class Unit>
 __device__ __forceinline__ unsigned long long dict_unit_probe(const Unit& un, uint64_t q, int32_t L, bool have_first, uint4 first,
-                                                              uint32_t& c_lookups, uint32_t& c_cands, bool* wide = nullptr, uint64_t qh = 0ull) {
+                                                              uint32_t& c_lookups, uint32_t& c_cands, bool* wide = nullptr, QH qh = QH{nullptr, 0u}) {
   const int32_t pass_index = un.m[0].pass_index, seed_len = un.m[0].seed_len, max_total = un.m[0].max_mm_total;
   const uint32_t smask = (1u << un.log2_slots) - 1u;
   const uint32_t kmask = un.key_bases >= 16u ? 0xFFFFFFFFu : ((1u << (2u * un.key_bases)) - 1u);
   bool fallback = (uint32_t)L < un.key_bases || (LONG && L > 32);
   unsigned long long key = ~0ull;
+  if (LONG && L > 32 && (uint32_t)L >= un.key_bases) {
+    // (the table as a negative filter: no window like the read's first 32 bases in the home's chain -> no alignment)
+    uint4 sl = first;
+    if (!have_first) {
+      sl = un.slots[(((uint32_t)q & kmask) * kDictHashMul) >> (32u - un.log2_slots)];
+      ++c_lookups;
+    }
+    if (((sl.w >> kDictChainShift) & kDictChainMask) != kDictChainOverflow && !dict_window_hit(un, q, sl)) return ~0ull;
+  }
   if (!fallback) {
     const uint64_t lmask = low_bits(2u * (uint32_t)L), seedmask = low_bits(2u * (uint32_t)min(L, seed_len));
     const uint32_t home = (((uint32_t)q & kmask) * kDictHashMul) >> (32u - un.log2_slots);
@@ -1201,7 +1261,7 @@ __device__ __forceinline__ unsigned long long dict_unit_probe(const Unit& un, ui
     // the FM index (device_util.hpp: fm_exact_search)
     uint32_t bseg = 0xFFFFu, bbefore = 255u, rows = 0, steps = 0;
     const uint64_t bestk = fm_exact_search<LONG>(un.blocks, un.super, un.primary, un.ftab, un.tabs, un.sa, un.text, un.n, q, L, min(L, seed_len),
-                                                 max_total, bseg, bbefore, rows, steps, wide ? kDictFallbackRows : 0xFFFFFFFFu, qh);
+                                                 max_total, bseg, bbefore, rows, steps, wide ? kDictFallbackRows : 0xFFFFFFFFu, (LONG && L > 32) ? qh.v() : 0ull);
     if (wide && rows > kDictFallbackRows) {
       *wide = true;
       c_lookups += 1u + steps;
@@ -1231,7 +1291,8 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 // The FM fallback of a dictionary unit by the whole wave (wave-uniform arguments): the backward search as in
 // fm_exact_search (every lane the same addresses), the interval's rows 64 a trip.  Returns the unit's key for the read.
 template <bool LONG = false, class Unit>
-__device__ __forceinline__ unsigned long long dict_fallback_wave(const Unit& un, uint64_t q, int32_t L, uint32_t* cands, uint64_t qh = 0ull) {
+__device__ __forceinline__ unsigned long long dict_fallback_wave(const Unit& un, uint64_t q, int32_t L, uint32_t* cands, QH qhp = QH{nullptr, 0u}) {
+  const uint64_t qh = LONG ? qhp.v() : 0ull;  // (one read, the whole wave: loaded once)
   const uint32_t lane = threadIdx.x & 63u;
   const int32_t pass_index = un.m[0].pass_index, seed_len = un.m[0].seed_len, max_total = un.m[0].max_mm_total;
   const int32_t R = min(L, seed_len);
@@ -1660,7 +1721,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
       const uint32_t flags = ut[UW_FLAGS];
       uint64_t q;
       int32_t L;
-      uint64_t qh = 0;
+      QH qh{nullptr, 0u};
       unit_view_t<LONG>(0, 255, (int32_t)((flags >> 16) & 1u), (int32_t)(flags & 255u), (int32_t)((flags >> 8) & 255u), w.rd[c], LONG ? w.rdh[c] : 0ull,
                  w.meta[c] & 255u, q, qh, L);
       const uint4* wide = reinterpret_cast<const uint4*>(lds_pointer(ut, from_bucket ? UW_BUCKETS : UW_SA16));
@@ -1718,7 +1779,8 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
         wave_lds_sync();
         const bool has = lane < m;
         uint32_t cl = 0, j = 0;
-        uint64_t q = 0, qh = 0;
+        uint64_t q = 0;
+        QH qh{nullptr, 0u};
         int32_t L = 0;
         bool pair_mode = false;
         if (has) {
@@ -1761,7 +1823,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
           c_cands += n_rows;
           tag = cl | (ui << 11) | ((i0 * A) << 13) | kRowFromPair;
         } else if (has) {
-          const int32_t k = seed_bases<LONG>(L, un.min_seed_len, un.max_mm_seed);
+          const int32_t k = unit_seed_bases<LONG>(un, L);
           const uint32_t off = j * (uint32_t)k;
           uint32_t kp = 0, bcnt = kSeedBucketOverflow;
           if (BUCKETS && un.buckets && (uint32_t)k == un.bucket_k) {
@@ -1807,7 +1869,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
           wide_m &= wide_m - 1ull;
           const uint32_t w_lo = __shfl(lo, src, 64), w_n = __shfl(n_rows, src, 64), w_tag = __shfl(tag, src, 64);
           const uint64_t w_q = __shfl((unsigned long long)q, src, 64);
-          const uint64_t w_qh = LONG ? __shfl((unsigned long long)qh, src, 64) : 0ull;
+          const QH w_qh{LONG ? reinterpret_cast<const uint64_t*>((uintptr_t)__shfl((unsigned long long)(uintptr_t)qh.p, src, 64)) : nullptr, qh.sh};
           const int32_t w_L = __shfl(L, src, 64);
           const uint32_t* ut = utab + ui * kUnitWords;
           unsigned long long* slot = &w.best[cbase + (w_tag & 63u)];
@@ -1891,7 +1953,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
     const uint32_t r = r_b, L0 = active ? L_b : 255u;
     const uint64_t rd = rd_b;
     // (a long read's second word: gathered here, where it is needed -- the lists carry the first word only)
-    const uint64_t rdh = (LONG && active && L0 > 32u) ? p.reads_hi[r] : 0ull;
+    const uint64_t rdh = (LONG && active && L0 > 32u) ? (uint64_t)(uintptr_t)(p.reads_hi + r) : 0ull;  // (where it lies: QH)
     L_b = 255u;
     rd_b = 0;
     if (fat_in) {
@@ -1914,13 +1976,14 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
     bool pre_direct = false;
     if (pre_ui < p.n_units) {
       const KUnit& un = kargs->unit[pre_ui];
-      uint64_t q = 0, qh = 0;
+      uint64_t q = 0;
+        QH qh{nullptr, 0u};
       int32_t L = 0;
       const bool el = active && unit_view_t<LONG>(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, rd, rdh, L0, q, qh, L);
       const bool search = el && L > 0;
       if ((uint32_t)__popcll(__ballot(search)) >= 16u) {
         const uint32_t kmask = un.key_bases >= 16u ? 0xFFFFFFFFu : ((1u << (2u * un.key_bases)) - 1u);
-        pre_direct = search && (uint32_t)L >= un.key_bases && !(LONG && L > 32);   // (a long read takes the FM search: parked)
+        pre_direct = search && (uint32_t)L >= un.key_bases;
         if (pre_direct) {
           // (one 16-byte load: left to itself the compiler loads the meta half, tests the chain, then loads the window)
           const uint4* sp = un.slots + ((((uint32_t)q & kmask) * kDictHashMul) >> (32u - un.log2_slots));
@@ -1932,7 +1995,8 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
     }
     for (uint32_t ui = 0; ui < p.n_units; ++ui) {
       const KUnit& un = kargs->unit[ui];
-      uint64_t q = 0, qh = 0;
+      uint64_t q = 0;
+        QH qh{nullptr, 0u};
       int32_t L = 0;
       const bool el = active && unit_view_t<LONG>(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, rd, rdh, L0, q, qh, L);
       el_mask |= el ? 1u << ui : 0u;
@@ -1949,7 +2013,12 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
         if (ui == pre_ui && pre_direct) {
           ++c_dl;
           const uint32_t chain = (pre_sl.w >> kDictChainShift) & kDictChainMask;
-          if (chain != kDictChainOverflow) {
+          if (LONG && L > 32) {
+            // a long read: the table cannot answer it (dict_unit_probe), but it can say NO -- an alignment needs a position
+            // whose 32-base window agrees with the read's first 32 bases under the pass's rules, and every such window sits in
+            // a slot of this chain; only a read with such a slot (or an overflowed home) is parked for the FM search
+            if (chain != kDictChainOverflow && !dict_window_hit(un, q, pre_sl)) queued = 0u;
+          } else if (chain != kDictChainOverflow) {
             // (the home slot is in hand: the probe neither loads nor counts it again; the few lanes whose key
             // chains further walk their chain here -- parked, they would leave the stream's order)
             uint32_t dl = 0;
@@ -1960,7 +2029,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
         }
       } else {
         const uint32_t n_seeds = (uint32_t)V + 1u;
-        const int32_t k = seed_bases<LONG>(L, un.min_seed_len, V);
+        const int32_t k = unit_seed_bases<LONG>(un, L);
         queued = search ? (1u << n_seeds) - 1u : 0u;  // seeds that need the index
         // a seed region of 3 A .. 4 A - 1 bases in a large library: the three anchor pairs instead of two seeds of
         // 8..9 bases (40..170 rows each in 11 Mbp); parked, the pair lookups run with dense lanes
@@ -2005,7 +2074,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
               if (cnt0 != kSeedBucketOverflow) {
                 c_bc += cnt0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) my_best = min(my_best, seed_row_key(ut, ra[i], q, L, 0u, un.bucket_k, true));
+                for (int i = 0; i < 4; ++i) my_best = min(my_best, seed_row_key<LONG>(ut, ra[i], q, L, 0u, un.bucket_k, true, qh));
                 more0 = cnt0 > 4u;
               } else {
                 queued |= 1u;
@@ -2014,7 +2083,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
                 if (cnt1 != kSeedBucketOverflow) {
                   c_bc += cnt1;
 #pragma unroll
-                  for (int i = 0; i < 4; ++i) my_best = min(my_best, seed_row_key(ut, rb[i], q, L, un.bucket_k, un.bucket_k, true));
+                  for (int i = 0; i < 4; ++i) my_best = min(my_best, seed_row_key<LONG>(ut, rb[i], q, L, un.bucket_k, un.bucket_k, true, qh));
                   more1 = cnt1 > 4u;
                 } else {
                   queued |= 2u;
@@ -2032,11 +2101,11 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
               }
               if (more0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) my_best = min(my_best, seed_row_key(ut, ra[i], q, L, 0u, un.bucket_k, true));
+                for (int i = 0; i < 4; ++i) my_best = min(my_best, seed_row_key<LONG>(ut, ra[i], q, L, 0u, un.bucket_k, true, qh));
               }
               if (more1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) my_best = min(my_best, seed_row_key(ut, rb[i], q, L, un.bucket_k, un.bucket_k, true));
+                for (int i = 0; i < 4; ++i) my_best = min(my_best, seed_row_key<LONG>(ut, rb[i], q, L, un.bucket_k, un.bucket_k, true, qh));
               }
             }
           }
@@ -2099,7 +2168,8 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
         for (uint32_t ui = 0; ui < p.n_units; ++ui) {
           const KUnit& un = kargs->unit[ui];
           if (!((cm >> (8u + ui)) & 1u)) continue;
-          uint64_t q = 0, qh = 0;
+          uint64_t q = 0;
+        QH qh{nullptr, 0u};
           int32_t L = 0;
           unit_view_t<LONG>(un.min_len, un.max_len, un.poly_t, un.trim5, un.trim3, rdv, rdhv, cm & 255u, q, qh, L);
           if (un.kind == 1u) {
@@ -2120,7 +2190,7 @@ __global__ void __launch_bounds__(kSeedThreads, WAVES) wave_seed_kernel(const Se
             continue;
           }
           if (!un.pos_rows) continue;
-          if (L <= un.max_mm_seed || (uint32_t)seed_bases<LONG>(L, un.min_seed_len, un.max_mm_seed) != un.bucket_k) continue;
+          if (L <= un.max_mm_seed || (uint32_t)unit_seed_bases<LONG>(un, L) != un.bucket_k) continue;
           const unsigned long long cur = w.best[i];
           // an earlier pass has the read, or this one has it without a mismatch (found by a seed verified completely: every
           // exact alignment lies in its rows): nothing here can be better
@@ -2622,7 +2692,10 @@ uint32_t seed_lds_bytes(const SeedParams& p) {
 uint32_t seed_wgs_per_cu(const SeedParams& p) {
   bool buckets = false;
   for (uint32_t u = 0; u < p.n_units; ++u) buckets |= p.unit[u].kind == 0u && p.unit[u].buckets != nullptr;
-  const uint32_t by_regs = (p.impl == 1u && (p.wave_regs & 1u)) ? (buckets ? 5u : 6u) : (buckets ? 6u : 8u), by_lds = (160u * 1024u) / seed_lds_bytes(p);
+  uint32_t by_regs = (p.impl == 1u && (p.wave_regs & 1u)) ? (buckets ? 5u : 6u) : (buckets ? 6u : 8u);
+  // (the instantiations that carry long reads get more registers: one or two workgroups per CU fewer)
+  if (p.reads_hi) by_regs = p.impl == 1u ? (buckets ? 4u : 5u) : (buckets ? 5u : 6u);
+  const uint32_t by_lds = (160u * 1024u) / seed_lds_bytes(p);
   return by_regs < by_lds ? by_regs : (by_lds ? by_lds : 1u);
 }
 
@@ -2642,16 +2715,16 @@ hipError_t launch_seed(const SeedParams& p, uint32_t grid, hipStream_t stream) {
       if (e != hipSuccess) return e;
     }
     if (p.reads_hi) {  // a batch with reads of 33..63 nt: the instantiations that carry the second word
-      const void* lk = buckets ? (more_regs ? reinterpret_cast<const void*>(wave_seed_kernel<true, 5, true>) : reinterpret_cast<const void*>(wave_seed_kernel<true, 6, true>))
-                               : (more_regs ? reinterpret_cast<const void*>(wave_seed_kernel<false, 6, true>) : reinterpret_cast<const void*>(wave_seed_kernel<false, 8, true>));
+      const void* lk = buckets ? (more_regs ? reinterpret_cast<const void*>(wave_seed_kernel<true, 4, true>) : reinterpret_cast<const void*>(wave_seed_kernel<true, 4, true>))
+                               : (more_regs ? reinterpret_cast<const void*>(wave_seed_kernel<false, 5, true>) : reinterpret_cast<const void*>(wave_seed_kernel<false, 5, true>));
       if (lds > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(lk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
       }
-      if (buckets && more_regs) hipLaunchKernelGGL((wave_seed_kernel<true, 5, true>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
-      else if (buckets) hipLaunchKernelGGL((wave_seed_kernel<true, 6, true>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
-      else if (more_regs) hipLaunchKernelGGL((wave_seed_kernel<false, 6, true>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
-      else hipLaunchKernelGGL((wave_seed_kernel<false, 8, true>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+      if (buckets && more_regs) hipLaunchKernelGGL((wave_seed_kernel<true, 4, true>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+      else if (buckets) hipLaunchKernelGGL((wave_seed_kernel<true, 4, true>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+      else if (more_regs) hipLaunchKernelGGL((wave_seed_kernel<false, 5, true>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+      else hipLaunchKernelGGL((wave_seed_kernel<false, 5, true>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
       return hipGetLastError();
     }
     if (buckets && more_regs) hipLaunchKernelGGL((wave_seed_kernel<true, 5, false>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
@@ -2664,16 +2737,16 @@ hipError_t launch_seed(const SeedParams& p, uint32_t grid, hipStream_t stream) {
   // (the same four instantiations with and without the second word of long reads)
   auto go = [&](auto long_tag) -> hipError_t {
     constexpr bool LONG = decltype(long_tag)::value;
-    const void* kern = buckets ? (fat ? reinterpret_cast<const void*>(seed_kernel<true, 6, true, LONG>) : reinterpret_cast<const void*>(seed_kernel<true, 6, false, LONG>))
-                               : (fat ? reinterpret_cast<const void*>(seed_kernel<false, 8, true, LONG>) : reinterpret_cast<const void*>(seed_kernel<false, 8, false, LONG>));
+    const void* kern = buckets ? (fat ? reinterpret_cast<const void*>(seed_kernel<true, (LONG ? 5 : 6), true, LONG>) : reinterpret_cast<const void*>(seed_kernel<true, (LONG ? 5 : 6), false, LONG>))
+                               : (fat ? reinterpret_cast<const void*>(seed_kernel<false, (LONG ? 6 : 8), true, LONG>) : reinterpret_cast<const void*>(seed_kernel<false, (LONG ? 6 : 8), false, LONG>));
     if (lds > 48u * 1024u) {
       hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
-    if (buckets && fat) hipLaunchKernelGGL((seed_kernel<true, 6, true, LONG>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
-    else if (buckets) hipLaunchKernelGGL((seed_kernel<true, 6, false, LONG>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
-    else if (fat) hipLaunchKernelGGL((seed_kernel<false, 8, true, LONG>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
-    else hipLaunchKernelGGL((seed_kernel<false, 8, false, LONG>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+    if (buckets && fat) hipLaunchKernelGGL((seed_kernel<true, (LONG ? 5 : 6), true, LONG>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+    else if (buckets) hipLaunchKernelGGL((seed_kernel<true, (LONG ? 5 : 6), false, LONG>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+    else if (fat) hipLaunchKernelGGL((seed_kernel<false, (LONG ? 6 : 8), true, LONG>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
+    else hipLaunchKernelGGL((seed_kernel<false, (LONG ? 6 : 8), false, LONG>), dim3(grid), dim3(kSeedThreads), lds, stream, p);
     return hipGetLastError();
   };
   return p.reads_hi ? go(std::true_type{}) : go(std::false_type{});

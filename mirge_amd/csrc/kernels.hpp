@@ -320,7 +320,6 @@ struct SeedParams {
   uint32_t row_cap;         // rows a tile (seed_kernel) / a wave (wave_seed_kernel) can queue
   uint64_t* stats;          // counter slots [pass][5]: processed, aligned, steps, candidates, lookups
   const uint64_t* reads;
-  const uint64_t* reads_hi;  // round 6: the second word of every read (a two-word batch whose reads of 33..63 nt ride the seed kernels), null = none
   const uint8_t* lens;
   uint32_t n_total;
   // the input list: entries of in_stride words, word 0 = the read's index (1: an index list as exact_dict_kernel and
@@ -344,6 +343,10 @@ struct SeedParams {
   uint4* walk_buf;
   uint32_t walk_cap;
   uint32_t walk_diag;  // experiments: the number of such reads goes into the `steps` counter of the launch's first pass
+  // round 6: the second word of every read (a two-word batch whose reads of 33..63 nt ride the seed kernels), null = none.
+  // (Behind everything else: the walk reads list pointers and counts from the kernel-argument segment every trip, and a
+  // field in front of them moved their offsets -- the headline's large launch lost 4 % to that.)
+  const uint64_t* reads_hi;
 };
 uint32_t seed_lds_bytes(const SeedParams& p);
 // workgroups per CU the instantiation a launch gets can keep resident (registers; LDS permitting)

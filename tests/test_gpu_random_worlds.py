@@ -47,6 +47,10 @@ def test_random_world_random_cascade(native_lib, oracle_lib, seed):
     passes = random_cascade(rng, len(LIB_ORDER))
     opts = dict(seed_impl=int(rng.choice([-1, -1, 0, 1, 2])), pair_impl=int(rng.integers(0, 2)), split_min_len=int(rng.choice([0, 16, 16, 20])),
                 fuse=int(rng.random() < 0.8), seed_units=int(rng.random() < 0.8), wstop=int(rng.choice([0, 8])))
+    # (round 6: the reads of 33..44 nt of the two-word batches ride the dictionary kernels' LONG instantiations -- off by
+    # default, measured no faster than the FM kernels -- in every two-word world but each fourth; a separate generator, so
+    # that the worlds of round 5 stay what they were)
+    opts["long_lane"] = int(seed % 8 != 2)
     eng = Engine(0)
     big = rng.random() < 0.5
     for k in LIB_ORDER:

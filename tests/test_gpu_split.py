@@ -52,6 +52,11 @@ def test_split_batch_equals_port_and_unsplit_run(engine, world):
     assert st[0]["lds_mode"] == 7 and st[0]["n_launches"] == 2
     assert st[2]["lds_mode"] in (8, 9)
     assert st[0]["ms_rest"] > 0 and st[0]["ms"] > 0     # each cascade has its own per-pass times
+    engine.set_option("long_lane", 1)    # (round 6: the reads of 33..63 nt in the one-word lane too)
+    lane = engine.cascade(rs, passes)
+    engine.set_option("long_lane", 0)
+    same(lane, ref)
+    assert lane.stats[2]["variant"] & 8 and lane.stats[0]["lds_mode"] == 7
     engine.set_option("split_mixed", 0)
     whole = engine.cascade(rs, passes)
     engine.set_option("split_mixed", 1)
@@ -91,8 +96,9 @@ def test_split_batch_with_an_empty_side(engine, world, keep):
 def test_which_kernels_serve_which_length_class(engine, world):
     """Round 4: reads of 16..32 nt without N -- the reference's own length floor is 16 (trim_file.py:33) -- run the
     cascade through the dictionary kernels (exact_dict_kernel, seed_kernel / wave_seed_kernel with the pair tables
-    of three anchors for the 16..19-nt reads' one-mismatch passes on a large library, pair_wave_kernel); round 6: so
-    do the N-free reads of 33..63 nt (the LONG instantiations); reads with N, reads under 16 nt and beyond 63 take the FM kernels.  Told from the per-pass statistics of
+    of three anchors for the 16..19-nt reads' one-mismatch passes on a large library, pair_wave_kernel); round 6: with
+    `long_lane` = 1 so do the N-free reads of 33..63 nt (the LONG instantiations: built, parity-green, measured no faster than
+    the FM kernels, hence off by default); reads with N, reads under 16 nt and beyond 63 take the FM kernels.  Told from the per-pass statistics of
     single-class batches: a batch of one class launches one cascade, and `lds_mode` / `variant` name its kernels."""
     from mirge_amd.engine import ReadSet
     clean = world.nmask[0] == 0
@@ -112,7 +118,9 @@ def test_which_kernels_serve_which_length_class(engine, world):
         ref = model.fm_cascade(world.views, world.passes, words, lens, nmask, wstop=DEFAULT_WSTOP, ftab=True)
         if name in ("16..19", "20..32"):   # what a trimmed small-RNA batch is: one word per read, no N mask
             words, nmask = np.ascontiguousarray(words[:1]), None
+        engine.set_option("long_lane", 1 if name == "33..60" else 0)
         res = engine.cascade(ReadSet(words, lens, nmask, None, device=engine.device), passes)
+        engine.set_option("long_lane", 0)
         same(res, ref)
         st = res.stats
         launched = [s for s in st if s["n_launches"]]
@@ -129,7 +137,7 @@ def test_which_kernels_serve_which_length_class(engine, world):
                 # (the pair tables of three anchors for these reads' one-mismatch passes on a LARGE library are exercised
                 # by tests/test_gpu_dict.py::test_seed_buckets_and_jump_tables_on_a_large_library)
         elif name == "33..60":
-            # round 6: the N-free reads of 33..63 nt ride the dictionary kernels' LONG instantiations (variant + 8): the
+            # round 6, option long_lane = 1: the N-free reads of 33..63 nt ride the dictionary kernels' LONG instantiations (variant + 8): the
             # hairpin pass (len > 25) and the other one-mismatch passes in the seed launches, the 2-mismatch pass in
             # pair_wave_kernel (it sees at most 32 bases of a 33..35-nt read behind `-5 1 -3 2`; a 36-nt read could still
             # align to a 33-nt miRNA entry with all of its 33 bases: that length stays with the FM kernels, as do reads with N)
@@ -137,9 +145,7 @@ def test_which_kernels_serve_which_length_class(engine, world):
             assert st[6]["lds_mode"] in (8, 9) and st[6]["variant"] & 8 and st[7]["variant"] & 3 == 2, name
             assert st[8]["lds_mode"] == 11 and st[8]["variant"] & 8, name
             assert st[1]["aligned"] > 50 and st[1]["ms_rest"] > 0, name          # two cascades: some reads (N, 36 nt) stayed with the FM kernels
-            engine.set_option("long_lane", 0)
-            old = engine.cascade(ReadSet(words, lens, nmask, None, device=engine.device), passes)
-            engine.set_option("long_lane", 1)
+            old = engine.cascade(ReadSet(words, lens, nmask, None, device=engine.device), passes)   # the default: long_lane = 0
             same(old, ref)
             assert all(s["lds_mode"] not in (7, 8, 9, 11) for s in old.stats if s["n_launches"]), name   # match / fused / stratum kernels only
         else:
