@@ -230,6 +230,7 @@ struct mrg_ctx {
   int64_t split_min_len = 16;  // ... and so do not reads shorter than this (the reference's own minimum length, trim_file.py:33; shorter seed regions than 15 bases have no pair tables)
   int64_t stratum0_unit = 0;  // (measured slower, default off) the exact stratum of a 2-mismatch pass behind a seed launch rides in that launch
   int64_t walk_diag = 0;
+  int64_t count_variants = 1;  // mrg_count_best, one seed mismatch: the jump-table variants kernel in front of the pigeonhole kernel
   int64_t long_lane = 0;   // round 6: 1 = the reads of 33..63 nt of a split batch ride the dictionary kernels too (their LONG instantiations; measured no faster than the FM kernels: off)
   void* walk_buf = nullptr;  // wave_seed_kernel: records of the reads left to their position lists (grid x 4 waves x 256 x 32 B)
   size_t walk_bytes = 0;
@@ -761,6 +762,8 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->pos_lists = value != 0;
   } else if (k == "pos_scan") {
     ctx->pos_scan = value != 0;
+  } else if (k == "count_variants") {
+    ctx->count_variants = value != 0;
   } else if (k == "walk_diag") {
     ctx->walk_diag = value;
   } else if (k == "long_lane") {
@@ -2503,6 +2506,15 @@ int mrg_count_best(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_rea
   if (n == 0) return MRG_OK;
   p.best_mm = d_best_mm;
   p.count = d_count;
+  // one-mismatch run on one-word reads without N: the largest jump table's K-mers and their variants first (kernels.hip:
+  // count_variants_kernel); the pigeonhole kernel then takes what that left (reads shorter than a usable table, longer than
+  // the seed) -- nothing, for the 18..21-nt reads the -ai path submits
+  if (ctx->count_variants && words_per_read == 1 && !d_nmask && max_mm_seed == 1 && ctx->use_ftab) {
+    const uint64_t want = (n + 7) / 8;
+    const uint32_t vgrid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)ctx->n_cu * 32u));
+    HIP_TRY(mrg::launch_count_variants(p, vgrid, (hipStream_t)stream));
+    p.only_todo = 1u;
+  }
   HIP_TRY(mrg::launch_count(p, words_per_read, grid, lds, (hipStream_t)stream));
   return MRG_OK;
 }

@@ -1664,6 +1664,7 @@ __global__ void __launch_bounds__(1024, (W == 1 ? 8 : 4)) stratum_kernel(const M
   if (p.idx_out && threadIdx.x == 0) p.out_count[blockIdx.x] = ctl[0];
 }
 
+constexpr uint32_t kCountTodoMark = 254u;  // best_mm of a read count_variants_kernel left to count_kernel
 // ---------------------------------------------------------------------------
 // count_kernel: best stratum of every read against one library -- fewest mismatches of a
 // valid alignment and how many alignments reach it.  Replaces the two genome bowtie runs
@@ -1702,6 +1703,7 @@ __global__ void __launch_bounds__(kCountThreads) count_kernel(const CountParams 
       nm[k] = p.nmask ? p.nmask[(size_t)k * p.n_reads + r] : 0ull;
     }
     const int32_t L = (int32_t)p.lens[r];
+    if (!LIST && p.only_todo && p.best_mm[r] != (uint8_t)kCountTodoMark) continue;  // (count_variants_kernel answered this read)
     uint32_t best_mm = 255u, count = 0u;
     const uint32_t want_mm = LIST ? (uint32_t)p.best_mm[r] : 0u;
     const uint64_t out_base = LIST ? p.offsets[r] : 0ull;
@@ -1814,6 +1816,105 @@ __global__ void __launch_bounds__(kCountThreads) count_kernel(const CountParams 
       p.best_mm[r] = (uint8_t)best_mm;
       if (p.count32) p.count32[r] = best_mm == 255u ? 0u : count;
       else p.count[r] = (uint8_t)(best_mm == 255u ? 0u : count);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// count_variants_kernel (round 6): the one-mismatch genome run (`-n 1 -a -3 2`, writeDataToCSV.py:1263) for one-word reads
+// without N whose whole length is seed region (L <= seed_len), through the library's LARGEST jump table instead of
+// the pigeonhole pieces.  count_kernel halves a 20-nt read into pieces of 10 bases; in a 300 Mbp part a 10-mer has
+// ~290 rows, so a read cost ~570 row + text verifications, one after the other in its lane: 65 M reads/s
+// (profiles/r01_genome_part_300m.json).  With K = the largest table's k <= L (14 for a genome part):
+//   A = the read's first K bases, exact       -> every alignment whose mismatch (if any) lies behind base K;
+//   B = its last K bases, exact               -> those with exactly one mismatch in front of base L - K;
+//   one variant of A per (position p in [L - K, K), other base)  -> those with exactly one mismatch, at p
+// -- disjoint classes that cover every alignment with at most one mismatch, 2 + 3 (2 K - L) table lookups of ~1 row each
+// (26 for a 20-nt read).  Half a wave (32 lanes) per read, a lane per lookup: nothing is walked serially, and no LF step
+// is made at all.  Reads this does not fit (shorter than a usable table, longer than the seed, two mismatches...) are
+// marked kCountTodo in best_mm and left to count_kernel, which then skips every other read.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kCountTodo = kCountTodoMark;
+
+__global__ void __launch_bounds__(kCountThreads) count_variants_kernel(const CountParams p) {
+  const uint32_t lane32 = threadIdx.x & 31u;
+  const uint64_t groups = (uint64_t)gridDim.x * (kCountThreads / 32u);
+  for (uint64_t r = (uint64_t)blockIdx.x * (kCountThreads / 32u) + (threadIdx.x >> 5); r < p.n_reads; r += groups) {
+    const uint64_t rd = p.reads[r];
+    const int32_t L = (int32_t)p.lens[r];
+    // the largest table a read of L bases can use (tables in ascending k)
+    uint32_t K = 0, tab_off = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool take = p.tabs.k[i] != 0u && (int32_t)p.tabs.k[i] <= L;
+      K = take ? p.tabs.k[i] : K;
+      tab_off = take ? p.tabs.off[i] : tab_off;
+    }
+    if (K < 8u || L > p.seed_len || L > 32 || L <= p.max_mm_seed) {  // (not this kernel's read)
+      if (lane32 == 0u) p.best_mm[r] = (L <= p.max_mm_seed) ? 255u : (uint8_t)kCountTodo;
+      if (lane32 == 0u && L <= p.max_mm_seed) p.count[r] = 0u;
+      continue;
+    }
+    const uint32_t tail = (uint32_t)L - K;                    // B starts here; positions [tail, K) need the variants
+    const uint32_t n_var = K > tail ? 3u * (K - tail) : 0u;
+    const uint32_t n_items = 2u + n_var;
+    const uint64_t lmask = low_bits(2u * (uint32_t)L);
+    uint32_t best = 255u, cnt = 0u;
+    bool sat = false;
+    for (uint32_t it = lane32; it < n_items; it += 32u) {
+      if (it == 1u && tail == 0u) continue;                  // (L == K: B is A)
+      uint64_t q = rd;
+      uint32_t off = 0u;                                     // read offset of the K-mer looked up
+      if (it == 1u) {
+        off = tail;
+      } else if (it >= 2u) {
+        const uint32_t v = it - 2u;
+        q = rd ^ ((uint64_t)(v % 3u + 1u) << (2u * (tail + v / 3u)));
+      }
+      const uint32_t* tab = p.ftab + tab_off + lex_code((q >> (2u * off)) & low_bits(2u * K), K);
+      const uint32_t lo = tab[0];
+      uint32_t hi = tab[1];
+      if (hi > lo && hi - lo > p.max_rows) {  // (count_kernel's rule: a seed this repetitive cannot have a unique best hit)
+        sat = true;
+        hi = lo + p.max_rows;
+      }
+      for (uint32_t i = lo; i < hi; ++i) {
+        const uint64_t row = p.sa[i];
+        const uint32_t before = (uint32_t)(row >> 32) & 255u, after = (uint32_t)(row >> 40) & 255u;
+        if ((off > before) | ((uint32_t)L - off > after)) continue;
+        const uint32_t s = (uint32_t)row - off;
+        const uint32_t w = s >> 4, sh = (s & 15u) * 2u;
+        const uint64_t lo64 = (uint64_t)p.text[w] | ((uint64_t)p.text[w + 1] << 32);
+        const uint64_t win = (lo64 >> sh) | ((((uint64_t)p.text[w + 2]) << 1) << (63u - sh));
+        const uint64_t x = win ^ rd;
+        const uint64_t mb = ((x | (x >> 1)) & 0x5555555555555555ull) & lmask;
+        const uint32_t mm = (uint32_t)__popcll(mb);
+        if ((int32_t)mm > p.max_mm_seed || (int32_t)mm > p.max_mm_total) continue;
+        if (it != 0u && mm != 1u) continue;                  // B and the variants own the alignments with their one mismatch
+        // (a read of more than 2 K bases: A and B do not meet, and a mismatch between them leaves BOTH exact -- A's)
+        if (it == 1u && (uint32_t)(__ffsll((long long)mb) - 1) / 2u >= K) continue;
+        if (mm < best) {
+          best = mm;
+          cnt = 1u;
+        } else if (mm == best) {
+          ++cnt;
+        }
+      }
+    }
+    // the 32 lanes' (best, count) -> the read's
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      const uint32_t ob = __shfl_xor(best, o, 32), oc = __shfl_xor(cnt, o, 32);
+      const bool os = __shfl_xor((int)sat, o, 32) != 0;
+      cnt = ob < best ? oc : (ob == best ? cnt + oc : cnt);
+      best = min(best, ob);
+      sat |= os;
+    }
+    if (lane32 == 0u) {
+      p.best_mm[r] = (uint8_t)best;
+      const uint32_t c = best == 255u ? 0u : ((sat && !p.count32) ? 255u : cnt);
+      if (p.count32) p.count32[r] = best == 255u ? 0u : cnt;
+      else p.count[r] = (uint8_t)min(c, 255u);
     }
   }
 }
@@ -2345,6 +2446,11 @@ hipError_t launch_tally(const TallyParams& p, bool lds_hist, uint32_t grid,
   } else {
     hipLaunchKernelGGL(tally_kernel<false>, dim3(grid), dim3(kTallyThreads), 0, stream, p);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_count_variants(const CountParams& p, uint32_t grid, hipStream_t stream) {
+  hipLaunchKernelGGL(count_variants_kernel, dim3(grid), dim3(kCountThreads), 0, stream, p);
   return hipGetLastError();
 }
 

@@ -469,6 +469,7 @@ struct CountParams {
   int32_t* out_ref;
   int32_t* out_pos;
   uint64_t out_cap;
+  uint32_t only_todo;  // round 6: count_variants_kernel ran first; count_kernel takes the reads it marked (best_mm 254) only
 };
 
 struct TallyParams {
@@ -544,6 +545,7 @@ hipError_t collapse_reads(const uint64_t* d_reads, uint32_t W, const uint8_t* d_
                           uint8_t* d_u_lens, uint64_t* d_u_nmask, uint32_t* d_quant,
                           uint64_t* d_len_hist, uint32_t* h_n_unique, hipStream_t stream, void* arena_base = nullptr,
                           uint64_t arena_bytes = 0, int n_cu = 0, bool allow_fast = true);  // arena: device scratch the temporaries are carved from
+hipError_t launch_count_variants(const CountParams& p, uint32_t grid, hipStream_t stream);
 hipError_t launch_count(const CountParams& p, uint32_t words_per_read, uint32_t grid, uint32_t lds_bytes,
                         hipStream_t stream);
 hipError_t exclusive_sum_u32_u64(const uint32_t* in, uint64_t* out, uint64_t n_plus_1, hipStream_t stream);
