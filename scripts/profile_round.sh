@@ -47,3 +47,15 @@ timeout 600 python scripts/collapse_bench.py > gpurun_out/${tag}_collapse_plain.
 timeout 600 python scripts/lib_load_timing.py 1.0 > /dev/null 2> gpurun_out/${tag}_lib_load.txt
 timeout 900 python scripts/cli_scale_check.py 32000000 1.0 1 > gpurun_out/${tag}_cli_scale_32m.txt 2>&1
 timeout 600 python scripts/cli_scale_check.py 32000000 0.2 1 > gpurun_out/${tag}_cli_scale_32m_s02.txt 2>&1
+# ---- round 6 ----
+# the repeats workload's kernels by time and by HBM bytes (the large launch answers wide seeds from position lists), the LONG
+# lane against the default on the varlen batch, one genome part under the profiler (count_variants_kernel + count_kernel)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_repeats_stats -- $B --workload repeats --steps 5 --warmup 1 > gpurun_out/${tag}_repeats_stats.json 2> gpurun_out/${tag}_repeats_stats.err
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_repeats_fetch -- $B --workload repeats --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${tag}_repeats_fetch.err
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_repeats_write -- $B --workload repeats --steps 1 --warmup 0 > /dev/null 2> gpurun_out/${tag}_repeats_write.err
+python bench.py --workload varlen --no-extras --no-legs --opt long_lane=1 2> /dev/null > gpurun_out/${tag}_bench_varlen_long_lane.json
+python bench.py --workload varlen --no-extras --no-legs --no-cpu-baseline --scan-sample 0 --keep-lens 33,40 --opt long_lane=1 2> /dev/null > gpurun_out/${tag}_bench_long_only_lane.json
+python bench.py --workload varlen --no-extras --no-legs --no-cpu-baseline --scan-sample 0 --keep-lens 33,40 --opt long_lane=0 2> /dev/null > gpurun_out/${tag}_bench_long_only_fm.json
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_genome_stats -- python3 scripts/genome_scale_check.py --reads 2000000 > gpurun_out/${tag}_genome_part.json 2> gpurun_out/${tag}_genome_stats.err
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_genome_fetch -- python3 scripts/genome_scale_check.py --reads 2000000 > /dev/null 2> gpurun_out/${tag}_genome_fetch.err
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_genome_write -- python3 scripts/genome_scale_check.py --reads 2000000 > /dev/null 2> gpurun_out/${tag}_genome_write.err
