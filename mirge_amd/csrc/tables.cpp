@@ -8,7 +8,12 @@
 //   row = uniqueSequence,annotFlag,<slot 1>,...,<slot n_slots>,<count sample 1>,...
 // mapped: annotFlag 1 and the claiming pass's slot holds the library entry name (RAP:341-345);
 // unmapped: annotFlag 0 and every slot empty.
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -77,76 +82,113 @@ uint64_t format_rows(const TableArgs& a, uint64_t lo, uint64_t hi, std::string& 
 
 }  // namespace
 
-// The rows are formatted by several threads, a block of rows each, and written in order: at 10^7-10^8 rows one thread
-// formatting a gigabyte of text was most of the command line's "Summarizing" phase (MIRGE_AMD_TABLE_THREADS overrides
-// the thread count: hardware threads, at most 16).
+// The rows are formatted by several threads, a block of 2^18 rows each.  Round 4 wrote the blocks of a round in order from
+// ONE thread while the others waited (1 GB of unmapped.csv for 27 M reads: 1.9-2.9 s, most of it that copy into the page
+// cache); round 6: a worker formats its block, learns where the block starts from the worker of the block in front (a
+// chain of SIZES only: it is passed on as soon as a block is formatted, not when it is written), and writes it there itself
+// with pwrite -- formatting and the writes of up to 16 blocks overlap.  Same bytes for every thread count
+// (tests/test_report_tables.py; MIRGE_AMD_TABLE_THREADS overrides the count: hardware threads, at most 16).
 uint64_t write_read_table(const char* path, bool mapped, const char* header, bool append, const uint64_t* reads,
                           uint32_t W, uint64_t stride, const uint8_t* lens, const uint64_t* nmask, uint64_t n,
                           const int8_t* pass_id, const int32_t* ref_id, const uint32_t* quant, uint32_t n_samples,
                           uint32_t n_slots, const char* const* names, const uint64_t* names_off) {
-  FILE* f = std::fopen(path, append ? "ab" : "wb");
-  if (!f) throw std::runtime_error(std::string("cannot open ") + path);
-  std::vector<char> buf(8u << 20);
-  std::setvbuf(f, buf.data(), _IOFBF, buf.size());
-  if (header && !append) std::fputs(header, f);
+  const int fd = ::open(path, append ? (O_WRONLY | O_CREAT) : (O_WRONLY | O_CREAT | O_TRUNC), 0644);
+  if (fd < 0) throw std::runtime_error(std::string("cannot open ") + path);
+  struct Closer {
+    int fd;
+    ~Closer() {
+      if (fd >= 0) ::close(fd);
+    }
+  } closer{fd};
+  auto write_at = [&](const char* data, size_t len, uint64_t at) {
+    while (len) {
+      const ssize_t w = ::pwrite(fd, data, len, (off_t)at);
+      if (w < 0) {
+        if (errno == EINTR) continue;
+        throw std::runtime_error(std::string("write to ") + path + " failed");
+      }
+      data += w;
+      len -= (size_t)w;
+      at += (uint64_t)w;
+    }
+  };
+  uint64_t start = 0;
+  if (append) {
+    const off_t end = ::lseek(fd, 0, SEEK_END);
+    if (end < 0) throw std::runtime_error(std::string("cannot seek in ") + path);
+    start = (uint64_t)end;
+  } else if (header) {
+    write_at(header, std::strlen(header), 0);
+    start = std::strlen(header);
+  }
   const TableArgs a{mapped, reads, W, stride, lens, nmask, pass_id, ref_id, quant, n_samples, n_slots, names, names_off};
   unsigned n_threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   if (const char* e = std::getenv("MIRGE_AMD_TABLE_THREADS")) n_threads = (unsigned)std::max(1, std::atoi(e));
   constexpr uint64_t kBlockRows = 1u << 18;
-  if (n <= kBlockRows) n_threads = 1;
-  std::vector<std::string> text(n_threads);
-  std::vector<uint64_t> got(n_threads, 0);
-  uint64_t rows = 0;
-  // (a worker that throws -- std::bad_alloc from a growing row buffer -- must not take the process down: the exception is
-  // kept, every thread is joined -- also when starting one fails --, and it is rethrown here, where the C-ABI turns it
-  // into an error code)
+  const uint64_t n_blocks = (n + kBlockRows - 1) / kBlockRows;
+  if (n_blocks <= 1) n_threads = 1;
+  n_threads = (unsigned)std::min<uint64_t>(n_threads, std::max<uint64_t>(n_blocks, 1));
+  // begin[b] = file offset of block b, known once block b - 1 is formatted (begin[0] = start)
+  std::vector<std::atomic<uint64_t>> begin(n_blocks + 1);
+  for (auto& x : begin) x.store(~0ull, std::memory_order_relaxed);
+  begin[0].store(start, std::memory_order_release);
+  std::atomic<uint64_t> next{0}, rows{0};
+  std::atomic<bool> stop{false};
   std::vector<std::exception_ptr> failed(n_threads);
-  struct Joiner {
-    std::vector<std::thread>& p;
-    ~Joiner() {
-      for (auto& th : p)
-        if (th.joinable()) th.join();
+  auto worker = [&](unsigned t) {
+    std::string text;
+    try {
+      for (;;) {
+        const uint64_t b = next.fetch_add(1, std::memory_order_relaxed);
+        if (b >= n_blocks || stop.load(std::memory_order_relaxed)) break;
+        const uint64_t lo = b * kBlockRows, hi = std::min(n, lo + kBlockRows);
+        text.clear();
+        const uint64_t got = format_rows(a, lo, hi, text);
+        if (got == ~0ull) throw std::runtime_error("write_read_table: entry index out of range for its pass");
+        uint64_t at;
+        while ((at = begin[b].load(std::memory_order_acquire)) == ~0ull) {
+          if (stop.load(std::memory_order_relaxed)) return;
+          std::this_thread::yield();
+        }
+        begin[b + 1].store(at + text.size(), std::memory_order_release);   // (the block behind may go on before this one is written)
+        if (!text.empty()) write_at(text.data(), text.size(), at);
+        rows.fetch_add(got, std::memory_order_relaxed);
+      }
+    } catch (...) {
+      // (a worker that throws -- std::bad_alloc from a growing row buffer, a full disk -- must not take the process down: the
+      // exception is kept, the others stop at their next block, every thread is joined, and it is rethrown below, where the
+      // C-ABI turns it into an error code)
+      failed[t] = std::current_exception();
+      stop.store(true, std::memory_order_relaxed);
     }
   };
-  for (uint64_t base = 0; base < n; base += (uint64_t)n_threads * kBlockRows) {
+  if (n_threads == 1) {
+    worker(0);
+  } else {
     std::vector<std::thread> pool;
+    struct Joiner {
+      std::vector<std::thread>& p;
+      ~Joiner() {
+        for (auto& th : p)
+          if (th.joinable()) th.join();
+      }
+    };
     {
       Joiner joiner{pool};
-      for (unsigned t = 0; t < n_threads; ++t) {
-        const uint64_t lo = std::min(n, base + (uint64_t)t * kBlockRows), hi = std::min(n, lo + kBlockRows);
-        text[t].clear();
-        got[t] = 0;
-        if (lo >= hi) continue;
-        if (n_threads == 1) got[t] = format_rows(a, lo, hi, text[t]);
-        else
-          pool.emplace_back([&a, &text, &got, &failed, t, lo, hi] {
-            try {
-              got[t] = format_rows(a, lo, hi, text[t]);
-            } catch (...) {
-              failed[t] = std::current_exception();
-            }
-          });
+      try {
+        for (unsigned t = 0; t < n_threads; ++t) pool.emplace_back(worker, t);
+      } catch (...) {
+        stop.store(true, std::memory_order_relaxed);
+        throw;
       }
-    }
-    for (unsigned t = 0; t < n_threads; ++t)
-      if (failed[t]) {
-        std::fclose(f);
-        std::rethrow_exception(failed[t]);
-      }
-    for (unsigned t = 0; t < n_threads; ++t) {
-      if (got[t] == ~0ull) {
-        std::fclose(f);
-        throw std::runtime_error("write_read_table: entry index out of range for its pass");
-      }
-      if (!text[t].empty() && std::fwrite(text[t].data(), 1, text[t].size(), f) != text[t].size()) {
-        std::fclose(f);
-        throw std::runtime_error(std::string("short write to ") + path);
-      }
-      rows += got[t];
     }
   }
-  if (std::fclose(f) != 0) throw std::runtime_error(std::string("cannot close ") + path);
-  return rows;
+  for (unsigned t = 0; t < n_threads; ++t)
+    if (failed[t]) std::rethrow_exception(failed[t]);
+  const int fd_close = closer.fd;
+  closer.fd = -1;
+  if (::close(fd_close) != 0) throw std::runtime_error(std::string("cannot close ") + path);
+  return rows.load();
 }
 
 }  // namespace mrg
