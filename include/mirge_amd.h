@@ -685,6 +685,22 @@ int mrg_write_read_table(const char *path, int32_t mapped, const char *header, i
                          uint32_t n_slots, const char *const *names, const uint64_t *names_off,
                          uint64_t *rows);
 
+/*
+ * isomirs.csv and isomirs.samples.csv (utils/writeDataToCSV.py:1090-1170, over the grouping of :588-606) from the same
+ * arrays (round 6): the reads claimed by canon_pass ("exact miRNA", slot 1) and isomir_pass ("isomiR miRNA", slot 9) are
+ * grouped by group_of_entry[ref_id] -- the caller's map from a miRNA library entry to its name with the ".SNP..." suffix
+ * stripped (:599-600), n_groups names in group_names --, groups in the order their first read appears, a group's isomiR
+ * reads in array order.  filtered[s] = the sample's mirnaReadsFiltered (the RPM divisor).  Values are formatted as Python 2's
+ * str(float) and the entropies are added in the reference's order: the files equal report.write_isomir_tables' byte for
+ * byte (tests/test_report_tables.py).  header1 / header2: the two header lines.  *rows = rows of isomirs.csv.
+ */
+int mrg_write_isomir_tables(const char *isomirs_path, const char *samples_path, const char *header1, const char *header2,
+                            const uint64_t *reads, uint32_t words_per_read, uint64_t stride, const uint8_t *lens,
+                            const uint64_t *nmask, uint64_t n, const int8_t *pass_id, const int32_t *ref_id,
+                            const uint32_t *quant, uint32_t n_samples, int32_t canon_pass, int32_t isomir_pass,
+                            const int32_t *group_of_entry, uint64_t n_entries, const char *const *group_names,
+                            uint32_t n_groups, const double *filtered, uint64_t *rows);
+
 /* Packing helper used by hosts without numpy: ASCII reads -> SoA words. */
 int mrg_pack_reads(const char *const *seqs, uint64_t n, uint32_t words_per_read,
                    uint64_t *reads, uint8_t *lens, uint64_t *nmask, int *has_n);

@@ -170,6 +170,10 @@ SIGNATURES = {
                                        C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_char_p), C.c_void_p,
                                        C.POINTER(C.c_uint64)]),
+    "mrg_write_isomir_tables": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint64,
+                                          C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                          C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_char_p), C.c_uint32,
+                                          C.c_void_p, C.POINTER(C.c_uint64)]),
     "mrg_pack_reads": (C.c_int, [C.POINTER(C.c_char_p), C.c_uint64, C.c_uint32, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "mrg_pack_reads_ragged": (C.c_int, [C.POINTER(C.c_char_p), C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -451,11 +451,16 @@ def annotate_main(args, engine_factory=None, materialize=False):
     report.write_annotation_report_csv(os.path.join(outdir, "annotation.report.csv"), sample_list, log_dic, spike)
     columnar.write_read_tables(outdir, names, sample_list, h_words, h_lens, h_nmask, h_quant, h_pass, h_ref, npp,
                                extra=long_res)
-    # the reads the remaining consumers look at
+    # the reads the remaining consumers look at: dict records only when the GFF, the tRF tables or the -ai report want them
+    # (round 6: the isomiR tables alone come straight from the arrays, columnar.write_isomir_tables)
     want = {CANON_PASS, ISOMIR_PASS} | ({2, 3} if args.trf_output else set())
-    sub, align = columnar.read_subset(h_words, h_lens, h_nmask, h_quant, h_pass, h_ref, h_pos, h_mm, npp, want, spike)
-    if long_res is not None:
-        columnar.add_long_records(sub, align, long_res, npp, want, spike)
+    long_mirna = long_res is not None and bool(np.isin(np.asarray(long_res[2]), (CANON_PASS, ISOMIR_PASS)).any())
+    need_records = args.gff_output or args.trf_output or args.a_to_i or (args.diff_isomirs and long_mirna)
+    sub, align = {}, {}
+    if need_records:
+        sub, align = columnar.read_subset(h_words, h_lens, h_nmask, h_quant, h_pass, h_ref, h_pos, h_mm, npp, want, spike)
+        if long_res is not None:
+            columnar.add_long_records(sub, align, long_res, npp, want, spike)
     if args.gff_output:   # RAP:609-619, :653-656
         from . import isomir
         hairpin_seqs = engine.indexes["hairpin"].name_seq_dict()
@@ -472,7 +477,10 @@ def annotate_main(args, engine_factory=None, materialize=False):
         trf.collect_trf_content(trf_content, sub, sample_list, trf_tables["trnaStruDic"], pre_seqs,
                                 trf.engine_lister(engine))
         trf.write_trf_tables(outdir, sample_list, log_dic, trf_content, trf_tables, pre_seqs)
-    if args.diff_isomirs:
+    if args.diff_isomirs and not long_mirna:
+        columnar.write_isomir_tables(os.path.join(outdir, "isomirs.csv"), os.path.join(outdir, "isomirs.samples.csv"), sample_list,
+                                     h_words, h_lens, h_nmask, h_quant, h_pass, h_ref, npp[CANON_PASS], log_dic)
+    elif args.diff_isomirs:   # (a read beyond 255 nt claimed by a miRNA pass: the records, which hold it)
         report.write_isomir_tables(os.path.join(outdir, "isomirs.csv"), os.path.join(outdir, "isomirs.samples.csv"),
                                    sample_list, columnar.isomir_dic(sub, S), log_dic)
     report.write_counts_csv(os.path.join(outdir, "miR.Counts.csv"), sample_list, mir_dic, log_dic)

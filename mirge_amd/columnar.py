@@ -162,6 +162,41 @@ def isomir_dic(records, n_samples):
     return out
 
 
+def write_isomir_tables(isomir_path, sample_path, sample_list, words, lens, nmask, quant, pass_id, ref_id, mirna_names, log_dic):
+    """isomirs.csv + isomirs.samples.csv (W2C:1090-1170) from the arrays by the native writer (mrg_write_isomir_tables) -- the
+    files report.write_isomir_tables(..., isomir_dic(read_subset(...)), ...) writes, byte for byte, without a Python record per
+    miRNA read.  Returns the rows of isomirs.csv."""
+    lib = _native.load()
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    W, n = words.shape
+    lens = np.ascontiguousarray(lens, dtype=np.uint8)
+    nm = None if nmask is None else np.ascontiguousarray(nmask, dtype=np.uint64)
+    quant = np.ascontiguousarray(quant, dtype=np.uint32)
+    S = quant.shape[1] if quant.ndim == 2 else 1
+    pass_id = np.ascontiguousarray(pass_id, dtype=np.int8)
+    ref_id = np.ascontiguousarray(ref_id, dtype=np.int32)
+    # a miRNA entry's group: its name with the SNP suffix stripped (W2C:599-600)
+    gid, gnames = {}, []
+    group_of = np.empty(len(mirna_names), dtype=np.int32)
+    for e, name in enumerate(mirna_names):
+        key = name.split(".SNP")[0] if ".SNP" in name else name
+        if key not in gid:
+            gid[key] = len(gnames)
+            gnames.append(key)
+        group_of[e] = gid[key]
+    arr = (C.c_char_p * max(len(gnames), 1))(*[g.encode("ascii") for g in gnames])
+    filtered = np.array([float(log_dic["quantStats"][i]["mirnaReadsFiltered"]) for i in range(S)], dtype=np.float64)
+    h1 = "miRNA,sequence" + "".join("," + s for s in sample_list) + ",Entropy\n"
+    h2 = "miRNA" + "".join(",%s isomir+miRNA Entropy,%s Canonical Sequence,%s Canonical RPM,%s Top Isomir RPM" % (s, s, s, s)
+                           for s in sample_list) + "\n"
+    k = C.c_uint64(0)
+    check(lib.mrg_write_isomir_tables(
+        os.fsencode(isomir_path), os.fsencode(sample_path), h1.encode(), h2.encode(), words.ctypes.data, W, n, lens.ctypes.data,
+        None if nm is None else nm.ctypes.data, n, pass_id.ctypes.data, ref_id.ctypes.data, quant.ctypes.data, S,
+        CANON_PASS, ISOMIR_PASS, group_of.ctypes.data, len(mirna_names), arr, len(gnames), filtered.ctypes.data, C.byref(k)))
+    return int(k.value)
+
+
 def mirna_read_subset(engine, cols, words, lens, nmask, quant, log_dic=None, spike_in=False, for_a2i=False):
     """seqDic-shaped records ({'quant', 'annot', 'length'}) of the reads claimed by the miRNA passes.
     for_a2i: keep an isomiR read only if its RPM (against mirnaReadsFiltered, W2C:1240-1247) is

@@ -2998,6 +2998,28 @@ int mrg_write_read_table(const char* path, int32_t mapped, const char* header, i
   }
 }
 
+int mrg_write_isomir_tables(const char* isomirs_path, const char* samples_path, const char* header1, const char* header2,
+                            const uint64_t* reads, uint32_t words_per_read, uint64_t stride, const uint8_t* lens,
+                            const uint64_t* nmask, uint64_t n, const int8_t* pass_id, const int32_t* ref_id, const uint32_t* quant,
+                            uint32_t n_samples, int32_t canon_pass, int32_t isomir_pass, const int32_t* group_of_entry,
+                            uint64_t n_entries, const char* const* group_names, uint32_t n_groups, const double* filtered,
+                            uint64_t* rows) {
+  if (!isomirs_path || !samples_path || !header1 || !header2 || !filtered || !n_samples ||
+      (n && (!reads || !lens || !pass_id || !ref_id || !quant || !group_of_entry || !group_names)))
+    return fail(MRG_ERR_ARG, "mrg_write_isomir_tables: null argument");
+  if (words_per_read == 0 || words_per_read > MRG_MAX_WORDS || stride < n)
+    return fail(MRG_ERR_ARG, "mrg_write_isomir_tables: bad words_per_read / stride");
+  try {
+    const uint64_t k = mrg::write_isomir_tables(isomirs_path, samples_path, header1, header2, reads, words_per_read, stride, lens, nmask, n,
+                                                pass_id, ref_id, quant, n_samples, canon_pass, isomir_pass, group_of_entry, n_entries,
+                                                group_names, n_groups, filtered);
+    if (rows) *rows = k;
+    return MRG_OK;
+  } catch (const std::exception& e) {
+    return fail(MRG_ERR_IO, "mrg_write_isomir_tables: %s", e.what());
+  }
+}
+
 // ------------------------------------------------------------- packing
 int mrg_pack_reads(const char* const* seqs, uint64_t n, uint32_t words_per_read, uint64_t* reads,
                    uint8_t* lens, uint64_t* nmask, int* has_n) {

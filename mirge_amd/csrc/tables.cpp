@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -189,6 +190,164 @@ uint64_t write_read_table(const char* path, bool mapped, const char* header, boo
   closer.fd = -1;
   if (::close(fd_close) != 0) throw std::runtime_error(std::string("cannot close ") + path);
   return rows.load();
+}
+
+// ---------------------------------------------------------------------------
+// isomirs.csv + isomirs.samples.csv (writeDataToCSV.py:1090-1170; the grouping of :588-606) straight from the columnar
+// arrays -- what report.write_isomir_tables(columnar.isomir_dic(columnar.read_subset(...))) writes, without the 10^5..10^6
+// Python dict records in between (1.5 s of the command line's 3 s on a 32 M-read sample).  The reference's arithmetic in
+// the reference's order, so that the text comes out byte for byte: str(float) of Python 2 is "%.12g" (+ ".0" for a whole
+// number), math.log(x, 2) is log(x) / log(2), calcEntropy adds -1 * f * log2(f) over the entries > 1 in list order.
+namespace {
+
+void py2_float(double x, std::string& out) {
+  char buf[40];
+  if (x != x) {
+    out += "nan";
+    return;
+  }
+  if (x > 1.7976931348623157e308 || x < -1.7976931348623157e308) {
+    out += x > 0 ? "inf" : "-inf";
+    return;
+  }
+  const int len = std::snprintf(buf, sizeof buf, "%.12g", x);
+  out.append(buf, (size_t)len);
+  if (!std::memchr(buf, '.', (size_t)len) && !std::memchr(buf, 'e', (size_t)len) && !std::memchr(buf, 'n', (size_t)len)) out += ".0";
+}
+
+double calc_entropy(const uint64_t* v, size_t n) {
+  uint64_t total = 0;
+  for (size_t i = 0; i < n; ++i) total += v[i];
+  double h = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (v[i] > 1) {
+      const double f = (double)v[i] / (double)total;
+      h = h + (-1.0 * f) * (std::log(f) / std::log(2.0));
+    }
+  return h;
+}
+
+}  // namespace
+
+uint64_t write_isomir_tables(const char* isomirs_path, const char* samples_path, const char* header1, const char* header2,
+                             const uint64_t* reads, uint32_t W, uint64_t stride, const uint8_t* lens, const uint64_t* nmask,
+                             uint64_t n, const int8_t* pass_id, const int32_t* ref_id, const uint32_t* quant, uint32_t S,
+                             int32_t canon_pass, int32_t isomir_pass, const int32_t* group_of_entry, uint64_t n_entries,
+                             const char* const* group_names, uint32_t n_groups, const double* filtered) {
+  static const char kBase[4] = {'A', 'C', 'G', 'T'};
+  // groups in the order their first read (exact-miRNA or isomiR pass) appears; the isomiR reads of each, in read order
+  std::vector<uint32_t> order;
+  std::vector<uint8_t> seen(n_groups, 0);
+  std::vector<std::vector<uint64_t>> iso(n_groups);
+  std::vector<uint64_t> canon((size_t)n_groups * S, 0);
+  for (uint64_t r = 0; r < n; ++r) {
+    const int p = pass_id[r];
+    if (p != canon_pass && p != isomir_pass) continue;
+    const int32_t e = ref_id[r];
+    if (e < 0 || (uint64_t)e >= n_entries) throw std::runtime_error("write_isomir_tables: entry index out of range");
+    const int32_t g = group_of_entry[e];
+    if (g < 0 || (uint32_t)g >= n_groups) throw std::runtime_error("write_isomir_tables: group index out of range");
+    if (!seen[g]) {
+      seen[g] = 1;
+      order.push_back((uint32_t)g);
+    }
+    if (p == isomir_pass) iso[g].push_back(r);
+    else
+      for (uint32_t s = 0; s < S; ++s) canon[(size_t)g * S + s] += quant[r * S + s];
+  }
+  FILE* f1 = std::fopen(isomirs_path, "wb");
+  if (!f1) throw std::runtime_error(std::string("cannot open ") + isomirs_path);
+  FILE* f2 = std::fopen(samples_path, "wb");
+  if (!f2) {
+    std::fclose(f1);
+    throw std::runtime_error(std::string("cannot open ") + samples_path);
+  }
+  struct Files {
+    FILE *a, *b;
+    ~Files() {
+      if (a) std::fclose(a);
+      if (b) std::fclose(b);
+    }
+  } files{f1, f2};
+  std::fputs(header1, f1);
+  std::fputs(header2, f2);
+  std::string out1, out2;
+  std::vector<uint64_t> vals, counts(S);
+  uint64_t rows = 0;
+  for (uint32_t g : order) {
+    const char* name = group_names[g];
+    for (uint64_t r : iso[g]) {
+      out1 += name;
+      out1.push_back(',');
+      const uint32_t L = lens[r];
+      for (uint32_t i = 0; i < L; ++i) {
+        const uint64_t w = reads[(uint64_t)(i >> 5) * stride + r];
+        const bool is_n = nmask && ((nmask[(uint64_t)(i >> 5) * stride + r] >> ((i & 31) * 2)) & 1ull);
+        out1.push_back(is_n ? 'N' : kBase[(w >> ((i & 31) * 2)) & 3ull]);
+      }
+      for (uint32_t s = 0; s < S; ++s) {
+        counts[s] = quant[r * S + s];
+        out1.push_back(',');
+        py2_float((double)counts[s] * 1000000.0 / filtered[s], out1);
+      }
+      out1.push_back(',');
+      if (S == 1) {
+        out1 += "NA";
+      } else {
+        const double hmax = std::log((double)S) / std::log(2.0);
+        if (hmax == 0) out1 += "NA";
+        else py2_float(calc_entropy(counts.data(), S) / hmax, out1);
+      }
+      out1.push_back('\n');
+      ++rows;
+      if (out1.size() > (4u << 20)) {
+        if (std::fwrite(out1.data(), 1, out1.size(), f1) != out1.size()) throw std::runtime_error("short write to isomirs.csv");
+        out1.clear();
+      }
+    }
+    // isomirs.samples.csv: the reference appends to ONE row list across the samples and writes it after each sample
+    // that has isomiRs (sic)
+    if (!iso[g].empty()) {
+      std::string row = name;
+      for (uint32_t lane = 0; lane < S; ++lane) {
+        const double factor = 1000000.0 / filtered[lane];
+        vals.clear();
+        uint64_t top = 0, sum = 0;
+        for (uint64_t r : iso[g]) {
+          const uint64_t v = quant[r * S + lane];
+          vals.push_back(v);
+          top = std::max(top, v);
+          sum += v;
+        }
+        const double top_rpm = (double)top * factor, iso_sum = (double)sum * factor;
+        vals.push_back(canon[(size_t)g * S + lane]);
+        const double h_all = calc_entropy(vals.data(), vals.size());
+        const double canon_rpm = (double)canon[(size_t)g * S + lane] * factor;
+        const size_t nv = vals.size();
+        row.push_back(',');
+        if (nv > 1) py2_float(h_all / (std::log((double)nv) / std::log(2.0)), row);
+        else row += "NA";
+        const double combined = canon_rpm + iso_sum;
+        row.push_back(',');
+        if (combined > 0) py2_float(100.0 * canon_rpm / combined, row);
+        else row += "NA";
+        row.push_back(',');
+        py2_float(canon_rpm, row);
+        row.push_back(',');
+        py2_float(top_rpm, row);
+        out2 += row;
+        out2.push_back('\n');
+      }
+    }
+  }
+  if (!out1.empty() && std::fwrite(out1.data(), 1, out1.size(), f1) != out1.size()) throw std::runtime_error("short write to isomirs.csv");
+  if (!out2.empty() && std::fwrite(out2.data(), 1, out2.size(), f2) != out2.size()) throw std::runtime_error("short write to isomirs.samples.csv");
+  FILE* a = files.a;
+  FILE* b = files.b;
+  files.a = files.b = nullptr;
+  const int ca = std::fclose(a), cb = std::fclose(b);
+  if (ca != 0 || cb != 0) throw std::runtime_error("cannot close the isomiR tables");
+  return rows;
 }
 
 }  // namespace mrg

@@ -139,3 +139,39 @@ def test_read_table_writer_many_blocks_equals_one_thread(native_lib, tmp_path, m
     from mirge_amd._native import MirgeAmdError
     with pytest.raises(MirgeAmdError, match="out of range"):
         columnar.write_read_tables(str(tmp_path), ["A", "B", "C"], ["s0", "s1", "s2"], words, lens, nmask, quant, pass_id, bad, names)
+
+
+@pytest.mark.parametrize("n_samples", [1, 3])
+def test_native_isomir_tables_equal_the_python_path(native_lib, tmp_path, n_samples):
+    """columnar.write_isomir_tables (mrg_write_isomir_tables, round 6) = report.write_isomir_tables over
+    isomir_dic(read_subset(...)), byte for byte: groups in order of first appearance, SNP suffixes folded, Python 2's
+    str(float), the entropy sums in the reference's order, the isomirs.samples.csv row quirk with several samples."""
+    import numpy as np
+    from mirge_amd import columnar, pack
+    rng = np.random.default_rng(600 + n_samples)
+    M = 120
+    mirna_names = []
+    for i in range(M):
+        base = "syn-miR-%d-5p" % (i // 2 if i % 7 == 0 else i)
+        mirna_names.append(base + (".SNP%d" % i if i % 5 == 0 else ""))
+    n = 6000
+    reads = ["".join("ACGTN"[c] for c in rng.choice(5, int(rng.integers(16, 31)), p=[.249, .249, .249, .249, .004])) for _ in range(n)]
+    reads = list(dict.fromkeys(reads))
+    n = len(reads)
+    words, lens, nmask = pack.pack_reads(reads)
+    quant = rng.integers(0, 400, (n, n_samples)).astype(np.uint32)
+    quant[rng.random((n, n_samples)) < 0.3] = 1          # (entropy skips entries <= 1)
+    pass_id = rng.choice(np.array([-1, 0, 3, 8], dtype=np.int8), n, p=[0.2, 0.15, 0.05, 0.6])
+    ref_id = rng.integers(0, M, n).astype(np.int32)
+    ref_id[rng.random(n) < 0.5] = 7                      # one abundant miRNA
+    npp = [mirna_names] + [["x%d" % i for i in range(M)]] * 7 + [mirna_names]
+    log_dic = {"quantStats": [{"mirnaReadsFiltered": int(1000 + 977 * i)} for i in range(n_samples)]}
+    samples = ["s%d.fastq" % i for i in range(n_samples)]
+    sub, _ = columnar.read_subset(words, lens, nmask, quant, pass_id, ref_id, np.zeros(n, np.int32), np.zeros(n, np.uint8), npp, (0, 8))
+    py = [str(tmp_path / "py_isomirs.csv"), str(tmp_path / "py_samples.csv")]
+    report.write_isomir_tables(py[0], py[1], samples, columnar.isomir_dic(sub, n_samples), log_dic)
+    nat = [str(tmp_path / "isomirs.csv"), str(tmp_path / "samples.csv")]
+    rows = columnar.write_isomir_tables(nat[0], nat[1], samples, words, lens, nmask, quant, pass_id, ref_id, mirna_names, log_dic)
+    for a, b in zip(py, nat):
+        assert open(a, "rb").read() == open(b, "rb").read(), b
+    assert rows == int((pass_id == 8).sum()) and rows > 1000
