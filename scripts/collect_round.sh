@@ -8,6 +8,7 @@ python profiles/summarize_rocprof.py ${tag}_a2i --workload a2i > /dev/null 2>&1
 python profiles/summarize_collapse.py $tag > /dev/null
 for n in bench_cascade bench_exact bench_a2i bench_varlen bench_sorted bench_repeats shard_12m5 shard_25m shard_50m shard_full; do cp gpurun_out/${tag}_$n.json profiles/${tag}_$n.json; done
 cp gpurun_out/${tag}_lib_load.txt profiles/${tag}_lib_load.txt
+cp gpurun_out/${tag}_shard_halves.txt profiles/${tag}_shard_halves.txt; cp gpurun_out/${tag}_genome_whole.json profiles/${tag}_genome_whole.json
 cp gpurun_out/${tag}_collapse_plain.json profiles/${tag}_collapse_bench.json
 cp "$(ls -t gpurun_out/${tag}_varlen_stats/*/*kernel_stats.csv | head -1)" profiles/${tag}_varlen_kernel_stats.csv
 cp "$(ls -t gpurun_out/${tag}_collapse_stats/*/*kernel_stats.csv | head -1)" profiles/${tag}_collapse_kernel_stats.csv

@@ -59,3 +59,6 @@ python bench.py --workload varlen --no-extras --no-legs --no-cpu-baseline --scan
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_genome_stats -- python3 scripts/genome_scale_check.py --reads 2000000 > gpurun_out/${tag}_genome_part.json 2> gpurun_out/${tag}_genome_stats.err
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_genome_fetch -- python3 scripts/genome_scale_check.py --reads 2000000 > /dev/null 2> gpurun_out/${tag}_genome_fetch.err
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_genome_write -- python3 scripts/genome_scale_check.py --reads 2000000 > /dev/null 2> gpurun_out/${tag}_genome_write.err
+# a 12.5 M-read shard as two half-shards on two streams (round-5 verdict, item 9): cascade only, results not checked
+timeout 900 python scripts/overlap_probe.py --reads 12500000 --chunks 1,2 --grid-pct 100,60,50 --opt fused_step=1 --reps 20 2> /dev/null > gpurun_out/${tag}_shard_halves.txt
+timeout 2400 python scripts/genome_whole_check.py 2> /dev/null | grep "^{" > gpurun_out/${tag}_genome_whole.json
