@@ -480,9 +480,6 @@ def main():
         torch.cuda.synchronize()
         state["last"] = keep
     fused = state.get("last", fused)   # the last step's (reduced) count vector
-    cold = None
-    if wl == "exact" and world == 1 and not args.no_cold:
-        cold = run_cold(eng, passes, words, lens, quant, M, n_pass, canon, iso, ln, ln_tally, fused, log)
     reduce_check = None
     if world > 1:
         # every read falls into exactly one category: the reduced category totals sum to the reads of ALL ranks
@@ -496,6 +493,9 @@ def main():
     # timed step; reading them synchronises, so it is done after the timed region
     st = res.stats
     per_pass_ms = np.array([s["ms"] for s in st])
+    cold = None   # (after the step's own counters are read: the protocol launches cascades of its own)
+    if wl == "exact" and world == 1 and not args.no_cold:
+        cold = run_cold(eng, passes, words, lens, quant, M, n_pass, canon, iso, ln, ln_tally, fused, log)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)

@@ -219,6 +219,8 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * seed by walking that list up to the first valid alignment (plus a 64-ary search of the suffix-sorted rows for an
  * exact occurrence) instead of verifying every row of the suffix interval -- same answers (runAnnotationPipeline.py:
  * 581-584 offers every read to every library, whatever the library holds);
+ * "walk_cap" = 256 (default; 0..256): records a wave of wave_seed_kernel may leave behind its stream (reads whose seeds
+ * meet repeats); beyond it such a seed is verified row by row as before round 6 (tests shrink it);
  * "long_lane" = 0 (default) / 1: in a batch of two words per read, the N-free reads of 33..63 nt take the FM kernels / go
  * with the one-word reads through the dictionary kernels' LONG instantiations (seeds from the first 32 bases, the second
  * word fetched where an alignment is verified; exact_dict_kernel and the FM kernels of that lane cannot see them: a length
@@ -319,7 +321,9 @@ typedef struct mrg_pass_stats {
 } mrg_pass_stats;
 
 /* Bytes of device workspace mrg_cascade_run needs for n reads (three survivor lists of n + 2^23 entries of 16 bytes --
- * the seed launches' lists carry their reads --, segment counts, counters: 48 B per read + 400 MB). */
+ * the seed launches' lists carry their reads --, segment counts, counters, and since round 6 the 67 MB of records of the
+ * reads wave_seed_kernel answers behind its stream: 48 B per read + 470 MB).  A workspace belongs to ONE cascade at a
+ * time: cascades of one context on several streams each bring their own. */
 int mrg_cascade_workspace_bytes(uint64_t n, uint64_t *bytes);
 
 /*

@@ -132,6 +132,7 @@ int upload(T** dst, const std::vector<T>& v, size_t pad_to_multiple = 1) {
 }
 
 constexpr uint32_t kStatsPerPass = 5;
+constexpr uint32_t kWalkCap = 256;  // wave_seed_kernel: records a wave may leave behind its stream (in the cascade workspace)
 
 void free_dev_lib(DevLib& l);
 
@@ -232,8 +233,7 @@ struct mrg_ctx {
   int64_t walk_diag = 0;
   int64_t count_variants = 1;  // mrg_count_best, one seed mismatch: the jump-table variants kernel in front of the pigeonhole kernel
   int64_t long_lane = 0;   // round 6: 1 = the reads of 33..63 nt of a split batch ride the dictionary kernels too (their LONG instantiations; measured no faster than the FM kernels: off)
-  void* walk_buf = nullptr;  // wave_seed_kernel: records of the reads left to their position lists (grid x 4 waves x 256 x 32 B)
-  size_t walk_bytes = 0;
+  int64_t walk_cap = 256;  // records a wave may leave behind its stream (<= 256; tests shrink it: beyond it a seed is verified row by row)
   int64_t pos_scan = 1;   // 0 at run time: the seed launches verify a wide interval row by row as before round 6
   int64_t pos_lists = 1;  // overflowing seed buckets get their rows in text order too (set before add_library)
   int64_t seed_buckets = 1;  // large libraries get seed buckets where they pay (set before add_library); 0 at run time: not used
@@ -466,7 +466,6 @@ void mrg_ctx_destroy(mrg_ctx* ctx) {
   }
   if (ctx->comm) (void)rccl_api()->CommDestroy(ctx->comm);
   (void)hipFree(ctx->scratch);
-  (void)hipFree(ctx->walk_buf);
   for (auto& kv : ctx->round_tables) (void)hipFree(kv.second);
   delete ctx;
 }
@@ -764,6 +763,9 @@ int mrg_ctx_set_option(mrg_ctx* ctx, const char* key, int64_t value) {
     ctx->pos_scan = value != 0;
   } else if (k == "count_variants") {
     ctx->count_variants = value != 0;
+  } else if (k == "walk_cap") {
+    if (value < 0 || value > (int64_t)kWalkCap) return fail(MRG_ERR_ARG, "walk_cap must be in [0,256]");
+    ctx->walk_cap = value;
   } else if (k == "walk_diag") {
     ctx->walk_diag = value;
   } else if (k == "long_lane") {
@@ -915,10 +917,14 @@ static uint64_t ws_idx_bytes(uint64_t n) {
 }
 static const uint64_t kWsCountsBytes = 3 * mrg::kMaxSegments * 4;
 static const uint64_t kWsStatsBytes = MRG_MAX_PASSES * kStatsPerPass * 8;
+// round 6: the records of the reads a wave of wave_seed_kernel answers behind its stream (dict.hip; 32 bytes each, kWalkCap per
+// wave of the largest grid) -- in the caller's workspace, not in the context: cascades of one context on several streams
+// (the e2e leg's chunks) must not share them
+static const uint64_t kWsWalkBytes = (uint64_t)mrg::kMaxSegments * (mrg::kSeedThreads / 64u) * kWalkCap * 32ull;
 
 int mrg_cascade_workspace_bytes(uint64_t n, uint64_t* bytes) {
   if (!bytes) return fail(MRG_ERR_ARG, "mrg_cascade_workspace_bytes: null argument");
-  *bytes = 3 * ws_idx_bytes(n) + kWsCountsBytes + kWsStatsBytes;
+  *bytes = 3 * ws_idx_bytes(n) + kWsCountsBytes + kWsStatsBytes + kWsWalkBytes;
   return MRG_OK;
 }
 
@@ -1041,6 +1047,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
   uint32_t* idx[3] = {(uint32_t*)ws, (uint32_t*)(ws + ws_idx_bytes(n)), (uint32_t*)(ws + 2 * ws_idx_bytes(n))};
   uint32_t* counts = (uint32_t*)(ws + 3 * ws_idx_bytes(n));
   uint64_t* stats = (uint64_t*)(ws + 3 * ws_idx_bytes(n) + kWsCountsBytes);
+  uint4* const ws_walk = (uint4*)(ws + 3 * ws_idx_bytes(n) + kWsCountsBytes + kWsStatsBytes);
   // per-pass counters only; the outputs need no memset (the last pass writes the
   // "unannotated" values for whatever it does not claim)
   HIP_TRY(hipMemsetAsync(stats, 0, kWsStatsBytes, stream));
@@ -1780,18 +1787,8 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       bool lists = false;
       for (uint32_t u = 0; u < sp.n_units; ++u) lists |= sp.unit[u].kind == 0u && sp.unit[u].pos_rows != nullptr;
       if (lists) {
-        const uint32_t cap = 256u;
-        const size_t need = (size_t)grid * (mrg::kSeedThreads / 64u) * cap * 32u;
-        if (ctx->walk_bytes < need) {
-          HIP_TRY(hipStreamSynchronize(stream));
-          (void)hipFree(ctx->walk_buf);
-          ctx->walk_buf = nullptr;
-          ctx->walk_bytes = 0;
-          HIP_TRY(hipMalloc(&ctx->walk_buf, need));
-          ctx->walk_bytes = need;
-        }
-        sp.walk_buf = reinterpret_cast<uint4*>(ctx->walk_buf);
-        sp.walk_cap = cap;
+        sp.walk_buf = ws_walk;
+        sp.walk_cap = (uint32_t)std::min<int64_t>(std::max<int64_t>(ctx->walk_cap, 0), (int64_t)kWalkCap);
       }
     }
     if (n) HIP_TRY(mrg::launch_seed(sp, grid, stream));

@@ -64,10 +64,15 @@ def test_headline_line_has_the_contract_keys():
 
 def test_default_run_carries_the_exact_and_a2i_legs():
     """The default workload also runs BASELINE configs[1] and configs[4] (1-GPU form) as child runs
-    with their own roofline and parity gates."""
+    with their own roofline and parity gates -- and, round 6, the two unfriendly inputs (`repeats`: libraries with
+    interspersed elements, poly-A, tandem motifs; `varlen`: reads of 16..40 nt), so that the driver's one command times
+    them; the exact leg reports its kernel cache-cold and warm."""
     d = run_bench("--legs-reads", "200000", "--scan-sample", "300")
-    assert set(d["legs"]) == {"exact", "a2i"}
-    for leg in ("exact", "a2i"):
+    assert set(d["legs"]) == {"exact", "a2i", "repeats", "varlen"}
+    cold = d["legs"]["exact"]["roofline"]["cold"]
+    assert cold["cold"]["kernel_ms"] > 0 and cold["warm"]["kernel_ms"] > 0 and isinstance(cold["meets_0.40_cold"], bool)
+    assert "repeats" in d["legs"]["repeats"] and d["legs"]["varlen"]["split_batch"]
+    for leg in ("exact", "a2i", "repeats", "varlen"):
         L = d["legs"][leg]
         assert "error" not in L, L
         assert L["value"] > 0 and L["roofline"]["frac"] > 0 and "identical" in L["parity"]["cpu_port"]

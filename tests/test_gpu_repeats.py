@@ -173,3 +173,15 @@ def test_position_lists_with_host_built_tables(case):
     assert chk_h["seed_buckets"] == 0, chk_h
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+def test_a_full_walk_buffer_falls_back_to_the_row_by_row_path(case):
+    """walk_cap = 64: a wave may leave ONE batch of reads behind its stream, every later wide seed is verified row by row
+    (and a dictionary fallback's wide interval by its lane) as before round 6; walk_cap = 0: nothing is left behind at all.
+    Same answers."""
+    a, st_a, _, _ = run(case)
+    for cap in (64, 0):
+        b, st_b, _, _ = run(case, walk_cap=cap)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), cap
+        assert st_b[1]["candidates"] > st_a[1]["candidates"], cap     # (more rows looked at: the fallback ran)
