@@ -226,7 +226,7 @@ int mrg_ctx_add_library(mrg_ctx *ctx, const mrg_index *ix, int32_t *lib_id);
  * word fetched where an alignment is verified; exact_dict_kernel and the FM kernels of that lane cannot see them: a length
  * is taken only when every pass either runs in a seed launch, keeps it out by its window, or -- pair_wave_kernel -- sees
  * at most 32 bases of it behind the trims or could not align it at all).  Same results (tests/test_gpu_split.py,
- * test_gpu_random_worlds.py); measured no faster -- 1.10 against 1.08 ms for the 6.4 M reads of 33..40 nt of
+ * test_gpu_random_worlds.py); measured slower -- 1.10 against 0.67 ms for the 6.4 M reads of 33..40 nt of
  * `bench.py --workload varlen`: a long read's candidate costs two or three dependent text trips where a short one is
  * judged from its 16-byte row -- hence off;
  * "wide_rows_16", "round_large": see DESIGN.md. */
