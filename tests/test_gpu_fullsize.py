@@ -203,3 +203,58 @@ def test_properties_at_the_a2i_size(native_lib):
     assert np.array_equal(eng.tally(rs_q, res_q, M).cpu().numpy(), whole)
     assert np.array_equal(eng.edit_tally(rs_q, res_q, "mirna").cpu().numpy(), edits)
     eng.close()
+
+
+def test_properties_on_the_repeats_set(native_lib):
+    """bench.py --workload repeats at its full size (20 M reads; full-size libraries with poly-A/T tails, tandem repeats,
+    paralog families and the 10^5-copy element): the reads whose seeds meet repeats are answered behind the stream, by
+    whichever wave happened to take them -- so a permutation of the reads, a split into 8 shards and a second run all
+    have to give every read the same answer, and the lane has to have run (walk_diag counts its records)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from mirge_amd import dist, synth
+    from mirge_amd.engine import Engine, ReadSet
+    from mirge_amd.index import FmIndex
+    N = 20_000_000
+    libs = synth.SynthLibraries(seed=20181, scale=1.0, repeats=True)
+    keys = list(synth.LIB_KEYS)
+    with ThreadPoolExecutor(max_workers=len(keys)) as pool:
+        fut = {k: pool.submit(FmIndex.build, *libs.libs[k]) for k in keys}
+        words, lens, quant = synth.global_read_slice(libs, N, 0, N, workload="cascade", seed0=355, mix=None, n_samples=1)
+        index = {k: f.result() for k, f in fut.items()}
+    eng = Engine(0)
+    for k in keys:
+        eng.add_library(k, index[k])
+    eng.set_option("walk_diag", 1)
+    passes = eng.mirge_passes()
+    M = index["mirna"].n_ref
+    rs = ReadSet(words, lens, None, quant, device=eng.device)
+    res = eng.cascade(rs, passes)
+    whole = eng.tally(rs, res, M).cpu().numpy()
+    st = res.stats
+    assert st[6]["steps"] > 50_000, st[6]        # records left behind the stream in the ncRNA-others / mRNA launch
+    a = [t.clone() for t in (res.pass_id, res.ref_id, res.pos, res.mm)]
+    res2 = eng.cascade(rs, passes)
+    for x, y in zip(a, (res2.pass_id, res2.ref_id, res2.pos, res2.mm)):
+        assert torch.equal(x, y)
+    total = np.zeros_like(whole)
+    for r in range(8):
+        lo, hi = dist.shard_bounds(N, r, 8)
+        rs_r = ReadSet.from_device(rs.words[:, lo:hi].contiguous(), rs.lens[lo:hi], None, rs.quant[lo:hi], 22, 22)
+        res_r = eng.cascade(rs_r, passes)
+        total += eng.tally(rs_r, res_r, M).cpu().numpy()
+        assert torch.equal(res_r.pass_id, a[0][lo:hi]) and torch.equal(res_r.ref_id, a[1][lo:hi]) and torch.equal(res_r.pos, a[2][lo:hi]) and \
+            torch.equal(res_r.mm, a[3][lo:hi])
+    assert np.array_equal(total, whole)
+    perm = torch.randperm(N, device=eng.device, generator=torch.Generator(device=eng.device).manual_seed(3))
+    rs_q = ReadSet.from_device(rs.words[:, perm].contiguous(), rs.lens[perm], None, rs.quant[perm], 22, 22)
+    res_q = eng.cascade(rs_q, passes)
+    assert torch.equal(res_q.pass_id, a[0][perm]) and torch.equal(res_q.ref_id, a[1][perm]) and torch.equal(res_q.pos, a[2][perm]) and \
+        torch.equal(res_q.mm, a[3][perm])
+    # the collapse order (equal reads side by side: the lane's records bunch up in few waves)
+    order = torch.argsort(rs.words[0], stable=True)
+    rs_s = ReadSet.from_device(rs.words[:, order].contiguous(), rs.lens[order], None, rs.quant[order], 22, 22)
+    res_s = eng.cascade(rs_s, passes)
+    assert torch.equal(res_s.pass_id, a[0][order]) and torch.equal(res_s.ref_id, a[1][order]) and torch.equal(res_s.pos, a[2][order]) and \
+        torch.equal(res_s.mm, a[3][order])
+    eng.close()
