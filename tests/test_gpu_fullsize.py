@@ -258,3 +258,58 @@ def test_properties_on_the_repeats_set(native_lib):
     assert torch.equal(res_s.pass_id, a[0][order]) and torch.equal(res_s.ref_id, a[1][order]) and torch.equal(res_s.pos, a[2][order]) and \
         torch.equal(res_s.mm, a[3][order])
     eng.close()
+
+
+def test_properties_on_the_varlen_set(native_lib):
+    """bench.py --workload varlen at its full size (20 M reads of 16..40 nt, two words per read: the batch is split on the
+    device into the one-word lane -- dictionary kernels -- and the rest -- FM kernels): the lanes' lists are built by
+    whichever workgroup took a read, so shards and a permutation must not change any read's answer; and the reads of
+    33..40 nt get the same answers on the dictionary kernels' LONG instantiations (long_lane = 1) as on the FM kernels."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from mirge_amd import dist, synth
+    from mirge_amd.engine import Engine, ReadSet
+    from mirge_amd.index import FmIndex
+    N = 20_000_000
+    libs = synth.SynthLibraries(seed=20181, scale=1.0)
+    keys = list(synth.LIB_KEYS)
+    with ThreadPoolExecutor(max_workers=len(keys)) as pool:
+        fut = {k: pool.submit(FmIndex.build, *libs.libs[k]) for k in keys}
+        words, lens, quant = synth.global_read_slice(libs, N, 0, N, workload="varlen", seed0=355, mix=None, n_samples=1)
+        index = {k: f.result() for k, f in fut.items()}
+    assert words.shape[0] == 2 and int(lens.min()) == 16 and int(lens.max()) == 40
+    eng = Engine(0)
+    for k in keys:
+        eng.add_library(k, index[k])
+    passes = eng.mirge_passes()
+    M = index["mirna"].n_ref
+    rs = ReadSet(words, lens, None, quant, device=eng.device)
+    res = eng.cascade(rs, passes)
+    whole = eng.tally(rs, res, M).cpu().numpy()
+    st = res.stats
+    assert st[1]["aligned"] > 100_000, st[1]          # (the hairpin pass, len > 25, has work here)
+    a = [t.clone() for t in (res.pass_id, res.ref_id, res.pos, res.mm)]
+    long_hit = int(((rs.lens > 32) & (a[0] >= 0)).sum().item())
+    assert long_hit > 1_000_000
+    eng.set_option("long_lane", 1)
+    res_l = eng.cascade(rs, passes)
+    for x, y in zip(a, (res_l.pass_id, res_l.ref_id, res_l.pos, res_l.mm)):
+        assert torch.equal(x, y)
+    assert np.array_equal(eng.tally(rs, res_l, M).cpu().numpy(), whole)
+    for lane in (1, 0):
+        eng.set_option("long_lane", lane)
+        total = np.zeros_like(whole)
+        for r in range(8):
+            lo, hi = dist.shard_bounds(N, r, 8)
+            rs_r = ReadSet.from_device(rs.words[:, lo:hi].contiguous(), rs.lens[lo:hi], None, rs.quant[lo:hi], 16, 40)
+            res_r = eng.cascade(rs_r, passes)
+            total += eng.tally(rs_r, res_r, M).cpu().numpy()
+            assert torch.equal(res_r.pass_id, a[0][lo:hi]) and torch.equal(res_r.ref_id, a[1][lo:hi]) and torch.equal(res_r.pos, a[2][lo:hi]) and \
+                torch.equal(res_r.mm, a[3][lo:hi])
+        assert np.array_equal(total, whole)
+    perm = torch.randperm(N, device=eng.device, generator=torch.Generator(device=eng.device).manual_seed(5))
+    rs_q = ReadSet.from_device(rs.words[:, perm].contiguous(), rs.lens[perm], None, rs.quant[perm], 16, 40)
+    res_q = eng.cascade(rs_q, passes)
+    assert torch.equal(res_q.pass_id, a[0][perm]) and torch.equal(res_q.ref_id, a[1][perm]) and torch.equal(res_q.pos, a[2][perm]) and \
+        torch.equal(res_q.mm, a[3][perm])
+    eng.close()
