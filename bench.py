@@ -100,7 +100,10 @@ def kernel_name(W, table_row, s, n_bases):
         return "mrg::stratum_kernel<%d>" % W
     if s["lds_mode"] == 7:
         # (FIRST = the pass streams the whole read set; KBITS = its library has the 9-mer bitmap)
-        return "mrg::exact_dict_kernel<%s, %s>" % ("true" if s.get("first_pass") else "false", "true" if n_bases <= 190000 else "false")
+        # (third argument, round 6: one contiguous stretch of the batch per workgroup -- variant + 16: a batch whose 4096-read
+        # chunks would not go round the workgroups evenly, e.g. the 10 M reads of configs[1])
+        return "mrg::exact_dict_kernel<%s, %s, %s>" % ("true" if s.get("first_pass") else "false", "true" if n_bases <= 190000 else "false",
+                                                       "true" if s.get("variant", 0) & 16 else "false")
     if s["lds_mode"] == 11:
         return "mrg::pair_wave_kernel<%s>" % ("true" if s.get("variant", 0) & 8 else "false")
     if s["lds_mode"] in (8, 9):

@@ -315,6 +315,9 @@ typedef struct mrg_pass_stats {
                           launch in front of it: seed_kernel<.., .., true>);
                           + 8 (round 6) = the LONG instantiation: the batch's reads of 33..63 nt ride this launch too
                           (seeds from their first 32 bases, the second word compared where an alignment is verified).
+                          lds_mode 7 (exact_dict_kernel): 16 (round 6) = the streaming launch gave every workgroup one
+                          contiguous stretch of the batch instead of every gridDim-th chunk of 4096 reads (taken when
+                          more than 2 % of the (workgroup, trip) slots of the chunked run would stay empty).
                           lds_mode 11 (round 4) = pair_wave_kernel: the anchor-pair search of a 2-mismatch pass for
                           one-word reads without N, items and rows compacted over the wave */
   uint32_t reserved;

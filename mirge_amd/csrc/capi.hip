@@ -1241,6 +1241,7 @@ int cascade_run_impl(mrg_ctx* ctx, const uint64_t* d_reads, uint32_t words_per_r
       if (long_mask & window_bits(c))
         return fail(MRG_ERR_ARG, "mrg_cascade_run: internal: reads of more than 32 nt reached exact_dict_kernel (pass %u)", i);
       if (n) HIP_TRY(mrg::launch_exact_dict(e, grid, stream));
+      ctx->last_variant[i] = (n && mrg::exact_dict_stretches(e, grid)) ? 16u : 0u;
       ctx->last_launches[i] += 1;
       HIP_TRY(mark(i, true));
       if (n && mrg::exact_dict_streams(e)) out_init = true;  // (every output of the batch is written: later launches write claims only)

@@ -88,8 +88,11 @@ static_assert(kBlock * kExactU == kExactChunk, "kernels.hpp: kExactChunk");
 typedef unsigned long long ull2_t __attribute__((ext_vector_type(2)));
 typedef int int4_t __attribute__((ext_vector_type(4)));
 
-template <bool FIRST, bool KBITS>
+// STRETCH (a streaming launch whose chunks do not go round: exact_dict_stretches): every workgroup takes ONE contiguous
+// stretch of the batch instead of every gridDim-th chunk; <.., .., false> is the code of rounds 4-6, bit for bit.
+template <bool FIRST, bool KBITS, bool STRETCH = false>
 __global__ void __launch_bounds__(kBlock, 8) exact_dict_kernel(const ExactParams p) {
+  static_assert(FIRST || !STRETCH, "stretches are the streaming instantiation's");
   constexpr int U = kExactU;
   __shared__ uint32_t ctl[2];  // [0] survivors appended by this workgroup, [1] longest input segment
   __shared__ unsigned long long wg_cnt[5];
@@ -119,10 +122,21 @@ __global__ void __launch_bounds__(kBlock, 8) exact_dict_kernel(const ExactParams
   const uint32_t in_nseg = have_list ? p.in_nseg : 1u;
   const uint32_t depth_chunks = have_list ? (ctl[1] + kChunk - 1) / kChunk : (p.n_total + kChunk - 1) / kChunk;
   const uint32_t n_chunks = in_nseg * depth_chunks;
-  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-    const uint32_t sgi = chunk % in_nseg, depth = chunk / in_nseg;
-    const uint32_t t0 = depth * kChunk + threadIdx.x * U;
-    const uint32_t count = have_list ? p.in_count[sgi] : p.n_total;
+  // STRETCH: one contiguous stretch per workgroup (a multiple of four reads: the vector loads and stores stay aligned).
+  // 10 M reads are 4.77 chunks per workgroup: by chunks, three quarters of the workgroups run a fifth trip while the rest
+  // have left; by stretches every workgroup's last trip is three quarters full (configs[1]: 49.7 -> 47.7 us).  A batch
+  // whose chunks go round evenly (100 M reads: 47.7 of 48) keeps the chunks: 512 streams 1.5 MB apart cost the headline's
+  // pass 0 5 % (0.695 -> 0.73 ms), a sweep of neighbouring chunks does not -- and a run-time choice between the two in
+  // ONE instantiation cost it 9 % (8 B more scratch): hence two.
+  const uint32_t per = STRETCH ? (((p.n_total + gridDim.x - 1u) / gridDim.x) + 3u) & ~3u : 0u;
+  const uint32_t my_lo = STRETCH ? (uint32_t)min((uint64_t)p.n_total, (uint64_t)blockIdx.x * per) : 0u;
+  const uint32_t my_hi = STRETCH ? (uint32_t)min((uint64_t)p.n_total, (uint64_t)my_lo + per) : 0u;
+  // (STRETCH: `chunk` is the trip's first read)
+  const uint32_t c_first = STRETCH ? my_lo : blockIdx.x, c_step = STRETCH ? kChunk : gridDim.x, c_end = STRETCH ? my_hi : n_chunks;
+  for (uint32_t chunk = c_first; chunk < c_end; chunk += c_step) {
+    const uint32_t sgi = STRETCH ? 0u : chunk % in_nseg, depth = STRETCH ? 0u : chunk / in_nseg;
+    const uint32_t t0 = (STRETCH ? chunk : depth * kChunk) + threadIdx.x * U;
+    const uint32_t count = have_list ? p.in_count[sgi] : (STRETCH ? my_hi : p.n_total);
     const bool full = t0 + U <= count;
     uint32_t r[U], L0[U];
     uint64_t rd[U];
@@ -2761,9 +2775,22 @@ bool exact_dict_streams(const ExactParams& p) {
   return !p.idx_in && ((uintptr_t)p.reads % 16 == 0) && ((uintptr_t)p.lens % 4 == 0) && out_ok;
 }
 
+// ... and takes it by stretches when more than 2 % of the (workgroup, trip) slots of a chunked run would stay empty
+bool exact_dict_stretches(const ExactParams& p, uint32_t grid) {
+  if (!exact_dict_streams(p) || !grid) return false;
+  const uint64_t per_round = (uint64_t)grid * kExactChunk;
+  const uint64_t rounds = (p.n_total + per_round - 1) / per_round;
+  return rounds * per_round * 50ull > (uint64_t)p.n_total * 51ull;
+}
+
 hipError_t launch_exact_dict(const ExactParams& p, uint32_t grid, hipStream_t stream) {
   const bool first = exact_dict_streams(p);
   const bool kb = p.kbits != nullptr && p.key_bases >= kKmerBitsK;
+  if (first && exact_dict_stretches(p, grid)) {
+    if (kb) hipLaunchKernelGGL((exact_dict_kernel<true, true, true>), dim3(grid), dim3(kBlock), 0, stream, p);
+    else hipLaunchKernelGGL((exact_dict_kernel<true, false, true>), dim3(grid), dim3(kBlock), 0, stream, p);
+    return hipGetLastError();
+  }
   if (first && kb) hipLaunchKernelGGL((exact_dict_kernel<true, true>), dim3(grid), dim3(kBlock), 0, stream, p);
   else if (first) hipLaunchKernelGGL((exact_dict_kernel<true, false>), dim3(grid), dim3(kBlock), 0, stream, p);
   else if (kb) hipLaunchKernelGGL((exact_dict_kernel<false, true>), dim3(grid), dim3(kBlock), 0, stream, p);

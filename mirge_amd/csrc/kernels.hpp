@@ -245,6 +245,7 @@ struct ExactParams {
 constexpr uint32_t kExactChunk = 4096u;  // reads a workgroup takes per trip (four per lane)
 hipError_t launch_exact_dict(const ExactParams& p, uint32_t grid, hipStream_t stream);
 bool exact_dict_streams(const ExactParams& p);  // the launch takes the streaming instantiation: it writes every output of the batch
+bool exact_dict_stretches(const ExactParams& p, uint32_t grid);  // ... its <.., .., true> form: one contiguous stretch per workgroup (mrg_pass_stats.variant bit 4)
 
 // seed_kernel: one launch = a run of consecutive passes with at most one seed mismatch, as UNITS:
 //   kind 0  V + 1 disjoint seeds of k = floor(R / (V + 1)) bases at the front of the seed region

@@ -229,3 +229,25 @@ def test_unaligned_outputs_take_the_non_streaming_first_pass(engine, world):
     got = engine.cascade_packed(rs, passes, out=(big[1:1 + n], counts)).packed.cpu().numpy()
     assert np.array_equal(got, want)
     assert int(big[0].item()) == -1 and int(big[n + 1].item()) == -1
+
+
+def test_the_streaming_pass_by_chunks_and_by_stretches(engine, world):
+    """exact_dict_kernel's streaming instantiation hands the batch out as every gridDim-th chunk of 4096 reads or -- when
+    more than 2 % of the (workgroup, trip) slots of that would stay empty -- as one contiguous stretch per workgroup
+    (mrg_pass_stats.variant bit 4).  With five workgroups (grid_pct 1 of 512): 20 480 reads are one round of chunks, one
+    read more is stretches; both equal the CPU port, as does the whole batch on the full grid."""
+    from mirge_amd.engine import ReadSet
+    seen = {}
+    n_all = world.words.shape[1]
+    assert 2 * n_all > 20481
+    w2, l2 = np.concatenate([world.words, world.words], axis=1), np.concatenate([world.lens, world.lens])   # (records, not distinct reads)
+    for n_take, pct in ((20480, 1), (20481, 1), (n_all, 100)):
+        words, lens = np.ascontiguousarray(w2[:, :n_take]), np.ascontiguousarray(l2[:n_take])
+        ref = model.fm_cascade(world.views, world.passes, words, lens, None)
+        engine.set_option("grid_pct", pct)
+        res = engine.cascade(ReadSet(words, lens, None, None, device=engine.device), engine.mirge_passes())
+        same_assignments(res, ref)
+        assert res.stats[0]["lds_mode"] == 7
+        seen[(n_take, pct)] = res.stats[0]["variant"] & 16
+    engine.set_option("grid_pct", 100)
+    assert seen[(20480, 1)] == 0 and seen[(20481, 1)] == 16 and seen[(n_all, 100)] == 16, seen
