@@ -177,11 +177,15 @@ def test_position_lists_with_host_built_tables(case):
 
 def test_a_full_walk_buffer_falls_back_to_the_row_by_row_path(case):
     """walk_cap = 64: a wave may leave ONE batch of reads behind its stream, every later wide seed is verified row by row
-    (and a dictionary fallback's wide interval by its lane) as before round 6; walk_cap = 0: nothing is left behind at all.
-    Same answers."""
+    (and a dictionary fallback's wide interval by its lane) as before round 6 -- on a grid of a hundredth of the
+    workgroups, so that a wave certainly meets more than 64 such reads whatever order the pass in front leaves them in;
+    walk_cap = 0: nothing is left behind at all.  Same answers."""
     a, st_a, _, _ = run(case)
-    for cap in (64, 0):
-        b, st_b, _, _ = run(case, walk_cap=cap)
+    for cap, pct in ((64, 1), (64, 100), (0, 100)):
+        ref_st = st_a if pct == 100 else run(case, grid_pct=pct)[1]
+        b, st_b, _, _ = run(case, walk_cap=cap, grid_pct=pct)
         for x, y in zip(a, b):
-            assert np.array_equal(x, y), cap
-        assert st_b[1]["candidates"] > st_a[1]["candidates"], cap     # (more rows looked at: the fallback ran)
+            assert np.array_equal(x, y), (cap, pct)
+        assert st_b[1]["candidates"] >= ref_st[1]["candidates"], (cap, pct)
+        if (cap, pct) != (64, 100):
+            assert st_b[1]["candidates"] > ref_st[1]["candidates"], (cap, pct)     # (more rows looked at: the fallback ran)
